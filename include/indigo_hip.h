@@ -1,0 +1,168 @@
+/*
+ * indigo_hip.h -- C ABI of libindigo_hip.so, the MI355X (gfx950) leaf-kernel
+ * library behind the `indigo.backends.Backend` plugin surface.
+ *
+ * Every entry point is `extern "C"`, takes plain pointers / sizes / scalars and
+ * returns an int status (0 = IG_OK).  On failure a human-readable message is
+ * available from ig_last_error().  All device work is enqueued asynchronously
+ * on the context's HIP stream; only the entry points documented as
+ * "synchronous" wait for the device.
+ *
+ * Each group cites the reference interface it replaces (paths relative to the
+ * mbdriscoll/indigo tree).  Panels (X, Y) are column-major with an explicit
+ * leading dimension in ELEMENTS, exactly like the reference's
+ * `dndarray._leading_dim` (indigo/backends/backend.py:50).
+ *
+ * Complex numbers are interleaved (re, im) float32 pairs ("complex64").
+ */
+#ifndef INDIGO_HIP_H
+#define INDIGO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IG_ABI_VERSION 1
+
+/* status codes */
+#define IG_OK            0
+#define IG_ERR_HIP       1   /* a HIP runtime call failed                    */
+#define IG_ERR_ARG       2   /* invalid argument (shape, alignment, NULL)    */
+#define IG_ERR_NODEVICE  3   /* no usable gfx950 device                      */
+#define IG_ERR_UNSUPPORTED 4 /* valid request this build cannot serve        */
+#define IG_ERR_NOMEM     5
+
+/* copy kinds for ig_copy2d (values follow cudaMemcpyKind / hipMemcpyKind,
+ * the enum the reference passes at indigo/backends/cuda.py:111-115)         */
+#define IG_H2D 1
+#define IG_D2H 2
+#define IG_D2D 3
+
+typedef struct ig_ctx   ig_ctx;    /* one device + one stream                */
+typedef struct ig_fft   ig_fft;    /* batched C2C FFT plan                   */
+typedef struct ig_event ig_event;  /* timing event on the context's stream   */
+
+/* ------------------------------------------------------------------------
+ * Context.  Replaces the handle/bring-up code of CudaBackend.__init__
+ * (indigo/backends/cuda.py:28-38: cudaSetDevice, cublas/cusparse handles)
+ * and Backend.barrier (cuda.py:120-121).
+ * ---------------------------------------------------------------------- */
+int  ig_abi_version(void);
+int  ig_device_count(int* count);                   /* never fails loudly: count=0 if no GPU */
+int  ig_init(int device_id, ig_ctx** out);          /* creates its own non-blocking stream   */
+int  ig_init_on_stream(int device_id, void* hip_stream, ig_ctx** out); /* adopt caller's stream (NULL = legacy default stream) */
+void ig_destroy(ig_ctx* ctx);
+const char* ig_last_error(ig_ctx* ctx);             /* ctx may be NULL: error of the last failed call on this thread */
+int  ig_sync(ig_ctx* ctx);                          /* synchronous: waits for the stream     */
+void* ig_stream(ig_ctx* ctx);                       /* the hipStream_t, for interop          */
+int  ig_device_name(ig_ctx* ctx, char* buf, size_t len);
+int  ig_mem_info(ig_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
+
+/* ------------------------------------------------------------------------
+ * Device memory.  Replaces CudaBackend.dndarray._malloc/_free/_zero/_copy*
+ * (indigo/backends/cuda.py:126-181: 256-byte aligned cudaMalloc, cudaMemset,
+ * cudaMemcpy2D pitch copies).  Ownership stays with the caller.
+ * ---------------------------------------------------------------------- */
+int  ig_malloc(ig_ctx* ctx, size_t nbytes, void** dptr);      /* >=256-B aligned; nbytes==0 gives a valid unique pointer */
+int  ig_free(ig_ctx* ctx, void* dptr);                         /* synchronous w.r.t. the stream */
+int  ig_memset0(ig_ctx* ctx, void* dptr, size_t nbytes);
+/* 2-D strided copy of `height` rows of `width_bytes` bytes.  H2D and D2H are
+ * synchronous (host buffer is pageable numpy memory); D2D is asynchronous.  */
+int  ig_copy2d(ig_ctx* ctx, void* dst, size_t dpitch, const void* src, size_t spitch,
+               size_t width_bytes, size_t height, int kind);
+
+/* ------------------------------------------------------------------------
+ * Timing events on the context's stream (hipEvent).  Counterpart of the
+ * barrier+wallclock `profile` context manager (indigo/util.py:33-80) without
+ * its forced device syncs.
+ * ---------------------------------------------------------------------- */
+int  ig_event_create(ig_ctx* ctx, ig_event** out);
+int  ig_event_record(ig_event* ev);
+int  ig_event_elapsed_ms(ig_event* start, ig_event* stop, float* ms);   /* synchronous on `stop` */
+int  ig_event_destroy(ig_event* ev);
+
+/* ------------------------------------------------------------------------
+ * BLAS-1 glue.  Replaces Backend.axpby/scale/dot/norm2/max
+ * (indigo/backends/backend.py:453-467,734; numpy oracle np.py:53-74,141-145;
+ *  CUDA: cublasCscal+cublasCaxpy cuda.py:239-248, cublasCdotc :260-277,
+ *  cublasScnrm2 :279-296, cu_max _customgpu.cu:7-13).
+ * n counts complex elements.  beta == 0 means y is not read (BLAS rule).
+ * ---------------------------------------------------------------------- */
+int  ig_caxpby(ig_ctx* ctx, int64_t n, float beta_re, float beta_im, void* y,
+               float alpha_re, float alpha_im, const void* x);              /* y = beta*y + alpha*x */
+int  ig_cscal(ig_ctx* ctx, int64_t n, float alpha_re, float alpha_im, void* x); /* x *= alpha */
+int  ig_cdotc(ig_ctx* ctx, int64_t n, const void* x, const void* y, double out[2]); /* sum conj(x)*y ; synchronous */
+int  ig_scnrm2sq(ig_ctx* ctx, int64_t n, const void* x, double* out);       /* ||x||_2^2 ; synchronous */
+int  ig_cmax(ig_ctx* ctx, int64_t nfloats, float val, void* arr);           /* arr[i] = max(arr[i], val) over floats */
+
+/* ------------------------------------------------------------------------
+ * CSR x dense-panel SpMM.  Replaces Backend.ccsrmm
+ * (indigo/backends/backend.py:514-519; oracle np.py:120-127;
+ *  cusparseCcsrmm cuda.py:582-596; custom_ccc_csrmm _customcpu.c:14-114;
+ *  cu_exw_csrmm_H _customgpu.cu:49-81,182-216).
+ *
+ *   adjoint == 0 :  Y(MxN) = alpha *  A   * X(KxN) + beta * Y
+ *   adjoint != 0 :  Y(KxN) = alpha * A^H * X(MxN) + beta * Y
+ *
+ * A is M x K, CSR, 0-based int32 rowptr (M+1) / colind (nnz), complex64
+ * values, sorted or unsorted columns.  X, Y column-major, leading dims in
+ * elements.  The adjoint is a scatter over A's rows: with exwrite != 0 the
+ * caller asserts every column of A holds at most one nonzero (plain stores,
+ * the reference's `_exwrite` property, backend.py:555-567); otherwise float
+ * atomics are used (correct, order-nondeterministic, slow).  For a fast
+ * deterministic adjoint use ig_ccsrmm_t with a transposed copy.
+ * ---------------------------------------------------------------------- */
+int  ig_ccsrmm(ig_ctx* ctx, int adjoint, int exwrite,
+               int64_t M, int64_t K, int64_t N, int64_t nnz,
+               float alpha_re, float alpha_im,
+               const void* vals, const int32_t* colind, const int32_t* rowptr,
+               const void* X, int64_t ldx,
+               float beta_re, float beta_im,
+               void* Y, int64_t ldy);
+
+/* Y(KxN) = alpha * A^H * X(MxN) + beta * Y  in GATHER form, given the CSR of
+ * A^T (K rows, M columns; values NOT conjugated -- the kernel conjugates).
+ * Same role as the reference's "store the transpose, wrap in Adjoint" recipe
+ * (examples/pics.py:104-109).                                              */
+int  ig_ccsrmm_t(ig_ctx* ctx,
+                 int64_t M, int64_t K, int64_t N, int64_t nnz,
+                 float alpha_re, float alpha_im,
+                 const void* vals_t, const int32_t* colind_t, const int32_t* rowptr_t,
+                 const void* X, int64_t ldx,
+                 float beta_re, float beta_im,
+                 void* Y, int64_t ldy);
+
+/* Host-side structure analysis.  Replaces `inspect`
+ * (indigo/backends/_customcpu.c:179-215): number of non-empty rows / columns
+ * and exwrite = "every column has <= 1 nonzero".  Pointers are HOST memory. */
+int  ig_csr_inspect(const int32_t* rowptr, const int32_t* colind, int64_t M, int64_t K,
+                    int64_t* nzrow, int64_t* nzcol, int* exwrite);
+
+/* Host-side CSR transpose (counting sort, stable => sorted columns).
+ * All pointers are HOST memory; outputs sized K+1 / nnz / nnz.              */
+int  ig_csr_transpose(int64_t M, int64_t K, int64_t nnz,
+                      const int32_t* rowptr, const int32_t* colind, const void* vals,
+                      int32_t* rowptr_t, int32_t* colind_t, void* vals_t);
+
+/* ------------------------------------------------------------------------
+ * Batched complex-to-complex FFT.  Replaces Backend.fftn/ifftn
+ * (indigo/backends/backend.py:497-512; oracle np.py:102-115; cuFFT plan
+ *  cache + workspace cuda.py:470-498).
+ * Fortran-ordered array dims[0] (contiguous) .. dims[rank-1], then `batch`
+ * contiguous volumes.  Both directions are UNNORMALISED (forward e^{-i..},
+ * inverse e^{+i..}, no 1/N).  x == y (in place) is allowed.
+ * ---------------------------------------------------------------------- */
+int  ig_fft_plan(ig_ctx* ctx, int rank, const int64_t* dims, int64_t batch,
+                 ig_fft** plan, size_t* workspace_bytes);
+int  ig_fft_exec(ig_fft* plan, const void* x, void* y, int direction /* -1 fwd, +1 inv */,
+                 void* workspace /* >= workspace_bytes, may be NULL if 0 */);
+int  ig_fft_describe(ig_fft* plan, char* buf, size_t len);   /* kernel / radix schedule, for logs and tests */
+int  ig_fft_destroy(ig_fft* plan);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INDIGO_HIP_H */

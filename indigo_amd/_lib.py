@@ -1,0 +1,105 @@
+"""ctypes binding of ``libindigo_hip.so`` (declared in ``include/indigo_hip.h``).
+
+This module is the only place that knows symbol names and argument types; the
+backend (``indigo_amd/backends/hip.py``) calls through :func:`lib`.  There is
+no CPU fallback: if the shared object is missing, :func:`lib` raises.
+"""
+import ctypes
+import os
+import sys
+from ctypes import (POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64,
+                    c_size_t, c_void_p)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+IG_OK = 0
+IG_H2D, IG_D2H, IG_D2D = 1, 2, 3
+
+# name -> (restype, argtypes); mirrors include/indigo_hip.h one to one
+PROTOTYPES = {
+    "ig_abi_version":     (c_int, []),
+    "ig_device_count":    (c_int, [POINTER(c_int)]),
+    "ig_init":            (c_int, [c_int, POINTER(c_void_p)]),
+    "ig_init_on_stream":  (c_int, [c_int, c_void_p, POINTER(c_void_p)]),
+    "ig_destroy":         (None,  [c_void_p]),
+    "ig_last_error":      (c_char_p, [c_void_p]),
+    "ig_sync":            (c_int, [c_void_p]),
+    "ig_stream":          (c_void_p, [c_void_p]),
+    "ig_device_name":     (c_int, [c_void_p, c_char_p, c_size_t]),
+    "ig_mem_info":        (c_int, [c_void_p, POINTER(c_size_t), POINTER(c_size_t)]),
+    "ig_malloc":          (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
+    "ig_free":            (c_int, [c_void_p, c_void_p]),
+    "ig_memset0":         (c_int, [c_void_p, c_void_p, c_size_t]),
+    "ig_copy2d":          (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_size_t, c_size_t, c_int]),
+    "ig_event_create":    (c_int, [c_void_p, POINTER(c_void_p)]),
+    "ig_event_record":    (c_int, [c_void_p]),
+    "ig_event_elapsed_ms": (c_int, [c_void_p, c_void_p, POINTER(c_float)]),
+    "ig_event_destroy":   (c_int, [c_void_p]),
+    "ig_caxpby":          (c_int, [c_void_p, c_int64, c_float, c_float, c_void_p, c_float, c_float, c_void_p]),
+    "ig_cscal":           (c_int, [c_void_p, c_int64, c_float, c_float, c_void_p]),
+    "ig_cdotc":           (c_int, [c_void_p, c_int64, c_void_p, c_void_p, POINTER(c_double)]),
+    "ig_scnrm2sq":        (c_int, [c_void_p, c_int64, c_void_p, POINTER(c_double)]),
+    "ig_cmax":            (c_int, [c_void_p, c_int64, c_float, c_void_p]),
+    "ig_ccsrmm":          (c_int, [c_void_p, c_int, c_int, c_int64, c_int64, c_int64, c_int64,
+                                   c_float, c_float, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_int64, c_float, c_float, c_void_p, c_int64]),
+    "ig_ccsrmm_t":        (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64,
+                                   c_float, c_float, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_int64, c_float, c_float, c_void_p, c_int64]),
+    "ig_csr_inspect":     (c_int, [c_void_p, c_void_p, c_int64, c_int64,
+                                   POINTER(c_int64), POINTER(c_int64), POINTER(c_int)]),
+    "ig_csr_transpose":   (c_int, [c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p]),
+    "ig_fft_plan":        (c_int, [c_void_p, c_int, POINTER(c_int64), c_int64, POINTER(c_void_p), POINTER(c_size_t)]),
+    "ig_fft_exec":        (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "ig_fft_describe":    (c_int, [c_void_p, c_char_p, c_size_t]),
+    "ig_fft_destroy":     (c_int, [c_void_p]),
+}
+
+
+def lib_path():
+    return os.environ.get("INDIGO_HIP_LIB") or os.path.join(_HERE, "lib", "libindigo_hip.so")
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises RuntimeError if the library is absent."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            "indigo_amd: %s not found. Build it with `python -m indigo_amd.build` "
+            "(needs hipcc); there is no CPU fallback." % path)
+    # torch ships its own copy of the HIP runtime.  If the process is going to use torch
+    # (torch.distributed for the multi-GPU all-reduce), torch must be imported FIRST so that
+    # both share one runtime instance (same SONAME => the loader reuses it).
+    if os.environ.get("INDIGO_HIP_WITH_TORCH", "0") == "1" and "torch" not in sys.modules:
+        import torch  # noqa: F401
+    handle = ctypes.CDLL(path)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(handle, name)      # AttributeError here means header and library disagree
+        fn.restype = res
+        fn.argtypes = args
+    if handle.ig_abi_version() != 1:
+        raise RuntimeError("indigo_amd: ABI version mismatch in %s" % path)
+    _LIB = handle
+    return _LIB
+
+
+def last_error(ctx=None):
+    msg = lib().ig_last_error(ctx)
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(rc, ctx=None, what=""):
+    """Status int -> RuntimeError carrying ig_last_error (reference: cuda.py:42-49)."""
+    if rc != IG_OK:
+        raise RuntimeError("%s failed (status %d): %s" % (what or "libindigo_hip call", rc, last_error(ctx)))
+
+
+def device_count():
+    n = c_int(0)
+    lib().ig_device_count(ctypes.byref(n))
+    return n.value

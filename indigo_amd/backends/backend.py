@@ -1,0 +1,564 @@
+"""The `Backend` plugin surface: device arrays, device CSR matrices, the leaf
+kernel contract, operator factories, the scratch arena and CG.
+
+Own re-statement of indigo/backends/backend.py (the boundary named by the
+north star).  A concrete backend subclasses `Backend`, provides
+`dndarray._malloc/_free/_zero/_copy_from/_copy_to/_copy/__getitem__` and the
+leaf kernels (`axpby, scale, dot, norm2, fftn, ifftn, ccsrmm, max`).  Method
+names, argument order (outputs first: `fftn(y, x)`, `ccsrmm(y, ...)`,
+`axpby(beta, y, alpha, x)`) and error behaviour follow the reference:
+
+  dndarray                      backend.py:22-220
+  scratch (LIFO bump arena)     backend.py:262-281
+  factories Diag..NUFFT         backend.py:287-448
+  leaf contract                 backend.py:453-533
+  csr_matrix                    backend.py:535-596
+  cg                            backend.py:639-689
+
+Differences, all deliberate: structure analysis (`inspect`) comes from the
+backend instead of the optional `_customcpu` module (whose absence breaks every
+adjoint in the reference, backend.py:564-567 vs :585); `Zpad` indexes with a
+tuple of slices (the reference's list indexing is an IndexError on numpy >=
+1.23); `beta == 0` never reads `y` (BLAS rule; the numpy oracle multiplies
+0 * y and so propagates NaNs from uninitialised memory).
+"""
+import logging
+from contextlib import contextmanager
+
+import numpy as np
+import scipy.sparse as spp
+
+import indigo_amd.operators as op
+
+log = logging.getLogger(__name__)
+_C64 = np.dtype('complex64')
+
+
+class Backend(object):
+
+    def __init__(self, device_id=0):
+        self.trace = None          # attach an indigo_amd.util.Trace to record leaf calls
+
+    # ---------------------------------------------------------------------------
+    # device arrays
+    # ---------------------------------------------------------------------------
+    class dndarray(object):
+        """N-d array in device memory, column-major, with a leading dimension.
+
+        `shape[0]` elements are contiguous; column j of a 2-d view starts
+        `_leading_dim * j` elements after column 0.  Views (`own=False`) never free.
+        """
+        _memory = dict()
+
+        def __init__(self, backend, shape, dtype, ld=None, own=True, data=None, name=''):
+            assert isinstance(shape, (tuple, list))
+            self.shape = tuple(int(s) for s in shape)
+            self.dtype = np.dtype(dtype)
+            self._backend = backend
+            self._leading_dim = int(ld) if ld else (self.shape[0] if self.shape else 1)
+            self._own = own
+            self._name = name
+            if data is None:
+                self._arr = self._malloc(self.shape, self.dtype)
+                self._memory[id(self)] = (name, self.shape, self.dtype)
+            else:
+                self._arr = data
+
+        # -- metadata ---------------------------------------------------------------
+        @property
+        def size(self):
+            return int(np.prod(self.shape, dtype=np.int64))
+
+        @property
+        def itemsize(self):
+            return self.dtype.itemsize
+
+        @property
+        def nbytes(self):
+            return self.size * self.dtype.itemsize
+
+        @property
+        def ndim(self):
+            return len(self.shape)
+
+        @property
+        def contiguous(self):
+            return self.ndim == 1 or self._leading_dim == self.shape[0]
+
+        def reshape(self, new_shape):
+            """View with a new shape.  Mirrors the leading-dimension rules of backend.py:59-89."""
+            new_shape = tuple(int(s) for s in new_shape)
+            if -1 in new_shape:
+                known = -int(np.prod(new_shape, dtype=np.int64))
+                assert known > 0 and self.size % known == 0, \
+                    "Cannot reshape {} into {}. (size mismatch)".format(self.shape, new_shape)
+                new_shape = tuple(self.size // known if s == -1 else s for s in new_shape)
+            assert int(np.prod(new_shape, dtype=np.int64)) == self.size, \
+                "Cannot reshape {} into {}. (size mismatch)".format(self.shape, new_shape)
+            if new_shape[0] > self.shape[0]:
+                assert self.shape[0] == self._leading_dim, "Cannot stack non-contiguous columns."
+            ld = new_shape[0] if new_shape[0] < self.shape[0] else self._leading_dim
+            return self._view(new_shape, ld, self._arr)
+
+        def _view(self, shape, ld, data):
+            v = self._backend.dndarray(self._backend, shape, self.dtype, ld=ld, own=False, data=data)
+            v._base = getattr(self, '_base', None) or self     # keep the owner alive
+            return v
+
+        # -- transfers ----------------------------------------------------------------
+        def copy_from(self, arr):
+            """host -> device into an existing array"""
+            assert isinstance(arr, np.ndarray)
+            if self.size != arr.size:
+                raise ValueError("size mismatch, expected {} got {}".format(self.shape, arr.shape))
+            if self.dtype != arr.dtype:
+                raise TypeError("dtype mismatch, expected {} got {}".format(self.dtype, arr.dtype))
+            if not arr.flags['F_CONTIGUOUS']:
+                raise TypeError("order mismatch, expected 'F' got {}".format(arr.flags['F_CONTIGUOUS']))
+            self._copy_from(arr)
+
+        def copy_to(self, arr):
+            """device -> host into an existing array"""
+            assert isinstance(arr, np.ndarray)
+            if self.size != arr.size:
+                raise ValueError("size mismatch, expected {} got {}".format(self.shape, arr.shape))
+            if self.dtype != arr.dtype:
+                raise TypeError("dtype mismatch, expected {} got {}".format(self.dtype, arr.dtype))
+            self._copy_to(arr)
+
+        def to_host(self):
+            arr = np.ndarray(self.shape, self.dtype, order='F')
+            self.copy_to(arr)
+            return arr
+
+        @contextmanager
+        def on_host(self):
+            arr = self.to_host()
+            yield arr
+            self.copy_from(arr)
+
+        def copy(self, other=None, name=''):
+            """`a.copy()` returns a device copy; `a.copy(b)` copies b into a."""
+            if other is not None:
+                assert isinstance(other, self._backend.dndarray)
+                self._copy(other)
+                return None
+            dup = self._backend.zero_array(self.shape, self.dtype, name=name)
+            dup._copy(self)
+            return dup
+
+        @classmethod
+        def to_device(cls, backend, arr, name=''):
+            arr_f = np.require(arr, requirements='F')
+            d_arr = cls(backend, arr.shape, arr.dtype, name=name)
+            d_arr.copy_from(arr_f)
+            return d_arr
+
+        def __setitem__(self, slc, other):
+            assert isinstance(slc, slice) and not (slc.start or slc.stop), "dndarray setitem cant slice"
+            self._copy(other)
+
+        def __del__(self):
+            if getattr(self, '_own', False) and hasattr(self, '_arr'):
+                self._memory.pop(id(self), None)
+                try:
+                    self._free()
+                except Exception:       # interpreter shutdown: the library may be gone already
+                    pass
+
+        # -- to be provided by the concrete backend ---------------------------------
+        def __getitem__(self, slc):
+            raise NotImplementedError()
+
+        def _copy_from(self, arr):
+            raise NotImplementedError()
+
+        def _copy_to(self, arr):
+            raise NotImplementedError()
+
+        def _copy(self, d_arr):
+            raise NotImplementedError()
+
+        def _malloc(self, shape, dtype):
+            raise NotImplementedError()
+
+        def _free(self):
+            raise NotImplementedError()
+
+        def _zero(self):
+            raise NotImplementedError()
+
+    def copy_array(self, arr, name=''):
+        return self.dndarray.to_device(self, arr, name=name)
+
+    def empty_array(self, shape, dtype, name=''):
+        return self.dndarray(self, shape, dtype, name=name)
+
+    def zero_array(self, shape, dtype, name=''):
+        d_arr = self.empty_array(shape, dtype, name=name)
+        d_arr._zero()
+        return d_arr
+
+    def zeros_like(self, other, name=''):
+        return self.zero_array(other.shape, other.dtype, name=name)
+
+    def rand_array(self, shape, dtype=_C64, name='', seed=None):
+        rng = np.random.default_rng(seed)
+        x = rng.random(shape) + 1j * rng.random(shape)
+        x = np.require(x, dtype=_C64, requirements='F')
+        return self.copy_array(x, name=name)
+
+    def get_max_threads(self):
+        return 1
+
+    def barrier(self):
+        pass
+
+    def mem_usage(self):
+        total = 0
+        rows = []
+        for name, shape, dtype in list(self.dndarray._memory.values()):
+            n = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+            rows.append((n, name, shape, dtype))
+            total += n
+        log.info("Memory report:")
+        for n, name, shape, dtype in sorted(rows, key=lambda r: r[0]):
+            if n > 1e6:
+                log.info("  %40s: % 3.0f MB, %20s, %15s", name, n / 1e6, shape, dtype)
+        return total
+
+    # ---------------------------------------------------------------------------
+    # scratch arena
+    # ---------------------------------------------------------------------------
+    def reserve_scratch(self, nelems):
+        """Reserve a complex64 arena of `nelems` elements for `scratch()` (LIFO)."""
+        self._scratch = self.empty_array((max(int(nelems), 1),), _C64, name='scratch')
+        self._scratch_pos = 0
+
+    @contextmanager
+    def scratch(self, shape=None, nbytes=None):
+        assert not (shape is not None and nbytes is not None), \
+            "Specify either shape or nbytes to backend.scratch()."
+        if nbytes is not None:
+            shape = (int(nbytes) // _C64.itemsize,)
+        size = int(np.prod(shape, dtype=np.int64))
+        arena = getattr(self, '_scratch', None)
+        if arena is not None and self._scratch_pos + size > arena.size:
+            # the arena was sized for another tree: serve this request dynamically instead of failing
+            # (the reference asserts here, backend.py:272)
+            log.warning("scratch arena too small (wanted %d elements at offset %d of %d); allocating dynamically",
+                        size, self._scratch_pos, arena.size)
+            arena = None
+        if arena is not None:
+            pos = self._scratch_pos
+            mem = arena[pos:pos + size].reshape(tuple(shape))
+            # keep successive carvings 256-byte aligned (32 complex64) like fresh allocations
+            bump = (size + 31) // 32 * 32
+            self._scratch_pos += bump
+            try:
+                yield mem
+            finally:
+                self._scratch_pos -= bump
+        else:
+            mem = self.zero_array(tuple(shape), dtype=_C64, name='scratch(dynamic)')
+            yield mem
+            del mem
+
+    # ---------------------------------------------------------------------------
+    # operator factories
+    # ---------------------------------------------------------------------------
+    def SpMatrix(self, M, **kwargs):
+        assert spp.issparse(M)
+        return op.SpMatrix(self, M, **kwargs)
+
+    def DenseMatrix(self, M, **kwargs):
+        assert isinstance(M, np.ndarray) and M.ndim == 2
+        return op.DenseMatrix(self, M, **kwargs)
+
+    def Diag(self, v, **kwargs):
+        """diag(v); v is flattened in memory ('A') order, i.e. F order for F arrays"""
+        v = np.require(v, requirements='F')
+        if v.ndim > 1:
+            v = v.flatten(order='A')
+        dtype = kwargs.pop('dtype', _C64)
+        return self.SpMatrix(spp.diags(v, offsets=0).astype(dtype), **kwargs)
+
+    def Adjoint(self, A, **kwargs):
+        return op.Adjoint(self, A, **kwargs)
+
+    def KronI(self, c, B, **kwargs):
+        """I_c (x) B"""
+        return op.Kron(self, self.Eye(c), B, **kwargs)
+
+    def Kron(self, A, B, **kwargs):
+        return op.Kron(self, A, B, **kwargs)
+
+    def BlockDiag(self, Ms, **kwargs):
+        return op.BlockDiag(self, *Ms, **kwargs)
+
+    def VStack(self, Ms, **kwargs):
+        return op.VStack(self, *Ms, **kwargs)
+
+    def HStack(self, Ms, **kwargs):
+        return op.HStack(self, *Ms, **kwargs)
+
+    def UnscaledFFT(self, shape, dtype=_C64, **kwargs):
+        return op.UnscaledFFT(self, shape, dtype=dtype, **kwargs)
+
+    def Eye(self, n, dtype=_C64, **kwargs):
+        return op.Eye(self, n, dtype=dtype, **kwargs)
+
+    def One(self, shape, dtype=_C64, **kwargs):
+        return op.One(self, shape, dtype=dtype, **kwargs)
+
+    def FFT(self, shape, dtype=_C64, **kwargs):
+        """unitary FFT = diag(1/sqrt(n)) * UnscaledFFT"""
+        n = int(np.prod(shape))
+        s = np.ones(n, order='F', dtype=dtype) / np.sqrt(n)
+        return self.Diag(s, name='scale') * self.UnscaledFFT(shape, dtype, **kwargs)
+
+    @staticmethod
+    def fftc_mod(ft_shape, dtype=_C64):
+        """Modulation vector of the centred FFT: exp(2 pi i sum_d (idx_d - c_d/2) c_d / n_d), c_d = n_d // 2."""
+        idx = np.mgrid[tuple(slice(d) for d in ft_shape)]
+        phase = 0
+        for i, n in enumerate(ft_shape):
+            c = n // 2
+            phase = phase + (idx[i] - c / 2.0) * (c / n)
+        return np.exp(1j * 2.0 * np.pi * phase).astype(dtype)
+
+    def FFTc(self, ft_shape, dtype=_C64, normalize=True, **kwargs):
+        """centred (fftshift-ed) FFT as mod * F * mod"""
+        M = self.Diag(self.fftc_mod(ft_shape, dtype), name='mod')
+        F = self.FFT(ft_shape, dtype=dtype, **kwargs) if normalize else self.UnscaledFFT(ft_shape, dtype=dtype, **kwargs)
+        return M * F * M
+
+    @staticmethod
+    def zpad_rows(M, N, mode='center'):
+        """Flat (F-order) indices in the padded volume M that receive the N-volume's samples."""
+        if mode == 'center':
+            slc = tuple(slice(m // 2 + int(np.ceil(-n / 2)), m // 2 + int(np.ceil(n / 2))) for m, n in zip(M, N))
+        elif mode == 'edge':
+            slc = tuple(slice(n) for n in N)
+        else:
+            raise ValueError("unknown zpad mode %r" % mode)
+        x = np.arange(int(np.prod(M)), dtype=np.int64).reshape(M, order='F')
+        return x[slc].flatten(order='F')
+
+    def Zpad(self, M, N, mode='center', dtype=_C64, **kwargs):
+        """zero-pad an N-volume into an M-volume; a 0/1 matrix of shape (prod M, prod N)"""
+        rows = self.zpad_rows(M, N, mode)
+        cols = np.arange(rows.size)
+        mat = spp.coo_matrix((np.ones(rows.size), (rows, cols)), shape=(int(np.prod(M)), int(np.prod(N))), dtype=dtype)
+        return self.SpMatrix(mat, **kwargs)
+
+    def Crop(self, M, N, dtype=_C64, **kwargs):
+        return self.Zpad(N, M, dtype=dtype, **kwargs).H
+
+    def Interp(self, N, coord, width, table, dtype=_C64, **kwargs):
+        """gridding / interpolation matrix (npts x prod N) from a k-space trajectory"""
+        assert len(N) == 3
+        ndim = coord.shape[0]
+        npts = int(np.prod(coord.shape[1:]))
+        coord = coord.reshape((ndim, -1), order='F')
+        from indigo_amd.interp import interp_mat
+        return self.SpMatrix(interp_mat(npts, N, width, table, coord).astype(dtype), **kwargs)
+
+    @staticmethod
+    def nufft_params(width, oversamp):
+        omin = min(oversamp) if isinstance(oversamp, tuple) else oversamp
+        beta = np.pi * np.sqrt(((width * 2. / omin) * (omin - 0.5)) ** 2 - 0.8)
+        return omin, beta
+
+    def NUFFT(self, M, N, coord, width=3, n=128, oversamp=None, dtype=_C64, **kwargs):
+        """non-uniform FFT  G * Fc * Z * R  (interp, centred FFT, zero-pad, roll-off)"""
+        assert len(M) == 3 and len(N) == 3
+        assert tuple(M[1:]) == tuple(coord.shape[1:])
+        from scipy.signal.windows import kaiser
+        from indigo_amd.noncart import rolloff3
+        omin, beta = self.nufft_params(width, oversamp)
+        osf = oversamp if isinstance(oversamp, tuple) else (omin,) * 3
+        oN = tuple(int(N[i] * osf[i]) for i in range(3))
+
+        Z = self.Zpad(oN, N, dtype=dtype, name='zpad')
+        F = self.FFTc(oN, dtype=dtype, name='fft')
+        kb = kaiser(2 * n + 1, beta)[n:]
+        G = self.Interp(oN, coord, width, kb, dtype=np.float32, name='interp')
+        R = self.Diag(rolloff3(omin, width, beta, N), name='apod')
+        return G * F * Z * R
+
+    # ---------------------------------------------------------------------------
+    # leaf-kernel contract
+    # ---------------------------------------------------------------------------
+    def axpby(self, beta, y, alpha, x):
+        """y = beta*y + alpha*x"""
+        raise NotImplementedError()
+
+    def dot(self, x, y):
+        """Re(x^H y)"""
+        raise NotImplementedError()
+
+    def norm2(self, x):
+        """||x||_2 ** 2"""
+        raise NotImplementedError()
+
+    def scale(self, x, alpha):
+        """x *= alpha"""
+        raise NotImplementedError()
+
+    def pdot(self, x, y, comm):
+        v = self.dot(x, y)
+        return v if comm is None else comm.allreduce(v)
+
+    def pnorm2(self, x, comm):
+        v = self.norm2(x)
+        return v if comm is None else comm.allreduce(v)
+
+    def fftn(self, y, x):
+        raise NotImplementedError()
+
+    def ifftn(self, y, x):
+        raise NotImplementedError()
+
+    def _fft_workspace_size(self, x_shape):
+        return 0
+
+    def ccsrmm(self, y, A_shape, A_indx, A_ptr, A_vals, x, alpha=1, beta=0, adjoint=False, exwrite=False):
+        raise NotImplementedError()
+
+    def cdiamm(self, y, shape, offsets, data, x, alpha=1.0, beta=0.0, adjoint=True):
+        raise NotImplementedError("DIA matrices are outside the SENSE hot path")
+
+    def onemm(self, y, x, alpha=1, beta=0):
+        raise NotImplementedError("One operators are outside the SENSE hot path")
+
+    def cgemm(self, y, M, x, alpha, beta, forward):
+        raise NotImplementedError("dense matrices are outside the SENSE hot path")
+
+    def csymm(self, y, M, x, alpha, beta, left=True):
+        raise NotImplementedError("dense matrices are outside the SENSE hot path")
+
+    def max(self, val, arr):
+        raise NotImplementedError()
+
+    def inspect(self, csr):
+        """(nonzero rows, nonzero cols, exwrite) of a scipy CSR matrix; exwrite = every column has <= 1 nonzero."""
+        counts = np.bincount(csr.indices, minlength=csr.shape[1])
+        nzrow = int(np.count_nonzero(np.diff(csr.indptr)))
+        return nzrow, int(np.count_nonzero(counts)), bool(counts.max(initial=0) <= 1)
+
+    # ---------------------------------------------------------------------------
+    # device CSR matrix
+    # ---------------------------------------------------------------------------
+    class csr_matrix(object):
+        _index_base = 0
+
+        def __init__(self, backend, A, name='mat'):
+            if not spp.isspmatrix_csr(A):
+                A = A.tocsr()
+            A = self._type_correct(A)
+            assert A.nnz < 2 ** 31 and max(A.shape) < 2 ** 31, "int32 CSR indices"
+            self._backend = backend
+            self._name = name
+            self.shape = tuple(int(s) for s in A.shape)
+            self.dtype = A.dtype
+            self.rowPtrs = backend.copy_array(A.indptr.astype(np.int32) + self._index_base, name=name + ".rowPtrs")
+            self.colInds = backend.copy_array(A.indices.astype(np.int32) + self._index_base, name=name + ".colInds")
+            self.values = backend.copy_array(A.data, name=name + ".data")
+            nzrow, nzcol, self._exwrite = backend.inspect(A)
+            self._row_frac = nzrow / A.shape[0] if A.shape[0] else 1.0
+            self._col_frac = nzcol / A.shape[1] if A.shape[1] else 1.0
+
+        @staticmethod
+        def _check_panels(y, x, vals):
+            assert x.dtype == _C64, "Bad dtype: expected complex64, got %s" % x.dtype
+            assert y.dtype == _C64, "Bad dtype: expected complex64, got %s" % y.dtype
+            assert vals.dtype == _C64
+
+        def forward(self, y, x, alpha=1, beta=0):
+            """y = alpha * A * x + beta * y"""
+            self._check_panels(y, x, self.values)
+            self._backend.ccsrmm(y, self.shape, self.colInds, self.rowPtrs, self.values,
+                                 x, alpha=alpha, beta=beta, adjoint=False, exwrite=True)
+
+        def adjoint(self, y, x, alpha=1, beta=0):
+            """y = alpha * A^H * x + beta * y"""
+            self._check_panels(y, x, self.values)
+            self._backend.ccsrmm(y, self.shape, self.colInds, self.rowPtrs, self.values,
+                                 x, alpha=alpha, beta=beta, adjoint=True, exwrite=self._exwrite)
+
+        @property
+        def nbytes(self):
+            return self.rowPtrs.nbytes + self.colInds.nbytes + self.values.nbytes
+
+        @property
+        def nnz(self):
+            return self.values.size
+
+        def _type_correct(self, A):
+            return A.astype(_C64)
+
+    # ---------------------------------------------------------------------------
+    # solvers
+    # ---------------------------------------------------------------------------
+    def cg(self, A, b_h, x_h, lamda=0.0, tol=1e-10, maxiter=100, team=None):
+        """Conjugate gradients on (A + lamda I) x = b; x_h is the start and receives the result.
+
+        Same update sequence as the reference (backend.py:651-689): r = b - A x - lamda x,
+        then per iteration one A.eval, five axpby/scale passes, one dot and one norm2.
+        Returns the list of relative residuals.
+        """
+        x = self.copy_array(x_h, name='x')
+        b = self.copy_array(b_h, name='b')
+        Ap = x.copy()
+
+        r = b
+        A.eval(Ap, x)
+        self.axpby(1, r, -1, Ap)
+        self.axpby(1, r, -lamda, x)
+
+        p = r.copy(name='p')
+        rr = self.pnorm2(r, team)
+        r0 = rr
+        history = []
+        for it in range(maxiter):
+            A.eval(Ap, p)
+            self.axpby(1, Ap, lamda, p)
+            alpha = rr / self.pdot(p, Ap, team)
+            self.axpby(1, x, alpha, p)
+            self.axpby(1, r, -alpha, Ap)
+            r2 = self.pnorm2(r, team)
+            beta = r2 / rr
+            self.scale(p, beta)
+            self.axpby(1, p, 1, r)
+            rr = r2
+            resid = float(np.sqrt(rr / r0))
+            history.append(resid)
+            log.info("iter %d, residual %g", it, resid)
+            if resid < tol:
+                log.info("cg reached tolerance")
+                break
+        else:
+            log.info("cg reached maxiter")
+        x.copy_to(x_h)
+        return history
+
+    def apgd(self, gradf, proxg, alpha, x_h, maxiter=100, team=None):
+        """Accelerated proximal gradient descent (reference backend.py:691-732)."""
+        x_k = self.copy_array(x_h)
+        y_k = x_k.copy()
+        y_k1 = x_k.copy()
+        x_k1 = x_k.copy()
+        gf = x_k.copy()
+        t_k = 1
+        for it in range(1, maxiter + 1):
+            gradf(gf, y_k)
+            self.axpby(1, x_k, -alpha, gf)
+            proxg(x_k, alpha)
+            t_k1 = (1.0 + np.sqrt(1.0 + 4.0 * t_k ** 2)) / 2.0
+            t_ratio = (t_k - 1) / t_k1
+            self.axpby(0, y_k1, 1 + t_ratio, x_k)
+            self.axpby(1, y_k1, -t_ratio, x_k1)
+            x_k1.copy(x_k)
+            y_k.copy(y_k1)
+        x_k.copy_to(x_h)

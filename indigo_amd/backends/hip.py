@@ -1,0 +1,379 @@
+"""`HipBackend`: the MI355X backend.  Every leaf kernel is one ctypes call into
+``libindigo_hip.so`` (hand-written HIP for gfx950, C ABI in include/indigo_hip.h).
+
+Plays the role `CudaBackend` plays in the reference (indigo/backends/cuda.py:
+device pointers in `dndarray._arr`, pitch copies, plan cache, one call per leaf)
+but is not derived from it: there are no vendor BLAS/FFT/sparse libraries
+underneath, no per-leaf device synchronisation, sizes are 64-bit, and the
+adjoint SpMM uses a cached transposed CSR (gather) instead of a scatter.
+
+There is no CPU fallback.  Constructing the backend without a usable GPU or
+without the built library raises RuntimeError.
+"""
+import ctypes
+import logging
+
+import numpy as np
+
+from indigo_amd import _lib
+from indigo_amd.backends.backend import Backend
+
+log = logging.getLogger(__name__)
+_C64 = np.dtype('complex64')
+
+
+def _cplx(v):
+    v = complex(v)
+    return ctypes.c_float(v.real), ctypes.c_float(v.imag)
+
+
+class HipBackend(Backend):
+
+    def __init__(self, device_id=0, stream=None):
+        """`stream`: optional raw hipStream_t (int) to adopt, e.g. a torch stream's `.cuda_stream`."""
+        super().__init__(device_id)
+        self._L = _lib.lib()
+        ctx = ctypes.c_void_p()
+        if stream is None:
+            rc = self._L.ig_init(int(device_id), ctypes.byref(ctx))
+        else:
+            rc = self._L.ig_init_on_stream(int(device_id), ctypes.c_void_p(stream), ctypes.byref(ctx))
+        _lib.check(rc, None, "ig_init")
+        self._ctx = ctx
+        self.device_id = int(device_id)
+        self._plans = dict()
+        # 'transpose': adjoint of a non-exwrite matrix gathers through a cached CSR of A^T (deterministic)
+        # 'atomic'   : adjoint scatters with float atomics straight from A's CSR (no extra memory)
+        self.adjoint_policy = 'transpose'
+
+    def __del__(self):
+        try:
+            for plan, _ in getattr(self, '_plans', {}).values():
+                self._L.ig_fft_destroy(plan)
+            if getattr(self, '_ctx', None):
+                self._L.ig_destroy(self._ctx)
+                self._ctx = None
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            _lib.check(rc, self._ctx, what)
+
+    # -- housekeeping ---------------------------------------------------------------
+    def barrier(self):
+        self._check(self._L.ig_sync(self._ctx), "ig_sync")
+
+    @property
+    def stream(self):
+        """raw hipStream_t of this backend (int)"""
+        return self._L.ig_stream(self._ctx) or 0
+
+    def device_name(self):
+        buf = ctypes.create_string_buffer(256)
+        self._check(self._L.ig_device_name(self._ctx, buf, 256), "ig_device_name")
+        return buf.value.decode()
+
+    def mem_info(self):
+        free, total = ctypes.c_size_t(), ctypes.c_size_t()
+        self._check(self._L.ig_mem_info(self._ctx, ctypes.byref(free), ctypes.byref(total)), "ig_mem_info")
+        return free.value, total.value
+
+    # events: (start, stop) pairs on the backend's stream, no host sync until `elapsed_ms`
+    def event(self):
+        ev = ctypes.c_void_p()
+        self._check(self._L.ig_event_create(self._ctx, ctypes.byref(ev)), "ig_event_create")
+        return ev
+
+    def record(self, ev):
+        self._check(self._L.ig_event_record(ev), "ig_event_record")
+
+    def elapsed_ms(self, start, stop):
+        ms = ctypes.c_float()
+        self._check(self._L.ig_event_elapsed_ms(start, stop, ctypes.byref(ms)), "ig_event_elapsed_ms")
+        return ms.value
+
+    def event_destroy(self, ev):
+        self._L.ig_event_destroy(ev)
+
+    # -- arrays -----------------------------------------------------------------------
+    class dndarray(Backend.dndarray):
+        """`_arr` is the device address (Python int)."""
+
+        def _malloc(self, shape, dtype):
+            b = self._backend
+            ptr = ctypes.c_void_p()
+            b._check(b._L.ig_malloc(b._ctx, self.nbytes, ctypes.byref(ptr)), "ig_malloc(%d bytes)" % self.nbytes)
+            return ptr.value
+
+        def _free(self):
+            b = self._backend
+            if getattr(b, '_ctx', None):
+                b._L.ig_free(b._ctx, ctypes.c_void_p(self._arr))
+
+        def _zero(self):
+            b = self._backend
+            if self.ndim == 2 and not self.contiguous:
+                # strided view: clear column by column through a scale by zero
+                b.scale(self, 0)
+            else:
+                b._check(b._L.ig_memset0(b._ctx, ctypes.c_void_p(self._arr), self.nbytes), "ig_memset0")
+
+        def _pitched(self, host_rows):
+            """(device pitch, host pitch, row bytes, count) for a 2-d column-major transfer"""
+            return (self._leading_dim * self.itemsize, host_rows * self.itemsize,
+                    self.shape[0] * self.itemsize, self.shape[1])
+
+        def _copy_from(self, arr):
+            assert arr.flags['F_CONTIGUOUS']
+            b = self._backend
+            src = ctypes.c_void_p(arr.ctypes.data)
+            dst = ctypes.c_void_p(self._arr)
+            if self.size == 0:
+                return
+            if self.ndim == 2 and not self.contiguous:
+                dpitch, spitch, width, height = self._pitched(self.shape[0])
+                rc = b._L.ig_copy2d(b._ctx, dst, dpitch, src, spitch, width, height, _lib.IG_H2D)
+            else:
+                assert self.contiguous
+                rc = b._L.ig_copy2d(b._ctx, dst, self.nbytes, src, self.nbytes, self.nbytes, 1, _lib.IG_H2D)
+            b._check(rc, "ig_copy2d(H2D)")
+
+        def _copy_to(self, arr):
+            b = self._backend
+            if self.size == 0:
+                return
+            out = arr if arr.flags['F_CONTIGUOUS'] else np.empty(self.shape, self.dtype, order='F')
+            dst = ctypes.c_void_p(out.ctypes.data)
+            src = ctypes.c_void_p(self._arr)
+            if self.ndim == 2 and not self.contiguous:
+                spitch, dpitch, width, height = self._pitched(self.shape[0])
+                rc = b._L.ig_copy2d(b._ctx, dst, dpitch, src, spitch, width, height, _lib.IG_D2H)
+            else:
+                assert self.contiguous
+                rc = b._L.ig_copy2d(b._ctx, dst, self.nbytes, src, self.nbytes, self.nbytes, 1, _lib.IG_D2H)
+            b._check(rc, "ig_copy2d(D2H)")
+            if out is not arr:
+                arr[...] = out.reshape(arr.shape, order='F')
+
+        def _copy(self, d_arr):
+            """device -> device: self <- d_arr"""
+            b = self._backend
+            assert self.size == d_arr.size
+            if self.size == 0:
+                return
+            dst, src = ctypes.c_void_p(self._arr), ctypes.c_void_p(d_arr._arr)
+            if self.ndim == 2 and d_arr.ndim == 2 and not (self.contiguous and d_arr.contiguous):
+                assert self.shape == d_arr.shape
+                rc = b._L.ig_copy2d(b._ctx, dst, self._leading_dim * self.itemsize,
+                                    src, d_arr._leading_dim * d_arr.itemsize,
+                                    self.shape[0] * self.itemsize, self.shape[1], _lib.IG_D2D)
+            else:
+                assert self.contiguous and d_arr.contiguous
+                rc = b._L.ig_copy2d(b._ctx, dst, self.nbytes, src, self.nbytes, self.nbytes, 1, _lib.IG_D2D)
+            b._check(rc, "ig_copy2d(D2D)")
+
+        def __getitem__(self, slc):
+            """Contiguous-box slicing; returns a view (pointer + F-order offset, same leading dim)."""
+            if not isinstance(slc, tuple):
+                slc = (slc,)
+            slc = slc + (slice(None),) * (self.ndim - len(slc))
+            start, shape = [], []
+            for s, n in zip(slc, self.shape):
+                if isinstance(s, (int, np.integer)):
+                    s = slice(int(s), int(s) + 1)
+                assert s.step in (None, 1), "strided slices are not supported"
+                b, e, _ = s.indices(n)
+                if e < b:
+                    e = b
+                start.append(b)
+                shape.append(e - b)
+            if self.ndim == 1:
+                offset = start[0]
+            else:
+                # element (i0, i1, ...) lives at i0 + ld*(i1 + shape[1]*(i2 + ...))
+                offset, stride = start[0], self._leading_dim
+                for d in range(1, self.ndim):
+                    offset += start[d] * stride
+                    stride *= self.shape[d]
+            ptr = self._arr + offset * self.itemsize
+            return self._view(tuple(shape), self._leading_dim, ptr)
+
+    # -- BLAS-1 ---------------------------------------------------------------------------
+    def _flat(self, a):
+        assert a.contiguous or a.ndim == 2, "unsupported layout"
+        return a.contiguous
+
+    def axpby(self, beta, y, alpha, x):
+        """y = beta*y + alpha*x  (one fused pass; the CUDA reference takes two, cuda.py:239-248)"""
+        assert isinstance(x, self.dndarray) and isinstance(y, self.dndarray)
+        assert x.dtype == _C64 and y.dtype == _C64, "only complex64 is supported"
+        assert x.size == y.size
+        br, bi = _cplx(beta)
+        ar, ai = _cplx(alpha)
+        if self._flat(y) and self._flat(x):
+            self._check(self._L.ig_caxpby(self._ctx, y.size, br, bi, ctypes.c_void_p(y._arr),
+                                          ar, ai, ctypes.c_void_p(x._arr)), "ig_caxpby")
+        else:
+            x2 = x if x.ndim == 2 else x.reshape(y.shape)
+            assert x2.shape == y.shape
+            for j in range(y.shape[1]):
+                yp = y._arr + j * y._leading_dim * 8
+                xp = x2._arr + j * x2._leading_dim * 8
+                self._check(self._L.ig_caxpby(self._ctx, y.shape[0], br, bi, ctypes.c_void_p(yp),
+                                              ar, ai, ctypes.c_void_p(xp)), "ig_caxpby")
+
+    def scale(self, x, alpha):
+        assert isinstance(x, self.dndarray) and x.dtype == _C64
+        ar, ai = _cplx(alpha)
+        if self._flat(x):
+            self._check(self._L.ig_cscal(self._ctx, x.size, ar, ai, ctypes.c_void_p(x._arr)), "ig_cscal")
+        else:
+            for j in range(x.shape[1]):
+                xp = x._arr + j * x._leading_dim * 8
+                self._check(self._L.ig_cscal(self._ctx, x.shape[0], ar, ai, ctypes.c_void_p(xp)), "ig_cscal")
+
+    def dot(self, x, y):
+        """Re(x^H y) as a Python float (device -> host sync point)"""
+        assert x.dtype == _C64 and y.dtype == _C64 and x.size == y.size
+        assert x.contiguous and y.contiguous
+        out = (ctypes.c_double * 2)()
+        self._check(self._L.ig_cdotc(self._ctx, x.size, ctypes.c_void_p(x._arr), ctypes.c_void_p(y._arr), out), "ig_cdotc")
+        return out[0]
+
+    def cdot(self, x, y):
+        """full complex x^H y"""
+        out = (ctypes.c_double * 2)()
+        self._check(self._L.ig_cdotc(self._ctx, x.size, ctypes.c_void_p(x._arr), ctypes.c_void_p(y._arr), out), "ig_cdotc")
+        return complex(out[0], out[1])
+
+    def norm2(self, x):
+        """||x||^2"""
+        assert x.dtype == _C64 and x.contiguous
+        out = ctypes.c_double()
+        self._check(self._L.ig_scnrm2sq(self._ctx, x.size, ctypes.c_void_p(x._arr), ctypes.byref(out)), "ig_scnrm2sq")
+        return out.value
+
+    def max(self, val, arr):
+        """elementwise max on the real and imaginary parts independently"""
+        assert arr.dtype == _C64 and arr.contiguous
+        self._check(self._L.ig_cmax(self._ctx, arr.size * 2, ctypes.c_float(val), ctypes.c_void_p(arr._arr)), "ig_cmax")
+
+    # -- FFT --------------------------------------------------------------------------------
+    def _get_or_create_plan(self, x_shape):
+        x_shape = tuple(int(s) for s in x_shape)
+        if x_shape not in self._plans:
+            dims = x_shape[:-1]
+            assert 1 <= len(dims) <= 3, "FFT rank must be 1, 2 or 3"
+            c_dims = (ctypes.c_int64 * len(dims))(*dims)
+            plan, ws = ctypes.c_void_p(), ctypes.c_size_t()
+            self._check(self._L.ig_fft_plan(self._ctx, len(dims), c_dims, x_shape[-1],
+                                            ctypes.byref(plan), ctypes.byref(ws)), "ig_fft_plan%s" % (x_shape,))
+            self._plans[x_shape] = (plan, ws.value)
+        return self._plans[x_shape]
+
+    def _fft_workspace_size(self, x_shape):
+        return self._get_or_create_plan(x_shape)[1]
+
+    def fft_describe(self, x_shape):
+        plan, _ = self._get_or_create_plan(x_shape)
+        buf = ctypes.create_string_buffer(1024)
+        self._check(self._L.ig_fft_describe(plan, buf, 1024), "ig_fft_describe")
+        return buf.value.decode()
+
+    def _fft(self, y, x, direction):
+        assert x.dtype == _C64 and y.dtype == _C64, "only complex64 is supported"
+        assert x.shape == y.shape and x.contiguous and y.contiguous
+        plan, ws = self._get_or_create_plan(x.shape)
+        if ws:
+            with self.scratch(nbytes=ws) as tmp:
+                rc = self._L.ig_fft_exec(plan, ctypes.c_void_p(x._arr), ctypes.c_void_p(y._arr), direction,
+                                         ctypes.c_void_p(tmp._arr))
+        else:
+            rc = self._L.ig_fft_exec(plan, ctypes.c_void_p(x._arr), ctypes.c_void_p(y._arr), direction, None)
+        self._check(rc, "ig_fft_exec")
+
+    def fftn(self, y, x):
+        self._fft(y, x, -1)
+
+    def ifftn(self, y, x):
+        self._fft(y, x, +1)
+
+    # -- SpMM -------------------------------------------------------------------------------
+    def ccsrmm(self, y, A_shape, A_indx, A_ptr, A_vals, x, alpha=1, beta=0, adjoint=False, exwrite=False):
+        m, k = A_shape
+        n = x.shape[1]
+        ar, ai = _cplx(alpha)
+        br, bi = _cplx(beta)
+        rc = self._L.ig_ccsrmm(self._ctx, 1 if adjoint else 0, 1 if exwrite else 0, m, k, n, A_vals.size,
+                               ar, ai, ctypes.c_void_p(A_vals._arr), ctypes.c_void_p(A_indx._arr),
+                               ctypes.c_void_p(A_ptr._arr),
+                               ctypes.c_void_p(x._arr), x._leading_dim, br, bi,
+                               ctypes.c_void_p(y._arr), y._leading_dim)
+        self._check(rc, "ig_ccsrmm")
+
+    def ccsrmm_t(self, y, A_shape, At_indx, At_ptr, At_vals, x, alpha=1, beta=0):
+        """y = alpha * A^H x + beta*y through the CSR of A^T (gather)"""
+        m, k = A_shape
+        ar, ai = _cplx(alpha)
+        br, bi = _cplx(beta)
+        rc = self._L.ig_ccsrmm_t(self._ctx, m, k, x.shape[1], At_vals.size,
+                                 ar, ai, ctypes.c_void_p(At_vals._arr), ctypes.c_void_p(At_indx._arr),
+                                 ctypes.c_void_p(At_ptr._arr),
+                                 ctypes.c_void_p(x._arr), x._leading_dim, br, bi,
+                                 ctypes.c_void_p(y._arr), y._leading_dim)
+        self._check(rc, "ig_ccsrmm_t")
+
+    def inspect(self, csr):
+        indptr = np.ascontiguousarray(csr.indptr, dtype=np.int32)
+        indices = np.ascontiguousarray(csr.indices, dtype=np.int32)
+        nzrow, nzcol, exw = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
+        rc = self._L.ig_csr_inspect(ctypes.c_void_p(indptr.ctypes.data), ctypes.c_void_p(indices.ctypes.data),
+                                    csr.shape[0], csr.shape[1], ctypes.byref(nzrow), ctypes.byref(nzcol),
+                                    ctypes.byref(exw))
+        _lib.check(rc, None, "ig_csr_inspect")
+        return nzrow.value, nzcol.value, bool(exw.value)
+
+    def csr_transpose(self, csr):
+        """(indptr_t, indices_t, data_t) of csr^T via the library's native counting sort"""
+        M, K = csr.shape
+        indptr = np.ascontiguousarray(csr.indptr, dtype=np.int32)
+        indices = np.ascontiguousarray(csr.indices, dtype=np.int32)
+        data = np.ascontiguousarray(csr.data, dtype=np.complex64)
+        pt = np.empty(K + 1, dtype=np.int32)
+        it = np.empty(csr.nnz, dtype=np.int32)
+        dt = np.empty(csr.nnz, dtype=np.complex64)
+        rc = self._L.ig_csr_transpose(M, K, csr.nnz, ctypes.c_void_p(indptr.ctypes.data),
+                                      ctypes.c_void_p(indices.ctypes.data), ctypes.c_void_p(data.ctypes.data),
+                                      ctypes.c_void_p(pt.ctypes.data), ctypes.c_void_p(it.ctypes.data),
+                                      ctypes.c_void_p(dt.ctypes.data))
+        _lib.check(rc, None, "ig_csr_transpose")
+        return pt, it, dt
+
+    class csr_matrix(Backend.csr_matrix):
+        """Device CSR with an optional cached CSR of the transpose for gather-form adjoints."""
+
+        def __init__(self, backend, A, name='mat'):
+            super().__init__(backend, A, name)
+            self._host_csr = A if A.dtype == _C64 else A.astype(_C64)   # kept until the transpose is built
+            self._t = None
+
+        def _transposed(self):
+            if self._t is None:
+                b = self._backend
+                pt, it, dt = b.csr_transpose(self._host_csr)
+                self._t = (b.copy_array(pt, name=self._name + ".T.rowPtrs"),
+                           b.copy_array(it, name=self._name + ".T.colInds"),
+                           b.copy_array(dt, name=self._name + ".T.data"))
+                self._host_csr = None
+            return self._t
+
+        def adjoint(self, y, x, alpha=1, beta=0):
+            self._check_panels(y, x, self.values)
+            b = self._backend
+            if self._exwrite or b.adjoint_policy != 'transpose':
+                b.ccsrmm(y, self.shape, self.colInds, self.rowPtrs, self.values,
+                         x, alpha=alpha, beta=beta, adjoint=True, exwrite=self._exwrite)
+            else:
+                pt, it, dt = self._transposed()
+                b.ccsrmm_t(y, self.shape, it, pt, dt, x, alpha=alpha, beta=beta)

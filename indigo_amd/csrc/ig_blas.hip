@@ -1,0 +1,243 @@
+// BLAS-1 glue kernels: axpby, scale, dotc, nrm2^2, elementwise max.
+// All are pure HBM streams: 16-byte (two complex64) accesses per lane,
+// grid-stride over a grid capped at 8 workgroups per CU.
+//
+// Reference semantics: indigo/backends/np.py:53-74,141-145 (numpy oracle),
+// indigo/backends/cuda.py:239-302 (cuBLAS two-pass axpby that this fuses
+// into one pass), indigo/backends/_customgpu.cu:7-13 (cu_max).
+#include "ig_common.h"
+
+namespace {
+
+constexpr int BLK = 256;
+
+inline int grid_for(const ig_ctx* ctx, int64_t work_items) {
+    int64_t g = (work_items + BLK - 1) / BLK;
+    int64_t cap = (int64_t)ctx->num_cu * 8;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// MODE 0: y = a*x            (beta == 0, y not read)
+// MODE 1: y = y + a*x        (beta == 1)
+// MODE 2: y = b*y + a*x      (general)
+// MODE 3: y = b*y            (alpha == 0)
+template <int MODE>
+__global__ void __launch_bounds__(BLK)
+k_caxpby(int64_t n, float2 b, float2* __restrict__ y, float2 a, const float2* __restrict__ x, int vec_ok) {
+    const int64_t tid = (int64_t)blockIdx.x * BLK + threadIdx.x;
+    const int64_t nth = (int64_t)gridDim.x * BLK;
+    if (vec_ok) {
+        const int64_t n2 = n >> 1;
+        float4* y4 = reinterpret_cast<float4*>(y);
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        for (int64_t i = tid; i < n2; i += nth) {
+            float4 xv = (MODE != 3) ? x4[i] : make_float4(0, 0, 0, 0);
+            float4 yv = (MODE != 0) ? y4[i] : make_float4(0, 0, 0, 0);
+            float2 r0, r1;
+            float2 x0 = make_float2(xv.x, xv.y), x1 = make_float2(xv.z, xv.w);
+            float2 y0 = make_float2(yv.x, yv.y), y1 = make_float2(yv.z, yv.w);
+            if (MODE == 0)      { r0 = cmul(a, x0); r1 = cmul(a, x1); }
+            else if (MODE == 1) { r0 = y0; cfma(r0, a, x0); r1 = y1; cfma(r1, a, x1); }
+            else if (MODE == 2) { r0 = cmul(b, y0); cfma(r0, a, x0); r1 = cmul(b, y1); cfma(r1, a, x1); }
+            else                { r0 = cmul(b, y0); r1 = cmul(b, y1); }
+            y4[i] = make_float4(r0.x, r0.y, r1.x, r1.y);
+        }
+        // odd tail element
+        if ((n & 1) && tid == 0) {
+            const int64_t i = n - 1;
+            float2 xv = (MODE != 3) ? x[i] : make_float2(0, 0);
+            float2 yv = (MODE != 0) ? y[i] : make_float2(0, 0);
+            float2 r;
+            if (MODE == 0)      r = cmul(a, xv);
+            else if (MODE == 1) { r = yv; cfma(r, a, xv); }
+            else if (MODE == 2) { r = cmul(b, yv); cfma(r, a, xv); }
+            else                r = cmul(b, yv);
+            y[i] = r;
+        }
+    } else {
+        for (int64_t i = tid; i < n; i += nth) {
+            float2 xv = (MODE != 3) ? x[i] : make_float2(0, 0);
+            float2 yv = (MODE != 0) ? y[i] : make_float2(0, 0);
+            float2 r;
+            if (MODE == 0)      r = cmul(a, xv);
+            else if (MODE == 1) { r = yv; cfma(r, a, xv); }
+            else if (MODE == 2) { r = cmul(b, yv); cfma(r, a, xv); }
+            else                r = cmul(b, yv);
+            y[i] = r;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(BLK)
+k_smax(int64_t n, float val, float* __restrict__ a, int vec_ok) {
+    const int64_t tid = (int64_t)blockIdx.x * BLK + threadIdx.x;
+    const int64_t nth = (int64_t)gridDim.x * BLK;
+    if (vec_ok) {
+        float4* a4 = reinterpret_cast<float4*>(a);
+        const int64_t n4 = n >> 2;
+        for (int64_t i = tid; i < n4; i += nth) {
+            float4 v = a4[i];
+            v.x = fmaxf(v.x, val); v.y = fmaxf(v.y, val); v.z = fmaxf(v.z, val); v.w = fmaxf(v.w, val);
+            a4[i] = v;
+        }
+        for (int64_t i = (n4 << 2) + tid; i < n; i += nth) a[i] = fmaxf(a[i], val);
+    } else {
+        for (int64_t i = tid; i < n; i += nth) a[i] = fmaxf(a[i], val);
+    }
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// per-thread float accumulation over a strided slice, then double from the
+// wave reduction upwards; block partials land in `partials` (2 per block).
+// DOT: sum conj(x)*y (re, im);  !DOT: sum |x|^2 (re only).
+template <bool DOT>
+__global__ void __launch_bounds__(BLK)
+k_reduce(int64_t n, const float2* __restrict__ x, const float2* __restrict__ y, double* __restrict__ partials) {
+    const int64_t tid = (int64_t)blockIdx.x * BLK + threadIdx.x;
+    const int64_t nth = (int64_t)gridDim.x * BLK;
+    double re = 0.0, im = 0.0;
+    // accumulate short runs in float, flush to double to bound the error growth
+    int64_t i = tid;
+    while (i < n) {
+        float fr = 0.f, fi = 0.f;
+#pragma unroll 4
+        for (int k = 0; k < 16 && i < n; ++k, i += nth) {
+            float2 a = x[i];
+            if (DOT) {
+                float2 b = y[i];
+                fr = fmaf(a.x, b.x, fr); fr = fmaf(a.y, b.y, fr);
+                fi = fmaf(a.x, b.y, fi); fi = fmaf(-a.y, b.x, fi);
+            } else {
+                fr = fmaf(a.x, a.x, fr); fr = fmaf(a.y, a.y, fr);
+            }
+        }
+        re += (double)fr; im += (double)fi;
+    }
+    re = wave_sum(re);
+    if (DOT) im = wave_sum(im);
+    __shared__ double s_re[BLK / 64], s_im[BLK / 64];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) { s_re[wid] = re; s_im[wid] = im; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = 0, m = 0;
+        for (int w = 0; w < BLK / 64; ++w) { r += s_re[w]; m += s_im[w]; }
+        partials[2 * blockIdx.x] = r;
+        partials[2 * blockIdx.x + 1] = m;
+    }
+}
+
+__global__ void __launch_bounds__(BLK)
+k_reduce_final(int nblocks, const double* __restrict__ partials, double* __restrict__ out) {
+    double re = 0, im = 0;
+    for (int i = threadIdx.x; i < nblocks; i += BLK) { re += partials[2 * i]; im += partials[2 * i + 1]; }
+    re = wave_sum(re); im = wave_sum(im);
+    __shared__ double s_re[BLK / 64], s_im[BLK / 64];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) { s_re[wid] = re; s_im[wid] = im; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = 0, m = 0;
+        for (int w = 0; w < BLK / 64; ++w) { r += s_re[w]; m += s_im[w]; }
+        out[0] = r; out[1] = m;
+    }
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+int reduce_common(ig_ctx* ctx, bool dot, int64_t n, const void* x, const void* y, double out[2]) {
+    if (int rc = ig_set_device(ctx)) return rc;
+    if (n == 0) { out[0] = out[1] = 0.0; return IG_OK; }
+    int g = grid_for(ctx, n);
+    if (g > IG_MAX_RED_BLOCKS) g = IG_MAX_RED_BLOCKS;
+    if (dot)
+        hipLaunchKernelGGL(k_reduce<true>, dim3(g), dim3(BLK), 0, ctx->stream, n,
+                           (const float2*)x, (const float2*)y, ctx->d_partials);
+    else
+        hipLaunchKernelGGL(k_reduce<false>, dim3(g), dim3(BLK), 0, ctx->stream, n,
+                           (const float2*)x, (const float2*)x, ctx->d_partials);
+    IG_LAUNCH_CHECK(ctx, "k_reduce");
+    // the final (re, im) pair lives in the extra slot behind the per-block partials
+    double* d_out = ctx->d_partials + 2 * IG_MAX_RED_BLOCKS;
+    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(BLK), 0, ctx->stream, g, ctx->d_partials, d_out);
+    IG_LAUNCH_CHECK(ctx, "k_reduce_final");
+    IG_HIP(ctx, hipMemcpyAsync(ctx->h_result, d_out, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    IG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    out[0] = ctx->h_result[0];
+    out[1] = ctx->h_result[1];
+    return IG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ig_caxpby(ig_ctx* ctx, int64_t n, float br, float bi, void* y, float ar, float ai, const void* x) {
+    IG_REQUIRE(ctx, ctx != nullptr, "ig_caxpby: ctx is NULL");
+    IG_REQUIRE(ctx, n >= 0, "ig_caxpby: negative length");
+    if (n == 0) return IG_OK;
+    IG_REQUIRE(ctx, y != nullptr, "ig_caxpby: y is NULL");
+    const bool a0 = (ar == 0.f && ai == 0.f);
+    const bool b0 = (br == 0.f && bi == 0.f);
+    const bool b1 = (br == 1.f && bi == 0.f);
+    IG_REQUIRE(ctx, a0 || x != nullptr, "ig_caxpby: x is NULL");
+    if (a0 && b1) return IG_OK;
+    if (int rc = ig_set_device(ctx)) return rc;
+    if (a0 && b0) {
+        IG_HIP(ctx, hipMemsetAsync(y, 0, (size_t)n * 8, ctx->stream));
+        return IG_OK;
+    }
+    const int vec_ok = aligned16(y) && (a0 || aligned16(x));
+    const int g = grid_for(ctx, vec_ok ? (n + 1) / 2 : n);
+    const float2 a = make_float2(ar, ai), b = make_float2(br, bi);
+    float2* yp = (float2*)y;
+    const float2* xp = (const float2*)x;
+    if (a0)       hipLaunchKernelGGL(k_caxpby<3>, dim3(g), dim3(BLK), 0, ctx->stream, n, b, yp, a, xp, vec_ok);
+    else if (b0)  hipLaunchKernelGGL(k_caxpby<0>, dim3(g), dim3(BLK), 0, ctx->stream, n, b, yp, a, xp, vec_ok);
+    else if (b1)  hipLaunchKernelGGL(k_caxpby<1>, dim3(g), dim3(BLK), 0, ctx->stream, n, b, yp, a, xp, vec_ok);
+    else          hipLaunchKernelGGL(k_caxpby<2>, dim3(g), dim3(BLK), 0, ctx->stream, n, b, yp, a, xp, vec_ok);
+    IG_LAUNCH_CHECK(ctx, "k_caxpby");
+    return IG_OK;
+}
+
+int ig_cscal(ig_ctx* ctx, int64_t n, float ar, float ai, void* x) {
+    // x = alpha * x  ==  axpby with beta := alpha, alpha := 0
+    return ig_caxpby(ctx, n, ar, ai, x, 0.f, 0.f, nullptr);
+}
+
+int ig_cdotc(ig_ctx* ctx, int64_t n, const void* x, const void* y, double out[2]) {
+    IG_REQUIRE(ctx, ctx && out, "ig_cdotc: bad arguments");
+    IG_REQUIRE(ctx, n >= 0 && (n == 0 || (x && y)), "ig_cdotc: bad vector arguments");
+    return reduce_common(ctx, true, n, x, y, out);
+}
+
+int ig_scnrm2sq(ig_ctx* ctx, int64_t n, const void* x, double* out) {
+    IG_REQUIRE(ctx, ctx && out, "ig_scnrm2sq: bad arguments");
+    IG_REQUIRE(ctx, n >= 0 && (n == 0 || x), "ig_scnrm2sq: bad vector argument");
+    double r[2];
+    int rc = reduce_common(ctx, false, n, x, nullptr, r);
+    if (rc == IG_OK) *out = r[0];
+    return rc;
+}
+
+int ig_cmax(ig_ctx* ctx, int64_t nfloats, float val, void* arr) {
+    IG_REQUIRE(ctx, ctx != nullptr, "ig_cmax: ctx is NULL");
+    IG_REQUIRE(ctx, nfloats >= 0, "ig_cmax: negative length");
+    if (nfloats == 0) return IG_OK;
+    IG_REQUIRE(ctx, arr != nullptr, "ig_cmax: NULL pointer");
+    if (int rc = ig_set_device(ctx)) return rc;
+    const int vec_ok = aligned16(arr);
+    const int g = grid_for(ctx, vec_ok ? (nfloats + 3) / 4 : nfloats);
+    hipLaunchKernelGGL(k_smax, dim3(g), dim3(BLK), 0, ctx->stream, nfloats, val, (float*)arr, vec_ok);
+    IG_LAUNCH_CHECK(ctx, "k_smax");
+    return IG_OK;
+}
+
+}  // extern "C"

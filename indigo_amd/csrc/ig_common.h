@@ -1,0 +1,76 @@
+// Internal definitions shared by the HIP translation units of libindigo_hip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdarg>
+#include <string>
+
+#include "indigo_hip.h"
+
+struct ig_ctx {
+    int          device      = 0;
+    hipStream_t  stream      = nullptr;
+    bool         own_stream  = false;
+    int          num_cu      = 256;
+    std::string  err;
+    // small device/pinned scratch used by the reductions (dot, nrm2)
+    double*      d_partials  = nullptr;   // (IG_MAX_RED_BLOCKS + 1) * 2 doubles
+    double*      h_result    = nullptr;   // pinned, 2 doubles
+};
+
+struct ig_event {
+    ig_ctx*    ctx = nullptr;
+    hipEvent_t ev  = nullptr;
+};
+
+constexpr int IG_MAX_RED_BLOCKS = 2048;
+
+// thread-local error for calls without a context
+std::string& ig_tls_error();
+
+int ig_fail(ig_ctx* ctx, int code, const char* fmt, ...) __attribute__((format(printf, 3, 4)));
+
+#define IG_HIP(ctx, call)                                                              \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess)                                                          \
+            return ig_fail((ctx), IG_ERR_HIP, "%s failed: %s (%s:%d)", #call,          \
+                           hipGetErrorString(e_), __FILE__, __LINE__);                 \
+    } while (0)
+
+#define IG_REQUIRE(ctx, cond, ...)                                                     \
+    do {                                                                               \
+        if (!(cond)) return ig_fail((ctx), IG_ERR_ARG, __VA_ARGS__);                   \
+    } while (0)
+
+// checks the launch itself (configuration errors); execution errors surface at the next sync
+#define IG_LAUNCH_CHECK(ctx, what)                                                     \
+    do {                                                                               \
+        hipError_t e_ = hipGetLastError();                                             \
+        if (e_ != hipSuccess)                                                          \
+            return ig_fail((ctx), IG_ERR_HIP, "launch of %s failed: %s", (what),       \
+                           hipGetErrorString(e_));                                     \
+    } while (0)
+
+static inline int ig_set_device(ig_ctx* ctx) {
+    IG_HIP(ctx, hipSetDevice(ctx->device));
+    return IG_OK;
+}
+
+// ---- tiny complex helpers (device) -----------------------------------------
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
+}
+// conj(a) * b
+__device__ __forceinline__ float2 cmulc(float2 a, float2 b) {
+    return make_float2(fmaf(a.x, b.x, a.y * b.y), fmaf(a.x, b.y, -a.y * b.x));
+}
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+// acc += a*b
+__device__ __forceinline__ void cfma(float2& acc, float2 a, float2 b) {
+    acc.x = fmaf(a.x, b.x, acc.x); acc.x = fmaf(-a.y, b.y, acc.x);
+    acc.y = fmaf(a.x, b.y, acc.y); acc.y = fmaf(a.y, b.x, acc.y);
+}

@@ -1,0 +1,222 @@
+// Context, memory, copies, events.
+// Counterpart of the bring-up + dndarray plumbing in the reference's CUDA
+// backend (indigo/backends/cuda.py:28-38,126-181) -- written against the HIP
+// runtime for gfx950, not translated from it.
+#include "ig_common.h"
+#include <cstring>
+
+std::string& ig_tls_error() {
+    static thread_local std::string e;
+    return e;
+}
+
+int ig_fail(ig_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    ig_tls_error() = buf;
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+extern "C" {
+
+int ig_abi_version(void) { return IG_ABI_VERSION; }
+
+int ig_device_count(int* count) {
+    if (!count) return ig_fail(nullptr, IG_ERR_ARG, "ig_device_count: count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { n = 0; (void)hipGetLastError(); }
+    *count = n;
+    return IG_OK;
+}
+
+static int ig_init_common(int device_id, bool adopt, void* ext_stream, ig_ctx** out) {
+    if (!out) return ig_fail(nullptr, IG_ERR_ARG, "ig_init: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return ig_fail(nullptr, IG_ERR_NODEVICE,
+                       "ig_init: no HIP device available (%s); this library has no CPU fallback",
+                       e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    }
+    if (device_id < 0 || device_id >= n)
+        return ig_fail(nullptr, IG_ERR_ARG, "ig_init: device_id %d out of range [0,%d)", device_id, n);
+
+    ig_ctx* ctx = new ig_ctx();
+    ctx->device = device_id;
+    auto bail = [&](const char* what, hipError_t err) {
+        int rc = ig_fail(nullptr, IG_ERR_HIP, "ig_init: %s failed: %s", what, hipGetErrorString(err));
+        delete ctx;
+        return rc;
+    };
+    if ((e = hipSetDevice(device_id)) != hipSuccess) return bail("hipSetDevice", e);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) return bail("hipGetDeviceProperties", e);
+    ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (adopt) {
+        ctx->stream = (hipStream_t)ext_stream;
+        ctx->own_stream = false;
+    } else {
+        if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
+            return bail("hipStreamCreateWithFlags", e);
+        ctx->own_stream = true;
+    }
+    if ((e = hipMalloc((void**)&ctx->d_partials, sizeof(double) * 2 * (IG_MAX_RED_BLOCKS + 1))) != hipSuccess)
+        return bail("hipMalloc(partials)", e);
+    if ((e = hipHostMalloc((void**)&ctx->h_result, sizeof(double) * 2, hipHostMallocDefault)) != hipSuccess)
+        return bail("hipHostMalloc(result)", e);
+    *out = ctx;
+    return IG_OK;
+}
+
+int ig_init(int device_id, ig_ctx** out) { return ig_init_common(device_id, false, nullptr, out); }
+
+int ig_init_on_stream(int device_id, void* hip_stream, ig_ctx** out) {
+    return ig_init_common(device_id, true, hip_stream, out);
+}
+
+void ig_destroy(ig_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->d_partials) (void)hipFree(ctx->d_partials);
+    if (ctx->h_result) (void)hipHostFree(ctx->h_result);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* ig_last_error(ig_ctx* ctx) {
+    if (ctx) return ctx->err.c_str();
+    return ig_tls_error().c_str();
+}
+
+int ig_sync(ig_ctx* ctx) {
+    IG_REQUIRE(ctx, ctx != nullptr, "ig_sync: ctx is NULL");
+    if (int rc = ig_set_device(ctx)) return rc;
+    IG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return IG_OK;
+}
+
+void* ig_stream(ig_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int ig_device_name(ig_ctx* ctx, char* buf, size_t len) {
+    IG_REQUIRE(ctx, ctx && buf && len > 0, "ig_device_name: bad arguments");
+    hipDeviceProp_t prop;
+    IG_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    snprintf(buf, len, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return IG_OK;
+}
+
+int ig_mem_info(ig_ctx* ctx, size_t* free_bytes, size_t* total_bytes) {
+    IG_REQUIRE(ctx, ctx && free_bytes && total_bytes, "ig_mem_info: bad arguments");
+    if (int rc = ig_set_device(ctx)) return rc;
+    IG_HIP(ctx, hipMemGetInfo(free_bytes, total_bytes));
+    return IG_OK;
+}
+
+// ---- memory -----------------------------------------------------------------
+
+int ig_malloc(ig_ctx* ctx, size_t nbytes, void** dptr) {
+    IG_REQUIRE(ctx, ctx && dptr, "ig_malloc: bad arguments");
+    if (int rc = ig_set_device(ctx)) return rc;
+    *dptr = nullptr;
+    // hipMalloc returns >=256-byte aligned memory; never hand out NULL for an empty array
+    size_t n = nbytes ? nbytes : 256;
+    hipError_t e = hipMalloc(dptr, n);
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        return ig_fail(ctx, IG_ERR_NOMEM, "ig_malloc: out of device memory requesting %zu bytes", nbytes);
+    }
+    if (e != hipSuccess) return ig_fail(ctx, IG_ERR_HIP, "hipMalloc(%zu) failed: %s", nbytes, hipGetErrorString(e));
+    return IG_OK;
+}
+
+int ig_free(ig_ctx* ctx, void* dptr) {
+    IG_REQUIRE(ctx, ctx != nullptr, "ig_free: ctx is NULL");
+    if (!dptr) return IG_OK;
+    if (int rc = ig_set_device(ctx)) return rc;
+    // work queued on our (non-blocking) stream may still use the buffer
+    IG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    IG_HIP(ctx, hipFree(dptr));
+    return IG_OK;
+}
+
+int ig_memset0(ig_ctx* ctx, void* dptr, size_t nbytes) {
+    IG_REQUIRE(ctx, ctx != nullptr, "ig_memset0: ctx is NULL");
+    if (nbytes == 0) return IG_OK;
+    IG_REQUIRE(ctx, dptr != nullptr, "ig_memset0: NULL pointer");
+    if (int rc = ig_set_device(ctx)) return rc;
+    IG_HIP(ctx, hipMemsetAsync(dptr, 0, nbytes, ctx->stream));
+    return IG_OK;
+}
+
+int ig_copy2d(ig_ctx* ctx, void* dst, size_t dpitch, const void* src, size_t spitch,
+              size_t width_bytes, size_t height, int kind) {
+    IG_REQUIRE(ctx, ctx != nullptr, "ig_copy2d: ctx is NULL");
+    if (width_bytes == 0 || height == 0) return IG_OK;
+    IG_REQUIRE(ctx, dst && src, "ig_copy2d: NULL pointer");
+    IG_REQUIRE(ctx, height == 1 || (dpitch >= width_bytes && spitch >= width_bytes),
+               "ig_copy2d: pitch smaller than row width");
+    hipMemcpyKind k;
+    switch (kind) {
+        case IG_H2D: k = hipMemcpyHostToDevice; break;
+        case IG_D2H: k = hipMemcpyDeviceToHost; break;
+        case IG_D2D: k = hipMemcpyDeviceToDevice; break;
+        default: return ig_fail(ctx, IG_ERR_ARG, "ig_copy2d: unknown kind %d", kind);
+    }
+    if (int rc = ig_set_device(ctx)) return rc;
+    const bool dense = (height == 1) || (dpitch == width_bytes && spitch == width_bytes);
+    if (dense) {
+        IG_HIP(ctx, hipMemcpyAsync(dst, src, width_bytes * height, k, ctx->stream));
+    } else {
+        IG_HIP(ctx, hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, height, k, ctx->stream));
+    }
+    if (kind != IG_D2D) IG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return IG_OK;
+}
+
+// ---- events -----------------------------------------------------------------
+
+int ig_event_create(ig_ctx* ctx, ig_event** out) {
+    IG_REQUIRE(ctx, ctx && out, "ig_event_create: bad arguments");
+    if (int rc = ig_set_device(ctx)) return rc;
+    ig_event* ev = new ig_event();
+    ev->ctx = ctx;
+    hipError_t e = hipEventCreate(&ev->ev);
+    if (e != hipSuccess) { delete ev; return ig_fail(ctx, IG_ERR_HIP, "hipEventCreate failed: %s", hipGetErrorString(e)); }
+    *out = ev;
+    return IG_OK;
+}
+
+int ig_event_record(ig_event* ev) {
+    if (!ev) return ig_fail(nullptr, IG_ERR_ARG, "ig_event_record: NULL event");
+    ig_ctx* ctx = ev->ctx;
+    if (int rc = ig_set_device(ctx)) return rc;
+    IG_HIP(ctx, hipEventRecord(ev->ev, ctx->stream));
+    return IG_OK;
+}
+
+int ig_event_elapsed_ms(ig_event* start, ig_event* stop, float* ms) {
+    if (!start || !stop || !ms) return ig_fail(nullptr, IG_ERR_ARG, "ig_event_elapsed_ms: bad arguments");
+    ig_ctx* ctx = stop->ctx;
+    if (int rc = ig_set_device(ctx)) return rc;
+    IG_HIP(ctx, hipEventSynchronize(stop->ev));
+    IG_HIP(ctx, hipEventElapsedTime(ms, start->ev, stop->ev));
+    return IG_OK;
+}
+
+int ig_event_destroy(ig_event* ev) {
+    if (!ev) return IG_OK;
+    (void)hipSetDevice(ev->ctx->device);
+    (void)hipEventDestroy(ev->ev);
+    delete ev;
+    return IG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,471 @@
+// Batched complex-to-complex FFT for complex64 on gfx950 -- hand-written
+// Stockham autosort kernels, no vendor FFT library.
+//
+// Contract (Backend.fftn/ifftn, indigo/backends/backend.py:497-509; oracle
+// np.py:102-115; cuFFT usage cuda.py:470-498): Fortran-ordered volume
+// dims[0..rank-1] (dims[0] contiguous) times `batch` contiguous volumes,
+// unnormalised in both directions.
+//
+// One pass per axis.  For an axis of length n the array is viewed as
+// [outer][n][inner] (inner contiguous), i.e. inner*outer independent
+// "columns" of n elements with stride `inner`.
+//
+//  * LDS kernel (n <= 4096 with prime factors in {2,3,5,7}):
+//    a workgroup owns a tile of W neighbouring columns.  The tile is loaded
+//    with coalesced global reads (for axis 0, where a column is a contiguous
+//    line, the tile is one contiguous block and is transposed on the way in),
+//    kept in LDS as [n][W+1] (one pad element per row against bank conflicts)
+//    next to an LDS copy of the n twiddles, transformed by radix-8/4/2/3/5/7
+//    Stockham stages (each thread holds up to 8 elements in registers between
+//    the read barrier and the write barrier, so one LDS buffer suffices), and
+//    written back the way it came.  Tiles are disjoint, so an axis can run in
+//    place.  HBM traffic: exactly one read and one write of the volume per axis.
+//
+//  * generic kernel (anything else: large prime factors, n > 4096):
+//    one Stockham stage per launch through global memory, one thread per
+//    output element, any radix (a prime radix p is a direct p-point DFT).
+//    Slow, but exact in structure for every size; needs a ping-pong workspace.
+//
+// The inverse transform is computed as conj(FFT(conj(x))).
+#include "ig_common.h"
+#include <vector>
+#include <cmath>
+#include <cstring>
+#include <string>
+
+namespace {
+
+constexpr int MAX_STAGES = 16;
+constexpr int E = 8;                 // complex elements a thread holds per LDS stage
+constexpr int LDS_NMAX = 4096;
+constexpr size_t LDS_BUDGET = 150 * 1024;
+
+struct Radices { int r[MAX_STAGES]; };
+
+// ---- butterflies --------------------------------------------------------------
+__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }   // a * (-i)
+
+__device__ __forceinline__ void bfly2(float2& a, float2& b) {
+    const float2 t = csub(a, b);
+    a = cadd(a, b);
+    b = t;
+}
+
+// forward 4-point DFT in place, natural output order
+__device__ __forceinline__ void bfly4(float2& a0, float2& a1, float2& a2, float2& a3) {
+    const float2 t0 = cadd(a0, a2), t1 = csub(a0, a2);
+    const float2 t2 = cadd(a1, a3), t3 = mul_mi(csub(a1, a3));
+    a0 = cadd(t0, t2); a2 = csub(t0, t2);
+    a1 = cadd(t1, t3); a3 = csub(t1, t3);
+}
+
+template <int R>
+struct Bfly {
+    // generic small prime: direct R-point DFT, roots read from the LDS twiddle
+    // table of the enclosing length-n transform (R divides n)
+    __device__ static __forceinline__ void run(float2 (&v)[R], const float2* __restrict__ tws, int n) {
+        float2 o[R];
+        const int step = n / R;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            float2 acc = v[0];
+#pragma unroll
+            for (int q = 1; q < R; ++q) cfma(acc, v[q], tws[((q * k) % R) * step]);
+            o[k] = acc;
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k) v[k] = o[k];
+    }
+};
+template <> struct Bfly<2> {
+    __device__ static __forceinline__ void run(float2 (&v)[2], const float2*, int) { bfly2(v[0], v[1]); }
+};
+template <> struct Bfly<4> {
+    __device__ static __forceinline__ void run(float2 (&v)[4], const float2*, int) { bfly4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct Bfly<8> {
+    __device__ static __forceinline__ void run(float2 (&v)[8], const float2*, int) {
+        // two 4-point DFTs on even / odd inputs, then the 8th-root twiddles
+        bfly4(v[0], v[2], v[4], v[6]);
+        bfly4(v[1], v[3], v[5], v[7]);
+        const float h = 0.70710678118654752440f;
+        const float2 w1 = make_float2(h, -h), w3 = make_float2(-h, -h);
+        v[3] = cmul(v[3], w1);
+        v[5] = mul_mi(v[5]);
+        v[7] = cmul(v[7], w3);
+        // after bfly4 the even half holds E[0..3] in v[0],v[2],v[4],v[6] and the odd half O[0..3] in v[1],v[3],v[5],v[7]
+        bfly2(v[0], v[1]);   // X0, X4
+        bfly2(v[2], v[3]);   // X1, X5
+        bfly2(v[4], v[5]);   // X2, X6
+        bfly2(v[6], v[7]);   // X3, X7
+        // reorder to natural output order X0..X7
+        const float2 x4 = v[1], x1 = v[2], x5 = v[3], x2 = v[4], x6 = v[5], x3 = v[6];
+        v[1] = x1; v[2] = x2; v[3] = x3; v[4] = x4; v[5] = x5; v[6] = x6;
+    }
+};
+
+// One Stockham stage over the LDS tile.  lds[j*WP + w] is element j of column w.
+// Thread (w, t) handles butterflies b = t, t+T, ... (< n/R) of column w.
+template <int R>
+__device__ __forceinline__ void lds_stage(float2* __restrict__ lds, const float2* __restrict__ tws,
+                                          int n, int Ns, int T, int t, int w, int WP) {
+    constexpr int BPT = E / R;
+    const int nb = n / R;
+    float2 v[BPT][R];
+#pragma unroll
+    for (int q = 0; q < BPT; ++q) {
+        const int b = t + q * T;
+        if (b < nb) {
+#pragma unroll
+            for (int k = 0; k < R; ++k) v[q][k] = lds[(b + k * nb) * WP + w];
+        }
+    }
+    __syncthreads();
+    const int tstride = nb / Ns;     // n / (Ns * R)
+#pragma unroll
+    for (int q = 0; q < BPT; ++q) {
+        const int b = t + q * T;
+        if (b < nb) {
+            const int m = b % Ns;
+            if (Ns > 1) {
+#pragma unroll
+                for (int k = 1; k < R; ++k) v[q][k] = cmul(v[q][k], tws[k * m * tstride]);
+            }
+            Bfly<R>::run(v[q], tws, n);
+            const int base = (b - m) * R + m;
+#pragma unroll
+            for (int k = 0; k < R; ++k) lds[(base + k * Ns) * WP + w] = v[q][k];
+        }
+    }
+    __syncthreads();
+}
+
+// AXIS0: inner == 1 (columns are contiguous lines of n elements).
+template <bool AXIS0>
+__global__ void __launch_bounds__(1024)
+k_fft_lds(const float2* __restrict__ x, float2* __restrict__ y, const float2* __restrict__ tw,
+          int n, int64_t inner, int64_t ncols, int W, int T, int nstages, Radices rad, int inverse) {
+    extern __shared__ float2 lds[];
+    const int WP = W + 1;
+    float2* __restrict__ tws = lds + (size_t)n * WP;
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const int64_t c0 = (int64_t)blockIdx.x * W;
+    const int wcount = (int)((ncols - c0 < W) ? (ncols - c0) : W);
+
+    for (int k = tid; k < n; k += nth) tws[k] = tw[k];
+
+    const int w = tid % W, t = tid / W;
+    int64_t colbase = 0;
+    if (AXIS0) {
+        const float2* __restrict__ src = x + c0 * n;
+        const int cnt = wcount * n;
+        for (int e = tid; e < cnt; e += nth) {
+            const int ww = e / n, j = e - ww * n;
+            float2 v = src[e];
+            if (inverse) v.y = -v.y;
+            lds[j * WP + ww] = v;
+        }
+    } else {
+        if (w < wcount) {
+            const int64_t col = c0 + w;
+            const int64_t o = col / inner, i = col - o * inner;
+            colbase = i + inner * n * o;
+            const float2* __restrict__ src = x + colbase;
+            for (int j = t; j < n; j += T) {
+                float2 v = src[(int64_t)j * inner];
+                if (inverse) v.y = -v.y;
+                lds[j * WP + w] = v;
+            }
+        }
+    }
+    __syncthreads();
+
+    int Ns = 1;
+    for (int s = 0; s < nstages; ++s) {
+        const int R = rad.r[s];
+        switch (R) {
+            case 8: lds_stage<8>(lds, tws, n, Ns, T, t, w, WP); break;
+            case 4: lds_stage<4>(lds, tws, n, Ns, T, t, w, WP); break;
+            case 2: lds_stage<2>(lds, tws, n, Ns, T, t, w, WP); break;
+            case 3: lds_stage<3>(lds, tws, n, Ns, T, t, w, WP); break;
+            case 5: lds_stage<5>(lds, tws, n, Ns, T, t, w, WP); break;
+            case 7: lds_stage<7>(lds, tws, n, Ns, T, t, w, WP); break;
+            default: break;   // the planner never emits other radices for this kernel
+        }
+        Ns *= R;
+    }
+
+    if (AXIS0) {
+        float2* __restrict__ dst = y + c0 * n;
+        const int cnt = wcount * n;
+        for (int e = tid; e < cnt; e += nth) {
+            const int ww = e / n, j = e - ww * n;
+            float2 v = lds[j * WP + ww];
+            if (inverse) v.y = -v.y;
+            dst[e] = v;
+        }
+    } else {
+        if (w < wcount) {
+            float2* __restrict__ dst = y + colbase;
+            for (int j = t; j < n; j += T) {
+                float2 v = lds[j * WP + w];
+                if (inverse) v.y = -v.y;
+                dst[(int64_t)j * inner] = v;
+            }
+        }
+    }
+}
+
+// One Stockham stage through global memory, one thread per output element.
+__global__ void __launch_bounds__(256)
+k_fft_generic_stage(const float2* __restrict__ in, float2* __restrict__ out, const float2* __restrict__ tw,
+                    int64_t n, int64_t inner, int64_t total, int R, int64_t Ns, int inverse) {
+    const int64_t nb = n / R;
+    const int64_t tstride = nb / Ns;
+    const int64_t rstride = n / R;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t i = idx % inner;
+        const int64_t rest = idx / inner;
+        const int64_t jo = rest % n;
+        const int64_t o = rest / n;
+        const int64_t m = jo % Ns;
+        const int64_t k = (jo / Ns) % R;
+        const int64_t b = (jo / (Ns * R)) * Ns + m;
+        const float2* __restrict__ src = in + i + inner * n * o;
+        float2 acc = make_float2(0.f, 0.f);
+        for (int q = 0; q < R; ++q) {
+            const float2 v = src[(b + q * nb) * inner];
+            const int64_t ti = (q * m * tstride + (int64_t)((q * k) % R) * rstride) % n;
+            float2 wv = tw[ti];
+            if (inverse) wv.y = -wv.y;
+            cfma(acc, v, wv);
+        }
+        out[idx] = acc;
+    }
+}
+
+// ---- planning -----------------------------------------------------------------
+
+struct AxisPlan {
+    int64_t n = 1, inner = 1, outer = 1;
+    int kind = 2;                      // 0 LDS kernel, 1 generic stages, 2 nothing to do (n == 1)
+    int nstages = 0;
+    Radices rad{};
+    std::vector<int64_t> gen_radices;  // generic path may carry large prime radices
+    int W = 16, T = 1;
+    size_t lds_bytes = 0;
+    float2* d_tw = nullptr;
+};
+
+bool factor_lds(int64_t n, Radices& rad, int& nstages) {
+    nstages = 0;
+    int64_t m = n;
+    auto push = [&](int r) { rad.r[nstages++] = r; };
+    while (m % 8 == 0 && nstages < MAX_STAGES) { push(8); m /= 8; }
+    while (m % 4 == 0 && nstages < MAX_STAGES) { push(4); m /= 4; }
+    while (m % 2 == 0 && nstages < MAX_STAGES) { push(2); m /= 2; }
+    for (int p : {3, 5, 7})
+        while (m % p == 0 && nstages < MAX_STAGES) { push(p); m /= p; }
+    return m == 1;
+}
+
+void factor_generic(int64_t n, std::vector<int64_t>& out) {
+    out.clear();
+    int64_t m = n;
+    while (m % 8 == 0) { out.push_back(8); m /= 8; }
+    while (m % 4 == 0) { out.push_back(4); m /= 4; }
+    while (m % 2 == 0) { out.push_back(2); m /= 2; }
+    for (int64_t p = 3; p * p <= m; p += 2)
+        while (m % p == 0) { out.push_back(p); m /= p; }
+    if (m > 1) out.push_back(m);
+}
+
+}  // namespace
+
+struct ig_fft {
+    ig_ctx* ctx = nullptr;
+    int rank = 0;
+    int64_t dims[3] = {1, 1, 1};
+    int64_t batch = 1;
+    int64_t total = 0;               // elements in all volumes
+    AxisPlan axis[3];
+    size_t workspace_bytes = 0;
+    std::string desc;
+};
+
+namespace {
+
+int plan_axis(ig_ctx* ctx, ig_fft* p, int a) {
+    AxisPlan& ax = p->axis[a];
+    ax.n = p->dims[a];
+    ax.inner = 1;
+    for (int d = 0; d < a; ++d) ax.inner *= p->dims[d];
+    ax.outer = p->total / (ax.n * ax.inner);
+    if (ax.n == 1) { ax.kind = 2; return IG_OK; }
+
+    const bool force_generic = getenv("INDIGO_HIP_FFT_GENERIC") && getenv("INDIGO_HIP_FFT_GENERIC")[0] == '1';
+    Radices rad{};
+    int ns = 0;
+    bool lds_ok = !force_generic && ax.n <= LDS_NMAX && factor_lds(ax.n, rad, ns);
+    if (lds_ok) {
+        int T = 1;
+        for (int s = 0; s < ns; ++s) {
+            const int R = rad.r[s];
+            const int bpt = E / R;
+            const int nb = (int)(ax.n / R);
+            const int need = (nb + bpt - 1) / bpt;
+            if (need > T) T = need;
+        }
+        // widest tile (multiple of 16 columns = 128-byte segments for strided axes) within the
+        // thread and LDS limits; narrow it for long transforms
+        int W = 16;
+        while (W > 1 && ((int64_t)W * T > 1024 || ((size_t)ax.n * (W + 1) + ax.n) * 8 > 72 * 1024)) W >>= 1;
+        while (W < 64 && (int64_t)(W * 2) * T <= 256 && ((size_t)ax.n * (2 * W + 1) + ax.n) * 8 <= 72 * 1024) W <<= 1;
+        const size_t lds = ((size_t)ax.n * (W + 1) + ax.n) * 8;
+        if ((int64_t)W * T > 1024 || lds > LDS_BUDGET) lds_ok = false;
+        else {
+            ax.kind = 0; ax.rad = rad; ax.nstages = ns; ax.W = W; ax.T = T; ax.lds_bytes = lds;
+            if (lds > 48 * 1024) {
+                // more than the default dynamic-LDS limit: opt in (gfx950 has 160 KiB per CU)
+                IG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fft_lds<true>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
+                IG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fft_lds<false>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
+            }
+        }
+    }
+    if (!lds_ok) {
+        ax.kind = 1;
+        factor_generic(ax.n, ax.gen_radices);
+        ax.nstages = (int)ax.gen_radices.size();
+    }
+    // twiddles exp(-2 pi i k / n), rounded once from double
+    std::vector<float2> tw((size_t)ax.n);
+    for (int64_t k = 0; k < ax.n; ++k) {
+        const double ang = -2.0 * M_PI * (double)k / (double)ax.n;
+        tw[k] = make_float2((float)cos(ang), (float)sin(ang));
+    }
+    IG_HIP(ctx, hipMalloc((void**)&ax.d_tw, sizeof(float2) * (size_t)ax.n));
+    IG_HIP(ctx, hipMemcpy(ax.d_tw, tw.data(), sizeof(float2) * (size_t)ax.n, hipMemcpyHostToDevice));
+    return IG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ig_fft_plan(ig_ctx* ctx, int rank, const int64_t* dims, int64_t batch, ig_fft** plan, size_t* workspace_bytes) {
+    IG_REQUIRE(ctx, ctx && dims && plan, "ig_fft_plan: bad arguments");
+    IG_REQUIRE(ctx, rank >= 1 && rank <= 3, "ig_fft_plan: rank %d not in 1..3", rank);
+    IG_REQUIRE(ctx, batch >= 1, "ig_fft_plan: batch must be >= 1");
+    *plan = nullptr;
+    if (int rc = ig_set_device(ctx)) return rc;
+    ig_fft* p = new ig_fft();
+    p->ctx = ctx; p->rank = rank; p->batch = batch;
+    p->total = batch;
+    for (int a = 0; a < rank; ++a) {
+        if (dims[a] < 1) { delete p; return ig_fail(ctx, IG_ERR_ARG, "ig_fft_plan: dims[%d] = %lld", a, (long long)dims[a]); }
+        p->dims[a] = dims[a];
+        p->total *= dims[a];
+    }
+    bool need_ws = false;
+    for (int a = 0; a < rank; ++a) {
+        int rc = plan_axis(ctx, p, a);
+        if (rc != IG_OK) { ig_fft_destroy(p); return rc; }
+        if (p->axis[a].kind == 1) need_ws = true;
+    }
+    p->workspace_bytes = need_ws ? (size_t)p->total * 8 : 0;
+    if (workspace_bytes) *workspace_bytes = p->workspace_bytes;
+
+    char buf[256];
+    p->desc.clear();
+    for (int a = 0; a < rank; ++a) {
+        const AxisPlan& ax = p->axis[a];
+        if (ax.kind == 2) { snprintf(buf, sizeof(buf), "axis%d n=1 skip; ", a); p->desc += buf; continue; }
+        snprintf(buf, sizeof(buf), "axis%d n=%lld %s", a, (long long)ax.n, ax.kind == 0 ? "lds" : "generic");
+        p->desc += buf;
+        if (ax.kind == 0) {
+            snprintf(buf, sizeof(buf), " W=%d T=%d lds=%zuB radices=", ax.W, ax.T, ax.lds_bytes);
+            p->desc += buf;
+            for (int s = 0; s < ax.nstages; ++s) { snprintf(buf, sizeof(buf), s ? "x%d" : "%d", ax.rad.r[s]); p->desc += buf; }
+        } else {
+            p->desc += " radices=";
+            for (size_t s = 0; s < ax.gen_radices.size(); ++s) { snprintf(buf, sizeof(buf), s ? "x%lld" : "%lld", (long long)ax.gen_radices[s]); p->desc += buf; }
+        }
+        p->desc += "; ";
+    }
+    *plan = p;
+    return IG_OK;
+}
+
+int ig_fft_exec(ig_fft* p, const void* xv, void* yv, int direction, void* workspace) {
+    if (!p) return ig_fail(nullptr, IG_ERR_ARG, "ig_fft_exec: plan is NULL");
+    ig_ctx* ctx = p->ctx;
+    IG_REQUIRE(ctx, xv && yv, "ig_fft_exec: NULL array");
+    IG_REQUIRE(ctx, direction == -1 || direction == 1, "ig_fft_exec: direction must be -1 or +1");
+    IG_REQUIRE(ctx, p->workspace_bytes == 0 || workspace != nullptr, "ig_fft_exec: plan needs %zu bytes of workspace", p->workspace_bytes);
+    IG_REQUIRE(ctx, (reinterpret_cast<uintptr_t>(xv) & 7u) == 0 && (reinterpret_cast<uintptr_t>(yv) & 7u) == 0,
+               "ig_fft_exec: arrays must be 8-byte aligned");
+    if (int rc = ig_set_device(ctx)) return rc;
+    const int inverse = direction > 0 ? 1 : 0;
+    const float2* cur = (const float2*)xv;
+    float2* y = (float2*)yv;
+    float2* work = (float2*)workspace;
+
+    for (int a = 0; a < p->rank; ++a) {
+        const AxisPlan& ax = p->axis[a];
+        if (ax.kind == 2) continue;
+        if (ax.kind == 0) {
+            const int64_t ncols = ax.inner * ax.outer;
+            const int64_t blocks = (ncols + ax.W - 1) / ax.W;
+            IG_REQUIRE(ctx, blocks <= 0x7fffffffLL, "ig_fft_exec: too many tiles");
+            const dim3 grid((unsigned)blocks), block((unsigned)(ax.W * ax.T));
+            if (ax.inner == 1)
+                hipLaunchKernelGGL(k_fft_lds<true>, grid, block, ax.lds_bytes, ctx->stream, cur, y, ax.d_tw,
+                                   (int)ax.n, ax.inner, ncols, ax.W, ax.T, ax.nstages, ax.rad, inverse);
+            else
+                hipLaunchKernelGGL(k_fft_lds<false>, grid, block, ax.lds_bytes, ctx->stream, cur, y, ax.d_tw,
+                                   (int)ax.n, ax.inner, ncols, ax.W, ax.T, ax.nstages, ax.rad, inverse);
+            IG_LAUNCH_CHECK(ctx, "k_fft_lds");
+            cur = y;
+        } else {
+            int64_t Ns = 1;
+            int64_t g = (p->total + 255) / 256;
+            const int64_t cap = (int64_t)ctx->num_cu * 16;
+            if (g > cap) g = cap;
+            for (size_t s = 0; s < ax.gen_radices.size(); ++s) {
+                const int64_t R = ax.gen_radices[s];
+                IG_REQUIRE(ctx, R <= 0x7fffffffLL, "ig_fft_exec: radix too large");
+                float2* dst = (cur == y) ? work : y;
+                hipLaunchKernelGGL(k_fft_generic_stage, dim3((unsigned)g), dim3(256), 0, ctx->stream,
+                                   cur, dst, ax.d_tw, ax.n, ax.inner, p->total, (int)R, Ns, inverse);
+                IG_LAUNCH_CHECK(ctx, "k_fft_generic_stage");
+                cur = dst;
+                Ns *= R;
+            }
+        }
+    }
+    if (cur != y) {
+        // all axes were length 1 (cur == x) or the last generic stage landed in the workspace
+        IG_HIP(ctx, hipMemcpyAsync(y, cur, (size_t)p->total * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    return IG_OK;
+}
+
+int ig_fft_describe(ig_fft* p, char* buf, size_t len) {
+    if (!p || !buf || len == 0) return ig_fail(nullptr, IG_ERR_ARG, "ig_fft_describe: bad arguments");
+    snprintf(buf, len, "%s", p->desc.c_str());
+    return IG_OK;
+}
+
+int ig_fft_destroy(ig_fft* p) {
+    if (!p) return IG_OK;
+    (void)hipSetDevice(p->ctx->device);
+    (void)hipStreamSynchronize(p->ctx->stream);
+    for (int a = 0; a < 3; ++a)
+        if (p->axis[a].d_tw) (void)hipFree(p->axis[a].d_tw);
+    delete p;
+    return IG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,507 @@
+"""Structured linear-operator tree evaluated on a `Backend`.
+
+Re-statement (own code) of the operator algebra of the reference,
+indigo/operators.py: the class names, constructor arguments, the
+`eval(y, x, alpha, beta, forward, left)` contract and the order in which a
+composite hands (alpha, beta) to its children are the reference's, so a tree
+built for the reference evaluates identically here:
+
+  * `Product`   puts alpha on the factor applied first and beta on the one
+                applied last, with a scratch panel in between (operators.py:520-530)
+  * `Sum`       evaluates the right child with beta, then the left with beta=1 (:562-567)
+  * `Scale`     conjugates its factor on the adjoint (:587-591)
+  * `Kron(I,B)` is B applied to the (N, c) reshaped panel (:374-375)
+  * `VStack`    adjoint = scale(y, beta) then accumulate children with beta=1 (:440-447)
+  * `UnscaledFFT` requires alpha == 1 and beta == 0 (:314-315)
+
+Only left-multiplication is provided (the reference's right-multiplication
+exists solely for dense real-symmetric factors, which are outside the hot path).
+
+Leaves report the reference's own algorithmic-bytes model to `backend.trace`
+when one is attached (operators.py:246-259, :319-334, :351-353); nothing here
+synchronises the device.
+"""
+import io
+import numpy as np
+import scipy.sparse as spp
+
+_C64 = np.dtype('complex64')
+
+
+def _is_number(v):
+    return isinstance(v, (int, float, complex, np.number)) and not isinstance(v, bool)
+
+
+class Operator(object):
+    """Base class: shape (M, N), dtype, eval, algebra."""
+
+    def __init__(self, backend, name='', alpha=1, batch=None):
+        self._backend = backend
+        self._name = name
+        self._batch = batch
+
+    # -- evaluation -----------------------------------------------------------
+    def eval(self, y, x, alpha=1, beta=0, forward=True, left=True):
+        """y = alpha * op(A) * x + beta * y, with op = identity (forward) or ^H."""
+        if not left:
+            raise NotImplementedError("Right-multiplication is not implemented for %s." % type(self).__name__)
+        rows, cols = self.shape if forward else self.shape[::-1]
+        x2 = x.reshape((cols, -1))
+        y2 = y.reshape((rows, -1))
+        if x2.shape[1] != y2.shape[1]:
+            raise AssertionError("Dimension mismatch: x has %d columns, y has %d" % (x2.shape[1], y2.shape[1]))
+        self._eval(y2, x2, alpha=alpha, beta=beta, forward=forward, left=left)
+
+    def _eval(self, y, x, alpha=1, beta=0, forward=True, left=True):
+        raise NotImplementedError()
+
+    @property
+    def shape(self):
+        raise NotImplementedError()
+
+    @property
+    def dtype(self):
+        raise NotImplementedError()
+
+    # -- algebra ----------------------------------------------------------------
+    def __mul__(self, other):
+        if isinstance(other, Operator):
+            return Product(self._backend, self, other)
+        if isinstance(other, np.ndarray):
+            # convenience: host array in, host array out
+            x = np.asfortranarray(other.reshape((self.shape[1], -1), order='F'))
+            x_d = self._backend.copy_array(x)
+            y_d = self._backend.zero_array((self.shape[0], x.shape[1]), dtype=other.dtype)
+            self.eval(y_d, x_d)
+            return y_d.to_host()
+        if _is_number(other):
+            return Scale(self._backend, other, self)
+        raise ValueError("Cannot multiply Operator by %s" % type(other))
+
+    def __rmul__(self, other):
+        if _is_number(other):
+            return self * other
+        raise ValueError("Cannot right-multiply Operator by %s" % type(other))
+
+    def __add__(self, other):
+        if _is_number(other):
+            other = other * self._backend.Eye(self.shape[1])
+        if isinstance(other, Operator):
+            return Sum(self._backend, self, other)
+        raise ValueError("Cannot add %s to an Operator" % type(other))
+
+    __radd__ = __add__
+
+    def __sub__(self, other):
+        return self + Scale(self._backend, -1, other)
+
+    @property
+    def H(self):
+        return Adjoint(self._backend, self, name=self._name + ".H")
+
+    # -- introspection ------------------------------------------------------------
+    def dump(self):
+        """Indented text rendering of the tree (one node per line)."""
+        buf = io.StringIO()
+        self._dump(buf, 0)
+        return buf.getvalue()
+
+    def _dump(self, file, indent=0):
+        print('%s%s, %s, %s, %s MB, %s' % ('|   ' * indent, self._name or 'noname', type(self).__name__,
+                                           self.shape, self._mem_usage(ncols=1) / 1e6, self.dtype), file=file)
+
+    def optimize(self, recipe=None):
+        from indigo_amd.transforms import Optimize
+        return Optimize(recipe).visit(self)
+
+    def memusage(self, ncols=1):
+        from indigo_amd.analyses import Memusage
+        return Memusage().measure(self, ncols)
+
+    def _mem_usage(self, ncols):
+        return 0
+
+    def has(self, *op_classes):
+        from indigo_amd.analyses import TreeHasOp
+        return TreeHasOp(op_classes).search(self)
+
+
+class CompositeOperator(Operator):
+    def __init__(self, backend, *children, **kwargs):
+        super().__init__(backend, **kwargs)
+        self._adopt(children)
+
+    def _adopt(self, children):
+        self._children = list(children)
+
+    @property
+    def children(self):
+        return self._children
+
+    @property
+    def child(self):
+        assert len(self._children) == 1
+        return self._children[0]
+
+    @property
+    def dtype(self):
+        return self._children[0].dtype
+
+    def _dump(self, file, indent=0):
+        super()._dump(file, indent)
+        for c in self._children:
+            c._dump(file, indent + 1)
+
+    def realize(self):
+        from indigo_amd.transforms import RealizeMatrices
+        return RealizeMatrices().visit(self)
+
+
+class BinaryOperator(CompositeOperator):
+    @property
+    def left(self):
+        return self._children[0]
+
+    @property
+    def right(self):
+        return self._children[1]
+
+
+class MatrixFreeOperator(CompositeOperator):
+    def __init__(self, backend, shape, *args, dtype=_C64, **kwargs):
+        super().__init__(backend, *args, **kwargs)
+        self._shape = tuple(int(s) for s in shape)
+        self._dtype = np.dtype(dtype)
+
+    @property
+    def shape(self):
+        return self._shape
+
+    @property
+    def dtype(self):
+        return self._dtype
+
+
+# ------------------------------------------------------------------------------
+# leaves
+# ------------------------------------------------------------------------------
+
+class SpMatrix(Operator):
+    """Leaf holding a scipy sparse matrix; device CSR is built lazily on first use."""
+
+    def __init__(self, backend, M, **kwargs):
+        super().__init__(backend, **kwargs)
+        assert spp.issparse(M)
+        self._matrix = M
+        self._matrix_d = None
+        self._allow_exwrite = True
+        self._use_dia = False
+
+    @property
+    def shape(self):
+        return tuple(int(s) for s in self._matrix.shape)
+
+    @property
+    def dtype(self):
+        return self._matrix.dtype
+
+    @property
+    def nnz(self):
+        return self._matrix.nnz
+
+    def _mem_usage(self, ncols=1):
+        return self._matrix.data.nbytes
+
+    def _get_or_create_device_matrix(self):
+        if self._matrix_d is None:
+            if self._use_dia:
+                raise NotImplementedError("DIA storage is outside the SENSE hot path")
+            self._matrix = self._matrix.astype(_C64)
+            csr = self._matrix.tocsr()
+            csr.sort_indices()
+            self._matrix_d = self._backend.csr_matrix(self._backend, csr, self._name)
+            if not self._allow_exwrite:
+                self._matrix_d._exwrite = False
+        return self._matrix_d
+
+    def csrmm_bytes(self, x, y, beta, forward):
+        """The reference's traffic model for one csrmm (operators.py:246-256)."""
+        M = self._get_or_create_device_matrix()
+        read_frac, write_frac = (M._col_frac, M._row_frac) if forward else (M._row_frac, M._col_frac)
+        if beta == 0:
+            y_part = 1
+        elif beta == 1:
+            y_part = write_frac * (1 if M._exwrite else 2)
+        else:
+            y_part = 2
+        return M.nbytes + x.nbytes * read_frac + y.nbytes * y_part
+
+    def _eval(self, y, x, alpha=1, beta=0, forward=True, left=True):
+        M = self._get_or_create_device_matrix()
+        trace = getattr(self._backend, 'trace', None)
+        if trace is not None:
+            trace.add('csrmm', nbytes=self.csrmm_bytes(x, y, beta, forward),
+                      nflops=5 * self._matrix.nnz * x.shape[1], shape=x.shape, forward=forward,
+                      name=self._name)
+        if forward:
+            M.forward(y, x, alpha=alpha, beta=beta)
+        else:
+            M.adjoint(y, x, alpha=alpha, beta=beta)
+
+
+class UnscaledFFT(MatrixFreeOperator):
+    """Unnormalised n-dimensional DFT of every column (a column is an F-ordered volume)."""
+
+    def __init__(self, backend, ft_shape, forward=True, **kwargs):
+        self._ft_shape = tuple(int(s) for s in ft_shape)
+        n = int(np.prod(self._ft_shape))
+        super().__init__(backend, shape=(n, n), **kwargs)
+
+    def _eval(self, y, x, alpha=1, beta=0, forward=True, left=True):
+        assert alpha == 1, "FFT expected alpha == 1, got %s" % alpha
+        assert beta == 0, "FFT expected beta == 0, got %s" % beta
+        batch = x.shape[1]
+        X = x.reshape(self._ft_shape + (batch,))
+        Y = y.reshape(self._ft_shape + (batch,))
+        trace = getattr(self._backend, 'trace', None)
+        if trace is not None:
+            n = self.shape[0]
+            trace.add('fft', nbytes=4 * x.nbytes, nflops=batch * 5 * n * np.log2(n), shape=X.shape,
+                      forward=forward, name=self._name)
+        if forward:
+            self._backend.fftn(Y, X)
+        else:
+            self._backend.ifftn(Y, X)
+
+    def _mem_usage(self, ncols):
+        ncols = min(ncols, self._batch or ncols)
+        return self._backend._fft_workspace_size(self._ft_shape + (ncols,))
+
+
+class Eye(MatrixFreeOperator):
+    def __init__(self, backend, n, **kwargs):
+        super().__init__(backend, shape=(n, n), **kwargs)
+
+    def _eval(self, y, x, alpha=1, beta=0, forward=True, left=True):
+        trace = getattr(self._backend, 'trace', None)
+        if trace is not None:
+            trace.add('axpby', nbytes=(0 if alpha == 0 else x.nbytes) + (0 if beta == 0 else y.nbytes) + y.nbytes,
+                      name=self._name)
+        self._backend.axpby(beta, y, alpha, x)
+
+
+class One(MatrixFreeOperator):
+    """Matrix of ones (outside the hot path; evaluates through backend.onemm)."""
+
+    def _eval(self, y, x, alpha=1, beta=0, forward=None, left=True):
+        self._backend.onemm(y, x, alpha, beta)
+
+
+class DenseMatrix(Operator):
+    """Dense complex64 matrix (outside the hot path; evaluates through backend.cgemm)."""
+
+    def __init__(self, backend, M, **kwargs):
+        super().__init__(backend, **kwargs)
+        M = np.require(M, requirements='F')
+        assert M.dtype == _C64 and M.ndim == 2
+        self._matrix = M
+        self._matrix_d = None
+
+    @property
+    def shape(self):
+        return self._matrix.shape
+
+    @property
+    def dtype(self):
+        return self._matrix.dtype
+
+    def _eval(self, y, x, alpha=1, beta=0, forward=True, left=True):
+        if self._matrix_d is None:
+            self._matrix_d = self._backend.copy_array(self._matrix)
+        self._backend.cgemm(y, self._matrix_d, x, alpha=alpha, beta=beta, forward=forward)
+
+
+# ------------------------------------------------------------------------------
+# composites
+# ------------------------------------------------------------------------------
+
+class Adjoint(CompositeOperator):
+    def __init__(self, backend, child, *args, **kwargs):
+        super().__init__(backend, child, *args, **kwargs)
+
+    @property
+    def shape(self):
+        return self.child.shape[::-1]
+
+    @property
+    def dtype(self):
+        return self.child.dtype
+
+    @property
+    def H(self):
+        return self.child
+
+    def _eval(self, y, x, alpha=1, beta=0, forward=True, left=True):
+        self.child.eval(y, x, alpha, beta, forward=not forward, left=left)
+
+
+class Scale(CompositeOperator):
+    def __init__(self, backend, v, child, **kwargs):
+        super().__init__(backend, child, **kwargs)
+        self._name = "%s*{}".format(child._name)
+        self._val = v
+
+    @property
+    def shape(self):
+        return self.child.shape
+
+    @property
+    def dtype(self):
+        return self.child.dtype
+
+    def _eval(self, y, x, alpha=1, beta=0, forward=True, left=True):
+        factor = self._val if forward else np.conj(self._val)
+        self.child.eval(y, x, alpha=alpha * factor, beta=beta, forward=forward, left=left)
+
+
+class Product(BinaryOperator):
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._name = "{}*{}".format(self.left._name, self.right._name)
+
+    def _adopt(self, children):
+        L, R = children
+        if L.shape[1] != R.shape[0]:
+            raise ValueError("Mismatched shapes in Product: attempting {} x {} ({} x {})".format(
+                L.shape, R.shape, L._name, R._name))
+        super()._adopt(children)
+
+    @property
+    def shape(self):
+        return self.left.shape[0], self.right.shape[1]
+
+    def _eval(self, y, x, alpha=1, beta=0, forward=True, left=True):
+        L, R = self._children
+        first, last = (R, L) if forward else (L, R)
+        with self._backend.scratch(shape=(R.shape[0], x.shape[1])) as tmp:
+            first.eval(tmp, x, alpha=alpha, beta=0, forward=forward, left=left)
+            last.eval(y, tmp, alpha=1, beta=beta, forward=forward, left=left)
+
+    def _mem_usage(self, ncols):
+        ncols = min(ncols, self._batch or ncols)
+        return self._children[1].shape[0] * ncols * self.dtype.itemsize
+
+
+class Sum(BinaryOperator):
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._name = "{}+{}".format(self.left._name, self.right._name)
+
+    def _adopt(self, children):
+        L, R = children
+        if L.shape != R.shape:
+            raise ValueError("Mismatched shapes in Sum: attempting {} + {} ({} + {})".format(
+                L.shape, R.shape, L._name, R._name))
+        super()._adopt(children)
+
+    @property
+    def shape(self):
+        return self.left.shape
+
+    def _eval(self, y, x, alpha=1, beta=0, forward=True, left=True):
+        L, R = self._children
+        R.eval(y, x, alpha=alpha, beta=beta, forward=forward, left=left)
+        L.eval(y, x, alpha=alpha, beta=1.0, forward=forward, left=left)
+
+
+class Kron(BinaryOperator):
+    """A (x) B.  Only the KronI form (A = identity) is on the hot path."""
+
+    @property
+    def shape(self):
+        h = int(np.prod([c.shape[0] for c in self._children]))
+        w = int(np.prod([c.shape[1] for c in self._children]))
+        return h, w
+
+    def _eval(self, y, x, alpha=1, beta=0, forward=True, left=True):
+        L, R = self._children
+        if isinstance(L, Eye):
+            # I_c (x) B: the c blocks become c panel columns; R.eval does the reshape
+            R.eval(y, x, alpha=alpha, beta=beta, forward=forward, left=left)
+        else:
+            raise NotImplementedError(
+                "Kron with a non-identity left factor needs right-multiplication, which only the "
+                "reference's dense real-symmetric path provides; outside the SENSE hot path.")
+
+
+def _slice_rows(arr, start, stop):
+    return arr[slice(start, stop), :]
+
+
+class BlockDiag(CompositeOperator):
+    @property
+    def shape(self):
+        return (sum(c.shape[0] for c in self._children), sum(c.shape[1] for c in self._children))
+
+    def _eval(self, y, x, alpha=1, beta=0, forward=True, left=True):
+        yo = xo = 0
+        for C in self._children:
+            h, w = C.shape if forward else C.shape[::-1]
+            C.eval(_slice_rows(y, yo, yo + h), _slice_rows(x, xo, xo + w),
+                   alpha=alpha, beta=beta, forward=forward, left=left)
+            yo += h
+            xo += w
+
+
+class VStack(CompositeOperator):
+    def _adopt(self, children):
+        widths = [c.shape[1] for c in children]
+        if len(set(widths)) > 1:
+            raise ValueError("Mismatched widths in VStack: attempting to stack {}".format(
+                list(zip(widths, [c._name for c in children]))))
+        super()._adopt(children)
+
+    @property
+    def shape(self):
+        return sum(c.shape[0] for c in self._children), self._children[-1].shape[1]
+
+    def _eval(self, y, x, alpha=1, beta=0, forward=True, left=True):
+        off = 0
+        if forward:
+            for C in self._children:
+                h = C.shape[0]
+                C.eval(_slice_rows(y, off, off + h), x, alpha=alpha, beta=beta, forward=True, left=left)
+                off += h
+        else:
+            self._backend.scale(y, beta)
+            for C in self._children:
+                h = C.shape[0]
+                C.eval(y, _slice_rows(x, off, off + h), alpha=alpha, beta=1, forward=False, left=left)
+                off += h
+
+
+class HStack(CompositeOperator):
+    def _adopt(self, children):
+        heights = [c.shape[0] for c in children]
+        if len(set(heights)) > 1:
+            raise ValueError("Mismatched heights in HStack: attempting to stack {}".format(
+                list(zip(heights, [c._name for c in children]))))
+        super()._adopt(children)
+
+    @property
+    def shape(self):
+        return self._children[-1].shape[0], sum(c.shape[1] for c in self._children)
+
+    def _eval(self, y, x, alpha=1, beta=0, forward=True, left=True):
+        off = 0
+        if forward:
+            self._backend.scale(y, beta)
+            for C in self._children:
+                w = C.shape[1]
+                C.eval(y, _slice_rows(x, off, off + w), alpha=alpha, beta=1, forward=True, left=left)
+                off += w
+        else:
+            for C in self._children:
+                w = C.shape[1]
+                C.eval(_slice_rows(y, off, off + w), x, alpha=alpha, beta=beta, forward=False, left=left)
+                off += w

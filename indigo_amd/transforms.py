@@ -1,0 +1,251 @@
+"""Setup-time tree rewrites.
+
+`Transform` / `Visitor` / `Optimize` / `RealizeMatrices` follow
+indigo/transforms.py:19-175; the SENSE recipe passes (`MakeRightLeaning`,
+`AssocSpMatrices`, `DistKroniOverFFT`, `MriRealize`, `MriGoodAdjoints`) restate
+the classes the reference keeps inside its driver script
+(examples/pics.py:104-177) so that `sense_recipe(level)` reproduces `pics.py -O<level>`.
+
+All of this runs on the host with scipy; it decides WHICH leaves run, the HIP
+library decides how fast.  `Optimize` also reserves the scratch arena, sized by
+`ScratchUsage` (the reference's own sizing under-counts KronI trees and trips
+its arena assertion, backend.py:272).
+"""
+import logging
+
+import numpy as np
+import scipy.sparse as spp
+
+from indigo_amd.operators import (Adjoint, BlockDiag, CompositeOperator, Eye, HStack, Kron, One,
+                                  Product, Scale, SpMatrix, UnscaledFFT, VStack)
+
+log = logging.getLogger(__name__)
+
+
+class Transform(object):
+    """Rewrites a tree bottom-up or top-down via `visit_<ClassName>` methods (cf. ast.NodeTransformer)."""
+
+    def visit(self, node):
+        method = getattr(self, "visit_%s" % type(node).__name__, None)
+        return method(node) if method else self.generic_visit(node)
+
+    def generic_visit(self, node):
+        if isinstance(node, CompositeOperator):
+            node._adopt([self.visit(c) for c in node._children])
+        return node
+
+
+class Visitor(object):
+    """Read-only traversal, children first (cf. ast.NodeVisitor)."""
+
+    def visit(self, node):
+        self.generic_visit(node)
+        method = getattr(self, "visit_%s" % type(node).__name__, None)
+        if method:
+            method(node)
+
+    def generic_visit(self, node):
+        if isinstance(node, CompositeOperator):
+            for child in node._children:
+                self.visit(child)
+
+
+class Optimize(Transform):
+    """Run a recipe (list of Transform classes), then reserve the backend's scratch arena."""
+
+    def __init__(self, recipe=None, ncols=1):
+        self._recipe = recipe or []
+        self._ncols = ncols
+
+    def visit(self, node):
+        for Step in self._recipe:
+            log.info("running optimization step: %s", Step.__name__)
+            node = Step().visit(node)
+        from indigo_amd.analyses import ScratchUsage
+        # A and A^H need the same temporaries; AHA = A^H A stacks one more Product on top, so
+        # callers that wrap the optimised tree should call `reserve_for` again on the final tree.
+        reserve_for(node, self._ncols)
+        return node
+
+
+def reserve_for(node, ncols=1, slack_products=2):
+    """Size and allocate `backend._scratch` for evaluating `node` (and `node.H * node`) on `ncols` columns."""
+    from indigo_amd.analyses import ScratchUsage
+    elems = ScratchUsage().measure(node, ncols)
+    # room for the extra Product levels of A^H*A (+ lamda*I): each adds one panel of A's rows or cols
+    extra = slack_products * ((max(node.shape) * ncols + 31) // 32 * 32)
+    node._backend.reserve_scratch(elems + extra)
+    return elems + extra
+
+
+class RealizeMatrices(Transform):
+    """Fold subtrees made only of sparse matrices into a single SpMatrix (scipy on the host)."""
+
+    def visit_Product(self, node):
+        node = self.generic_visit(node)
+        L, R = node._children
+        if isinstance(L, SpMatrix) and isinstance(R, SpMatrix):
+            return SpMatrix(node._backend, L._matrix @ R._matrix, name="{}*{}".format(L._name, R._name))
+        return node
+
+    def _stack(self, node, stacker):
+        node = self.generic_visit(node)
+        kids = node._children
+        if all(isinstance(c, SpMatrix) for c in kids):
+            m = stacker([c._matrix for c in kids], dtype=kids[0].dtype)
+            return SpMatrix(node._backend, m, name="{}+".format(kids[0]._name))
+        return node
+
+    def visit_VStack(self, node):
+        return self._stack(node, spp.vstack)
+
+    def visit_HStack(self, node):
+        return self._stack(node, spp.hstack)
+
+    def visit_BlockDiag(self, node):
+        return self._stack(node, spp.block_diag)
+
+    def visit_Kron(self, node):
+        node = self.generic_visit(node)
+        L, R = node._children
+        if isinstance(L, Eye):
+            L = self.visit_Eye(L)
+        if isinstance(L, SpMatrix) and isinstance(R, SpMatrix):
+            return SpMatrix(node._backend, spp.kron(L._matrix, R._matrix), name="({}(x){})".format(L._name, R._name))
+        return node
+
+    def visit_Adjoint(self, node):
+        node = self.generic_visit(node)
+        child = node.child
+        if isinstance(child, SpMatrix):
+            return SpMatrix(node._backend, child._matrix.conjugate().transpose(), name="{}.H".format(child._name))
+        return node
+
+    def visit_Eye(self, node):
+        return SpMatrix(node._backend, spp.eye(node.shape[0], dtype=node.dtype), name=node._name)
+
+    def visit_Scale(self, node):
+        node = self.generic_visit(node)
+        if isinstance(node.child, SpMatrix):
+            return SpMatrix(node._backend, node.child._matrix * node._val, name=node._name)
+        return node
+
+    def visit_One(self, node):
+        return SpMatrix(node._backend, spp.csr_matrix(np.ones(node.shape, dtype=node.dtype)), name=node._name)
+
+
+class DistributeKroniOverProd(Transform):
+    """Kron(I, A*B) => Kron(I, A) * Kron(I, B)"""
+
+    def visit_Kron(self, node):
+        node = self.generic_visit(node)
+        L, R = node._children
+        if isinstance(L, Eye) and isinstance(R, Product):
+            b = node._backend
+            return self.visit(b.Kron(L, R.left) * b.Kron(L, R.right))
+        return node
+
+
+class DistributeAdjointOverProd(Transform):
+    """Adjoint(A*B) => Adjoint(B) * Adjoint(A)"""
+
+    def visit_Adjoint(self, node):
+        node = self.generic_visit(node)
+        if isinstance(node.child, Product):
+            l, r = node.child._children
+            return r.H * l.H
+        return node
+
+
+# -------------------------------------------------------------------------------
+# SENSE recipe (examples/pics.py:104-193)
+# -------------------------------------------------------------------------------
+
+class MakeRightLeaning(Transform):
+    """(A*B)*C => A*(B*C), recursively"""
+
+    def visit_Product(self, node):
+        l = self.visit(node.left)
+        r = self.visit(node.right)
+        if isinstance(l, Product):
+            return self.visit(l.left * (l.right * r))
+        return l * r
+
+
+class MakeLeftLeaning(Transform):
+    """A*(B*C) => (A*B)*C, recursively"""
+
+    def visit_Product(self, node):
+        l = self.visit(node.left)
+        r = self.visit(node.right)
+        if isinstance(r, Product):
+            return self.visit((l * r.left) * r.right)
+        return l * r
+
+
+class AssocSpMatrices(Transform):
+    """S*(X*Y) => (S*X)*Y when S is sparse and X is not an FFT: brings sparse factors together"""
+
+    def visit_Product(self, node):
+        l = self.visit(node.left)
+        r = self.visit(node.right)
+        if isinstance(l, SpMatrix) and isinstance(r, Product) and not isinstance(r.left, UnscaledFFT):
+            return (l * r.left) * r.right
+        return l * r
+
+
+class DistKroniOverFFT(Transform):
+    """Kron(I, A*B) => Kron(I,A)*Kron(I,B) for subtrees containing an FFT"""
+
+    def visit_Kron(self, node):
+        L, R = node._children
+        if isinstance(L, Eye) and isinstance(R, Product) and node.has(UnscaledFFT):
+            b = node._backend
+            return self.visit(b.Kron(L, R.left) * b.Kron(L, R.right))
+        return node
+
+
+class MriRealize(Transform):
+    """Fold the all-sparse parts of a SENSE tree into single CSR matrices"""
+
+    def visit_VStack(self, node):
+        return node.realize()
+
+    def visit_Product(self, node):
+        l, r = node._children
+        if isinstance(r, VStack) and isinstance(l, Kron):
+            return node.realize()
+        node = self.generic_visit(node)
+        l, r = node._children
+        if isinstance(r, SpMatrix) and isinstance(l, SpMatrix):
+            return node.realize()
+        return node
+
+
+class MriGoodAdjoints(Transform):
+    """Store zero-pad-like matrices transposed (wrapped in Adjoint) so their forward is an exwrite scatter"""
+
+    def visit_SpMatrix(self, node):
+        if 'zpad' in node._name:
+            return node.H.realize().H
+        return node
+
+
+class UseExwriteProperty(Transform):
+    def visit_SpMatrix(self, node):
+        node._allow_exwrite = True
+        return node
+
+
+def sense_recipe(level=3):
+    """The pass list of `pics.py -O<level>` (examples/pics.py:179-193)."""
+    recipe = []
+    if level >= 1:
+        recipe += [MakeRightLeaning, AssocSpMatrices, DistKroniOverFFT, MakeRightLeaning]
+    if level >= 2:
+        recipe += [MriRealize]
+    if level >= 3:
+        recipe += [MriGoodAdjoints]
+    if level >= 4:
+        recipe += [UseExwriteProperty]
+    return recipe

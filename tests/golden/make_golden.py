@@ -1,0 +1,379 @@
+#!/usr/bin/env python3
+"""Generates the golden vectors under tests/golden/ by RUNNING THE REFERENCE.
+
+Run in the build container only (the reference tree is absent on the GPU box):
+
+    python tests/golden/make_golden.py
+
+It imports the reference package from /root/reference (read-only), feeds it
+seeded inputs from *our* generators (indigo_amd.util) and stores inputs and
+the reference's outputs as small .npz fixtures.  Nothing from the reference's
+source is written to this repository -- fixtures are data only.
+
+Third-party drift shims, applied to this process only (reference written for
+python 3.5 / numpy 1.13 / scipy 0.19 / numba / numexpr):
+  * scipy sparse `.H`            -> conjugate().transpose()   (used np.py:125)
+  * `np.int`                     -> int                        (interp.py:80)
+  * `scipy.signal.kaiser`        -> scipy.signal.windows.kaiser (backend.py:436)
+  * `numba.jit`                  -> identity decorator (pure-python speed is fine at fixture sizes)
+  * `numexpr.evaluate`           -> numpy eval                 (noncart.py:7,12)
+  * `Backend.Zpad` indexes with a list of slices (IndexError on numpy >= 1.23); the zero-pad
+    matrix is built here with the same formula and handed to the reference's `SpMatrix`.
+The reference's native `_customcpu` module (oracle/_ref, built from its own C file) is registered
+as `indigo.backends._customcpu` so that `csr_matrix._exwrite` exists and adjoints run.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import scipy.signal
+import scipy.sparse as spp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.dont_write_bytecode = True
+sys.path.insert(0, ROOT)
+
+from indigo_amd.util import rand64c, randM          # noqa: E402  (our seeded generators)
+from oracle import native                           # noqa: E402
+
+
+def install_shims():
+    for cls in (spp.csr_matrix, spp.csc_matrix, spp.coo_matrix, spp.dia_matrix, spp.bsr_matrix, spp.lil_matrix):
+        if not hasattr(cls, "H"):
+            cls.H = property(lambda self: self.conjugate().transpose())
+    if not hasattr(np, "int"):
+        np.int = int
+    if not hasattr(scipy.signal, "kaiser"):
+        scipy.signal.kaiser = scipy.signal.windows.kaiser
+    nb = types.ModuleType("numba")
+    nb.jit = lambda *a, **k: (lambda f: f)
+    sys.modules["numba"] = nb
+    ne = types.ModuleType("numexpr")
+
+    def evaluate(expr, local_dict=None, global_dict=None):
+        frame = sys._getframe(1)
+        env = dict(vars(np))
+        env.update(frame.f_globals)
+        env.update(frame.f_locals)
+        return eval(expr, env)
+    ne.evaluate = evaluate
+    sys.modules["numexpr"] = ne
+
+
+def import_reference():
+    install_shims()
+    native.build(ref=True)
+    mod = native.ref_native()
+    assert mod is not None, "reference native module did not build"
+    sys.path.insert(0, REF)
+    import indigo.backends                      # noqa: F401
+    sys.modules["indigo.backends._customcpu"] = mod
+    indigo.backends._customcpu = mod
+    from indigo.backends import get_backend
+    return get_backend("numpy")
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("%-28s %7.1f KB" % (name + ".npz", os.path.getsize(path) / 1024))
+
+
+def csr_parts(A):
+    A = A.tocsr()
+    A.sort_indices()
+    return dict(indptr=A.indptr.astype(np.int32), indices=A.indices.astype(np.int32),
+                data=A.data.astype(np.complex64), shape=np.array(A.shape))
+
+
+# --------------------------------------------------------------------------------------
+def gold_blas(B):
+    out = {}
+    for i, (n, alpha, beta) in enumerate([(10, 1.5 - 2j, 0.5), (129, -0.1 + 3j, 1.0), (144, 1.2, 0.0), (23, 0.0, 1.5)]):
+        x, y = rand64c(n, seed=100 + i), rand64c(n, seed=200 + i)
+        x_d, y_d = B.copy_array(x), B.copy_array(y)
+        B.axpby(beta, y_d, alpha, x_d)
+        out["axpby%d_x" % i], out["axpby%d_y" % i] = x, y
+        out["axpby%d_ab" % i] = np.array([alpha, beta], dtype=np.complex128)
+        out["axpby%d_out" % i] = y_d.to_host()
+        s_d = B.copy_array(x)
+        B.scale(s_d, alpha)
+        out["scale%d_out" % i] = s_d.to_host()
+        out["dot%d" % i] = np.array(B.dot(B.copy_array(x), B.copy_array(y)))
+        out["nrm%d" % i] = np.array(B.norm2(B.copy_array(x)))
+        m_d = B.copy_array(x)
+        B.max(0.5, m_d)
+        out["max%d_out" % i] = m_d.to_host()
+    out["count"] = np.array(4)
+    save("leaf_blas", **out)
+
+
+def gold_csrmm(B):
+    out = {}
+    cases = []
+    i = 0
+    for (M, K, n, dens) in [(23, 45, 1, 0.1), (45, 23, 8, 0.5), (23, 45, 9, 0.01), (45, 45, 17, 0.1), (64, 80, 64, 0.2)]:
+        for (alpha, beta) in [(1, 0), (0.5, 1.0), (1.5 - 0.5j, 0.5)]:
+            A = randM(M, K, dens, seed=300 + i)
+            A_d = B.csr_matrix(B, A)
+            x, y = rand64c(K, n, seed=400 + i), rand64c(M, n, seed=500 + i)
+            y_d = B.copy_array(y)
+            A_d.forward(y_d, B.copy_array(x), alpha=alpha, beta=beta)
+            xa, ya = rand64c(M, n, seed=600 + i), rand64c(K, n, seed=700 + i)
+            ya_d = B.copy_array(ya)
+            A_d.adjoint(ya_d, B.copy_array(xa), alpha=alpha, beta=beta)
+            for k, v in csr_parts(A).items():
+                out["c%d_%s" % (i, k)] = v
+            out["c%d_ab" % i] = np.array([alpha, beta], dtype=np.complex128)
+            out["c%d_x" % i], out["c%d_y" % i], out["c%d_fwd" % i] = x, y, y_d.to_host()
+            out["c%d_xa" % i], out["c%d_ya" % i], out["c%d_adj" % i] = xa, ya, ya_d.to_host()
+            out["c%d_inspect" % i] = np.array([A_d._row_frac, A_d._col_frac, float(A_d._exwrite)])
+            cases.append(i)
+            i += 1
+    # exwrite matrices: at most one nonzero per column (reference test_backends.py:213-243)
+    for (M, K, n) in [(23, 18, 8), (45, 19, 17)]:
+        rng = np.random.default_rng(800 + i)
+        counts = rng.integers(0, 2, K)
+        ptr = np.concatenate([[0], np.cumsum(counts)])
+        cols = rng.integers(0, M, counts.sum())
+        vals = rand64c(int(counts.sum()), seed=900 + i)
+        A = spp.csr_matrix((vals, cols, ptr), shape=(K, M)).T.tocsr()      # M x K, <= 1 nnz per column
+        A_d = B.csr_matrix(B, A)
+        alpha, beta = 0.5, 1.5
+        x, y = rand64c(K, n, seed=400 + i), rand64c(M, n, seed=500 + i)
+        y_d = B.copy_array(y)
+        A_d.forward(y_d, B.copy_array(x), alpha=alpha, beta=beta)
+        xa, ya = rand64c(M, n, seed=600 + i), rand64c(K, n, seed=700 + i)
+        ya_d = B.copy_array(ya)
+        A_d.adjoint(ya_d, B.copy_array(xa), alpha=alpha, beta=beta)
+        for k, v in csr_parts(A).items():
+            out["c%d_%s" % (i, k)] = v
+        out["c%d_ab" % i] = np.array([alpha, beta], dtype=np.complex128)
+        out["c%d_x" % i], out["c%d_y" % i], out["c%d_fwd" % i] = x, y, y_d.to_host()
+        out["c%d_xa" % i], out["c%d_ya" % i], out["c%d_adj" % i] = xa, ya, ya_d.to_host()
+        out["c%d_inspect" % i] = np.array([A_d._row_frac, A_d._col_frac, float(A_d._exwrite)])
+        cases.append(i)
+        i += 1
+    out["count"] = np.array(len(cases))
+    save("leaf_csrmm", **out)
+
+
+def gold_fft(B):
+    out = {}
+    shapes = [(8,), (16,), (22,), (23,), (25,), (32,), (64,), (24, 25), (16, 8), (22, 23), (23, 24, 25), (8, 16, 4), (24, 22, 23), (16, 16, 16)]
+    for i, shp in enumerate(shapes):
+        batch = 1 + (i % 3)
+        x = rand64c(*(shp + (batch,)), seed=1000 + i)
+        x_d = B.copy_array(x)
+        y_d = B.zero_array(x.shape, x.dtype)
+        B.fftn(y_d, x_d)
+        z_d = B.zero_array(x.shape, x.dtype)
+        B.ifftn(z_d, x_d)
+        out["f%d_x" % i], out["f%d_fwd" % i], out["f%d_inv" % i] = x, y_d.to_host(), z_d.to_host()
+    out["count"] = np.array(len(shapes))
+    save("leaf_fft", **out)
+
+
+def gold_composites(B):
+    out = {}
+    K = 5
+    A0, A1 = randM(6, 7, 0.5, seed=1100), randM(7, 8, 0.5, seed=1101)
+    P = B.SpMatrix(A0, name='A0') * B.SpMatrix(A1, name='A1')
+    x, y = rand64c(8, K, seed=1102), rand64c(6, K, seed=1103)
+    y_d = B.copy_array(y)
+    P.eval(y_d, B.copy_array(x), alpha=0.5, beta=1.0)
+    xa, ya = rand64c(6, K, seed=1104), rand64c(8, K, seed=1105)
+    ya_d = B.copy_array(ya)
+    P.H.eval(ya_d, B.copy_array(xa), alpha=0.5, beta=1.0)
+    out.update({"prod_A0_" + k: v for k, v in csr_parts(A0).items()})
+    out.update({"prod_A1_" + k: v for k, v in csr_parts(A1).items()})
+    out.update(prod_x=x, prod_y=y, prod_fwd=y_d.to_host(), prod_xa=xa, prod_ya=ya, prod_adj=ya_d.to_host())
+
+    # KronI and nested KronI (test_operators.py:195-224, 435-468)
+    A00 = randM(3, 4, 0.9, seed=1110)
+    Kn = B.KronI(6, B.KronI(4, B.SpMatrix(A00)))
+    u, v = rand64c(Kn.shape[1], 2, seed=1111), rand64c(Kn.shape[0], 2, seed=1112)
+    v_d = B.copy_array(v)
+    Kn.eval(v_d, B.copy_array(u))
+    u_d = B.copy_array(u)
+    Kn.H.eval(u_d, B.copy_array(v))
+    out.update({"kron_A_" + k: val for k, val in csr_parts(A00).items()})
+    out.update(kron_u=u, kron_v=v, kron_fwd=v_d.to_host(), kron_adj=u_d.to_host())
+
+    # VStack / BlockDiag with alpha, beta (test_operators.py:87-116, 151-180)
+    mats = [randM(5, 7, 0.5, seed=1120 + j) for j in range(3)]
+    V = B.VStack([B.SpMatrix(m) for m in mats])
+    x, y = rand64c(7, K, seed=1124), rand64c(15, K, seed=1125)
+    y_d = B.copy_array(y)
+    V.eval(y_d, B.copy_array(x), alpha=0.5, beta=0.5)
+    xa, ya = rand64c(15, K, seed=1126), rand64c(7, K, seed=1127)
+    ya_d = B.copy_array(ya)
+    V.H.eval(ya_d, B.copy_array(xa), alpha=0.5, beta=0.5)
+    for j, m in enumerate(mats):
+        out.update({"stack_A%d_%s" % (j, k): val for k, val in csr_parts(m).items()})
+    out.update(vs_x=x, vs_y=y, vs_fwd=y_d.to_host(), vs_xa=xa, vs_ya=ya, vs_adj=ya_d.to_host())
+    D = B.BlockDiag([B.SpMatrix(m) for m in mats])
+    x, y = rand64c(21, K, seed=1128), rand64c(15, K, seed=1129)
+    y_d = B.copy_array(y)
+    D.eval(y_d, B.copy_array(x), alpha=1.0, beta=0.5)
+    xa, ya = rand64c(15, K, seed=1130), rand64c(21, K, seed=1131)
+    ya_d = B.copy_array(ya)
+    D.H.eval(ya_d, B.copy_array(xa), alpha=1.0, beta=0.5)
+    out.update(bd_x=x, bd_y=y, bd_fwd=y_d.to_host(), bd_xa=xa, bd_ya=ya, bd_adj=ya_d.to_host())
+
+    # Sum + Scale incl. conjugation on the adjoint (test_operators.py:515-547)
+    S0, S1 = randM(6, 6, 0.5, seed=1140), randM(6, 6, 0.5, seed=1141)
+    Sm = (2 - 1j) * B.SpMatrix(S0) + B.SpMatrix(S1) - 0.5 * B.Eye(6)
+    x, y = rand64c(6, K, seed=1142), rand64c(6, K, seed=1143)
+    y_d = B.copy_array(y)
+    Sm.eval(y_d, B.copy_array(x), alpha=1.0, beta=0.0)
+    ya_d = B.copy_array(y)
+    Sm.H.eval(ya_d, B.copy_array(x), alpha=1.0, beta=0.0)
+    out.update({"sum_S0_" + k: val for k, val in csr_parts(S0).items()})
+    out.update({"sum_S1_" + k: val for k, val in csr_parts(S1).items()})
+    out.update(sum_x=x, sum_fwd=y_d.to_host(), sum_adj=ya_d.to_host())
+
+    # centred unitary FFT (test_operators.py:337-367)
+    shp = (6, 5, 4)
+    Fc = B.FFTc(shp, dtype=np.dtype('complex64'))
+    x = rand64c(int(np.prod(shp)), 2, seed=1150)
+    y_d = B.zero_array(x.shape, x.dtype)
+    Fc.eval(y_d, B.copy_array(x))
+    ya_d = B.zero_array(x.shape, x.dtype)
+    Fc.H.eval(ya_d, B.copy_array(x))
+    out.update(fftc_x=x, fftc_fwd=y_d.to_host(), fftc_adj=ya_d.to_host(), fftc_shape=np.array(shp))
+    save("composites", **out)
+
+
+def ref_zpad(B, M, N, dtype, name):
+    """The reference's Zpad formula (backend.py:371-387) with tuple indexing."""
+    slc = tuple(slice(m // 2 + int(np.ceil(-n / 2)), m // 2 + int(np.ceil(n / 2))) for m, n in zip(M, N))
+    x = np.arange(np.prod(M), dtype=int).reshape(M, order='F')
+    rows = x[slc].flatten(order='F')
+    cols = np.arange(rows.size)
+    mat = spp.coo_matrix((np.ones_like(cols), (rows, cols)), shape=(np.prod(M), np.prod(N)), dtype=dtype)
+    return B.SpMatrix(mat, name=name), rows
+
+
+def ref_nufft(B, M, N, coord, width, n, oversamp, dtype):
+    """G*F*Z*R composed from the reference's own factories (backend.py:403-442)."""
+    from indigo.noncart import rolloff3
+    oN = tuple(int(d * oversamp) for d in N)
+    Z, zrows = ref_zpad(B, oN, N, dtype, 'zpad')
+    F = B.FFTc(oN, dtype=dtype, name='fft')
+    beta = np.pi * np.sqrt(((width * 2. / oversamp) * (oversamp - 0.5)) ** 2 - 0.8)
+    kb = scipy.signal.windows.kaiser(2 * n + 1, beta)[n:]
+    G = B.Interp(oN, coord, width, kb, dtype=np.float32, name='interp')
+    r = rolloff3(oversamp, width, beta, N)
+    R = B.Diag(r, name='apod')
+    return G * F * Z * R, dict(G=G, r=r, beta=beta, kb=kb, zrows=zrows, oN=oN)
+
+
+def gold_sense(B):
+    import logging
+    out = {}
+    N, C, width, ntab, osf = (12, 13, 14), 3, 3, 128, 1.5
+    ro, tr = 60, 4
+    T = ro * tr
+    rng = np.random.default_rng(1200)
+    coord = rng.random((3, ro, tr)) - 0.5
+    maps = rand64c(*N, C, seed=1201)
+    dtype = np.dtype('complex64')
+
+    F1, parts = ref_nufft(B, (1, ro, tr), N, coord, width, ntab, osf, dtype)
+    G = parts['G']._matrix.tocsr()
+    G.sort_indices()
+    out.update({"interp_" + k: v for k, v in csr_parts(G.astype(np.complex64)).items()})
+    out.update(coord=coord, maps=maps, rolloff=parts['r'], kb=parts['kb'], beta=np.array(parts['beta']),
+               zpad_rows=parts['zrows'], oN=np.array(parts['oN']), N=np.array(N),
+               params=np.array([C, width, ntab, osf, ro, tr], dtype=np.float64))
+    from indigo.backends.backend import Backend as RefBackend
+    # FFTc modulation vector as the reference computes it (backend.py:357-363)
+    oN = parts['oN']
+    idx = np.mgrid[[slice(d) for d in oN]] if False else np.mgrid[tuple(slice(d) for d in oN)]
+    mod = 0
+    for i in range(3):
+        c = oN[i] // 2
+        mod += (idx[i] - c / 2.0) * (c / oN[i])
+    out['fftc_mod'] = np.exp(1j * 2.0 * np.pi * mod).astype(dtype)
+
+    # NUFFT apply
+    x1 = rand64c(int(np.prod(N)), 2, seed=1202)
+    y_d = B.zero_array((T, 2), dtype)
+    F1.eval(y_d, B.copy_array(x1))
+    k1 = rand64c(T, 2, seed=1203)
+    xa_d = B.zero_array(x1.shape, dtype)
+    F1.H.eval(xa_d, B.copy_array(k1))
+    out.update(nufft_x=x1, nufft_fwd=y_d.to_host(), nufft_k=k1, nufft_adj=xa_d.to_host())
+
+    # SENSE A, A^H, A^H A + lamda I   (examples/pics.py:92-95,195)
+    def build():
+        F1, _ = ref_nufft(B, (1, ro, tr), N, coord, width, ntab, osf, dtype)
+        F = B.KronI(C, F1)
+        S = B.VStack([B.Diag(maps[:, :, :, c:c + 1]) for c in range(C)], name='maps')
+        return F * S
+    A = build()
+    x = rand64c(A.shape[1], 1, seed=1204)
+    k = rand64c(A.shape[0], 1, seed=1205)
+    Ax = A * x
+    AHk = A.H * k
+    lamda = 0.1
+    AHA = A.H * A + lamda * B.Eye(A.shape[1])
+    y_d = B.zero_array((A.shape[1], 1), dtype)
+    AHA.eval(y_d, B.copy_array(x))
+    out.update(sense_x=x, sense_k=k, sense_Ax=Ax, sense_AHk=AHk, sense_AHAx=y_d.to_host(), lamda=np.array(lamda))
+
+    # pics.py -O3 tree: exec the reference's recipe classes from its own script text, in this process
+    src = open(os.path.join(REF, "examples", "pics.py")).read().split("\n")
+    ns = {}
+    exec("\n".join(src[96:177]), ns)       # pics.py:97-177: imports + Transform classes
+    recipe = [ns['MakeRightLeaning'], ns['AssocSpMatrices'], ns['DistKroniOverFFT'], ns['MakeRightLeaning'],
+              ns['MriRealize'], ns['MriGoodAdjoints']]
+    A3 = build()
+    for Step in recipe:
+        A3 = Step().visit(A3)
+    if hasattr(B, '_scratch'):
+        del B._scratch
+    out['sense_O3_Ax'] = A3 * x
+    out['sense_O3_AHk'] = A3.H * k
+    out['sense_O3_dump'] = np.array(A3.dump())
+    # the fused matrices themselves (G' and S')
+    from indigo.operators import SpMatrix as RefSp
+
+    def collect(node, acc):
+        if isinstance(node, RefSp):
+            acc.append(node)
+        for c in getattr(node, '_children', []):
+            collect(c, acc)
+    leaves = []
+    collect(A3, leaves)
+    for j, leaf in enumerate(leaves):
+        out.update({"O3_leaf%d_%s" % (j, kk): v for kk, v in csr_parts(leaf._matrix.astype(np.complex64)).items()})
+        out["O3_leaf%d_name" % j] = np.array(leaf._name)
+    out['O3_nleaves'] = np.array(len(leaves))
+
+    # three CG iterates (backend.py:639-689)
+    AHy = AHk / np.abs(AHk).max()
+    for it in (1, 2, 3):
+        x0 = np.zeros((A.shape[1], 1), dtype=dtype, order='F')
+        B.cg(AHA, AHy.copy(order='F'), x0, maxiter=it)
+        out['cg_it%d' % it] = x0
+    out['cg_b'] = AHy
+    save("sense", **out)
+
+
+def main():
+    B = import_reference()
+    print("reference backend:", type(B).__module__, type(B).__name__)
+    gold_blas(B)
+    gold_csrmm(B)
+    gold_fft(B)
+    gold_composites(B)
+    gold_sense(B)
+
+
+if __name__ == "__main__":
+    main()
