@@ -84,6 +84,16 @@ int  ig_event_record(ig_event* ev);
 int  ig_event_elapsed_ms(ig_event* start, ig_event* stop, float* ms);   /* synchronous on `stop` */
 int  ig_event_destroy(ig_event* ev);
 
+/* Profile mode: while enabled, every kernel launch made through this context
+ * is bracketed by two events on the stream (no host sync).  ig_prof_report
+ * synchronises, writes one line per kernel name
+ *     "<name> <launches> <total_ms> <algorithmic_bytes>\n"
+ * into buf (truncated to len), and clears the records.  This is how bench.py
+ * measures a kernel's average launch duration live (the reference's `profile`
+ * hooks, indigo/operators.py:259,334,353, carry the same bytes model).       */
+int  ig_prof_enable(ig_ctx* ctx, int on);
+int  ig_prof_report(ig_ctx* ctx, char* buf, size_t len);
+
 /* ------------------------------------------------------------------------
  * BLAS-1 glue.  Replaces Backend.axpby/scale/dot/norm2/max
  * (indigo/backends/backend.py:453-467,734; numpy oracle np.py:53-74,141-145;

@@ -96,6 +96,20 @@ class HipBackend(Backend):
     def event_destroy(self, ev):
         self._L.ig_event_destroy(ev)
 
+    def profile(self, on=True):
+        """bracket every kernel launch with stream events (no host sync) until switched off"""
+        self._check(self._L.ig_prof_enable(self._ctx, 1 if on else 0), "ig_prof_enable")
+
+    def profile_report(self):
+        """{kernel: dict(launches, total_ms, avg_ms, bytes)} since the last report; synchronises"""
+        buf = ctypes.create_string_buffer(1 << 16)
+        self._check(self._L.ig_prof_report(self._ctx, buf, len(buf)), "ig_prof_report")
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, n, ms, nbytes = line.split()
+            out[name] = dict(launches=int(n), total_ms=float(ms), avg_ms=float(ms) / max(int(n), 1), bytes=float(nbytes))
+        return out
+
     # -- arrays -----------------------------------------------------------------------
     class dndarray(Backend.dndarray):
         """`_arr` is the device address (Python int)."""

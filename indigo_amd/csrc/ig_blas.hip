@@ -157,6 +157,7 @@ int reduce_common(ig_ctx* ctx, bool dot, int64_t n, const void* x, const void* y
     if (n == 0) { out[0] = out[1] = 0.0; return IG_OK; }
     int g = grid_for(ctx, n);
     if (g > IG_MAX_RED_BLOCKS) g = IG_MAX_RED_BLOCKS;
+    ig_prof_scope prof(ctx, dot ? "cdotc" : "scnrm2", (double)n * 8.0 * (dot ? 2 : 1));
     if (dot)
         hipLaunchKernelGGL(k_reduce<true>, dim3(g), dim3(BLK), 0, ctx->stream, n,
                            (const float2*)x, (const float2*)y, ctx->d_partials);
@@ -197,6 +198,7 @@ int ig_caxpby(ig_ctx* ctx, int64_t n, float br, float bi, void* y, float ar, flo
     const int vec_ok = aligned16(y) && (a0 || aligned16(x));
     const int g = grid_for(ctx, vec_ok ? (n + 1) / 2 : n);
     const float2 a = make_float2(ar, ai), b = make_float2(br, bi);
+    ig_prof_scope prof(ctx, "caxpby", (double)n * 8.0 * ((a0 ? 0 : 1) + (b0 ? 1 : 2)));
     float2* yp = (float2*)y;
     const float2* xp = (const float2*)x;
     if (a0)       hipLaunchKernelGGL(k_caxpby<3>, dim3(g), dim3(BLK), 0, ctx->stream, n, b, yp, a, xp, vec_ok);

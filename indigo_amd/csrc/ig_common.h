@@ -6,8 +6,16 @@
 #include <cstdio>
 #include <cstdarg>
 #include <string>
+#include <vector>
 
 #include "indigo_hip.h"
+
+// one timed kernel launch (profile mode): events recorded on the context's stream
+struct ig_prof_rec {
+    const char* name;
+    double      bytes;     // caller-supplied algorithmic bytes of this launch (0 if not given)
+    hipEvent_t  e0, e1;
+};
 
 struct ig_ctx {
     int          device      = 0;
@@ -18,6 +26,28 @@ struct ig_ctx {
     // small device/pinned scratch used by the reductions (dot, nrm2)
     double*      d_partials  = nullptr;   // (IG_MAX_RED_BLOCKS + 1) * 2 doubles
     double*      h_result    = nullptr;   // pinned, 2 doubles
+    // profile mode (ig_prof_enable): every kernel launch is bracketed by two events
+    bool                     prof_on = false;
+    std::vector<ig_prof_rec> prof;
+    std::vector<hipEvent_t>  prof_pool;    // recycled events
+};
+
+// RAII bracket around a kernel launch; a no-op unless profile mode is on.
+struct ig_prof_scope {
+    ig_ctx* ctx; size_t idx; bool on;
+    ig_prof_scope(ig_ctx* c, const char* name, double bytes = 0.0) : ctx(c), idx(0), on(c && c->prof_on) {
+        if (!on) return;
+        ig_prof_rec r; r.name = name; r.bytes = bytes;
+        auto get = [&]() { hipEvent_t e = nullptr;
+            if (!ctx->prof_pool.empty()) { e = ctx->prof_pool.back(); ctx->prof_pool.pop_back(); }
+            else (void)hipEventCreate(&e);
+            return e; };
+        r.e0 = get(); r.e1 = get();
+        (void)hipEventRecord(r.e0, ctx->stream);
+        idx = ctx->prof.size();
+        ctx->prof.push_back(r);
+    }
+    ~ig_prof_scope() { if (on) (void)hipEventRecord(ctx->prof[idx].e1, ctx->stream); }
 };
 
 struct ig_event {

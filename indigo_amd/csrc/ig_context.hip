@@ -85,6 +85,8 @@ void ig_destroy(ig_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    for (ig_prof_rec& r : ctx->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
     if (ctx->d_partials) (void)hipFree(ctx->d_partials);
     if (ctx->h_result) (void)hipHostFree(ctx->h_result);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -208,6 +210,39 @@ int ig_event_elapsed_ms(ig_event* start, ig_event* stop, float* ms) {
     if (int rc = ig_set_device(ctx)) return rc;
     IG_HIP(ctx, hipEventSynchronize(stop->ev));
     IG_HIP(ctx, hipEventElapsedTime(ms, start->ev, stop->ev));
+    return IG_OK;
+}
+
+int ig_prof_enable(ig_ctx* ctx, int on) {
+    IG_REQUIRE(ctx, ctx != nullptr, "ig_prof_enable: ctx is NULL");
+    ctx->prof_on = on != 0;
+    return IG_OK;
+}
+
+int ig_prof_report(ig_ctx* ctx, char* buf, size_t len) {
+    IG_REQUIRE(ctx, ctx && buf && len > 0, "ig_prof_report: bad arguments");
+    if (int rc = ig_set_device(ctx)) return rc;
+    IG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    struct Acc { const char* name; long n; double ms; double bytes; };
+    std::vector<Acc> acc;
+    for (const ig_prof_rec& r : ctx->prof) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) { (void)hipGetLastError(); ms = 0.f; }
+        Acc* a = nullptr;
+        for (Acc& c : acc) if (strcmp(c.name, r.name) == 0) { a = &c; break; }
+        if (!a) { acc.push_back(Acc{r.name, 0, 0.0, 0.0}); a = &acc.back(); }
+        a->n += 1; a->ms += ms; a->bytes += r.bytes;
+        ctx->prof_pool.push_back(r.e0);
+        ctx->prof_pool.push_back(r.e1);
+    }
+    ctx->prof.clear();
+    size_t off = 0;
+    buf[0] = 0;
+    for (const Acc& a : acc) {
+        int w = snprintf(buf + off, len - off, "%s %ld %.6f %.0f\n", a.name, a.n, a.ms, a.bytes);
+        if (w < 0 || (size_t)w >= len - off) break;
+        off += (size_t)w;
+    }
     return IG_OK;
 }
 

@@ -412,10 +412,17 @@ int ig_fft_exec(ig_fft* p, const void* xv, void* yv, int direction, void* worksp
     float2* y = (float2*)yv;
     float2* work = (float2*)workspace;
 
+    int live_axes = 0;
+    for (int a = 0; a < p->rank; ++a) if (p->axis[a].kind != 2) ++live_axes;
+    // the reference's convention books 4 * nbytes per multi-dimensional FFT (benchmark.py:55); each axis
+    // pass gets an equal share of it
+    const double pass_bytes = live_axes ? 4.0 * (double)p->total * 8.0 / live_axes : 0.0;
+
     for (int a = 0; a < p->rank; ++a) {
         const AxisPlan& ax = p->axis[a];
         if (ax.kind == 2) continue;
         if (ax.kind == 0) {
+            ig_prof_scope prof(ctx, ax.inner == 1 ? "fft_lds_axis0" : "fft_lds_strided", pass_bytes);
             const int64_t ncols = ax.inner * ax.outer;
             const int64_t blocks = (ncols + ax.W - 1) / ax.W;
             IG_REQUIRE(ctx, blocks <= 0x7fffffffLL, "ig_fft_exec: too many tiles");
@@ -437,6 +444,7 @@ int ig_fft_exec(ig_fft* p, const void* xv, void* yv, int direction, void* worksp
                 const int64_t R = ax.gen_radices[s];
                 IG_REQUIRE(ctx, R <= 0x7fffffffLL, "ig_fft_exec: radix too large");
                 float2* dst = (cur == y) ? work : y;
+                ig_prof_scope prof(ctx, "fft_generic_stage", pass_bytes / (double)ax.gen_radices.size());
                 hipLaunchKernelGGL(k_fft_generic_stage, dim3((unsigned)g), dim3(256), 0, ctx->stream,
                                    cur, dst, ax.d_tw, ax.n, ax.inner, p->total, (int)R, Ns, inverse);
                 IG_LAUNCH_CHECK(ctx, "k_fft_generic_stage");

@@ -187,6 +187,7 @@ int launch_gather(ig_ctx* ctx, int64_t rows, int64_t N, int64_t nnz,
     IG_REQUIRE(ctx, blocks <= 0x7fffffffLL, "csrmm: matrix too large for one launch (%lld blocks)", (long long)blocks);
     const int xcd = env_flag("INDIGO_HIP_SPMM_XCD", true) ? 1 : 0;
     const bool b0 = (beta.x == 0.f && beta.y == 0.f);
+    ig_prof_scope prof(ctx, CONJ ? "csrmm_gather_conj" : "csrmm_gather");
 #define IG_GATHER(CL_, NL_)                                                                        \
     do {                                                                                           \
         if (b0) hipLaunchKernelGGL((k_csrmm_gather<CL_, NL_, CONJ, 0>), dim3((unsigned)blocks),    \
@@ -230,6 +231,7 @@ int launch_panel_scale(ig_ctx* ctx, int64_t rows, int64_t N, float2* Y, int64_t 
     const int64_t cap = (int64_t)ctx->num_cu * 8;
     if (gx > cap) gx = cap;
     const bool zero = (beta.x == 0.f && beta.y == 0.f);
+    ig_prof_scope prof(ctx, "panel_scale", (double)rows * (double)N * 8.0 * (zero ? 1 : 2));
     if (zero && ld == rows) {
         IG_HIP(ctx, hipMemsetAsync(Y, 0, (size_t)rows * (size_t)N * 8, ctx->stream));
         return IG_OK;
@@ -250,6 +252,7 @@ int launch_scatter(ig_ctx* ctx, int64_t M, int64_t N, int64_t nnz,
     const int64_t blocks = (waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     IG_REQUIRE(ctx, blocks <= 0x7fffffffLL, "csrmm: matrix too large for one launch (%lld blocks)", (long long)blocks);
     const int xcd = env_flag("INDIGO_HIP_SPMM_XCD", true) ? 1 : 0;
+    ig_prof_scope prof(ctx, ATOMIC ? "csrmm_scatter_atomic" : "csrmm_scatter_exwrite");
 #define IG_SCATTER(CL_, NL_)                                                                       \
     hipLaunchKernelGGL((k_csrmm_scatter<CL_, NL_, ATOMIC>), dim3((unsigned)blocks), dim3(BLK), 0,  \
                        ctx->stream, M, N, rowptr, colind, vals, X, ldx, Y, ldy, alpha, xcd)

@@ -89,14 +89,16 @@ def interp_csr_arrays(m, N, width, table, coord, dtype=np.float32, chunk=65536):
     wraps onto the same column twice (true when every N_d exceeds the tap count);
     that condition is checked.  Avoids the COO->CSR conversion of ~5e7 triplets.
     """
+    from concurrent.futures import ThreadPoolExecutor
+    import os
     N = tuple(int(n) for n in N)
     coord = np.asarray(coord, dtype=np.float64).reshape(3, -1)
     indptr = np.zeros(m + 1, dtype=np.int64)
-    idx_parts, val_parts = [], []
-    for lo in range(0, m, chunk):
+    big = np.iinfo(np.int64).max
+
+    def one_chunk(lo):
         hi = min(lo + chunk, m)
         _, col, ker, valid = _chunk_triplets(N, width, table, coord, lo, hi)
-        big = np.iinfo(np.int64).max
         key = np.where(valid, col, big)
         order = np.argsort(key, axis=1, kind='stable')
         key = np.take_along_axis(key, order, axis=1)
@@ -106,9 +108,16 @@ def interp_csr_arrays(m, N, width, table, coord, dtype=np.float32, chunk=65536):
         if dup.any():
             raise ValueError("interp_csr_arrays: a row wraps onto one column twice; use interp_mat")
         keep = np.arange(key.shape[1])[None, :] < cnt[:, None]
-        idx_parts.append(key[keep].astype(np.int32))
-        val_parts.append(ker[keep].astype(dtype))
-        indptr[lo + 1:hi + 1] = cnt
+        return lo, hi, cnt, key[keep].astype(np.int32), ker[keep].astype(dtype)
+
+    # numpy releases the GIL in the heavy steps, so a few threads cut the wall time of big trajectories
+    workers = max(1, min(8, (os.cpu_count() or 2) // 2))
+    idx_parts, val_parts = [], []
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        for lo, hi, cnt, idx, val in ex.map(one_chunk, range(0, m, chunk)):
+            indptr[lo + 1:hi + 1] = cnt
+            idx_parts.append(idx)
+            val_parts.append(val)
     np.cumsum(indptr, out=indptr)
     indices = np.concatenate(idx_parts) if idx_parts else np.zeros(0, dtype=np.int32)
     data = np.concatenate(val_parts) if val_parts else np.zeros(0, dtype=dtype)

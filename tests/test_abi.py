@@ -1,0 +1,93 @@
+"""The C-ABI library: loads, exports every symbol include/indigo_hip.h declares,
+refuses to run without a GPU, and its HOST-side helpers (inspect, transpose)
+agree with scipy.  No device compute here (CPU-only suite).
+"""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import scipy.sparse as spp
+
+from conftest import ROOT
+from indigo_amd import _lib
+
+HEADER = os.path.join(ROOT, "include", "indigo_hip.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ig_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    L = _lib.lib()
+    names = declared_symbols()
+    assert len(names) >= 30
+    for name in names:
+        assert hasattr(L, name), "library does not export %s" % name
+    # and the ctypes prototype table covers exactly the header
+    assert sorted(_lib.PROTOTYPES) == names
+    assert L.ig_abi_version() == 1
+
+
+def test_no_gpu_means_loud_failure():
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is present")
+    from indigo_amd.backends import available_backends, get_backend
+    with pytest.raises(RuntimeError, match="no HIP device|no CPU fallback"):
+        get_backend("hip")
+    assert available_backends() == []
+    with pytest.raises(ValueError):
+        get_backend("numpy")          # the oracle is not a product backend
+
+
+def test_host_inspect_matches_definition():
+    L = _lib.lib()
+    rng = np.random.default_rng(5)
+    for trial in range(6):
+        M, K = int(rng.integers(1, 60)), int(rng.integers(1, 60))
+        A = spp.random(M, K, density=float(rng.choice([0.01, 0.1, 0.5])), format='csr', random_state=rng)
+        if trial == 0:       # exwrite structure: <= 1 nonzero per column
+            cols = rng.permutation(K)[:min(M, K)]
+            A = spp.csr_matrix((np.ones(cols.size), (np.arange(cols.size) % M, cols)), shape=(M, K))
+        indptr, indices = A.indptr.astype(np.int32), A.indices.astype(np.int32)
+        nzr, nzc, exw = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
+        rc = L.ig_csr_inspect(indptr.ctypes.data, indices.ctypes.data, M, K, ctypes.byref(nzr), ctypes.byref(nzc), ctypes.byref(exw))
+        assert rc == 0
+        counts = np.bincount(A.indices, minlength=K)
+        assert nzr.value == np.count_nonzero(np.diff(A.indptr))
+        assert nzc.value == np.count_nonzero(counts)
+        assert bool(exw.value) == bool(counts.max(initial=0) <= 1)
+
+
+def test_host_inspect_rejects_bad_indices():
+    L = _lib.lib()
+    indptr = np.array([0, 1], dtype=np.int32)
+    indices = np.array([7], dtype=np.int32)
+    nzr, nzc, exw = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
+    rc = L.ig_csr_inspect(indptr.ctypes.data, indices.ctypes.data, 1, 3, ctypes.byref(nzr), ctypes.byref(nzc), ctypes.byref(exw))
+    assert rc == 2 and "out of range" in _lib.last_error()
+
+
+def test_host_transpose_matches_scipy():
+    L = _lib.lib()
+    rng = np.random.default_rng(6)
+    for M, K, d in [(1, 1, 1.0), (17, 33, 0.2), (64, 8, 0.5), (5, 40, 0.0)]:
+        A = spp.random(M, K, density=d, format='csr', random_state=rng, dtype=np.float64)
+        A = (A + 1j * A).astype(np.complex64).tocsr()
+        A.sort_indices()
+        indptr, indices = A.indptr.astype(np.int32), A.indices.astype(np.int32)
+        pt = np.empty(K + 1, np.int32)
+        it = np.empty(A.nnz, np.int32)
+        dt = np.empty(A.nnz, np.complex64)
+        rc = L.ig_csr_transpose(M, K, A.nnz, indptr.ctypes.data, indices.ctypes.data, A.data.ctypes.data,
+                                pt.ctypes.data, it.ctypes.data, dt.ctypes.data)
+        assert rc == 0
+        T = A.T.tocsr()
+        T.sort_indices()
+        np.testing.assert_array_equal(pt, T.indptr)
+        np.testing.assert_array_equal(it, T.indices)
+        np.testing.assert_array_equal(dt, T.data)

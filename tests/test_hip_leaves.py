@@ -1,0 +1,374 @@
+"""GPU parity tests for the leaf kernels, called through the C ABI (HipBackend -> ctypes).
+
+Compared against (a) the golden vectors captured from the reference and (b) the
+numpy oracle / inline numpy-scipy expressions on seeded inputs, the way the
+reference's own suite does it (indigo/backends/test_backends.py).  Tolerance
+for complex64 results: 1e-5 relative (north star), stated per assertion.
+"""
+import itertools
+
+import numpy as np
+import pytest
+import scipy.sparse as spp
+
+from conftest import csr_from, golden, rel_err
+from indigo_amd.util import rand64c, randM
+
+pytestmark = pytest.mark.gpu
+C64 = np.dtype('complex64')
+RTOL = 1e-5
+
+
+# ---------------------------------------------------------------------------------------
+# arrays (reference test_backends.py:13-151)
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [4, 8, 129])
+def test_array_roundtrips(hip, n):
+    arr = rand64c(n, seed=n)
+    d = hip.copy_array(arr)
+    np.testing.assert_equal(d.to_host(), arr)
+    z = hip.zero_array(arr.shape, arr.dtype)
+    assert not z.to_host().any()
+    z.copy_from(arr)
+    np.testing.assert_equal(z.to_host(), arr)
+    out = np.zeros_like(arr)
+    d.copy_to(out)
+    np.testing.assert_equal(out, arr)
+    dup = d.copy()
+    d._zero()
+    np.testing.assert_equal(dup.to_host(), arr)
+    into = hip.zero_array(arr.shape, arr.dtype)
+    into.copy(dup)
+    np.testing.assert_equal(into.to_host(), arr)
+    into2 = hip.zero_array(arr.shape, arr.dtype)
+    into2[:] = dup
+    np.testing.assert_equal(into2.to_host(), arr)
+    with pytest.raises(ValueError):
+        hip.zero_array((n + 1,), arr.dtype).copy_from(arr)
+    with pytest.raises(TypeError):
+        hip.zero_array(arr.shape, np.complex128).copy_from(arr)
+
+
+@pytest.mark.parametrize("s", [-2, -1, 1, 2])
+def test_array_slice_1d(hip, s):
+    arr = np.arange(10)
+    d = hip.copy_array(arr)
+    np.testing.assert_equal(d[:s].to_host(), arr[:s])
+    np.testing.assert_equal(d[s:].to_host(), arr[s:])
+
+
+@pytest.mark.parametrize("M,N,xb,xe,yb,ye", itertools.product([6, 7], [8, 9], [0, 2], [4, 5], [0, 1], [6, 7]))
+def test_array_slice_2d(hip, M, N, xb, xe, yb, ye):
+    arr = rand64c(M, N, seed=M * N)
+    d = hip.copy_array(arr)
+    sub = d[xb:xe, yb:ye]
+    np.testing.assert_equal(sub.to_host(), arr[xb:xe, yb:ye])
+    dup = hip.zeros_like(sub)
+    dup.copy(sub)
+    np.testing.assert_equal(dup.to_host(), arr[xb:xe, yb:ye])
+    # writing through a strided view
+    patch = rand64c(xe - xb, ye - yb, seed=1)
+    sub.copy_from(patch)
+    exp = arr.copy()
+    exp[xb:xe, yb:ye] = patch
+    np.testing.assert_equal(d.to_host(), exp)
+
+
+def test_array_bad_reshape_of_row_slice(hip):
+    d = hip.copy_array(rand64c(8, 4, seed=0))
+    with pytest.raises(AssertionError):
+        d[2:6, :].reshape((8, 2))
+
+
+def test_on_host_and_mem_usage(hip):
+    d = hip.copy_array(np.zeros(11, dtype=C64))
+    with d.on_host() as h:
+        h += 1
+    assert d.to_host().sum() == 11
+    assert hip.mem_usage() > 0
+
+
+def test_only_complex64(hip):
+    x = hip.copy_array(np.ones(4, dtype=np.complex128))
+    with pytest.raises(AssertionError):
+        hip.axpby(1, x, 1, x)
+
+
+# ---------------------------------------------------------------------------------------
+# BLAS-1
+# ---------------------------------------------------------------------------------------
+def test_blas_golden(hip):
+    g = golden("leaf_blas")
+    for i in range(int(g["count"])):
+        x, y = g["axpby%d_x" % i], g["axpby%d_y" % i]
+        alpha, beta = g["axpby%d_ab" % i]
+        y_d = hip.copy_array(y)
+        hip.axpby(beta.real, y_d, alpha, hip.copy_array(x))
+        assert rel_err(y_d.to_host(), g["axpby%d_out" % i]) < RTOL
+        s_d = hip.copy_array(x)
+        hip.scale(s_d, alpha)
+        assert rel_err(s_d.to_host(), g["scale%d_out" % i]) < RTOL
+        np.testing.assert_allclose(hip.dot(hip.copy_array(x), hip.copy_array(y)), float(g["dot%d" % i]), rtol=RTOL)
+        np.testing.assert_allclose(hip.norm2(hip.copy_array(x)), float(g["nrm%d" % i]), rtol=RTOL)
+        m_d = hip.copy_array(x)
+        hip.max(0.5, m_d)
+        np.testing.assert_array_equal(m_d.to_host(), g["max%d_out" % i])
+
+
+@pytest.mark.parametrize("n,alpha,beta", itertools.product(
+    [1, 2, 3, 10, 23, 129, 144, 100003], [-2.1, 0.0, 1.0, 1.2 + 3j], [0.0, 0.5, 1.0, 1.5 - 1j]))
+def test_blas_axpby_scale_grid(hip, n, alpha, beta):
+    x, y = rand64c(n, seed=n), rand64c(n, seed=n + 1)
+    y_d = hip.copy_array(y)
+    hip.axpby(beta, y_d, alpha, hip.copy_array(x))
+    exp = (np.complex64(beta) * y + np.complex64(alpha) * x).astype(C64)
+    np.testing.assert_allclose(y_d.to_host(), exp, atol=2e-6)
+    x_d = hip.copy_array(x)
+    hip.scale(x_d, alpha)
+    np.testing.assert_allclose(x_d.to_host(), np.complex64(alpha) * x, atol=2e-6)
+
+
+def test_blas_unaligned_views_and_beta0_ignores_nan(hip):
+    n = 1001
+    x, y = rand64c(n, seed=1), rand64c(n, seed=2)
+    x_d, y_d = hip.copy_array(x), hip.copy_array(y)
+    hip.axpby(0.5, y_d[1:], 2.0, x_d[:-1])        # 8-byte aligned, not 16
+    exp = y.copy()
+    exp[1:] = 0.5 * y[1:] + 2.0 * x[:-1]
+    np.testing.assert_allclose(y_d.to_host(), exp, atol=2e-6)
+    bad = hip.copy_array(np.full(n, np.nan + 1j * np.nan, dtype=C64))
+    hip.axpby(0, bad, 1.5, x_d)                    # BLAS rule: beta == 0 never reads y
+    np.testing.assert_allclose(bad.to_host(), 1.5 * x, atol=2e-6)
+
+
+@pytest.mark.parametrize("n", [1, 10, 23, 129, 144, 1 << 20, 3000001])
+def test_blas_dot_nrm2(hip, n):
+    x, y = rand64c(n, seed=n), rand64c(n, seed=n + 7)
+    x_d, y_d = hip.copy_array(x), hip.copy_array(y)
+    exp = np.vdot(x.astype(np.complex128), y.astype(np.complex128))
+    np.testing.assert_allclose(hip.dot(x_d, y_d), exp.real, rtol=RTOL)
+    np.testing.assert_allclose(hip.cdot(x_d, y_d), exp, rtol=RTOL)
+    np.testing.assert_allclose(hip.norm2(x_d), np.linalg.norm(x.astype(np.complex128)) ** 2, rtol=RTOL)
+
+
+@pytest.mark.parametrize("val,N", itertools.product([-1.5, 0, 0.5, 1.5], [4, 5, 6, 1025]))
+def test_max(hip, val, N):
+    arr = rand64c(N, seed=N)
+    d = hip.copy_array(arr)
+    hip.max(val, d)
+    act = d.to_host()
+    np.testing.assert_array_equal(act.real, np.maximum(arr.real, np.float32(val)))
+    np.testing.assert_array_equal(act.imag, np.maximum(arr.imag, np.float32(val)))
+
+
+# ---------------------------------------------------------------------------------------
+# SpMM
+# ---------------------------------------------------------------------------------------
+def test_csrmm_golden(hip):
+    g = golden("leaf_csrmm")
+    for policy in ("transpose", "atomic"):
+        hip.adjoint_policy = policy
+        for i in range(int(g["count"])):
+            p = "c%d_" % i
+            A = csr_from(g, p)
+            alpha, beta = g[p + "ab"]
+            A_d = hip.csr_matrix(hip, A)
+            assert A_d._exwrite == bool(g[p + "inspect"][2])
+            assert abs(A_d._row_frac - g[p + "inspect"][0]) < 1e-12
+            assert abs(A_d._col_frac - g[p + "inspect"][1]) < 1e-12
+            y_d = hip.copy_array(g[p + "y"])
+            A_d.forward(y_d, hip.copy_array(g[p + "x"]), alpha=alpha, beta=beta)
+            assert rel_err(y_d.to_host(), g[p + "fwd"]) < RTOL, (policy, i)
+            ya_d = hip.copy_array(g[p + "ya"])
+            A_d.adjoint(ya_d, hip.copy_array(g[p + "xa"]), alpha=alpha, beta=beta)
+            assert rel_err(ya_d.to_host(), g[p + "adj"]) < RTOL, (policy, i)
+    hip.adjoint_policy = "transpose"
+
+
+@pytest.mark.parametrize("M,K,n,density", itertools.product([23, 45], [45, 23], [1, 2, 3, 8, 9, 17, 64, 65, 130], [0.01, 0.1, 0.5, 1.0]))
+def test_csr_matrix_vs_scipy(hip, M, K, n, density):
+    """reference test_backends.py:183-210 / test_operators.py:12-52 on a wider column grid"""
+    A = randM(M, K, density, seed=M * 1000 + K * 10 + n)
+    A_d = hip.csr_matrix(hip, A)
+    x = rand64c(K, n, seed=1)
+    y_d = hip.zero_array((M, n), C64)
+    A_d.forward(y_d, hip.copy_array(x))
+    np.testing.assert_allclose(y_d.to_host(), A @ x, rtol=RTOL, atol=1e-5)
+    xa = rand64c(M, n, seed=2)
+    for policy in ("transpose", "atomic"):
+        hip.adjoint_policy = policy
+        ya_d = hip.zero_array((K, n), C64)
+        A_d.adjoint(ya_d, hip.copy_array(xa))
+        np.testing.assert_allclose(ya_d.to_host(), A.conj().T @ xa, rtol=RTOL, atol=1e-5)
+    hip.adjoint_policy = "transpose"
+
+
+@pytest.mark.parametrize("M,n,K,alpha,beta", itertools.product([23, 45], [1, 8, 17], [18, 19], [0.0, 0.5, 1.5], [0.0, 1.0, 1.5]))
+def test_exwrite_csr_matrix(hip, M, n, K, alpha, beta):
+    """at most one nonzero per column (reference test_backends.py:213-243)"""
+    rng = np.random.default_rng(M * 100 + K)
+    counts = rng.integers(0, 2, K)
+    ptr = np.concatenate([[0], np.cumsum(counts)])
+    cols = rng.integers(0, M, counts.sum())
+    A = spp.csr_matrix((rand64c(int(counts.sum()), seed=5), cols, ptr), shape=(K, M)).T.tocsr()
+    A_d = hip.csr_matrix(hip, A)
+    assert A_d._exwrite
+    x, y = rand64c(K, n, seed=1), rand64c(M, n, seed=2)
+    y_d = hip.copy_array(y)
+    A_d.forward(y_d, hip.copy_array(x), alpha=alpha, beta=beta)
+    np.testing.assert_allclose(y_d.to_host(), beta * y + alpha * (A @ x), atol=1e-5)
+    x, y = rand64c(M, n, seed=3), rand64c(K, n, seed=4)
+    y_d = hip.copy_array(y)
+    A_d.adjoint(y_d, hip.copy_array(x), alpha=alpha, beta=beta)
+    np.testing.assert_allclose(y_d.to_host(), beta * y + alpha * (A.conj().T @ x), atol=1e-5)
+
+
+def test_csrmm_strided_panels_and_complex_scalars(hip):
+    """X and Y are row-slices of wider panels: leading dimension > rows"""
+    M, K, n = 37, 29, 5
+    A = randM(M, K, 0.3, seed=11)
+    A_d = hip.csr_matrix(hip, A)
+    Xbig, Ybig = rand64c(K + 6, n, seed=12), rand64c(M + 9, n, seed=13)
+    Xd, Yd = hip.copy_array(Xbig), hip.copy_array(Ybig)
+    alpha, beta = 0.7 - 0.2j, -0.3 + 0.4j
+    A_d.forward(Yd[4:4 + M, :], Xd[2:2 + K, :], alpha=alpha, beta=beta)
+    exp = Ybig.copy()
+    exp[4:4 + M] = beta * Ybig[4:4 + M] + alpha * (A @ Xbig[2:2 + K])
+    np.testing.assert_allclose(Yd.to_host(), exp, atol=1e-5)
+    for policy in ("transpose", "atomic"):
+        hip.adjoint_policy = policy
+        Xd, Yd = hip.copy_array(Ybig), hip.copy_array(Xbig)
+        A_d.adjoint(Yd[2:2 + K, :], Xd[4:4 + M, :], alpha=alpha, beta=beta)
+        exp = Xbig.copy()
+        exp[2:2 + K] = beta * Xbig[2:2 + K] + alpha * (A.conj().T @ Ybig[4:4 + M])
+        np.testing.assert_allclose(Yd.to_host(), exp, atol=1e-5)
+    hip.adjoint_policy = "transpose"
+
+
+def test_csrmm_edge_cases(hip):
+    # empty matrix: y = beta*y, and beta == 0 must overwrite NaNs
+    A = spp.csr_matrix((40, 30), dtype=C64)
+    A_d = hip.csr_matrix(hip, A)
+    y = rand64c(40, 3, seed=1)
+    y_d = hip.copy_array(y)
+    A_d.forward(y_d, hip.copy_array(rand64c(30, 3, seed=2)), alpha=1, beta=0.5)
+    np.testing.assert_allclose(y_d.to_host(), 0.5 * y, atol=1e-6)
+    nan_d = hip.copy_array(np.full((40, 3), np.nan, dtype=C64, order='F'))
+    A_d.forward(nan_d, hip.copy_array(rand64c(30, 3, seed=2)))
+    assert not nan_d.to_host().any()
+    nan_d = hip.copy_array(np.full((30, 3), np.nan, dtype=C64, order='F'))
+    A_d.adjoint(nan_d, hip.copy_array(rand64c(40, 3, seed=2)))
+    assert not nan_d.to_host().any()
+    # ragged rows: one dense row, many empty ones, a long tail
+    rng = np.random.default_rng(3)
+    rows = np.concatenate([np.zeros(500, int), rng.integers(0, 200, 300)])
+    cols = np.concatenate([rng.permutation(700)[:500], rng.integers(0, 700, 300)])
+    A = spp.coo_matrix((rand64c(800, seed=4), (rows, cols)), shape=(200, 700)).tocsr()
+    A_d = hip.csr_matrix(hip, A)
+    for n in (1, 8, 64):
+        x = rand64c(700, n, seed=5)
+        y_d = hip.zero_array((200, n), C64)
+        A_d.forward(y_d, hip.copy_array(x))
+        np.testing.assert_allclose(y_d.to_host(), A @ x, rtol=RTOL, atol=1e-4)
+        xa = rand64c(200, n, seed=6)
+        ya_d = hip.zero_array((700, n), C64)
+        A_d.adjoint(ya_d, hip.copy_array(xa))
+        np.testing.assert_allclose(ya_d.to_host(), A.conj().T @ xa, rtol=RTOL, atol=1e-4)
+
+
+def test_csrmm_config1_spmm_example(hip, oracle_backend):
+    """BASELINE config 1 (examples/spmm.py scaled up): 1e4 x 1e4, 1 % nnz, 8 RHS, vs the numpy oracle"""
+    rng = np.random.default_rng(1)
+    A = spp.random(10000, 10000, density=0.01, format='csr', random_state=rng, dtype=np.float32).astype(C64)
+    x = rand64c(10000, 8, seed=1)
+    S_h, S_o = hip.SpMatrix(A), oracle_backend.SpMatrix(A)
+    y_h = S_h * x
+    y_o = S_o * x
+    assert rel_err(y_h, y_o) < RTOL
+    z_h = S_h.H * x
+    z_o = S_o.H * x
+    assert rel_err(z_h, z_o) < RTOL
+
+
+# ---------------------------------------------------------------------------------------
+# FFT
+# ---------------------------------------------------------------------------------------
+def test_fft_golden(hip):
+    g = golden("leaf_fft")
+    for i in range(int(g["count"])):
+        x = g["f%d_x" % i]
+        y_d = hip.zero_array(x.shape, C64)
+        hip.fftn(y_d, hip.copy_array(x))
+        assert rel_err(y_d.to_host(), g["f%d_fwd" % i]) < RTOL, (i, x.shape, hip.fft_describe(x.shape))
+        hip.ifftn(y_d, hip.copy_array(x))
+        assert rel_err(y_d.to_host(), g["f%d_inv" % i]) < RTOL, (i, x.shape, hip.fft_describe(x.shape))
+
+
+def _check_fft(hip, shape, batch, seed=0):
+    x = rand64c(*(shape + (batch,)), seed=seed)
+    axes = tuple(range(len(shape)))
+    x_d = hip.copy_array(x)
+    y_d = hip.zero_array(x.shape, C64)
+    hip.fftn(y_d, x_d)
+    w = y_d.to_host()
+    assert rel_err(w, np.fft.fftn(x.astype(np.complex128), axes=axes)) < RTOL, hip.fft_describe(x.shape)
+    np.testing.assert_equal(x_d.to_host(), x)                 # out of place leaves the input alone
+    z_d = hip.zero_array(x.shape, C64)
+    hip.ifftn(z_d, y_d)
+    n = np.prod(shape)
+    assert rel_err(z_d.to_host() / n, x) < RTOL               # unnormalised round trip = n * identity
+    hip.ifftn(y_d, y_d)                                       # in place
+    assert rel_err(y_d.to_host() / n, x) < RTOL
+
+
+@pytest.mark.parametrize("batch,x,y,z", itertools.product([1, 2, 8], [23, 24, 25], [23, 25], [24, 25]))
+def test_fft_3d_small_sizes(hip, batch, x, y, z):
+    """reference test_backends.py:153-180 sizes incl. primes"""
+    _check_fft(hip, (z, y, x), batch, seed=x * y * z)
+
+
+@pytest.mark.parametrize("shape", [(2,), (4,), (8,), (64,), (512,), (1024,), (4096,), (8192,), (6,), (12,), (30,),
+                                   (210,), (320,), (35,), (49,), (97,), (121,), (1009,), (2 * 1009,),
+                                   (32, 32), (64, 48), (320, 20), (100, 101), (128, 128), (512, 6),
+                                   (16, 16, 16), (32, 8, 64), (20, 30, 12), (64, 64, 64), (40, 48, 56), (1, 1, 8), (8, 1, 1)])
+def test_fft_shapes(hip, shape):
+    _check_fft(hip, tuple(shape), 3, seed=sum(shape))
+
+
+def test_fft_generic_path_matches_lds_path(hip, monkeypatch):
+    """the global-memory fallback and the LDS kernels compute the same transform"""
+    from indigo_amd.backends import get_backend
+    x = rand64c(24, 20, 16, 2, seed=9)
+    y_d = hip.zero_array(x.shape, C64)
+    hip.fftn(y_d, hip.copy_array(x))
+    monkeypatch.setenv("INDIGO_HIP_FFT_GENERIC", "1")
+    other = get_backend("hip")
+    assert "generic" in other.fft_describe(x.shape)
+    z_d = other.zero_array(x.shape, C64)
+    other.fftn(z_d, other.copy_array(x))
+    assert rel_err(z_d.to_host(), y_d.to_host()) < 1e-6
+
+
+def test_fft_config2_shape_properties(hip):
+    """BASELINE config 2 shape (256^3, reduced batch): Parseval + round trip + impulse response"""
+    n, batch = 256, 2
+    x = rand64c(n, n, n, batch, seed=2)
+    x_d = hip.copy_array(x)
+    y_d = hip.zero_array(x.shape, C64)
+    hip.fftn(y_d, x_d)
+    e_in, e_out = hip.norm2(x_d), hip.norm2(y_d)
+    np.testing.assert_allclose(e_out, e_in * n ** 3, rtol=1e-5)           # Parseval, unnormalised
+    dc = y_d.reshape((x.size,))[0:1].to_host()[0]
+    np.testing.assert_allclose(dc, x[..., 0].astype(np.complex128).sum(), rtol=1e-4)    # DC bin of volume 0
+    hip.ifftn(y_d, y_d)
+    hip.axpby(1.0 / n ** 3, y_d, -1.0, x_d)
+    assert np.sqrt(hip.norm2(y_d) / e_in) < RTOL
+    # impulse at (1, 2, 3) -> separable complex exponential
+    imp = np.zeros((n, n, n, 1), dtype=C64, order='F')
+    imp[1, 2, 3, 0] = 1
+    y1 = hip.zero_array(imp.shape, C64)
+    hip.fftn(y1, hip.copy_array(imp))
+    k = np.arange(n)
+    e = lambda s: np.exp(-2j * np.pi * s * k / n)
+    exp = e(1)[:, None, None] * e(2)[None, :, None] * e(3)[None, None, :]
+    assert rel_err(y1.to_host()[..., 0], exp) < RTOL

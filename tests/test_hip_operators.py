@@ -1,0 +1,186 @@
+"""GPU parity tests for composed operator trees and the SENSE path on HipBackend.
+
+Golden vectors from the reference (tests/golden), the numpy oracle on identical
+seeded inputs, and size-independent properties (adjointness, linearity,
+normal-operator symmetry) at sizes the oracle cannot finish quickly.
+"""
+import itertools
+
+import numpy as np
+import pytest
+import scipy.sparse as spp
+
+from conftest import csr_from, golden, rel_err
+from indigo_amd.sense import SenseProblem, normal_operator
+from indigo_amd.transforms import reserve_for
+from indigo_amd.util import rand64c, randM, Trace
+
+pytestmark = pytest.mark.gpu
+C64 = np.dtype('complex64')
+RTOL = 1e-5
+
+
+def _eval(op, backend, y0, x, **kw):
+    y_d = backend.copy_array(y0)
+    op.eval(y_d, backend.copy_array(x), **kw)
+    return y_d.to_host()
+
+
+def test_composites_golden(hip):
+    B, g = hip, golden("composites")
+    B._scratch = None
+    P = B.SpMatrix(csr_from(g, "prod_A0_"), name='A0') * B.SpMatrix(csr_from(g, "prod_A1_"), name='A1')
+    assert rel_err(_eval(P, B, g["prod_y"], g["prod_x"], alpha=0.5, beta=1.0), g["prod_fwd"]) < RTOL
+    assert rel_err(_eval(P.H, B, g["prod_ya"], g["prod_xa"], alpha=0.5, beta=1.0), g["prod_adj"]) < RTOL
+    Kn = B.KronI(6, B.KronI(4, B.SpMatrix(csr_from(g, "kron_A_"))))
+    assert rel_err(_eval(Kn, B, g["kron_v"], g["kron_u"]), g["kron_fwd"]) < RTOL
+    assert rel_err(_eval(Kn.H, B, g["kron_u"], g["kron_v"]), g["kron_adj"]) < RTOL
+    mats = [csr_from(g, "stack_A%d_" % j) for j in range(3)]
+    V = B.VStack([B.SpMatrix(m) for m in mats])
+    assert rel_err(_eval(V, B, g["vs_y"], g["vs_x"], alpha=0.5, beta=0.5), g["vs_fwd"]) < RTOL
+    assert rel_err(_eval(V.H, B, g["vs_ya"], g["vs_xa"], alpha=0.5, beta=0.5), g["vs_adj"]) < RTOL
+    D = B.BlockDiag([B.SpMatrix(m) for m in mats])
+    assert rel_err(_eval(D, B, g["bd_y"], g["bd_x"], alpha=1.0, beta=0.5), g["bd_fwd"]) < RTOL
+    assert rel_err(_eval(D.H, B, g["bd_ya"], g["bd_xa"], alpha=1.0, beta=0.5), g["bd_adj"]) < RTOL
+    Sm = (2 - 1j) * B.SpMatrix(csr_from(g, "sum_S0_")) + B.SpMatrix(csr_from(g, "sum_S1_")) - 0.5 * B.Eye(6)
+    z = np.zeros_like(g["sum_x"], order='F')
+    assert rel_err(_eval(Sm, B, z, g["sum_x"]), g["sum_fwd"]) < RTOL
+    assert rel_err(_eval(Sm.H, B, z, g["sum_x"]), g["sum_adj"]) < RTOL
+    Fc = B.FFTc(tuple(int(s) for s in g["fftc_shape"]), dtype=C64)
+    z = np.zeros_like(g["fftc_x"], order='F')
+    assert rel_err(_eval(Fc, B, z, g["fftc_x"]), g["fftc_fwd"]) < RTOL
+    assert rel_err(_eval(Fc.H, B, z, g["fftc_x"]), g["fftc_adj"]) < RTOL
+
+
+@pytest.mark.parametrize("L,M,N,K,density,alpha,beta", itertools.product([3], [5, 6], [7], [1, 8, 17], [0.1, 1], [0, .5, 1], [0, .5, 1]))
+def test_product_grid(hip, L, M, N, K, density, alpha, beta):
+    """reference test_operators.py:55-84"""
+    hip._scratch = None
+    A0, A1 = randM(L, M, density, seed=1), randM(M, N, density, seed=2)
+    A = hip.SpMatrix(A0, name='A0') * hip.SpMatrix(A1, name='A1')
+    x, y = rand64c(N, K, seed=3), rand64c(L, K, seed=4)
+    np.testing.assert_allclose(_eval(A, hip, y, x, alpha=alpha, beta=beta), beta * y + alpha * (A0 @ (A1 @ x)), rtol=RTOL, atol=1e-5)
+    x, y = rand64c(L, K, seed=5), rand64c(N, K, seed=6)
+    np.testing.assert_allclose(_eval(A.H, hip, y, x, alpha=alpha, beta=beta),
+                               beta * y + alpha * (A1.conj().T @ (A0.conj().T @ x)), rtol=RTOL, atol=1e-5)
+    assert A.shape == (L, N) and A.H.shape == (N, L) and A.dtype == C64
+
+
+@pytest.mark.parametrize("stack,K,alpha,beta", itertools.product([1, 2, 3], [1, 4, 9], [0.5, 1], [0, 1, 0.5]))
+def test_vstack_blockdiag_kroni_grid(hip, stack, K, alpha, beta):
+    """reference test_operators.py:87-116, 151-224"""
+    hip._scratch = None
+    M, N = 5, 7
+    mats = [randM(M, N, 0.5, seed=10 + j) for j in range(stack)]
+    V, Vh = hip.VStack([hip.SpMatrix(m) for m in mats]), spp.vstack(mats)
+    x, y = rand64c(N, K, seed=1), rand64c(M * stack, K, seed=2)
+    np.testing.assert_allclose(_eval(V, hip, y, x, alpha=alpha, beta=beta), beta * y + alpha * (Vh @ x), rtol=RTOL, atol=1e-5)
+    np.testing.assert_allclose(_eval(V.H, hip, x, y, alpha=alpha, beta=beta), beta * x + alpha * (Vh.conj().T @ y), rtol=RTOL, atol=1e-5)
+    D, Dh = hip.BlockDiag([hip.SpMatrix(m) for m in mats]), spp.block_diag(mats)
+    x, y = rand64c(N * stack, K, seed=3), rand64c(M * stack, K, seed=4)
+    np.testing.assert_allclose(_eval(D, hip, y, x, alpha=alpha, beta=beta), beta * y + alpha * (Dh @ x), rtol=RTOL, atol=1e-5)
+    np.testing.assert_allclose(_eval(D.H, hip, x, y, alpha=alpha, beta=beta), beta * x + alpha * (Dh.conj().T @ y), rtol=RTOL, atol=1e-5)
+    Kr, Kh = hip.KronI(stack + 1, hip.SpMatrix(mats[0])), spp.kron(spp.eye(stack + 1), mats[0])
+    x, y = rand64c(Kr.shape[1], K, seed=5), rand64c(Kr.shape[0], K, seed=6)
+    np.testing.assert_allclose(_eval(Kr, hip, y, x, alpha=alpha, beta=beta), beta * y + alpha * (Kh @ x), rtol=RTOL, atol=1e-5)
+    np.testing.assert_allclose(_eval(Kr.H, hip, x, y, alpha=alpha, beta=beta), beta * x + alpha * (Kh.conj().T @ y), rtol=RTOL, atol=1e-5)
+
+
+@pytest.mark.parametrize("shape,B", itertools.product([(22, 23, 24), (24, 22), (23,)], [1, 3]))
+def test_unscaled_and_centered_fft_operators(hip, shape, B):
+    """reference test_operators.py:227-367"""
+    hip._scratch = None
+    n = int(np.prod(shape))
+    ax = tuple(range(len(shape)))
+    x = rand64c(n, B, seed=n)
+    xh = x.reshape(shape + (B,), order='F')
+    F = hip.UnscaledFFT(shape, dtype=C64)
+    z = np.zeros_like(x, order='F')
+    assert rel_err(_eval(F, hip, z, x).reshape(xh.shape, order='F'), np.fft.fftn(xh, axes=ax)) < RTOL
+    assert rel_err(_eval(F.H, hip, z, x).reshape(xh.shape, order='F'), np.fft.ifftn(xh, axes=ax) * n) < RTOL
+    U = hip.FFT(shape, dtype=C64)
+    back = _eval(U.H, hip, z, _eval(U, hip, z, x))
+    assert rel_err(back, x) < RTOL                                    # unitary
+    Fc = hip.FFTc(shape, dtype=C64)
+    from numpy.fft import fftshift, ifftshift, fftn, ifftn
+    assert rel_err(_eval(Fc, hip, z, x).reshape(xh.shape, order='F'),
+                   fftshift(fftn(ifftshift(xh, axes=ax), axes=ax, norm='ortho'), axes=ax)) < 1e-4
+    assert rel_err(_eval(Fc.H, hip, z, x).reshape(xh.shape, order='F'),
+                   fftshift(ifftn(ifftshift(xh, axes=ax), axes=ax, norm='ortho'), axes=ax)) < 1e-4
+    with pytest.raises(AssertionError):
+        F.eval(hip.copy_array(z), hip.copy_array(x), alpha=2)
+
+
+def test_zpad_and_interp_operators(hip):
+    """reference test_operators.py:370-432"""
+    hip._scratch = None
+    N, M, batch = (3, 4, 3), (5, 6, 7), 2
+    u = rand64c(*N, batch, seed=1)
+    Z = hip.Zpad(M, N, dtype=C64)
+    v = _eval(Z, hip, np.zeros((int(np.prod(M)), batch), C64, order='F'), u.reshape(-1, batch, order='F')).reshape(M + (batch,), order='F')
+    assert np.count_nonzero(v) == u.size
+    np.testing.assert_array_equal(v[1:4, 1:5, 2:5, :], u)
+    back = _eval(Z.H, hip, np.zeros((u.size // batch, batch), C64, order='F'), v.reshape(-1, batch, order='F'))
+    np.testing.assert_array_equal(back.reshape(u.shape, order='F'), u)
+    rng = np.random.default_rng(2)
+    coord = rng.random((3, 6, 8)) - 0.5
+    G = hip.Interp(M, coord, 3, rng.random(128), dtype=C64)
+    a, b = rand64c(G.shape[1], batch, seed=3), rand64c(G.shape[0], batch, seed=4)
+    Ga = _eval(G, hip, np.zeros_like(b, order='F'), a)
+    GHb = _eval(G.H, hip, np.zeros_like(a, order='F'), b)
+    np.testing.assert_allclose(np.vdot(b, Ga), np.vdot(GHb, a), rtol=1e-4)
+
+
+@pytest.mark.parametrize("level", [0, 3, "fused"])
+def test_sense_golden(hip, level):
+    g = golden("sense")
+    C, width, ntab, osf, ro, tr = g["params"]
+    p = SenseProblem(tuple(int(n) for n in g["N"]), g["coord"], np.asfortranarray(g["maps"]),
+                     width=int(width), ntable=int(ntab), oversamp=float(osf))
+    hip._scratch = None
+    A = p.build_fused(hip) if level == "fused" else p.build_tree(hip, level=level)
+    x, k = g["sense_x"], g["sense_k"]
+    assert rel_err(A * x, g["sense_Ax"]) < RTOL
+    assert rel_err(A.H * k, g["sense_AHk"]) < RTOL
+    AHA = normal_operator(A, lamda=float(g["lamda"]))
+    y_d = hip.zero_array((A.shape[1], 1), C64)
+    AHA.eval(y_d, hip.copy_array(x))
+    assert rel_err(y_d.to_host(), g["sense_AHAx"]) < RTOL
+    # CG iterates (reference backend.py:639-689)
+    hip._scratch = None
+    AHA = A.H * A + float(g["lamda"]) * hip.Eye(A.shape[1])
+    for it in (1, 3):
+        x0 = np.zeros((A.shape[1], 1), dtype=C64, order='F')
+        hist = hip.cg(AHA, g["cg_b"].copy(order='F'), x0, maxiter=it)
+        assert rel_err(x0, g["cg_it%d" % it]) < 1e-4 and len(hist) == it
+    hip._scratch = None
+
+
+def test_sense_medium_vs_oracle_and_properties(hip, oracle_backend):
+    """64^3 image, 4 coils, grid 128^3 (pow-2 LDS FFT path), ~1e5 samples: oracle parity + adjointness + linearity"""
+    p = SenseProblem.synthetic((64, 64, 64), 4, nspokes=400, nreadout=128, width=2, oversamp=2.0, seed=4)
+    hip._scratch = None
+    oracle_backend._scratch = None
+    A = p.build_fused(hip)
+    Ao = p.build_fused(oracle_backend)
+    assert "lds" in hip.fft_describe(p.oN + (p.C,))
+    x = rand64c(A.shape[1], 1, seed=1)
+    k = rand64c(A.shape[0], 1, seed=2)
+    Ax, AHk = A * x, A.H * k
+    assert rel_err(Ax, Ao * x) < RTOL
+    assert rel_err(AHk, Ao.H * k) < RTOL
+    np.testing.assert_allclose(np.vdot(k, Ax), np.vdot(AHk, x), rtol=1e-4)          # <Ax,k> = <x,A^H k>
+    x2 = rand64c(A.shape[1], 1, seed=3)
+    assert rel_err(A * (x + (2 - 1j) * x2).astype(C64), Ax + (2 - 1j) * (A * x2)) < RTOL   # linearity
+    AHA = normal_operator(A)
+    tr = Trace()
+    hip.trace = tr
+    y_d = hip.zero_array((A.shape[1], 1), C64)
+    AHA.eval(y_d, hip.copy_array(x))
+    hip.trace = None
+    assert rel_err(y_d.to_host(), A.H * Ax) < RTOL
+    ev = tr.by_event()
+    assert ev['csrmm']['calls'] == 4 and ev['fft']['calls'] == 2       # S', G', G'^H, S'^H + FFT, IFFT
+    x_d = hip.copy_array(x)
+    assert hip.cdot(x_d, y_d).real > 0 and abs(hip.cdot(x_d, y_d).imag) < 1e-3 * hip.cdot(x_d, y_d).real  # x^H AHA x real > 0
+    hip._scratch = None
