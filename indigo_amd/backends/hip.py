@@ -211,7 +211,8 @@ class HipBackend(Backend):
                     offset += start[d] * stride
                     stride *= self.shape[d]
             ptr = self._arr + offset * self.itemsize
-            return self._view(tuple(shape), self._leading_dim, ptr)
+            ld = shape[0] if self.ndim == 1 else self._leading_dim
+            return self._view(tuple(shape), ld, ptr)
 
     # -- BLAS-1 ---------------------------------------------------------------------------
     def _flat(self, a):

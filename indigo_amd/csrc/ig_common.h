@@ -26,6 +26,9 @@ struct ig_ctx {
     // small device/pinned scratch used by the reductions (dot, nrm2)
     double*      d_partials  = nullptr;   // (IG_MAX_RED_BLOCKS + 1) * 2 doubles
     double*      h_result    = nullptr;   // pinned, 2 doubles
+    void*        d_xpack     = nullptr;   // SpMM repacked-panel scratch (grown on demand)
+    size_t       xpack_bytes = 0;
+    int32_t*     d_worklist  = nullptr;   // SpMM deferred-row lists + counters (allocated on first use)
     // profile mode (ig_prof_enable): every kernel launch is bracketed by two events
     bool                     prof_on = false;
     std::vector<ig_prof_rec> prof;

@@ -140,6 +140,127 @@ __device__ __forceinline__ void lds_stage(float2* __restrict__ lds, const float2
     __syncthreads();
 }
 
+// ---- register-resident DFTs of 16 and 32 points --------------------------------
+// cos(2 pi j / 32); compile-time foldable so that unrolled code carries literals
+__host__ __device__ constexpr float cos32(int j) {
+    j &= 31;
+    if (j > 16) j = 32 - j;
+    const float T[9] = {1.0f, 0.980785251f, 0.923879504f, 0.831469595f, 0.707106769f,
+                        0.555570245f, 0.382683426f, 0.195090324f, 0.0f};
+    return j <= 8 ? T[j] : -T[16 - j];
+}
+// a * exp(-2 pi i j / 32), trivial rotations without multiplies (j is a constant after unrolling)
+__device__ __forceinline__ float2 mul_w32(float2 a, int j) {
+    j &= 31;
+    if (j == 0) return a;
+    if (j == 8) return make_float2(a.y, -a.x);
+    if (j == 16) return make_float2(-a.x, -a.y);
+    if (j == 24) return make_float2(-a.y, a.x);
+    const float c = cos32(j), s = -cos32(j + 24);      // w = c + i s, s = -sin(2 pi j/32)
+    return make_float2(fmaf(a.x, c, -a.y * s), fmaf(a.x, s, a.y * c));
+}
+
+template <int N> struct RegFFT;       // in-place forward DFT of N register values, natural order out
+template <> struct RegFFT<4> {
+    __device__ static __forceinline__ void run(float2 (&x)[4]) { bfly4(x[0], x[1], x[2], x[3]); }
+};
+template <> struct RegFFT<8> {
+    __device__ static __forceinline__ void run(float2 (&x)[8]) { Bfly<8>::run(x, nullptr, 0); }
+};
+template <int N> struct RegFFT {      // N = 16, 32: radix-4 decimation in frequency over N/4-point DFTs
+    __device__ static __forceinline__ void run(float2 (&x)[N]) {
+        constexpr int M = N / 4;
+        float2 z[4][M];
+#pragma unroll
+        for (int r = 0; r < M; ++r) {
+            bfly4(x[r], x[r + M], x[r + 2 * M], x[r + 3 * M]);
+            z[0][r] = x[r];
+#pragma unroll
+            for (int q = 1; q < 4; ++q) z[q][r] = mul_w32(x[r + q * M], r * q * (32 / N));
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) RegFFT<M>::run(z[q]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int k = 0; k < M; ++k) x[4 * k + q] = z[q][k];
+    }
+};
+
+// Two-stage kernel for n = R1*R2 (256 = 16x16, 512 = 32x16): the whole column lives in registers
+// twice -- stage 1 reads its R1 inputs straight from global memory, stage 2 writes its R2 outputs
+// straight back -- with ONE LDS exchange in between (Stockham index map, inter-stage twiddles applied
+// on the way into LDS).  A workgroup = W columns x T threads; lanes run along the direction that is
+// contiguous in memory (columns for strided axes, elements for axis 0), so every wave access is a
+// set of 128-byte segments and every LDS access is conflict-free at the minimum cycle count
+// (axis 0 uses a 16-element XOR swizzle of the line).
+template <int R1, int R2, int T, int W, bool AXIS0>
+__global__ void __launch_bounds__(W * T)
+k_fft_2stage(const float2* __restrict__ x, float2* __restrict__ y, const float2* __restrict__ tw,
+             int64_t inner, int64_t ncols, int inverse) {
+    constexpr int n = R1 * R2, B1 = R2 / T, B2 = R1 / T, NT = W * T;
+    static_assert(R2 % T == 0 && R1 % T == 0 && T == 16, "lane groups of 16");
+    extern __shared__ float2 lds[];
+    float2* __restrict__ tws = lds + n * W;
+    const int tid = threadIdx.x;
+    for (int k = tid; k < n; k += NT) tws[k] = tw[k];
+
+    const int t = AXIS0 ? (tid % T) : (tid / W);
+    const int w = AXIS0 ? (tid / T) : (tid % W);
+    const int64_t col = (int64_t)blockIdx.x * W + w;
+    const bool valid = col < ncols;
+    int64_t colbase, sj;
+    if (AXIS0) { colbase = col * n; sj = 1; }
+    else { const int64_t o = col / inner; colbase = (col - o * inner) + inner * n * o; sj = inner; }
+    auto lidx = [&](int j) -> int {
+        if (AXIS0) return w * n + ((j & ~15) | ((j ^ (j / R1)) & 15));
+        return j * W + w;
+    };
+
+    // ---- stage 1: radix R1 on inputs b + k*R2, results (times w_n^{b k}) to LDS row b*R1 + k
+    float2 v[B1][R1];
+#pragma unroll
+    for (int q = 0; q < B1; ++q) {
+        const int b = t + q * T;
+        const float2* __restrict__ src = x + colbase + (int64_t)b * sj;
+#pragma unroll
+        for (int k = 0; k < R1; ++k) {
+            float2 a = valid ? src[(int64_t)(k * R2) * sj] : make_float2(0.f, 0.f);
+            if (inverse) a.y = -a.y;
+            v[q][k] = a;
+        }
+    }
+    __syncthreads();            // twiddle table visible (the global loads above are already in flight)
+#pragma unroll
+    for (int q = 0; q < B1; ++q) {
+        const int b = t + q * T;
+        RegFFT<R1>::run(v[q]);
+        lds[lidx(b * R1)] = v[q][0];
+#pragma unroll
+        for (int k = 1; k < R1; ++k) lds[lidx(b * R1 + k)] = cmul(v[q][k], tws[b * k]);
+    }
+    __syncthreads();
+
+    // ---- stage 2: radix R2 on rows b2 + k2*R1, outputs b2 + r*R1 straight to global memory
+#pragma unroll
+    for (int q = 0; q < B2; ++q) {
+        const int b2 = t + q * T;
+        float2 u[R2];
+#pragma unroll
+        for (int k2 = 0; k2 < R2; ++k2) u[k2] = lds[lidx(b2 + k2 * R1)];
+        RegFFT<R2>::run(u);
+        if (valid) {
+            float2* __restrict__ dst = y + colbase + (int64_t)b2 * sj;
+#pragma unroll
+            for (int r = 0; r < R2; ++r) {
+                float2 a = u[r];
+                if (inverse) a.y = -a.y;
+                dst[(int64_t)(r * R1) * sj] = a;
+            }
+        }
+    }
+}
+
 // AXIS0: inner == 1 (columns are contiguous lines of n elements).
 template <bool AXIS0>
 __global__ void __launch_bounds__(1024)
@@ -306,7 +427,21 @@ int plan_axis(ig_ctx* ctx, ig_fft* p, int a) {
     const bool force_generic = getenv("INDIGO_HIP_FFT_GENERIC") && getenv("INDIGO_HIP_FFT_GENERIC")[0] == '1';
     Radices rad{};
     int ns = 0;
-    bool lds_ok = !force_generic && ax.n <= LDS_NMAX && factor_lds(ax.n, rad, ns);
+    const char* e2 = getenv("INDIGO_HIP_FFT_2STAGE");
+    const bool two_stage = !force_generic && !(e2 && e2[0] == '0') && (ax.n == 512 || ax.n == 256);
+    if (two_stage) {
+        ax.kind = 3; ax.W = 16; ax.T = 16; ax.nstages = 2;
+        ax.rad.r[0] = ax.n == 512 ? 32 : 16; ax.rad.r[1] = 16;
+        ax.lds_bytes = ((size_t)ax.n * ax.W + ax.n) * 8;
+        const void* fns[4] = {
+            reinterpret_cast<const void*>(&k_fft_2stage<32, 16, 16, 16, true>),
+            reinterpret_cast<const void*>(&k_fft_2stage<32, 16, 16, 16, false>),
+            reinterpret_cast<const void*>(&k_fft_2stage<16, 16, 16, 16, true>),
+            reinterpret_cast<const void*>(&k_fft_2stage<16, 16, 16, 16, false>)};
+        for (const void* f : fns)
+            IG_HIP(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
+    }
+    bool lds_ok = !two_stage && !force_generic && ax.n <= LDS_NMAX && factor_lds(ax.n, rad, ns);
     if (lds_ok) {
         int T = 1;
         for (int s = 0; s < ns; ++s) {
@@ -334,7 +469,7 @@ int plan_axis(ig_ctx* ctx, ig_fft* p, int a) {
             }
         }
     }
-    if (!lds_ok) {
+    if (!lds_ok && !two_stage) {
         ax.kind = 1;
         factor_generic(ax.n, ax.gen_radices);
         ax.nstages = (int)ax.gen_radices.size();
@@ -382,9 +517,9 @@ int ig_fft_plan(ig_ctx* ctx, int rank, const int64_t* dims, int64_t batch, ig_ff
     for (int a = 0; a < rank; ++a) {
         const AxisPlan& ax = p->axis[a];
         if (ax.kind == 2) { snprintf(buf, sizeof(buf), "axis%d n=1 skip; ", a); p->desc += buf; continue; }
-        snprintf(buf, sizeof(buf), "axis%d n=%lld %s", a, (long long)ax.n, ax.kind == 0 ? "lds" : "generic");
+        snprintf(buf, sizeof(buf), "axis%d n=%lld %s", a, (long long)ax.n, ax.kind == 0 ? "lds" : ax.kind == 3 ? "2stage" : "generic");
         p->desc += buf;
-        if (ax.kind == 0) {
+        if (ax.kind == 0 || ax.kind == 3) {
             snprintf(buf, sizeof(buf), " W=%d T=%d lds=%zuB radices=", ax.W, ax.T, ax.lds_bytes);
             p->desc += buf;
             for (int s = 0; s < ax.nstages; ++s) { snprintf(buf, sizeof(buf), s ? "x%d" : "%d", ax.rad.r[s]); p->desc += buf; }
@@ -421,8 +556,22 @@ int ig_fft_exec(ig_fft* p, const void* xv, void* yv, int direction, void* worksp
     for (int a = 0; a < p->rank; ++a) {
         const AxisPlan& ax = p->axis[a];
         if (ax.kind == 2) continue;
-        if (ax.kind == 0) {
-            ig_prof_scope prof(ctx, ax.inner == 1 ? "fft_lds_axis0" : "fft_lds_strided", pass_bytes);
+        if (ax.kind == 3) {
+            ig_prof_scope prof(ctx, a == 0 ? "fft_2stage_axis0" : a == 1 ? "fft_2stage_axis1" : "fft_2stage_axis2", pass_bytes);
+            const int64_t ncols = ax.inner * ax.outer;
+            const int64_t blocks = (ncols + ax.W - 1) / ax.W;
+            IG_REQUIRE(ctx, blocks <= 0x7fffffffLL, "ig_fft_exec: too many tiles");
+            const dim3 grid((unsigned)blocks), block((unsigned)(ax.W * ax.T));
+#define IG_2S(R1_, AX0_)                                                                              \
+            hipLaunchKernelGGL((k_fft_2stage<R1_, 16, 16, 16, AX0_>), grid, block, ax.lds_bytes, ctx->stream, \
+                               cur, y, ax.d_tw, ax.inner, ncols, inverse)
+            if (ax.n == 512) { if (ax.inner == 1) IG_2S(32, true); else IG_2S(32, false); }
+            else             { if (ax.inner == 1) IG_2S(16, true); else IG_2S(16, false); }
+#undef IG_2S
+            IG_LAUNCH_CHECK(ctx, "k_fft_2stage");
+            cur = y;
+        } else if (ax.kind == 0) {
+            ig_prof_scope prof(ctx, a == 0 ? "fft_lds_axis0" : a == 1 ? "fft_lds_axis1" : "fft_lds_axis2", pass_bytes);
             const int64_t ncols = ax.inner * ax.outer;
             const int64_t blocks = (ncols + ax.W - 1) / ax.W;
             IG_REQUIRE(ctx, blocks <= 0x7fffffffLL, "ig_fft_exec: too many tiles");

@@ -42,15 +42,37 @@ __device__ __forceinline__ int64_t xcd_block(int64_t b, int64_t nb) {
     return (xcd < rem) ? xcd * (q + 1) + idx : rem * (q + 1) + (xcd - rem) * q + idx;
 }
 
+// ---- deferred rows ---------------------------------------------------------------
+// Gridding transposes have a few rows that are orders of magnitude longer than the
+// mean (the k-space centre).  The row-slot kernel therefore only computes rows of
+// at most `thr_mid` nonzeros inline; longer rows are appended to one of two device
+// work lists (one atomic per deferred row) and finished by
+//   k_csrmm_rows_wave   one wavefront per listed row   (thr_mid < nnz <= thr_long)
+//   k_csrmm_rows_block  one 1024-thread workgroup per listed row (nnz > thr_long)
+// both of which read the list length from device memory, so the host never syncs.
+// If a list is full the row is simply computed inline (slow, still correct).
+struct WorkLists {
+    int32_t*  rows[2];     // [0] wave-per-row list, [1] workgroup-per-row list
+    uint32_t* count;       // count[0], count[1]
+    uint32_t  cap;
+};
+
+template <bool CONJ>
+__device__ __forceinline__ void acc_nz(float2& acc, float2 v, float2 x) {
+    if (CONJ) acc = cadd(acc, cmulc(v, x));
+    else      cfma(acc, v, x);
+}
+
 // BMODE: 0 => beta == 0 (Y not read), 1 => general beta
 template <int CL, int NL, bool CONJ, int BMODE>
 __global__ void __launch_bounds__(BLK)
 k_csrmm_gather(int64_t M, int64_t N,
                const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
                const float2* __restrict__ vals,
-               const float2* __restrict__ X, int64_t ldx,
+               const float2* __restrict__ X, int64_t ldx, int64_t sxr,
                float2* __restrict__ Y, int64_t ldy,
-               float2 alpha, float2 beta, int xcd_remap) {
+               float2 alpha, float2 beta, int xcd_remap,
+               WorkLists wl, int32_t thr_mid, int32_t thr_long) {
     constexpr int RPW = 64 / (CL * NL);
     const int lane = threadIdx.x & 63;
     const int c = lane % CL;
@@ -64,6 +86,19 @@ k_csrmm_gather(int64_t M, int64_t N,
     int32_t p0 = 0, p1 = 0;
     if (row_ok) { p0 = rowptr[row]; p1 = rowptr[row + 1]; }
 
+    // defer long rows: the slot's first lane claims a list entry, the slot learns the outcome by shuffle
+    int deferred = 0;
+    const int32_t len = p1 - p0;
+    if (len > thr_mid) {
+        if (c == 0 && i == 0) {
+            const int which = len > thr_long ? 1 : 0;
+            const uint32_t idx = atomicAdd(&wl.count[which], 1u);
+            if (idx < wl.cap) { wl.rows[which][idx] = (int32_t)row; deferred = 1; }
+        }
+    }
+    deferred = __shfl(deferred, r * CL * NL, 64);
+    if (deferred) p1 = p0;          // nothing to do here, and no store below
+
     for (int64_t jb = 0; jb < N; jb += CL) {
         const int64_t j = jb + c;
         const bool col_ok = j < N;
@@ -74,27 +109,187 @@ k_csrmm_gather(int64_t M, int64_t N,
         for (; p + NL < p1; p += 2 * NL) {
             const int32_t k0 = colind[p], k1 = colind[p + NL];
             const float2 v0 = vals[p], v1 = vals[p + NL];
-            const float2 x0 = xcol[k0], x1 = xcol[k1];
-            if (CONJ) { acc = cadd(acc, cmulc(v0, x0)); acc = cadd(acc, cmulc(v1, x1)); }
-            else      { cfma(acc, v0, x0); cfma(acc, v1, x1); }
+            const float2 x0 = xcol[k0 * sxr], x1 = xcol[k1 * sxr];
+            acc_nz<CONJ>(acc, v0, x0);
+            acc_nz<CONJ>(acc, v1, x1);
         }
-        if (p < p1) {
-            const int32_t k0 = colind[p];
-            const float2 v0 = vals[p];
-            const float2 x0 = xcol[k0];
-            if (CONJ) acc = cadd(acc, cmulc(v0, x0));
-            else      cfma(acc, v0, x0);
-        }
+        if (p < p1) acc_nz<CONJ>(acc, vals[p], xcol[colind[p] * sxr]);
 #pragma unroll
         for (int off = CL * NL / 2; off >= CL; off >>= 1) {
             acc.x += __shfl_xor(acc.x, off, 64);
             acc.y += __shfl_xor(acc.y, off, 64);
         }
-        if (i == 0 && row_ok && col_ok) {
+        if (i == 0 && row_ok && col_ok && !deferred) {
             float2* yp = Y + j * ldy + row;
             float2 out = cmul(alpha, acc);
             if (BMODE == 1) cfma(out, beta, *yp);
             *yp = out;
+        }
+    }
+}
+
+// Row-per-lane variant for matrices whose rows are mostly empty or very short (mean <= 1 nonzero per
+// row, e.g. the transposed gridding matrix: 89 % empty rows).  A lane owns a row and keeps NC panel
+// columns in registers, so a wave covers 64 rows, every store instruction writes 512 contiguous bytes
+// of one panel column, and each nonzero issues NC independent gathers.  With one row per 8 lanes the
+// same matrix needs 8x more waves, each a short dependent chain: that version is latency bound.
+template <int NC, bool CONJ, int BMODE, bool PACKED>
+__global__ void __launch_bounds__(BLK)
+k_csrmm_rowlane(int64_t M, int64_t N,
+                const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
+                const float2* __restrict__ vals,
+                const float2* __restrict__ X, int64_t ldx,
+                float2* __restrict__ Y, int64_t ldy,
+                float2 alpha, float2 beta, int xcd_remap,
+                WorkLists wl, int32_t thr_mid, int32_t thr_long) {
+    const int64_t blk = xcd_remap ? xcd_block(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
+    const int64_t row = blk * BLK + threadIdx.x;
+    if (row >= M) return;
+    const int32_t p0 = rowptr[row];
+    int32_t p1 = rowptr[row + 1];
+    const int32_t len = p1 - p0;
+    if (len > thr_mid) {
+        const int which = len > thr_long ? 1 : 0;
+        const uint32_t idx = atomicAdd(&wl.count[which], 1u);
+        if (idx < wl.cap) { wl.rows[which][idx] = (int32_t)row; return; }
+    }
+    for (int64_t jb = 0; jb < N; jb += NC) {
+        float2 acc[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c] = make_float2(0.f, 0.f);
+        // one nonzero per trip.  (A four-wide predicated trip was measured slower here: 4.7 vs 4.2 ms on the
+        // 134M-row transposed gridding matrix -- the kernel is bound by per-lane address processing of the
+        // scattered panel-row loads, not by their latency.)
+        for (int32_t p = p0; p < p1; ++p) {
+            const int32_t k = colind[p];
+            const float2 v = vals[p];
+            if (PACKED && NC >= 2) {
+                // packed panel: the NC values of row k are contiguous (NC*8 bytes, 16-byte aligned)
+                const float4* __restrict__ q = reinterpret_cast<const float4*>(X + (int64_t)k * NC);
+                float4 t4[NC / 2 > 0 ? NC / 2 : 1];
+#pragma unroll
+                for (int h = 0; h < NC / 2; ++h) t4[h] = q[h];
+#pragma unroll
+                for (int h = 0; h < NC / 2; ++h) {
+                    acc_nz<CONJ>(acc[2 * h], v, make_float2(t4[h].x, t4[h].y));
+                    acc_nz<CONJ>(acc[2 * h + 1], v, make_float2(t4[h].z, t4[h].w));
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    if (jb + c < N)
+                        acc_nz<CONJ>(acc[c], v, X[PACKED ? (int64_t)k * NC + c : (jb + c) * ldx + k]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            if (jb + c < N) {
+                float2* yp = Y + (jb + c) * ldy + row;
+                float2 out = cmul(alpha, acc[c]);
+                if (BMODE == 1) cfma(out, beta, *yp);
+                *yp = out;
+            }
+        }
+    }
+}
+
+// one wavefront per listed row: 64/CL nonzero-lanes x CL column-lanes, four gathers in flight per lane
+template <int CL, bool CONJ, int BMODE>
+__global__ void __launch_bounds__(BLK)
+k_csrmm_rows_wave(int64_t N, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
+                  const float2* __restrict__ vals, const float2* __restrict__ X, int64_t ldx, int64_t sxr,
+                  float2* __restrict__ Y, int64_t ldy, float2 alpha, float2 beta,
+                  const int32_t* __restrict__ list, const uint32_t* __restrict__ count, uint32_t cap) {
+    constexpr int NLW = 64 / CL;
+    const int lane = threadIdx.x & 63;
+    const int c = lane % CL, i = lane / CL;
+    uint32_t n = *count;
+    if (n > cap) n = cap;
+    const uint32_t nwaves = gridDim.x * WAVES_PER_BLOCK;
+    for (uint32_t e = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6); e < n; e += nwaves) {
+        const int64_t row = list[e];
+        const int32_t p0 = rowptr[row], p1 = rowptr[row + 1];
+        for (int64_t jb = 0; jb < N; jb += CL) {
+            const int64_t j = jb + c;
+            const bool col_ok = j < N;
+            const float2* __restrict__ xcol = X + (col_ok ? j : 0) * ldx;
+            float2 a0 = make_float2(0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+            int32_t p = p0 + i;
+            for (; p + 3 * NLW < p1; p += 4 * NLW) {
+                const int32_t k0 = colind[p], k1 = colind[p + NLW], k2 = colind[p + 2 * NLW], k3 = colind[p + 3 * NLW];
+                const float2 v0 = vals[p], v1 = vals[p + NLW], v2 = vals[p + 2 * NLW], v3 = vals[p + 3 * NLW];
+                const float2 x0 = xcol[k0 * sxr], x1 = xcol[k1 * sxr], x2 = xcol[k2 * sxr], x3 = xcol[k3 * sxr];
+                acc_nz<CONJ>(a0, v0, x0); acc_nz<CONJ>(a1, v1, x1);
+                acc_nz<CONJ>(a2, v2, x2); acc_nz<CONJ>(a3, v3, x3);
+            }
+            for (; p < p1; p += NLW) acc_nz<CONJ>(a0, vals[p], xcol[colind[p] * sxr]);
+            float2 acc = cadd(cadd(a0, a1), cadd(a2, a3));
+#pragma unroll
+            for (int off = 32; off >= CL; off >>= 1) {
+                acc.x += __shfl_xor(acc.x, off, 64);
+                acc.y += __shfl_xor(acc.y, off, 64);
+            }
+            if (i == 0 && col_ok) {
+                float2* yp = Y + j * ldy + row;
+                float2 out = cmul(alpha, acc);
+                if (BMODE == 1) cfma(out, beta, *yp);
+                *yp = out;
+            }
+        }
+    }
+}
+
+// one 1024-thread workgroup per listed row; partial sums meet in LDS in a fixed order (deterministic)
+template <int CL, bool CONJ, int BMODE>
+__global__ void __launch_bounds__(1024)
+k_csrmm_rows_block(int64_t N, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
+                   const float2* __restrict__ vals, const float2* __restrict__ X, int64_t ldx, int64_t sxr,
+                   float2* __restrict__ Y, int64_t ldy, float2 alpha, float2 beta,
+                   const int32_t* __restrict__ list, const uint32_t* __restrict__ count, uint32_t cap) {
+    constexpr int NLB = 1024 / CL;
+    __shared__ float2 part[16][64];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int c = tid % CL, i = tid / CL;
+    uint32_t n = *count;
+    if (n > cap) n = cap;
+    for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
+        const int64_t row = list[e];
+        const int32_t p0 = rowptr[row], p1 = rowptr[row + 1];
+        for (int64_t jb = 0; jb < N; jb += CL) {
+            const int64_t j = jb + c;
+            const bool col_ok = j < N;
+            const float2* __restrict__ xcol = X + (col_ok ? j : 0) * ldx;
+            float2 a0 = make_float2(0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+            int32_t p = p0 + i;
+            for (; p + 3 * NLB < p1; p += 4 * NLB) {
+                const int32_t k0 = colind[p], k1 = colind[p + NLB], k2 = colind[p + 2 * NLB], k3 = colind[p + 3 * NLB];
+                const float2 v0 = vals[p], v1 = vals[p + NLB], v2 = vals[p + 2 * NLB], v3 = vals[p + 3 * NLB];
+                const float2 x0 = xcol[k0 * sxr], x1 = xcol[k1 * sxr], x2 = xcol[k2 * sxr], x3 = xcol[k3 * sxr];
+                acc_nz<CONJ>(a0, v0, x0); acc_nz<CONJ>(a1, v1, x1);
+                acc_nz<CONJ>(a2, v2, x2); acc_nz<CONJ>(a3, v3, x3);
+            }
+            for (; p < p1; p += NLB) acc_nz<CONJ>(a0, vals[p], xcol[colind[p] * sxr]);
+            float2 acc = cadd(cadd(a0, a1), cadd(a2, a3));
+            // fold the nonzero-lanes that share a wave (lanes with equal c), then across the 16 waves
+#pragma unroll
+            for (int off = 32; off >= CL; off >>= 1) {
+                acc.x += __shfl_xor(acc.x, off, 64);
+                acc.y += __shfl_xor(acc.y, off, 64);
+            }
+            part[wid][lane] = acc;
+            __syncthreads();
+            if (tid < CL) {
+                float2 sum = make_float2(0.f, 0.f);
+#pragma unroll
+                for (int w = 0; w < 16; ++w) sum = cadd(sum, part[w][tid]);
+                if (col_ok) {
+                    float2* yp = Y + j * ldy + row;
+                    float2 out = cmul(alpha, sum);
+                    if (BMODE == 1) cfma(out, beta, *yp);
+                    *yp = out;
+                }
+            }
+            __syncthreads();
         }
     }
 }
@@ -154,6 +349,18 @@ k_panel_scale(int64_t rows, int64_t N, float2* __restrict__ Y, int64_t ld, float
     }
 }
 
+// X(rows x N, column-major, leading dim ld)  ->  Xp[rows][NP] with the NP (= pow2 >= N) columns of a
+// row contiguous; pad columns are zero.  Used when every panel row is gathered many times.
+template <int NP>
+__global__ void __launch_bounds__(BLK)
+k_pack_panel(int64_t rows, int64_t N, const float2* __restrict__ X, int64_t ld, float2* __restrict__ Xp) {
+    for (int64_t e = (int64_t)blockIdx.x * BLK + threadIdx.x; e < rows * NP; e += (int64_t)gridDim.x * BLK) {
+        const int64_t k = e / NP;
+        const int c = (int)(e % NP);
+        Xp[e] = c < N ? X[c * ld + k] : make_float2(0.f, 0.f);
+    }
+}
+
 inline int pow2_ceil(int64_t v, int cap) {
     int p = 1;
     while (p < v && p < cap) p <<= 1;
@@ -176,26 +383,103 @@ inline bool env_flag(const char* name, bool dflt) {
     return e[0] != '0';
 }
 
+constexpr uint32_t WL_CAP = 1u << 20;
+
+int ensure_worklists(ig_ctx* ctx) {
+    if (ctx->d_worklist) return IG_OK;
+    IG_HIP(ctx, hipMalloc((void**)&ctx->d_worklist, sizeof(int32_t) * 2 * WL_CAP + 64));
+    return IG_OK;
+}
+
 template <bool CONJ>
-int launch_gather(ig_ctx* ctx, int64_t rows, int64_t N, int64_t nnz,
+int launch_gather(ig_ctx* ctx, int64_t rows, int64_t xrows, int64_t N, int64_t nnz,
                   const int32_t* rowptr, const int32_t* colind, const float2* vals,
                   const float2* X, int64_t ldx, float2* Y, int64_t ldy, float2 alpha, float2 beta) {
     const Shape s = pick_shape(rows, N, nnz);
+    // Panel rows that are gathered many times each (nnz >> xrows) from a small panel: repack the panel
+    // once so that one gathered row is one contiguous 16..64-byte access instead of N scattered ones.
+    int64_t sxc = ldx, sxr = 1;          // element (k, j) of X lives at X[j*sxc + k*sxr]
+    bool packed = false;
+    if (N >= 2 && N <= 8 && nnz >= 4 * xrows && env_flag("INDIGO_HIP_SPMM_PACK", true)) {
+        const int np = s.CL;             // pow2 >= N, <= 8
+        const size_t need = (size_t)xrows * np * 8;
+        if (need <= ((size_t)1 << 30)) {
+            if (ctx->xpack_bytes < need) {
+                if (ctx->d_xpack) { IG_HIP(ctx, hipStreamSynchronize(ctx->stream)); IG_HIP(ctx, hipFree(ctx->d_xpack)); ctx->d_xpack = nullptr; ctx->xpack_bytes = 0; }
+                IG_HIP(ctx, hipMalloc((void**)&ctx->d_xpack, need));
+                ctx->xpack_bytes = need;
+            }
+            ig_prof_scope prof(ctx, "pack_panel", (double)xrows * N * 8.0 + (double)need);
+            int64_t g = (xrows * np + BLK - 1) / BLK;
+            const int64_t cap = (int64_t)ctx->num_cu * 16;
+            if (g > cap) g = cap;
+            float2* xp = (float2*)ctx->d_xpack;
+            if (np == 2)      hipLaunchKernelGGL(k_pack_panel<2>, dim3((unsigned)g), dim3(BLK), 0, ctx->stream, xrows, N, X, ldx, xp);
+            else if (np == 4) hipLaunchKernelGGL(k_pack_panel<4>, dim3((unsigned)g), dim3(BLK), 0, ctx->stream, xrows, N, X, ldx, xp);
+            else              hipLaunchKernelGGL(k_pack_panel<8>, dim3((unsigned)g), dim3(BLK), 0, ctx->stream, xrows, N, X, ldx, xp);
+            IG_LAUNCH_CHECK(ctx, "k_pack_panel");
+            X = xp; sxc = 1; sxr = np; packed = true;
+        }
+    }
     const int rpw = 64 / (s.CL * s.NL);
     const int64_t waves = (rows + rpw - 1) / rpw;
     const int64_t blocks = (waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     IG_REQUIRE(ctx, blocks <= 0x7fffffffLL, "csrmm: matrix too large for one launch (%lld blocks)", (long long)blocks);
     const int xcd = env_flag("INDIGO_HIP_SPMM_XCD", true) ? 1 : 0;
     const bool b0 = (beta.x == 0.f && beta.y == 0.f);
-    ig_prof_scope prof(ctx, CONJ ? "csrmm_gather_conj" : "csrmm_gather");
+
+    // row deferral thresholds (nonzeros): a wave-per-row pass only pays when the slot is narrower than a wave
+    const bool defer = env_flag("INDIGO_HIP_SPMM_DEFER", true);
+    const int nlw = 64 / s.CL;
+    const int32_t thr_long = defer ? 256 * nlw : 0x7fffffff;
+    const int32_t thr_mid = !defer ? 0x7fffffff : (nlw > s.NL ? 16 * s.NL : thr_long);
+    WorkLists wl{};
+    if (defer) {
+        if (int rc = ensure_worklists(ctx)) return rc;
+        wl.rows[0] = ctx->d_worklist;
+        wl.rows[1] = ctx->d_worklist + WL_CAP;
+        wl.count = reinterpret_cast<uint32_t*>(ctx->d_worklist + 2 * WL_CAP);
+        wl.cap = WL_CAP;
+        IG_HIP(ctx, hipMemsetAsync(wl.count, 0, 2 * sizeof(uint32_t), ctx->stream));
+    }
+    const bool rowlane = s.NL == 1 && env_flag("INDIGO_HIP_SPMM_ROWLANE", true);
+    if (rowlane) {
+        ig_prof_scope prof(ctx, CONJ ? "csrmm_rowlane_conj" : "csrmm_rowlane");
+        const int64_t rblocks = (rows + BLK - 1) / BLK;
+        const int32_t tm = defer ? (thr_long < 16 ? thr_long : 16) : 0x7fffffff;
+#define IG_ROWLANE(NC_)                                                                            \
+    do {                                                                                           \
+        if (packed) {                                                                              \
+            if (b0) hipLaunchKernelGGL((k_csrmm_rowlane<NC_, CONJ, 0, true>), dim3((unsigned)rblocks), \
+                        dim3(BLK), 0, ctx->stream, rows, N, rowptr, colind, vals, X, sxc, Y, ldy,  \
+                        alpha, beta, xcd, wl, tm, thr_long);                                       \
+            else    hipLaunchKernelGGL((k_csrmm_rowlane<NC_, CONJ, 1, true>), dim3((unsigned)rblocks), \
+                        dim3(BLK), 0, ctx->stream, rows, N, rowptr, colind, vals, X, sxc, Y, ldy,  \
+                        alpha, beta, xcd, wl, tm, thr_long);                                       \
+        } else                                                                                     \
+        if (b0) hipLaunchKernelGGL((k_csrmm_rowlane<NC_, CONJ, 0, false>), dim3((unsigned)rblocks), \
+                    dim3(BLK), 0, ctx->stream, rows, N, rowptr, colind, vals, X, sxc, Y, ldy,      \
+                    alpha, beta, xcd, wl, tm, thr_long);                                           \
+        else    hipLaunchKernelGGL((k_csrmm_rowlane<NC_, CONJ, 1, false>), dim3((unsigned)rblocks), \
+                    dim3(BLK), 0, ctx->stream, rows, N, rowptr, colind, vals, X, sxc, Y, ldy,      \
+                    alpha, beta, xcd, wl, tm, thr_long);                                           \
+    } while (0)
+        if (s.CL >= 8) IG_ROWLANE(8);
+        else if (s.CL == 4) IG_ROWLANE(4);
+        else if (s.CL == 2) IG_ROWLANE(2);
+        else IG_ROWLANE(1);
+#undef IG_ROWLANE
+        IG_LAUNCH_CHECK(ctx, "k_csrmm_rowlane");
+    } else {
+        ig_prof_scope prof(ctx, CONJ ? "csrmm_gather_conj" : "csrmm_gather");
 #define IG_GATHER(CL_, NL_)                                                                        \
     do {                                                                                           \
         if (b0) hipLaunchKernelGGL((k_csrmm_gather<CL_, NL_, CONJ, 0>), dim3((unsigned)blocks),    \
-                    dim3(BLK), 0, ctx->stream, rows, N, rowptr, colind, vals, X, ldx, Y, ldy,      \
-                    alpha, beta, xcd);                                                             \
+                    dim3(BLK), 0, ctx->stream, rows, N, rowptr, colind, vals, X, sxc, sxr, Y, ldy, \
+                    alpha, beta, xcd, wl, thr_mid, thr_long);                                      \
         else    hipLaunchKernelGGL((k_csrmm_gather<CL_, NL_, CONJ, 1>), dim3((unsigned)blocks),    \
-                    dim3(BLK), 0, ctx->stream, rows, N, rowptr, colind, vals, X, ldx, Y, ldy,      \
-                    alpha, beta, xcd);                                                             \
+                    dim3(BLK), 0, ctx->stream, rows, N, rowptr, colind, vals, X, sxc, sxr, Y, ldy, \
+                    alpha, beta, xcd, wl, thr_mid, thr_long);                                      \
     } while (0)
 #define IG_NL_SWITCH(CL_, MACRO)                                                                   \
     switch (s.NL) {                                                                                \
@@ -217,9 +501,37 @@ int launch_gather(ig_ctx* ctx, int64_t rows, int64_t N, int64_t nnz,
         case 32: IG_NL_SWITCH(32, MACRO) break;                                                    \
         case 64: IG_NL_SWITCH(64, MACRO) break;                                                    \
     }
-    IG_CL_SWITCH(IG_GATHER)
+        IG_CL_SWITCH(IG_GATHER)
 #undef IG_GATHER
-    IG_LAUNCH_CHECK(ctx, "k_csrmm_gather");
+        IG_LAUNCH_CHECK(ctx, "k_csrmm_gather");
+    }
+    if (defer) {
+        const unsigned gw = (unsigned)ctx->num_cu * 8, gb = (unsigned)ctx->num_cu * 2;
+#define IG_ROWS(CL_)                                                                               \
+    do {                                                                                           \
+        if (thr_mid < thr_long || rowlane) {                                                       \
+            ig_prof_scope prof(ctx, "csrmm_rows_wave");                                            \
+            if (b0) hipLaunchKernelGGL((k_csrmm_rows_wave<CL_, CONJ, 0>), dim3(gw), dim3(BLK), 0, ctx->stream, \
+                        N, rowptr, colind, vals, X, sxc, sxr, Y, ldy, alpha, beta, wl.rows[0], wl.count, wl.cap);   \
+            else    hipLaunchKernelGGL((k_csrmm_rows_wave<CL_, CONJ, 1>), dim3(gw), dim3(BLK), 0, ctx->stream, \
+                        N, rowptr, colind, vals, X, sxc, sxr, Y, ldy, alpha, beta, wl.rows[0], wl.count, wl.cap);   \
+        }                                                                                          \
+        {                                                                                          \
+            ig_prof_scope prof(ctx, "csrmm_rows_block");                                           \
+            if (b0) hipLaunchKernelGGL((k_csrmm_rows_block<CL_, CONJ, 0>), dim3(gb), dim3(1024), 0, ctx->stream, \
+                        N, rowptr, colind, vals, X, sxc, sxr, Y, ldy, alpha, beta, wl.rows[1], wl.count + 1, wl.cap); \
+            else    hipLaunchKernelGGL((k_csrmm_rows_block<CL_, CONJ, 1>), dim3(gb), dim3(1024), 0, ctx->stream, \
+                        N, rowptr, colind, vals, X, sxc, sxr, Y, ldy, alpha, beta, wl.rows[1], wl.count + 1, wl.cap); \
+        }                                                                                          \
+    } while (0)
+        switch (s.CL) {
+            case 1: IG_ROWS(1); break;   case 2: IG_ROWS(2); break;   case 4: IG_ROWS(4); break;
+            case 8: IG_ROWS(8); break;   case 16: IG_ROWS(16); break; case 32: IG_ROWS(32); break;
+            case 64: IG_ROWS(64); break;
+        }
+#undef IG_ROWS
+        IG_LAUNCH_CHECK(ctx, "k_csrmm_rows");
+    }
     return IG_OK;
 }
 
@@ -292,7 +604,7 @@ int ig_ccsrmm(ig_ctx* ctx, int adjoint, int exwrite,
     if (int rc = ig_set_device(ctx)) return rc;
     const float2 alpha = make_float2(ar, ai), beta = make_float2(br, bi);
     if (!adjoint) {
-        return launch_gather<false>(ctx, M, N, nnz, rowptr, colind, (const float2*)vals,
+        return launch_gather<false>(ctx, M, K, N, nnz, rowptr, colind, (const float2*)vals,
                                     (const float2*)X, ldx, (float2*)Y, ldy, alpha, beta);
     }
     if (int rc = launch_panel_scale(ctx, K, N, (float2*)Y, ldy, beta)) return rc;
@@ -311,7 +623,7 @@ int ig_ccsrmm_t(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, int64_t nnz,
     if (int rc = check_panel_args(ctx, "ig_ccsrmm_t", M, K, N, nnz, vals_t, colind_t, rowptr_t, X, ldx, Y, ldy)) return rc;
     if (N == 0 || K == 0) return IG_OK;
     if (int rc = ig_set_device(ctx)) return rc;
-    return launch_gather<true>(ctx, K, N, nnz, rowptr_t, colind_t, (const float2*)vals_t,
+    return launch_gather<true>(ctx, K, M, N, nnz, rowptr_t, colind_t, (const float2*)vals_t,
                                (const float2*)X, ldx, (float2*)Y, ldy,
                                make_float2(ar, ai), make_float2(br, bi));
 }

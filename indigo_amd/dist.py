@@ -62,9 +62,9 @@ class TorchComm(object):
             self._cache = {key: t}          # keep only the latest alias
         return t
 
-    def allreduce_(self, arr):
-        """in-place sum over ranks"""
-        if self.world == 1:
+    def allreduce_(self, arr, force=False):
+        """in-place sum over ranks (`force` issues the collective even for a single rank: used by tests)"""
+        if self.world == 1 and not force:
             return
         t = self._tensor(arr)
         if self._on_gpu:

@@ -1,0 +1,57 @@
+"""GPU side of the multi-GPU path, exercised with ONE rank on the one GPU of the test box:
+torch (RCCL) aliases the backend's device buffer through __cuda_array_interface__ and the
+all-reduce is enqueued on the backend's own stream.  Runs in a subprocess because torch must be
+imported before libindigo_hip.so so that both share one HIP runtime."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+WORKER = r"""
+import os, sys
+sys.path.insert(0, os.environ["REPO_ROOT"])
+os.environ["INDIGO_HIP_WITH_TORCH"] = "1"
+import torch, torch.distributed as dist
+import numpy as np
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from indigo_amd.backends import get_backend
+from indigo_amd.dist import TorchComm, ShardedNormalOperator
+from indigo_amd.sense import SenseProblem, normal_operator
+from indigo_amd.util import rand64c
+B = get_backend("hip")
+comm = TorchComm(B)
+x = rand64c(100003, seed=1)
+d = B.copy_array(x)
+t = comm._tensor(d)
+assert t.data_ptr() == d._arr and t.numel() == 2 * x.size
+B.scale(d, 2.0)                       # queued on the backend stream ...
+comm.allreduce_(d, force=True)        # ... the collective must see it (same stream), sum over 1 rank = identity
+B.axpby(1, d, 1, B.copy_array(x))     # ... and later work must see the collective's result
+np.testing.assert_allclose(d.to_host(), 3 * x, rtol=1e-6)
+# sharded operator with a single shard == plain normal operator
+p = SenseProblem.synthetic((16, 16, 16), 2, nspokes=24, nreadout=32, seed=4)
+A = p.build_fused(B)
+xs = B.copy_array(rand64c(A.shape[1], 1, seed=2))
+y1 = B.zero_array((A.shape[1], 1), np.dtype("complex64"))
+y2 = B.zero_array((A.shape[1], 1), np.dtype("complex64"))
+ShardedNormalOperator(A, comm, lamda=0.1).eval(y1, xs)
+normal_operator(A, lamda=0.1).eval(y2, xs)
+a, b = y1.to_host(), y2.to_host()
+assert np.linalg.norm(a - b) <= 1e-6 * np.linalg.norm(b)
+dist.destroy_process_group()
+print("OK")
+"""
+
+
+def test_torch_aliasing_and_stream_ordered_allreduce():
+    env = dict(os.environ, REPO_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29517",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-4000:]
