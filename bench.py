@@ -30,6 +30,27 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+# profile-scope name (call site) -> device kernel symbol as rocprofv3 prints it
+KERNEL_SYMBOL = {
+    "fft_2stage_axis0": "k_fft_2stage<32, 16, 16, 16, true>",
+    "fft_2stage_axis1": "k_fft_2stage<32, 16, 16, 16, false>",
+    "fft_2stage_axis2": "k_fft_2stage<32, 16, 16, 16, false>",
+}
+
+
+def pmc_traffic(kernel, grid, ncoils):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (profiles/), if that
+    summary was taken on the same panel shape (512^3 x 8); otherwise None.  PMC counters cannot be read
+    from inside the benchmark process, so this figure comes from the profile run of the same kernel."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_fft512x8_traffic.json")
+    if not os.path.exists(path) or tuple(grid) != (512, 512, 512) or ncoils != 8:
+        return None, None
+    d = json.load(open(path)).get(kernel)
+    if not d:
+        return None, None
+    return d["hbm_bytes_per_launch"], "profiles/r01_pmc_fft512x8_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2)"
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -125,18 +146,26 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = args.steps / elapsed
 
-    # dominant kernel and its roofline point
-    dom = max(prof, key=lambda k: prof[k]['total_ms']) if prof else None
+    # dominant kernel and its roofline point.  The event brackets are per call site; call sites that launch
+    # the same device kernel (the two strided FFT axes) are merged so the figure matches rocprofv3's row.
+    kernels = {}
+    for name, d in prof.items():
+        sym = KERNEL_SYMBOL.get(name, name)
+        k = kernels.setdefault(sym, dict(launches=0, total_ms=0.0, bytes=0.0))
+        k['launches'] += d['launches']
+        k['total_ms'] += d['total_ms']
+        k['bytes'] += d['bytes']
+    dom = max(kernels, key=lambda k: kernels[k]['total_ms']) if kernels else None
     roofline = None
     if dom:
-        d = prof[dom]
+        d = kernels[dom]
+        avg_ms = d['total_ms'] / d['launches']
         per_launch_bytes = d['bytes'] / d['launches'] if d['bytes'] else None
-        if per_launch_bytes is None and dom.startswith("csrmm"):
-            per_launch_bytes = ev['csrmm']['nbytes'] / ev['csrmm']['calls']
-        achieved = per_launch_bytes / (d['avg_ms'] * 1e-3) / 1e9 if per_launch_bytes else None
+        achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9 if per_launch_bytes else None
+        traffic, traffic_src = pmc_traffic(dom, p.oN, len(coils))
         roofline = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=(achieved / HBM_PEAK_GBS) if achieved else None, traffic=None,
-                        avg_launch_ms=d['avg_ms'], launches=d['launches'],
+                        frac=(achieved / HBM_PEAK_GBS) if achieved else None, traffic=traffic,
+                        traffic_source=traffic_src, avg_launch_ms=avg_ms, launches=d['launches'],
                         algorithmic_bytes_per_launch=per_launch_bytes)
     for k in sorted(prof, key=lambda k: -prof[k]['total_ms']):
         log(rank, "  %-24s %4d launches  avg %8.3f ms  total %9.2f ms" % (k, prof[k]['launches'], prof[k]['avg_ms'], prof[k]['total_ms']))
