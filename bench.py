@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--image", type=int, default=256, help="image edge (debug: smaller problems)")
     ap.add_argument("--coils", type=int, default=8)
+    ap.add_argument("--tree", choices=["zpadfft", "o3"], default="zpadfft",
+                    help="zpadfft: S' and the FFT fused into one zero-pad-aware leaf (default); o3: the reference's -O3 leaves")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-budget", type=float, default=60.0, help="skip the CPU leg if setup says it will exceed this many seconds")
     return ap.parse_args()
@@ -101,7 +103,10 @@ def main():
                                oversamp=2.0, seed=4)
     coils = list(coil_range(C, rank, world))
     log(rank, "problem: image %d^3, %d coils (%d on this rank), grid %s, T=%d (%.1fs)" % (img, C, len(coils), p.oN, p.T, time.time() - t_setup))
-    A = p.build_fused(B, coils=coils)
+    fused_fft = args.tree == "zpadfft" and B.supports_padded_fft(p.oN)
+    A = p.build_zpadfft(B, coils=coils) if fused_fft else p.build_fused(B, coils=coils)
+    log(rank, "tree:", "KronI(G') * ZpadFFT (S' folded into a zero-pad-aware FFT)" if fused_fft
+        else "-O3: KronI(G') * (KronI(FFT) * S')")
     c64 = np.dtype('complex64')
     Nvox = A.shape[1]
     x = B.copy_array(rand64c(Nvox, 1, seed=1))

@@ -107,6 +107,11 @@ int  ig_cscal(ig_ctx* ctx, int64_t n, float alpha_re, float alpha_im, void* x); 
 int  ig_cdotc(ig_ctx* ctx, int64_t n, const void* x, const void* y, double out[2]); /* sum conj(x)*y ; synchronous */
 int  ig_scnrm2sq(ig_ctx* ctx, int64_t n, const void* x, double* out);       /* ||x||_2^2 ; synchronous */
 int  ig_cmax(ig_ctx* ctx, int64_t nfloats, float val, void* arr);           /* arr[i] = max(arr[i], val) over floats */
+/* y(rows) = beta*y + alpha * sum_j X[:, j]  for a column-major rows x ncols panel: the coil
+ * combination that VStack._eval_adjoint performs with one scale + ncols axpby-like passes
+ * (indigo/operators.py:440-447), in one pass.                                              */
+int  ig_csum_cols(ig_ctx* ctx, int64_t rows, int64_t ncols, const void* X, int64_t ldx,
+                  float alpha_re, float alpha_im, float beta_re, float beta_im, void* y);
 
 /* ------------------------------------------------------------------------
  * CSR x dense-panel SpMM.  Replaces Backend.ccsrmm
@@ -170,6 +175,23 @@ int  ig_fft_plan(ig_ctx* ctx, int rank, const int64_t* dims, int64_t batch,
 int  ig_fft_exec(ig_fft* plan, const void* x, void* y, int direction /* -1 fwd, +1 inv */,
                  void* workspace /* >= workspace_bytes, may be NULL if 0 */);
 int  ig_fft_describe(ig_fft* plan, char* buf, size_t len);   /* kernel / radix schedule, for logs and tests */
+
+/* Zero-padded forward / cropped inverse 3-D transforms: the fusion of the reference's
+ * Zpad . diag . FFT chain (indigo/backends/backend.py:371-387 Zpad, :355-369 FFTc, :403-442 NUFFT;
+ * the `-O3` tree's S' matrix, examples/pics.py:104-193) into the transform's first / last pass.
+ * The image occupies the box box_lo[a] .. box_lo[a]+box_dims[a] of a dims[0] x dims[1] x dims[2]
+ * grid (each grid axis 256 or 512, else IG_ERR_UNSUPPORTED).  Compact arrays are F-ordered
+ * box_dims (x batch); `w` (optional, may be NULL) holds one complex weight per compact element and
+ * batch member; `x_bstride` is the element distance between batch members of x (0: one image
+ * shared by all members, as in SENSE where the coils share the image).
+ *   padded :  Y[..,c] = FFT3( zeropad( w[..,c] .* x[..,c] ) )            unnormalised, forward
+ *   cropped:  x[..,c] = conj(w[..,c]) .* crop( IFFT3( Y[..,c] ) )        unnormalised, inverse
+ * Y is a full grid x batch array; the cropped transform leaves Y intact and needs
+ * workspace_bytes (= one grid x batch array) of scratch.                                      */
+int  ig_fft_plan_padded(ig_ctx* ctx, const int64_t* dims, const int64_t* box_lo, const int64_t* box_dims,
+                        int64_t batch, ig_fft** plan, size_t* workspace_bytes);
+int  ig_fft_exec_padded(ig_fft* plan, const void* x, int64_t x_bstride, const void* w, void* y);
+int  ig_fft_exec_cropped(ig_fft* plan, const void* y, const void* w, void* x, int64_t x_bstride, void* workspace);
 int  ig_fft_destroy(ig_fft* plan);
 
 #ifdef __cplusplus

@@ -43,6 +43,7 @@ PROTOTYPES = {
     "ig_cdotc":           (c_int, [c_void_p, c_int64, c_void_p, c_void_p, POINTER(c_double)]),
     "ig_scnrm2sq":        (c_int, [c_void_p, c_int64, c_void_p, POINTER(c_double)]),
     "ig_cmax":            (c_int, [c_void_p, c_int64, c_float, c_void_p]),
+    "ig_csum_cols":       (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_void_p]),
     "ig_ccsrmm":          (c_int, [c_void_p, c_int, c_int, c_int64, c_int64, c_int64, c_int64,
                                    c_float, c_float, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_int64, c_float, c_float, c_void_p, c_int64]),
@@ -57,6 +58,10 @@ PROTOTYPES = {
     "ig_fft_exec":        (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ig_fft_describe":    (c_int, [c_void_p, c_char_p, c_size_t]),
     "ig_fft_destroy":     (c_int, [c_void_p]),
+    "ig_fft_plan_padded": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), c_int64,
+                                   POINTER(c_void_p), POINTER(c_size_t)]),
+    "ig_fft_exec_padded": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "ig_fft_exec_cropped": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
 }
 
 

@@ -308,6 +308,10 @@ class Backend(object):
     def Eye(self, n, dtype=_C64, **kwargs):
         return op.Eye(self, n, dtype=dtype, **kwargs)
 
+    def ZpadFFT(self, grid_shape, box_shape, weights, **kwargs):
+        """fused  KronI(C, UnscaledFFT) * zero-pad * diag(weights)  leaf (see operators.ZpadFFT)"""
+        return op.ZpadFFT(self, grid_shape, box_shape, weights, **kwargs)
+
     def One(self, shape, dtype=_C64, **kwargs):
         return op.One(self, shape, dtype=dtype, **kwargs)
 
@@ -422,6 +426,26 @@ class Backend(object):
 
     def _fft_workspace_size(self, x_shape):
         return 0
+
+    # fused zero-pad/crop transforms used by operators.ZpadFFT (not part of the reference's contract:
+    # they replace its Zpad-CSR + FFT composition; see include/indigo_hip.h ig_fft_exec_padded)
+    def fft_padded(self, y, x, w, grid, box_lo, box_dims):
+        """y[:, c] = FFT(zeropad(w[:, c] * x)); y: (prod grid, C), x: (prod box, 1), w: (prod box, C)"""
+        raise NotImplementedError()
+
+    def ifft_cropped(self, xc, y, w, grid, box_lo, box_dims, workspace):
+        """xc[:, c] = conj(w[:, c]) * crop(IFFT(y[:, c])); xc: (prod box, C), y: (prod grid, C) left intact"""
+        raise NotImplementedError()
+
+    def _fft_padded_workspace(self, grid, box_lo, box_dims, batch):
+        return 0
+
+    def sum_columns(self, y, X, alpha=1, beta=0):
+        """y = beta*y + alpha * sum_j X[:, j]"""
+        raise NotImplementedError()
+
+    def supports_padded_fft(self, grid):
+        return False
 
     def ccsrmm(self, y, A_shape, A_indx, A_ptr, A_vals, x, alpha=1, beta=0, adjoint=False, exwrite=False):
         raise NotImplementedError()

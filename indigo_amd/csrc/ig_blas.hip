@@ -88,6 +88,20 @@ k_smax(int64_t n, float val, float* __restrict__ a, int vec_ok) {
     }
 }
 
+// y[k] = beta*y[k] + alpha * sum_j X[k + j*ld]   (coil combination: the VStack adjoint's accumulation in one pass)
+template <bool BETA0>
+__global__ void __launch_bounds__(BLK)
+k_csum_cols(int64_t rows, int64_t ncols, const float2* __restrict__ X, int64_t ld, float2 alpha, float2 beta,
+            float2* __restrict__ y) {
+    for (int64_t k = (int64_t)blockIdx.x * BLK + threadIdx.x; k < rows; k += (int64_t)gridDim.x * BLK) {
+        float2 acc = make_float2(0.f, 0.f);
+        for (int64_t j = 0; j < ncols; ++j) acc = cadd(acc, X[k + j * ld]);
+        float2 out = cmul(alpha, acc);
+        if (!BETA0) cfma(out, beta, y[k]);
+        y[k] = out;
+    }
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -227,6 +241,25 @@ int ig_scnrm2sq(ig_ctx* ctx, int64_t n, const void* x, double* out) {
     int rc = reduce_common(ctx, false, n, x, nullptr, r);
     if (rc == IG_OK) *out = r[0];
     return rc;
+}
+
+int ig_csum_cols(ig_ctx* ctx, int64_t rows, int64_t ncols, const void* X, int64_t ldx,
+                 float ar, float ai, float br, float bi, void* y) {
+    IG_REQUIRE(ctx, ctx != nullptr, "ig_csum_cols: ctx is NULL");
+    IG_REQUIRE(ctx, rows >= 0 && ncols >= 0, "ig_csum_cols: negative dimension");
+    if (rows == 0) return IG_OK;
+    IG_REQUIRE(ctx, y && (ncols == 0 || X), "ig_csum_cols: NULL pointer");
+    IG_REQUIRE(ctx, ncols <= 1 || ldx >= rows, "ig_csum_cols: ldx smaller than rows");
+    if (int rc = ig_set_device(ctx)) return rc;
+    const bool b0 = (br == 0.f && bi == 0.f);
+    ig_prof_scope prof(ctx, "csum_cols", (double)rows * 8.0 * (ncols + (b0 ? 1 : 2)));
+    const int g = grid_for(ctx, rows);
+    if (b0) hipLaunchKernelGGL(k_csum_cols<true>, dim3(g), dim3(BLK), 0, ctx->stream, rows, ncols, (const float2*)X, ldx,
+                               make_float2(ar, ai), make_float2(br, bi), (float2*)y);
+    else    hipLaunchKernelGGL(k_csum_cols<false>, dim3(g), dim3(BLK), 0, ctx->stream, rows, ncols, (const float2*)X, ldx,
+                               make_float2(ar, ai), make_float2(br, bi), (float2*)y);
+    IG_LAUNCH_CHECK(ctx, "k_csum_cols");
+    return IG_OK;
 }
 
 int ig_cmax(ig_ctx* ctx, int64_t nfloats, float val, void* arr) {

@@ -187,17 +187,34 @@ template <int N> struct RegFFT {      // N = 16, 32: radix-4 decimation in frequ
     }
 };
 
+// One axis pass, described generally enough for plain, zero-padded and cropped transforms.
+// Columns are enumerated by three indices (k0 fastest, then k1, k2); element j of column k lives at
+//   in  + k0*in_s[0]  + k1*in_s[1]  + k2*in_s[2]  + j*in_sj      (read only for in_lo  <= j < in_hi, else 0)
+//   out + k0*out_s[0] + k1*out_s[1] + k2*out_s[2] + j*out_sj     (stored only for out_lo <= j < out_hi)
+// The base pointers are pre-offset on the host (index origins of boxes / compact arrays), so they may
+// point outside the buffers; they are only dereferenced inside the boxes.  Optional diagonal weights
+// `w` (same indexing, own strides): WMODE 1 multiplies the inputs by w, WMODE 2 the outputs by conj(w).
+struct PassDesc {
+    const float2* in; float2* out; const float2* w;
+    int64_t in_sj, out_sj, w_sj;
+    int64_t in_s[3], out_s[3], w_s[3];
+    int64_t ext0, ext1, ncols;
+    int in_lo, in_hi, out_lo, out_hi;
+    int inverse;
+};
+
 // Two-stage kernel for n = R1*R2 (256 = 16x16, 512 = 32x16): the whole column lives in registers
 // twice -- stage 1 reads its R1 inputs straight from global memory, stage 2 writes its R2 outputs
 // straight back -- with ONE LDS exchange in between (Stockham index map, inter-stage twiddles applied
 // on the way into LDS).  A workgroup = W columns x T threads; lanes run along the direction that is
 // contiguous in memory (columns for strided axes, elements for axis 0), so every wave access is a
 // set of 128-byte segments and every LDS access is conflict-free at the minimum cycle count
-// (axis 0 uses a 16-element XOR swizzle of the line).
-template <int R1, int R2, int T, int W, bool AXIS0>
+// (axis 0 uses a 16-element XOR swizzle of the line).  Inputs outside [in_lo, in_hi) are zeros that
+// are never loaded and outputs outside [out_lo, out_hi) are never stored: that is what makes the
+// zero-padded forward / cropped inverse transforms cheap (SENSE: 1/8 of the grid is non-zero).
+template <int R1, int R2, int T, int W, bool AXIS0, int WMODE, bool BOXED>
 __global__ void __launch_bounds__(W * T)
-k_fft_2stage(const float2* __restrict__ x, float2* __restrict__ y, const float2* __restrict__ tw,
-             int64_t inner, int64_t ncols, int inverse) {
+k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
     constexpr int n = R1 * R2, B1 = R2 / T, B2 = R1 / T, NT = W * T;
     static_assert(R2 % T == 0 && R1 % T == 0 && T == 16, "lane groups of 16");
     extern __shared__ float2 lds[];
@@ -208,10 +225,12 @@ k_fft_2stage(const float2* __restrict__ x, float2* __restrict__ y, const float2*
     const int t = AXIS0 ? (tid % T) : (tid / W);
     const int w = AXIS0 ? (tid / T) : (tid % W);
     const int64_t col = (int64_t)blockIdx.x * W + w;
-    const bool valid = col < ncols;
-    int64_t colbase, sj;
-    if (AXIS0) { colbase = col * n; sj = 1; }
-    else { const int64_t o = col / inner; colbase = (col - o * inner) + inner * n * o; sj = inner; }
+    const bool valid = col < d.ncols;
+    const int64_t k0 = col % d.ext0, rest = col / d.ext0;
+    const int64_t k1 = rest % d.ext1, k2 = rest / d.ext1;
+    const int64_t cb_in = k0 * d.in_s[0] + k1 * d.in_s[1] + k2 * d.in_s[2];
+    const int64_t cb_out = k0 * d.out_s[0] + k1 * d.out_s[1] + k2 * d.out_s[2];
+    const int64_t cb_w = WMODE ? k0 * d.w_s[0] + k1 * d.w_s[1] + k2 * d.w_s[2] : 0;
     auto lidx = [&](int j) -> int {
         if (AXIS0) return w * n + ((j & ~15) | ((j ^ (j / R1)) & 15));
         return j * W + w;
@@ -222,11 +241,15 @@ k_fft_2stage(const float2* __restrict__ x, float2* __restrict__ y, const float2*
 #pragma unroll
     for (int q = 0; q < B1; ++q) {
         const int b = t + q * T;
-        const float2* __restrict__ src = x + colbase + (int64_t)b * sj;
 #pragma unroll
         for (int k = 0; k < R1; ++k) {
-            float2 a = valid ? src[(int64_t)(k * R2) * sj] : make_float2(0.f, 0.f);
-            if (inverse) a.y = -a.y;
+            const int j = b + k * R2;
+            float2 a = make_float2(0.f, 0.f);
+            if (valid && (!BOXED || (j >= d.in_lo && j < d.in_hi))) {
+                a = d.in[cb_in + (int64_t)j * d.in_sj];
+                if (WMODE == 1) a = cmul(a, d.w[cb_w + (int64_t)j * d.w_sj]);
+            }
+            if (d.inverse) a.y = -a.y;
             v[q][k] = a;
         }
     }
@@ -250,12 +273,15 @@ k_fft_2stage(const float2* __restrict__ x, float2* __restrict__ y, const float2*
         for (int k2 = 0; k2 < R2; ++k2) u[k2] = lds[lidx(b2 + k2 * R1)];
         RegFFT<R2>::run(u);
         if (valid) {
-            float2* __restrict__ dst = y + colbase + (int64_t)b2 * sj;
 #pragma unroll
             for (int r = 0; r < R2; ++r) {
-                float2 a = u[r];
-                if (inverse) a.y = -a.y;
-                dst[(int64_t)(r * R1) * sj] = a;
+                const int j = b2 + r * R1;
+                if (!BOXED || (j >= d.out_lo && j < d.out_hi)) {
+                    float2 a = u[r];
+                    if (d.inverse) a.y = -a.y;
+                    if (WMODE == 2) a = cmulc(d.w[cb_w + (int64_t)j * d.w_sj], a);
+                    d.out[cb_out + (int64_t)j * d.out_sj] = a;
+                }
             }
         }
     }
@@ -412,6 +438,9 @@ struct ig_fft {
     AxisPlan axis[3];
     size_t workspace_bytes = 0;
     std::string desc;
+    // zero-padded / cropped plans (ig_fft_plan_padded): the image occupies box_lo .. box_lo+box_dims of the grid
+    bool padded = false;
+    int64_t box_lo[3] = {0, 0, 0}, box_dims[3] = {1, 1, 1};
 };
 
 namespace {
@@ -433,11 +462,23 @@ int plan_axis(ig_ctx* ctx, ig_fft* p, int a) {
         ax.kind = 3; ax.W = 16; ax.T = 16; ax.nstages = 2;
         ax.rad.r[0] = ax.n == 512 ? 32 : 16; ax.rad.r[1] = 16;
         ax.lds_bytes = ((size_t)ax.n * ax.W + ax.n) * 8;
-        const void* fns[4] = {
-            reinterpret_cast<const void*>(&k_fft_2stage<32, 16, 16, 16, true>),
-            reinterpret_cast<const void*>(&k_fft_2stage<32, 16, 16, 16, false>),
-            reinterpret_cast<const void*>(&k_fft_2stage<16, 16, 16, 16, true>),
-            reinterpret_cast<const void*>(&k_fft_2stage<16, 16, 16, 16, false>)};
+        const void* fns[16] = {
+            reinterpret_cast<const void*>(&k_fft_2stage<32, 16, 16, 16, true, 0, false>),
+            reinterpret_cast<const void*>(&k_fft_2stage<32, 16, 16, 16, true, 0, true>),
+            reinterpret_cast<const void*>(&k_fft_2stage<32, 16, 16, 16, true, 1, true>),
+            reinterpret_cast<const void*>(&k_fft_2stage<32, 16, 16, 16, true, 2, true>),
+            reinterpret_cast<const void*>(&k_fft_2stage<32, 16, 16, 16, false, 0, false>),
+            reinterpret_cast<const void*>(&k_fft_2stage<32, 16, 16, 16, false, 0, true>),
+            reinterpret_cast<const void*>(&k_fft_2stage<32, 16, 16, 16, false, 1, true>),
+            reinterpret_cast<const void*>(&k_fft_2stage<32, 16, 16, 16, false, 2, true>),
+            reinterpret_cast<const void*>(&k_fft_2stage<16, 16, 16, 16, true, 0, false>),
+            reinterpret_cast<const void*>(&k_fft_2stage<16, 16, 16, 16, true, 0, true>),
+            reinterpret_cast<const void*>(&k_fft_2stage<16, 16, 16, 16, true, 1, true>),
+            reinterpret_cast<const void*>(&k_fft_2stage<16, 16, 16, 16, true, 2, true>),
+            reinterpret_cast<const void*>(&k_fft_2stage<16, 16, 16, 16, false, 0, false>),
+            reinterpret_cast<const void*>(&k_fft_2stage<16, 16, 16, 16, false, 0, true>),
+            reinterpret_cast<const void*>(&k_fft_2stage<16, 16, 16, 16, false, 1, true>),
+            reinterpret_cast<const void*>(&k_fft_2stage<16, 16, 16, 16, false, 2, true>)};
         for (const void* f : fns)
             IG_HIP(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
     }
@@ -482,6 +523,30 @@ int plan_axis(ig_ctx* ctx, ig_fft* p, int a) {
     }
     IG_HIP(ctx, hipMalloc((void**)&ax.d_tw, sizeof(float2) * (size_t)ax.n));
     IG_HIP(ctx, hipMemcpy(ax.d_tw, tw.data(), sizeof(float2) * (size_t)ax.n, hipMemcpyHostToDevice));
+    return IG_OK;
+}
+
+// launch one 2-stage axis pass (n in {256, 512}); axis0 selects the lane mapping for contiguous columns
+int launch_2stage(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d, bool axis0, int wmode) {
+    const int64_t blocks = (d.ncols + ax.W - 1) / ax.W;
+    if (blocks == 0) return IG_OK;
+    IG_REQUIRE(ctx, blocks <= 0x7fffffffLL, "ig_fft: too many tiles");
+    const dim3 grid((unsigned)blocks), block((unsigned)(ax.W * ax.T));
+#define IG_2S(R1_, AX0_, WM_, BX_)                                                                  \
+    hipLaunchKernelGGL((k_fft_2stage<R1_, 16, 16, 16, AX0_, WM_, BX_>), grid, block, ax.lds_bytes, ctx->stream, d, ax.d_tw)
+#define IG_2S_W(R1_, AX0_)                                                                           \
+    do {                                                                                             \
+        if (!boxed && wmode == 0) IG_2S(R1_, AX0_, 0, false);                                        \
+        else if (wmode == 0) IG_2S(R1_, AX0_, 0, true);                                              \
+        else if (wmode == 1) IG_2S(R1_, AX0_, 1, true);                                              \
+        else IG_2S(R1_, AX0_, 2, true);                                                              \
+    } while (0)
+    const bool boxed = !(d.in_lo <= 0 && d.in_hi >= (int)ax.n && d.out_lo <= 0 && d.out_hi >= (int)ax.n);
+    if (ax.n == 512) { if (axis0) IG_2S_W(32, true); else IG_2S_W(32, false); }
+    else             { if (axis0) IG_2S_W(16, true); else IG_2S_W(16, false); }
+#undef IG_2S_W
+#undef IG_2S
+    IG_LAUNCH_CHECK(ctx, "k_fft_2stage");
     return IG_OK;
 }
 
@@ -558,17 +623,13 @@ int ig_fft_exec(ig_fft* p, const void* xv, void* yv, int direction, void* worksp
         if (ax.kind == 2) continue;
         if (ax.kind == 3) {
             ig_prof_scope prof(ctx, a == 0 ? "fft_2stage_axis0" : a == 1 ? "fft_2stage_axis1" : "fft_2stage_axis2", pass_bytes);
-            const int64_t ncols = ax.inner * ax.outer;
-            const int64_t blocks = (ncols + ax.W - 1) / ax.W;
-            IG_REQUIRE(ctx, blocks <= 0x7fffffffLL, "ig_fft_exec: too many tiles");
-            const dim3 grid((unsigned)blocks), block((unsigned)(ax.W * ax.T));
-#define IG_2S(R1_, AX0_)                                                                              \
-            hipLaunchKernelGGL((k_fft_2stage<R1_, 16, 16, 16, AX0_>), grid, block, ax.lds_bytes, ctx->stream, \
-                               cur, y, ax.d_tw, ax.inner, ncols, inverse)
-            if (ax.n == 512) { if (ax.inner == 1) IG_2S(32, true); else IG_2S(32, false); }
-            else             { if (ax.inner == 1) IG_2S(16, true); else IG_2S(16, false); }
-#undef IG_2S
-            IG_LAUNCH_CHECK(ctx, "k_fft_2stage");
+            PassDesc d{};
+            d.in = cur; d.out = y; d.w = nullptr;
+            d.in_sj = d.out_sj = ax.inner; d.w_sj = 0;
+            d.ext0 = ax.inner; d.ext1 = ax.outer; d.ncols = ax.inner * ax.outer;
+            d.in_s[0] = d.out_s[0] = 1; d.in_s[1] = d.out_s[1] = ax.inner * ax.n; d.in_s[2] = d.out_s[2] = 0;
+            d.in_lo = d.out_lo = 0; d.in_hi = d.out_hi = (int)ax.n; d.inverse = inverse;
+            if (int rc = launch_2stage(ctx, ax, d, ax.inner == 1, 0)) return rc;
             cur = y;
         } else if (ax.kind == 0) {
             ig_prof_scope prof(ctx, a == 0 ? "fft_lds_axis0" : a == 1 ? "fft_lds_axis1" : "fft_lds_axis2", pass_bytes);
@@ -605,6 +666,135 @@ int ig_fft_exec(ig_fft* p, const void* xv, void* yv, int direction, void* worksp
     if (cur != y) {
         // all axes were length 1 (cur == x) or the last generic stage landed in the workspace
         IG_HIP(ctx, hipMemcpyAsync(y, cur, (size_t)p->total * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    return IG_OK;
+}
+
+// ---- zero-padded forward / cropped inverse 3-D transforms ------------------------------
+// The gridding FFT of a non-Cartesian SENSE operator never sees a dense grid: its input is the image
+// zero-padded into an oversampled grid (backend.py:371-387 Zpad, :432-442 NUFFT) and, on the adjoint,
+// only the image box of its output is kept.  An axis pass then only has to touch the columns that
+// are non-zero (forward) or kept (inverse), and only the in-box part of each column:
+//     forward : pass x reads b0*b1*b2      writes n0*b1*b2      (per batch member)
+//               pass y reads n0*b1*b2      writes n0*n1*b2
+//               pass z reads n0*n1*b2      writes n0*n1*n2
+// i.e. 2.6x the grid volume instead of 6x at 2x oversampling, and the diagonal factors of the tree
+// (maps * roll-off * modulation) ride along as load/store weights instead of a (C*P)-row CSR matrix.
+
+int ig_fft_plan_padded(ig_ctx* ctx, const int64_t* dims, const int64_t* box_lo, const int64_t* box_dims,
+                       int64_t batch, ig_fft** plan, size_t* workspace_bytes) {
+    IG_REQUIRE(ctx, ctx && dims && box_lo && box_dims && plan, "ig_fft_plan_padded: bad arguments");
+    for (int a = 0; a < 3; ++a) {
+        IG_REQUIRE(ctx, box_lo[a] >= 0 && box_dims[a] >= 1 && box_lo[a] + box_dims[a] <= dims[a],
+                   "ig_fft_plan_padded: box [%lld, %lld) outside grid axis %d of length %lld", (long long)box_lo[a],
+                   (long long)(box_lo[a] + box_dims[a]), a, (long long)dims[a]);
+    }
+    size_t ws = 0;
+    int rc = ig_fft_plan(ctx, 3, dims, batch, plan, &ws);
+    if (rc != IG_OK) return rc;
+    ig_fft* p = *plan;
+    for (int a = 0; a < 3; ++a) {
+        if (p->axis[a].kind != 3) {
+            ig_fft_destroy(p);
+            *plan = nullptr;
+            return ig_fail(ctx, IG_ERR_UNSUPPORTED,
+                           "ig_fft_plan_padded: grid axis %d has length %lld; the padded path needs 256 or 512", a, (long long)dims[a]);
+        }
+        p->box_lo[a] = box_lo[a];
+        p->box_dims[a] = box_dims[a];
+    }
+    p->padded = true;
+    p->workspace_bytes = (size_t)p->total * 8;      // the cropped inverse keeps its input intact
+    if (workspace_bytes) *workspace_bytes = p->workspace_bytes;
+    p->desc = "padded " + p->desc;
+    return IG_OK;
+}
+
+int ig_fft_exec_padded(ig_fft* p, const void* xv, int64_t x_bstride, const void* wv, void* yv) {
+    if (!p) return ig_fail(nullptr, IG_ERR_ARG, "ig_fft_exec_padded: plan is NULL");
+    ig_ctx* ctx = p->ctx;
+    IG_REQUIRE(ctx, p->padded, "ig_fft_exec_padded: plan was not made by ig_fft_plan_padded");
+    IG_REQUIRE(ctx, xv && yv, "ig_fft_exec_padded: NULL array");
+    if (int rc = ig_set_device(ctx)) return rc;
+    const int64_t n0 = p->dims[0], n1 = p->dims[1], n2 = p->dims[2];
+    const int64_t b0 = p->box_dims[0], b1 = p->box_dims[1], b2 = p->box_dims[2];
+    const int64_t l0 = p->box_lo[0], l1 = p->box_lo[1], l2 = p->box_lo[2];
+    const int64_t vol = n0 * n1 * n2, bvol = b0 * b1 * b2, C = p->batch;
+    const float2* x = (const float2*)xv;
+    const float2* w = (const float2*)wv;
+    float2* y = (float2*)yv;
+    {   // pass x: compact (weighted) image rows -> full-length rows at the box's (y, z) positions
+        ig_prof_scope prof(ctx, "fft_pad_x", (double)(bvol + (w ? bvol : 0) + n0 * b1 * b2) * C * 8.0);
+        PassDesc d{};
+        d.in = x - l0; d.in_sj = 1; d.in_s[0] = b0; d.in_s[1] = b0 * b1; d.in_s[2] = x_bstride;
+        d.w = w ? w - l0 : nullptr; d.w_sj = 1; d.w_s[0] = b0; d.w_s[1] = b0 * b1; d.w_s[2] = bvol;
+        d.out = y + l1 * n0 + l2 * n0 * n1; d.out_sj = 1; d.out_s[0] = n0; d.out_s[1] = n0 * n1; d.out_s[2] = vol;
+        d.ext0 = b1; d.ext1 = b2; d.ncols = b1 * b2 * C;
+        d.in_lo = (int)l0; d.in_hi = (int)(l0 + b0); d.out_lo = 0; d.out_hi = (int)n0; d.inverse = 0;
+        if (int rc = launch_2stage(ctx, p->axis[0], d, true, w ? 1 : 0)) return rc;
+    }
+    {   // pass y: columns (kx, z in box), inputs y in box
+        ig_prof_scope prof(ctx, "fft_pad_y", (double)(n0 * b1 * b2 + n0 * n1 * b2) * C * 8.0);
+        PassDesc d{};
+        d.in = d.out = y + l2 * n0 * n1; d.in_sj = d.out_sj = n0;
+        d.in_s[0] = d.out_s[0] = 1; d.in_s[1] = d.out_s[1] = n0 * n1; d.in_s[2] = d.out_s[2] = vol;
+        d.ext0 = n0; d.ext1 = b2; d.ncols = n0 * b2 * C;
+        d.in_lo = (int)l1; d.in_hi = (int)(l1 + b1); d.out_lo = 0; d.out_hi = (int)n1; d.inverse = 0;
+        if (int rc = launch_2stage(ctx, p->axis[1], d, false, 0)) return rc;
+    }
+    {   // pass z: all columns (kx, ky), inputs z in box
+        ig_prof_scope prof(ctx, "fft_pad_z", (double)(n0 * n1 * b2 + vol) * C * 8.0);
+        PassDesc d{};
+        d.in = d.out = y; d.in_sj = d.out_sj = n0 * n1;
+        d.in_s[0] = d.out_s[0] = 1; d.in_s[1] = d.out_s[1] = n0; d.in_s[2] = d.out_s[2] = vol;
+        d.ext0 = n0; d.ext1 = n1; d.ncols = n0 * n1 * C;
+        d.in_lo = (int)l2; d.in_hi = (int)(l2 + b2); d.out_lo = 0; d.out_hi = (int)n2; d.inverse = 0;
+        if (int rc = launch_2stage(ctx, p->axis[2], d, false, 0)) return rc;
+    }
+    return IG_OK;
+}
+
+int ig_fft_exec_cropped(ig_fft* p, const void* yv, const void* wv, void* xv, int64_t x_bstride, void* workspace) {
+    if (!p) return ig_fail(nullptr, IG_ERR_ARG, "ig_fft_exec_cropped: plan is NULL");
+    ig_ctx* ctx = p->ctx;
+    IG_REQUIRE(ctx, p->padded, "ig_fft_exec_cropped: plan was not made by ig_fft_plan_padded");
+    IG_REQUIRE(ctx, xv && yv && workspace, "ig_fft_exec_cropped: NULL array");
+    if (int rc = ig_set_device(ctx)) return rc;
+    const int64_t n0 = p->dims[0], n1 = p->dims[1], n2 = p->dims[2];
+    const int64_t b0 = p->box_dims[0], b1 = p->box_dims[1], b2 = p->box_dims[2];
+    const int64_t l0 = p->box_lo[0], l1 = p->box_lo[1], l2 = p->box_lo[2];
+    const int64_t vol = n0 * n1 * n2, bvol = b0 * b1 * b2, C = p->batch;
+    const float2* y = (const float2*)yv;
+    const float2* w = (const float2*)wv;
+    float2* x = (float2*)xv;
+    float2* work = (float2*)workspace;
+    {   // pass z: all columns, keep z in box (input stays intact: written to the workspace)
+        ig_prof_scope prof(ctx, "fft_crop_z", (double)(vol + n0 * n1 * b2) * C * 8.0);
+        PassDesc d{};
+        d.in = y; d.out = work; d.in_sj = d.out_sj = n0 * n1;
+        d.in_s[0] = d.out_s[0] = 1; d.in_s[1] = d.out_s[1] = n0; d.in_s[2] = d.out_s[2] = vol;
+        d.ext0 = n0; d.ext1 = n1; d.ncols = n0 * n1 * C;
+        d.in_lo = 0; d.in_hi = (int)n2; d.out_lo = (int)l2; d.out_hi = (int)(l2 + b2); d.inverse = 1;
+        if (int rc = launch_2stage(ctx, p->axis[2], d, false, 0)) return rc;
+    }
+    {   // pass y: columns (kx, z in box), keep y in box
+        ig_prof_scope prof(ctx, "fft_crop_y", (double)(n0 * n1 * b2 + n0 * b1 * b2) * C * 8.0);
+        PassDesc d{};
+        d.in = d.out = work + l2 * n0 * n1; d.in_sj = d.out_sj = n0;
+        d.in_s[0] = d.out_s[0] = 1; d.in_s[1] = d.out_s[1] = n0 * n1; d.in_s[2] = d.out_s[2] = vol;
+        d.ext0 = n0; d.ext1 = b2; d.ncols = n0 * b2 * C;
+        d.in_lo = 0; d.in_hi = (int)n1; d.out_lo = (int)l1; d.out_hi = (int)(l1 + b1); d.inverse = 1;
+        if (int rc = launch_2stage(ctx, p->axis[1], d, false, 0)) return rc;
+    }
+    {   // pass x: rows (y, z in box), keep x in box, times conj(w), into the compact array
+        ig_prof_scope prof(ctx, "fft_crop_x", (double)(n0 * b1 * b2 + bvol + (w ? bvol : 0)) * C * 8.0);
+        PassDesc d{};
+        d.in = work + l1 * n0 + l2 * n0 * n1; d.in_sj = 1; d.in_s[0] = n0; d.in_s[1] = n0 * n1; d.in_s[2] = vol;
+        d.out = x - l0; d.out_sj = 1; d.out_s[0] = b0; d.out_s[1] = b0 * b1; d.out_s[2] = x_bstride;
+        d.w = w ? w - l0 : nullptr; d.w_sj = 1; d.w_s[0] = b0; d.w_s[1] = b0 * b1; d.w_s[2] = bvol;
+        d.ext0 = b1; d.ext1 = b2; d.ncols = b1 * b2 * C;
+        d.in_lo = 0; d.in_hi = (int)n0; d.out_lo = (int)l0; d.out_hi = (int)(l0 + b0); d.inverse = 1;
+        if (int rc = launch_2stage(ctx, p->axis[0], d, true, w ? 2 : 0)) return rc;
     }
     return IG_OK;
 }

@@ -278,6 +278,82 @@ class UnscaledFFT(MatrixFreeOperator):
         return self._backend._fft_workspace_size(self._ft_shape + (ncols,))
 
 
+class ZpadFFT(MatrixFreeOperator):
+    """Fused leaf  KronI(C, UnscaledFFT) * (I_C (x) Zpad) * VStack(Diag(w_c)):  image -> C oversampled k-space grids.
+
+        forward :  y[:, c] = FFT( zeropad( w[:, c] * x ) )                    shape (C*P, N)
+        adjoint :  x = sum_c conj(w[:, c]) * crop( IFFT( y[:, c] ) )
+
+    Mathematically this is the `KronI(C, fft) * S'` part of the reference's `-O3` SENSE tree
+    (examples/pics.py:104-193; Zpad backend.py:371-387, FFTc modulation :355-369, roll-off :439-440)
+    with the (C*P) x N CSR matrix S' replaced by its generator: a box position and one complex weight
+    per voxel and coil.  A backend that implements `fft_padded / ifft_cropped / sum_columns` can skip
+    the zero parts of the grid inside the transform; the numpy oracle implements the same three calls
+    with dense arrays, and tests pin both to the reference's S' + FFT composition.
+    """
+
+    def __init__(self, backend, grid_shape, box_shape, weights, box_lo=None, **kwargs):
+        self._grid = tuple(int(s) for s in grid_shape)
+        self._box = tuple(int(s) for s in box_shape)
+        assert len(self._grid) == 3 and len(self._box) == 3
+        if box_lo is None:      # centred, as Backend.Zpad(mode='center')
+            box_lo = tuple(m // 2 + int(np.ceil(-n / 2)) for m, n in zip(self._grid, self._box))
+        self._lo = tuple(int(s) for s in box_lo)
+        w = np.asfortranarray(np.asarray(weights, dtype=_C64))
+        assert w.shape[:3] == self._box, "weights must be box_shape + (ncoils,)"
+        self._C = int(w.shape[3])
+        self._w_h = w
+        self._w_d = None
+        P, N = int(np.prod(self._grid)), int(np.prod(self._box))
+        super().__init__(backend, shape=(self._C * P, N), **kwargs)
+
+    def _weights(self):
+        if self._w_d is None:
+            self._w_d = self._backend.copy_array(self._w_h.reshape((-1, self._C), order='F'), name=self._name + '.weights')
+            self._w_h = None
+        return self._w_d
+
+    def _trace(self, forward):
+        trace = getattr(self._backend, 'trace', None)
+        if trace is None:
+            return
+        # book what the reference's S' csrmm + batched FFT would move for the same result (SURVEY 8d)
+        P, N, C = int(np.prod(self._grid)), int(np.prod(self._box)), self._C
+        nnz = C * N
+        mat = nnz * 12 + (N + 1) * 4                  # S'^H stored as N x (C*P) CSR
+        if forward:
+            spmm = mat + N * 8 * 1.0 + C * P * 8 * 1
+        else:
+            spmm = mat + C * P * 8 * (nnz / (C * P)) + N * 8 * 1
+        trace.add('csrmm', nbytes=spmm, nflops=5 * nnz, name=self._name + '.S', forward=forward, fused=True)
+        trace.add('fft', nbytes=4 * C * P * 8, nflops=C * 5 * P * np.log2(P), name=self._name + '.F', forward=forward, fused=True)
+
+    def _eval(self, y, x, alpha=1, beta=0, forward=True, left=True):
+        B = self._backend
+        P, N, C = int(np.prod(self._grid)), int(np.prod(self._box)), self._C
+        ncols = x.shape[1]
+        w = self._weights()
+        for j in range(ncols):
+            xj = x if ncols == 1 else x[:, j:j + 1]
+            yj = y if ncols == 1 else y[:, j:j + 1]
+            self._trace(forward)
+            if forward:
+                assert beta == 0, "ZpadFFT forward expects beta == 0, got %s" % beta
+                B.fft_padded(yj.reshape((P, C)), xj, w, self._grid, self._lo, self._box)
+                if alpha != 1:
+                    B.scale(yj, alpha)
+            else:
+                with B.scratch(shape=(N, C)) as tmp:
+                    with B.scratch(nbytes=B._fft_padded_workspace(self._grid, self._lo, self._box, C)) as ws:
+                        B.ifft_cropped(tmp, xj.reshape((P, C)), w, self._grid, self._lo, self._box, ws)
+                    B.sum_columns(yj, tmp, alpha=alpha, beta=beta)
+
+    def _mem_usage(self, ncols):
+        N, C = int(np.prod(self._box)), self._C
+        ws = self._backend._fft_padded_workspace(self._grid, self._lo, self._box, C)
+        return (N * C * 8 + 255) // 256 * 256 + ws
+
+
 class Eye(MatrixFreeOperator):
     def __init__(self, backend, n, **kwargs):
         super().__init__(backend, shape=(n, n), **kwargs)

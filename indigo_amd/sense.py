@@ -111,6 +111,30 @@ class SenseProblem(object):
             data[:, j] = np.conj(base * maps[:, c])
         return spp.csr_matrix((data.reshape(-1), indices.reshape(-1), indptr), shape=(Nn, Cn * P))
 
+    def fused_weights(self, coils=None):
+        """w[..., c] = mod(box) * apod * maps[..., c]: the per-voxel, per-coil factor of S' (F-ordered, box + (C,))."""
+        coils = list(range(self.C) if coils is None else coils)
+        from indigo_amd.backends.backend import Backend
+        zrows = Backend.zpad_rows(self.oN, self.N)
+        mod = backend_mod(self.oN).reshape(-1, order='F')[zrows].reshape(self.N, order='F')
+        apod = rolloff3(self.oversamp, self.width, self.beta, self.N).astype(_C64)
+        base = (mod * apod).astype(_C64)
+        w = np.empty(self.N + (len(coils),), dtype=_C64, order='F')
+        for j, c in enumerate(coils):
+            np.multiply(base, self.maps[:, :, :, c], out=w[:, :, :, j])
+        return w
+
+    def build_zpadfft(self, backend, coils=None):
+        """A = KronI(C, G') * ZpadFFT: the `-O3` tree with S' and the FFT fused into one leaf
+        (zero-pad aware transform; needs backend.supports_padded_fft(grid))."""
+        coils = list(range(self.C) if coils is None else coils)
+        Cn = len(coils)
+        G = backend.SpMatrix(self.fused_interp(), name='interp*mod*scale')
+        Z = backend.ZpadFFT(self.oN, self.N, self.fused_weights(coils), name='fft*zpad*apod*maps')
+        A = backend.KronI(Cn, G) * Z
+        A._name = 'SENSE-fusedFFT'
+        return A
+
     def build_fused(self, backend, coils=None):
         coils = list(range(self.C) if coils is None else coils)
         Cn = len(coils)

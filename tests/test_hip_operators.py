@@ -184,3 +184,100 @@ def test_sense_medium_vs_oracle_and_properties(hip, oracle_backend):
     x_d = hip.copy_array(x)
     assert hip.cdot(x_d, y_d).real > 0 and abs(hip.cdot(x_d, y_d).imag) < 1e-3 * hip.cdot(x_d, y_d).real  # x^H AHA x real > 0
     hip._scratch = None
+
+
+# ---------------------------------------------------------------------------------------
+# fused zero-pad / crop transforms (ZpadFFT leaf)
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("grid,box,lo,C,weighted", [
+    ((256, 256, 256), (128, 128, 128), None, 3, True),
+    ((256, 256, 256), (100, 77, 130), (5, 100, 126), 2, True),
+    ((256, 512, 256), (128, 256, 32), None, 1, False),
+    ((256, 256, 256), (256, 256, 256), (0, 0, 0), 2, True),          # no padding at all
+])
+def test_padded_and_cropped_fft_leaves(hip, grid, box, lo, C, weighted):
+    """fft_padded == fftn(zero-pad(w*x)) and ifft_cropped == conj(w)*crop(ifftn(y)), both computed on the GPU
+    by the plain (dense) transform of the same library, plus the adjoint identity between the two."""
+    hip._scratch = None
+    lo = lo or tuple(m // 2 + int(np.ceil(-n / 2)) for m, n in zip(grid, box))
+    P, N = int(np.prod(grid)), int(np.prod(box))
+    x = rand64c(N, 1, seed=1)
+    w = rand64c(N, C, seed=2) if weighted else None
+    w_d = hip.copy_array(w) if weighted else None
+    sl = tuple(slice(l, l + b) for l, b in zip(lo, box))
+    # dense reference on the same GPU: explicit zero-padded array through the plain transform
+    full = np.zeros(grid + (C,), dtype=C64, order='F')
+    full[sl + (slice(None),)] = (w if weighted else np.ones((N, C), C64)).reshape(box + (C,), order='F') * x.reshape(box + (1,), order='F')
+    full_d = hip.copy_array(full)
+    ref_d = hip.zero_array(full.shape, C64)
+    hip.fftn(ref_d, full_d)
+    y_d = hip.copy_array(np.full((P, C), np.nan, dtype=C64, order='F'))       # every element must be overwritten
+    hip.fft_padded(y_d, hip.copy_array(x), w_d, grid, lo, box)
+    y = y_d.to_host()
+    assert rel_err(y, ref_d.to_host().reshape(P, C, order='F')) < 2e-6
+    # cropped inverse of a random grid panel
+    k = rand64c(P, C, seed=3)
+    k_d = hip.copy_array(k)
+    inv_d = hip.zero_array(grid + (C,), C64)
+    hip.ifftn(inv_d, k_d.reshape(grid + (C,)))
+    exp = inv_d.to_host()[sl + (slice(None),)].reshape(N, C, order='F')
+    if weighted:
+        exp = np.conj(w) * exp
+    xc_d = hip.copy_array(np.full((N, C), np.nan, dtype=C64, order='F'))
+    ws = hip.zero_array((hip._fft_padded_workspace(grid, lo, box, C) // 8,), C64)
+    hip.ifft_cropped(xc_d, k_d, w_d, grid, lo, box, ws)
+    np.testing.assert_array_equal(k_d.to_host(), k)                           # the input panel stays intact
+    assert rel_err(xc_d.to_host(), exp) < 2e-6
+    # <F x, k> == <x, F^H k>
+    s_d = hip.zero_array((N, 1), C64)
+    hip.sum_columns(s_d, xc_d)
+    np.testing.assert_allclose(np.vdot(k, y), np.vdot(s_d.to_host(), x), rtol=1e-4)
+
+
+def test_sum_columns(hip):
+    X = rand64c(1000, 7, seed=1)
+    y = rand64c(1000, 1, seed=2)
+    Xd = hip.copy_array(rand64c(1003, 7, seed=3))
+    Xd[2:1002, :].copy_from(X)
+    y_d = hip.copy_array(y)
+    hip.sum_columns(y_d, Xd[2:1002, :], alpha=0.5 - 1j, beta=2.0)
+    np.testing.assert_allclose(y_d.to_host(), 2.0 * y + (0.5 - 1j) * X.sum(axis=1, keepdims=True), rtol=1e-5, atol=1e-5)
+    hip.sum_columns(y_d, Xd[2:1002, :])
+    np.testing.assert_allclose(y_d.to_host(), X.sum(axis=1, keepdims=True), rtol=1e-5, atol=1e-5)
+
+
+def test_zpadfft_operator_matches_reference_composition(hip, oracle_backend):
+    """ZpadFFT == KronI(C, fft) * S' (the reference's -O3 leaves) on the GPU, and == the oracle's ZpadFFT;
+    SENSE through it == SENSE through the -O3 tree; alpha/beta handling of the adjoint."""
+    p = SenseProblem.synthetic((128, 128, 128), 3, nspokes=300, nreadout=256, width=2, oversamp=2.0, seed=4)
+    assert hip.supports_padded_fft(p.oN)
+    hip._scratch = None
+    oracle_backend._scratch = None
+    A_ref = p.build_fused(hip)                   # G' * (KronI(fft) * S'), leaves pinned by the goldens
+    A = p.build_zpadfft(hip)
+    A_o = p.build_zpadfft(oracle_backend)
+    x = rand64c(A.shape[1], 1, seed=1)
+    k = rand64c(A.shape[0], 1, seed=2)
+    Ax, AHk = A * x, A.H * k
+    assert rel_err(Ax, A_ref * x) < RTOL and rel_err(AHk, A_ref.H * k) < RTOL
+    assert rel_err(Ax, A_o * x) < RTOL and rel_err(AHk, A_o.H * k) < RTOL
+    y0 = rand64c(A.shape[1], 1, seed=5)
+    got = _eval(A.H, hip, y0, k, alpha=0.5 + 0.25j, beta=-1.5)
+    assert rel_err(got, (0.5 + 0.25j) * AHk - 1.5 * y0) < RTOL
+    AHA, AHA_ref = normal_operator(A, lamda=0.2), None
+    tr = Trace()
+    hip.trace = tr
+    y_d = hip.zero_array((A.shape[1], 1), C64)
+    AHA.eval(y_d, hip.copy_array(x))
+    hip.trace = None
+    hip._scratch = None
+    AHA_ref = normal_operator(A_ref, lamda=0.2)
+    tr2 = Trace()
+    hip.trace = tr2
+    y2_d = hip.zero_array((A.shape[1], 1), C64)
+    AHA_ref.eval(y2_d, hip.copy_array(x))
+    hip.trace = None
+    assert rel_err(y_d.to_host(), y2_d.to_host()) < RTOL
+    # the fused leaf books the same algorithmic bytes as the leaves it replaces
+    np.testing.assert_allclose(tr.total_bytes(), tr2.total_bytes(), rtol=1e-3)
+    hip._scratch = None
