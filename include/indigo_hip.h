@@ -186,11 +186,15 @@ int  ig_fft_describe(ig_fft* plan, char* buf, size_t len);   /* kernel / radix s
  * shared by all members, as in SENSE where the coils share the image).
  *   padded :  Y[..,c] = FFT3( zeropad( w[..,c] .* x[..,c] ) )            unnormalised, forward
  *   cropped:  x[..,c] = conj(w[..,c]) .* crop( IFFT3( Y[..,c] ) )        unnormalised, inverse
- * Y is a full grid x batch array; the cropped transform leaves Y intact and needs
- * workspace_bytes (= one grid x batch array) of scratch.                                      */
+ * Y is a full grid x batch array; the cropped transform leaves Y intact.  Both need
+ * workspace_bytes of scratch (a grid x batch array plus a compact intermediate; the padded
+ * transform only uses it for grid_layout 1).
+ * grid_layout: memory order of Y.  0 = (x, y, z), the reference's Fortran order; 1 = (x, z, y), i.e.
+ * element (kx, ky, kz) at kx + n0*kz + n0*n2*ky -- an internal order that keeps the largest axis pass
+ * at a 4 KB stride; the consumer of Y (the gridding matrix) must be indexed the same way.      */
 int  ig_fft_plan_padded(ig_ctx* ctx, const int64_t* dims, const int64_t* box_lo, const int64_t* box_dims,
-                        int64_t batch, ig_fft** plan, size_t* workspace_bytes);
-int  ig_fft_exec_padded(ig_fft* plan, const void* x, int64_t x_bstride, const void* w, void* y);
+                        int64_t batch, int grid_layout, ig_fft** plan, size_t* workspace_bytes);
+int  ig_fft_exec_padded(ig_fft* plan, const void* x, int64_t x_bstride, const void* w, void* y, void* workspace);
 int  ig_fft_exec_cropped(ig_fft* plan, const void* y, const void* w, void* x, int64_t x_bstride, void* workspace);
 int  ig_fft_destroy(ig_fft* plan);
 

@@ -58,9 +58,9 @@ PROTOTYPES = {
     "ig_fft_exec":        (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ig_fft_describe":    (c_int, [c_void_p, c_char_p, c_size_t]),
     "ig_fft_destroy":     (c_int, [c_void_p]),
-    "ig_fft_plan_padded": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), c_int64,
+    "ig_fft_plan_padded": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), c_int64, c_int,
                                    POINTER(c_void_p), POINTER(c_size_t)]),
-    "ig_fft_exec_padded": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "ig_fft_exec_padded": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "ig_fft_exec_cropped": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
 }
 

@@ -429,15 +429,16 @@ class Backend(object):
 
     # fused zero-pad/crop transforms used by operators.ZpadFFT (not part of the reference's contract:
     # they replace its Zpad-CSR + FFT composition; see include/indigo_hip.h ig_fft_exec_padded)
-    def fft_padded(self, y, x, w, grid, box_lo, box_dims):
-        """y[:, c] = FFT(zeropad(w[:, c] * x)); y: (prod grid, C), x: (prod box, 1), w: (prod box, C)"""
+    def fft_padded(self, y, x, w, grid, box_lo, box_dims, workspace=None, layout=0):
+        """y[:, c] = FFT(zeropad(w[:, c] * x)); y: (prod grid, C), x: (prod box, 1), w: (prod box, C).
+        layout 1 stores each grid in (x, z, y) memory order instead of (x, y, z)."""
         raise NotImplementedError()
 
-    def ifft_cropped(self, xc, y, w, grid, box_lo, box_dims, workspace):
+    def ifft_cropped(self, xc, y, w, grid, box_lo, box_dims, workspace, layout=0):
         """xc[:, c] = conj(w[:, c]) * crop(IFFT(y[:, c])); xc: (prod box, C), y: (prod grid, C) left intact"""
         raise NotImplementedError()
 
-    def _fft_padded_workspace(self, grid, box_lo, box_dims, batch):
+    def _fft_padded_workspace(self, grid, box_lo, box_dims, batch, layout=0):
         return 0
 
     def sum_columns(self, y, X, alpha=1, beta=0):

@@ -312,34 +312,38 @@ class HipBackend(Backend):
     def supports_padded_fft(self, grid):
         return len(grid) == 3 and all(int(n) in (256, 512) for n in grid)
 
-    def _padded_plan(self, grid, box_lo, box_dims, batch):
-        key = ('padded', tuple(grid), tuple(box_lo), tuple(box_dims), int(batch))
+    def _padded_plan(self, grid, box_lo, box_dims, batch, layout=0):
+        key = ('padded', tuple(grid), tuple(box_lo), tuple(box_dims), int(batch), int(layout))
         if key not in self._plans:
             a3 = ctypes.c_int64 * 3
             plan, ws = ctypes.c_void_p(), ctypes.c_size_t()
             self._check(self._L.ig_fft_plan_padded(self._ctx, a3(*grid), a3(*box_lo), a3(*box_dims), int(batch),
-                                                   ctypes.byref(plan), ctypes.byref(ws)), "ig_fft_plan_padded%s" % (key,))
+                                                   int(layout), ctypes.byref(plan), ctypes.byref(ws)),
+                        "ig_fft_plan_padded%s" % (key,))
             self._plans[key] = (plan, ws.value)
         return self._plans[key]
 
-    def _fft_padded_workspace(self, grid, box_lo, box_dims, batch):
-        return self._padded_plan(grid, box_lo, box_dims, batch)[1]
+    def _fft_padded_workspace(self, grid, box_lo, box_dims, batch, layout=0):
+        return self._padded_plan(grid, box_lo, box_dims, batch, layout)[1]
 
-    def fft_padded(self, y, x, w, grid, box_lo, box_dims):
+    def fft_padded(self, y, x, w, grid, box_lo, box_dims, workspace=None, layout=0):
         C = y.shape[1]
         assert y.dtype == _C64 and x.dtype == _C64 and y.contiguous and x.contiguous
         assert y.shape[0] == int(np.prod(grid)) and x.size == int(np.prod(box_dims))
         assert w is None or (w.contiguous and w.size == x.size * C)
-        plan, _ = self._padded_plan(grid, box_lo, box_dims, C)
+        plan, ws = self._padded_plan(grid, box_lo, box_dims, C, layout)
+        assert layout == 0 or (workspace is not None and workspace.nbytes >= ws)
         self._check(self._L.ig_fft_exec_padded(plan, ctypes.c_void_p(x._arr), 0,
                                                ctypes.c_void_p(w._arr) if w is not None else None,
-                                               ctypes.c_void_p(y._arr)), "ig_fft_exec_padded")
+                                               ctypes.c_void_p(y._arr),
+                                               ctypes.c_void_p(workspace._arr) if workspace is not None else None),
+                    "ig_fft_exec_padded")
 
-    def ifft_cropped(self, xc, y, w, grid, box_lo, box_dims, workspace):
+    def ifft_cropped(self, xc, y, w, grid, box_lo, box_dims, workspace, layout=0):
         C = y.shape[1]
         assert y.dtype == _C64 and xc.dtype == _C64 and y.contiguous and xc.contiguous
         assert xc.shape == (int(np.prod(box_dims)), C)
-        plan, ws = self._padded_plan(grid, box_lo, box_dims, C)
+        plan, ws = self._padded_plan(grid, box_lo, box_dims, C, layout)
         assert workspace.nbytes >= ws
         self._check(self._L.ig_fft_exec_cropped(plan, ctypes.c_void_p(y._arr),
                                                 ctypes.c_void_p(w._arr) if w is not None else None,

@@ -292,7 +292,8 @@ class ZpadFFT(MatrixFreeOperator):
     with dense arrays, and tests pin both to the reference's S' + FFT composition.
     """
 
-    def __init__(self, backend, grid_shape, box_shape, weights, box_lo=None, **kwargs):
+    def __init__(self, backend, grid_shape, box_shape, weights, box_lo=None, layout=0, **kwargs):
+        self._layout = int(layout)     # memory order of each output grid: 0 = (x, y, z), 1 = (x, z, y)
         self._grid = tuple(int(s) for s in grid_shape)
         self._box = tuple(int(s) for s in box_shape)
         assert len(self._grid) == 3 and len(self._box) == 3
@@ -339,19 +340,25 @@ class ZpadFFT(MatrixFreeOperator):
             self._trace(forward)
             if forward:
                 assert beta == 0, "ZpadFFT forward expects beta == 0, got %s" % beta
-                B.fft_padded(yj.reshape((P, C)), xj, w, self._grid, self._lo, self._box)
+                if self._layout:
+                    with B.scratch(nbytes=self._ws_bytes()) as ws:
+                        B.fft_padded(yj.reshape((P, C)), xj, w, self._grid, self._lo, self._box, ws, self._layout)
+                else:
+                    B.fft_padded(yj.reshape((P, C)), xj, w, self._grid, self._lo, self._box)
                 if alpha != 1:
                     B.scale(yj, alpha)
             else:
                 with B.scratch(shape=(N, C)) as tmp:
-                    with B.scratch(nbytes=B._fft_padded_workspace(self._grid, self._lo, self._box, C)) as ws:
-                        B.ifft_cropped(tmp, xj.reshape((P, C)), w, self._grid, self._lo, self._box, ws)
+                    with B.scratch(nbytes=self._ws_bytes()) as ws:
+                        B.ifft_cropped(tmp, xj.reshape((P, C)), w, self._grid, self._lo, self._box, ws, self._layout)
                     B.sum_columns(yj, tmp, alpha=alpha, beta=beta)
+
+    def _ws_bytes(self):
+        return self._backend._fft_padded_workspace(self._grid, self._lo, self._box, self._C, self._layout)
 
     def _mem_usage(self, ncols):
         N, C = int(np.prod(self._box)), self._C
-        ws = self._backend._fft_padded_workspace(self._grid, self._lo, self._box, C)
-        return (N * C * 8 + 255) // 256 * 256 + ws
+        return (N * C * 8 + 255) // 256 * 256 + self._ws_bytes()
 
 
 class Eye(MatrixFreeOperator):

@@ -79,8 +79,9 @@ class SenseProblem(object):
         return A
 
     # -- direct construction of the -O3 factors ------------------------------------------------
-    def fused_interp(self):
-        """G' = interp * mod * (1/sqrt(P)) as a complex64 CSR (T x P)."""
+    def fused_interp(self, layout=0):
+        """G' = interp * mod * (1/sqrt(P)) as a complex64 CSR (T x P).
+        layout=1 indexes the grid columns in (x, z, y) memory order (see operators.ZpadFFT)."""
         P = int(np.prod(self.oN))
         indptr, indices, w = interp_csr_arrays(self.T, self.oN, self.width, self.table,
                                                self.coord.reshape(3, -1, order='F'), dtype=np.float32)
@@ -88,6 +89,15 @@ class SenseProblem(object):
         scale = np.complex64(np.float32(1.0) / np.sqrt(np.float32(P)))
         data = w.astype(_C64) * mod[indices]
         data *= scale
+        if layout == 1:
+            n0, n1, n2 = self.oN
+            kx = indices % n0
+            ky = (indices // n0) % n1
+            kz = indices // (n0 * n1)
+            indices = (kx + n0 * (kz + n2 * ky)).astype(np.int32)
+            G = spp.csr_matrix((data, indices, indptr), shape=(self.T, P))
+            G.sort_indices()
+            return G
         return spp.csr_matrix((data, indices, indptr), shape=(self.T, P))
 
     def fused_maps_T(self, coils=None):
@@ -124,13 +134,15 @@ class SenseProblem(object):
             np.multiply(base, self.maps[:, :, :, c], out=w[:, :, :, j])
         return w
 
-    def build_zpadfft(self, backend, coils=None):
+    def build_zpadfft(self, backend, coils=None, layout=1):
         """A = KronI(C, G') * ZpadFFT: the `-O3` tree with S' and the FFT fused into one leaf
-        (zero-pad aware transform; needs backend.supports_padded_fft(grid))."""
+        (zero-pad aware transform; needs backend.supports_padded_fft(grid)).  The oversampled grid is
+        private to this pair of leaves, so it may live in the (x, z, y) order (layout=1) that keeps the
+        transform's largest pass at a small stride; G' is indexed to match."""
         coils = list(range(self.C) if coils is None else coils)
         Cn = len(coils)
-        G = backend.SpMatrix(self.fused_interp(), name='interp*mod*scale')
-        Z = backend.ZpadFFT(self.oN, self.N, self.fused_weights(coils), name='fft*zpad*apod*maps')
+        G = backend.SpMatrix(self.fused_interp(layout), name='interp*mod*scale')
+        Z = backend.ZpadFFT(self.oN, self.N, self.fused_weights(coils), layout=layout, name='fft*zpad*apod*maps')
         A = backend.KronI(Cn, G) * Z
         A._name = 'SENSE-fusedFFT'
         return A

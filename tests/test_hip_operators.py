@@ -189,13 +189,30 @@ def test_sense_medium_vs_oracle_and_properties(hip, oracle_backend):
 # ---------------------------------------------------------------------------------------
 # fused zero-pad / crop transforms (ZpadFFT leaf)
 # ---------------------------------------------------------------------------------------
-@pytest.mark.parametrize("grid,box,lo,C,weighted", [
-    ((256, 256, 256), (128, 128, 128), None, 3, True),
-    ((256, 256, 256), (100, 77, 130), (5, 100, 126), 2, True),
-    ((256, 512, 256), (128, 256, 32), None, 1, False),
-    ((256, 256, 256), (256, 256, 256), (0, 0, 0), 2, True),          # no padding at all
+def _to_layout(v4, layout):
+    """(x, y, z, c) host array -> (P, C) in the grid's memory order"""
+    if layout == 1:
+        v4 = v4.transpose(0, 2, 1, 3)
+    return np.asfortranarray(v4.reshape(-1, v4.shape[3], order='F'))
+
+
+def _from_layout(flat, grid, layout):
+    C = flat.shape[1]
+    if layout == 1:
+        return flat.reshape((grid[0], grid[2], grid[1], C), order='F').transpose(0, 2, 1, 3)
+    return flat.reshape(tuple(grid) + (C,), order='F')
+
+
+@pytest.mark.parametrize("grid,box,lo,C,weighted,layout", [
+    ((256, 256, 256), (128, 128, 128), None, 3, True, 0),
+    ((256, 256, 256), (128, 128, 128), None, 3, True, 1),
+    ((256, 256, 256), (100, 77, 130), (5, 100, 126), 2, True, 0),
+    ((256, 256, 256), (100, 77, 130), (5, 100, 126), 2, True, 1),
+    ((256, 512, 256), (128, 256, 32), None, 1, False, 0),
+    ((512, 256, 256), (128, 200, 32), None, 2, False, 1),
+    ((256, 256, 256), (256, 256, 256), (0, 0, 0), 2, True, 1),       # no padding at all
 ])
-def test_padded_and_cropped_fft_leaves(hip, grid, box, lo, C, weighted):
+def test_padded_and_cropped_fft_leaves(hip, grid, box, lo, C, weighted, layout):
     """fft_padded == fftn(zero-pad(w*x)) and ifft_cropped == conj(w)*crop(ifftn(y)), both computed on the GPU
     by the plain (dense) transform of the same library, plus the adjoint identity between the two."""
     hip._scratch = None
@@ -212,26 +229,28 @@ def test_padded_and_cropped_fft_leaves(hip, grid, box, lo, C, weighted):
     ref_d = hip.zero_array(full.shape, C64)
     hip.fftn(ref_d, full_d)
     y_d = hip.copy_array(np.full((P, C), np.nan, dtype=C64, order='F'))       # every element must be overwritten
-    hip.fft_padded(y_d, hip.copy_array(x), w_d, grid, lo, box)
+    ws = hip.zero_array((hip._fft_padded_workspace(grid, lo, box, C, layout) // 8,), C64)
+    hip.fft_padded(y_d, hip.copy_array(x), w_d, grid, lo, box, ws, layout)
     y = y_d.to_host()
-    assert rel_err(y, ref_d.to_host().reshape(P, C, order='F')) < 2e-6
-    # cropped inverse of a random grid panel
+    assert rel_err(y, _to_layout(ref_d.to_host(), layout)) < 2e-6
+    # cropped inverse of a random grid panel (given in the grid's memory order)
     k = rand64c(P, C, seed=3)
     k_d = hip.copy_array(k)
     inv_d = hip.zero_array(grid + (C,), C64)
-    hip.ifftn(inv_d, k_d.reshape(grid + (C,)))
+    hip.ifftn(inv_d, hip.copy_array(np.asfortranarray(_from_layout(k, grid, layout))))
     exp = inv_d.to_host()[sl + (slice(None),)].reshape(N, C, order='F')
     if weighted:
         exp = np.conj(w) * exp
     xc_d = hip.copy_array(np.full((N, C), np.nan, dtype=C64, order='F'))
-    ws = hip.zero_array((hip._fft_padded_workspace(grid, lo, box, C) // 8,), C64)
-    hip.ifft_cropped(xc_d, k_d, w_d, grid, lo, box, ws)
+    hip.ifft_cropped(xc_d, k_d, w_d, grid, lo, box, ws, layout)
     np.testing.assert_array_equal(k_d.to_host(), k)                           # the input panel stays intact
     assert rel_err(xc_d.to_host(), exp) < 2e-6
     # <F x, k> == <x, F^H k>
     s_d = hip.zero_array((N, 1), C64)
     hip.sum_columns(s_d, xc_d)
-    np.testing.assert_allclose(np.vdot(k, y), np.vdot(s_d.to_host(), x), rtol=1e-4)
+    c128 = np.complex128            # float32 accumulation over ~1e8 terms is itself only good to ~1e-4
+    np.testing.assert_allclose(np.vdot(k.astype(c128), y.astype(c128)),
+                               np.vdot(s_d.to_host().astype(c128), x.astype(c128)), rtol=1e-4)
 
 
 def test_sum_columns(hip):
@@ -254,13 +273,15 @@ def test_zpadfft_operator_matches_reference_composition(hip, oracle_backend):
     hip._scratch = None
     oracle_backend._scratch = None
     A_ref = p.build_fused(hip)                   # G' * (KronI(fft) * S'), leaves pinned by the goldens
-    A = p.build_zpadfft(hip)
-    A_o = p.build_zpadfft(oracle_backend)
+    A = p.build_zpadfft(hip)                     # grid in (x, z, y) order, G' permuted to match
+    A_o = p.build_zpadfft(oracle_backend, layout=0)
+    A_l0 = p.build_zpadfft(hip, layout=0)
     x = rand64c(A.shape[1], 1, seed=1)
     k = rand64c(A.shape[0], 1, seed=2)
     Ax, AHk = A * x, A.H * k
     assert rel_err(Ax, A_ref * x) < RTOL and rel_err(AHk, A_ref.H * k) < RTOL
     assert rel_err(Ax, A_o * x) < RTOL and rel_err(AHk, A_o.H * k) < RTOL
+    assert rel_err(A_l0 * x, Ax) < RTOL and rel_err(A_l0.H * k, AHk) < RTOL
     y0 = rand64c(A.shape[1], 1, seed=5)
     got = _eval(A.H, hip, y0, k, alpha=0.5 + 0.25j, beta=-1.5)
     assert rel_err(got, (0.5 + 0.25j) * AHk - 1.5 * y0) < RTOL

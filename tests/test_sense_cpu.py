@@ -69,17 +69,22 @@ def test_nufft_apply(prob, oracle_backend):
     assert rel_err(x_d.to_host(), g["nufft_adj"]) < 1e-5
 
 
-@pytest.mark.parametrize("level", [0, 1, 2, 3, "fused", "zpadfft"])
+@pytest.mark.parametrize("level", [0, 1, 2, 3, "fused", "zpadfft", "zpadfft-xyz"])
 def test_sense_forward_adjoint_normal(prob, oracle_backend, level):
     p, g = prob
     B = oracle_backend
     if hasattr(B, '_scratch'):
         B._scratch = None
-    A = p.build_fused(B) if level == "fused" else p.build_zpadfft(B) if level == "zpadfft" else p.build_tree(B, level=level)
+    if level == "fused":
+        A = p.build_fused(B)
+    elif level in ("zpadfft", "zpadfft-xyz"):
+        A = p.build_zpadfft(B, layout=1 if level == "zpadfft" else 0)
+    else:
+        A = p.build_tree(B, level=level)
     x, k = g["sense_x"], g["sense_k"]
     assert rel_err(A * x, g["sense_Ax"]) < 1e-5
     assert rel_err(A.H * k, g["sense_AHk"]) < 1e-5
-    if level in (3, "fused", "zpadfft"):
+    if level in (3, "fused", "zpadfft", "zpadfft-xyz"):
         assert rel_err(A * x, g["sense_O3_Ax"]) < 1e-5
         assert rel_err(A.H * k, g["sense_O3_AHk"]) < 1e-5
     AHA = normal_operator(A, lamda=float(g["lamda"]))
