@@ -30,25 +30,34 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-# profile-scope name (call site) -> device kernel symbol as rocprofv3 prints it
+# profile-scope name (call site) -> device kernel symbol as rocprofv3 prints it (512-point axes)
 KERNEL_SYMBOL = {
-    "fft_2stage_axis0": "k_fft_2stage<32, 16, 16, 16, true>",
-    "fft_2stage_axis1": "k_fft_2stage<32, 16, 16, 16, false>",
-    "fft_2stage_axis2": "k_fft_2stage<32, 16, 16, 16, false>",
+    "fft_2stage_axis0": "k_fft_2stage<32, 16, 16, 16, true, 0, false>",
+    "fft_2stage_axis1": "k_fft_2stage<32, 16, 16, 16, false, 0, false>",
+    "fft_2stage_axis2": "k_fft_2stage<32, 16, 16, 16, false, 0, false>",
+    # zero-pad-aware passes of the fused ZpadFFT leaf: the four strided ones are one device kernel
+    "fft_pad_x": "k_fft_2stage<32, 16, 16, 16, true, 1, true>",
+    "fft_crop_x": "k_fft_2stage<32, 16, 16, 16, true, 2, true>",
+    "fft_pad_y": "k_fft_2stage<32, 16, 16, 16, false, 0, true>",
+    "fft_pad_z": "k_fft_2stage<32, 16, 16, 16, false, 0, true>",
+    "fft_crop_y": "k_fft_2stage<32, 16, 16, 16, false, 0, true>",
+    "fft_crop_z": "k_fft_2stage<32, 16, 16, 16, false, 0, true>",
 }
+PMC_SUMMARY = os.path.join("profiles", "r01e_pmc_traffic.json")
 
 
-def pmc_traffic(kernel, grid, ncoils):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (profiles/), if that
-    summary was taken on the same panel shape (512^3 x 8); otherwise None.  PMC counters cannot be read
-    from inside the benchmark process, so this figure comes from the profile run of the same kernel."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_fft512x8_traffic.json")
-    if not os.path.exists(path) or tuple(grid) != (512, 512, 512) or ncoils != 8:
+def pmc_traffic(kernel, grid, ncoils, image):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (profiles/), valid only
+    for the configuration it was taken on (image 256^3, grid 512^3, 8 coils on one GPU); otherwise None.
+    PMC counters cannot be read from inside the benchmark process, so this figure comes from the
+    separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same script."""
+    path = os.path.join(ROOT, PMC_SUMMARY)
+    if not os.path.exists(path) or tuple(grid) != (512, 512, 512) or ncoils != 8 or image != 256:
         return None, None
     d = json.load(open(path)).get(kernel)
     if not d:
         return None, None
-    return d["hbm_bytes_per_launch"], "profiles/r01_pmc_fft512x8_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2)"
+    return d["hbm_bytes_per_launch"], PMC_SUMMARY + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE x2 per the gfx950 note)"
 
 
 def parse():
@@ -167,7 +176,7 @@ def main():
         avg_ms = d['total_ms'] / d['launches']
         per_launch_bytes = d['bytes'] / d['launches'] if d['bytes'] else None
         achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9 if per_launch_bytes else None
-        traffic, traffic_src = pmc_traffic(dom, p.oN, len(coils))
+        traffic, traffic_src = pmc_traffic(dom, p.oN, len(coils), img)
         roofline = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=(achieved / HBM_PEAK_GBS) if achieved else None, traffic=traffic,
                         traffic_source=traffic_src, avg_launch_ms=avg_ms, launches=d['launches'],
