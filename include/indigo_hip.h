@@ -150,6 +150,18 @@ int  ig_ccsrmm_t(ig_ctx* ctx,
                  float beta_re, float beta_im,
                  void* Y, int64_t ldy);
 
+/* ig_ccsrmm_t restricted to a support region of a 3-D grid of output rows: row = kx + n0*(km + nm*ks);
+ * rows with km outside support[2*(ks*(n0/16) + kx/16) + {0,1}] = [lo, hi) are neither computed nor
+ * written (they hold no nonzero by construction of the table).  Same table as ig_fft_exec_cropped.  */
+int  ig_ccsrmm_t_grid(ig_ctx* ctx,
+                      int64_t M, int64_t K, int64_t N, int64_t nnz,
+                      float alpha_re, float alpha_im,
+                      const void* vals_t, const int32_t* colind_t, const int32_t* rowptr_t,
+                      const void* X, int64_t ldx,
+                      float beta_re, float beta_im,
+                      void* Y, int64_t ldy,
+                      const int16_t* support, int64_t n0, int64_t nm);
+
 /* Host-side structure analysis.  Replaces `inspect`
  * (indigo/backends/_customcpu.c:179-215): number of non-empty rows / columns
  * and exwrite = "every column has <= 1 nonzero".  Pointers are HOST memory. */
@@ -194,8 +206,15 @@ int  ig_fft_describe(ig_fft* plan, char* buf, size_t len);   /* kernel / radix s
  * at a 4 KB stride; the consumer of Y (the gridding matrix) must be indexed the same way.      */
 int  ig_fft_plan_padded(ig_ctx* ctx, const int64_t* dims, const int64_t* box_lo, const int64_t* box_dims,
                         int64_t batch, int grid_layout, ig_fft** plan, size_t* workspace_bytes);
-int  ig_fft_exec_padded(ig_fft* plan, const void* x, int64_t x_bstride, const void* w, void* y, void* workspace);
-int  ig_fft_exec_cropped(ig_fft* plan, const void* y, const void* w, void* x, int64_t x_bstride, void* workspace);
+/* support (optional, grid_layout 1 only; may be NULL): the k-space support of the gridding matrix that
+ * consumes / produced Y, as int16 pairs support[2*(ky*(n0/16) + kx/16) + {0,1}] = [z_lo, z_hi): the
+ * padded transform then only guarantees kz inside the range (the rest of Y is undefined and must not
+ * be read), the cropped transform reads only kz inside it (the rest counts as zero and may hold
+ * anything).  A radial trajectory covers a ball, 52 % of the grid cube.                        */
+int  ig_fft_exec_padded(ig_fft* plan, const void* x, int64_t x_bstride, const void* w, void* y, void* workspace,
+                        const int16_t* support);
+int  ig_fft_exec_cropped(ig_fft* plan, const void* y, const void* w, void* x, int64_t x_bstride, void* workspace,
+                         const int16_t* support);
 int  ig_fft_destroy(ig_fft* plan);
 
 #ifdef __cplusplus

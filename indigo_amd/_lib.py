@@ -50,6 +50,10 @@ PROTOTYPES = {
     "ig_ccsrmm_t":        (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64,
                                    c_float, c_float, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_int64, c_float, c_float, c_void_p, c_int64]),
+    "ig_ccsrmm_t_grid":   (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64,
+                                   c_float, c_float, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_int64, c_float, c_float, c_void_p, c_int64,
+                                   c_void_p, c_int64, c_int64]),
     "ig_csr_inspect":     (c_int, [c_void_p, c_void_p, c_int64, c_int64,
                                    POINTER(c_int64), POINTER(c_int64), POINTER(c_int)]),
     "ig_csr_transpose":   (c_int, [c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
@@ -60,8 +64,8 @@ PROTOTYPES = {
     "ig_fft_destroy":     (c_int, [c_void_p]),
     "ig_fft_plan_padded": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), c_int64, c_int,
                                    POINTER(c_void_p), POINTER(c_size_t)]),
-    "ig_fft_exec_padded": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
-    "ig_fft_exec_cropped": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "ig_fft_exec_padded": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ig_fft_exec_cropped": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
 }
 
 

@@ -429,12 +429,12 @@ class Backend(object):
 
     # fused zero-pad/crop transforms used by operators.ZpadFFT (not part of the reference's contract:
     # they replace its Zpad-CSR + FFT composition; see include/indigo_hip.h ig_fft_exec_padded)
-    def fft_padded(self, y, x, w, grid, box_lo, box_dims, workspace=None, layout=0):
+    def fft_padded(self, y, x, w, grid, box_lo, box_dims, workspace=None, layout=0, support=None):
         """y[:, c] = FFT(zeropad(w[:, c] * x)); y: (prod grid, C), x: (prod box, 1), w: (prod box, C).
         layout 1 stores each grid in (x, z, y) memory order instead of (x, y, z)."""
         raise NotImplementedError()
 
-    def ifft_cropped(self, xc, y, w, grid, box_lo, box_dims, workspace, layout=0):
+    def ifft_cropped(self, xc, y, w, grid, box_lo, box_dims, workspace, layout=0, support=None):
         """xc[:, c] = conj(w[:, c]) * crop(IFFT(y[:, c])); xc: (prod box, C), y: (prod grid, C) left intact"""
         raise NotImplementedError()
 
@@ -511,6 +511,12 @@ class Backend(object):
             self._check_panels(y, x, self.values)
             self._backend.ccsrmm(y, self.shape, self.colInds, self.rowPtrs, self.values,
                                  x, alpha=alpha, beta=beta, adjoint=True, exwrite=self._exwrite)
+
+        def set_grid_support(self, table, n0, nm):
+            """Hint: the columns of this matrix index a 3-D grid and only the tabulated support is ever
+            non-zero / read in an adjoint product.  Backends may ignore it (the result inside the support
+            is the same either way)."""
+            pass
 
         @property
         def nbytes(self):

@@ -326,7 +326,7 @@ class HipBackend(Backend):
     def _fft_padded_workspace(self, grid, box_lo, box_dims, batch, layout=0):
         return self._padded_plan(grid, box_lo, box_dims, batch, layout)[1]
 
-    def fft_padded(self, y, x, w, grid, box_lo, box_dims, workspace=None, layout=0):
+    def fft_padded(self, y, x, w, grid, box_lo, box_dims, workspace=None, layout=0, support=None):
         C = y.shape[1]
         assert y.dtype == _C64 and x.dtype == _C64 and y.contiguous and x.contiguous
         assert y.shape[0] == int(np.prod(grid)) and x.size == int(np.prod(box_dims))
@@ -336,10 +336,11 @@ class HipBackend(Backend):
         self._check(self._L.ig_fft_exec_padded(plan, ctypes.c_void_p(x._arr), 0,
                                                ctypes.c_void_p(w._arr) if w is not None else None,
                                                ctypes.c_void_p(y._arr),
-                                               ctypes.c_void_p(workspace._arr) if workspace is not None else None),
+                                               ctypes.c_void_p(workspace._arr) if workspace is not None else None,
+                                               ctypes.c_void_p(support._arr) if support is not None else None),
                     "ig_fft_exec_padded")
 
-    def ifft_cropped(self, xc, y, w, grid, box_lo, box_dims, workspace, layout=0):
+    def ifft_cropped(self, xc, y, w, grid, box_lo, box_dims, workspace, layout=0, support=None):
         C = y.shape[1]
         assert y.dtype == _C64 and xc.dtype == _C64 and y.contiguous and xc.contiguous
         assert xc.shape == (int(np.prod(box_dims)), C)
@@ -348,7 +349,9 @@ class HipBackend(Backend):
         self._check(self._L.ig_fft_exec_cropped(plan, ctypes.c_void_p(y._arr),
                                                 ctypes.c_void_p(w._arr) if w is not None else None,
                                                 ctypes.c_void_p(xc._arr), xc.shape[0],
-                                                ctypes.c_void_p(workspace._arr)), "ig_fft_exec_cropped")
+                                                ctypes.c_void_p(workspace._arr),
+                                                ctypes.c_void_p(support._arr) if support is not None else None),
+                    "ig_fft_exec_cropped")
 
     def sum_columns(self, y, X, alpha=1, beta=0):
         assert y.dtype == _C64 and X.dtype == _C64 and y.contiguous and y.size == X.shape[0]
@@ -376,11 +379,22 @@ class HipBackend(Backend):
                                ctypes.c_void_p(y._arr), y._leading_dim)
         self._check(rc, "ig_ccsrmm")
 
-    def ccsrmm_t(self, y, A_shape, At_indx, At_ptr, At_vals, x, alpha=1, beta=0):
-        """y = alpha * A^H x + beta*y through the CSR of A^T (gather)"""
+    def ccsrmm_t(self, y, A_shape, At_indx, At_ptr, At_vals, x, alpha=1, beta=0, support=None):
+        """y = alpha * A^H x + beta*y through the CSR of A^T (gather); `support` = (table, n0, nm) restricts
+        the output rows to a grid support region (rows outside are left untouched)"""
         m, k = A_shape
         ar, ai = _cplx(alpha)
         br, bi = _cplx(beta)
+        if support is not None:
+            tab, n0, nm = support
+            rc = self._L.ig_ccsrmm_t_grid(self._ctx, m, k, x.shape[1], At_vals.size,
+                                          ar, ai, ctypes.c_void_p(At_vals._arr), ctypes.c_void_p(At_indx._arr),
+                                          ctypes.c_void_p(At_ptr._arr),
+                                          ctypes.c_void_p(x._arr), x._leading_dim, br, bi,
+                                          ctypes.c_void_p(y._arr), y._leading_dim,
+                                          ctypes.c_void_p(tab._arr), n0, nm)
+            self._check(rc, "ig_ccsrmm_t_grid")
+            return
         rc = self._L.ig_ccsrmm_t(self._ctx, m, k, x.shape[1], At_vals.size,
                                  ar, ai, ctypes.c_void_p(At_vals._arr), ctypes.c_void_p(At_indx._arr),
                                  ctypes.c_void_p(At_ptr._arr),
@@ -432,9 +446,18 @@ class HipBackend(Backend):
                 self._host_csr = None
             return self._t
 
+        def set_grid_support(self, table, n0, nm):
+            self._support = (self._backend.copy_array(np.ascontiguousarray(table, dtype=np.int16).reshape(-1),
+                                                      name=self._name + ".support"), int(n0), int(nm))
+
         def adjoint(self, y, x, alpha=1, beta=0):
             self._check_panels(y, x, self.values)
             b = self._backend
+            sup = getattr(self, '_support', None)
+            if sup is not None and not self._exwrite and b.adjoint_policy == 'transpose':
+                pt, it, dt = self._transposed()
+                b.ccsrmm_t(y, self.shape, it, pt, dt, x, alpha=alpha, beta=beta, support=sup)
+                return
             if self._exwrite or b.adjoint_policy != 'transpose':
                 b.ccsrmm(y, self.shape, self.colInds, self.rowPtrs, self.values,
                          x, alpha=alpha, beta=beta, adjoint=True, exwrite=self._exwrite)

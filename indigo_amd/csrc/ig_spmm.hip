@@ -51,6 +51,13 @@ __device__ __forceinline__ int64_t xcd_block(int64_t b, int64_t nb) {
 //   k_csrmm_rows_block  one 1024-thread workgroup per listed row (nnz > thr_long)
 // both of which read the list length from device memory, so the host never syncs.
 // If a list is full the row is simply computed inline (slow, still correct).
+// Optional support region of a 3-D grid of output rows, row = kx + n0*(km + nm*ks): a row is only computed
+// and written if km lies in tab[ks*(n0/16) + kx/16] = [lo, hi).  tab == nullptr: every row.
+struct GridMask {
+    const short2* tab;
+    int64_t n0, nm;
+};
+
 struct WorkLists {
     int32_t*  rows[2];     // [0] wave-per-row list, [1] workgroup-per-row list
     uint32_t* count;       // count[0], count[1]
@@ -141,10 +148,17 @@ k_csrmm_rowlane(int64_t M, int64_t N,
                 const float2* __restrict__ X, int64_t ldx,
                 float2* __restrict__ Y, int64_t ldy,
                 float2 alpha, float2 beta, int xcd_remap,
-                WorkLists wl, int32_t thr_mid, int32_t thr_long) {
+                WorkLists wl, int32_t thr_mid, int32_t thr_long, GridMask mask) {
     const int64_t blk = xcd_remap ? xcd_block(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
     const int64_t row = blk * BLK + threadIdx.x;
     if (row >= M) return;
+    if (mask.tab) {
+        // rows outside the gridding support hold no nonzero and nobody reads them: no load, no store
+        const int64_t kx = row % mask.n0, rest = row / mask.n0;
+        const int64_t km = rest % mask.nm, ks = rest / mask.nm;
+        const short2 r = mask.tab[ks * (mask.n0 >> 4) + (kx >> 4)];
+        if (km < r.x || km >= r.y) return;
+    }
     const int32_t p0 = rowptr[row];
     int32_t p1 = rowptr[row + 1];
     const int32_t len = p1 - p0;
@@ -399,7 +413,8 @@ int ensure_worklists(ig_ctx* ctx) {
 template <bool CONJ>
 int launch_gather(ig_ctx* ctx, int64_t rows, int64_t xrows, int64_t N, int64_t nnz,
                   const int32_t* rowptr, const int32_t* colind, const float2* vals,
-                  const float2* X, int64_t ldx, float2* Y, int64_t ldy, float2 alpha, float2 beta) {
+                  const float2* X, int64_t ldx, float2* Y, int64_t ldy, float2 alpha, float2 beta,
+                  GridMask mask = GridMask{nullptr, 0, 0}) {
     const Shape s = pick_shape(rows, N, nnz);
     // Panel rows that are gathered many times each (nnz >> xrows) from a small panel: repack the panel
     // once so that one gathered row is one contiguous 16..64-byte access instead of N scattered ones.
@@ -457,17 +472,17 @@ int launch_gather(ig_ctx* ctx, int64_t rows, int64_t xrows, int64_t N, int64_t n
         if (packed) {                                                                              \
             if (b0) hipLaunchKernelGGL((k_csrmm_rowlane<NC_, CONJ, 0, true>), dim3((unsigned)rblocks), \
                         dim3(BLK), 0, ctx->stream, rows, N, rowptr, colind, vals, X, sxc, Y, ldy,  \
-                        alpha, beta, xcd, wl, tm, thr_long);                                       \
+                        alpha, beta, xcd, wl, tm, thr_long, mask);                                       \
             else    hipLaunchKernelGGL((k_csrmm_rowlane<NC_, CONJ, 1, true>), dim3((unsigned)rblocks), \
                         dim3(BLK), 0, ctx->stream, rows, N, rowptr, colind, vals, X, sxc, Y, ldy,  \
-                        alpha, beta, xcd, wl, tm, thr_long);                                       \
+                        alpha, beta, xcd, wl, tm, thr_long, mask);                                       \
         } else                                                                                     \
         if (b0) hipLaunchKernelGGL((k_csrmm_rowlane<NC_, CONJ, 0, false>), dim3((unsigned)rblocks), \
                     dim3(BLK), 0, ctx->stream, rows, N, rowptr, colind, vals, X, sxc, Y, ldy,      \
-                    alpha, beta, xcd, wl, tm, thr_long);                                           \
+                    alpha, beta, xcd, wl, tm, thr_long, mask);                                           \
         else    hipLaunchKernelGGL((k_csrmm_rowlane<NC_, CONJ, 1, false>), dim3((unsigned)rblocks), \
                     dim3(BLK), 0, ctx->stream, rows, N, rowptr, colind, vals, X, sxc, Y, ldy,      \
-                    alpha, beta, xcd, wl, tm, thr_long);                                           \
+                    alpha, beta, xcd, wl, tm, thr_long, mask);                                           \
     } while (0)
         if (s.CL >= 8) IG_ROWLANE(8);
         else if (s.CL == 4) IG_ROWLANE(4);
@@ -631,6 +646,23 @@ int ig_ccsrmm_t(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, int64_t nnz,
     return launch_gather<true>(ctx, K, M, N, nnz, rowptr_t, colind_t, (const float2*)vals_t,
                                (const float2*)X, ldx, (float2*)Y, ldy,
                                make_float2(ar, ai), make_float2(br, bi));
+}
+
+int ig_ccsrmm_t_grid(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, int64_t nnz,
+                     float ar, float ai, const void* vals_t, const int32_t* colind_t, const int32_t* rowptr_t,
+                     const void* X, int64_t ldx, float br, float bi, void* Y, int64_t ldy,
+                     const int16_t* support, int64_t n0, int64_t nm) {
+    IG_REQUIRE(ctx, ctx != nullptr, "ig_ccsrmm_t_grid: ctx is NULL");
+    if (int rc = check_panel_args(ctx, "ig_ccsrmm_t_grid", M, K, N, nnz, vals_t, colind_t, rowptr_t, X, ldx, Y, ldy)) return rc;
+    IG_REQUIRE(ctx, !support || (n0 > 0 && nm > 0 && n0 % 16 == 0 && K % (n0 * nm) == 0),
+               "ig_ccsrmm_t_grid: rows (%lld) are not a grid of n0=%lld (multiple of 16) x nm=%lld x ...",
+               (long long)K, (long long)n0, (long long)nm);
+    if (N == 0 || K == 0) return IG_OK;
+    if (int rc = ig_set_device(ctx)) return rc;
+    GridMask mask{reinterpret_cast<const short2*>(support), n0, nm};
+    return launch_gather<true>(ctx, K, M, N, nnz, rowptr_t, colind_t, (const float2*)vals_t,
+                               (const float2*)X, ldx, (float2*)Y, ldy,
+                               make_float2(ar, ai), make_float2(br, bi), mask);
 }
 
 // ---- host-side structure analysis -------------------------------------------

@@ -222,6 +222,8 @@ class SpMatrix(Operator):
             self._matrix_d = self._backend.csr_matrix(self._backend, csr, self._name)
             if not self._allow_exwrite:
                 self._matrix_d._exwrite = False
+            if getattr(self, '_grid_support', None) is not None:
+                self._matrix_d.set_grid_support(*self._grid_support)
         return self._matrix_d
 
     def csrmm_bytes(self, x, y, beta, forward):
@@ -292,8 +294,12 @@ class ZpadFFT(MatrixFreeOperator):
     with dense arrays, and tests pin both to the reference's S' + FFT composition.
     """
 
-    def __init__(self, backend, grid_shape, box_shape, weights, box_lo=None, layout=0, **kwargs):
+    def __init__(self, backend, grid_shape, box_shape, weights, box_lo=None, layout=0, support=None, **kwargs):
         self._layout = int(layout)     # memory order of each output grid: 0 = (x, y, z), 1 = (x, z, y)
+        # optional k-space support table (layout 1): int16 [z_lo, z_hi) per (kx tile of 16, ky); outside it the
+        # forward grid is left unwritten and the adjoint's input is taken as zero (see ig_fft_exec_padded)
+        self._support_h = None if support is None else np.ascontiguousarray(support, dtype=np.int16)
+        self._support_d = None
         self._grid = tuple(int(s) for s in grid_shape)
         self._box = tuple(int(s) for s in box_shape)
         assert len(self._grid) == 3 and len(self._box) == 3
@@ -307,6 +313,13 @@ class ZpadFFT(MatrixFreeOperator):
         self._w_d = None
         P, N = int(np.prod(self._grid)), int(np.prod(self._box))
         super().__init__(backend, shape=(self._C * P, N), **kwargs)
+
+    def _support(self):
+        if self._support_h is None:
+            return None
+        if self._support_d is None:
+            self._support_d = self._backend.copy_array(self._support_h.reshape(-1), name=self._name + '.support')
+        return self._support_d
 
     def _weights(self):
         if self._w_d is None:
@@ -342,7 +355,8 @@ class ZpadFFT(MatrixFreeOperator):
                 assert beta == 0, "ZpadFFT forward expects beta == 0, got %s" % beta
                 if self._layout:
                     with B.scratch(nbytes=self._ws_bytes()) as ws:
-                        B.fft_padded(yj.reshape((P, C)), xj, w, self._grid, self._lo, self._box, ws, self._layout)
+                        B.fft_padded(yj.reshape((P, C)), xj, w, self._grid, self._lo, self._box, ws, self._layout,
+                                     self._support())
                 else:
                     B.fft_padded(yj.reshape((P, C)), xj, w, self._grid, self._lo, self._box)
                 if alpha != 1:
@@ -350,7 +364,8 @@ class ZpadFFT(MatrixFreeOperator):
             else:
                 with B.scratch(shape=(N, C)) as tmp:
                     with B.scratch(nbytes=self._ws_bytes()) as ws:
-                        B.ifft_cropped(tmp, xj.reshape((P, C)), w, self._grid, self._lo, self._box, ws, self._layout)
+                        B.ifft_cropped(tmp, xj.reshape((P, C)), w, self._grid, self._lo, self._box, ws, self._layout,
+                                       self._support())
                     B.sum_columns(yj, tmp, alpha=alpha, beta=beta)
 
     def _ws_bytes(self):

@@ -134,15 +134,42 @@ class SenseProblem(object):
             np.multiply(base, self.maps[:, :, :, c], out=w[:, :, :, j])
         return w
 
-    def build_zpadfft(self, backend, coils=None, layout=1):
+    def grid_support(self, G):
+        """k-space support of a layout-1 gridding matrix G (T x P): int16 table of shape (n1 * n0/16, 2) with
+        [z_lo, z_hi) per (16-wide kx tile, ky) -- the kz range outside which no sample touches the grid.
+        A radial trajectory fills a ball: about half of the grid cube lies outside and is never needed."""
+        n0, n1, n2 = self.oN
+        assert n0 % 16 == 0
+        cols = np.unique(G.indices)
+        kx = cols % n0
+        kz = (cols // n0) % n2
+        ky = cols // (n0 * n2)
+        key = ky * (n0 // 16) + kx // 16
+        order = np.argsort(key, kind='stable')
+        key, kz = key[order], kz[order]
+        table = np.zeros((n1 * (n0 // 16), 2), dtype=np.int16)
+        if key.size:
+            starts = np.flatnonzero(np.r_[True, key[1:] != key[:-1]])
+            table[key[starts], 0] = np.minimum.reduceat(kz, starts)
+            table[key[starts], 1] = np.maximum.reduceat(kz, starts) + 1
+        return table
+
+    def build_zpadfft(self, backend, coils=None, layout=1, support=None):
         """A = KronI(C, G') * ZpadFFT: the `-O3` tree with S' and the FFT fused into one leaf
         (zero-pad aware transform; needs backend.supports_padded_fft(grid)).  The oversampled grid is
         private to this pair of leaves, so it may live in the (x, z, y) order (layout=1) that keeps the
         transform's largest pass at a small stride; G' is indexed to match."""
         coils = list(range(self.C) if coils is None else coils)
         Cn = len(coils)
-        G = backend.SpMatrix(self.fused_interp(layout), name='interp*mod*scale')
-        Z = backend.ZpadFFT(self.oN, self.N, self.fused_weights(coils), layout=layout, name='fft*zpad*apod*maps')
+        Gm = self.fused_interp(layout)
+        G = backend.SpMatrix(Gm, name='interp*mod*scale')
+        table = None
+        if (support is None or support) and layout == 1 and self.oN[0] % 16 == 0:
+            # restrict the transform's z pass and the adjoint gridding to the k-space support of G'
+            table = self.grid_support(Gm)
+            G._grid_support = (table, self.oN[0], self.oN[2])
+        Z = backend.ZpadFFT(self.oN, self.N, self.fused_weights(coils), layout=layout, support=table,
+                            name='fft*zpad*apod*maps')
         A = backend.KronI(Cn, G) * Z
         A._name = 'SENSE-fusedFFT'
         return A

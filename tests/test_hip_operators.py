@@ -302,3 +302,60 @@ def test_zpadfft_operator_matches_reference_composition(hip, oracle_backend):
     # the fused leaf books the same algorithmic bytes as the leaves it replaces
     np.testing.assert_allclose(tr.total_bytes(), tr2.total_bytes(), rtol=1e-3)
     hip._scratch = None
+
+
+def test_padded_fft_with_support_table(hip):
+    """k-space support ranges: the padded transform guarantees only kz inside [lo, hi) of each (kx tile, ky);
+    the cropped transform ignores whatever lies outside; the masked adjoint SpMM writes only rows inside."""
+    grid, box, C, layout = (256, 256, 256), (128, 128, 128), 2, 1
+    lo = tuple(m // 2 + int(np.ceil(-n / 2)) for m, n in zip(grid, box))
+    n0, n1, n2 = grid
+    P, N = int(np.prod(grid)), int(np.prod(box))
+    rng = np.random.default_rng(7)
+    table = np.zeros((n1 * (n0 // 16), 2), dtype=np.int16)
+    table[:, 0] = rng.integers(0, 200, table.shape[0])
+    table[:, 1] = table[:, 0] + rng.integers(0, 57, table.shape[0])          # some ranges empty
+    sup = hip.copy_array(table.reshape(-1))
+    # membership mask in (x, z, y) memory order
+    zlo = np.repeat(table[:, 0].reshape(n1, n0 // 16), 16, axis=1)          # (ky, kx)
+    zhi = np.repeat(table[:, 1].reshape(n1, n0 // 16), 16, axis=1)
+    kz = np.arange(n2)[None, :, None]
+    inside = ((kz >= zlo.T[:, None, :]) & (kz < zhi.T[:, None, :])).reshape(-1, order='F')      # index kx + n0*(kz + n2*ky)
+    x, w = rand64c(N, 1, seed=1), rand64c(N, C, seed=2)
+    ws = hip.zero_array((hip._fft_padded_workspace(grid, lo, box, C, layout) // 8,), C64)
+    full_d = hip.zero_array((P, C), C64)
+    hip.fft_padded(full_d, hip.copy_array(x), hip.copy_array(w), grid, lo, box, ws, layout)
+    sentinel = np.full((P, C), 7 - 3j, dtype=C64, order='F')
+    y_d = hip.copy_array(sentinel)
+    hip.fft_padded(y_d, hip.copy_array(x), hip.copy_array(w), grid, lo, box, ws, layout, sup)
+    y, full = y_d.to_host(), full_d.to_host()
+    np.testing.assert_array_equal(y[inside], full[inside])        # outside the support Y is undefined
+    skipped = np.repeat(table[:, 1] <= table[:, 0], 16)             # tiles with an empty range are not touched at all
+    untouched = np.broadcast_to(skipped.reshape(n1, n0).T[:, None, :], (n0, n2, n1)).reshape(-1, order='F')
+    z_in_box = np.zeros(n2, bool)
+    z_in_box[lo[2]:lo[2] + box[2]] = True                           # (rows z in the box hold pass-y intermediates)
+    zmask = np.broadcast_to(z_in_box[None, :, None], (n0, n2, n1)).reshape(-1, order='F')
+    np.testing.assert_array_equal(y[untouched & ~zmask], sentinel[untouched & ~zmask])
+    # cropped: garbage outside the support must not matter
+    k = rand64c(P, C, seed=3)
+    k_clean = k.copy(order='F')
+    k_clean[~inside] = 0
+    k_dirty = k.copy(order='F')
+    k_dirty[~inside] = np.nan
+    a_d, b_d = hip.zero_array((N, C), C64), hip.zero_array((N, C), C64)
+    hip.ifft_cropped(a_d, hip.copy_array(k_clean), hip.copy_array(w), grid, lo, box, ws, layout)
+    hip.ifft_cropped(b_d, hip.copy_array(k_dirty), hip.copy_array(w), grid, lo, box, ws, layout, sup)
+    assert rel_err(b_d.to_host(), a_d.to_host()) < 1e-6
+    # masked adjoint SpMM: rows outside the support keep their old contents, rows inside get A^H x
+    T = 5000
+    cols = rng.choice(np.flatnonzero(inside), size=T * 4)
+    A = spp.csr_matrix((rand64c(T * 4, seed=4), cols, np.arange(0, T * 4 + 1, 4)), shape=(T, P))
+    A_d = hip.csr_matrix(hip, A)
+    A_d.set_grid_support(table, n0, n2)
+    xs = rand64c(T, C, seed=5)
+    out_d = hip.copy_array(sentinel)
+    A_d.adjoint(out_d, hip.copy_array(xs))
+    out = out_d.to_host()
+    exp = A.conj().T @ xs
+    assert rel_err(out[inside], exp[inside]) < RTOL
+    np.testing.assert_array_equal(out[~inside], sentinel[~inside])
