@@ -152,7 +152,8 @@ int  ig_ccsrmm_t(ig_ctx* ctx,
 
 /* ig_ccsrmm_t restricted to a support region of a 3-D grid of output rows: row = kx + n0*(km + nm*ks);
  * rows with km outside support[2*(ks*(n0/16) + kx/16) + {0,1}] = [lo, hi) are neither computed nor
- * written (they hold no nonzero by construction of the table).  Same table as ig_fft_exec_cropped.  */
+ * written (they hold no nonzero by construction of the table; support may be NULL = all rows).
+ * Same table as ig_fft_exec_cropped.                                                               */
 int  ig_ccsrmm_t_grid(ig_ctx* ctx,
                       int64_t M, int64_t K, int64_t N, int64_t nnz,
                       float alpha_re, float alpha_im,
@@ -160,7 +161,21 @@ int  ig_ccsrmm_t_grid(ig_ctx* ctx,
                       const void* X, int64_t ldx,
                       float beta_re, float beta_im,
                       void* Y, int64_t ldy,
-                      const int16_t* support, int64_t n0, int64_t nm);
+                      const int16_t* support, int64_t n0, int64_t nm, const int32_t* xrow_perm);
+
+/* Locality-ordered variants.  The caller may store A with its ROWS reordered (row r of the stored
+ * matrix is row perm[r] of A; e.g. k-space samples sorted by the grid cell they touch, so that
+ * neighbouring rows gather neighbouring panel rows and share cache lines):
+ *   ig_ccsrmm_rowperm : forward product of the stored matrix, result row r written to Y[yrow_perm[r], :]
+ *   ig_ccsrmm_t_grid  : xrow_perm (may be NULL) -- panel row k of the stored transpose's product is
+ *                       X[xrow_perm[k], :] (folded into the panel repacking pass; needs N <= 8).      */
+int  ig_ccsrmm_rowperm(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, int64_t nnz,
+                       float alpha_re, float alpha_im,
+                       const void* vals, const int32_t* colind, const int32_t* rowptr,
+                       const void* X, int64_t ldx,
+                       float beta_re, float beta_im,
+                       void* Y, int64_t ldy,
+                       const int32_t* yrow_perm);
 
 /* Host-side structure analysis.  Replaces `inspect`
  * (indigo/backends/_customcpu.c:179-215): number of non-empty rows / columns
@@ -210,7 +225,9 @@ int  ig_fft_plan_padded(ig_ctx* ctx, const int64_t* dims, const int64_t* box_lo,
  * consumes / produced Y, as int16 pairs support[2*(ky*(n0/16) + kx/16) + {0,1}] = [z_lo, z_hi): the
  * padded transform then only guarantees kz inside the range (the rest of Y is undefined and must not
  * be read), the cropped transform reads only kz inside it (the rest counts as zero and may hold
- * anything).  A radial trajectory covers a ball, 52 % of the grid cube.                        */
+ * anything).  The table has a second part behind the n1*(n0/16) z-ranges: n0/16 pairs [y_lo, y_hi),
+ * the ky range of each kx tile outside which every z-range is empty (used by the y pass).
+ * A radial trajectory covers a ball, 52 % of the grid cube.                                    */
 int  ig_fft_exec_padded(ig_fft* plan, const void* x, int64_t x_bstride, const void* w, void* y, void* workspace,
                         const int16_t* support);
 int  ig_fft_exec_cropped(ig_fft* plan, const void* y, const void* w, void* x, int64_t x_bstride, void* workspace,

@@ -53,7 +53,10 @@ PROTOTYPES = {
     "ig_ccsrmm_t_grid":   (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64,
                                    c_float, c_float, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_int64, c_float, c_float, c_void_p, c_int64,
-                                   c_void_p, c_int64, c_int64]),
+                                   c_void_p, c_int64, c_int64, c_void_p]),
+    "ig_ccsrmm_rowperm":  (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64,
+                                   c_float, c_float, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_int64, c_float, c_float, c_void_p, c_int64, c_void_p]),
     "ig_csr_inspect":     (c_int, [c_void_p, c_void_p, c_int64, c_int64,
                                    POINTER(c_int64), POINTER(c_int64), POINTER(c_int)]),
     "ig_csr_transpose":   (c_int, [c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,

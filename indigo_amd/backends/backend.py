@@ -518,6 +518,10 @@ class Backend(object):
             is the same either way)."""
             pass
 
+        def set_row_order(self, perm):
+            """Hint: processing the rows in the order `perm` improves locality.  Backends may ignore it."""
+            pass
+
         @property
         def nbytes(self):
             return self.rowPtrs.nbytes + self.colInds.nbytes + self.values.nbytes

@@ -379,20 +379,21 @@ class HipBackend(Backend):
                                ctypes.c_void_p(y._arr), y._leading_dim)
         self._check(rc, "ig_ccsrmm")
 
-    def ccsrmm_t(self, y, A_shape, At_indx, At_ptr, At_vals, x, alpha=1, beta=0, support=None):
+    def ccsrmm_t(self, y, A_shape, At_indx, At_ptr, At_vals, x, alpha=1, beta=0, support=None, xperm=None):
         """y = alpha * A^H x + beta*y through the CSR of A^T (gather); `support` = (table, n0, nm) restricts
         the output rows to a grid support region (rows outside are left untouched)"""
         m, k = A_shape
         ar, ai = _cplx(alpha)
         br, bi = _cplx(beta)
-        if support is not None:
-            tab, n0, nm = support
+        if support is not None or xperm is not None:
+            tab, n0, nm = support if support is not None else (None, 0, 0)
             rc = self._L.ig_ccsrmm_t_grid(self._ctx, m, k, x.shape[1], At_vals.size,
                                           ar, ai, ctypes.c_void_p(At_vals._arr), ctypes.c_void_p(At_indx._arr),
                                           ctypes.c_void_p(At_ptr._arr),
                                           ctypes.c_void_p(x._arr), x._leading_dim, br, bi,
                                           ctypes.c_void_p(y._arr), y._leading_dim,
-                                          ctypes.c_void_p(tab._arr), n0, nm)
+                                          ctypes.c_void_p(tab._arr) if tab is not None else None, n0, nm,
+                                          ctypes.c_void_p(xperm._arr) if xperm is not None else None)
             self._check(rc, "ig_ccsrmm_t_grid")
             return
         rc = self._L.ig_ccsrmm_t(self._ctx, m, k, x.shape[1], At_vals.size,
@@ -450,13 +451,50 @@ class HipBackend(Backend):
             self._support = (self._backend.copy_array(np.ascontiguousarray(table, dtype=np.int16).reshape(-1),
                                                       name=self._name + ".support"), int(n0), int(nm))
 
+        def set_row_order(self, perm):
+            """Store the matrix with its rows in the order `perm` (stored row r = row perm[r] of A), e.g. gridding
+            samples sorted by the grid cell they touch: neighbouring rows then gather neighbouring panel rows.
+            The products are unchanged -- the forward result is written through the permutation and the
+            adjoint reads its panel through it."""
+            b = self._backend
+            perm = np.ascontiguousarray(perm, dtype=np.int32)
+            assert self._host_csr is not None and perm.shape == (self.shape[0],)
+            Ap = self._host_csr[perm]
+            Ap.sort_indices()
+            self.rowPtrs = b.copy_array(Ap.indptr.astype(np.int32), name=self._name + ".rowPtrs")
+            self.colInds = b.copy_array(Ap.indices.astype(np.int32), name=self._name + ".colInds")
+            self.values = b.copy_array(Ap.data.astype(_C64), name=self._name + ".data")
+            self._host_csr = Ap
+            self._t = None
+            self._perm = b.copy_array(perm, name=self._name + ".rowOrder")
+
+        def forward(self, y, x, alpha=1, beta=0):
+            perm = getattr(self, '_perm', None)
+            if perm is None:
+                return super().forward(y, x, alpha=alpha, beta=beta)
+            self._check_panels(y, x, self.values)
+            b = self._backend
+            ar, ai = _cplx(alpha)
+            br, bi = _cplx(beta)
+            m, k = self.shape
+            b._check(b._L.ig_ccsrmm_rowperm(b._ctx, m, k, x.shape[1], self.values.size, ar, ai,
+                                            ctypes.c_void_p(self.values._arr), ctypes.c_void_p(self.colInds._arr),
+                                            ctypes.c_void_p(self.rowPtrs._arr),
+                                            ctypes.c_void_p(x._arr), x._leading_dim, br, bi,
+                                            ctypes.c_void_p(y._arr), y._leading_dim,
+                                            ctypes.c_void_p(perm._arr)), "ig_ccsrmm_rowperm")
+
         def adjoint(self, y, x, alpha=1, beta=0):
             self._check_panels(y, x, self.values)
             b = self._backend
             sup = getattr(self, '_support', None)
-            if sup is not None and not self._exwrite and b.adjoint_policy == 'transpose':
+            perm = getattr(self, '_perm', None)
+            if perm is not None:
+                assert not self._exwrite and b.adjoint_policy == 'transpose' and x.shape[1] <= 8, \
+                    "row-ordered matrices use the packed transposed gather"
+            if (sup is not None or perm is not None) and not self._exwrite and b.adjoint_policy == 'transpose':
                 pt, it, dt = self._transposed()
-                b.ccsrmm_t(y, self.shape, it, pt, dt, x, alpha=alpha, beta=beta, support=sup)
+                b.ccsrmm_t(y, self.shape, it, pt, dt, x, alpha=alpha, beta=beta, support=sup, xperm=perm)
                 return
             if self._exwrite or b.adjoint_policy != 'transpose':
                 b.ccsrmm(y, self.shape, self.colInds, self.rowPtrs, self.values,

@@ -228,6 +228,7 @@ struct PassDesc {
     // range are skipped altogether), mode 2 narrows the INPUT box (everything outside reads as zero)
     const short2* tile_range;
     int tile_range_mode;
+    int64_t tile_range_k1;      // table row stride per k1 (ext0 / W), or 0 if the ranges do not depend on k1
 };
 
 // Two-stage kernel for n = R1*R2 (256 = 16x16, 512 = 32x16): the whole column lives in registers
@@ -266,7 +267,7 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
     int in_lo = d.in_lo, in_hi = d.in_hi, out_lo = d.out_lo, out_hi = d.out_hi;
     if (BOXED && !AXIS0 && d.tile_range) {
         const int64_t col0 = (int64_t)blockIdx.x * W;                 // uniform over the workgroup
-        const short2 r = d.tile_range[((col0 / d.ext0) % d.ext1) * (d.ext0 / W) + (col0 % d.ext0) / W];
+        const short2 r = d.tile_range[((col0 / d.ext0) % d.ext1) * d.tile_range_k1 + (col0 % d.ext0) / W];
         if (d.tile_range_mode == 1) {
             out_lo = out_lo > r.x ? out_lo : r.x;
             out_hi = out_hi < r.y ? out_hi : r.y;
@@ -791,6 +792,8 @@ static int exec_padded_layout1(ig_fft* p, const float2* x, int64_t x_bstride, co
         d.out = y + l2 * n0; d.out_sj = n0 * n2; d.out_s[0] = 1; d.out_s[1] = n0; d.out_s[2] = vol;
         d.ext0 = n0; d.ext1 = b2; d.ncols = n0 * b2 * C;
         d.in_lo = (int)l1; d.in_hi = (int)(l1 + b1); d.out_lo = 0; d.out_hi = (int)n1; d.inverse = 0;
+        // ky outside the support of this kx tile is never transformed along z: do not produce it
+        if (support) { d.tile_range = support + n1 * (n0 / 16); d.tile_range_mode = 1; d.tile_range_k1 = 0; }
         if (int rc = launch_2stage(ctx, p->axis[1], d, false, 0)) return rc;
     }
     {   // pass z: all columns (kx, ky), in place, stride n0 on both sides
@@ -800,7 +803,7 @@ static int exec_padded_layout1(ig_fft* p, const float2* x, int64_t x_bstride, co
         d.in_s[0] = d.out_s[0] = 1; d.in_s[1] = d.out_s[1] = n0 * n2; d.in_s[2] = d.out_s[2] = vol;
         d.ext0 = n0; d.ext1 = n1; d.ncols = n0 * n1 * C;
         d.in_lo = (int)l2; d.in_hi = (int)(l2 + b2); d.out_lo = 0; d.out_hi = (int)n2; d.inverse = 0;
-        d.tile_range = support; d.tile_range_mode = 1;       // only the k-space support is ever gridded from
+        d.tile_range = support; d.tile_range_mode = 1; d.tile_range_k1 = n0 / 16;   // only the support is ever gridded from
         if (int rc = launch_2stage(ctx, p->axis[2], d, false, 0)) return rc;
     }
     return IG_OK;
@@ -822,7 +825,7 @@ static int exec_cropped_layout1(ig_fft* p, const float2* y, const float2* w, flo
         d.in_s[0] = d.out_s[0] = 1; d.in_s[1] = d.out_s[1] = n0 * n2; d.in_s[2] = d.out_s[2] = vol;
         d.ext0 = n0; d.ext1 = n1; d.ncols = n0 * n1 * C;
         d.in_lo = 0; d.in_hi = (int)n2; d.out_lo = (int)l2; d.out_hi = (int)(l2 + b2); d.inverse = 1;
-        d.tile_range = support; d.tile_range_mode = 2;       // the adjoint gridding only wrote the support
+        d.tile_range = support; d.tile_range_mode = 2; d.tile_range_k1 = n0 / 16;   // the adjoint gridding only wrote the support
         if (int rc = launch_2stage(ctx, p->axis[2], d, false, 0)) return rc;
     }
     {   // pass y: columns (kx, z'), grid in (stride n0*n2), compact out, keep y in box
@@ -832,6 +835,7 @@ static int exec_cropped_layout1(ig_fft* p, const float2* y, const float2* w, flo
         d.out = L1 - l1 * n0; d.out_sj = n0; d.out_s[0] = 1; d.out_s[1] = n0 * b1; d.out_s[2] = cvol;
         d.ext0 = n0; d.ext1 = b2; d.ncols = n0 * b2 * C;
         d.in_lo = 0; d.in_hi = (int)n1; d.out_lo = (int)l1; d.out_hi = (int)(l1 + b1); d.inverse = 1;
+        if (support) { d.tile_range = support + n1 * (n0 / 16); d.tile_range_mode = 2; d.tile_range_k1 = 0; }
         if (int rc = launch_2stage(ctx, p->axis[1], d, false, 0)) return rc;
     }
     {   // pass x: compact rows, keep x in box, times conj(w), into the compact image array

@@ -62,7 +62,12 @@ struct WorkLists {
     int32_t*  rows[2];     // [0] wave-per-row list, [1] workgroup-per-row list
     uint32_t* count;       // count[0], count[1]
     uint32_t  cap;
+    const int32_t* yperm;  // optional: result row r is stored at Y[yperm[r]] (rows of A were reordered for locality)
 };
+
+__device__ __forceinline__ int64_t out_row(const int32_t* __restrict__ perm, int64_t row) {
+    return perm ? (int64_t)perm[row] : row;
+}
 
 template <bool CONJ>
 __device__ __forceinline__ void acc_nz(float2& acc, float2 v, float2 x) {
@@ -111,23 +116,33 @@ k_csrmm_gather(int64_t M, int64_t N,
         const bool col_ok = j < N;
         const float2* __restrict__ xcol = X + (col_ok ? j : 0) * ldx;
         float2 acc = make_float2(0.f, 0.f);
-        int32_t p = p0 + i;
-        // two nonzeros per trip keep two panel gathers in flight per lane
-        for (; p + NL < p1; p += 2 * NL) {
-            const int32_t k0 = colind[p], k1 = colind[p + NL];
-            const float2 v0 = vals[p], v1 = vals[p + NL];
-            const float2 x0 = xcol[k0 * sxr], x1 = xcol[k1 * sxr];
-            acc_nz<CONJ>(acc, v0, x0);
-            acc_nz<CONJ>(acc, v1, x1);
+        // Four nonzeros per trip and lane, predicated (index clamped to the row's last nonzero, value zeroed):
+        // a gridding row (27 nonzeros on 8 nonzero-lanes) is then ONE trip, i.e. a dependent chain of three
+        // memory round trips (rowptr -> index/value -> panel) instead of five.  This kernel is latency bound.
+        for (int32_t p = p0 + i; p < p1; p += 4 * NL) {
+            int32_t k4[4];
+            float2 v4[4], x4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int32_t pu = p + u * NL;
+                const bool ok = pu < p1;
+                const int32_t q = ok ? pu : p1 - 1;
+                k4[u] = colind[q];
+                const float2 vv = vals[q];
+                v4[u] = ok ? vv : make_float2(0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x4[u] = xcol[k4[u] * sxr];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc_nz<CONJ>(acc, v4[u], x4[u]);
         }
-        if (p < p1) acc_nz<CONJ>(acc, vals[p], xcol[colind[p] * sxr]);
 #pragma unroll
         for (int off = CL * NL / 2; off >= CL; off >>= 1) {
             acc.x += __shfl_xor(acc.x, off, 64);
             acc.y += __shfl_xor(acc.y, off, 64);
         }
         if (i == 0 && row_ok && col_ok && !deferred) {
-            float2* yp = Y + j * ldy + row;
+            float2* yp = Y + j * ldy + out_row(wl.yperm, row);
             float2 out = cmul(alpha, acc);
             if (BMODE == 1) cfma(out, beta, *yp);
             *yp = out;
@@ -198,7 +213,7 @@ k_csrmm_rowlane(int64_t M, int64_t N,
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             if (jb + c < N) {
-                float2* yp = Y + (jb + c) * ldy + row;
+                float2* yp = Y + (jb + c) * ldy + out_row(wl.yperm, row);
                 float2 out = cmul(alpha, acc[c]);
                 if (BMODE == 1) cfma(out, beta, *yp);
                 *yp = out;
@@ -218,7 +233,8 @@ __global__ void __launch_bounds__(BLK)
 k_csrmm_rows_wave(int64_t N, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
                   const float2* __restrict__ vals, const float2* __restrict__ X, int64_t ldx, int64_t sxr,
                   float2* __restrict__ Y, int64_t ldy, float2 alpha, float2 beta,
-                  const int32_t* __restrict__ list, const uint32_t* __restrict__ count, uint32_t cap) {
+                  const int32_t* __restrict__ list, const uint32_t* __restrict__ count, uint32_t cap,
+                  const int32_t* __restrict__ yperm) {
     constexpr int NLW = 64 / CL;
     const int lane = threadIdx.x & 63;
     const int c = lane % CL, i = lane / CL;
@@ -249,7 +265,7 @@ k_csrmm_rows_wave(int64_t N, const int32_t* __restrict__ rowptr, const int32_t* 
                 acc.y += __shfl_xor(acc.y, off, 64);
             }
             if (i == 0 && col_ok) {
-                float2* yp = Y + j * ldy + row;
+                float2* yp = Y + j * ldy + out_row(yperm, row);
                 float2 out = cmul(alpha, acc);
                 if (BMODE == 1) cfma(out, beta, *yp);
                 *yp = out;
@@ -264,7 +280,8 @@ __global__ void __launch_bounds__(1024)
 k_csrmm_rows_block(int64_t N, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
                    const float2* __restrict__ vals, const float2* __restrict__ X, int64_t ldx, int64_t sxr,
                    float2* __restrict__ Y, int64_t ldy, float2 alpha, float2 beta,
-                   const int32_t* __restrict__ list, const uint32_t* __restrict__ count, uint32_t cap) {
+                   const int32_t* __restrict__ list, const uint32_t* __restrict__ count, uint32_t cap,
+                   const int32_t* __restrict__ yperm) {
     constexpr int NLB = 1024 / CL;
     __shared__ float2 part[16][64];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -302,7 +319,7 @@ k_csrmm_rows_block(int64_t N, const int32_t* __restrict__ rowptr, const int32_t*
 #pragma unroll
                 for (int w = 0; w < 16; ++w) sum = cadd(sum, part[w][tid]);
                 if (col_ok) {
-                    float2* yp = Y + j * ldy + row;
+                    float2* yp = Y + j * ldy + out_row(yperm, row);
                     float2 out = cmul(alpha, sum);
                     if (BMODE == 1) cfma(out, beta, *yp);
                     *yp = out;
@@ -372,11 +389,14 @@ k_panel_scale(int64_t rows, int64_t N, float2* __restrict__ Y, int64_t ld, float
 // row contiguous; pad columns are zero.  Used when every panel row is gathered many times.
 template <int NP>
 __global__ void __launch_bounds__(BLK)
-k_pack_panel(int64_t rows, int64_t N, const float2* __restrict__ X, int64_t ld, float2* __restrict__ Xp) {
+k_pack_panel(int64_t rows, int64_t N, const float2* __restrict__ X, int64_t ld, float2* __restrict__ Xp,
+             const int32_t* __restrict__ xperm) {
+    // xperm (optional): packed row k is panel row xperm[k] (the matrix's columns were renumbered for locality)
     for (int64_t e = (int64_t)blockIdx.x * BLK + threadIdx.x; e < rows * NP; e += (int64_t)gridDim.x * BLK) {
         const int64_t k = e / NP;
         const int c = (int)(e % NP);
-        Xp[e] = c < N ? X[c * ld + k] : make_float2(0.f, 0.f);
+        const int64_t src = xperm ? (int64_t)xperm[k] : k;
+        Xp[e] = c < N ? X[c * ld + src] : make_float2(0.f, 0.f);
     }
 }
 
@@ -414,13 +434,14 @@ template <bool CONJ>
 int launch_gather(ig_ctx* ctx, int64_t rows, int64_t xrows, int64_t N, int64_t nnz,
                   const int32_t* rowptr, const int32_t* colind, const float2* vals,
                   const float2* X, int64_t ldx, float2* Y, int64_t ldy, float2 alpha, float2 beta,
-                  GridMask mask = GridMask{nullptr, 0, 0}) {
+                  GridMask mask = GridMask{nullptr, 0, 0}, const int32_t* yperm = nullptr,
+                  const int32_t* xperm = nullptr) {
     const Shape s = pick_shape(rows, N, nnz);
     // Panel rows that are gathered many times each (nnz >> xrows) from a small panel: repack the panel
     // once so that one gathered row is one contiguous 16..64-byte access instead of N scattered ones.
     int64_t sxc = ldx, sxr = 1;          // element (k, j) of X lives at X[j*sxc + k*sxr]
     bool packed = false;
-    if (N >= 2 && N <= 8 && nnz >= 4 * xrows && env_flag("INDIGO_HIP_SPMM_PACK", true)) {
+    if (((N >= 2 && N <= 8 && nnz >= 4 * xrows) || (xperm && N <= 8)) && env_flag("INDIGO_HIP_SPMM_PACK", true)) {
         const int np = s.CL;             // pow2 >= N, <= 8
         const size_t need = (size_t)xrows * np * 8;
         if (need <= ((size_t)1 << 30)) {
@@ -434,13 +455,15 @@ int launch_gather(ig_ctx* ctx, int64_t rows, int64_t xrows, int64_t N, int64_t n
             const int64_t cap = (int64_t)ctx->num_cu * 16;
             if (g > cap) g = cap;
             float2* xp = (float2*)ctx->d_xpack;
-            if (np == 2)      hipLaunchKernelGGL(k_pack_panel<2>, dim3((unsigned)g), dim3(BLK), 0, ctx->stream, xrows, N, X, ldx, xp);
-            else if (np == 4) hipLaunchKernelGGL(k_pack_panel<4>, dim3((unsigned)g), dim3(BLK), 0, ctx->stream, xrows, N, X, ldx, xp);
-            else              hipLaunchKernelGGL(k_pack_panel<8>, dim3((unsigned)g), dim3(BLK), 0, ctx->stream, xrows, N, X, ldx, xp);
+            if (np == 1)      hipLaunchKernelGGL(k_pack_panel<1>, dim3((unsigned)g), dim3(BLK), 0, ctx->stream, xrows, N, X, ldx, xp, xperm);
+            else if (np == 2) hipLaunchKernelGGL(k_pack_panel<2>, dim3((unsigned)g), dim3(BLK), 0, ctx->stream, xrows, N, X, ldx, xp, xperm);
+            else if (np == 4) hipLaunchKernelGGL(k_pack_panel<4>, dim3((unsigned)g), dim3(BLK), 0, ctx->stream, xrows, N, X, ldx, xp, xperm);
+            else              hipLaunchKernelGGL(k_pack_panel<8>, dim3((unsigned)g), dim3(BLK), 0, ctx->stream, xrows, N, X, ldx, xp, xperm);
             IG_LAUNCH_CHECK(ctx, "k_pack_panel");
             X = xp; sxc = 1; sxr = np; packed = true;
         }
     }
+    IG_REQUIRE(ctx, !xperm || packed, "csrmm: a panel-row permutation needs the packed path (N <= 8, panel <= 1 GiB)");
     const int rpw = 64 / (s.CL * s.NL);
     const int64_t waves = (rows + rpw - 1) / rpw;
     const int64_t blocks = (waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
@@ -454,6 +477,7 @@ int launch_gather(ig_ctx* ctx, int64_t rows, int64_t xrows, int64_t N, int64_t n
     const int32_t thr_long = defer ? 256 * nlw : 0x7fffffff;
     const int32_t thr_mid = !defer ? 0x7fffffff : (nlw > s.NL ? 16 * s.NL : thr_long);
     WorkLists wl{};
+    wl.yperm = yperm;
     if (defer) {
         if (int rc = ensure_worklists(ctx)) return rc;
         wl.rows[0] = ctx->d_worklist;
@@ -532,16 +556,16 @@ int launch_gather(ig_ctx* ctx, int64_t rows, int64_t xrows, int64_t N, int64_t n
         if (thr_mid < thr_long || rowlane) {                                                       \
             ig_prof_scope prof(ctx, "csrmm_rows_wave");                                            \
             if (b0) hipLaunchKernelGGL((k_csrmm_rows_wave<CL_, CONJ, 0>), dim3(gw), dim3(BLK), 0, ctx->stream, \
-                        N, rowptr, colind, vals, X, sxc, sxr, Y, ldy, alpha, beta, wl.rows[0], wl.count, wl.cap);   \
+                        N, rowptr, colind, vals, X, sxc, sxr, Y, ldy, alpha, beta, wl.rows[0], wl.count, wl.cap, wl.yperm);   \
             else    hipLaunchKernelGGL((k_csrmm_rows_wave<CL_, CONJ, 1>), dim3(gw), dim3(BLK), 0, ctx->stream, \
-                        N, rowptr, colind, vals, X, sxc, sxr, Y, ldy, alpha, beta, wl.rows[0], wl.count, wl.cap);   \
+                        N, rowptr, colind, vals, X, sxc, sxr, Y, ldy, alpha, beta, wl.rows[0], wl.count, wl.cap, wl.yperm);   \
         }                                                                                          \
         {                                                                                          \
             ig_prof_scope prof(ctx, "csrmm_rows_block");                                           \
             if (b0) hipLaunchKernelGGL((k_csrmm_rows_block<CL_, CONJ, 0>), dim3(gb), dim3(1024), 0, ctx->stream, \
-                        N, rowptr, colind, vals, X, sxc, sxr, Y, ldy, alpha, beta, wl.rows[1], wl.count + 1, wl.cap); \
+                        N, rowptr, colind, vals, X, sxc, sxr, Y, ldy, alpha, beta, wl.rows[1], wl.count + 1, wl.cap, wl.yperm); \
             else    hipLaunchKernelGGL((k_csrmm_rows_block<CL_, CONJ, 1>), dim3(gb), dim3(1024), 0, ctx->stream, \
-                        N, rowptr, colind, vals, X, sxc, sxr, Y, ldy, alpha, beta, wl.rows[1], wl.count + 1, wl.cap); \
+                        N, rowptr, colind, vals, X, sxc, sxr, Y, ldy, alpha, beta, wl.rows[1], wl.count + 1, wl.cap, wl.yperm); \
         }                                                                                          \
     } while (0)
         switch (s.CL) {
@@ -648,10 +672,23 @@ int ig_ccsrmm_t(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, int64_t nnz,
                                make_float2(ar, ai), make_float2(br, bi));
 }
 
+int ig_ccsrmm_rowperm(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, int64_t nnz,
+                      float ar, float ai, const void* vals, const int32_t* colind, const int32_t* rowptr,
+                      const void* X, int64_t ldx, float br, float bi, void* Y, int64_t ldy,
+                      const int32_t* yrow_perm) {
+    IG_REQUIRE(ctx, ctx != nullptr, "ig_ccsrmm_rowperm: ctx is NULL");
+    if (int rc = check_panel_args(ctx, "ig_ccsrmm_rowperm", K, M, N, nnz, vals, colind, rowptr, X, ldx, Y, ldy)) return rc;
+    if (N == 0 || M == 0) return IG_OK;
+    if (int rc = ig_set_device(ctx)) return rc;
+    return launch_gather<false>(ctx, M, K, N, nnz, rowptr, colind, (const float2*)vals,
+                                (const float2*)X, ldx, (float2*)Y, ldy, make_float2(ar, ai), make_float2(br, bi),
+                                GridMask{nullptr, 0, 0}, yrow_perm, nullptr);
+}
+
 int ig_ccsrmm_t_grid(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, int64_t nnz,
                      float ar, float ai, const void* vals_t, const int32_t* colind_t, const int32_t* rowptr_t,
                      const void* X, int64_t ldx, float br, float bi, void* Y, int64_t ldy,
-                     const int16_t* support, int64_t n0, int64_t nm) {
+                     const int16_t* support, int64_t n0, int64_t nm, const int32_t* xrow_perm) {
     IG_REQUIRE(ctx, ctx != nullptr, "ig_ccsrmm_t_grid: ctx is NULL");
     if (int rc = check_panel_args(ctx, "ig_ccsrmm_t_grid", M, K, N, nnz, vals_t, colind_t, rowptr_t, X, ldx, Y, ldy)) return rc;
     IG_REQUIRE(ctx, !support || (n0 > 0 && nm > 0 && n0 % 16 == 0 && K % (n0 * nm) == 0),
@@ -662,7 +699,7 @@ int ig_ccsrmm_t_grid(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, int64_t nnz,
     GridMask mask{reinterpret_cast<const short2*>(support), n0, nm};
     return launch_gather<true>(ctx, K, M, N, nnz, rowptr_t, colind_t, (const float2*)vals_t,
                                (const float2*)X, ldx, (float2*)Y, ldy,
-                               make_float2(ar, ai), make_float2(br, bi), mask);
+                               make_float2(ar, ai), make_float2(br, bi), mask, nullptr, xrow_perm);
 }
 
 // ---- host-side structure analysis -------------------------------------------

@@ -224,6 +224,8 @@ class SpMatrix(Operator):
                 self._matrix_d._exwrite = False
             if getattr(self, '_grid_support', None) is not None:
                 self._matrix_d.set_grid_support(*self._grid_support)
+            if getattr(self, '_row_order', None) is not None:
+                self._matrix_d.set_row_order(self._row_order)
         return self._matrix_d
 
     def csrmm_bytes(self, x, y, beta, forward):

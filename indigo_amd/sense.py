@@ -135,8 +135,9 @@ class SenseProblem(object):
         return w
 
     def grid_support(self, G):
-        """k-space support of a layout-1 gridding matrix G (T x P): int16 table of shape (n1 * n0/16, 2) with
-        [z_lo, z_hi) per (16-wide kx tile, ky) -- the kz range outside which no sample touches the grid.
+        """k-space support of a layout-1 gridding matrix G (T x P): int16 table with [z_lo, z_hi) per (16-wide
+        kx tile, ky) -- the kz range outside which no sample touches the grid -- followed by [y_lo, y_hi) per
+        kx tile (see ig_fft_exec_padded).
         A radial trajectory fills a ball: about half of the grid cube lies outside and is never needed."""
         n0, n1, n2 = self.oN
         assert n0 % 16 == 0
@@ -147,14 +148,30 @@ class SenseProblem(object):
         key = ky * (n0 // 16) + kx // 16
         order = np.argsort(key, kind='stable')
         key, kz = key[order], kz[order]
-        table = np.zeros((n1 * (n0 // 16), 2), dtype=np.int16)
+        nt = n0 // 16
+        table = np.zeros((n1 * nt + nt, 2), dtype=np.int16)
         if key.size:
             starts = np.flatnonzero(np.r_[True, key[1:] != key[:-1]])
             table[key[starts], 0] = np.minimum.reduceat(kz, starts)
             table[key[starts], 1] = np.maximum.reduceat(kz, starts) + 1
+        # second part: per kx tile the ky range with a non-empty z range (used by the transform's y pass)
+        nonempty = (table[:n1 * nt, 1] > table[:n1 * nt, 0]).reshape(n1, nt)
+        for t in range(nt):
+            ys = np.flatnonzero(nonempty[:, t])
+            if ys.size:
+                table[n1 * nt + t] = (ys[0], ys[-1] + 1)
         return table
 
-    def build_zpadfft(self, backend, coils=None, layout=1, support=None):
+    @staticmethod
+    def locality_order(G):
+        """Row order of a gridding matrix that keeps spatial neighbours together: samples sorted by the first
+        (lowest) grid column they touch, i.e. lexicographically by grid cell in the grid's memory order."""
+        first = np.full(G.shape[0], np.iinfo(np.int64).max, dtype=np.int64)
+        nz = np.flatnonzero(np.diff(G.indptr))
+        first[nz] = G.indices[G.indptr[nz]]
+        return np.argsort(first, kind='stable').astype(np.int32)
+
+    def build_zpadfft(self, backend, coils=None, layout=1, support=None, reorder=False):
         """A = KronI(C, G') * ZpadFFT: the `-O3` tree with S' and the FFT fused into one leaf
         (zero-pad aware transform; needs backend.supports_padded_fft(grid)).  The oversampled grid is
         private to this pair of leaves, so it may live in the (x, z, y) order (layout=1) that keeps the
@@ -168,6 +185,8 @@ class SenseProblem(object):
             # restrict the transform's z pass and the adjoint gridding to the k-space support of G'
             table = self.grid_support(Gm)
             G._grid_support = (table, self.oN[0], self.oN[2])
+        if reorder and Cn <= 8:
+            G._row_order = self.locality_order(Gm)
         Z = backend.ZpadFFT(self.oN, self.N, self.fused_weights(coils), layout=layout, support=table,
                             name='fft*zpad*apod*maps')
         A = backend.KronI(Cn, G) * Z

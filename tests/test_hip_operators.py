@@ -312,10 +312,18 @@ def test_padded_fft_with_support_table(hip):
     n0, n1, n2 = grid
     P, N = int(np.prod(grid)), int(np.prod(box))
     rng = np.random.default_rng(7)
-    table = np.zeros((n1 * (n0 // 16), 2), dtype=np.int16)
+    nt = n0 // 16
+    table = np.zeros((n1 * nt, 2), dtype=np.int16)
     table[:, 0] = rng.integers(0, 200, table.shape[0])
     table[:, 1] = table[:, 0] + rng.integers(0, 57, table.shape[0])          # some ranges empty
-    sup = hip.copy_array(table.reshape(-1))
+    tz = table.reshape(n1, nt, 2)
+    tz[:30, ::2] = 0                                                          # even kx tiles: no support for ky < 30
+    tz[220:, ::2] = 0                                                         #                 ... nor for ky >= 220
+    ypart = np.zeros((nt, 2), dtype=np.int16)                                 # second part: ky range per kx tile
+    for t in range(nt):
+        ys = np.flatnonzero(tz[:, t, 1] > tz[:, t, 0])
+        ypart[t] = (ys[0], ys[-1] + 1)
+    sup = hip.copy_array(np.concatenate([table, ypart]).reshape(-1))
     # membership mask in (x, z, y) memory order
     zlo = np.repeat(table[:, 0].reshape(n1, n0 // 16), 16, axis=1)          # (ky, kx)
     zhi = np.repeat(table[:, 1].reshape(n1, n0 // 16), 16, axis=1)
@@ -351,7 +359,7 @@ def test_padded_fft_with_support_table(hip):
     cols = rng.choice(np.flatnonzero(inside), size=T * 4)
     A = spp.csr_matrix((rand64c(T * 4, seed=4), cols, np.arange(0, T * 4 + 1, 4)), shape=(T, P))
     A_d = hip.csr_matrix(hip, A)
-    A_d.set_grid_support(table, n0, n2)
+    A_d.set_grid_support(np.concatenate([table, ypart]), n0, n2)
     xs = rand64c(T, C, seed=5)
     out_d = hip.copy_array(sentinel)
     A_d.adjoint(out_d, hip.copy_array(xs))
