@@ -38,6 +38,9 @@ namespace {
 // Non-temporal loads/stores in the 2-stage axis passes (every byte is touched exactly once per pass).
 // A/B on the 256^3 x 8 SENSE eval, same box, same process layout: 21.44 ms (off) -> 20.54 ms (both on);
 // loads alone 20.77, stores alone 20.98.
+#ifndef IG_FFT_MINWAVES
+#define IG_FFT_MINWAVES 1      // minimum waves per SIMD the 2-stage kernels are compiled for (register cap)
+#endif
 #ifndef IG_FFT_NT_LOAD
 #define IG_FFT_NT_LOAD 1
 #endif
@@ -241,13 +244,13 @@ struct PassDesc {
 // are never loaded and outputs outside [out_lo, out_hi) are never stored: that is what makes the
 // zero-padded forward / cropped inverse transforms cheap (SENSE: 1/8 of the grid is non-zero).
 template <int R1, int R2, int T, int W, bool AXIS0, int WMODE, bool BOXED>
-__global__ void __launch_bounds__(W * T)
+__global__ void __launch_bounds__(W * T, IG_FFT_MINWAVES)
 k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
     constexpr int n = R1 * R2, B1 = R2 / T, B2 = R1 / T, NT = W * T;
     constexpr bool NT_LD = IG_FFT_NT_LOAD, NT_ST = IG_FFT_NT_STORE;
     static_assert(R2 % T == 0 && R1 % T == 0 && T == 16, "lane groups of 16");
     extern __shared__ float2 lds[];
-    float2* __restrict__ tws = lds + n * W;
+    float2* __restrict__ tws = lds + 16 * T * W;
     const int tid = threadIdx.x;
     for (int k = tid; k < n; k += NT) tws[k] = tw[k];
 
@@ -260,10 +263,6 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
     const int64_t cb_in = k0 * d.in_s[0] + k1 * d.in_s[1] + k2 * d.in_s[2];
     const int64_t cb_out = k0 * d.out_s[0] + k1 * d.out_s[1] + k2 * d.out_s[2];
     const int64_t cb_w = WMODE ? k0 * d.w_s[0] + k1 * d.w_s[1] + k2 * d.w_s[2] : 0;
-    auto lidx = [&](int j) -> int {
-        if (AXIS0) return w * n + ((j & ~15) | ((j ^ (j / R1)) & 15));
-        return j * W + w;
-    };
     int in_lo = d.in_lo, in_hi = d.in_hi, out_lo = d.out_lo, out_hi = d.out_hi;
     if (BOXED && !AXIS0 && d.tile_range) {
         const int64_t col0 = (int64_t)blockIdx.x * W;                 // uniform over the workgroup
@@ -299,23 +298,29 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
         }
     }
     __syncthreads();            // twiddle table visible (the global loads above are already in flight)
+    static_assert(B1 == 1, "one stage-1 butterfly per thread");
+    RegFFT<R1>::run(v[0]);
 #pragma unroll
-    for (int q = 0; q < B1; ++q) {
-        const int b = t + q * T;
-        RegFFT<R1>::run(v[q]);
-        lds[lidx(b * R1)] = v[q][0];
-#pragma unroll
-        for (int k = 1; k < R1; ++k) lds[lidx(b * R1 + k)] = cmul(v[q][k], tws[b * k]);
-    }
-    __syncthreads();
+    for (int k = 1; k < R1; ++k) v[0][k] = cmul(v[0][k], tws[t * k]);
 
-    // ---- stage 2: radix R2 on rows b2 + k2*R1, outputs b2 + r*R1 straight to global memory
+    // ---- exchange + stage 2 in B2 = R1/16 rounds.  Stage-2 butterfly b2 = t + 16*q needs, from every
+    // stage-1 thread b, exactly its output k = b2: round q therefore moves only the outputs
+    // k in [16q, 16q+16) through LDS (row b*16 + k%16), i.e. 16 x 16 x W elements = 32 KB per round
+    // whatever R1 is.  Half the LDS of a one-shot exchange for n = 512 -> twice the workgroups per CU.
+    auto lidx2 = [&](int jr) -> int {           // jr = b*16 + kk, 256 rows
+        if (AXIS0) return w * (16 * T) + ((jr & ~15) | ((jr ^ (jr >> 4)) & 15));
+        return jr * W + w;
+    };
 #pragma unroll
     for (int q = 0; q < B2; ++q) {
+        if (q > 0) __syncthreads();             // the previous round's reads are done
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) lds[lidx2(t * 16 + kk)] = v[0][16 * q + kk];
+        __syncthreads();
         const int b2 = t + q * T;
         float2 u[R2];
 #pragma unroll
-        for (int k2 = 0; k2 < R2; ++k2) u[k2] = lds[lidx(b2 + k2 * R1)];
+        for (int k2 = 0; k2 < R2; ++k2) u[k2] = lds[lidx2(k2 * 16 + t)];
         RegFFT<R2>::run(u);
         if (valid) {
 #pragma unroll
@@ -507,7 +512,7 @@ int plan_axis(ig_ctx* ctx, ig_fft* p, int a) {
     if (two_stage) {
         ax.kind = 3; ax.W = 16; ax.T = 16; ax.nstages = 2;
         ax.rad.r[0] = ax.n == 512 ? 32 : 16; ax.rad.r[1] = 16;
-        ax.lds_bytes = ((size_t)ax.n * ax.W + ax.n) * 8;
+        ax.lds_bytes = ((size_t)16 * 16 * ax.W + ax.n) * 8;     // one exchange round + the twiddle table
         const void* fns[16] = {
             reinterpret_cast<const void*>(&k_fft_2stage<32, 16, 16, 16, true, 0, false>),
             reinterpret_cast<const void*>(&k_fft_2stage<32, 16, 16, 16, true, 0, true>),
