@@ -4,8 +4,9 @@
     python bench.py --gpus N --steps K --warmup W
 
 One "step" is one evaluation y = A^H A x of the composed non-Cartesian SENSE
-normal operator (the reference's `-O3` tree: S' -> FFT -> G' -> G'^H -> IFFT -> S'^H)
-on synthetic inputs already resident in HBM: image 256^3, 8 coils, oversampled
+normal operator (the reference's `-O3` tree: S' -> FFT -> G' -> G'^H -> IFFT -> S'^H;
+by default with S' and the FFT fused into the zero-pad-aware `ZpadFFT` leaf, `--tree o3`
+runs the reference's leaves one by one) on synthetic inputs already resident in HBM: image 256^3, 8 coils, oversampled
 grid 512^3, 3-D radial trajectory with 1,851,904 samples, width-4 (indigo
 width=2) Kaiser-Bessel gridding (BASELINE config 4).  For N > 1 (launched by
 torch.distributed.run, one rank per GPU) the 8 coils are sharded over the ranks
@@ -90,8 +91,14 @@ def main():
         os.environ["INDIGO_HIP_WITH_TORCH"] = "1"
         import torch
         import torch.distributed as dist
+        # one rank per GPU over RCCL; INDIGO_BENCH_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal only)
+        dist_backend = os.environ.get("INDIGO_BENCH_DIST_BACKEND", "nccl")
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=dist_backend)
 
     import numpy as np
     from indigo_amd.backends import get_backend
@@ -202,6 +209,12 @@ def main():
                        "algorithmic_GB_per_eval_per_gpu": alg_bytes_rank / 1e9},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
+            # whole-eval rate in the reference's own bytes model, and the per-call-site breakdown
+            "eval_algorithmic_GBps_per_gpu": alg_bytes_rank / (ms_per_step * 1e-3) / 1e9,
+            "eval_frac_of_hbm_peak": alg_bytes_rank / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "kernels": {k: {"launches_per_eval": v['launches'] / args.steps, "avg_ms": round(v['avg_ms'], 4),
+                            "GBps": round(v['bytes'] / v['launches'] / (v['avg_ms'] * 1e-3) / 1e9, 1) if v['bytes'] else None}
+                        for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['total_ms'])},
         }
         print(json.dumps(out), flush=True)
     if world > 1:
