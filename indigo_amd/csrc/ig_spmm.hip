@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(BLK)
 k_csrmm_rowlane(int64_t M, int64_t N,
                 const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
                 const float2* __restrict__ vals,
-                const float2* __restrict__ X, int64_t ldx,
+                const float2* __restrict__ X, int64_t ldx, int64_t sxr,
                 float2* __restrict__ Y, int64_t ldy,
                 float2 alpha, float2 beta, int xcd_remap,
                 WorkLists wl, int32_t thr_mid, int32_t thr_long, GridMask mask) {
@@ -194,7 +194,9 @@ k_csrmm_rowlane(int64_t M, int64_t N,
             const float2 v = vals[p];
             if (PACKED && NC >= 2) {
                 // packed panel: the NC values of row k are contiguous (NC*8 bytes, 16-byte aligned)
-                const float4* __restrict__ q = reinterpret_cast<const float4*>(X + (int64_t)k * NC);
+                // packed panel: row k holds its columns contiguously (sxr elements per row); this chunk of NC
+                // columns is NC*8 contiguous, 16-byte aligned bytes
+                const float4* __restrict__ q = reinterpret_cast<const float4*>(X + (int64_t)k * sxr + jb);
                 float4 t4[NC / 2 > 0 ? NC / 2 : 1];
 #pragma unroll
                 for (int h = 0; h < NC / 2; ++h) t4[h] = q[h];
@@ -207,7 +209,7 @@ k_csrmm_rowlane(int64_t M, int64_t N,
 #pragma unroll
                 for (int c = 0; c < NC; ++c)
                     if (jb + c < N)
-                        acc_nz<CONJ>(acc[c], v, X[PACKED ? (int64_t)k * NC + c : (jb + c) * ldx + k]);
+                        acc_nz<CONJ>(acc[c], v, X[PACKED ? (int64_t)k * sxr + jb + c : (jb + c) * ldx + k]);
             }
         }
 #pragma unroll
@@ -400,6 +402,29 @@ k_pack_panel(int64_t rows, int64_t N, const float2* __restrict__ X, int64_t ld, 
     }
 }
 
+// The same repacking for wide panels (NP = 16, 32, 64) as an LDS-tiled transpose: a workgroup moves 64 panel
+// rows x NP columns, reading 512 contiguous bytes per column and writing NP*8 contiguous bytes per row.
+template <int NP>
+__global__ void __launch_bounds__(BLK)
+k_pack_panel_tiled(int64_t rows, int64_t N, const float2* __restrict__ X, int64_t ld, float2* __restrict__ Xp,
+                   const int32_t* __restrict__ xperm) {
+    __shared__ float2 tile[NP][65];
+    const int tid = threadIdx.x;
+    for (int64_t k0 = (int64_t)blockIdx.x * 64; k0 < rows; k0 += (int64_t)gridDim.x * 64) {
+        const int kk = tid & 63;
+        const int64_t k = k0 + kk;
+        const int64_t src = k < rows ? (xperm ? (int64_t)xperm[k] : k) : 0;
+        for (int c = tid >> 6; c < NP; c += BLK / 64)
+            tile[c][kk] = (c < N && k < rows) ? X[c * ld + src] : make_float2(0.f, 0.f);
+        __syncthreads();
+        for (int e = tid; e < 64 * NP; e += BLK) {
+            const int r = e / NP, c = e % NP;
+            if (k0 + r < rows) Xp[(k0 + r) * NP + c] = tile[c][r];
+        }
+        __syncthreads();
+    }
+}
+
 inline int pow2_ceil(int64_t v, int cap) {
     int p = 1;
     while (p < v && p < cap) p <<= 1;
@@ -441,10 +466,13 @@ int launch_gather(ig_ctx* ctx, int64_t rows, int64_t xrows, int64_t N, int64_t n
     // once so that one gathered row is one contiguous 16..64-byte access instead of N scattered ones.
     int64_t sxc = ldx, sxr = 1;          // element (k, j) of X lives at X[j*sxc + k*sxr]
     bool packed = false;
-    if (((N >= 2 && N <= 8 && nnz >= 4 * xrows) || (xperm && N <= 8)) && env_flag("INDIGO_HIP_SPMM_PACK", true)) {
-        const int np = s.CL;             // pow2 >= N, <= 8
+    // Packing costs one read + one write of the panel (16 B per element) and turns nnz*N scattered 8-byte gathers
+    // (each pulling a 32..64-byte sector) into nnz contiguous N*8-byte ones: worth it once every panel row is
+    // gathered at least about once (nnz >= xrows); always for small hot panels.
+    if (((N >= 2 && N <= 64 && nnz >= xrows) || (xperm && N <= 8)) && env_flag("INDIGO_HIP_SPMM_PACK", true)) {
+        const int np = s.CL;             // pow2 >= N, <= 64
         const size_t need = (size_t)xrows * np * 8;
-        if (need <= ((size_t)1 << 30)) {
+        if (need <= ((size_t)16 << 30)) {
             if (ctx->xpack_bytes < need) {
                 if (ctx->d_xpack) { IG_HIP(ctx, hipStreamSynchronize(ctx->stream)); IG_HIP(ctx, hipFree(ctx->d_xpack)); ctx->d_xpack = nullptr; ctx->xpack_bytes = 0; }
                 IG_HIP(ctx, hipMalloc((void**)&ctx->d_xpack, need));
@@ -458,7 +486,14 @@ int launch_gather(ig_ctx* ctx, int64_t rows, int64_t xrows, int64_t N, int64_t n
             if (np == 1)      hipLaunchKernelGGL(k_pack_panel<1>, dim3((unsigned)g), dim3(BLK), 0, ctx->stream, xrows, N, X, ldx, xp, xperm);
             else if (np == 2) hipLaunchKernelGGL(k_pack_panel<2>, dim3((unsigned)g), dim3(BLK), 0, ctx->stream, xrows, N, X, ldx, xp, xperm);
             else if (np == 4) hipLaunchKernelGGL(k_pack_panel<4>, dim3((unsigned)g), dim3(BLK), 0, ctx->stream, xrows, N, X, ldx, xp, xperm);
-            else              hipLaunchKernelGGL(k_pack_panel<8>, dim3((unsigned)g), dim3(BLK), 0, ctx->stream, xrows, N, X, ldx, xp, xperm);
+            else if (np == 8) hipLaunchKernelGGL(k_pack_panel<8>, dim3((unsigned)g), dim3(BLK), 0, ctx->stream, xrows, N, X, ldx, xp, xperm);
+            else {
+                int64_t gt = (xrows + 63) / 64;
+                if (gt > cap) gt = cap;
+                if (np == 16)      hipLaunchKernelGGL(k_pack_panel_tiled<16>, dim3((unsigned)gt), dim3(BLK), 0, ctx->stream, xrows, N, X, ldx, xp, xperm);
+                else if (np == 32) hipLaunchKernelGGL(k_pack_panel_tiled<32>, dim3((unsigned)gt), dim3(BLK), 0, ctx->stream, xrows, N, X, ldx, xp, xperm);
+                else               hipLaunchKernelGGL(k_pack_panel_tiled<64>, dim3((unsigned)gt), dim3(BLK), 0, ctx->stream, xrows, N, X, ldx, xp, xperm);
+            }
             IG_LAUNCH_CHECK(ctx, "k_pack_panel");
             X = xp; sxc = 1; sxr = np; packed = true;
         }
@@ -486,26 +521,33 @@ int launch_gather(ig_ctx* ctx, int64_t rows, int64_t xrows, int64_t N, int64_t n
         wl.cap = WL_CAP;
         IG_HIP(ctx, hipMemsetAsync(wl.count, 0, 2 * sizeof(uint32_t), ctx->stream));
     }
-    const bool rowlane = s.NL == 1 && env_flag("INDIGO_HIP_SPMM_ROWLANE", true);
+    // row-per-lane only pays for (mostly) empty / very short rows; NL == 1 alone also happens for wide panels
+    // ... and for wide packed panels with short rows, where a row-slot's 8-byte stores would each hit a different
+    // line of Y (config 3's transpose, 64 columns, 3 nonzeros/row: 15.7 ms row-per-lane vs 56.6 ms row-slot; its
+    // forward, 27 nonzeros/row, is the other way round: 4.8 vs 17.1 ms)
+    const bool rowlane = ((s.NL == 1 && nnz <= 2 * rows) || (packed && N >= 16 && nnz <= 8 * rows)) &&
+                         env_flag("INDIGO_HIP_SPMM_ROWLANE", true);
     if (rowlane) {
         ig_prof_scope prof(ctx, CONJ ? "csrmm_rowlane_conj" : "csrmm_rowlane");
         const int64_t rblocks = (rows + BLK - 1) / BLK;
-        const int32_t tm = defer ? (thr_long < 16 ? thr_long : 16) : 0x7fffffff;
+        // sparse-row matrices defer rows beyond 16 nonzeros; wide-panel use keeps ordinary rows inline
+        const int32_t tm_want = nnz <= 2 * rows ? 16 : 512;
+        const int32_t tm = defer ? (thr_long < tm_want ? thr_long : tm_want) : 0x7fffffff;
 #define IG_ROWLANE(NC_)                                                                            \
     do {                                                                                           \
         if (packed) {                                                                              \
             if (b0) hipLaunchKernelGGL((k_csrmm_rowlane<NC_, CONJ, 0, true>), dim3((unsigned)rblocks), \
-                        dim3(BLK), 0, ctx->stream, rows, N, rowptr, colind, vals, X, sxc, Y, ldy,  \
+                        dim3(BLK), 0, ctx->stream, rows, N, rowptr, colind, vals, X, sxc, sxr, Y, ldy, \
                         alpha, beta, xcd, wl, tm, thr_long, mask);                                       \
             else    hipLaunchKernelGGL((k_csrmm_rowlane<NC_, CONJ, 1, true>), dim3((unsigned)rblocks), \
-                        dim3(BLK), 0, ctx->stream, rows, N, rowptr, colind, vals, X, sxc, Y, ldy,  \
+                        dim3(BLK), 0, ctx->stream, rows, N, rowptr, colind, vals, X, sxc, sxr, Y, ldy, \
                         alpha, beta, xcd, wl, tm, thr_long, mask);                                       \
         } else                                                                                     \
         if (b0) hipLaunchKernelGGL((k_csrmm_rowlane<NC_, CONJ, 0, false>), dim3((unsigned)rblocks), \
-                    dim3(BLK), 0, ctx->stream, rows, N, rowptr, colind, vals, X, sxc, Y, ldy,      \
+                    dim3(BLK), 0, ctx->stream, rows, N, rowptr, colind, vals, X, sxc, sxr, Y, ldy, \
                     alpha, beta, xcd, wl, tm, thr_long, mask);                                           \
         else    hipLaunchKernelGGL((k_csrmm_rowlane<NC_, CONJ, 1, false>), dim3((unsigned)rblocks), \
-                    dim3(BLK), 0, ctx->stream, rows, N, rowptr, colind, vals, X, sxc, Y, ldy,      \
+                    dim3(BLK), 0, ctx->stream, rows, N, rowptr, colind, vals, X, sxc, sxr, Y, ldy, \
                     alpha, beta, xcd, wl, tm, thr_long, mask);                                           \
     } while (0)
         if (s.CL >= 8) IG_ROWLANE(8);

@@ -85,7 +85,31 @@ def empty_rows_probe():
     report(B, 5)
 
 
+def cfg3():
+    """BASELINE config 3: 3-D radial gridding CSR (1,851,904 x 256^3, 27 taps/row, nnz ~5e7) x 64-column panel"""
+    from indigo_amd.sense import SenseProblem
+    B = get_backend("hip")
+    c64 = np.dtype('complex64')
+    ncol = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+    p = SenseProblem.synthetic((128,) * 3, 1, nspokes=3617, nreadout=512, seed=3)
+    G = p.fused_interp()
+    S = B.SpMatrix(G, name='G')
+    T, P = G.shape
+    x = B.copy_array(rand64c(P, ncol, seed=1)); k = B.zero_array((T, ncol), c64); xa = B.zero_array((P, ncol), c64)
+    S.eval(k, x); S.H.eval(xa, k); B.barrier()
+    fb = S.csrmm_bytes(x, k, 0, True); ab = S.csrmm_bytes(k, xa, 0, False)
+    print("cfg3 G: %d x %d nnz %d col_frac %.3f; algorithmic fwd %.2f GB adj %.2f GB" % (T, P, G.nnz, S._matrix_d._col_frac, fb / 1e9, ab / 1e9))
+    B.profile(True)
+    for _ in range(5):
+        S.eval(k, x)
+        S.H.eval(xa, k)
+    B.profile(False)
+    report(B, 5, {"csrmm_gather": fb, "csrmm_gather_conj": ab, "csrmm_rowlane_conj": ab})
+
+
 if len(sys.argv) > 1 and sys.argv[1] == "empty":
     empty_rows_probe()
+elif len(sys.argv) > 1 and sys.argv[1] == "cfg3":
+    cfg3()
 elif __name__ == "__main__":
     main()
