@@ -41,6 +41,9 @@ namespace {
 #ifndef IG_FFT_MINWAVES
 #define IG_FFT_MINWAVES 1      // minimum waves per SIMD the 2-stage kernels are compiled for (register cap)
 #endif
+#ifndef IG_FFT_MINWAVES_BOXED
+#define IG_FFT_MINWAVES_BOXED 3    // the boxed strided 512-point kernel needs 170 VGPRs uncapped; 168 fits three waves
+#endif
 #ifndef IG_FFT_NT_LOAD
 #define IG_FFT_NT_LOAD 1
 #endif
@@ -244,7 +247,7 @@ struct PassDesc {
 // are never loaded and outputs outside [out_lo, out_hi) are never stored: that is what makes the
 // zero-padded forward / cropped inverse transforms cheap (SENSE: 1/8 of the grid is non-zero).
 template <int R1, int R2, int T, int W, bool AXIS0, int WMODE, bool BOXED>
-__global__ void __launch_bounds__(W * T, IG_FFT_MINWAVES)
+__global__ void __launch_bounds__(W * T, (BOXED && !AXIS0 && R1 == 32) ? IG_FFT_MINWAVES_BOXED : IG_FFT_MINWAVES)
 k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
     constexpr int n = R1 * R2, B1 = R2 / T, B2 = R1 / T, NT = W * T;
     constexpr bool NT_LD = IG_FFT_NT_LOAD, NT_ST = IG_FFT_NT_STORE;
@@ -263,6 +266,8 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
     const int64_t cb_in = k0 * d.in_s[0] + k1 * d.in_s[1] + k2 * d.in_s[2];
     const int64_t cb_out = k0 * d.out_s[0] + k1 * d.out_s[1] + k2 * d.out_s[2];
     const int64_t cb_w = WMODE ? k0 * d.w_s[0] + k1 * d.w_s[1] + k2 * d.w_s[2] : 0;
+    // x-axis passes run along contiguous memory by construction: unit strides known at compile time
+    const int64_t isj = AXIS0 ? 1 : d.in_sj, osj = AXIS0 ? 1 : d.out_sj, wsj = AXIS0 ? 1 : d.w_sj;
     int in_lo = d.in_lo, in_hi = d.in_hi, out_lo = d.out_lo, out_hi = d.out_hi;
     if (BOXED && !AXIS0 && d.tile_range) {
         const int64_t col0 = (int64_t)blockIdx.x * W;                 // uniform over the workgroup
@@ -285,13 +290,16 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
 #pragma unroll
     for (int q = 0; q < B1; ++q) {
         const int b = t + q * T;
+        // in-box inputs j = b + k*R2  <=>  k in [klo, khi): two per-thread bounds instead of two compares per element
+        const int klo = BOXED ? (in_lo - b + R2 - 1 >= 0 ? (in_lo - b + R2 - 1) / R2 : 0) : 0;
+        const int khi = BOXED ? (in_hi - b + R2 - 1 >= 0 ? (in_hi - b + R2 - 1) / R2 : 0) : R1;
 #pragma unroll
         for (int k = 0; k < R1; ++k) {
             const int j = b + k * R2;
             float2 a = make_float2(0.f, 0.f);
-            if (valid && (!BOXED || (j >= in_lo && j < in_hi))) {
-                a = ld_stream<NT_LD>(d.in + cb_in + (int64_t)j * d.in_sj);
-                if (WMODE == 1) a = cmul(a, d.w[cb_w + (int64_t)j * d.w_sj]);
+            if (valid && (!BOXED || (k >= klo && k < khi))) {
+                a = ld_stream<NT_LD>(d.in + cb_in + (int64_t)j * isj);
+                if (WMODE == 1) a = cmul(a, d.w[cb_w + (int64_t)j * wsj]);
             }
             if (d.inverse) a.y = -a.y;
             v[q][k] = a;
@@ -323,14 +331,17 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
         for (int k2 = 0; k2 < R2; ++k2) u[k2] = lds[lidx2(k2 * 16 + t)];
         RegFFT<R2>::run(u);
         if (valid) {
+            // kept outputs j = b2 + r*R1  <=>  r in [rlo, rhi)
+            const int rlo = BOXED ? (out_lo - b2 + R1 - 1 >= 0 ? (out_lo - b2 + R1 - 1) / R1 : 0) : 0;
+            const int rhi = BOXED ? (out_hi - b2 + R1 - 1 >= 0 ? (out_hi - b2 + R1 - 1) / R1 : 0) : R2;
 #pragma unroll
             for (int r = 0; r < R2; ++r) {
                 const int j = b2 + r * R1;
-                if (!BOXED || (j >= out_lo && j < out_hi)) {
+                if (!BOXED || (r >= rlo && r < rhi)) {
                     float2 a = u[r];
                     if (d.inverse) a.y = -a.y;
-                    if (WMODE == 2) a = cmulc(d.w[cb_w + (int64_t)j * d.w_sj], a);
-                    st_stream<NT_ST>(d.out + cb_out + (int64_t)j * d.out_sj, a);
+                    if (WMODE == 2) a = cmulc(d.w[cb_w + (int64_t)j * wsj], a);
+                    st_stream<NT_ST>(d.out + cb_out + (int64_t)j * osj, a);
                 }
             }
         }
