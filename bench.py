@@ -169,6 +169,12 @@ def main():
 
     # dominant kernel and its roofline point.  The event brackets are per call site; call sites that launch
     # the same device kernel (the two strided FFT axes) are merged so the figure matches rocprofv3's row.
+    if fused_fft:
+        # price the fused passes with their exact compulsory bytes (box and k-space support taken into account)
+        exact = p.zpadfft_pass_bytes(len(coils), getattr(p, 'last_support_table', None))
+        for name, nbytes in exact.items():
+            if name in prof:
+                prof[name]['bytes'] = float(nbytes) * prof[name]['launches']
     kernels = {}
     for name, d in prof.items():
         sym = KERNEL_SYMBOL.get(name, name)

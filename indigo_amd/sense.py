@@ -162,6 +162,34 @@ class SenseProblem(object):
                 table[n1 * nt + t] = (ys[0], ys[-1] + 1)
         return table
 
+    def zpadfft_pass_bytes(self, ncoils, table=None):
+        """Compulsory HBM bytes of each axis pass of the fused transform (layout 1): what the pass must read
+        plus what it must write, given the image box and -- if present -- the k-space support table.
+        These are the per-launch "algorithmic bytes" bench.py prices the fused passes with (the reference
+        has no equivalent kernels; the rocprofv3 PMC traffic agrees with these figures)."""
+        n0, n1, n2 = self.oN
+        b0, b1, b2 = self.N
+        C, nt = ncoils, n0 // 16
+        bvol, cvol, vol = b0 * b1 * b2, n0 * b1 * b2, n0 * n1 * n2
+        if table is None:
+            zlen = np.full(n1 * nt, n2, dtype=np.int64)
+            ylen = np.full(nt, n1, dtype=np.int64)
+        else:
+            zlen = (table[:n1 * nt, 1].astype(np.int64) - table[:n1 * nt, 0]).clip(0)
+            ylen = (table[n1 * nt:, 1].astype(np.int64) - table[n1 * nt:, 0]).clip(0)
+        z_sup = int(zlen.sum()) * 16                 # grid points inside the support, per coil
+        z_tiles = int(np.count_nonzero(zlen))        # (kx tile, ky) columns with any support
+        y_sup = int(ylen.sum()) * 16 * b2            # points the y pass produces / consumes on its grid side
+        e = 8 * C
+        return {
+            "fft_pad_x": bvol * 8 + bvol * e + cvol * e,
+            "fft_pad_y": cvol * e + y_sup * e,
+            "fft_pad_z": z_tiles * 16 * b2 * e + z_sup * e,
+            "fft_crop_z": z_sup * e + n1 * nt * 16 * b2 * e,
+            "fft_crop_y": y_sup * e + cvol * e,
+            "fft_crop_x": cvol * e + bvol * e + bvol * e,
+        }
+
     @staticmethod
     def locality_order(G):
         """Row order of a gridding matrix that keeps spatial neighbours together: samples sorted by the first
@@ -185,6 +213,7 @@ class SenseProblem(object):
             # restrict the transform's z pass and the adjoint gridding to the k-space support of G'
             table = self.grid_support(Gm)
             G._grid_support = (table, self.oN[0], self.oN[2])
+        self.last_support_table = table
         if reorder and Cn <= 8:
             G._row_order = self.locality_order(Gm)
         Z = backend.ZpadFFT(self.oN, self.N, self.fused_weights(coils), layout=layout, support=table,
