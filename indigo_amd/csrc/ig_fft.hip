@@ -41,9 +41,6 @@ namespace {
 #ifndef IG_FFT_MINWAVES
 #define IG_FFT_MINWAVES 1      // minimum waves per SIMD the 2-stage kernels are compiled for (register cap)
 #endif
-#ifndef IG_FFT_MINWAVES_BOXED
-#define IG_FFT_MINWAVES_BOXED 3    // the boxed strided 512-point kernel needs 170 VGPRs uncapped; 168 fits three waves
-#endif
 #ifndef IG_FFT_NT_LOAD
 #define IG_FFT_NT_LOAD 1
 #endif
@@ -71,6 +68,25 @@ template <bool NT>
 __device__ __forceinline__ void st_stream(float2* p, float2 a) {
     if (NT) { v2f_t v; v.x = a.x; v.y = a.y; __builtin_nontemporal_store(v, reinterpret_cast<v2f_t*>(p)); }
     else *p = a;
+}
+
+// Raw buffer accesses: 128-bit descriptor (wave-uniform base, 2 GB window) + per-lane 32-bit byte offset + uniform
+// byte offset.  A lane offset >= the window (IG_OOB) is out of range: loads return 0, stores are dropped.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef unsigned int v2u_t __attribute__((ext_vector_type(2)));
+#define IG_OOB 0x80000000u
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)IG_OOB, 0x00020000);
+}
+template <bool NT>
+__device__ __forceinline__ float2 buf_ld(rsrc_t r, unsigned voff, unsigned soff) {
+    const v2u_t v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, NT ? 2 : 0);
+    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+}
+template <bool NT>
+__device__ __forceinline__ void buf_st(rsrc_t r, unsigned voff, unsigned soff, float2 a) {
+    v2u_t v; v.x = __float_as_uint(a.x); v.y = __float_as_uint(a.y);
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, NT ? 2 : 0);
 }
 
 __device__ __forceinline__ void bfly2(float2& a, float2& b) {
@@ -215,6 +231,32 @@ template <int N> struct RegFFT {      // N = 16, 32: radix-4 decimation in frequ
     }
 };
 
+// The same DFT when only the middle half of the inputs, x[N/4 .. 3N/4), is non-zero (the image box of a
+// 2x-oversampled grid): the first radix-4 layer collapses to one add/sub pair per butterfly and the outer
+// quarters of x are never read, so they cost neither loads nor registers.
+template <int N> struct RegFFTHalfIn {
+    __device__ static __forceinline__ void run(float2 (&x)[N]) {
+        constexpr int M = N / 4;
+        float2 z[4][M];
+#pragma unroll
+        for (int r = 0; r < M; ++r) {
+            const float2 a1 = x[r + M], a2 = x[r + 2 * M];
+            const float2 t3 = mul_mi(a1);
+            z[0][r] = cadd(a2, a1);
+            z[1][r] = mul_w32(csub(t3, a2), r * (32 / N));
+            z[2][r] = mul_w32(csub(a2, a1), r * 2 * (32 / N));
+            const float2 s = cadd(a2, t3);
+            z[3][r] = mul_w32(make_float2(-s.x, -s.y), r * 3 * (32 / N));
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) RegFFT<M>::run(z[q]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int k = 0; k < M; ++k) x[4 * k + q] = z[q][k];
+    }
+};
+
 // One axis pass, described generally enough for plain, zero-padded and cropped transforms.
 // Columns are enumerated by three indices (k0 fastest, then k1, k2); element j of column k lives at
 //   in  + k0*in_s[0]  + k1*in_s[1]  + k2*in_s[2]  + j*in_sj      (read only for in_lo  <= j < in_hi, else 0)
@@ -227,6 +269,7 @@ struct PassDesc {
     int64_t in_sj, out_sj, w_sj;
     int64_t in_s[3], out_s[3], w_s[3];
     int64_t ext0, ext1, ncols;
+    unsigned tpr;               // tiles per (k1, k2) row = ceil(ext0 / W); filled in by the launcher
     int in_lo, in_hi, out_lo, out_hi;
     int inverse;
     // optional per-tile override of the box along the transform axis (strided passes, W | ext0):
@@ -234,7 +277,7 @@ struct PassDesc {
     // range are skipped altogether), mode 2 narrows the INPUT box (everything outside reads as zero)
     const short2* tile_range;
     int tile_range_mode;
-    int64_t tile_range_k1;      // table row stride per k1 (ext0 / W), or 0 if the ranges do not depend on k1
+    int64_t tile_range_k1;      // table row stride per k1 (tiles per row), or 0 if the ranges do not depend on k1
 };
 
 // Two-stage kernel for n = R1*R2 (256 = 16x16, 512 = 32x16): the whole column lives in registers
@@ -246,32 +289,32 @@ struct PassDesc {
 // (axis 0 uses a 16-element XOR swizzle of the line).  Inputs outside [in_lo, in_hi) are zeros that
 // are never loaded and outputs outside [out_lo, out_hi) are never stored: that is what makes the
 // zero-padded forward / cropped inverse transforms cheap (SENSE: 1/8 of the grid is non-zero).
-template <int R1, int R2, int T, int W, bool AXIS0, int WMODE, bool BOXED>
-__global__ void __launch_bounds__(W * T, (BOXED && !AXIS0 && R1 == 32) ? IG_FFT_MINWAVES_BOXED : IG_FFT_MINWAVES)
+// HALF selects boxes known at compile time (the image box of a 2x-oversampled grid is [n/4, 3n/4)):
+//   1: input half, output box at run time      3: input half, output full
+//   2: output half, input box at run time      4: output half, input full
+// Half inputs prune the first butterfly layer; compile-time boxes need no predicates or bounds registers.
+template <int R1, int R2, int T, int W, bool AXIS0, int WMODE, bool BOXED, int HALF>
+__global__ void __launch_bounds__(W * T, IG_FFT_MINWAVES)
 k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
     constexpr int n = R1 * R2, B1 = R2 / T, B2 = R1 / T, NT = W * T;
     constexpr bool NT_LD = IG_FFT_NT_LOAD, NT_ST = IG_FFT_NT_STORE;
-    static_assert(R2 % T == 0 && R1 % T == 0 && T == 16, "lane groups of 16");
+    constexpr bool HALF_IN = HALF == 1 || HALF == 3, HALF_OUT = HALF == 2 || HALF == 4;
+    static_assert(R2 % T == 0 && R1 % T == 0 && T == 16 && B1 == 1, "lane groups of 16, one stage-1 butterfly per thread");
     extern __shared__ float2 lds[];
-    float2* __restrict__ tws = lds + 16 * T * W;
+    float2* __restrict__ tws = lds + (AXIS0 ? 16 * 17 * W : 16 * T * W);
     const int tid = threadIdx.x;
     for (int k = tid; k < n; k += NT) tws[k] = tw[k];
 
     const int t = AXIS0 ? (tid % T) : (tid / W);
     const int w = AXIS0 ? (tid / T) : (tid % W);
-    const int64_t col = (int64_t)blockIdx.x * W + w;
-    const bool valid = col < d.ncols;
-    const int64_t k0 = col % d.ext0, rest = col / d.ext0;
-    const int64_t k1 = rest % d.ext1, k2 = rest / d.ext1;
-    const int64_t cb_in = k0 * d.in_s[0] + k1 * d.in_s[1] + k2 * d.in_s[2];
-    const int64_t cb_out = k0 * d.out_s[0] + k1 * d.out_s[1] + k2 * d.out_s[2];
-    const int64_t cb_w = WMODE ? k0 * d.w_s[0] + k1 * d.w_s[1] + k2 * d.w_s[2] : 0;
-    // x-axis passes run along contiguous memory by construction: unit strides known at compile time
-    const int64_t isj = AXIS0 ? 1 : d.in_sj, osj = AXIS0 ? 1 : d.out_sj, wsj = AXIS0 ? 1 : d.w_sj;
+    // ---- the workgroup's tile: W consecutive k0 of one (k1, k2) row; everything below is wave-uniform
+    const unsigned tile = blockIdx.x;
+    const unsigned tr = tile % d.tpr, rest = tile / d.tpr;
+    const unsigned k1 = rest % d.ext1, k2 = rest / d.ext1;
+    const int64_t k0u = (int64_t)tr * W;
     int in_lo = d.in_lo, in_hi = d.in_hi, out_lo = d.out_lo, out_hi = d.out_hi;
     if (BOXED && !AXIS0 && d.tile_range) {
-        const int64_t col0 = (int64_t)blockIdx.x * W;                 // uniform over the workgroup
-        const short2 r = d.tile_range[((col0 / d.ext0) % d.ext1) * d.tile_range_k1 + (col0 % d.ext0) / W];
+        const short2 r = d.tile_range[(int64_t)k1 * d.tile_range_k1 + tr];
         if (d.tile_range_mode == 1) {
             out_lo = out_lo > r.x ? out_lo : r.x;
             out_hi = out_hi < r.y ? out_hi : r.y;
@@ -281,69 +324,87 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
             in_hi = in_hi < r.y ? in_hi : r.y;
         }
     }
-    // (A persistent, grid-stride variant that prefetched the next tile's inputs into the dead stage-1
-    // registers while stage 2 ran was measured 10 % SLOWER on the SENSE eval: it needs all 256 VGPRs,
-    // spills, and the two co-resident workgroups per CU already overlap each other's phases.)
+    // Buffer descriptors based at the tile's first column: every access is descriptor + a wave-uniform byte
+    // offset (SGPR, or an immediate on axis 0) + ONE per-lane 32-bit offset.  A lane offset of IG_OOB fails the
+    // hardware range check -- the load returns zero, the store is dropped -- which is how boxes and the ragged
+    // last tile are predicated without a branch, so all loads of a stage issue back to back.
+    const rsrc_t r_in = make_rsrc(d.in + (k0u * d.in_s[0] + (int64_t)k1 * d.in_s[1] + (int64_t)k2 * d.in_s[2]));
+    const rsrc_t r_out = make_rsrc(d.out + (k0u * d.out_s[0] + (int64_t)k1 * d.out_s[1] + (int64_t)k2 * d.out_s[2]));
+    const rsrc_t r_w = make_rsrc(WMODE ? d.w + (k0u * d.w_s[0] + (int64_t)k1 * d.w_s[1] + (int64_t)k2 * d.w_s[2]) : nullptr);
+    const bool valid = k0u + w < d.ext0;
+    // x-axis passes run along contiguous memory by construction: unit strides known at compile time
+    const unsigned isj = AXIS0 ? 1u : (unsigned)d.in_sj, osj = AXIS0 ? 1u : (unsigned)d.out_sj, wsj = AXIS0 ? 1u : (unsigned)d.w_sj;
+    const unsigned l_in = valid ? ((unsigned)w * (unsigned)d.in_s[0] + (unsigned)t * isj) * 8u : IG_OOB;
+    const unsigned l_out = valid ? ((unsigned)w * (unsigned)d.out_s[0] + (unsigned)t * osj) * 8u : IG_OOB;
+    const unsigned l_w = (WMODE && valid) ? ((unsigned)w * (unsigned)d.w_s[0] + (unsigned)t * wsj) * 8u : IG_OOB;
 
-    // ---- stage 1: radix R1 on inputs b + k*R2, results (times w_n^{b k}) to LDS row b*R1 + k
-    float2 v[B1][R1];
-#pragma unroll
-    for (int q = 0; q < B1; ++q) {
-        const int b = t + q * T;
-        // in-box inputs j = b + k*R2  <=>  k in [klo, khi): two per-thread bounds instead of two compares per element
-        const int klo = BOXED ? (in_lo - b + R2 - 1 >= 0 ? (in_lo - b + R2 - 1) / R2 : 0) : 0;
-        const int khi = BOXED ? (in_hi - b + R2 - 1 >= 0 ? (in_hi - b + R2 - 1) / R2 : 0) : R1;
+    // ---- stage 1: radix R1 on inputs j = t + k*R2, results (times w_n^{t k}) to the exchange
+    float2 v[R1];
+    {
+        // in-box inputs  <=>  k in [klo, khi): two per-thread bounds instead of two compares per element
+        const int klo = in_lo - t + R2 - 1 >= 0 ? (in_lo - t + R2 - 1) / R2 : 0;
+        const int khi = in_hi - t + R2 - 1 >= 0 ? (in_hi - t + R2 - 1) / R2 : 0;
+        float2 wv[R1];
 #pragma unroll
         for (int k = 0; k < R1; ++k) {
-            const int j = b + k * R2;
-            float2 a = make_float2(0.f, 0.f);
-            if (valid && (!BOXED || (k >= klo && k < khi))) {
-                a = ld_stream<NT_LD>(d.in + cb_in + (int64_t)j * isj);
-                if (WMODE == 1) a = cmul(a, d.w[cb_w + (int64_t)j * wsj]);
-            }
-            if (d.inverse) a.y = -a.y;
-            v[q][k] = a;
+            if (HALF_IN && (k < R1 / 4 || k >= 3 * R1 / 4)) continue;        // never read
+            const bool stat = !BOXED || HALF_IN || HALF == 4;                 // box known at compile time
+            const unsigned vo = (stat || (k >= klo && k < khi)) ? l_in : IG_OOB;
+            v[k] = buf_ld<NT_LD>(r_in, vo, (unsigned)(k * R2) * isj * 8u);
+            if (WMODE == 1) wv[k] = buf_ld<false>(r_w, (stat || (k >= klo && k < khi)) ? l_w : IG_OOB, (unsigned)(k * R2) * wsj * 8u);
+        }
+#pragma unroll
+        for (int k = 0; k < R1; ++k) {
+            if (HALF_IN && (k < R1 / 4 || k >= 3 * R1 / 4)) continue;
+            if (WMODE == 1) v[k] = cmul(v[k], wv[k]);
+            if (d.inverse) v[k].y = -v[k].y;
         }
     }
     __syncthreads();            // twiddle table visible (the global loads above are already in flight)
-    static_assert(B1 == 1, "one stage-1 butterfly per thread");
-    RegFFT<R1>::run(v[0]);
+    if (HALF_IN) RegFFTHalfIn<R1>::run(v);
+    else RegFFT<R1>::run(v);
 #pragma unroll
-    for (int k = 1; k < R1; ++k) v[0][k] = cmul(v[0][k], tws[t * k]);
+    for (int k = 1; k < R1; ++k) v[k] = cmul(v[k], tws[t * k]);
 
     // ---- exchange + stage 2 in B2 = R1/16 rounds.  Stage-2 butterfly b2 = t + 16*q needs, from every
     // stage-1 thread b, exactly its output k = b2: round q therefore moves only the outputs
-    // k in [16q, 16q+16) through LDS (row b*16 + k%16), i.e. 16 x 16 x W elements = 32 KB per round
-    // whatever R1 is.  Half the LDS of a one-shot exchange for n = 512 -> twice the workgroups per CU.
-    auto lidx2 = [&](int jr) -> int {           // jr = b*16 + kk, 256 rows
-        if (AXIS0) return w * (16 * T) + ((jr & ~15) | ((jr ^ (jr >> 4)) & 15));
-        return jr * W + w;
-    };
+    // k in [16q, 16q+16) through LDS, i.e. 16 x 16 x W elements = 32 KB per round whatever R1 is.
+    // Exchange element (b, kk) lives at row b, slot kk.  Strided axes: [b][kk][w] (lanes along w).  Axis 0: column
+    // group w owns 16 rows of 17 slots -- the odd row stride makes both the row-wise writes and the column-wise
+    // reads conflict-free, and every address is one per-thread base plus a compile-time offset.
+    float2* __restrict__ lw = AXIS0 ? lds + w * (16 * 17) + t * 17 : lds + (t * 16) * W + w;     // + kk * (AXIS0 ? 1 : W)
+    float2* __restrict__ lr = AXIS0 ? lds + w * (16 * 17) + t      : lds + t * W + w;            // + k2 * (AXIS0 ? 17 : 16 * W)
 #pragma unroll
     for (int q = 0; q < B2; ++q) {
         if (q > 0) __syncthreads();             // the previous round's reads are done
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) lds[lidx2(t * 16 + kk)] = v[0][16 * q + kk];
+        for (int kk = 0; kk < 16; ++kk) lw[kk * (AXIS0 ? 1 : W)] = v[16 * q + kk];
         __syncthreads();
         const int b2 = t + q * T;
         float2 u[R2];
 #pragma unroll
-        for (int k2 = 0; k2 < R2; ++k2) u[k2] = lds[lidx2(k2 * 16 + t)];
+        for (int r = 0; r < R2; ++r) u[r] = lr[r * (AXIS0 ? 17 : 16 * W)];
         RegFFT<R2>::run(u);
-        if (valid) {
-            // kept outputs j = b2 + r*R1  <=>  r in [rlo, rhi)
-            const int rlo = BOXED ? (out_lo - b2 + R1 - 1 >= 0 ? (out_lo - b2 + R1 - 1) / R1 : 0) : 0;
-            const int rhi = BOXED ? (out_hi - b2 + R1 - 1 >= 0 ? (out_hi - b2 + R1 - 1) / R1 : 0) : R2;
+        // kept outputs j = b2 + r*R1  <=>  r in [rlo, rhi)
+        const int rlo = out_lo - b2 + R1 - 1 >= 0 ? (out_lo - b2 + R1 - 1) / R1 : 0;
+        const int rhi = out_hi - b2 + R1 - 1 >= 0 ? (out_hi - b2 + R1 - 1) / R1 : 0;
+        float2 wv[R2];
+        if (WMODE == 2) {
 #pragma unroll
             for (int r = 0; r < R2; ++r) {
-                const int j = b2 + r * R1;
-                if (!BOXED || (r >= rlo && r < rhi)) {
-                    float2 a = u[r];
-                    if (d.inverse) a.y = -a.y;
-                    if (WMODE == 2) a = cmulc(d.w[cb_w + (int64_t)j * wsj], a);
-                    st_stream<NT_ST>(d.out + cb_out + (int64_t)j * osj, a);
-                }
+                if (HALF_OUT && (r < R2 / 4 || r >= 3 * R2 / 4)) continue;
+                const bool stat = !BOXED || HALF_OUT || HALF == 3;
+                wv[r] = buf_ld<false>(r_w, (stat || (r >= rlo && r < rhi)) ? l_w : IG_OOB, (unsigned)(q * T + r * R1) * wsj * 8u);
             }
+        }
+#pragma unroll
+        for (int r = 0; r < R2; ++r) {
+            if (HALF_OUT && (r < R2 / 4 || r >= 3 * R2 / 4)) continue;          // never stored
+            const bool stat = !BOXED || HALF_OUT || HALF == 3;
+            float2 a = u[r];
+            if (d.inverse) a.y = -a.y;
+            if (WMODE == 2) a = cmulc(wv[r], a);
+            buf_st<NT_ST>(r_out, (stat || (r >= rlo && r < rhi)) ? l_out : IG_OOB, (unsigned)(q * T + r * R1) * osj * 8u, a);
         }
     }
 }
@@ -519,30 +580,13 @@ int plan_axis(ig_ctx* ctx, ig_fft* p, int a) {
     Radices rad{};
     int ns = 0;
     const char* e2 = getenv("INDIGO_HIP_FFT_2STAGE");
-    const bool two_stage = !force_generic && !(e2 && e2[0] == '0') && (ax.n == 512 || ax.n == 256);
+    const bool two_stage = !force_generic && !(e2 && e2[0] == '0') && (ax.n == 512 || ax.n == 256) &&
+                           (ax.n + 16) * ax.inner * 8 < 0x7fffffffLL;     // 2 GB descriptor window per tile
     if (two_stage) {
         ax.kind = 3; ax.W = 16; ax.T = 16; ax.nstages = 2;
         ax.rad.r[0] = ax.n == 512 ? 32 : 16; ax.rad.r[1] = 16;
-        ax.lds_bytes = ((size_t)16 * 16 * ax.W + ax.n) * 8;     // one exchange round + the twiddle table
-        const void* fns[16] = {
-            reinterpret_cast<const void*>(&k_fft_2stage<32, 16, 16, 16, true, 0, false>),
-            reinterpret_cast<const void*>(&k_fft_2stage<32, 16, 16, 16, true, 0, true>),
-            reinterpret_cast<const void*>(&k_fft_2stage<32, 16, 16, 16, true, 1, true>),
-            reinterpret_cast<const void*>(&k_fft_2stage<32, 16, 16, 16, true, 2, true>),
-            reinterpret_cast<const void*>(&k_fft_2stage<32, 16, 16, 16, false, 0, false>),
-            reinterpret_cast<const void*>(&k_fft_2stage<32, 16, 16, 16, false, 0, true>),
-            reinterpret_cast<const void*>(&k_fft_2stage<32, 16, 16, 16, false, 1, true>),
-            reinterpret_cast<const void*>(&k_fft_2stage<32, 16, 16, 16, false, 2, true>),
-            reinterpret_cast<const void*>(&k_fft_2stage<16, 16, 16, 16, true, 0, false>),
-            reinterpret_cast<const void*>(&k_fft_2stage<16, 16, 16, 16, true, 0, true>),
-            reinterpret_cast<const void*>(&k_fft_2stage<16, 16, 16, 16, true, 1, true>),
-            reinterpret_cast<const void*>(&k_fft_2stage<16, 16, 16, 16, true, 2, true>),
-            reinterpret_cast<const void*>(&k_fft_2stage<16, 16, 16, 16, false, 0, false>),
-            reinterpret_cast<const void*>(&k_fft_2stage<16, 16, 16, 16, false, 0, true>),
-            reinterpret_cast<const void*>(&k_fft_2stage<16, 16, 16, 16, false, 1, true>),
-            reinterpret_cast<const void*>(&k_fft_2stage<16, 16, 16, 16, false, 2, true>)};
-        for (const void* f : fns)
-            IG_HIP(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BUDGET));
+        ax.lds_bytes = ((size_t)16 * 17 * ax.W + ax.n) * 8;     // one exchange round (padded rows, x passes) + the twiddle table
+        // 36 KB of dynamic LDS: below the 64 KB every kernel may use without an attribute
     }
     bool lds_ok = !two_stage && !force_generic && ax.n <= LDS_NMAX && factor_lds(ax.n, rad, ns);
     if (lds_ok) {
@@ -589,21 +633,47 @@ int plan_axis(ig_ctx* ctx, ig_fft* p, int a) {
 }
 
 // launch one 2-stage axis pass (n in {256, 512}); axis0 selects the lane mapping for contiguous columns
-int launch_2stage(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d, bool axis0, int wmode) {
-    const int64_t blocks = (d.ncols + ax.W - 1) / ax.W;
-    if (blocks == 0) return IG_OK;
-    IG_REQUIRE(ctx, blocks <= 0x7fffffffLL, "ig_fft: too many tiles");
+int launch_2stage(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d_in, bool axis0, int wmode) {
+    PassDesc d = d_in;
+    if (d.ncols == 0) return IG_OK;
+    const int64_t tpr = (d.ext0 + ax.W - 1) / ax.W;
+    const int64_t blocks = tpr * (d.ncols / d.ext0);           // ncols = ext0 * ext1 * ext2
+    IG_REQUIRE(ctx, blocks <= 0x7fffffffLL && d.ext1 <= 0x7fffffffLL, "ig_fft: too many tiles");
+    d.tpr = (unsigned)tpr;
+    {   // every in-tile byte offset must stay inside the 2 GB descriptor window
+        const int64_t lim = 0x7fffffffLL / 8;
+        const int64_t span_in = (ax.n + 15) * d.in_sj + 15 * d.in_s[0], span_out = (ax.n + 15) * d.out_sj + 15 * d.out_s[0];
+        const int64_t span_w = wmode ? (ax.n + 15) * d.w_sj + 15 * d.w_s[0] : 0;
+        IG_REQUIRE(ctx, d.in_sj >= 0 && d.out_sj >= 0 && d.in_s[0] >= 0 && d.out_s[0] >= 0 && span_in < lim && span_out < lim && span_w < lim,
+                   "ig_fft: axis stride too large for the two-stage kernel");
+    }
     const dim3 grid((unsigned)blocks), block((unsigned)(ax.W * ax.T));
-#define IG_2S(R1_, AX0_, WM_, BX_)                                                                  \
-    hipLaunchKernelGGL((k_fft_2stage<R1_, 16, 16, 16, AX0_, WM_, BX_>), grid, block, ax.lds_bytes, ctx->stream, d, ax.d_tw)
+#define IG_2S(R1_, AX0_, WM_, BX_, HF_)                                                             \
+    hipLaunchKernelGGL((k_fft_2stage<R1_, 16, 16, 16, AX0_, WM_, BX_, HF_>), grid, block, ax.lds_bytes, ctx->stream, d, ax.d_tw)
 #define IG_2S_W(R1_, AX0_)                                                                           \
     do {                                                                                             \
-        if (!boxed && wmode == 0) IG_2S(R1_, AX0_, 0, false);                                        \
-        else if (wmode == 0) IG_2S(R1_, AX0_, 0, true);                                              \
-        else if (wmode == 1) IG_2S(R1_, AX0_, 1, true);                                              \
-        else IG_2S(R1_, AX0_, 2, true);                                                              \
+        if (!boxed && wmode == 0) IG_2S(R1_, AX0_, 0, false, 0);                                     \
+        else if (wmode == 0) {                                                                       \
+            if (half == 1) IG_2S(R1_, AX0_, 0, true, 1); else if (half == 2) IG_2S(R1_, AX0_, 0, true, 2);   \
+            else if (half == 3) IG_2S(R1_, AX0_, 0, true, 3); else if (half == 4) IG_2S(R1_, AX0_, 0, true, 4); \
+            else IG_2S(R1_, AX0_, 0, true, 0); }                                                     \
+        else if (wmode == 1) { if (half == 3) IG_2S(R1_, AX0_, 1, true, 3); else IG_2S(R1_, AX0_, 1, true, 0); } \
+        else { if (half == 4) IG_2S(R1_, AX0_, 2, true, 4); else IG_2S(R1_, AX0_, 2, true, 0); }      \
     } while (0)
     const bool boxed = d.tile_range || !(d.in_lo <= 0 && d.in_hi >= (int)ax.n && d.out_lo <= 0 && d.out_hi >= (int)ax.n);
+    // the image box of a 2x-oversampled grid sits at [n/4, 3n/4): compile-time-pruned variants
+    static const int use_half = getenv("INDIGO_HIP_FFT_HALF") ? atoi(getenv("INDIGO_HIP_FFT_HALF")) : 1;
+    const int qn = (int)ax.n / 4;
+    int half = 0;
+    if (use_half && boxed) {
+        const bool in_full = d.in_lo <= 0 && d.in_hi >= (int)ax.n, out_full = d.out_lo <= 0 && d.out_hi >= (int)ax.n;
+        if (d.in_lo == qn && d.in_hi == 3 * qn && !(d.tile_range && d.tile_range_mode == 2))
+            half = (out_full && !d.tile_range) ? 3 : 1;
+        else if (d.out_lo == qn && d.out_hi == 3 * qn && !(d.tile_range && d.tile_range_mode == 1))
+            half = (in_full && !d.tile_range) ? 4 : 2;
+        if (wmode == 1 && half != 3) half = 0;      // weighted variants exist for the fully static boxes only
+        if (wmode == 2 && half != 4) half = 0;
+    }
     if (ax.n == 512) { if (axis0) IG_2S_W(32, true); else IG_2S_W(32, false); }
     else             { if (axis0) IG_2S_W(16, true); else IG_2S_W(16, false); }
 #undef IG_2S_W
@@ -688,8 +758,13 @@ int ig_fft_exec(ig_fft* p, const void* xv, void* yv, int direction, void* worksp
             PassDesc d{};
             d.in = cur; d.out = y; d.w = nullptr;
             d.in_sj = d.out_sj = ax.inner; d.w_sj = 0;
-            d.ext0 = ax.inner; d.ext1 = ax.outer; d.ncols = ax.inner * ax.outer;
-            d.in_s[0] = d.out_s[0] = 1; d.in_s[1] = d.out_s[1] = ax.inner * ax.n; d.in_s[2] = d.out_s[2] = 0;
+            d.ncols = ax.inner * ax.outer;
+            if (ax.inner == 1) {            // contiguous lines: the lines themselves are the tile's W columns
+                d.ext0 = ax.outer; d.ext1 = 1; d.in_s[0] = d.out_s[0] = ax.n; d.in_s[1] = d.out_s[1] = 0;
+            } else {
+                d.ext0 = ax.inner; d.ext1 = ax.outer; d.in_s[0] = d.out_s[0] = 1; d.in_s[1] = d.out_s[1] = ax.inner * ax.n;
+            }
+            d.in_s[2] = d.out_s[2] = 0;
             d.in_lo = d.out_lo = 0; d.in_hi = d.out_hi = (int)ax.n; d.inverse = inverse;
             if (int rc = launch_2stage(ctx, ax, d, ax.inner == 1, 0)) return rc;
             cur = y;
