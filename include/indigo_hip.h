@@ -150,10 +150,11 @@ int  ig_ccsrmm_t(ig_ctx* ctx,
                  float beta_re, float beta_im,
                  void* Y, int64_t ldy);
 
-/* ig_ccsrmm_t restricted to a support region of a 3-D grid of output rows: row = kx + n0*(km + nm*ks);
- * rows with km outside support[2*(ks*(n0/16) + kx/16) + {0,1}] = [lo, hi) are neither computed nor
- * written (they hold no nonzero by construction of the table; support may be NULL = all rows).
- * Same table as ig_fft_exec_cropped.                                                               */
+/* ig_ccsrmm_t restricted to the support of a 3-D grid of output rows, row = kx + n0*(km + nm*ks), nm a
+ * multiple of 16 and <= 512: only the 16-row segments (16 consecutive kx) flagged in the THIRD part of
+ * the support table are computed and written; all other rows are left untouched (they hold no nonzero by
+ * construction of the table; support may be NULL = all rows).  Same table as ig_fft_exec_cropped, which
+ * reads exactly the flagged segments and nothing else.                                            */
 int  ig_ccsrmm_t_grid(ig_ctx* ctx,
                       int64_t M, int64_t K, int64_t N, int64_t nnz,
                       float alpha_re, float alpha_im,
@@ -222,12 +223,16 @@ int  ig_fft_describe(ig_fft* plan, char* buf, size_t len);   /* kernel / radix s
 int  ig_fft_plan_padded(ig_ctx* ctx, const int64_t* dims, const int64_t* box_lo, const int64_t* box_dims,
                         int64_t batch, int grid_layout, ig_fft** plan, size_t* workspace_bytes);
 /* support (optional, grid_layout 1 only; may be NULL): the k-space support of the gridding matrix that
- * consumes / produced Y, as int16 pairs support[2*(ky*(n0/16) + kx/16) + {0,1}] = [z_lo, z_hi): the
- * padded transform then only guarantees kz inside the range (the rest of Y is undefined and must not
- * be read), the cropped transform reads only kz inside it (the rest counts as zero and may hold
- * anything).  The table has a second part behind the n1*(n0/16) z-ranges: n0/16 pairs [y_lo, y_hi),
- * the ky range of each kx tile outside which every z-range is empty (used by the y pass).
- * A radial trajectory covers a ball, 52 % of the grid cube.                                    */
+ * consumes / produced Y, one contiguous int16 buffer in three parts (nt = n0/16 kx tiles):
+ *   1. n1*nt pairs  [z_lo, z_hi)  at 2*(ky*nt + kx/16): the kz hull of the tile's column (empty: skip it);
+ *   2. nt pairs     [y_lo, y_hi)  per kx tile: the ky range outside which every z hull is empty (y pass);
+ *   3. n1*nt*16 uint32 words (4-byte aligned, every pair before it being 4 bytes):
+ *      bit m of word 16*(ky*nt + kx/16) + t is set iff the 16-row segment (kx tile, ky, kz = t + 16*m)
+ *      holds a nonzero of the gridding matrix.
+ * The padded transform only guarantees the flagged segments of Y (the rest is undefined and must not be
+ * read); the cropped transform reads only flagged segments (everything else counts as zero and may hold
+ * anything).  A radial trajectory covers a ball (52 % of the cube) with gaps between its outer spokes:
+ * 30 % of the segments of the 512^3 grid of the 256^3 SENSE problem are flagged.                  */
 int  ig_fft_exec_padded(ig_fft* plan, const void* x, int64_t x_bstride, const void* w, void* y, void* workspace,
                         const int16_t* support);
 int  ig_fft_exec_cropped(ig_fft* plan, const void* y, const void* w, void* x, int64_t x_bstride, void* workspace,

@@ -278,6 +278,9 @@ struct PassDesc {
     const short2* tile_range;
     int tile_range_mode;
     int64_t tile_range_k1;      // table row stride per k1 (tiles per row), or 0 if the ranges do not depend on k1
+    // optional refinement of tile_range (same mode, same indexing, 16 words per tile): bit m of word t is set iff
+    // element j = t + 16*m of the tile's columns is needed (mode 1) / was ever written (mode 2)
+    const uint32_t* tile_bits;
 };
 
 // Two-stage kernel for n = R1*R2 (256 = 16x16, 512 = 32x16): the whole column lives in registers
@@ -294,7 +297,7 @@ struct PassDesc {
 //   2: output half, input box at run time      4: output half, input full
 // Half inputs prune the first butterfly layer; compile-time boxes need no predicates or bounds registers.
 template <int R1, int R2, int T, int W, bool AXIS0, int WMODE, bool BOXED, int HALF>
-__global__ void __launch_bounds__(W * T, IG_FFT_MINWAVES)
+__global__ void __launch_bounds__(W * T, (!AXIS0 && R1 == 32 && (HALF == 1 || HALF == 3)) ? 4 : IG_FFT_MINWAVES)
 k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
     constexpr int n = R1 * R2, B1 = R2 / T, B2 = R1 / T, NT = W * T;
     constexpr bool NT_LD = IG_FFT_NT_LOAD, NT_ST = IG_FFT_NT_STORE;
@@ -338,20 +341,32 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
     const unsigned l_out = valid ? ((unsigned)w * (unsigned)d.out_s[0] + (unsigned)t * osj) * 8u : IG_OOB;
     const unsigned l_w = (WMODE && valid) ? ((unsigned)w * (unsigned)d.w_s[0] + (unsigned)t * wsj) * 8u : IG_OOB;
 
+    // Element j = t + 16*m of this thread's column <-> bit m of a 32-bit word: ibits flags the inputs to read
+    // (stage 1 loads m = k), obits the outputs to keep (stage 2 stores m = q + r*R1/16).  Boxes [lo, hi) become
+    // bit ranges; a per-tile bitmap (k-space support at 16-row granularity) is and-ed in.
+    uint32_t ibits = 0xffffffffu, obits = 0xffffffffu;
+    if (BOXED) {
+        auto ceil16 = [](int a) -> int { a += 15; return a <= 0 ? 0 : (a >= 512 ? 32 : a >> 4); };
+        auto below = [](int h) -> uint32_t { return h >= 32 ? 0xffffffffu : ((1u << h) - 1u); };
+        ibits = below(ceil16(in_hi - t)) & ~below(ceil16(in_lo - t));
+        obits = below(ceil16(out_hi - t)) & ~below(ceil16(out_lo - t));
+        if (!AXIS0 && d.tile_bits) {
+            const uint32_t zb = d.tile_bits[((int64_t)k1 * d.tile_range_k1 + tr) * 16 + t];
+            if (d.tile_range_mode == 1) obits &= zb; else ibits &= zb;
+        }
+    }
+
     // ---- stage 1: radix R1 on inputs j = t + k*R2, results (times w_n^{t k}) to the exchange
     float2 v[R1];
     {
-        // in-box inputs  <=>  k in [klo, khi): two per-thread bounds instead of two compares per element
-        const int klo = in_lo - t + R2 - 1 >= 0 ? (in_lo - t + R2 - 1) / R2 : 0;
-        const int khi = in_hi - t + R2 - 1 >= 0 ? (in_hi - t + R2 - 1) / R2 : 0;
         float2 wv[R1];
 #pragma unroll
         for (int k = 0; k < R1; ++k) {
             if (HALF_IN && (k < R1 / 4 || k >= 3 * R1 / 4)) continue;        // never read
             const bool stat = !BOXED || HALF_IN || HALF == 4;                 // box known at compile time
-            const unsigned vo = (stat || (k >= klo && k < khi)) ? l_in : IG_OOB;
-            v[k] = buf_ld<NT_LD>(r_in, vo, (unsigned)(k * R2) * isj * 8u);
-            if (WMODE == 1) wv[k] = buf_ld<false>(r_w, (stat || (k >= klo && k < khi)) ? l_w : IG_OOB, (unsigned)(k * R2) * wsj * 8u);
+            const bool on = stat || ((ibits >> k) & 1u);
+            v[k] = buf_ld<NT_LD>(r_in, on ? l_in : IG_OOB, (unsigned)(k * R2) * isj * 8u);
+            if (WMODE == 1) wv[k] = buf_ld<false>(r_w, on ? l_w : IG_OOB, (unsigned)(k * R2) * wsj * 8u);
         }
 #pragma unroll
         for (int k = 0; k < R1; ++k) {
@@ -380,21 +395,17 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) lw[kk * (AXIS0 ? 1 : W)] = v[16 * q + kk];
         __syncthreads();
-        const int b2 = t + q * T;
         float2 u[R2];
 #pragma unroll
         for (int r = 0; r < R2; ++r) u[r] = lr[r * (AXIS0 ? 17 : 16 * W)];
         RegFFT<R2>::run(u);
-        // kept outputs j = b2 + r*R1  <=>  r in [rlo, rhi)
-        const int rlo = out_lo - b2 + R1 - 1 >= 0 ? (out_lo - b2 + R1 - 1) / R1 : 0;
-        const int rhi = out_hi - b2 + R1 - 1 >= 0 ? (out_hi - b2 + R1 - 1) / R1 : 0;
-        float2 wv[R2];
+        float2 wv[R2];          // kept outputs j = t + 16*(q + r*B2): bit q + r*B2 of obits
         if (WMODE == 2) {
 #pragma unroll
             for (int r = 0; r < R2; ++r) {
                 if (HALF_OUT && (r < R2 / 4 || r >= 3 * R2 / 4)) continue;
                 const bool stat = !BOXED || HALF_OUT || HALF == 3;
-                wv[r] = buf_ld<false>(r_w, (stat || (r >= rlo && r < rhi)) ? l_w : IG_OOB, (unsigned)(q * T + r * R1) * wsj * 8u);
+                wv[r] = buf_ld<false>(r_w, (stat || ((obits >> (q + r * B2)) & 1u)) ? l_w : IG_OOB, (unsigned)(q * T + r * R1) * wsj * 8u);
             }
         }
 #pragma unroll
@@ -404,7 +415,7 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
             float2 a = u[r];
             if (d.inverse) a.y = -a.y;
             if (WMODE == 2) a = cmulc(wv[r], a);
-            buf_st<NT_ST>(r_out, (stat || (r >= rlo && r < rhi)) ? l_out : IG_OOB, (unsigned)(q * T + r * R1) * osj * 8u, a);
+            buf_st<NT_ST>(r_out, (stat || ((obits >> (q + r * B2)) & 1u)) ? l_out : IG_OOB, (unsigned)(q * T + r * R1) * osj * 8u, a);
         }
     }
 }
@@ -895,6 +906,7 @@ static int exec_padded_layout1(ig_fft* p, const float2* x, int64_t x_bstride, co
         d.ext0 = n0; d.ext1 = n1; d.ncols = n0 * n1 * C;
         d.in_lo = (int)l2; d.in_hi = (int)(l2 + b2); d.out_lo = 0; d.out_hi = (int)n2; d.inverse = 0;
         d.tile_range = support; d.tile_range_mode = 1; d.tile_range_k1 = n0 / 16;   // only the support is ever gridded from
+        if (support) d.tile_bits = reinterpret_cast<const uint32_t*>(support + n1 * (n0 / 16) + n0 / 16);
         if (int rc = launch_2stage(ctx, p->axis[2], d, false, 0)) return rc;
     }
     return IG_OK;
@@ -917,6 +929,7 @@ static int exec_cropped_layout1(ig_fft* p, const float2* y, const float2* w, flo
         d.ext0 = n0; d.ext1 = n1; d.ncols = n0 * n1 * C;
         d.in_lo = 0; d.in_hi = (int)n2; d.out_lo = (int)l2; d.out_hi = (int)(l2 + b2); d.inverse = 1;
         d.tile_range = support; d.tile_range_mode = 2; d.tile_range_k1 = n0 / 16;   // the adjoint gridding only wrote the support
+        if (support) d.tile_bits = reinterpret_cast<const uint32_t*>(support + n1 * (n0 / 16) + n0 / 16);
         if (int rc = launch_2stage(ctx, p->axis[2], d, false, 0)) return rc;
     }
     {   // pass y: columns (kx, z'), grid in (stride n0*n2), compact out, keep y in box

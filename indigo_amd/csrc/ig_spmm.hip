@@ -51,19 +51,41 @@ __device__ __forceinline__ int64_t xcd_block(int64_t b, int64_t nb) {
 //   k_csrmm_rows_block  one 1024-thread workgroup per listed row (nnz > thr_long)
 // both of which read the list length from device memory, so the host never syncs.
 // If a list is full the row is simply computed inline (slow, still correct).
-// Optional support region of a 3-D grid of output rows, row = kx + n0*(km + nm*ks): a row is only computed
-// and written if km lies in tab[ks*(n0/16) + kx/16] = [lo, hi).  tab == nullptr: every row.
+// Optional support of a 3-D grid of output rows, row = kx + n0*(km + nm*ks): a row is only computed and written
+// if its 16-row segment is flagged: bit (km >> 4) of bits[(ks*(n0/16) + kx/16)*16 + (km & 15)] (the third part of
+// the support table of ig_fft_exec_padded).  bits == nullptr: every row.
 struct GridMask {
-    const short2* tab;
+    const uint32_t* bits;
     int64_t n0, nm;
 };
 
+// Deferred-row lists are split into WL_SUB sub-lists with their own counters: a wave appends all its long rows
+// with ONE atomic on the counter its id hashes to.  (One atomic per row on a single counter serialised in L2:
+// 150k long rows of the 134M-row transposed gridding matrix cost 0.9 ms of a 3.6 ms launch.)
+constexpr int WL_SUB = 32;
 struct WorkLists {
-    int32_t*  rows[2];     // [0] wave-per-row list, [1] workgroup-per-row list
-    uint32_t* count;       // count[0], count[1]
-    uint32_t  cap;
+    int32_t*  rows[2];     // [0] wave-per-row lists, [1] workgroup-per-row lists; sub-list s starts at s*cap
+    uint32_t* count;       // count[which*WL_SUB + s]
+    uint32_t  cap;         // per sub-list
     const int32_t* yperm;  // optional: result row r is stored at Y[yperm[r]] (rows of A were reordered for locality)
 };
+
+// All lanes of the wave call this; lanes with `want` get a slot in sub-list (which, sub).  Returns true if the
+// lane's row was appended (false: list full, compute inline).
+__device__ __forceinline__ bool wl_append(const WorkLists& wl, int which, int sub, bool want, int32_t row) {
+    const uint64_t bal = __ballot(want);
+    if (!bal) return false;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)bal) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(&wl.count[which * WL_SUB + sub], (uint32_t)__popcll(bal));
+    base = __shfl(base, leader, 64);
+    if (!want) return false;
+    const uint32_t idx = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+    if (idx >= wl.cap) return false;
+    wl.rows[which][(size_t)sub * wl.cap + idx] = row;
+    return true;
+}
 
 __device__ __forceinline__ int64_t out_row(const int32_t* __restrict__ perm, int64_t row) {
     return perm ? (int64_t)perm[row] : row;
@@ -101,12 +123,11 @@ k_csrmm_gather(int64_t M, int64_t N,
     // defer long rows: the slot's first lane claims a list entry, the slot learns the outcome by shuffle
     int deferred = 0;
     const int32_t len = p1 - p0;
-    if (len > thr_mid) {
-        if (c == 0 && i == 0) {
-            const int which = len > thr_long ? 1 : 0;
-            const uint32_t idx = atomicAdd(&wl.count[which], 1u);
-            if (idx < wl.cap) { wl.rows[which][idx] = (int32_t)row; deferred = 1; }
-        }
+    {
+        const int sub = (int)(wave & (WL_SUB - 1));
+        const bool head = c == 0 && i == 0;
+        if (wl_append(wl, 0, sub, head && len > thr_mid && len <= thr_long, (int32_t)row)) deferred = 1;
+        if (wl_append(wl, 1, sub, head && len > thr_long, (int32_t)row)) deferred = 1;
     }
     deferred = __shfl(deferred, r * CL * NL, 64);
     if (deferred) p1 = p0;          // nothing to do here, and no store below
@@ -166,22 +187,26 @@ k_csrmm_rowlane(int64_t M, int64_t N,
                 WorkLists wl, int32_t thr_mid, int32_t thr_long, GridMask mask) {
     const int64_t blk = xcd_remap ? xcd_block(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
     const int64_t row = blk * BLK + threadIdx.x;
-    if (row >= M) return;
-    if (mask.tab) {
-        // rows outside the gridding support hold no nonzero and nobody reads them: no load, no store
-        const int64_t kx = row % mask.n0, rest = row / mask.n0;
-        const int64_t km = rest % mask.nm, ks = rest / mask.nm;
-        const short2 r = mask.tab[ks * (mask.n0 >> 4) + (kx >> 4)];
-        if (km < r.x || km >= r.y) return;
+    bool live = row < M;
+    if (live && mask.bits) {
+        // segments (16 rows) outside the gridding support hold no nonzero and nobody reads them: no load, no store.
+        // 32-bit index arithmetic: a grid has < 2^31 rows.
+        const uint32_t r32 = (uint32_t)row, n0 = (uint32_t)mask.n0, nm = (uint32_t)mask.nm;
+        const uint32_t rest = r32 / n0, kx = r32 - rest * n0;
+        const uint32_t ks = rest / nm, km = rest - ks * nm;
+        const uint32_t wbits = mask.bits[((size_t)ks * (n0 >> 4) + (kx >> 4)) * 16 + (km & 15)];
+        live = (wbits >> (km >> 4)) & 1u;
     }
-    const int32_t p0 = rowptr[row];
-    int32_t p1 = rowptr[row + 1];
+    if (!__ballot(live)) return;
+    int32_t p0 = 0, p1 = 0;
+    if (live) { p0 = rowptr[row]; p1 = rowptr[row + 1]; }
     const int32_t len = p1 - p0;
-    if (len > thr_mid) {
-        const int which = len > thr_long ? 1 : 0;
-        const uint32_t idx = atomicAdd(&wl.count[which], 1u);
-        if (idx < wl.cap) { wl.rows[which][idx] = (int32_t)row; return; }
+    {
+        const int sub = (int)((blk * WAVES_PER_BLOCK + (threadIdx.x >> 6)) & (WL_SUB - 1));
+        if (wl_append(wl, 0, sub, len > thr_mid && len <= thr_long, (int32_t)row)) live = false;
+        if (wl_append(wl, 1, sub, len > thr_long, (int32_t)row)) live = false;
     }
+    if (!live) return;
     for (int64_t jb = 0; jb < N; jb += NC) {
         float2 acc[NC];
 #pragma unroll
@@ -240,10 +265,13 @@ k_csrmm_rows_wave(int64_t N, const int32_t* __restrict__ rowptr, const int32_t* 
     constexpr int NLW = 64 / CL;
     const int lane = threadIdx.x & 63;
     const int c = lane % CL, i = lane / CL;
-    uint32_t n = *count;
+    // wave g serves sub-list g % WL_SUB (the grid has a multiple of WL_SUB waves)
+    const uint32_t gw = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const uint32_t sub = gw % WL_SUB, nwaves = gridDim.x * WAVES_PER_BLOCK / WL_SUB;
+    uint32_t n = count[sub];
     if (n > cap) n = cap;
-    const uint32_t nwaves = gridDim.x * WAVES_PER_BLOCK;
-    for (uint32_t e = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6); e < n; e += nwaves) {
+    list += (size_t)sub * cap;
+    for (uint32_t e = gw / WL_SUB; e < n; e += nwaves) {
         const int64_t row = list[e];
         const int32_t p0 = rowptr[row], p1 = rowptr[row + 1];
         for (int64_t jb = 0; jb < N; jb += CL) {
@@ -288,9 +316,11 @@ k_csrmm_rows_block(int64_t N, const int32_t* __restrict__ rowptr, const int32_t*
     __shared__ float2 part[16][64];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int c = tid % CL, i = tid / CL;
-    uint32_t n = *count;
+    const uint32_t sub = blockIdx.x % WL_SUB, nblk = gridDim.x / WL_SUB;     // grid is a multiple of WL_SUB blocks
+    uint32_t n = count[sub];
     if (n > cap) n = cap;
-    for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
+    list += (size_t)sub * cap;
+    for (uint32_t e = blockIdx.x / WL_SUB; e < n; e += nblk) {
         const int64_t row = list[e];
         const int32_t p0 = rowptr[row], p1 = rowptr[row + 1];
         for (int64_t jb = 0; jb < N; jb += CL) {
@@ -451,7 +481,7 @@ constexpr uint32_t WL_CAP = 1u << 20;
 
 int ensure_worklists(ig_ctx* ctx) {
     if (ctx->d_worklist) return IG_OK;
-    IG_HIP(ctx, hipMalloc((void**)&ctx->d_worklist, sizeof(int32_t) * 2 * WL_CAP + 64));
+    IG_HIP(ctx, hipMalloc((void**)&ctx->d_worklist, sizeof(int32_t) * 2 * WL_CAP + 2 * WL_SUB * sizeof(uint32_t)));
     return IG_OK;
 }
 
@@ -518,8 +548,8 @@ int launch_gather(ig_ctx* ctx, int64_t rows, int64_t xrows, int64_t N, int64_t n
         wl.rows[0] = ctx->d_worklist;
         wl.rows[1] = ctx->d_worklist + WL_CAP;
         wl.count = reinterpret_cast<uint32_t*>(ctx->d_worklist + 2 * WL_CAP);
-        wl.cap = WL_CAP;
-        IG_HIP(ctx, hipMemsetAsync(wl.count, 0, 2 * sizeof(uint32_t), ctx->stream));
+        wl.cap = WL_CAP / WL_SUB;
+        IG_HIP(ctx, hipMemsetAsync(wl.count, 0, 2 * WL_SUB * sizeof(uint32_t), ctx->stream));
     }
     // row-per-lane only pays for (mostly) empty / very short rows; NL == 1 alone also happens for wide panels
     // ... and for wide packed panels with short rows, where a row-slot's 8-byte stores would each hit a different
@@ -592,7 +622,7 @@ int launch_gather(ig_ctx* ctx, int64_t rows, int64_t xrows, int64_t N, int64_t n
         IG_LAUNCH_CHECK(ctx, "k_csrmm_gather");
     }
     if (defer) {
-        const unsigned gw = (unsigned)ctx->num_cu * 8, gb = (unsigned)ctx->num_cu * 2;
+        const unsigned gw = ((unsigned)ctx->num_cu * 8 + WL_SUB - 1) / WL_SUB * WL_SUB, gb = ((unsigned)ctx->num_cu * 2 + WL_SUB - 1) / WL_SUB * WL_SUB;
 #define IG_ROWS(CL_)                                                                               \
     do {                                                                                           \
         if (thr_mid < thr_long || rowlane) {                                                       \
@@ -605,9 +635,9 @@ int launch_gather(ig_ctx* ctx, int64_t rows, int64_t xrows, int64_t N, int64_t n
         {                                                                                          \
             ig_prof_scope prof(ctx, "csrmm_rows_block");                                           \
             if (b0) hipLaunchKernelGGL((k_csrmm_rows_block<CL_, CONJ, 0>), dim3(gb), dim3(1024), 0, ctx->stream, \
-                        N, rowptr, colind, vals, X, sxc, sxr, Y, ldy, alpha, beta, wl.rows[1], wl.count + 1, wl.cap, wl.yperm); \
+                        N, rowptr, colind, vals, X, sxc, sxr, Y, ldy, alpha, beta, wl.rows[1], wl.count + WL_SUB, wl.cap, wl.yperm); \
             else    hipLaunchKernelGGL((k_csrmm_rows_block<CL_, CONJ, 1>), dim3(gb), dim3(1024), 0, ctx->stream, \
-                        N, rowptr, colind, vals, X, sxc, sxr, Y, ldy, alpha, beta, wl.rows[1], wl.count + 1, wl.cap, wl.yperm); \
+                        N, rowptr, colind, vals, X, sxc, sxr, Y, ldy, alpha, beta, wl.rows[1], wl.count + WL_SUB, wl.cap, wl.yperm); \
         }                                                                                          \
     } while (0)
         switch (s.CL) {
@@ -733,12 +763,14 @@ int ig_ccsrmm_t_grid(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, int64_t nnz,
                      const int16_t* support, int64_t n0, int64_t nm, const int32_t* xrow_perm) {
     IG_REQUIRE(ctx, ctx != nullptr, "ig_ccsrmm_t_grid: ctx is NULL");
     if (int rc = check_panel_args(ctx, "ig_ccsrmm_t_grid", M, K, N, nnz, vals_t, colind_t, rowptr_t, X, ldx, Y, ldy)) return rc;
-    IG_REQUIRE(ctx, !support || (n0 > 0 && nm > 0 && n0 % 16 == 0 && K % (n0 * nm) == 0),
-               "ig_ccsrmm_t_grid: rows (%lld) are not a grid of n0=%lld (multiple of 16) x nm=%lld x ...",
+    IG_REQUIRE(ctx, !support || (n0 > 0 && nm > 0 && n0 % 16 == 0 && nm % 16 == 0 && nm <= 512 && K % (n0 * nm) == 0 && K < 0x7fffffffLL),
+               "ig_ccsrmm_t_grid: rows (%lld) are not a grid of n0=%lld (multiple of 16) x nm=%lld (multiple of 16, <= 512) x ...",
                (long long)K, (long long)n0, (long long)nm);
     if (N == 0 || K == 0) return IG_OK;
     if (int rc = ig_set_device(ctx)) return rc;
-    GridMask mask{reinterpret_cast<const short2*>(support), n0, nm};
+    // third part of the support table: one bit per 16-row segment (after the z ranges and the y ranges)
+    const int64_t ns = support ? K / (n0 * nm) : 0, nt = n0 / 16;
+    GridMask mask{support ? reinterpret_cast<const uint32_t*>(support + 2 * (ns * nt + nt)) : nullptr, n0, nm};
     return launch_gather<true>(ctx, K, M, N, nnz, rowptr_t, colind_t, (const float2*)vals_t,
                                (const float2*)X, ldx, (float2*)Y, ldy,
                                make_float2(ar, ai), make_float2(br, bi), mask, nullptr, xrow_perm);

@@ -135,32 +135,46 @@ class SenseProblem(object):
         return w
 
     def grid_support(self, G):
-        """k-space support of a layout-1 gridding matrix G (T x P): int16 table with [z_lo, z_hi) per (16-wide
-        kx tile, ky) -- the kz range outside which no sample touches the grid -- followed by [y_lo, y_hi) per
-        kx tile (see ig_fft_exec_padded).
-        A radial trajectory fills a ball: about half of the grid cube lies outside and is never needed."""
+        """k-space support of a layout-1 gridding matrix G (T x P) as the flat int16 table ig_fft_exec_padded,
+        ig_fft_exec_cropped and ig_ccsrmm_t_grid take.  Three parts:
+          1. [z_lo, z_hi) per (ky, 16-wide kx tile): the kz range outside which no sample touches the grid;
+          2. [y_lo, y_hi) per kx tile: the ky range with a non-empty z range (the transform's y pass);
+          3. 16 uint32 words per (ky, kx tile): bit m of word t is set iff the 16-row segment (kx tile, ky,
+             kz = t + 16*m) holds a nonzero of G.  Segments without a nonzero are never gridded from, never
+             written by the adjoint gridding and read as zero by the cropped transform.
+        A radial trajectory fills a ball (half of the grid cube lies outside) and, away from the centre, leaves
+        gaps between spokes: 30 % of the 16-row segments of the 512^3 grid of the headline problem are flagged."""
         n0, n1, n2 = self.oN
-        assert n0 % 16 == 0
+        assert n0 % 16 == 0 and n2 % 16 == 0 and n2 <= 512
+        nt = n0 // 16
         cols = np.unique(G.indices)
         kx = cols % n0
         kz = (cols // n0) % n2
         ky = cols // (n0 * n2)
-        key = ky * (n0 // 16) + kx // 16
+        key = ky * nt + kx // 16
+        bits = np.zeros((n1 * nt, 16), dtype=np.uint32)
+        np.bitwise_or.at(bits, (key, kz % 16), np.uint32(1) << (kz // 16).astype(np.uint32))
         order = np.argsort(key, kind='stable')
         key, kz = key[order], kz[order]
-        nt = n0 // 16
-        table = np.zeros((n1 * nt + nt, 2), dtype=np.int16)
+        ranges = np.zeros((n1 * nt + nt, 2), dtype=np.int16)
         if key.size:
             starts = np.flatnonzero(np.r_[True, key[1:] != key[:-1]])
-            table[key[starts], 0] = np.minimum.reduceat(kz, starts)
-            table[key[starts], 1] = np.maximum.reduceat(kz, starts) + 1
-        # second part: per kx tile the ky range with a non-empty z range (used by the transform's y pass)
-        nonempty = (table[:n1 * nt, 1] > table[:n1 * nt, 0]).reshape(n1, nt)
+            ranges[key[starts], 0] = np.minimum.reduceat(kz, starts)
+            ranges[key[starts], 1] = np.maximum.reduceat(kz, starts) + 1
+        nonempty = (ranges[:n1 * nt, 1] > ranges[:n1 * nt, 0]).reshape(n1, nt)
         for t in range(nt):
             ys = np.flatnonzero(nonempty[:, t])
             if ys.size:
-                table[n1 * nt + t] = (ys[0], ys[-1] + 1)
-        return table
+                ranges[n1 * nt + t] = (ys[0], ys[-1] + 1)
+        return np.concatenate([ranges.reshape(-1), bits.reshape(-1).view(np.int16)])
+
+    def split_support(self, table):
+        """(z ranges (n1*nt, 2), y ranges (nt, 2), segment bits (n1*nt, 16) uint32) views of a support table"""
+        n0, n1, n2 = self.oN
+        nt = n0 // 16
+        table = np.ascontiguousarray(table, dtype=np.int16).reshape(-1)
+        a, b = 2 * n1 * nt, 2 * (n1 * nt + nt)
+        return table[:a].reshape(-1, 2), table[a:b].reshape(-1, 2), table[b:].view(np.uint32).reshape(n1 * nt, 16)
 
     def zpadfft_pass_bytes(self, ncoils, table=None):
         """Compulsory HBM bytes of each axis pass of the fused transform (layout 1): what the pass must read
@@ -172,20 +186,20 @@ class SenseProblem(object):
         C, nt = ncoils, n0 // 16
         bvol, cvol, vol = b0 * b1 * b2, n0 * b1 * b2, n0 * n1 * n2
         if table is None:
-            zlen = np.full(n1 * nt, n2, dtype=np.int64)
+            z_sup, z_tiles = vol, n1 * nt
             ylen = np.full(nt, n1, dtype=np.int64)
         else:
-            zlen = (table[:n1 * nt, 1].astype(np.int64) - table[:n1 * nt, 0]).clip(0)
-            ylen = (table[n1 * nt:, 1].astype(np.int64) - table[n1 * nt:, 0]).clip(0)
-        z_sup = int(zlen.sum()) * 16                 # grid points inside the support, per coil
-        z_tiles = int(np.count_nonzero(zlen))        # (kx tile, ky) columns with any support
+            zr, yr, bits = self.split_support(table)
+            z_sup = int(np.unpackbits(bits.view(np.uint8)).sum()) * 16     # grid points in flagged segments, per coil
+            z_tiles = int(np.count_nonzero(zr[:, 1] > zr[:, 0]))           # (kx tile, ky) columns with any support
+            ylen = (yr[:, 1].astype(np.int64) - yr[:, 0]).clip(0)
         y_sup = int(ylen.sum()) * 16 * b2            # points the y pass produces / consumes on its grid side
         e = 8 * C
         return {
             "fft_pad_x": bvol * 8 + bvol * e + cvol * e,
             "fft_pad_y": cvol * e + y_sup * e,
             "fft_pad_z": z_tiles * 16 * b2 * e + z_sup * e,
-            "fft_crop_z": z_sup * e + n1 * nt * 16 * b2 * e,
+            "fft_crop_z": z_sup * e + z_tiles * 16 * b2 * e,
             "fft_crop_y": y_sup * e + cvol * e,
             "fft_crop_x": cvol * e + bvol * e + bvol * e,
         }

@@ -304,31 +304,46 @@ def test_zpadfft_operator_matches_reference_composition(hip, oracle_backend):
     hip._scratch = None
 
 
+def support_table_from_segments(seg):
+    """flat int16 support table (see SenseProblem.grid_support) from a boolean array seg[ky, kz, kx tile]"""
+    n1, n2, nt = seg.shape
+    kz = np.arange(n2)[None, :, None]
+    lo = np.where(seg, kz, n2).min(axis=1)
+    hi = np.where(seg, kz + 1, 0).max(axis=1)
+    ranges = np.zeros((n1 * nt + nt, 2), dtype=np.int16)
+    ranges[:n1 * nt, 0] = np.where(hi > lo, lo, 0).reshape(-1)
+    ranges[:n1 * nt, 1] = np.where(hi > lo, hi, 0).reshape(-1)
+    for t in range(nt):
+        ys = np.flatnonzero(hi[:, t] > lo[:, t])
+        if ys.size:
+            ranges[n1 * nt + t] = (ys[0], ys[-1] + 1)
+    bits = np.zeros((n1, nt, 16), dtype=np.uint32)
+    ky, kzz, tt = np.nonzero(seg)
+    np.bitwise_or.at(bits, (ky, tt, kzz % 16), np.uint32(1) << (kzz // 16).astype(np.uint32))
+    return np.concatenate([ranges.reshape(-1), bits.reshape(-1).view(np.int16)]), ranges[:n1 * nt]
+
+
 def test_padded_fft_with_support_table(hip):
-    """k-space support ranges: the padded transform guarantees only kz inside [lo, hi) of each (kx tile, ky);
-    the cropped transform ignores whatever lies outside; the masked adjoint SpMM writes only rows inside."""
+    """k-space support at 16-row-segment granularity: the padded transform guarantees only the flagged segments;
+    the cropped transform reads everything else as zero; the masked adjoint SpMM writes only flagged segments."""
     grid, box, C, layout = (256, 256, 256), (128, 128, 128), 2, 1
     lo = tuple(m // 2 + int(np.ceil(-n / 2)) for m, n in zip(grid, box))
     n0, n1, n2 = grid
     P, N = int(np.prod(grid)), int(np.prod(box))
     rng = np.random.default_rng(7)
     nt = n0 // 16
-    table = np.zeros((n1 * nt, 2), dtype=np.int16)
-    table[:, 0] = rng.integers(0, 200, table.shape[0])
-    table[:, 1] = table[:, 0] + rng.integers(0, 57, table.shape[0])          # some ranges empty
-    tz = table.reshape(n1, nt, 2)
-    tz[:30, ::2] = 0                                                          # even kx tiles: no support for ky < 30
-    tz[220:, ::2] = 0                                                         #                 ... nor for ky >= 220
-    ypart = np.zeros((nt, 2), dtype=np.int16)                                 # second part: ky range per kx tile
-    for t in range(nt):
-        ys = np.flatnonzero(tz[:, t, 1] > tz[:, t, 0])
-        ypart[t] = (ys[0], ys[-1] + 1)
-    sup = hip.copy_array(np.concatenate([table, ypart]).reshape(-1))
-    # membership mask in (x, z, y) memory order
-    zlo = np.repeat(table[:, 0].reshape(n1, n0 // 16), 16, axis=1)          # (ky, kx)
-    zhi = np.repeat(table[:, 1].reshape(n1, n0 // 16), 16, axis=1)
-    kz = np.arange(n2)[None, :, None]
-    inside = ((kz >= zlo.T[:, None, :]) & (kz < zhi.T[:, None, :])).reshape(-1, order='F')      # index kx + n0*(kz + n2*ky)
+    zlo = rng.integers(0, 200, (n1, 1, nt))
+    zhi = zlo + rng.integers(0, 57, (n1, 1, nt))                              # some ranges empty
+    kzv = np.arange(n2)[None, :, None]
+    seg = (kzv >= zlo) & (kzv < zhi) & (rng.random((n1, n2, nt)) < 0.6)       # gaps inside the ranges
+    seg[:30, :, ::2] = False                                                  # even kx tiles: no support for ky < 30
+    seg[220:, :, ::2] = False                                                 #                 ... nor for ky >= 220
+    flat_table, table = support_table_from_segments(seg)
+    sup = hip.copy_array(flat_table)
+    # membership mask in (x, z, y) memory order: index kx + n0*(kz + n2*ky)
+    inside = np.repeat(seg, 16, axis=2).reshape(-1)
+    from oracle.np_backend import NumpyBackend
+    np.testing.assert_array_equal(NumpyBackend.support_rows(flat_table, grid), inside)
     x, w = rand64c(N, 1, seed=1), rand64c(N, C, seed=2)
     ws = hip.zero_array((hip._fft_padded_workspace(grid, lo, box, C, layout) // 8,), C64)
     full_d = hip.zero_array((P, C), C64)
@@ -359,7 +374,7 @@ def test_padded_fft_with_support_table(hip):
     cols = rng.choice(np.flatnonzero(inside), size=T * 4)
     A = spp.csr_matrix((rand64c(T * 4, seed=4), cols, np.arange(0, T * 4 + 1, 4)), shape=(T, P))
     A_d = hip.csr_matrix(hip, A)
-    A_d.set_grid_support(np.concatenate([table, ypart]), n0, n2)
+    A_d.set_grid_support(flat_table, n0, n2)
     xs = rand64c(T, C, seed=5)
     out_d = hip.copy_array(sentinel)
     A_d.adjoint(out_d, hip.copy_array(xs))

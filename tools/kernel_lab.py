@@ -76,7 +76,10 @@ def empty_rows_probe():
     A = spp.csr_matrix((P, 1000), dtype=c64)
     S = B.SpMatrix(A, name='empty')
     x = B.copy_array(rand64c(1000, ncol, seed=1))
-    y = B.zero_array((P, ncol), c64)
+    pad = int(sys.argv[2]) if len(sys.argv) > 2 else 0      # extra rows of leading dimension (de-aliases the 1 GiB column stride)
+    y = B.zero_array((P + pad, ncol), c64)
+    if pad: y = y[:P]
+    print("ld =", y._leading_dim)
     S.eval(y, x); B.barrier()
     B.profile(True)
     for _ in range(5):
