@@ -70,25 +70,6 @@ __device__ __forceinline__ void st_stream(float2* p, float2 a) {
     else *p = a;
 }
 
-// Raw buffer accesses: 128-bit descriptor (wave-uniform base, 2 GB window) + per-lane 32-bit byte offset + uniform
-// byte offset.  A lane offset >= the window (IG_OOB) is out of range: loads return 0, stores are dropped.
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-typedef unsigned int v2u_t __attribute__((ext_vector_type(2)));
-#define IG_OOB 0x80000000u
-__device__ __forceinline__ rsrc_t make_rsrc(const void* p) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)IG_OOB, 0x00020000);
-}
-template <bool NT>
-__device__ __forceinline__ float2 buf_ld(rsrc_t r, unsigned voff, unsigned soff) {
-    const v2u_t v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, NT ? 2 : 0);
-    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
-}
-template <bool NT>
-__device__ __forceinline__ void buf_st(rsrc_t r, unsigned voff, unsigned soff, float2 a) {
-    v2u_t v; v.x = __float_as_uint(a.x); v.y = __float_as_uint(a.y);
-    __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, NT ? 2 : 0);
-}
-
 __device__ __forceinline__ void bfly2(float2& a, float2& b) {
     const float2 t = csub(a, b);
     a = cadd(a, b);

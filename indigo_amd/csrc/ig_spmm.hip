@@ -176,7 +176,9 @@ k_csrmm_gather(int64_t M, int64_t N,
 // columns in registers, so a wave covers 64 rows, every store instruction writes 512 contiguous bytes
 // of one panel column, and each nonzero issues NC independent gathers.  With one row per 8 lanes the
 // same matrix needs 8x more waves, each a short dependent chain: that version is latency bound.
-template <int NC, bool CONJ, int BMODE, bool PACKED>
+// BUF: index/value/panel loads go through buffer descriptors (all three arrays < 2 GB): the lanes of a trip that
+// are past their row's end get an out-of-range offset, i.e. no memory access at all, without a branch.
+template <int NC, bool CONJ, int BMODE, bool PACKED, int U, bool BUF>
 __global__ void __launch_bounds__(BLK)
 k_csrmm_rowlane(int64_t M, int64_t N,
                 const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
@@ -211,30 +213,72 @@ k_csrmm_rowlane(int64_t M, int64_t N,
         float2 acc[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) acc[c] = make_float2(0.f, 0.f);
-        // one nonzero per trip.  (A four-wide predicated trip was measured slower here: 4.7 vs 4.2 ms on the
-        // 134M-row transposed gridding matrix -- the kernel is bound by per-lane address processing of the
-        // scattered panel-row loads, not by their latency.)
-        for (int32_t p = p0; p < p1; ++p) {
-            const int32_t k = colind[p];
-            const float2 v = vals[p];
+        // U nonzeros per trip, predicated (index clamped to the row's last nonzero, value zeroed): the kernel is
+        // bound by the latency of its dependent chain (rowptr -> index/value -> panel row) times the few waves a
+        // CU holds, so U independent panel-row gathers in flight per lane shorten it almost U-fold.
+        if (BUF) {
+            const rsrc_t rc = make_rsrc(colind), rv = make_rsrc(vals), rx = make_rsrc(X);
+            for (int32_t p = p0; p < p1; p += U) {
+                int32_t k[U];
+                float2 v[U];
+                float4 t4[U][NC / 2 > 0 ? NC / 2 : 1];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const bool ok = p + u < p1;
+                    k[u] = buf_ld_i32(rc, ok ? (unsigned)(p + u) * 4u : IG_OOB);
+                    v[u] = buf_ld<false>(rv, ok ? (unsigned)(p + u) * 8u : IG_OOB, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const bool ok = p + u < p1;
+                    const unsigned xo = ((unsigned)k[u] * (unsigned)sxr + (unsigned)jb) * 8u;
+#pragma unroll
+                    for (int h = 0; h < NC / 2; ++h) t4[u][h] = buf_ld_f4(rx, ok ? xo + 16u * h : IG_OOB);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int h = 0; h < NC / 2; ++h) {
+                        acc_nz<CONJ>(acc[2 * h], v[u], make_float2(t4[u][h].x, t4[u][h].y));
+                        acc_nz<CONJ>(acc[2 * h + 1], v[u], make_float2(t4[u][h].z, t4[u][h].w));
+                    }
+            }
+        } else
+        for (int32_t p = p0; p < p1; p += U) {
+            int32_t k[U];
+            float2 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool ok = p + u < p1;
+                const int32_t q = ok ? p + u : p1 - 1;
+                k[u] = colind[q];
+                const float2 vv = vals[q];
+                v[u] = ok ? vv : make_float2(0.f, 0.f);
+            }
             if (PACKED && NC >= 2) {
-                // packed panel: the NC values of row k are contiguous (NC*8 bytes, 16-byte aligned)
                 // packed panel: row k holds its columns contiguously (sxr elements per row); this chunk of NC
                 // columns is NC*8 contiguous, 16-byte aligned bytes
-                const float4* __restrict__ q = reinterpret_cast<const float4*>(X + (int64_t)k * sxr + jb);
-                float4 t4[NC / 2 > 0 ? NC / 2 : 1];
+                float4 t4[U][NC / 2 > 0 ? NC / 2 : 1];
 #pragma unroll
-                for (int h = 0; h < NC / 2; ++h) t4[h] = q[h];
+                for (int u = 0; u < U; ++u) {
+                    const float4* __restrict__ q = reinterpret_cast<const float4*>(X + (int64_t)k[u] * sxr + jb);
 #pragma unroll
-                for (int h = 0; h < NC / 2; ++h) {
-                    acc_nz<CONJ>(acc[2 * h], v, make_float2(t4[h].x, t4[h].y));
-                    acc_nz<CONJ>(acc[2 * h + 1], v, make_float2(t4[h].z, t4[h].w));
+                    for (int h = 0; h < NC / 2; ++h) t4[u][h] = q[h];
                 }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int h = 0; h < NC / 2; ++h) {
+                        acc_nz<CONJ>(acc[2 * h], v[u], make_float2(t4[u][h].x, t4[u][h].y));
+                        acc_nz<CONJ>(acc[2 * h + 1], v[u], make_float2(t4[u][h].z, t4[u][h].w));
+                    }
             } else {
 #pragma unroll
-                for (int c = 0; c < NC; ++c)
-                    if (jb + c < N)
-                        acc_nz<CONJ>(acc[c], v, X[PACKED ? (int64_t)k * sxr + jb + c : (jb + c) * ldx + k]);
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int c = 0; c < NC; ++c)
+                        if (jb + c < N)
+                            acc_nz<CONJ>(acc[c], v[u], X[PACKED ? (int64_t)k[u] * sxr + jb + c : (jb + c) * ldx + k[u]]);
             }
         }
 #pragma unroll
@@ -246,6 +290,127 @@ k_csrmm_rowlane(int64_t M, int64_t N,
                 *yp = out;
             }
         }
+    }
+}
+
+// Dense-lane variant of the row-per-lane kernel for matrices with mostly empty rows (transposed gridding: 89 %
+// empty, the rest 3.4 nonzeros on average).  With a lane walking its own row only ~14 % of the lanes of a gather
+// instruction are active, and the texture-address unit spends the same cycles on it as on a full one: that, not
+// latency or HBM, bounded the row-per-lane kernel (2.4 ms; unrolling the row loop changed nothing).  Here the
+// nonzeros of a wave's 64 rows -- one contiguous range of the CSR arrays -- are processed 64 at a time, one per lane,
+// all lanes active: coalesced index/value loads, one gathered panel row per lane, products parked in LDS; then each
+// row's lane sums its own run of products (LDS reads, no atomics) and stores as before, 512 contiguous bytes per
+// panel column.  Rows beyond thr_mid go to the deferred-row lists and are skipped here.
+template <int NC, bool CONJ>
+__global__ void __launch_bounds__(BLK, 8)
+k_csrmm_dense64(int64_t M, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
+                const float2* __restrict__ vals, const float2* __restrict__ Xp,
+                float2* __restrict__ Y, int64_t ldy, float2 alpha,
+                WorkLists wl, int32_t thr_mid, int32_t thr_long, GridMask mask) {
+    __shared__ float4 prod[WAVES_PER_BLOCK][64][NC / 2];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // A wave strides over the 64-row tasks (the launcher normally gives every task its own wave; with a capped grid
+    // the next task's row pointers and bitmap word are fetched while the current one is processed).
+    const int64_t ntasks = (M + 63) / 64;
+    const int64_t stride = (int64_t)gridDim.x * WAVES_PER_BLOCK;
+    const rsrc_t rc = make_rsrc(colind), rv = make_rsrc(vals), rx = make_rsrc(Xp);
+
+    auto fetch = [&](int64_t task, int32_t& R, int32_t& R1, uint32_t& wbits, uint32_t& km) {
+        const int64_t row = task * 64 + lane;
+        const bool inb = task < ntasks && row < M;
+        R = rowptr[inb ? row : M];
+        R1 = rowptr[inb ? row + 1 : M];
+        wbits = inb ? 0xffffffffu : 0u;
+        km = 0;
+        if (inb && mask.bits) {
+            // 32-bit index arithmetic: a grid has < 2^31 rows
+            const uint32_t r32 = (uint32_t)row, n0 = (uint32_t)mask.n0, nm = (uint32_t)mask.nm;
+            const uint32_t rest = r32 / n0, kx = r32 - rest * n0;
+            const uint32_t ks = rest / nm;
+            km = rest - ks * nm;
+            wbits = mask.bits[((size_t)ks * (n0 >> 4) + (kx >> 4)) * 16 + (km & 15)];
+        }
+    };
+
+    int64_t task = (int64_t)blockIdx.x * WAVES_PER_BLOCK + wv;
+    int32_t R, R1;
+    uint32_t wbits, km;
+    fetch(task, R, R1, wbits, km);
+    for (; task < ntasks; task += stride) {
+        int32_t Rn, R1n;
+        uint32_t wbn, kmn;
+        fetch(task + stride, Rn, R1n, wbn, kmn);
+        const int64_t row = task * 64 + lane;
+        const bool live = (wbits >> (km >> 4)) & 1u;      // segments (16 rows) outside the support: no load, no store
+        if (__ballot(live)) {
+            const int32_t len = R1 - R;
+            bool mine = live;                                 // this lane computes and stores its row here
+            {
+                const int sub = (int)(task & (WL_SUB - 1));
+                if (wl_append(wl, 0, sub, live && len > thr_mid && len <= thr_long, (int32_t)row)) mine = false;
+                if (wl_append(wl, 1, sub, live && len > thr_long, (int32_t)row)) mine = false;
+            }
+            // compact numbering of the wave's inline nonzeros: row r owns [pe - n_r, pe)
+            const int32_t n_r = mine ? len : 0;
+            int32_t pe = n_r;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int32_t t = __shfl_up(pe, d, 64);
+                if (lane >= d) pe += t;
+            }
+            const int32_t ps = pe - n_r;
+            const int32_t total = __shfl(pe, 63, 64);
+
+            float2 acc[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[c] = make_float2(0.f, 0.f);
+            for (int32_t base = 0; base < total; base += 64) {
+                const int32_t q = base + lane;
+                const bool ok = q < total;
+                // owner of compact nonzero q: the first row whose inclusive prefix exceeds q
+                int lo = 0;
+#pragma unroll
+                for (int step = 32; step >= 1; step >>= 1) {
+                    const int32_t t = __shfl(pe, lo + step - 1, 64);
+                    if (t <= q) lo += step;
+                }
+                lo &= 63;
+                const int32_t p = __shfl(R, lo, 64) + (q - __shfl(ps, lo, 64));
+                const int32_t k = buf_ld_i32(rc, ok ? (unsigned)p * 4u : IG_OOB);
+                const float2 v = buf_ld<false>(rv, ok ? (unsigned)p * 8u : IG_OOB, 0);
+                float4 x4[NC / 2];
+#pragma unroll
+                for (int h = 0; h < NC / 2; ++h) x4[h] = buf_ld_f4(rx, ok ? (unsigned)k * (NC * 8u) + 16u * h : IG_OOB);
+#pragma unroll
+                for (int h = 0; h < NC / 2; ++h) {
+                    float2 a = make_float2(0.f, 0.f), b = a;
+                    acc_nz<CONJ>(a, v, make_float2(x4[h].x, x4[h].y));
+                    acc_nz<CONJ>(b, v, make_float2(x4[h].z, x4[h].w));
+                    prod[wv][lane][h] = make_float4(a.x, a.y, b.x, b.y);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int32_t j0 = (ps > base ? ps : base) - base, j1 = (pe < base + 64 ? pe : base + 64) - base;
+                for (int32_t j = j0; j < j1; ++j) {
+#pragma unroll
+                    for (int h = 0; h < NC / 2; ++h) {
+                        const float4 t = prod[wv][j][h];
+                        acc[2 * h].x += t.x; acc[2 * h].y += t.y;
+                        acc[2 * h + 1].x += t.z; acc[2 * h + 1].y += t.w;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            if (mine) {
+                const int64_t orow = out_row(wl.yperm, row);
+#pragma unroll
+                for (int c = 0; c < NC; ++c) Y[c * ldy + orow] = cmul(alpha, acc[c]);
+            }
+        }
+        R = Rn; R1 = R1n; wbits = wbn; km = kmn;
     }
 }
 
@@ -499,7 +664,7 @@ int launch_gather(ig_ctx* ctx, int64_t rows, int64_t xrows, int64_t N, int64_t n
     // Packing costs one read + one write of the panel (16 B per element) and turns nnz*N scattered 8-byte gathers
     // (each pulling a 32..64-byte sector) into nnz contiguous N*8-byte ones: worth it once every panel row is
     // gathered at least about once (nnz >= xrows); always for small hot panels.
-    if (((N >= 2 && N <= 64 && nnz >= xrows) || (xperm && N <= 8)) && env_flag("INDIGO_HIP_SPMM_PACK", true)) {
+    if (((N >= 2 && N <= 64 && nnz >= xrows) || (xperm && N <= 8) || env_flag("INDIGO_HIP_SPMM_FORCEPACK", false)) && env_flag("INDIGO_HIP_SPMM_PACK", true)) {
         const int np = s.CL;             // pow2 >= N, <= 64
         const size_t need = (size_t)xrows * np * 8;
         if (need <= ((size_t)16 << 30)) {
@@ -563,28 +728,45 @@ int launch_gather(ig_ctx* ctx, int64_t rows, int64_t xrows, int64_t N, int64_t n
         // sparse-row matrices defer rows beyond 16 nonzeros; wide-panel use keeps ordinary rows inline
         const int32_t tm_want = nnz <= 2 * rows ? 16 : 512;
         const int32_t tm = defer ? (thr_long < tm_want ? thr_long : tm_want) : 0x7fffffff;
+#define IG_ROWLANE_L(NC_, BM_, PK_, U_, BUF_)                                                      \
+    hipLaunchKernelGGL((k_csrmm_rowlane<NC_, CONJ, BM_, PK_, U_, BUF_>), dim3((unsigned)rblocks),  \
+                       dim3(BLK), 0, ctx->stream, rows, N, rowptr, colind, vals, X, sxc, sxr, Y, ldy, \
+                       alpha, beta, xcd, wl, tm, thr_long, mask)
 #define IG_ROWLANE(NC_)                                                                            \
     do {                                                                                           \
-        if (packed) {                                                                              \
-            if (b0) hipLaunchKernelGGL((k_csrmm_rowlane<NC_, CONJ, 0, true>), dim3((unsigned)rblocks), \
-                        dim3(BLK), 0, ctx->stream, rows, N, rowptr, colind, vals, X, sxc, sxr, Y, ldy, \
-                        alpha, beta, xcd, wl, tm, thr_long, mask);                                       \
-            else    hipLaunchKernelGGL((k_csrmm_rowlane<NC_, CONJ, 1, true>), dim3((unsigned)rblocks), \
-                        dim3(BLK), 0, ctx->stream, rows, N, rowptr, colind, vals, X, sxc, sxr, Y, ldy, \
-                        alpha, beta, xcd, wl, tm, thr_long, mask);                                       \
-        } else                                                                                     \
-        if (b0) hipLaunchKernelGGL((k_csrmm_rowlane<NC_, CONJ, 0, false>), dim3((unsigned)rblocks), \
-                    dim3(BLK), 0, ctx->stream, rows, N, rowptr, colind, vals, X, sxc, sxr, Y, ldy, \
-                    alpha, beta, xcd, wl, tm, thr_long, mask);                                           \
-        else    hipLaunchKernelGGL((k_csrmm_rowlane<NC_, CONJ, 1, false>), dim3((unsigned)rblocks), \
-                    dim3(BLK), 0, ctx->stream, rows, N, rowptr, colind, vals, X, sxc, sxr, Y, ldy, \
-                    alpha, beta, xcd, wl, tm, thr_long, mask);                                           \
+        if (packed && b0 && NC_ >= 2 && bufok) {                                                   \
+            if (unroll >= 4) IG_ROWLANE_L(NC_, 0, true, 4, true);                                  \
+            else if (unroll == 2) IG_ROWLANE_L(NC_, 0, true, 2, true);                             \
+            else IG_ROWLANE_L(NC_, 0, true, 1, true);                                              \
+        } else if (packed && b0) IG_ROWLANE_L(NC_, 0, true, 1, false);                             \
+        else if (packed) IG_ROWLANE_L(NC_, 1, true, 1, false);                                     \
+        else if (b0) IG_ROWLANE_L(NC_, 0, false, 1, false);                                        \
+        else IG_ROWLANE_L(NC_, 1, false, 1, false);                                                \
     } while (0)
+        // buffer-descriptor loads need every array inside a 2 GB window
+        const bool bufok = packed && nnz * 8 < 0x7fffffffLL && xrows * sxr * 8 < 0x7fffffffLL;
+        static const int unroll = getenv("INDIGO_HIP_SPMM_UNROLL") ? atoi(getenv("INDIGO_HIP_SPMM_UNROLL")) : 2;
+        // mostly-empty rows, packed panel of <= 8 columns, beta == 0: the dense-lane kernel
+        static const int dense_thr = getenv("INDIGO_HIP_SPMM_DENSE") ? atoi(getenv("INDIGO_HIP_SPMM_DENSE")) : 16;
+        if (dense_thr > 0 && packed && b0 && bufok && nnz <= 2 * rows && N == sxr && (sxr == 8 || sxr == 4 || sxr == 2)) {
+            const int32_t td = defer ? (thr_long < dense_thr ? thr_long : dense_thr) : 0x7fffffff;
+            int64_t dblocks = ((rows + 63) / 64 + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+            // One task per wave by default: the hardware dispatcher balances the very uneven tasks better than a
+            // static stride does (1.39 ms against 1.91 ms with 8 persistent workgroups per CU on the SENSE matrix).
+            static const int dense_wgs = getenv("INDIGO_HIP_SPMM_DENSE_WGS") ? atoi(getenv("INDIGO_HIP_SPMM_DENSE_WGS")) : 0;
+            if (dense_wgs > 0 && dblocks > (int64_t)ctx->num_cu * dense_wgs) dblocks = (int64_t)ctx->num_cu * dense_wgs;
+            IG_REQUIRE(ctx, dblocks <= 0x7fffffffLL, "csrmm: matrix too large for one launch");
+#define IG_DENSE(NC_) hipLaunchKernelGGL((k_csrmm_dense64<NC_, CONJ>), dim3((unsigned)dblocks), dim3(BLK), 0, ctx->stream, \
+                                         rows, rowptr, colind, vals, X, Y, ldy, alpha, wl, td, thr_long, mask)
+            if (sxr == 8) IG_DENSE(8); else if (sxr == 4) IG_DENSE(4); else IG_DENSE(2);
+#undef IG_DENSE
+        } else
         if (s.CL >= 8) IG_ROWLANE(8);
         else if (s.CL == 4) IG_ROWLANE(4);
         else if (s.CL == 2) IG_ROWLANE(2);
         else IG_ROWLANE(1);
 #undef IG_ROWLANE
+#undef IG_ROWLANE_L
         IG_LAUNCH_CHECK(ctx, "k_csrmm_rowlane");
     } else {
         ig_prof_scope prof(ctx, CONJ ? "csrmm_gather_conj" : "csrmm_gather");
