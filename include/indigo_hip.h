@@ -112,6 +112,9 @@ int  ig_cmax(ig_ctx* ctx, int64_t nfloats, float val, void* arr);           /* a
  * (indigo/operators.py:440-447), in one pass.                                              */
 int  ig_csum_cols(ig_ctx* ctx, int64_t rows, int64_t ncols, const void* X, int64_t ldx,
                   float alpha_re, float alpha_im, float beta_re, float beta_im, void* y);
+/* the same sum over a row-major (coil-interleaved) panel: y[k] = beta*y[k] + alpha * sum_j X_il[k*ncols + j] */
+int  ig_csum_il(ig_ctx* ctx, int64_t rows, int64_t ncols, const void* X_il,
+                float alpha_re, float alpha_im, float beta_re, float beta_im, void* y);
 
 /* ------------------------------------------------------------------------
  * CSR x dense-panel SpMM.  Replaces Backend.ccsrmm
@@ -163,6 +166,29 @@ int  ig_ccsrmm_t_grid(ig_ctx* ctx,
                       float beta_re, float beta_im,
                       void* Y, int64_t ldy,
                       const int16_t* support, int64_t n0, int64_t nm, const int32_t* xrow_perm);
+
+/* Coil-interleaved panels (the grid side of the fused transform's grid_layout 2): the K x N panel is stored
+ * row-major, element (k, j) at [k*N + j], so that one grid point's N coil values are one contiguous N*8-byte
+ * row.  The reference's KronI(C, G) batches the same products over column-major panels
+ * (indigo/operators.py:236-265 KronI._eval); only the memory order of the grid-side panel differs.
+ *   ig_ccsrmm_il        Y = alpha * A * X_il + beta * Y          A: M x K CSR, X_il interleaved, Y column-major
+ *   ig_ccsrmm_t_grid_il Y_il = alpha * A^H * X                   through the CSR of A^T (K rows), Y_il interleaved,
+ *                       restricted to the flagged segments of `support` exactly like ig_ccsrmm_t_grid
+ * N must be a power of two (ig_ccsrmm_il: <= 64; ig_ccsrmm_t_grid_il: 2, 4 or 8).                      */
+int  ig_ccsrmm_il(ig_ctx* ctx,
+                  int64_t M, int64_t K, int64_t N, int64_t nnz,
+                  float alpha_re, float alpha_im,
+                  const void* vals, const int32_t* colind, const int32_t* rowptr,
+                  const void* X_il,
+                  float beta_re, float beta_im,
+                  void* Y, int64_t ldy);
+int  ig_ccsrmm_t_grid_il(ig_ctx* ctx,
+                         int64_t M, int64_t K, int64_t N, int64_t nnz,
+                         float alpha_re, float alpha_im,
+                         const void* vals_t, const int32_t* colind_t, const int32_t* rowptr_t,
+                         const void* X, int64_t ldx,
+                         void* Y_il,
+                         const int16_t* support, int64_t n0, int64_t nm);
 
 /* Locality-ordered variants.  The caller may store A with its ROWS reordered (row r of the stored
  * matrix is row perm[r] of A; e.g. k-space samples sorted by the grid cell they touch, so that
@@ -219,7 +245,12 @@ int  ig_fft_describe(ig_fft* plan, char* buf, size_t len);   /* kernel / radix s
  * transform only uses it for grid_layout 1).
  * grid_layout: memory order of Y.  0 = (x, y, z), the reference's Fortran order; 1 = (x, z, y), i.e.
  * element (kx, ky, kz) at kx + n0*kz + n0*n2*ky -- an internal order that keeps the largest axis pass
- * at a 4 KB stride; the consumer of Y (the gridding matrix) must be indexed the same way.      */
+ * at a 4 KB stride; the consumer of Y (the gridding matrix) must be indexed the same way.
+ * 2 = (c, x, z, y): layout 1 with the batch (coils) interleaved below it, element (c, kx, ky, kz) at
+ * c + batch*(kx + n0*kz + n0*n2*ky), batch in {1, 2, 4, 8, 16}; the gridding products then move one contiguous
+ * row per grid point (ig_ccsrmm_il / ig_ccsrmm_t_grid_il).  With layout 2 the weights and, for the cropped
+ * transform, the compact result x are interleaved too: w[i*batch + c], x[i*batch + c] (x_bstride is ignored
+ * by the cropped transform; sum the coils with ig_csum_il).                                         */
 int  ig_fft_plan_padded(ig_ctx* ctx, const int64_t* dims, const int64_t* box_lo, const int64_t* box_dims,
                         int64_t batch, int grid_layout, ig_fft** plan, size_t* workspace_bytes);
 /* support (optional, grid_layout 1 only; may be NULL): the k-space support of the gridding matrix that

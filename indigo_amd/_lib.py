@@ -44,6 +44,14 @@ PROTOTYPES = {
     "ig_scnrm2sq":        (c_int, [c_void_p, c_int64, c_void_p, POINTER(c_double)]),
     "ig_cmax":            (c_int, [c_void_p, c_int64, c_float, c_void_p]),
     "ig_csum_cols":       (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_void_p]),
+    "ig_csum_il":         (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_float, c_float, c_float, c_float, c_void_p]),
+    "ig_ccsrmm_il":       (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64,
+                                   c_float, c_float, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_float, c_float, c_void_p, c_int64]),
+    "ig_ccsrmm_t_grid_il": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64,
+                                    c_float, c_float, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_int64, c_void_p,
+                                    c_void_p, c_int64, c_int64]),
     "ig_ccsrmm":          (c_int, [c_void_p, c_int, c_int, c_int64, c_int64, c_int64, c_int64,
                                    c_float, c_float, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_int64, c_float, c_float, c_void_p, c_int64]),

@@ -431,18 +431,20 @@ class Backend(object):
     # they replace its Zpad-CSR + FFT composition; see include/indigo_hip.h ig_fft_exec_padded)
     def fft_padded(self, y, x, w, grid, box_lo, box_dims, workspace=None, layout=0, support=None):
         """y[:, c] = FFT(zeropad(w[:, c] * x)); y: (prod grid, C), x: (prod box, 1), w: (prod box, C).
-        layout 1 stores each grid in (x, z, y) memory order instead of (x, y, z)."""
+        layout 1 stores each grid in (x, z, y) memory order instead of (x, y, z); layout 2 additionally interleaves
+        the coils below x (memory index c + C*(kx + n0*kz + n0*n2*ky)) and expects w interleaved, w[i*C + c]."""
         raise NotImplementedError()
 
     def ifft_cropped(self, xc, y, w, grid, box_lo, box_dims, workspace, layout=0, support=None):
-        """xc[:, c] = conj(w[:, c]) * crop(IFFT(y[:, c])); xc: (prod box, C), y: (prod grid, C) left intact"""
+        """xc[:, c] = conj(w[:, c]) * crop(IFFT(y[:, c])); xc: (prod box, C), y: (prod grid, C) left intact
+        (layout 2: y, w and xc are coil-interleaved in memory)"""
         raise NotImplementedError()
 
     def _fft_padded_workspace(self, grid, box_lo, box_dims, batch, layout=0):
         return 0
 
-    def sum_columns(self, y, X, alpha=1, beta=0):
-        """y = beta*y + alpha * sum_j X[:, j]"""
+    def sum_columns(self, y, X, alpha=1, beta=0, interleaved=False):
+        """y = beta*y + alpha * sum_j X[:, j]  (interleaved: X's memory holds element (i, j) at i*ncols + j)"""
         raise NotImplementedError()
 
     def supports_padded_fft(self, grid):
@@ -503,14 +505,23 @@ class Backend(object):
         def forward(self, y, x, alpha=1, beta=0):
             """y = alpha * A * x + beta * y"""
             self._check_panels(y, x, self.values)
+            il = {'x_il': True} if getattr(self, '_grid_il', False) else {}
             self._backend.ccsrmm(y, self.shape, self.colInds, self.rowPtrs, self.values,
-                                 x, alpha=alpha, beta=beta, adjoint=False, exwrite=True)
+                                 x, alpha=alpha, beta=beta, adjoint=False, exwrite=True, **il)
 
         def adjoint(self, y, x, alpha=1, beta=0):
             """y = alpha * A^H * x + beta * y"""
             self._check_panels(y, x, self.values)
+            il = {'y_il': True} if getattr(self, '_grid_il', False) else {}
             self._backend.ccsrmm(y, self.shape, self.colInds, self.rowPtrs, self.values,
-                                 x, alpha=alpha, beta=beta, adjoint=True, exwrite=self._exwrite)
+                                 x, alpha=alpha, beta=beta, adjoint=True, exwrite=self._exwrite, **il)
+
+        def set_grid_interleaved(self, flag=True):
+            """The panel on the COLUMN side of this matrix (x of a forward product, y of an adjoint one) is stored
+            row-major -- the values of one grid point for all panel columns (coils) contiguous -- instead of
+            column-major.  This is the memory order of the fused transform's grid layout 2; the products are the
+            same numbers in a different order."""
+            self._grid_il = bool(flag)
 
         def set_grid_support(self, table, n0, nm):
             """Hint: the columns of this matrix index a 3-D grid and only the tabulated support is ever

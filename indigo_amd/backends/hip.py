@@ -343,7 +343,7 @@ class HipBackend(Backend):
     def ifft_cropped(self, xc, y, w, grid, box_lo, box_dims, workspace, layout=0, support=None):
         C = y.shape[1]
         assert y.dtype == _C64 and xc.dtype == _C64 and y.contiguous and xc.contiguous
-        assert xc.shape == (int(np.prod(box_dims)), C)
+        assert xc.shape == (int(np.prod(box_dims)), C) and (layout != 2 or xc.contiguous)
         plan, ws = self._padded_plan(grid, box_lo, box_dims, C, layout)
         assert workspace.nbytes >= ws
         self._check(self._L.ig_fft_exec_cropped(plan, ctypes.c_void_p(y._arr),
@@ -353,10 +353,15 @@ class HipBackend(Backend):
                                                 ctypes.c_void_p(support._arr) if support is not None else None),
                     "ig_fft_exec_cropped")
 
-    def sum_columns(self, y, X, alpha=1, beta=0):
+    def sum_columns(self, y, X, alpha=1, beta=0, interleaved=False):
         assert y.dtype == _C64 and X.dtype == _C64 and y.contiguous and y.size == X.shape[0]
         ar, ai = _cplx(alpha)
         br, bi = _cplx(beta)
+        if interleaved:
+            assert X.contiguous
+            self._check(self._L.ig_csum_il(self._ctx, X.shape[0], X.shape[1], ctypes.c_void_p(X._arr),
+                                           ar, ai, br, bi, ctypes.c_void_p(y._arr)), "ig_csum_il")
+            return
         self._check(self._L.ig_csum_cols(self._ctx, X.shape[0], X.shape[1], ctypes.c_void_p(X._arr), X._leading_dim,
                                          ar, ai, br, bi, ctypes.c_void_p(y._arr)), "ig_csum_cols")
 
@@ -470,6 +475,18 @@ class HipBackend(Backend):
 
         def forward(self, y, x, alpha=1, beta=0):
             perm = getattr(self, '_perm', None)
+            if getattr(self, '_grid_il', False):
+                assert perm is None and x.contiguous, "interleaved panels: no row order, contiguous grid panel"
+                self._check_panels(y, x, self.values)
+                b = self._backend
+                ar, ai = _cplx(alpha)
+                br, bi = _cplx(beta)
+                m, k = self.shape
+                b._check(b._L.ig_ccsrmm_il(b._ctx, m, k, x.shape[1], self.values.size, ar, ai,
+                                           ctypes.c_void_p(self.values._arr), ctypes.c_void_p(self.colInds._arr),
+                                           ctypes.c_void_p(self.rowPtrs._arr), ctypes.c_void_p(x._arr), br, bi,
+                                           ctypes.c_void_p(y._arr), y._leading_dim), "ig_ccsrmm_il")
+                return
             if perm is None:
                 return super().forward(y, x, alpha=alpha, beta=beta)
             self._check_panels(y, x, self.values)
@@ -489,6 +506,18 @@ class HipBackend(Backend):
             b = self._backend
             sup = getattr(self, '_support', None)
             perm = getattr(self, '_perm', None)
+            if getattr(self, '_grid_il', False):
+                assert perm is None and beta == 0 and y.contiguous, "interleaved panels: no row order, beta = 0"
+                pt, it, dt = self._transposed()
+                tab, n0, nm = sup if sup is not None else (None, 0, 0)
+                ar, ai = _cplx(alpha)
+                m, k = self.shape
+                b._check(b._L.ig_ccsrmm_t_grid_il(b._ctx, m, k, x.shape[1], dt.size, ar, ai,
+                                                  ctypes.c_void_p(dt._arr), ctypes.c_void_p(it._arr), ctypes.c_void_p(pt._arr),
+                                                  ctypes.c_void_p(x._arr), x._leading_dim, ctypes.c_void_p(y._arr),
+                                                  ctypes.c_void_p(tab._arr) if tab is not None else None, n0, nm),
+                         "ig_ccsrmm_t_grid_il")
+                return
             if perm is not None:
                 assert not self._exwrite and b.adjoint_policy == 'transpose' and x.shape[1] <= 8, \
                     "row-ordered matrices use the packed transposed gather"

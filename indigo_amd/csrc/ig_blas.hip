@@ -102,6 +102,56 @@ k_csum_cols(int64_t rows, int64_t ncols, const float2* __restrict__ X, int64_t l
     }
 }
 
+// y[k] = alpha * sum_j X[k*ncols + j] + beta*y[k]: the panel's rows are contiguous (coil-interleaved layout)
+template <bool BETA0, bool VEC>
+__global__ void __launch_bounds__(BLK)
+k_csum_il(int64_t rows, int64_t ncols, const float2* __restrict__ X, float2 alpha, float2 beta, float2* __restrict__ y) {
+    for (int64_t k = (int64_t)blockIdx.x * BLK + threadIdx.x; k < rows; k += (int64_t)gridDim.x * BLK) {
+        float2 acc = make_float2(0.f, 0.f);
+        if (VEC) {              // even ncols, 16-byte aligned rows
+            const float4* __restrict__ p = reinterpret_cast<const float4*>(X + k * ncols);
+            for (int64_t h = 0; h < ncols / 2; ++h) {
+                const float4 t = p[h];
+                acc.x += t.x + t.z; acc.y += t.y + t.w;
+            }
+        } else {
+            for (int64_t j = 0; j < ncols; ++j) acc = cadd(acc, X[k * ncols + j]);
+        }
+        float2 out = cmul(alpha, acc);
+        if (!BETA0) cfma(out, beta, y[k]);
+        y[k] = out;
+    }
+}
+
+// the same for ncols = 2*PARTS in {2, 4, 8, 16, 32}: PARTS lanes share a row, each loads 16 bytes, so a wave reads
+// 1 KB of consecutive addresses per instruction; the partial sums meet by lane shuffles
+template <bool BETA0, int PARTS>
+__global__ void __launch_bounds__(BLK)
+k_csum_il_parts(int64_t rows, const float2* __restrict__ X, float2 alpha, float2 beta, float2* __restrict__ y) {
+    const int64_t total = rows * PARTS;
+    const int64_t span = (int64_t)gridDim.x * BLK;
+    // every lane of a wave runs the same number of trips (the shuffles need the whole wave)
+    for (int64_t e0 = (int64_t)blockIdx.x * BLK; e0 < total; e0 += span) {
+        const int64_t e = e0 + threadIdx.x;
+        float2 acc = make_float2(0.f, 0.f);
+        if (e < total) {
+            const float4 t = reinterpret_cast<const float4*>(X)[e];
+            acc.x = t.x + t.z; acc.y = t.y + t.w;
+        }
+#pragma unroll
+        for (int off = 1; off < PARTS; off <<= 1) {
+            acc.x += __shfl_xor(acc.x, off, 64);
+            acc.y += __shfl_xor(acc.y, off, 64);
+        }
+        if (e < total && (threadIdx.x % PARTS) == 0) {
+            const int64_t k = e / PARTS;
+            float2 out = cmul(alpha, acc);
+            if (!BETA0) cfma(out, beta, y[k]);
+            y[k] = out;
+        }
+    }
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -259,6 +309,36 @@ int ig_csum_cols(ig_ctx* ctx, int64_t rows, int64_t ncols, const void* X, int64_
     else    hipLaunchKernelGGL(k_csum_cols<false>, dim3(g), dim3(BLK), 0, ctx->stream, rows, ncols, (const float2*)X, ldx,
                                make_float2(ar, ai), make_float2(br, bi), (float2*)y);
     IG_LAUNCH_CHECK(ctx, "k_csum_cols");
+    return IG_OK;
+}
+
+int ig_csum_il(ig_ctx* ctx, int64_t rows, int64_t ncols, const void* X_il,
+               float ar, float ai, float br, float bi, void* y) {
+    IG_REQUIRE(ctx, ctx != nullptr, "ig_csum_il: ctx is NULL");
+    IG_REQUIRE(ctx, rows >= 0 && ncols >= 0, "ig_csum_il: negative dimension");
+    if (rows == 0) return IG_OK;
+    IG_REQUIRE(ctx, y && (ncols == 0 || X_il), "ig_csum_il: NULL pointer");
+    if (int rc = ig_set_device(ctx)) return rc;
+    const bool b0 = (br == 0.f && bi == 0.f);
+    const bool vec = ncols % 2 == 0 && aligned16(X_il);
+    ig_prof_scope prof(ctx, "csum_cols", (double)rows * 8.0 * (ncols + (b0 ? 1 : 2)));
+    const float2 a = make_float2(ar, ai), b = make_float2(br, bi);
+    if (vec && (ncols == 2 || ncols == 4 || ncols == 8 || ncols == 16 || ncols == 32)) {
+        const int gp = grid_for(ctx, rows * (ncols / 2));
+#define IG_CSUM_P(P_) do { if (b0) hipLaunchKernelGGL((k_csum_il_parts<true, P_>), dim3(gp), dim3(BLK), 0, ctx->stream, rows, (const float2*)X_il, a, b, (float2*)y); \
+                           else hipLaunchKernelGGL((k_csum_il_parts<false, P_>), dim3(gp), dim3(BLK), 0, ctx->stream, rows, (const float2*)X_il, a, b, (float2*)y); } while (0)
+        switch (ncols) { case 2: IG_CSUM_P(1); break; case 4: IG_CSUM_P(2); break; case 8: IG_CSUM_P(4); break;
+                         case 16: IG_CSUM_P(8); break; default: IG_CSUM_P(16); break; }
+#undef IG_CSUM_P
+        IG_LAUNCH_CHECK(ctx, "k_csum_il_parts");
+        return IG_OK;
+    }
+    const int g = grid_for(ctx, rows);
+    if (b0 && vec)       hipLaunchKernelGGL((k_csum_il<true, true>),   dim3(g), dim3(BLK), 0, ctx->stream, rows, ncols, (const float2*)X_il, a, b, (float2*)y);
+    else if (b0)         hipLaunchKernelGGL((k_csum_il<true, false>),  dim3(g), dim3(BLK), 0, ctx->stream, rows, ncols, (const float2*)X_il, a, b, (float2*)y);
+    else if (vec)        hipLaunchKernelGGL((k_csum_il<false, true>),  dim3(g), dim3(BLK), 0, ctx->stream, rows, ncols, (const float2*)X_il, a, b, (float2*)y);
+    else                 hipLaunchKernelGGL((k_csum_il<false, false>), dim3(g), dim3(BLK), 0, ctx->stream, rows, ncols, (const float2*)X_il, a, b, (float2*)y);
+    IG_LAUNCH_CHECK(ctx, "k_csum_il");
     return IG_OK;
 }
 

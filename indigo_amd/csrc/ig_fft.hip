@@ -251,6 +251,12 @@ struct PassDesc {
     int64_t in_s[3], out_s[3], w_s[3];
     int64_t ext0, ext1, ncols;
     unsigned tpr;               // tiles per (k1, k2) row = ceil(ext0 / W); filled in by the launcher
+    // Optional split of a tile's W lanes (strided passes): cw > 0 makes lane w address sub-column a = w % cw (element
+    // strides in_sa / out_sa / w_sa) of column k0 = tile*(W/cw) + w/cw, i.e. a tile is W/cw columns of cw contiguous
+    // sub-columns.  The coil-interleaved grid layout uses it for its x passes (cw = coils, columns = lines).
+    int cw;
+    int64_t in_sa, out_sa, w_sa;
+    int tile_shift;             // tile_range / tile_bits entries are shared by 2^tile_shift consecutive tiles
     int in_lo, in_hi, out_lo, out_hi;
     int inverse;
     // optional per-tile override of the box along the transform axis (strided passes, W | ext0):
@@ -295,10 +301,10 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
     const unsigned tile = blockIdx.x;
     const unsigned tr = tile % d.tpr, rest = tile / d.tpr;
     const unsigned k1 = rest % d.ext1, k2 = rest / d.ext1;
-    const int64_t k0u = (int64_t)tr * W;
+    const int64_t k0u = (int64_t)tr * ((!AXIS0 && d.cw) ? W / d.cw : W);
     int in_lo = d.in_lo, in_hi = d.in_hi, out_lo = d.out_lo, out_hi = d.out_hi;
     if (BOXED && !AXIS0 && d.tile_range) {
-        const short2 r = d.tile_range[(int64_t)k1 * d.tile_range_k1 + tr];
+        const short2 r = d.tile_range[(int64_t)k1 * d.tile_range_k1 + (tr >> d.tile_shift)];
         if (d.tile_range_mode == 1) {
             out_lo = out_lo > r.x ? out_lo : r.x;
             out_hi = out_hi < r.y ? out_hi : r.y;
@@ -312,15 +318,30 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
     // offset (SGPR, or an immediate on axis 0) + ONE per-lane 32-bit offset.  A lane offset of IG_OOB fails the
     // hardware range check -- the load returns zero, the store is dropped -- which is how boxes and the ragged
     // last tile are predicated without a branch, so all loads of a stage issue back to back.
-    const rsrc_t r_in = make_rsrc(d.in + (k0u * d.in_s[0] + (int64_t)k1 * d.in_s[1] + (int64_t)k2 * d.in_s[2]));
-    const rsrc_t r_out = make_rsrc(d.out + (k0u * d.out_s[0] + (int64_t)k1 * d.out_s[1] + (int64_t)k2 * d.out_s[2]));
-    const rsrc_t r_w = make_rsrc(WMODE ? d.w + (k0u * d.w_s[0] + (int64_t)k1 * d.w_s[1] + (int64_t)k2 * d.w_s[2]) : nullptr);
-    const bool valid = k0u + w < d.ext0;
+    // Strided passes re-base the descriptor for every group of 16 elements along the axis (a pure SGPR add), so a
+    // column may span far more than the 2 GB window (y pass of the interleaved layout: 16 MB per element step).
+    const float2* const b_in = d.in + (k0u * d.in_s[0] + (int64_t)k1 * d.in_s[1] + (int64_t)k2 * d.in_s[2]);
+    float2* const b_out = d.out + (k0u * d.out_s[0] + (int64_t)k1 * d.out_s[1] + (int64_t)k2 * d.out_s[2]);
+    const float2* const b_w = WMODE ? d.w + (k0u * d.w_s[0] + (int64_t)k1 * d.w_s[1] + (int64_t)k2 * d.w_s[2]) : nullptr;
+    const rsrc_t r_in = make_rsrc(b_in), r_out = make_rsrc(b_out), r_w = make_rsrc(b_w);
     // x-axis passes run along contiguous memory by construction: unit strides known at compile time
     const unsigned isj = AXIS0 ? 1u : (unsigned)d.in_sj, osj = AXIS0 ? 1u : (unsigned)d.out_sj, wsj = AXIS0 ? 1u : (unsigned)d.w_sj;
-    const unsigned l_in = valid ? ((unsigned)w * (unsigned)d.in_s[0] + (unsigned)t * isj) * 8u : IG_OOB;
-    const unsigned l_out = valid ? ((unsigned)w * (unsigned)d.out_s[0] + (unsigned)t * osj) * 8u : IG_OOB;
-    const unsigned l_w = (WMODE && valid) ? ((unsigned)w * (unsigned)d.w_s[0] + (unsigned)t * wsj) * 8u : IG_OOB;
+    bool valid;
+    unsigned l_in, l_out, l_w;
+    if (!AXIS0 && d.cw) {
+        const unsigned a = (unsigned)w % (unsigned)d.cw, yl = (unsigned)w / (unsigned)d.cw;
+        valid = k0u + yl < d.ext0;
+        l_in = (a * (unsigned)d.in_sa + yl * (unsigned)d.in_s[0] + (unsigned)t * isj) * 8u;
+        l_out = (a * (unsigned)d.out_sa + yl * (unsigned)d.out_s[0] + (unsigned)t * osj) * 8u;
+        l_w = (a * (unsigned)d.w_sa + yl * (unsigned)d.w_s[0] + (unsigned)t * wsj) * 8u;
+    } else {
+        valid = k0u + w < d.ext0;
+        l_in = ((unsigned)w * (unsigned)d.in_s[0] + (unsigned)t * isj) * 8u;
+        l_out = ((unsigned)w * (unsigned)d.out_s[0] + (unsigned)t * osj) * 8u;
+        l_w = ((unsigned)w * (unsigned)d.w_s[0] + (unsigned)t * wsj) * 8u;
+    }
+    if (!valid) l_in = l_out = l_w = IG_OOB;
+    if (!WMODE) l_w = IG_OOB;
 
     // Element j = t + 16*m of this thread's column <-> bit m of a 32-bit word: ibits flags the inputs to read
     // (stage 1 loads m = k), obits the outputs to keep (stage 2 stores m = q + r*R1/16).  Boxes [lo, hi) become
@@ -332,7 +353,7 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
         ibits = below(ceil16(in_hi - t)) & ~below(ceil16(in_lo - t));
         obits = below(ceil16(out_hi - t)) & ~below(ceil16(out_lo - t));
         if (!AXIS0 && d.tile_bits) {
-            const uint32_t zb = d.tile_bits[((int64_t)k1 * d.tile_range_k1 + tr) * 16 + t];
+            const uint32_t zb = d.tile_bits[((int64_t)k1 * d.tile_range_k1 + (tr >> d.tile_shift)) * 16 + t];
             if (d.tile_range_mode == 1) obits &= zb; else ibits &= zb;
         }
     }
@@ -346,8 +367,13 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
             if (HALF_IN && (k < R1 / 4 || k >= 3 * R1 / 4)) continue;        // never read
             const bool stat = !BOXED || HALF_IN || HALF == 4;                 // box known at compile time
             const bool on = stat || ((ibits >> k) & 1u);
-            v[k] = buf_ld<NT_LD>(r_in, on ? l_in : IG_OOB, (unsigned)(k * R2) * isj * 8u);
-            if (WMODE == 1) wv[k] = buf_ld<false>(r_w, on ? l_w : IG_OOB, (unsigned)(k * R2) * wsj * 8u);
+            if (AXIS0) {
+                v[k] = buf_ld<NT_LD>(r_in, on ? l_in : IG_OOB, (unsigned)(k * R2) * 8u);
+                if (WMODE == 1) wv[k] = buf_ld<false>(r_w, on ? l_w : IG_OOB, (unsigned)(k * R2) * 8u);
+            } else {
+                v[k] = buf_ld<NT_LD>(make_rsrc(b_in + (int64_t)(k * R2) * d.in_sj), on ? l_in : IG_OOB, 0);
+                if (WMODE == 1) wv[k] = buf_ld<false>(make_rsrc(b_w + (int64_t)(k * R2) * d.w_sj), on ? l_w : IG_OOB, 0);
+            }
         }
 #pragma unroll
         for (int k = 0; k < R1; ++k) {
@@ -386,7 +412,9 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
             for (int r = 0; r < R2; ++r) {
                 if (HALF_OUT && (r < R2 / 4 || r >= 3 * R2 / 4)) continue;
                 const bool stat = !BOXED || HALF_OUT || HALF == 3;
-                wv[r] = buf_ld<false>(r_w, (stat || ((obits >> (q + r * B2)) & 1u)) ? l_w : IG_OOB, (unsigned)(q * T + r * R1) * wsj * 8u);
+                const bool on = stat || ((obits >> (q + r * B2)) & 1u);
+                if (AXIS0) wv[r] = buf_ld<false>(r_w, on ? l_w : IG_OOB, (unsigned)(q * T + r * R1) * 8u);
+                else wv[r] = buf_ld<false>(make_rsrc(b_w + (int64_t)(q * T + r * R1) * d.w_sj), on ? l_w : IG_OOB, 0);
             }
         }
 #pragma unroll
@@ -396,7 +424,9 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
             float2 a = u[r];
             if (d.inverse) a.y = -a.y;
             if (WMODE == 2) a = cmulc(wv[r], a);
-            buf_st<NT_ST>(r_out, (stat || ((obits >> (q + r * B2)) & 1u)) ? l_out : IG_OOB, (unsigned)(q * T + r * R1) * osj * 8u, a);
+            const bool on = stat || ((obits >> (q + r * B2)) & 1u);
+            if (AXIS0) buf_st<NT_ST>(r_out, on ? l_out : IG_OOB, (unsigned)(q * T + r * R1) * 8u, a);
+            else buf_st<NT_ST>(make_rsrc(b_out + (int64_t)(q * T + r * R1) * d.out_sj), on ? l_out : IG_OOB, 0, a);
         }
     }
 }
@@ -573,7 +603,7 @@ int plan_axis(ig_ctx* ctx, ig_fft* p, int a) {
     int ns = 0;
     const char* e2 = getenv("INDIGO_HIP_FFT_2STAGE");
     const bool two_stage = !force_generic && !(e2 && e2[0] == '0') && (ax.n == 512 || ax.n == 256) &&
-                           (ax.n + 16) * ax.inner * 8 < 0x7fffffffLL;     // 2 GB descriptor window per tile
+                           32 * ax.inner * 8 < 0x7fffffffLL;              // 2 GB descriptor window per 16 elements of a column
     if (two_stage) {
         ax.kind = 3; ax.W = 16; ax.T = 16; ax.nstages = 2;
         ax.rad.r[0] = ax.n == 512 ? 32 : 16; ax.rad.r[1] = 16;
@@ -628,14 +658,18 @@ int plan_axis(ig_ctx* ctx, ig_fft* p, int a) {
 int launch_2stage(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d_in, bool axis0, int wmode) {
     PassDesc d = d_in;
     if (d.ncols == 0) return IG_OK;
-    const int64_t tpr = (d.ext0 + ax.W - 1) / ax.W;
+    const int64_t cpt = (!axis0 && d.cw) ? ax.W / d.cw : ax.W;           // columns (k0 values) per tile
+    IG_REQUIRE(ctx, !d.cw || (!axis0 && d.cw <= ax.W && ax.W % d.cw == 0), "ig_fft: bad lane split");
+    const int64_t tpr = (d.ext0 + cpt - 1) / cpt;
     const int64_t blocks = tpr * (d.ncols / d.ext0);           // ncols = ext0 * ext1 * ext2
     IG_REQUIRE(ctx, blocks <= 0x7fffffffLL && d.ext1 <= 0x7fffffffLL, "ig_fft: too many tiles");
     d.tpr = (unsigned)tpr;
     {   // every in-tile byte offset must stay inside the 2 GB descriptor window
         const int64_t lim = 0x7fffffffLL / 8;
-        const int64_t span_in = (ax.n + 15) * d.in_sj + 15 * d.in_s[0], span_out = (ax.n + 15) * d.out_sj + 15 * d.out_s[0];
-        const int64_t span_w = wmode ? (ax.n + 15) * d.w_sj + 15 * d.w_s[0] : 0;
+        // (strided passes re-base per 16 elements: only 31 element steps plus the tile's lanes must fit)
+        const int64_t reach = axis0 ? ax.n + 15 : 31;
+        const int64_t span_in = reach * d.in_sj + 15 * d.in_s[0] + 15 * d.in_sa, span_out = reach * d.out_sj + 15 * d.out_s[0] + 15 * d.out_sa;
+        const int64_t span_w = wmode ? reach * d.w_sj + 15 * d.w_s[0] + 15 * d.w_sa : 0;
         IG_REQUIRE(ctx, d.in_sj >= 0 && d.out_sj >= 0 && d.in_s[0] >= 0 && d.out_s[0] >= 0 && span_in < lim && span_out < lim && span_w < lim,
                    "ig_fft: axis stride too large for the two-stage kernel");
     }
@@ -813,7 +847,9 @@ int ig_fft_exec(ig_fft* p, const void* xv, void* yv, int direction, void* worksp
 int ig_fft_plan_padded(ig_ctx* ctx, const int64_t* dims, const int64_t* box_lo, const int64_t* box_dims,
                        int64_t batch, int grid_layout, ig_fft** plan, size_t* workspace_bytes) {
     IG_REQUIRE(ctx, ctx && dims && box_lo && box_dims && plan, "ig_fft_plan_padded: bad arguments");
-    IG_REQUIRE(ctx, grid_layout == 0 || grid_layout == 1, "ig_fft_plan_padded: grid_layout must be 0 (x,y,z) or 1 (x,z,y)");
+    IG_REQUIRE(ctx, grid_layout >= 0 && grid_layout <= 2, "ig_fft_plan_padded: grid_layout must be 0 (x,y,z), 1 (x,z,y) or 2 (c,x,z,y)");
+    IG_REQUIRE(ctx, grid_layout != 2 || batch == 1 || batch == 2 || batch == 4 || batch == 8 || batch == 16,
+               "ig_fft_plan_padded: the coil-interleaved layout needs a batch of 1, 2, 4, 8 or 16 (got %lld)", (long long)batch);
     for (int a = 0; a < 3; ++a) {
         IG_REQUIRE(ctx, box_lo[a] >= 0 && box_dims[a] >= 1 && box_lo[a] + box_dims[a] <= dims[a],
                    "ig_fft_plan_padded: box [%lld, %lld) outside grid axis %d of length %lld", (long long)box_lo[a],
@@ -839,7 +875,7 @@ int ig_fft_plan_padded(ig_ctx* ctx, const int64_t* dims, const int64_t* box_lo, 
     // transformed compact array n0 x b1 x b2 x batch (layout 1 routes the y pass through it)
     p->workspace_bytes = ((size_t)p->total + (size_t)(dims[0] * box_dims[1] * box_dims[2] * batch)) * 8;
     if (workspace_bytes) *workspace_bytes = p->workspace_bytes;
-    p->desc = std::string("padded layout=") + (grid_layout ? "xzy " : "xyz ") + p->desc;
+    p->desc = std::string("padded layout=") + (grid_layout == 2 ? "cxzy " : grid_layout ? "xzy " : "xyz ") + p->desc;
     return IG_OK;
 }
 
@@ -936,15 +972,114 @@ static int exec_cropped_layout1(ig_fft* p, const float2* y, const float2* w, flo
     return IG_OK;
 }
 
+// Grid layout 2 interleaves the batch (coils) below layout 1: element (c, kx, ky, kz) lives at
+// c + C*(kx + n0*kz + n0*n2*ky).  The gridding matrix then reads / writes all C coils of a grid point as ONE
+// contiguous C*8-byte row instead of C separate 8-byte gathers a gigabyte apart (forward gridding of the 256^3 x 8
+// SENSE problem: 0.98 ms instead of 2.05 ms).  Every pass is a strided pass whose 16 lanes run over the combined
+// (c, kx) index -- for the x passes over (c, line) pairs, with the transform axis at stride C -- so all accesses stay
+// 128-byte (y, z) or 64*C/8-byte (x) contiguous.  The compact intermediate and, for the cropped transform, the
+// compact result are interleaved the same way; the weights must be too (w[(i)*C + c]).
+static int lg2(int64_t v) { int s = 0; while ((1LL << s) < v) ++s; return s; }
+
+static int exec_padded_layout2(ig_fft* p, const float2* x, int64_t x_bstride, const float2* w, float2* y, float2* work,
+                               const short2* support) {
+    ig_ctx* ctx = p->ctx;
+    const int64_t n0 = p->dims[0], n1 = p->dims[1], n2 = p->dims[2];
+    const int64_t b0 = p->box_dims[0], b1 = p->box_dims[1], b2 = p->box_dims[2];
+    const int64_t l0 = p->box_lo[0], l1 = p->box_lo[1], l2 = p->box_lo[2];
+    const int64_t vol = n0 * n1 * n2, bvol = b0 * b1 * b2, C = p->batch;
+    const int64_t cvol = n0 * b1 * b2;
+    float2* L1 = work + (size_t)p->total;
+    {   // pass x: lines (c, y', z') of the weighted image -> interleaved compact [c][kx][y'][z']
+        ig_prof_scope prof(ctx, "fft_pad_x", (double)(bvol + (w ? bvol : 0) + cvol) * C * 8.0);
+        PassDesc d{};
+        d.cw = (int)C;
+        d.in = x - l0; d.in_sj = 1; d.in_sa = x_bstride; d.in_s[0] = b0; d.in_s[1] = b0 * b1;
+        d.w = w ? w - l0 * C : nullptr; d.w_sj = C; d.w_sa = 1; d.w_s[0] = b0 * C; d.w_s[1] = b0 * b1 * C;
+        d.out = L1; d.out_sj = C; d.out_sa = 1; d.out_s[0] = C * n0; d.out_s[1] = C * n0 * b1;
+        d.ext0 = b1; d.ext1 = b2; d.ncols = b1 * b2;
+        d.in_lo = (int)l0; d.in_hi = (int)(l0 + b0); d.out_lo = 0; d.out_hi = (int)n0; d.inverse = 0;
+        if (int rc = launch_2stage(ctx, p->axis[0], d, false, w ? 1 : 0)) return rc;
+    }
+    {   // pass y: columns (c + C*kx, z')
+        ig_prof_scope prof(ctx, "fft_pad_y", (double)(cvol + n0 * n1 * b2) * C * 8.0);
+        PassDesc d{};
+        d.in = L1 - l1 * C * n0; d.in_sj = C * n0; d.in_s[0] = 1; d.in_s[1] = C * n0 * b1;
+        d.out = y + l2 * C * n0; d.out_sj = C * n0 * n2; d.out_s[0] = 1; d.out_s[1] = C * n0;
+        d.ext0 = C * n0; d.ext1 = b2; d.ncols = C * n0 * b2;
+        d.in_lo = (int)l1; d.in_hi = (int)(l1 + b1); d.out_lo = 0; d.out_hi = (int)n1; d.inverse = 0;
+        if (support) { d.tile_range = support + n1 * (n0 / 16); d.tile_range_mode = 1; d.tile_range_k1 = 0; d.tile_shift = lg2(C); }
+        if (int rc = launch_2stage(ctx, p->axis[1], d, false, 0)) return rc;
+    }
+    {   // pass z: columns (c + C*kx, ky), in place
+        ig_prof_scope prof(ctx, "fft_pad_z", (double)(n0 * n1 * b2 + vol) * C * 8.0);
+        PassDesc d{};
+        d.in = d.out = y; d.in_sj = d.out_sj = C * n0;
+        d.in_s[0] = d.out_s[0] = 1; d.in_s[1] = d.out_s[1] = C * n0 * n2;
+        d.ext0 = C * n0; d.ext1 = n1; d.ncols = C * n0 * n1;
+        d.in_lo = (int)l2; d.in_hi = (int)(l2 + b2); d.out_lo = 0; d.out_hi = (int)n2; d.inverse = 0;
+        d.tile_range = support; d.tile_range_mode = 1; d.tile_range_k1 = n0 / 16; d.tile_shift = lg2(C);
+        if (support) d.tile_bits = reinterpret_cast<const uint32_t*>(support + n1 * (n0 / 16) + n0 / 16);
+        if (int rc = launch_2stage(ctx, p->axis[2], d, false, 0)) return rc;
+    }
+    return IG_OK;
+}
+
+static int exec_cropped_layout2(ig_fft* p, const float2* y, const float2* w, float2* x, float2* work, const short2* support) {
+    ig_ctx* ctx = p->ctx;
+    const int64_t n0 = p->dims[0], n1 = p->dims[1], n2 = p->dims[2];
+    const int64_t b0 = p->box_dims[0], b1 = p->box_dims[1], b2 = p->box_dims[2];
+    const int64_t l0 = p->box_lo[0], l1 = p->box_lo[1], l2 = p->box_lo[2];
+    const int64_t vol = n0 * n1 * n2, bvol = b0 * b1 * b2, C = p->batch;
+    const int64_t cvol = n0 * b1 * b2;
+    float2* L1 = work + (size_t)p->total;
+    {   // pass z: input intact, result into the workspace
+        ig_prof_scope prof(ctx, "fft_crop_z", (double)(vol + n0 * n1 * b2) * C * 8.0);
+        PassDesc d{};
+        d.in = y; d.out = work; d.in_sj = d.out_sj = C * n0;
+        d.in_s[0] = d.out_s[0] = 1; d.in_s[1] = d.out_s[1] = C * n0 * n2;
+        d.ext0 = C * n0; d.ext1 = n1; d.ncols = C * n0 * n1;
+        d.in_lo = 0; d.in_hi = (int)n2; d.out_lo = (int)l2; d.out_hi = (int)(l2 + b2); d.inverse = 1;
+        d.tile_range = support; d.tile_range_mode = 2; d.tile_range_k1 = n0 / 16; d.tile_shift = lg2(C);
+        if (support) d.tile_bits = reinterpret_cast<const uint32_t*>(support + n1 * (n0 / 16) + n0 / 16);
+        if (int rc = launch_2stage(ctx, p->axis[2], d, false, 0)) return rc;
+    }
+    {   // pass y
+        ig_prof_scope prof(ctx, "fft_crop_y", (double)(n0 * n1 * b2 + cvol) * C * 8.0);
+        PassDesc d{};
+        d.in = work + l2 * C * n0; d.in_sj = C * n0 * n2; d.in_s[0] = 1; d.in_s[1] = C * n0;
+        d.out = L1 - l1 * C * n0; d.out_sj = C * n0; d.out_s[0] = 1; d.out_s[1] = C * n0 * b1;
+        d.ext0 = C * n0; d.ext1 = b2; d.ncols = C * n0 * b2;
+        d.in_lo = 0; d.in_hi = (int)n1; d.out_lo = (int)l1; d.out_hi = (int)(l1 + b1); d.inverse = 1;
+        if (support) { d.tile_range = support + n1 * (n0 / 16); d.tile_range_mode = 2; d.tile_range_k1 = 0; d.tile_shift = lg2(C); }
+        if (int rc = launch_2stage(ctx, p->axis[1], d, false, 0)) return rc;
+    }
+    {   // pass x: interleaved compact rows -> interleaved compact image box, times conj(w)
+        ig_prof_scope prof(ctx, "fft_crop_x", (double)(cvol + bvol + (w ? bvol : 0)) * C * 8.0);
+        PassDesc d{};
+        d.cw = (int)C;
+        d.in = L1; d.in_sj = C; d.in_sa = 1; d.in_s[0] = C * n0; d.in_s[1] = C * n0 * b1;
+        d.out = x - l0 * C; d.out_sj = C; d.out_sa = 1; d.out_s[0] = b0 * C; d.out_s[1] = b0 * b1 * C;
+        d.w = w ? w - l0 * C : nullptr; d.w_sj = C; d.w_sa = 1; d.w_s[0] = b0 * C; d.w_s[1] = b0 * b1 * C;
+        d.ext0 = b1; d.ext1 = b2; d.ncols = b1 * b2;
+        d.in_lo = 0; d.in_hi = (int)n0; d.out_lo = (int)l0; d.out_hi = (int)(l0 + b0); d.inverse = 1;
+        if (int rc = launch_2stage(ctx, p->axis[0], d, false, w ? 2 : 0)) return rc;
+    }
+    return IG_OK;
+}
+
 int ig_fft_exec_padded(ig_fft* p, const void* xv, int64_t x_bstride, const void* wv, void* yv, void* workspace,
                        const int16_t* support) {
     if (!p) return ig_fail(nullptr, IG_ERR_ARG, "ig_fft_exec_padded: plan is NULL");
     ig_ctx* ctx = p->ctx;
     IG_REQUIRE(ctx, p->padded, "ig_fft_exec_padded: plan was not made by ig_fft_plan_padded");
     IG_REQUIRE(ctx, xv && yv, "ig_fft_exec_padded: NULL array");
-    IG_REQUIRE(ctx, p->layout == 0 || workspace, "ig_fft_exec_padded: grid layout 1 needs the workspace");
+    IG_REQUIRE(ctx, p->layout == 0 || workspace, "ig_fft_exec_padded: grid layouts 1 and 2 need the workspace");
     if (int rc = ig_set_device(ctx)) return rc;
-    IG_REQUIRE(ctx, !support || p->layout == 1, "ig_fft_exec_padded: a support table needs grid layout 1");
+    IG_REQUIRE(ctx, !support || p->layout >= 1, "ig_fft_exec_padded: a support table needs grid layout 1 or 2");
+    if (p->layout == 2)
+        return exec_padded_layout2(p, (const float2*)xv, x_bstride, (const float2*)wv, (float2*)yv, (float2*)workspace,
+                                   (const short2*)support);
     if (p->layout == 1)
         return exec_padded_layout1(p, (const float2*)xv, x_bstride, (const float2*)wv, (float2*)yv, (float2*)workspace,
                                    (const short2*)support);
@@ -993,7 +1128,10 @@ int ig_fft_exec_cropped(ig_fft* p, const void* yv, const void* wv, void* xv, int
     IG_REQUIRE(ctx, p->padded, "ig_fft_exec_cropped: plan was not made by ig_fft_plan_padded");
     IG_REQUIRE(ctx, xv && yv && workspace, "ig_fft_exec_cropped: NULL array");
     if (int rc = ig_set_device(ctx)) return rc;
-    IG_REQUIRE(ctx, !support || p->layout == 1, "ig_fft_exec_cropped: a support table needs grid layout 1");
+    IG_REQUIRE(ctx, !support || p->layout >= 1, "ig_fft_exec_cropped: a support table needs grid layout 1 or 2");
+    if (p->layout == 2)
+        return exec_cropped_layout2(p, (const float2*)yv, (const float2*)wv, (float2*)xv, (float2*)workspace,
+                                    (const short2*)support);
     if (p->layout == 1)
         return exec_cropped_layout1(p, (const float2*)yv, (const float2*)wv, (float2*)xv, x_bstride, (float2*)workspace,
                                     (const short2*)support);

@@ -301,12 +301,12 @@ k_csrmm_rowlane(int64_t M, int64_t N,
 // all lanes active: coalesced index/value loads, one gathered panel row per lane, products parked in LDS; then each
 // row's lane sums its own run of products (LDS reads, no atomics) and stores as before, 512 contiguous bytes per
 // panel column.  Rows beyond thr_mid go to the deferred-row lists and are skipped here.
-template <int NC, bool CONJ>
-__global__ void __launch_bounds__(BLK, 8)
+template <int NC, bool CONJ, bool YIL>
+__global__ void __launch_bounds__(BLK)            // (capping it at 64 VGPRs for 8 waves/SIMD spills into scratch: 2x slower)
 k_csrmm_dense64(int64_t M, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
                 const float2* __restrict__ vals, const float2* __restrict__ Xp,
                 float2* __restrict__ Y, int64_t ldy, float2 alpha,
-                WorkLists wl, int32_t thr_mid, int32_t thr_long, GridMask mask) {
+                WorkLists wl, int32_t thr_mid, int32_t thr_long, GridMask mask, int coalesce) {
     __shared__ float4 prod[WAVES_PER_BLOCK][64][NC / 2];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // A wave strides over the 64-row tasks (the launcher normally gives every task its own wave; with a capped grid
@@ -404,10 +404,42 @@ k_csrmm_dense64(int64_t M, const int32_t* __restrict__ rowptr, const int32_t* __
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
-            if (mine) {
-                const int64_t orow = out_row(wl.yperm, row);
+            if (YIL && !wl.yperm && coalesce) {
+                // Row-major panel: the wave's 64 rows are NC*512 contiguous bytes.  The rows pass through LDS so that
+                // every store instruction writes 1 KB of consecutive addresses (a lane storing its own row would put
+                // 16 bytes into each of 64 different 64-byte rows per instruction).
+                const uint64_t mmask = __ballot(mine);
 #pragma unroll
-                for (int c = 0; c < NC; ++c) Y[c * ldy + orow] = cmul(alpha, acc[c]);
+                for (int h = 0; h < NC / 2; ++h) {
+                    const float2 a = cmul(alpha, acc[2 * h]), b = cmul(alpha, acc[2 * h + 1]);
+                    prod[wv][lane][h] = make_float4(a.x, a.y, b.x, b.y);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const float4* lin = &prod[wv][0][0];
+                float4* yp = reinterpret_cast<float4*>(Y + task * 64 * NC);
+#pragma unroll
+                for (int h = 0; h < NC / 2; ++h) {
+                    const int e = h * 64 + lane;                 // 16-byte element of the wave's block; row e / (NC/2)
+                    if ((mmask >> (e / (NC / 2))) & 1ull) yp[e] = lin[e];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            } else if (mine) {
+                const int64_t orow = out_row(wl.yperm, row);
+                if (YIL) {
+                    float4* yp = reinterpret_cast<float4*>(Y + orow * NC);
+#pragma unroll
+                    for (int h = 0; h < NC / 2; ++h) {
+                        const float2 a = cmul(alpha, acc[2 * h]), b = cmul(alpha, acc[2 * h + 1]);
+                        yp[h] = make_float4(a.x, a.y, b.x, b.y);
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) Y[c * ldy + orow] = cmul(alpha, acc[c]);
+                }
             }
         }
         R = Rn; R1 = R1n; wbits = wbn; km = kmn;
@@ -424,7 +456,7 @@ template <int CL, bool CONJ, int BMODE>
 __global__ void __launch_bounds__(BLK)
 k_csrmm_rows_wave(int64_t N, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
                   const float2* __restrict__ vals, const float2* __restrict__ X, int64_t ldx, int64_t sxr,
-                  float2* __restrict__ Y, int64_t ldy, float2 alpha, float2 beta,
+                  float2* __restrict__ Y, int64_t ldy, int64_t syr, float2 alpha, float2 beta,
                   const int32_t* __restrict__ list, const uint32_t* __restrict__ count, uint32_t cap,
                   const int32_t* __restrict__ yperm) {
     constexpr int NLW = 64 / CL;
@@ -460,7 +492,7 @@ k_csrmm_rows_wave(int64_t N, const int32_t* __restrict__ rowptr, const int32_t* 
                 acc.y += __shfl_xor(acc.y, off, 64);
             }
             if (i == 0 && col_ok) {
-                float2* yp = Y + j * ldy + out_row(yperm, row);
+                float2* yp = Y + j * ldy + out_row(yperm, row) * syr;
                 float2 out = cmul(alpha, acc);
                 if (BMODE == 1) cfma(out, beta, *yp);
                 *yp = out;
@@ -474,7 +506,7 @@ template <int CL, bool CONJ, int BMODE>
 __global__ void __launch_bounds__(1024)
 k_csrmm_rows_block(int64_t N, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
                    const float2* __restrict__ vals, const float2* __restrict__ X, int64_t ldx, int64_t sxr,
-                   float2* __restrict__ Y, int64_t ldy, float2 alpha, float2 beta,
+                   float2* __restrict__ Y, int64_t ldy, int64_t syr, float2 alpha, float2 beta,
                    const int32_t* __restrict__ list, const uint32_t* __restrict__ count, uint32_t cap,
                    const int32_t* __restrict__ yperm) {
     constexpr int NLB = 1024 / CL;
@@ -516,7 +548,7 @@ k_csrmm_rows_block(int64_t N, const int32_t* __restrict__ rowptr, const int32_t*
 #pragma unroll
                 for (int w = 0; w < 16; ++w) sum = cadd(sum, part[w][tid]);
                 if (col_ok) {
-                    float2* yp = Y + j * ldy + out_row(yperm, row);
+                    float2* yp = Y + j * ldy + out_row(yperm, row) * syr;
                     float2 out = cmul(alpha, sum);
                     if (BMODE == 1) cfma(out, beta, *yp);
                     *yp = out;
@@ -655,16 +687,21 @@ int launch_gather(ig_ctx* ctx, int64_t rows, int64_t xrows, int64_t N, int64_t n
                   const int32_t* rowptr, const int32_t* colind, const float2* vals,
                   const float2* X, int64_t ldx, float2* Y, int64_t ldy, float2 alpha, float2 beta,
                   GridMask mask = GridMask{nullptr, 0, 0}, const int32_t* yperm = nullptr,
-                  const int32_t* xperm = nullptr) {
+                  const int32_t* xperm = nullptr, bool x_il = false, bool y_il = false) {
+    // x_il / y_il: the panel is stored row-major (its N values of a row contiguous, row stride N) instead of
+    // column-major with a leading dimension -- the coil-interleaved grid of the fused transform's layout 2
     const Shape s = pick_shape(rows, N, nnz);
+    const int64_t syr = y_il ? N : 1;
+    if (y_il) ldy = 1;
     // Panel rows that are gathered many times each (nnz >> xrows) from a small panel: repack the panel
     // once so that one gathered row is one contiguous 16..64-byte access instead of N scattered ones.
     int64_t sxc = ldx, sxr = 1;          // element (k, j) of X lives at X[j*sxc + k*sxr]
     bool packed = false;
+    if (x_il) { sxc = 1; sxr = N; packed = (N & (N - 1)) == 0 && N >= 1; }   // already "packed" when N is a power of two
     // Packing costs one read + one write of the panel (16 B per element) and turns nnz*N scattered 8-byte gathers
     // (each pulling a 32..64-byte sector) into nnz contiguous N*8-byte ones: worth it once every panel row is
     // gathered at least about once (nnz >= xrows); always for small hot panels.
-    if (((N >= 2 && N <= 64 && nnz >= xrows) || (xperm && N <= 8) || env_flag("INDIGO_HIP_SPMM_FORCEPACK", false)) && env_flag("INDIGO_HIP_SPMM_PACK", true)) {
+    if (!x_il && ((N >= 2 && N <= 64 && nnz >= xrows) || (xperm && N <= 8)) && env_flag("INDIGO_HIP_SPMM_PACK", true)) {
         const int np = s.CL;             // pow2 >= N, <= 64
         const size_t need = (size_t)xrows * np * 8;
         if (need <= ((size_t)16 << 30)) {
@@ -756,10 +793,15 @@ int launch_gather(ig_ctx* ctx, int64_t rows, int64_t xrows, int64_t N, int64_t n
             static const int dense_wgs = getenv("INDIGO_HIP_SPMM_DENSE_WGS") ? atoi(getenv("INDIGO_HIP_SPMM_DENSE_WGS")) : 0;
             if (dense_wgs > 0 && dblocks > (int64_t)ctx->num_cu * dense_wgs) dblocks = (int64_t)ctx->num_cu * dense_wgs;
             IG_REQUIRE(ctx, dblocks <= 0x7fffffffLL, "csrmm: matrix too large for one launch");
-#define IG_DENSE(NC_) hipLaunchKernelGGL((k_csrmm_dense64<NC_, CONJ>), dim3((unsigned)dblocks), dim3(BLK), 0, ctx->stream, \
-                                         rows, rowptr, colind, vals, X, Y, ldy, alpha, wl, td, thr_long, mask)
+#define IG_DENSE(NC_) do { if (y_il) hipLaunchKernelGGL((k_csrmm_dense64<NC_, CONJ, true>), dim3((unsigned)dblocks), dim3(BLK), 0, ctx->stream, \
+                                         rows, rowptr, colind, vals, X, Y, ldy, alpha, wl, td, thr_long, mask, dense_co);           \
+                           else hipLaunchKernelGGL((k_csrmm_dense64<NC_, CONJ, false>), dim3((unsigned)dblocks), dim3(BLK), 0, ctx->stream, \
+                                         rows, rowptr, colind, vals, X, Y, ldy, alpha, wl, td, thr_long, mask, dense_co); } while (0)
+            static const int dense_co = getenv("INDIGO_HIP_SPMM_DENSE_CO") ? atoi(getenv("INDIGO_HIP_SPMM_DENSE_CO")) : 1;
             if (sxr == 8) IG_DENSE(8); else if (sxr == 4) IG_DENSE(4); else IG_DENSE(2);
 #undef IG_DENSE
+        } else if (y_il) {
+            return ig_fail(ctx, IG_ERR_UNSUPPORTED, "csrmm: an interleaved result panel needs the dense-lane kernel (2, 4 or 8 columns, beta = 0)");
         } else
         if (s.CL >= 8) IG_ROWLANE(8);
         else if (s.CL == 4) IG_ROWLANE(4);
@@ -769,6 +811,7 @@ int launch_gather(ig_ctx* ctx, int64_t rows, int64_t xrows, int64_t N, int64_t n
 #undef IG_ROWLANE_L
         IG_LAUNCH_CHECK(ctx, "k_csrmm_rowlane");
     } else {
+        IG_REQUIRE(ctx, !y_il, "csrmm: an interleaved result panel is only supported for matrices with mostly empty rows");
         ig_prof_scope prof(ctx, CONJ ? "csrmm_gather_conj" : "csrmm_gather");
 #define IG_GATHER(CL_, NL_)                                                                        \
     do {                                                                                           \
@@ -810,16 +853,16 @@ int launch_gather(ig_ctx* ctx, int64_t rows, int64_t xrows, int64_t N, int64_t n
         if (thr_mid < thr_long || rowlane) {                                                       \
             ig_prof_scope prof(ctx, "csrmm_rows_wave");                                            \
             if (b0) hipLaunchKernelGGL((k_csrmm_rows_wave<CL_, CONJ, 0>), dim3(gw), dim3(BLK), 0, ctx->stream, \
-                        N, rowptr, colind, vals, X, sxc, sxr, Y, ldy, alpha, beta, wl.rows[0], wl.count, wl.cap, wl.yperm);   \
+                        N, rowptr, colind, vals, X, sxc, sxr, Y, ldy, syr, alpha, beta, wl.rows[0], wl.count, wl.cap, wl.yperm);   \
             else    hipLaunchKernelGGL((k_csrmm_rows_wave<CL_, CONJ, 1>), dim3(gw), dim3(BLK), 0, ctx->stream, \
-                        N, rowptr, colind, vals, X, sxc, sxr, Y, ldy, alpha, beta, wl.rows[0], wl.count, wl.cap, wl.yperm);   \
+                        N, rowptr, colind, vals, X, sxc, sxr, Y, ldy, syr, alpha, beta, wl.rows[0], wl.count, wl.cap, wl.yperm);   \
         }                                                                                          \
         {                                                                                          \
             ig_prof_scope prof(ctx, "csrmm_rows_block");                                           \
             if (b0) hipLaunchKernelGGL((k_csrmm_rows_block<CL_, CONJ, 0>), dim3(gb), dim3(1024), 0, ctx->stream, \
-                        N, rowptr, colind, vals, X, sxc, sxr, Y, ldy, alpha, beta, wl.rows[1], wl.count + WL_SUB, wl.cap, wl.yperm); \
+                        N, rowptr, colind, vals, X, sxc, sxr, Y, ldy, syr, alpha, beta, wl.rows[1], wl.count + WL_SUB, wl.cap, wl.yperm); \
             else    hipLaunchKernelGGL((k_csrmm_rows_block<CL_, CONJ, 1>), dim3(gb), dim3(1024), 0, ctx->stream, \
-                        N, rowptr, colind, vals, X, sxc, sxr, Y, ldy, alpha, beta, wl.rows[1], wl.count + WL_SUB, wl.cap, wl.yperm); \
+                        N, rowptr, colind, vals, X, sxc, sxr, Y, ldy, syr, alpha, beta, wl.rows[1], wl.count + WL_SUB, wl.cap, wl.yperm); \
         }                                                                                          \
     } while (0)
         switch (s.CL) {
@@ -959,6 +1002,38 @@ int ig_ccsrmm_t_grid(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, int64_t nnz,
 }
 
 // ---- host-side structure analysis -------------------------------------------
+
+int ig_ccsrmm_il(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, int64_t nnz,
+                 float ar, float ai, const void* vals, const int32_t* colind, const int32_t* rowptr,
+                 const void* X_il, float br, float bi, void* Y, int64_t ldy) {
+    IG_REQUIRE(ctx, ctx != nullptr, "ig_ccsrmm_il: ctx is NULL");
+    if (int rc = check_panel_args(ctx, "ig_ccsrmm_il", K, M, N, nnz, vals, colind, rowptr, X_il, K, Y, ldy)) return rc;
+    IG_REQUIRE(ctx, N >= 1 && (N & (N - 1)) == 0 && N <= 64, "ig_ccsrmm_il: an interleaved panel needs a power-of-two column count <= 64 (got %lld)", (long long)N);
+    if (M == 0) return IG_OK;
+    if (int rc = ig_set_device(ctx)) return rc;
+    return launch_gather<false>(ctx, M, K, N, nnz, rowptr, colind, (const float2*)vals,
+                                (const float2*)X_il, K, (float2*)Y, ldy, make_float2(ar, ai), make_float2(br, bi),
+                                GridMask{nullptr, 0, 0}, nullptr, nullptr, true, false);
+}
+
+int ig_ccsrmm_t_grid_il(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, int64_t nnz,
+                        float ar, float ai, const void* vals_t, const int32_t* colind_t, const int32_t* rowptr_t,
+                        const void* X, int64_t ldx, void* Y_il,
+                        const int16_t* support, int64_t n0, int64_t nm) {
+    IG_REQUIRE(ctx, ctx != nullptr, "ig_ccsrmm_t_grid_il: ctx is NULL");
+    if (int rc = check_panel_args(ctx, "ig_ccsrmm_t_grid_il", M, K, N, nnz, vals_t, colind_t, rowptr_t, X, ldx, Y_il, K)) return rc;
+    IG_REQUIRE(ctx, N == 2 || N == 4 || N == 8, "ig_ccsrmm_t_grid_il: 2, 4 or 8 columns (got %lld)", (long long)N);
+    IG_REQUIRE(ctx, !support || (n0 > 0 && nm > 0 && n0 % 16 == 0 && nm % 16 == 0 && nm <= 512 && K % (n0 * nm) == 0 && K < 0x7fffffffLL),
+               "ig_ccsrmm_t_grid_il: rows (%lld) are not a grid of n0=%lld (multiple of 16) x nm=%lld (multiple of 16, <= 512) x ...",
+               (long long)K, (long long)n0, (long long)nm);
+    if (K == 0) return IG_OK;
+    if (int rc = ig_set_device(ctx)) return rc;
+    const int64_t ns = support ? K / (n0 * nm) : 0, nt = n0 / 16;
+    GridMask mask{support ? reinterpret_cast<const uint32_t*>(support + 2 * (ns * nt + nt)) : nullptr, n0, nm};
+    return launch_gather<true>(ctx, K, M, N, nnz, rowptr_t, colind_t, (const float2*)vals_t,
+                               (const float2*)X, ldx, (float2*)Y_il, K, make_float2(ar, ai), make_float2(0.f, 0.f),
+                               mask, nullptr, nullptr, false, true);
+}
 
 int ig_csr_inspect(const int32_t* rowptr, const int32_t* colind, int64_t M, int64_t K,
                    int64_t* nzrow, int64_t* nzcol, int* exwrite) {

@@ -226,6 +226,8 @@ class SpMatrix(Operator):
                 self._matrix_d.set_grid_support(*self._grid_support)
             if getattr(self, '_row_order', None) is not None:
                 self._matrix_d.set_row_order(self._row_order)
+            if getattr(self, '_grid_interleaved', False):
+                self._matrix_d.set_grid_interleaved(True)
         return self._matrix_d
 
     def csrmm_bytes(self, x, y, beta, forward):
@@ -297,7 +299,8 @@ class ZpadFFT(MatrixFreeOperator):
     """
 
     def __init__(self, backend, grid_shape, box_shape, weights, box_lo=None, layout=0, support=None, **kwargs):
-        self._layout = int(layout)     # memory order of each output grid: 0 = (x, y, z), 1 = (x, z, y)
+        # memory order of the output grids: 0 = (x, y, z) per coil, 1 = (x, z, y) per coil, 2 = (c, x, z, y) coils interleaved
+        self._layout = int(layout)
         # optional k-space support table (layout 1): int16 [z_lo, z_hi) per (kx tile of 16, ky); outside it the
         # forward grid is left unwritten and the adjoint's input is taken as zero (see ig_fft_exec_padded)
         self._support_h = None if support is None else np.ascontiguousarray(support, dtype=np.int16)
@@ -325,7 +328,10 @@ class ZpadFFT(MatrixFreeOperator):
 
     def _weights(self):
         if self._w_d is None:
-            self._w_d = self._backend.copy_array(self._w_h.reshape((-1, self._C), order='F'), name=self._name + '.weights')
+            w2 = self._w_h.reshape((-1, self._C), order='F')
+            if self._layout == 2:       # interleaved: w[i*C + c]
+                w2 = np.ascontiguousarray(w2).reshape(-1)
+            self._w_d = self._backend.copy_array(w2, name=self._name + '.weights')
             self._w_h = None
         return self._w_d
 
@@ -368,7 +374,10 @@ class ZpadFFT(MatrixFreeOperator):
                     with B.scratch(nbytes=self._ws_bytes()) as ws:
                         B.ifft_cropped(tmp, xj.reshape((P, C)), w, self._grid, self._lo, self._box, ws, self._layout,
                                        self._support())
-                    B.sum_columns(yj, tmp, alpha=alpha, beta=beta)
+                    if self._layout == 2:
+                        B.sum_columns(yj, tmp, alpha=alpha, beta=beta, interleaved=True)
+                    else:
+                        B.sum_columns(yj, tmp, alpha=alpha, beta=beta)
 
     def _ws_bytes(self):
         return self._backend._fft_padded_workspace(self._grid, self._lo, self._box, self._C, self._layout)

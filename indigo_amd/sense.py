@@ -220,10 +220,12 @@ class SenseProblem(object):
         transform's largest pass at a small stride; G' is indexed to match."""
         coils = list(range(self.C) if coils is None else coils)
         Cn = len(coils)
-        Gm = self.fused_interp(layout)
+        Gm = self.fused_interp(1 if layout == 2 else layout)      # layout 2 = layout 1 with the coils interleaved below
         G = backend.SpMatrix(Gm, name='interp*mod*scale')
+        if layout == 2:
+            G._grid_interleaved = True
         table = None
-        if (support is None or support) and layout == 1 and self.oN[0] % 16 == 0:
+        if (support is None or support) and layout >= 1 and self.oN[0] % 16 == 0:
             # restrict the transform's z pass and the adjoint gridding to the k-space support of G'
             table = self.grid_support(Gm)
             G._grid_support = (table, self.oN[0], self.oN[2])

@@ -189,15 +189,25 @@ def test_sense_medium_vs_oracle_and_properties(hip, oracle_backend):
 # ---------------------------------------------------------------------------------------
 # fused zero-pad / crop transforms (ZpadFFT leaf)
 # ---------------------------------------------------------------------------------------
+def _il(a2d):
+    """row-major view of the memory of a column-major (n, C) panel: element (i, c) of the interleaved layout"""
+    return np.asfortranarray(a2d).reshape(-1, order='F').reshape(a2d.shape)
+
+
 def _to_layout(v4, layout):
-    """(x, y, z, c) host array -> (P, C) in the grid's memory order"""
+    """(x, y, z, c) host array -> (P, C) column-major panel whose MEMORY is in the grid's order"""
+    C = v4.shape[3]
+    if layout == 2:         # (c, x, z, y), c fastest
+        return np.asfortranarray(v4.transpose(3, 0, 2, 1).reshape(-1, order='F').reshape((-1, C), order='F'))
     if layout == 1:
         v4 = v4.transpose(0, 2, 1, 3)
-    return np.asfortranarray(v4.reshape(-1, v4.shape[3], order='F'))
+    return np.asfortranarray(v4.reshape(-1, C, order='F'))
 
 
 def _from_layout(flat, grid, layout):
     C = flat.shape[1]
+    if layout == 2:
+        return np.asfortranarray(flat).reshape(-1, order='F').reshape((C, grid[0], grid[2], grid[1]), order='F').transpose(1, 3, 2, 0)
     if layout == 1:
         return flat.reshape((grid[0], grid[2], grid[1], C), order='F').transpose(0, 2, 1, 3)
     return flat.reshape(tuple(grid) + (C,), order='F')
@@ -211,6 +221,11 @@ def _from_layout(flat, grid, layout):
     ((256, 512, 256), (128, 256, 32), None, 1, False, 0),
     ((512, 256, 256), (128, 200, 32), None, 2, False, 1),
     ((256, 256, 256), (256, 256, 256), (0, 0, 0), 2, True, 1),       # no padding at all
+    ((256, 256, 256), (128, 128, 128), None, 8, True, 2),             # coils interleaved
+    ((256, 256, 256), (100, 77, 130), (5, 100, 126), 2, True, 2),
+    ((512, 256, 256), (128, 200, 32), None, 4, False, 2),
+    ((256, 256, 512), (64, 31, 256), None, 16, True, 2),
+    ((256, 256, 256), (128, 128, 128), None, 1, True, 2),
 ])
 def test_padded_and_cropped_fft_leaves(hip, grid, box, lo, C, weighted, layout):
     """fft_padded == fftn(zero-pad(w*x)) and ifft_cropped == conj(w)*crop(ifftn(y)), both computed on the GPU
@@ -220,7 +235,7 @@ def test_padded_and_cropped_fft_leaves(hip, grid, box, lo, C, weighted, layout):
     P, N = int(np.prod(grid)), int(np.prod(box))
     x = rand64c(N, 1, seed=1)
     w = rand64c(N, C, seed=2) if weighted else None
-    w_d = hip.copy_array(w) if weighted else None
+    w_d = (hip.copy_array(np.ascontiguousarray(w).reshape(-1)) if layout == 2 else hip.copy_array(w)) if weighted else None
     sl = tuple(slice(l, l + b) for l, b in zip(lo, box))
     # dense reference on the same GPU: explicit zero-padded array through the plain transform
     full = np.zeros(grid + (C,), dtype=C64, order='F')
@@ -244,10 +259,12 @@ def test_padded_and_cropped_fft_leaves(hip, grid, box, lo, C, weighted, layout):
     xc_d = hip.copy_array(np.full((N, C), np.nan, dtype=C64, order='F'))
     hip.ifft_cropped(xc_d, k_d, w_d, grid, lo, box, ws, layout)
     np.testing.assert_array_equal(k_d.to_host(), k)                           # the input panel stays intact
-    assert rel_err(xc_d.to_host(), exp) < 2e-6
+    xc = xc_d.to_host()
+    assert rel_err(_il(xc) if layout == 2 else xc, exp) < 2e-6
     # <F x, k> == <x, F^H k>
     s_d = hip.zero_array((N, 1), C64)
-    hip.sum_columns(s_d, xc_d)
+    hip.sum_columns(s_d, xc_d, interleaved=(layout == 2))
+    np.testing.assert_allclose(s_d.to_host()[:, 0], exp.sum(axis=1), rtol=2e-4, atol=2e-4 * np.abs(exp).max())
     c128 = np.complex128            # float32 accumulation over ~1e8 terms is itself only good to ~1e-4
     np.testing.assert_allclose(np.vdot(k.astype(c128), y.astype(c128)),
                                np.vdot(s_d.to_host().astype(c128), x.astype(c128)), rtol=1e-4)
@@ -276,6 +293,13 @@ def test_zpadfft_operator_matches_reference_composition(hip, oracle_backend):
     A = p.build_zpadfft(hip)                     # grid in (x, z, y) order, G' permuted to match
     A_o = p.build_zpadfft(oracle_backend, layout=0)
     A_l0 = p.build_zpadfft(hip, layout=0)
+    p4 = SenseProblem.synthetic((128, 128, 128), 4, nspokes=300, nreadout=256, width=2, oversamp=2.0, seed=4)
+    A_il, A_il_o, A_l1 = p4.build_zpadfft(hip, layout=2), p4.build_zpadfft(oracle_backend, layout=2), p4.build_zpadfft(hip, layout=1)
+    x4, k4 = rand64c(A_il.shape[1], 1, seed=1), rand64c(A_il.shape[0], 1, seed=2)
+    assert rel_err(A_il * x4, A_l1 * x4) < RTOL and rel_err(A_il.H * k4, A_l1.H * k4) < RTOL
+    assert rel_err(A_il * x4, A_il_o * x4) < RTOL and rel_err(A_il.H * k4, A_il_o.H * k4) < RTOL
+    hip._scratch = None
+    oracle_backend._scratch = None
     x = rand64c(A.shape[1], 1, seed=1)
     k = rand64c(A.shape[0], 1, seed=2)
     Ax, AHk = A * x, A.H * k

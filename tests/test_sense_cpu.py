@@ -69,7 +69,7 @@ def test_nufft_apply(prob, oracle_backend):
     assert rel_err(x_d.to_host(), g["nufft_adj"]) < 1e-5
 
 
-@pytest.mark.parametrize("level", [0, 1, 2, 3, "fused", "zpadfft", "zpadfft-xyz"])
+@pytest.mark.parametrize("level", [0, 1, 2, 3, "fused", "zpadfft", "zpadfft-xyz", "zpadfft-il"])
 def test_sense_forward_adjoint_normal(prob, oracle_backend, level):
     p, g = prob
     B = oracle_backend
@@ -77,14 +77,14 @@ def test_sense_forward_adjoint_normal(prob, oracle_backend, level):
         B._scratch = None
     if level == "fused":
         A = p.build_fused(B)
-    elif level in ("zpadfft", "zpadfft-xyz"):
-        A = p.build_zpadfft(B, layout=1 if level == "zpadfft" else 0)
+    elif level in ("zpadfft", "zpadfft-xyz", "zpadfft-il"):
+        A = p.build_zpadfft(B, layout={"zpadfft": 1, "zpadfft-xyz": 0, "zpadfft-il": 2}[level])
     else:
         A = p.build_tree(B, level=level)
     x, k = g["sense_x"], g["sense_k"]
     assert rel_err(A * x, g["sense_Ax"]) < 1e-5
     assert rel_err(A.H * k, g["sense_AHk"]) < 1e-5
-    if level in (3, "fused", "zpadfft", "zpadfft-xyz"):
+    if level in (3, "fused", "zpadfft", "zpadfft-xyz", "zpadfft-il"):
         assert rel_err(A * x, g["sense_O3_Ax"]) < 1e-5
         assert rel_err(A.H * k, g["sense_O3_AHk"]) < 1e-5
     AHA = normal_operator(A, lamda=float(g["lamda"]))
