@@ -71,7 +71,7 @@ def parse():
     ap.add_argument("--tree", choices=["zpadfft", "o3"], default="zpadfft",
                     help="zpadfft: S' and the FFT fused into one zero-pad-aware leaf (default); o3: the reference's -O3 leaves")
     ap.add_argument("--layout", type=int, default=-1, help="grid layout of the fused tree: 1 = (x,z,y) per coil, 2 = coils interleaved "
-                    "(default: 2 when this rank holds 1, 2, 4, 8 or 16 coils, else 1)")
+                    "(default: 2 when this rank holds 2, 4 or 8 coils, else 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-budget", type=float, default=60.0, help="skip the CPU leg if setup says it will exceed this many seconds")
     return ap.parse_args()
@@ -122,7 +122,7 @@ def main():
     coils = list(coil_range(C, rank, world))
     log(rank, "problem: image %d^3, %d coils (%d on this rank), grid %s, T=%d (%.1fs)" % (img, C, len(coils), p.oN, p.T, time.time() - t_setup))
     fused_fft = args.tree == "zpadfft" and B.supports_padded_fft(p.oN)
-    layout = args.layout if args.layout >= 0 else (2 if len(coils) in (1, 2, 4, 8, 16) else 1)
+    layout = args.layout if args.layout >= 0 else (2 if len(coils) in (2, 4, 8) else 1)
     A = p.build_zpadfft(B, coils=coils, layout=layout) if fused_fft else p.build_fused(B, coils=coils)
     log(rank, "tree:", "KronI(G') * ZpadFFT (S' folded into a zero-pad-aware FFT)" if fused_fft
         else "-O3: KronI(G') * (KronI(FFT) * S')")

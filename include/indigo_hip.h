@@ -268,6 +268,12 @@ int  ig_fft_exec_padded(ig_fft* plan, const void* x, int64_t x_bstride, const vo
                         const int16_t* support);
 int  ig_fft_exec_cropped(ig_fft* plan, const void* y, const void* w, void* x, int64_t x_bstride, void* workspace,
                          const int16_t* support);
+/* Cropped transform fused with the coil combination (grid_layout 2 only, w required):
+ *   x = sum_c conj(w[.., c]) .* crop( IFFT3( Y[.., c] ) )          x: ONE compact box_dims array
+ * i.e. the adjoint of the SENSE map stack S'^H (examples/pics.py:104-193 builds it as a VStack of Diag(maps);
+ * indigo/operators.py:440-447 VStack._eval_adjoint sums the per-coil results) inside the transform's last pass. */
+int  ig_fft_exec_cropped_sum(ig_fft* plan, const void* y, const void* w, void* x, void* workspace,
+                             const int16_t* support);
 int  ig_fft_destroy(ig_fft* plan);
 
 #ifdef __cplusplus

@@ -77,6 +77,7 @@ PROTOTYPES = {
                                    POINTER(c_void_p), POINTER(c_size_t)]),
     "ig_fft_exec_padded": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ig_fft_exec_cropped": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "ig_fft_exec_cropped_sum": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 
 

@@ -353,6 +353,19 @@ class HipBackend(Backend):
                                                 ctypes.c_void_p(support._arr) if support is not None else None),
                     "ig_fft_exec_cropped")
 
+    def ifft_cropped_sum(self, x, y, w, grid, box_lo, box_dims, workspace, support=None):
+        """x = sum_c conj(w[:, c]) * crop(IFFT(y[:, c])) for a coil-interleaved grid panel y (layout 2): the cropped
+        transform with the coil combination folded into its last pass"""
+        C = y.shape[1]
+        assert y.dtype == _C64 and x.dtype == _C64 and y.contiguous and x.contiguous and w is not None
+        assert x.size == int(np.prod(box_dims))
+        plan, ws = self._padded_plan(grid, box_lo, box_dims, C, 2)
+        assert workspace.nbytes >= ws
+        self._check(self._L.ig_fft_exec_cropped_sum(plan, ctypes.c_void_p(y._arr), ctypes.c_void_p(w._arr),
+                                                    ctypes.c_void_p(x._arr), ctypes.c_void_p(workspace._arr),
+                                                    ctypes.c_void_p(support._arr) if support is not None else None),
+                    "ig_fft_exec_cropped_sum")
+
     def sum_columns(self, y, X, alpha=1, beta=0, interleaved=False):
         assert y.dtype == _C64 and X.dtype == _C64 and y.contiguous and y.size == X.shape[0]
         ar, ai = _cplx(alpha)

@@ -54,6 +54,12 @@ constexpr size_t LDS_BUDGET = 150 * 1024;
 
 struct Radices { int r[MAX_STAGES]; };
 
+// lane exchange inside a row of 16 lanes by a DPP control word (out-of-row sources read as zero)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+
 // ---- butterflies --------------------------------------------------------------
 __device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }   // a * (-i)
 
@@ -244,7 +250,9 @@ template <int N> struct RegFFTHalfIn {
 //   out + k0*out_s[0] + k1*out_s[1] + k2*out_s[2] + j*out_sj     (stored only for out_lo <= j < out_hi)
 // The base pointers are pre-offset on the host (index origins of boxes / compact arrays), so they may
 // point outside the buffers; they are only dereferenced inside the boxes.  Optional diagonal weights
-// `w` (same indexing, own strides): WMODE 1 multiplies the inputs by w, WMODE 2 the outputs by conj(w).
+// `w` (same indexing, own strides): WMODE 1 multiplies the inputs by w, WMODE 2 the outputs by conj(w); WMODE 3
+// additionally sums the weighted outputs over the cw sub-columns of a column (SENSE coil combination) and stores
+// the sum once, through the addressing of sub-column 0.
 struct PassDesc {
     const float2* in; float2* out; const float2* w;
     int64_t in_sj, out_sj, w_sj;
@@ -407,7 +415,7 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
         for (int r = 0; r < R2; ++r) u[r] = lr[r * (AXIS0 ? 17 : 16 * W)];
         RegFFT<R2>::run(u);
         float2 wv[R2];          // kept outputs j = t + 16*(q + r*B2): bit q + r*B2 of obits
-        if (WMODE == 2) {
+        if (WMODE >= 2) {
 #pragma unroll
             for (int r = 0; r < R2; ++r) {
                 if (HALF_OUT && (r < R2 / 4 || r >= 3 * R2 / 4)) continue;
@@ -423,8 +431,18 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
             const bool stat = !BOXED || HALF_OUT || HALF == 3;
             float2 a = u[r];
             if (d.inverse) a.y = -a.y;
-            if (WMODE == 2) a = cmulc(wv[r], a);
-            const bool on = stat || ((obits >> (q + r * B2)) & 1u);
+            if (WMODE >= 2) a = cmulc(wv[r], a);
+            bool on = stat || ((obits >> (q + r * B2)) & 1u);
+            if (WMODE == 3) {
+                // coil combination: the cw sub-columns (coils) of a column sit in cw consecutive lanes; data-parallel
+                // primitives move the partial sums (no LDS traffic, no extra registers): afterwards the group's
+                // first lane holds the total
+                if (d.cw >= 2)  { a.x += dpp_f<0xB1>(a.x);  a.y += dpp_f<0xB1>(a.y); }      // quad_perm [1,0,3,2]
+                if (d.cw >= 4)  { a.x += dpp_f<0x4E>(a.x);  a.y += dpp_f<0x4E>(a.y); }      // quad_perm [2,3,0,1]
+                if (d.cw >= 8)  { a.x += dpp_f<0x104>(a.x); a.y += dpp_f<0x104>(a.y); }     // row_shl:4
+                if (d.cw >= 16) { a.x += dpp_f<0x108>(a.x); a.y += dpp_f<0x108>(a.y); }     // row_shl:8
+                on = on && (w % d.cw) == 0;
+            }
             if (AXIS0) buf_st<NT_ST>(r_out, on ? l_out : IG_OOB, (unsigned)(q * T + r * R1) * 8u, a);
             else buf_st<NT_ST>(make_rsrc(b_out + (int64_t)(q * T + r * R1) * d.out_sj), on ? l_out : IG_OOB, 0, a);
         }
@@ -698,8 +716,13 @@ int launch_2stage(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d_in, bool ax
         else if (d.out_lo == qn && d.out_hi == 3 * qn && !(d.tile_range && d.tile_range_mode == 1))
             half = (in_full && !d.tile_range) ? 4 : 2;
         if (wmode == 1 && half != 3) half = 0;      // weighted variants exist for the fully static boxes only
-        if (wmode == 2 && half != 4) half = 0;
+        if (wmode >= 2 && half != 4) half = 0;
     }
+    if (wmode == 3) {
+        IG_REQUIRE(ctx, !axis0 && d.cw >= 1, "ig_fft: the coil-summing pass is a strided pass with a lane split");
+        if (ax.n == 512) { if (half == 4) IG_2S(32, false, 3, true, 4); else IG_2S(32, false, 3, true, 0); }
+        else             { if (half == 4) IG_2S(16, false, 3, true, 4); else IG_2S(16, false, 3, true, 0); }
+    } else
     if (ax.n == 512) { if (axis0) IG_2S_W(32, true); else IG_2S_W(32, false); }
     else             { if (axis0) IG_2S_W(16, true); else IG_2S_W(16, false); }
 #undef IG_2S_W
@@ -1025,7 +1048,8 @@ static int exec_padded_layout2(ig_fft* p, const float2* x, int64_t x_bstride, co
     return IG_OK;
 }
 
-static int exec_cropped_layout2(ig_fft* p, const float2* y, const float2* w, float2* x, float2* work, const short2* support) {
+static int exec_cropped_layout2(ig_fft* p, const float2* y, const float2* w, float2* x, float2* work, const short2* support,
+                                bool sum_coils = false) {
     ig_ctx* ctx = p->ctx;
     const int64_t n0 = p->dims[0], n1 = p->dims[1], n2 = p->dims[2];
     const int64_t b0 = p->box_dims[0], b1 = p->box_dims[1], b2 = p->box_dims[2];
@@ -1054,6 +1078,17 @@ static int exec_cropped_layout2(ig_fft* p, const float2* y, const float2* w, flo
         if (support) { d.tile_range = support + n1 * (n0 / 16); d.tile_range_mode = 2; d.tile_range_k1 = 0; d.tile_shift = lg2(C); }
         if (int rc = launch_2stage(ctx, p->axis[1], d, false, 0)) return rc;
     }
+    if (sum_coils) {   // pass x with the coil combination: x = sum_c conj(w_c) .* crop(...), one image box
+        ig_prof_scope prof(ctx, "fft_crop_x", (double)(cvol + bvol) * C * 8.0 + (double)bvol * 8.0);
+        PassDesc d{};
+        d.cw = (int)C;
+        d.in = L1; d.in_sj = C; d.in_sa = 1; d.in_s[0] = C * n0; d.in_s[1] = C * n0 * b1;
+        d.out = x - l0; d.out_sj = 1; d.out_sa = 0; d.out_s[0] = b0; d.out_s[1] = b0 * b1;
+        d.w = w - l0 * C; d.w_sj = C; d.w_sa = 1; d.w_s[0] = b0 * C; d.w_s[1] = b0 * b1 * C;
+        d.ext0 = b1; d.ext1 = b2; d.ncols = b1 * b2;
+        d.in_lo = 0; d.in_hi = (int)n0; d.out_lo = (int)l0; d.out_hi = (int)(l0 + b0); d.inverse = 1;
+        if (int rc = launch_2stage(ctx, p->axis[0], d, false, 3)) return rc;
+    } else
     {   // pass x: interleaved compact rows -> interleaved compact image box, times conj(w)
         ig_prof_scope prof(ctx, "fft_crop_x", (double)(cvol + bvol + (w ? bvol : 0)) * C * 8.0);
         PassDesc d{};
@@ -1172,6 +1207,16 @@ int ig_fft_exec_cropped(ig_fft* p, const void* yv, const void* wv, void* xv, int
         if (int rc = launch_2stage(ctx, p->axis[0], d, true, w ? 2 : 0)) return rc;
     }
     return IG_OK;
+}
+
+int ig_fft_exec_cropped_sum(ig_fft* p, const void* yv, const void* wv, void* xv, void* workspace, const int16_t* support) {
+    if (!p) return ig_fail(nullptr, IG_ERR_ARG, "ig_fft_exec_cropped_sum: plan is NULL");
+    ig_ctx* ctx = p->ctx;
+    IG_REQUIRE(ctx, p->padded && p->layout == 2, "ig_fft_exec_cropped_sum: needs a plan of ig_fft_plan_padded with grid_layout 2");
+    IG_REQUIRE(ctx, xv && yv && wv && workspace, "ig_fft_exec_cropped_sum: NULL array");
+    if (int rc = ig_set_device(ctx)) return rc;
+    return exec_cropped_layout2(p, (const float2*)yv, (const float2*)wv, (float2*)xv, (float2*)workspace,
+                                (const short2*)support, true);
 }
 
 int ig_fft_describe(ig_fft* p, char* buf, size_t len) {

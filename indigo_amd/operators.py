@@ -369,6 +369,10 @@ class ZpadFFT(MatrixFreeOperator):
                     B.fft_padded(yj.reshape((P, C)), xj, w, self._grid, self._lo, self._box)
                 if alpha != 1:
                     B.scale(yj, alpha)
+            elif self._layout == 2 and alpha == 1 and beta == 0 and hasattr(B, 'ifft_cropped_sum'):
+                # coil combination inside the transform's last pass: no per-coil image arrays at all
+                with B.scratch(nbytes=self._ws_bytes()) as ws:
+                    B.ifft_cropped_sum(yj, xj.reshape((P, C)), w, self._grid, self._lo, self._box, ws, self._support())
             else:
                 with B.scratch(shape=(N, C)) as tmp:
                     with B.scratch(nbytes=self._ws_bytes()) as ws:

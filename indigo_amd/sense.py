@@ -213,13 +213,15 @@ class SenseProblem(object):
         first[nz] = G.indices[G.indptr[nz]]
         return np.argsort(first, kind='stable').astype(np.int32)
 
-    def build_zpadfft(self, backend, coils=None, layout=1, support=None, reorder=False):
+    def build_zpadfft(self, backend, coils=None, layout=None, support=None, reorder=False):
         """A = KronI(C, G') * ZpadFFT: the `-O3` tree with S' and the FFT fused into one leaf
         (zero-pad aware transform; needs backend.supports_padded_fft(grid)).  The oversampled grid is
         private to this pair of leaves, so it may live in the (x, z, y) order (layout=1) that keeps the
         transform's largest pass at a small stride; G' is indexed to match."""
         coils = list(range(self.C) if coils is None else coils)
         Cn = len(coils)
+        if layout is None:      # coils interleaved below the grid where the kernels support it (2, 4 or 8 per rank)
+            layout = 2 if Cn in (2, 4, 8) else 1
         Gm = self.fused_interp(1 if layout == 2 else layout)      # layout 2 = layout 1 with the coils interleaved below
         G = backend.SpMatrix(Gm, name='interp*mod*scale')
         if layout == 2:

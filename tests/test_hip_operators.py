@@ -300,6 +300,13 @@ def test_zpadfft_operator_matches_reference_composition(hip, oracle_backend):
     assert rel_err(A_il * x4, A_il_o * x4) < RTOL and rel_err(A_il.H * k4, A_il_o.H * k4) < RTOL
     hip._scratch = None
     oracle_backend._scratch = None
+    # 8 coils (the headline configuration: widest lane split of the x passes and of the fused coil combination)
+    for nc in (8,):
+        pc = SenseProblem.synthetic((128, 128, 128), nc, nspokes=100, nreadout=256, width=2, oversamp=2.0, seed=6)
+        B_il, B_l1 = pc.build_zpadfft(hip, layout=2), pc.build_zpadfft(hip, layout=1)
+        xc_, kc_ = rand64c(B_il.shape[1], 1, seed=1), rand64c(B_il.shape[0], 1, seed=2)
+        assert rel_err(B_il * xc_, B_l1 * xc_) < RTOL and rel_err(B_il.H * kc_, B_l1.H * kc_) < RTOL
+        hip._scratch = None
     x = rand64c(A.shape[1], 1, seed=1)
     k = rand64c(A.shape[0], 1, seed=2)
     Ax, AHk = A * x, A.H * k
