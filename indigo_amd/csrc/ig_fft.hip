@@ -41,6 +41,9 @@ namespace {
 #ifndef IG_FFT_MINWAVES
 #define IG_FFT_MINWAVES 1      // minimum waves per SIMD the 2-stage kernels are compiled for (register cap)
 #endif
+#ifndef IG_FFT_CAP4_HALFOUT
+#define IG_FFT_CAP4_HALFOUT 0     // 1: also cap the strided half-output variants (cropped z / y passes) at 128 VGPRs -- measured slower (spills)
+#endif
 #ifndef IG_FFT_NT_LOAD
 #define IG_FFT_NT_LOAD 1
 #endif
@@ -292,7 +295,7 @@ struct PassDesc {
 //   2: output half, input box at run time      4: output half, input full
 // Half inputs prune the first butterfly layer; compile-time boxes need no predicates or bounds registers.
 template <int R1, int R2, int T, int W, bool AXIS0, int WMODE, bool BOXED, int HALF>
-__global__ void __launch_bounds__(W * T, (!AXIS0 && R1 == 32 && (HALF == 1 || HALF == 3)) ? 4 : IG_FFT_MINWAVES)
+__global__ void __launch_bounds__(W * T, (!AXIS0 && R1 == 32 && (HALF == 1 || HALF == 3 || (IG_FFT_CAP4_HALFOUT && WMODE == 0 && (HALF == 2 || HALF == 4)))) ? 4 : IG_FFT_MINWAVES)
 k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
     constexpr int n = R1 * R2, B1 = R2 / T, B2 = R1 / T, NT = W * T;
     constexpr bool NT_LD = IG_FFT_NT_LOAD, NT_ST = IG_FFT_NT_STORE;
