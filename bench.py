@@ -31,20 +31,31 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-# profile-scope name (call site) -> device kernel symbol as rocprofv3 prints it (512-point axes)
-KERNEL_SYMBOL = {
-    "fft_2stage_axis0": "k_fft_2stage<32, 16, 16, 16, true, 0, false>",
-    "fft_2stage_axis1": "k_fft_2stage<32, 16, 16, 16, false, 0, false>",
-    "fft_2stage_axis2": "k_fft_2stage<32, 16, 16, 16, false, 0, false>",
-    # zero-pad-aware passes of the fused ZpadFFT leaf: the four strided ones are one device kernel
-    "fft_pad_x": "k_fft_2stage<32, 16, 16, 16, true, 1, true>",
-    "fft_crop_x": "k_fft_2stage<32, 16, 16, 16, true, 2, true>",
-    "fft_pad_y": "k_fft_2stage<32, 16, 16, 16, false, 0, true>",
-    "fft_pad_z": "k_fft_2stage<32, 16, 16, 16, false, 0, true>",
-    "fft_crop_y": "k_fft_2stage<32, 16, 16, 16, false, 0, true>",
-    "fft_crop_z": "k_fft_2stage<32, 16, 16, 16, false, 0, true>",
-}
-PMC_SUMMARY = os.path.join("profiles", "r01e_pmc_traffic.json")
+# profile-scope name (call site) -> device kernel symbol as rocprofv3 prints it (512-point axes).  The template
+# arguments are <R1, R2, T, W, AXIS0, WMODE, BOXED, HALF> (indigo_amd/csrc/ig_fft.hip); which instantiation a pass
+# runs depends on the grid layout (bench default: 2 = coils interleaved when the rank holds 2, 4 or 8 coils).
+def kernel_symbols(layout, ncoils):
+    f = "k_fft_2stage<32, 16, 16, 16, %s>"
+    m = {
+        "fft_2stage_axis0": f % "true, 0, false, 0",
+        "fft_2stage_axis1": f % "false, 0, false, 0",
+        "fft_2stage_axis2": f % "false, 0, false, 0",
+        # zero-pad-aware passes of the fused ZpadFFT leaf: strided passes with the image half known at compile time
+        # (HALF 1: half input box + run-time output support; HALF 2: run-time input support + half output box)
+        "fft_pad_y": f % "false, 0, true, 1", "fft_pad_z": f % "false, 0, true, 1",
+        "fft_crop_y": f % "false, 0, true, 2", "fft_crop_z": f % "false, 0, true, 2",
+        "csrmm_gather": "k_csrmm_gather<8, 8, false, 0>",
+    }
+    if layout == 2:
+        m.update({"fft_pad_x": f % "false, 1, true, 3", "fft_crop_x": f % "false, 3, true, 4",
+                  "csrmm_rowlane_conj": "k_csrmm_dense64<%d, true, true>" % ncoils})
+    else:
+        m.update({"fft_pad_x": f % "true, 1, true, 3", "fft_crop_x": f % "true, 2, true, 4",
+                  "csrmm_rowlane_conj": "k_csrmm_dense64<%d, true, false>" % ncoils})
+    return m
+
+
+PMC_SUMMARY = os.path.join("profiles", "r01h_pmc_traffic.json")
 
 
 def pmc_traffic(kernel, grid, ncoils, image):
@@ -174,11 +185,12 @@ def main():
     # the same device kernel (the two strided FFT axes) are merged so the figure matches rocprofv3's row.
     if fused_fft:
         # price the fused passes with their exact compulsory bytes (box and k-space support taken into account)
-        exact = p.zpadfft_pass_bytes(len(coils), getattr(p, 'last_support_table', None))
+        exact = p.zpadfft_pass_bytes(len(coils), getattr(p, 'last_support_table', None), fused_sum=(layout == 2))
         for name, nbytes in exact.items():
             if name in prof:
                 prof[name]['bytes'] = float(nbytes) * prof[name]['launches']
     kernels = {}
+    KERNEL_SYMBOL = kernel_symbols(layout if fused_fft else 0, len(coils))
     for name, d in prof.items():
         sym = KERNEL_SYMBOL.get(name, name)
         k = kernels.setdefault(sym, dict(launches=0, total_ms=0.0, bytes=0.0))
@@ -215,6 +227,7 @@ def main():
             "config": {"workload": "non-Cartesian SENSE A^H A, image %d^3, %d coils, grid %d^3 (osf 2), radial T=%d, KB width 4; "
                                    "-O3 tree S'->FFT->G'->G'^H->IFFT->S'^H" % (img, C, p.oN[0], p.T),
                        "parallelism": "coil-sharded x%d, one all-reduce per eval" % world if world > 1 else "single GPU",
+                       "grid_layout": (layout if fused_fft else 0),
                        "algorithmic_GB_per_eval_per_gpu": alg_bytes_rank / 1e9},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,

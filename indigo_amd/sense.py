@@ -176,7 +176,7 @@ class SenseProblem(object):
         a, b = 2 * n1 * nt, 2 * (n1 * nt + nt)
         return table[:a].reshape(-1, 2), table[a:b].reshape(-1, 2), table[b:].view(np.uint32).reshape(n1 * nt, 16)
 
-    def zpadfft_pass_bytes(self, ncoils, table=None):
+    def zpadfft_pass_bytes(self, ncoils, table=None, fused_sum=False):
         """Compulsory HBM bytes of each axis pass of the fused transform (layout 1): what the pass must read
         plus what it must write, given the image box and -- if present -- the k-space support table.
         These are the per-launch "algorithmic bytes" bench.py prices the fused passes with (the reference
@@ -201,7 +201,8 @@ class SenseProblem(object):
             "fft_pad_z": z_tiles * 16 * b2 * e + z_sup * e,
             "fft_crop_z": z_sup * e + z_tiles * 16 * b2 * e,
             "fft_crop_y": y_sup * e + cvol * e,
-            "fft_crop_x": cvol * e + bvol * e + bvol * e,
+            # (fused_sum: the coil combination happens inside the pass -- one image box is written, not one per coil)
+            "fft_crop_x": cvol * e + bvol * e + (bvol * 8 if fused_sum else bvol * e),
         }
 
     @staticmethod
