@@ -307,7 +307,9 @@ k_csrmm_dense64(int64_t M, const int32_t* __restrict__ rowptr, const int32_t* __
                 const float2* __restrict__ vals, const float2* __restrict__ Xp,
                 float2* __restrict__ Y, int64_t ldy, float2 alpha,
                 WorkLists wl, int32_t thr_mid, int32_t thr_long, GridMask mask, int coalesce) {
-    __shared__ float4 prod[WAVES_PER_BLOCK][64][NC / 2];
+    __shared__ float4 prod[WAVES_PER_BLOCK][64][NC / 2 > 0 ? NC / 2 : 1];     // NC == 1 uses the .xy half of a slot
+    static_assert(NC == 1 || NC % 2 == 0, "one column or an even number of them");
+    static_assert(NC > 1 || !YIL, "a single column has no interleaved form");
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     // A wave strides over the 64-row tasks (the launcher normally gives every task its own wave; with a capped grid
     // the next task's row pointers and bitmap word are fetched while the current one is processed).
@@ -378,32 +380,47 @@ k_csrmm_dense64(int64_t M, const int32_t* __restrict__ rowptr, const int32_t* __
                 const int32_t p = __shfl(R, lo, 64) + (q - __shfl(ps, lo, 64));
                 const int32_t k = buf_ld_i32(rc, ok ? (unsigned)p * 4u : IG_OOB);
                 const float2 v = buf_ld<false>(rv, ok ? (unsigned)p * 8u : IG_OOB, 0);
-                float4 x4[NC / 2];
+                if constexpr (NC == 1) {
+                    const float2 x1 = buf_ld<false>(rx, ok ? (unsigned)k * 8u : IG_OOB, 0);
+                    float2 a = make_float2(0.f, 0.f);
+                    acc_nz<CONJ>(a, v, x1);
+                    prod[wv][lane][0] = make_float4(a.x, a.y, 0.f, 0.f);
+                } else {
+                    float4 x4[NC / 2 > 0 ? NC / 2 : 1];
 #pragma unroll
-                for (int h = 0; h < NC / 2; ++h) x4[h] = buf_ld_f4(rx, ok ? (unsigned)k * (NC * 8u) + 16u * h : IG_OOB);
+                    for (int h = 0; h < NC / 2; ++h) x4[h] = buf_ld_f4(rx, ok ? (unsigned)k * (NC * 8u) + 16u * h : IG_OOB);
 #pragma unroll
-                for (int h = 0; h < NC / 2; ++h) {
-                    float2 a = make_float2(0.f, 0.f), b = a;
-                    acc_nz<CONJ>(a, v, make_float2(x4[h].x, x4[h].y));
-                    acc_nz<CONJ>(b, v, make_float2(x4[h].z, x4[h].w));
-                    prod[wv][lane][h] = make_float4(a.x, a.y, b.x, b.y);
+                    for (int h = 0; h < NC / 2; ++h) {
+                        float2 a = make_float2(0.f, 0.f), b = a;
+                        acc_nz<CONJ>(a, v, make_float2(x4[h].x, x4[h].y));
+                        acc_nz<CONJ>(b, v, make_float2(x4[h].z, x4[h].w));
+                        prod[wv][lane][h] = make_float4(a.x, a.y, b.x, b.y);
+                    }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 const int32_t j0 = (ps > base ? ps : base) - base, j1 = (pe < base + 64 ? pe : base + 64) - base;
                 for (int32_t j = j0; j < j1; ++j) {
+                    if constexpr (NC == 1) {
+                        const float4 t = prod[wv][j][0];
+                        acc[0].x += t.x; acc[0].y += t.y;
+                    } else {
 #pragma unroll
-                    for (int h = 0; h < NC / 2; ++h) {
-                        const float4 t = prod[wv][j][h];
-                        acc[2 * h].x += t.x; acc[2 * h].y += t.y;
-                        acc[2 * h + 1].x += t.z; acc[2 * h + 1].y += t.w;
+                        for (int h = 0; h < NC / 2; ++h) {
+                            const float4 t = prod[wv][j][h];
+                            acc[2 * h].x += t.x; acc[2 * h].y += t.y;
+                            acc[2 * h + 1].x += t.z; acc[2 * h + 1].y += t.w;
+                        }
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
+            if constexpr (NC == 1) {
+                if (mine) Y[out_row(wl.yperm, row)] = cmul(alpha, acc[0]);
+            } else
             if (YIL && !wl.yperm && coalesce) {
                 // Row-major panel: the wave's 64 rows are NC*512 contiguous bytes.  The rows pass through LDS so that
                 // every store instruction writes 1 KB of consecutive addresses (a lane storing its own row would put
@@ -698,6 +715,7 @@ int launch_gather(ig_ctx* ctx, int64_t rows, int64_t xrows, int64_t N, int64_t n
     int64_t sxc = ldx, sxr = 1;          // element (k, j) of X lives at X[j*sxc + k*sxr]
     bool packed = false;
     if (x_il) { sxc = 1; sxr = N; packed = (N & (N - 1)) == 0 && N >= 1; }   // already "packed" when N is a power of two
+    if (!x_il && N == 1 && !xperm) { sxc = ldx; sxr = 1; packed = true; }      // so is a single column
     // Packing costs one read + one write of the panel (16 B per element) and turns nnz*N scattered 8-byte gathers
     // (each pulling a 32..64-byte sector) into nnz contiguous N*8-byte ones: worth it once every panel row is
     // gathered at least about once (nnz >= xrows); always for small hot panels.
@@ -785,7 +803,7 @@ int launch_gather(ig_ctx* ctx, int64_t rows, int64_t xrows, int64_t N, int64_t n
         static const int unroll = getenv("INDIGO_HIP_SPMM_UNROLL") ? atoi(getenv("INDIGO_HIP_SPMM_UNROLL")) : 2;
         // mostly-empty rows, packed panel of <= 8 columns, beta == 0: the dense-lane kernel
         static const int dense_thr = getenv("INDIGO_HIP_SPMM_DENSE") ? atoi(getenv("INDIGO_HIP_SPMM_DENSE")) : 16;
-        if (dense_thr > 0 && packed && b0 && bufok && nnz <= 2 * rows && N == sxr && (sxr == 8 || sxr == 4 || sxr == 2)) {
+        if (dense_thr > 0 && packed && b0 && bufok && nnz <= 2 * rows && N == sxr && (sxr == 8 || sxr == 4 || sxr == 2 || sxr == 1)) {
             const int32_t td = defer ? (thr_long < dense_thr ? thr_long : dense_thr) : 0x7fffffff;
             int64_t dblocks = ((rows + 63) / 64 + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
             // One task per wave by default: the hardware dispatcher balances the very uneven tasks better than a
@@ -798,7 +816,9 @@ int launch_gather(ig_ctx* ctx, int64_t rows, int64_t xrows, int64_t N, int64_t n
                            else hipLaunchKernelGGL((k_csrmm_dense64<NC_, CONJ, false>), dim3((unsigned)dblocks), dim3(BLK), 0, ctx->stream, \
                                          rows, rowptr, colind, vals, X, Y, ldy, alpha, wl, td, thr_long, mask, dense_co); } while (0)
             static const int dense_co = getenv("INDIGO_HIP_SPMM_DENSE_CO") ? atoi(getenv("INDIGO_HIP_SPMM_DENSE_CO")) : 1;
-            if (sxr == 8) IG_DENSE(8); else if (sxr == 4) IG_DENSE(4); else IG_DENSE(2);
+            if (sxr == 8) IG_DENSE(8); else if (sxr == 4) IG_DENSE(4); else if (sxr == 2) IG_DENSE(2);
+            else hipLaunchKernelGGL((k_csrmm_dense64<1, CONJ, false>), dim3((unsigned)dblocks), dim3(BLK), 0, ctx->stream,
+                                    rows, rowptr, colind, vals, X, Y, ldy, alpha, wl, td, thr_long, mask, dense_co);
 #undef IG_DENSE
         } else if (y_il) {
             return ig_fail(ctx, IG_ERR_UNSUPPORTED, "csrmm: an interleaved result panel needs the dense-lane kernel (2, 4 or 8 columns, beta = 0)");

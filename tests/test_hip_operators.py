@@ -354,6 +354,18 @@ def support_table_from_segments(seg):
     return np.concatenate([ranges.reshape(-1), bits.reshape(-1).view(np.int16)]), ranges[:n1 * nt]
 
 
+def test_single_coil_sense_rank(hip, oracle_backend):
+    """what one rank of an 8-GPU run evaluates: one coil, grid layout 1, single-column dense-lane adjoint gridding"""
+    p = SenseProblem.synthetic((64, 64, 64), 3, nspokes=400, nreadout=128, width=2, oversamp=4.0, seed=9)   # grid 256^3
+    hip._scratch = None
+    oracle_backend._scratch = None
+    A, A_o = p.build_zpadfft(hip, coils=[1]), p.build_zpadfft(oracle_backend, coils=[1])
+    x, k = rand64c(A.shape[1], 1, seed=1), rand64c(A.shape[0], 1, seed=2)
+    assert rel_err(A * x, A_o * x) < RTOL and rel_err(A.H * k, A_o.H * k) < RTOL
+    hip._scratch = None
+    oracle_backend._scratch = None
+
+
 def test_padded_fft_with_support_table(hip):
     """k-space support at 16-row-segment granularity: the padded transform guarantees only the flagged segments;
     the cropped transform reads everything else as zero; the masked adjoint SpMM writes only flagged segments."""
