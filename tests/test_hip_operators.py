@@ -186,6 +186,34 @@ def test_sense_medium_vs_oracle_and_properties(hip, oracle_backend):
     hip._scratch = None
 
 
+def test_sense_full_size_properties(hip):
+    """BASELINE config 4 at full size (image 256^3, 8 coils, grid 512^3, T = 1,851,904): the path bench.py times.
+    No oracle finishes here in seconds, so: adjointness, linearity, A^H A = A^H(A x), and agreement of the two
+    independent grid layouts (coil-interleaved kernels vs per-coil kernels)."""
+    p = SenseProblem.synthetic((256, 256, 256), 8, nspokes=3617, nreadout=512, width=2, ntable=128, oversamp=2.0, seed=4)
+    hip._scratch = None
+    c128 = np.complex128
+    A = p.build_zpadfft(hip)                      # layout 2: what the benchmark runs
+    x, x2 = rand64c(A.shape[1], 1, seed=1), rand64c(A.shape[1], 1, seed=3)
+    k = rand64c(A.shape[0], 1, seed=2)
+    Ax, AHk = A * x, A.H * k
+    lhs, rhs = np.vdot(k.astype(c128), Ax.astype(c128)), np.vdot(AHk.astype(c128), x.astype(c128))
+    assert abs(lhs - rhs) <= 1e-5 * abs(lhs)                                          # <Ax, k> = <x, A^H k>
+    assert rel_err(A * (x + (2 - 1j) * x2).astype(C64), Ax + (2 - 1j) * (A * x2)) < RTOL   # linearity
+    y_d = hip.zero_array((A.shape[1], 1), C64)
+    normal_operator(A).eval(y_d, hip.copy_array(x))
+    AHAx = y_d.to_host()
+    assert rel_err(AHAx, A.H * Ax) < RTOL
+    q = np.vdot(x.astype(c128), AHAx.astype(c128))
+    assert q.real > 0 and abs(q.imag) < 1e-5 * q.real                                 # x^H A^H A x is real and positive
+    del A, y_d
+    hip._scratch = None
+    A1 = p.build_zpadfft(hip, layout=1)           # per-coil grids: different FFT instantiations and SpMM kernels
+    assert rel_err(A1 * x, Ax) < RTOL and rel_err(A1.H * k, AHk) < RTOL
+    del A1
+    hip._scratch = None
+
+
 # ---------------------------------------------------------------------------------------
 # fused zero-pad / crop transforms (ZpadFFT leaf)
 # ---------------------------------------------------------------------------------------
