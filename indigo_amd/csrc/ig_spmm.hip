@@ -802,7 +802,7 @@ int launch_gather(ig_ctx* ctx, int64_t rows, int64_t xrows, int64_t N, int64_t n
         const bool bufok = packed && nnz * 8 < 0x7fffffffLL && xrows * sxr * 8 < 0x7fffffffLL;
         static const int unroll = getenv("INDIGO_HIP_SPMM_UNROLL") ? atoi(getenv("INDIGO_HIP_SPMM_UNROLL")) : 2;
         // mostly-empty rows, packed panel of <= 8 columns, beta == 0: the dense-lane kernel
-        static const int dense_thr = getenv("INDIGO_HIP_SPMM_DENSE") ? atoi(getenv("INDIGO_HIP_SPMM_DENSE")) : 16;
+        static const int dense_thr = getenv("INDIGO_HIP_SPMM_DENSE") ? atoi(getenv("INDIGO_HIP_SPMM_DENSE")) : 32;
         if (dense_thr > 0 && packed && b0 && bufok && nnz <= 2 * rows && N == sxr && (sxr == 8 || sxr == 4 || sxr == 2 || sxr == 1)) {
             const int32_t td = defer ? (thr_long < dense_thr ? thr_long : dense_thr) : 0x7fffffff;
             int64_t dblocks = ((rows + 63) / 64 + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
