@@ -295,7 +295,7 @@ struct PassDesc {
 //   2: output half, input box at run time      4: output half, input full
 // Half inputs prune the first butterfly layer; compile-time boxes need no predicates or bounds registers.
 template <int R1, int R2, int T, int W, bool AXIS0, int WMODE, bool BOXED, int HALF>
-__global__ void __launch_bounds__(W * T, (!AXIS0 && R1 == 32 && (HALF == 1 || HALF == 3 || (IG_FFT_CAP4_HALFOUT && WMODE == 0 && (HALF == 2 || HALF == 4)))) ? 4 : IG_FFT_MINWAVES)
+__global__ void __launch_bounds__(W * T, (!AXIS0 && R1 == 32 && (W == 32 || HALF == 1 || HALF == 3 || (IG_FFT_CAP4_HALFOUT && WMODE == 0 && (HALF == 2 || HALF == 4)))) ? 4 : IG_FFT_MINWAVES)
 k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
     constexpr int n = R1 * R2, B1 = R2 / T, B2 = R1 / T, NT = W * T;
     constexpr bool NT_LD = IG_FFT_NT_LOAD, NT_ST = IG_FFT_NT_STORE;
@@ -721,6 +721,33 @@ int launch_2stage(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d_in, bool ax
         if (wmode == 1 && half != 3) half = 0;      // weighted variants exist for the fully static boxes only
         if (wmode >= 2 && half != 4) half = 0;
     }
+    static const int use_w32 = getenv("INDIGO_HIP_FFT_W32") ? atoi(getenv("INDIGO_HIP_FFT_W32")) : 1;
+    // 32-column tiles (256-byte segments) pay where a side of the pass runs at a huge stride (y passes of the
+    // interleaved layout, 16 MB per element: -11...-15 %) and for the half-input variants, which fit 128 VGPRs;
+    // the half-output variants spill at that cap and lose on small-stride passes (cropped z pass: +16 %).
+    const bool big_stride = (d.in_sj > d.out_sj ? d.in_sj : d.out_sj) * 8 >= (1 << 20);
+    if (use_w32 && ax.n == 512 && !axis0 && wmode == 0 && !d.cw && d.ext0 % 32 == 0 &&
+        (half == 1 || half == 3 || ((half == 2 || half == 4) && (big_stride || use_w32 >= 2))) &&
+        (!d.tile_range || d.tile_shift >= 1)) {
+        // 32-column tiles: 256-byte segments per row, 512 threads, 69.6 KB of LDS (2 workgroups per CU)
+        PassDesc d2 = d;
+        d2.tpr = (unsigned)(d.ext0 / 32);
+        if (d2.tile_range) d2.tile_shift = d.tile_shift - 1;
+        const dim3 g2((unsigned)(d2.tpr * (d.ncols / d.ext0))), b2(512);
+        const size_t lds2 = ((size_t)16 * 16 * 32 + 512) * 8;
+        static bool attr_done = false;
+        if (!attr_done) {
+            IG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fft_2stage<32, 16, 16, 32, false, 0, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+            IG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fft_2stage<32, 16, 16, 32, false, 0, true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+            IG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fft_2stage<32, 16, 16, 32, false, 0, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+            IG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fft_2stage<32, 16, 16, 32, false, 0, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+            attr_done = true;
+        }
+        if (half == 1) hipLaunchKernelGGL((k_fft_2stage<32, 16, 16, 32, false, 0, true, 1>), g2, b2, lds2, ctx->stream, d2, ax.d_tw);
+        else if (half == 3) hipLaunchKernelGGL((k_fft_2stage<32, 16, 16, 32, false, 0, true, 3>), g2, b2, lds2, ctx->stream, d2, ax.d_tw);
+        else if (half == 2) hipLaunchKernelGGL((k_fft_2stage<32, 16, 16, 32, false, 0, true, 2>), g2, b2, lds2, ctx->stream, d2, ax.d_tw);
+        else hipLaunchKernelGGL((k_fft_2stage<32, 16, 16, 32, false, 0, true, 4>), g2, b2, lds2, ctx->stream, d2, ax.d_tw);
+    } else
     if (wmode == 3) {
         IG_REQUIRE(ctx, !axis0 && d.cw >= 1, "ig_fft: the coil-summing pass is a strided pass with a lane split");
         if (ax.n == 512) { if (half == 4) IG_2S(32, false, 3, true, 4); else IG_2S(32, false, 3, true, 0); }
