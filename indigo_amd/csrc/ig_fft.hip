@@ -279,6 +279,9 @@ struct PassDesc {
     // optional refinement of tile_range (same mode, same indexing, 16 words per tile): bit m of word t is set iff
     // element j = t + 16*m of the tile's columns is needed (mode 1) / was ever written (mode 2)
     const uint32_t* tile_bits;
+    // optional: tiles whose k1 lies outside k1_range[tile >> tile_shift] = [lo, hi) are skipped altogether (the
+    // cropped z pass: the y pass that follows never reads ky outside the kx tile's ky hull)
+    const short2* k1_range;
 };
 
 // Two-stage kernel for n = R1*R2 (256 = 16x16, 512 = 32x16): the whole column lives in registers
@@ -314,6 +317,10 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
     const unsigned k1 = rest % d.ext1, k2 = rest / d.ext1;
     const int64_t k0u = (int64_t)tr * ((!AXIS0 && d.cw) ? W / d.cw : W);
     int in_lo = d.in_lo, in_hi = d.in_hi, out_lo = d.out_lo, out_hi = d.out_hi;
+    if (BOXED && !AXIS0 && d.k1_range) {
+        const short2 r = d.k1_range[tr >> d.tile_shift];
+        if ((int)k1 < r.x || (int)k1 >= r.y) return;
+    }
     if (BOXED && !AXIS0 && d.tile_range) {
         const short2 r = d.tile_range[(int64_t)k1 * d.tile_range_k1 + (tr >> d.tile_shift)];
         if (d.tile_range_mode == 1) {
@@ -1000,6 +1007,7 @@ static int exec_cropped_layout1(ig_fft* p, const float2* y, const float2* w, flo
         d.in_lo = 0; d.in_hi = (int)n2; d.out_lo = (int)l2; d.out_hi = (int)(l2 + b2); d.inverse = 1;
         d.tile_range = support; d.tile_range_mode = 2; d.tile_range_k1 = n0 / 16;   // the adjoint gridding only wrote the support
         if (support) d.tile_bits = reinterpret_cast<const uint32_t*>(support + n1 * (n0 / 16) + n0 / 16);
+        if (support) d.k1_range = support + n1 * (n0 / 16);                         // ky the y pass will never read
         if (int rc = launch_2stage(ctx, p->axis[2], d, false, 0)) return rc;
     }
     {   // pass y: columns (kx, z'), grid in (stride n0*n2), compact out, keep y in box
@@ -1096,6 +1104,7 @@ static int exec_cropped_layout2(ig_fft* p, const float2* y, const float2* w, flo
         d.in_lo = 0; d.in_hi = (int)n2; d.out_lo = (int)l2; d.out_hi = (int)(l2 + b2); d.inverse = 1;
         d.tile_range = support; d.tile_range_mode = 2; d.tile_range_k1 = n0 / 16; d.tile_shift = lg2(C);
         if (support) d.tile_bits = reinterpret_cast<const uint32_t*>(support + n1 * (n0 / 16) + n0 / 16);
+        if (support) d.k1_range = support + n1 * (n0 / 16);                         // ky the y pass will never read
         if (int rc = launch_2stage(ctx, p->axis[2], d, false, 0)) return rc;
     }
     {   // pass y

@@ -199,7 +199,7 @@ class SenseProblem(object):
             "fft_pad_x": bvol * 8 + bvol * e + cvol * e,
             "fft_pad_y": cvol * e + y_sup * e,
             "fft_pad_z": z_tiles * 16 * b2 * e + z_sup * e,
-            "fft_crop_z": z_sup * e + z_tiles * 16 * b2 * e,
+            "fft_crop_z": z_sup * e + y_sup * e,            # writes every column the y pass will read (zeros where the hull is empty)
             "fft_crop_y": y_sup * e + cvol * e,
             # (fused_sum: the coil combination happens inside the pass -- one image box is written, not one per coil)
             "fft_crop_x": cvol * e + bvol * e + (bvol * 8 if fused_sum else bvol * e),
