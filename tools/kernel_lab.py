@@ -110,7 +110,33 @@ def cfg3():
     report(B, 5, {"csrmm_gather": fb, "csrmm_gather_conj": ab, "csrmm_rowlane_conj": ab})
 
 
-if len(sys.argv) > 1 and sys.argv[1] == "empty":
+def zpad_probe():
+    """fused padded transform, layout 2, no support table, straight through the C ABI"""
+    import ctypes
+    B = get_backend("hip")
+    c64 = np.dtype('complex64')
+    grid, box, C = (512, 512, 512), (256, 256, 256), 8
+    lo = tuple(m // 2 - n // 2 for m, n in zip(grid, box))
+    P, N = int(np.prod(grid)), int(np.prod(box))
+    plan, ws = B._padded_plan(grid, lo, box, C, 2)
+    x = B.copy_array(rand64c(N, 1, seed=1))
+    w = B.copy_array(rand64c(N * C, 1, seed=2))
+    y = B.zero_array((P * C,), c64)
+    work = B.zero_array((ws // 8,), c64)
+    def run():
+        B._check(B._L.ig_fft_exec_padded(plan, ctypes.c_void_p(x._arr), 0, ctypes.c_void_p(w._arr), ctypes.c_void_p(y._arr),
+                                         ctypes.c_void_p(work._arr), None), "pad")
+    run(); B.barrier()
+    B.profile(True)
+    for _ in range(5):
+        run()
+    B.profile(False)
+    report(B, 5)
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "zpad":
+    zpad_probe()
+elif len(sys.argv) > 1 and sys.argv[1] == "empty":
     empty_rows_probe()
 elif len(sys.argv) > 1 and sys.argv[1] == "cfg3":
     cfg3()
