@@ -1,7 +1,7 @@
 #!/bin/bash
 # Per-kernel register / spill / occupancy table for one HIP source: tools/kernel_regs.sh indigo_amd/csrc/ig_fft.hip [filter]
 R=$(cd "$(dirname "$0")/.." && pwd)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics $EXTRA -I$R/include -I$R/indigo_amd/csrc \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -fno-slp-vectorize $EXTRA -I$R/include -I$R/indigo_amd/csrc \
   -c "$1" -o /tmp/_regs.o -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c '
 import sys, re, subprocess
 rows = []; cur = None
