@@ -303,6 +303,9 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
     constexpr int n = R1 * R2, B1 = R2 / T, B2 = R1 / T, NT = W * T;
     constexpr bool NT_LD = IG_FFT_NT_LOAD, NT_ST = IG_FFT_NT_STORE;
     constexpr bool HALF_IN = HALF == 1 || HALF == 3, HALF_OUT = HALF == 2 || HALF == 4;
+    // direction: the half-input variants only serve forward (zero-padded) passes and the half-output variants only
+    // inverse (cropped) ones, so their conjugations are sign modifiers, not a select per element
+    const bool inv = HALF_OUT ? true : HALF_IN ? false : (d.inverse != 0);
     static_assert(R2 % T == 0 && R1 % T == 0 && T == 16 && B1 == 1, "lane groups of 16, one stage-1 butterfly per thread");
     extern __shared__ float2 lds[];
     float2* __restrict__ tws = lds + (AXIS0 ? 16 * 17 * W : 16 * T * W);
@@ -397,7 +400,7 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
         for (int k = 0; k < R1; ++k) {
             if (HALF_IN && (k < R1 / 4 || k >= 3 * R1 / 4)) continue;
             if (WMODE == 1) v[k] = cmul(v[k], wv[k]);
-            if (d.inverse) v[k].y = -v[k].y;
+            if (inv) v[k].y = -v[k].y;
         }
     }
     __syncthreads();            // twiddle table visible (the global loads above are already in flight)
@@ -440,7 +443,7 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
             if (HALF_OUT && (r < R2 / 4 || r >= 3 * R2 / 4)) continue;          // never stored
             const bool stat = !BOXED || HALF_OUT || HALF == 3;
             float2 a = u[r];
-            if (d.inverse) a.y = -a.y;
+            if (inv) a.y = -a.y;
             if (WMODE >= 2) a = cmulc(wv[r], a);
             bool on = stat || ((obits >> (q + r * B2)) & 1u);
             if (WMODE == 3) {
@@ -727,6 +730,7 @@ int launch_2stage(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d_in, bool ax
             half = (in_full && !d.tile_range) ? 4 : 2;
         if (wmode == 1 && half != 3) half = 0;      // weighted variants exist for the fully static boxes only
         if (wmode >= 2 && half != 4) half = 0;
+        if (((half == 1 || half == 3) && d.inverse) || ((half == 2 || half == 4) && !d.inverse)) half = 0;   // direction is baked in
     }
     static const int use_w32 = getenv("INDIGO_HIP_FFT_W32") ? atoi(getenv("INDIGO_HIP_FFT_W32")) : 1;
     // 32-column tiles (256-byte segments) pay where a side of the pass runs at a huge stride (y passes of the
