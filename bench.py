@@ -47,7 +47,8 @@ def kernel_symbols(layout, ncoils):
         "csrmm_gather": "k_csrmm_gather<8, 8, false, 0>",
     }
     if layout == 2:
-        m.update({"fft_pad_x": f % "false, 1, true, 3", "fft_crop_x": f % "false, 3, true, 4",
+        # coil-summing last pass: WMODE = 3 + log2(coils)
+        m.update({"fft_pad_x": f % "false, 1, true, 3", "fft_crop_x": f % ("false, %d, true, 4" % (3 + ncoils.bit_length() - 1)),
                   "csrmm_rowlane_conj": "k_csrmm_dense64<%d, true, true>" % ncoils})
     else:
         m.update({"fft_pad_x": f % "true, 1, true, 3", "fft_crop_x": f % "true, 2, true, 4",

@@ -253,9 +253,9 @@ template <int N> struct RegFFTHalfIn {
 //   out + k0*out_s[0] + k1*out_s[1] + k2*out_s[2] + j*out_sj     (stored only for out_lo <= j < out_hi)
 // The base pointers are pre-offset on the host (index origins of boxes / compact arrays), so they may
 // point outside the buffers; they are only dereferenced inside the boxes.  Optional diagonal weights
-// `w` (same indexing, own strides): WMODE 1 multiplies the inputs by w, WMODE 2 the outputs by conj(w); WMODE 3
-// additionally sums the weighted outputs over the cw sub-columns of a column (SENSE coil combination) and stores
-// the sum once, through the addressing of sub-column 0.
+// `w` (same indexing, own strides): WMODE 1 multiplies the inputs by w, WMODE 2 the outputs by conj(w); WMODE
+// 3 + log2(cw) additionally sums the weighted outputs over the cw sub-columns of a column (SENSE coil combination)
+// and stores the sum once, through the addressing of sub-column 0.
 struct PassDesc {
     const float2* in; float2* out; const float2* w;
     int64_t in_sj, out_sj, w_sj;
@@ -303,6 +303,7 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
     constexpr int n = R1 * R2, B1 = R2 / T, B2 = R1 / T, NT = W * T;
     constexpr bool NT_LD = IG_FFT_NT_LOAD, NT_ST = IG_FFT_NT_STORE;
     constexpr bool HALF_IN = HALF == 1 || HALF == 3, HALF_OUT = HALF == 2 || HALF == 4;
+    constexpr int SUMW = WMODE >= 3 ? (1 << (WMODE - 3)) : 0;       // WMODE 3 + log2(coils): 3 -> 1 (no sum), 4 -> 2, 5 -> 4, 6 -> 8, 7 -> 16
     // direction: the half-input variants only serve forward (zero-padded) passes and the half-output variants only
     // inverse (cropped) ones, so their conjugations are sign modifiers, not a select per element
     const bool inv = HALF_OUT ? true : HALF_IN ? false : (d.inverse != 0);
@@ -363,6 +364,7 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
     }
     if (!valid) l_in = l_out = l_w = IG_OOB;
     if (!WMODE) l_w = IG_OOB;
+    if (SUMW && (w % SUMW) != 0) l_out = IG_OOB;            // only a column's first sub-column stores the coil sum
 
     // Element j = t + 16*m of this thread's column <-> bit m of a 32-bit word: ibits flags the inputs to read
     // (stage 1 loads m = k), obits the outputs to keep (stage 2 stores m = q + r*R1/16).  Boxes [lo, hi) become
@@ -387,13 +389,14 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
         for (int k = 0; k < R1; ++k) {
             if (HALF_IN && (k < R1 / 4 || k >= 3 * R1 / 4)) continue;        // never read
             const bool stat = !BOXED || HALF_IN || HALF == 4;                 // box known at compile time
-            const bool on = stat || ((ibits >> k) & 1u);
+            // off = all ones (out of range) where the element is not wanted: one bit-field extract + one or
+            const unsigned off = stat ? 0u : (unsigned)__builtin_amdgcn_sbfe((int)~ibits, k, 1);
             if (AXIS0) {
-                v[k] = buf_ld<NT_LD>(r_in, on ? l_in : IG_OOB, (unsigned)(k * R2) * 8u);
-                if (WMODE == 1) wv[k] = buf_ld<false>(r_w, on ? l_w : IG_OOB, (unsigned)(k * R2) * 8u);
+                v[k] = buf_ld<NT_LD>(r_in, l_in | off, (unsigned)(k * R2) * 8u);
+                if (WMODE == 1) wv[k] = buf_ld<false>(r_w, l_w | off, (unsigned)(k * R2) * 8u);
             } else {
-                v[k] = buf_ld<NT_LD>(make_rsrc(b_in + (int64_t)(k * R2) * d.in_sj), on ? l_in : IG_OOB, 0);
-                if (WMODE == 1) wv[k] = buf_ld<false>(make_rsrc(b_w + (int64_t)(k * R2) * d.w_sj), on ? l_w : IG_OOB, 0);
+                v[k] = buf_ld<NT_LD>(make_rsrc(b_in + (int64_t)(k * R2) * d.in_sj), l_in | off, 0);
+                if (WMODE == 1) wv[k] = buf_ld<false>(make_rsrc(b_w + (int64_t)(k * R2) * d.w_sj), l_w | off, 0);
             }
         }
 #pragma unroll
@@ -433,9 +436,9 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
             for (int r = 0; r < R2; ++r) {
                 if (HALF_OUT && (r < R2 / 4 || r >= 3 * R2 / 4)) continue;
                 const bool stat = !BOXED || HALF_OUT || HALF == 3;
-                const bool on = stat || ((obits >> (q + r * B2)) & 1u);
-                if (AXIS0) wv[r] = buf_ld<false>(r_w, on ? l_w : IG_OOB, (unsigned)(q * T + r * R1) * 8u);
-                else wv[r] = buf_ld<false>(make_rsrc(b_w + (int64_t)(q * T + r * R1) * d.w_sj), on ? l_w : IG_OOB, 0);
+                const unsigned off = stat ? 0u : (unsigned)__builtin_amdgcn_sbfe((int)~obits, q + r * B2, 1);
+                if (AXIS0) wv[r] = buf_ld<false>(r_w, l_w | off, (unsigned)(q * T + r * R1) * 8u);
+                else wv[r] = buf_ld<false>(make_rsrc(b_w + (int64_t)(q * T + r * R1) * d.w_sj), l_w | off, 0);
             }
         }
 #pragma unroll
@@ -445,19 +448,18 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
             float2 a = u[r];
             if (inv) a.y = -a.y;
             if (WMODE >= 2) a = cmulc(wv[r], a);
-            bool on = stat || ((obits >> (q + r * B2)) & 1u);
-            if (WMODE == 3) {
-                // coil combination: the cw sub-columns (coils) of a column sit in cw consecutive lanes; data-parallel
+            const unsigned off = stat ? 0u : (unsigned)__builtin_amdgcn_sbfe((int)~obits, q + r * B2, 1);
+            if (SUMW) {
+                // coil combination: the SUMW sub-columns (coils) of a column sit in SUMW consecutive lanes; data-parallel
                 // primitives move the partial sums (no LDS traffic, no extra registers): afterwards the group's
-                // first lane holds the total
-                if (d.cw >= 2)  { a.x += dpp_f<0xB1>(a.x);  a.y += dpp_f<0xB1>(a.y); }      // quad_perm [1,0,3,2]
-                if (d.cw >= 4)  { a.x += dpp_f<0x4E>(a.x);  a.y += dpp_f<0x4E>(a.y); }      // quad_perm [2,3,0,1]
-                if (d.cw >= 8)  { a.x += dpp_f<0x104>(a.x); a.y += dpp_f<0x104>(a.y); }     // row_shl:4
-                if (d.cw >= 16) { a.x += dpp_f<0x108>(a.x); a.y += dpp_f<0x108>(a.y); }     // row_shl:8
-                on = on && (w % d.cw) == 0;
+                // first lane holds the total (the other lanes' l_out is out of range)
+                if (SUMW >= 2)  { a.x += dpp_f<0xB1>(a.x);  a.y += dpp_f<0xB1>(a.y); }      // quad_perm [1,0,3,2]
+                if (SUMW >= 4)  { a.x += dpp_f<0x4E>(a.x);  a.y += dpp_f<0x4E>(a.y); }      // quad_perm [2,3,0,1]
+                if (SUMW >= 8)  { a.x += dpp_f<0x104>(a.x); a.y += dpp_f<0x104>(a.y); }     // row_shl:4
+                if (SUMW >= 16) { a.x += dpp_f<0x108>(a.x); a.y += dpp_f<0x108>(a.y); }     // row_shl:8
             }
-            if (AXIS0) buf_st<NT_ST>(r_out, on ? l_out : IG_OOB, (unsigned)(q * T + r * R1) * 8u, a);
-            else buf_st<NT_ST>(make_rsrc(b_out + (int64_t)(q * T + r * R1) * d.out_sj), on ? l_out : IG_OOB, 0, a);
+            if (AXIS0) buf_st<NT_ST>(r_out, l_out | off, (unsigned)(q * T + r * R1) * 8u, a);
+            else buf_st<NT_ST>(make_rsrc(b_out + (int64_t)(q * T + r * R1) * d.out_sj), l_out | off, 0, a);
         }
     }
 }
@@ -761,8 +763,12 @@ int launch_2stage(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d_in, bool ax
     } else
     if (wmode == 3) {
         IG_REQUIRE(ctx, !axis0 && d.cw >= 1, "ig_fft: the coil-summing pass is a strided pass with a lane split");
-        if (ax.n == 512) { if (half == 4) IG_2S(32, false, 3, true, 4); else IG_2S(32, false, 3, true, 0); }
-        else             { if (half == 4) IG_2S(16, false, 3, true, 4); else IG_2S(16, false, 3, true, 0); }
+#define IG_2S_SUM(R1_, HF_) do { switch (d.cw) { case 1: IG_2S(R1_, false, 3, true, HF_); break; case 2: IG_2S(R1_, false, 4, true, HF_); break; \
+                                 case 4: IG_2S(R1_, false, 5, true, HF_); break; case 8: IG_2S(R1_, false, 6, true, HF_); break;              \
+                                 default: IG_2S(R1_, false, 7, true, HF_); break; } } while (0)
+        if (ax.n == 512) { if (half == 4) IG_2S_SUM(32, 4); else IG_2S_SUM(32, 0); }
+        else             { if (half == 4) IG_2S_SUM(16, 4); else IG_2S_SUM(16, 0); }
+#undef IG_2S_SUM
     } else
     if (ax.n == 512) { if (axis0) IG_2S_W(32, true); else IG_2S_W(32, false); }
     else             { if (axis0) IG_2S_W(16, true); else IG_2S_W(16, false); }
