@@ -247,6 +247,108 @@ template <int N> struct RegFFTHalfIn {
     }
 };
 
+// ---- packed complex arithmetic for the two-stage kernel ---------------------------------------------------------
+// A complex number is ONE 64-bit register pair (native 2-vector): complex add/sub is a single v_pk_add_f32, a complex
+// multiply is v_pk_mul_f32 + v_pk_fma_f32 with operand swizzles, multiplication by -i is a swizzle with a sign
+// modifier.  Written on float2 structs the same butterflies compile to scalar v_add/v_mul/v_fmac, twice the VALU
+// instructions -- and these kernels are bound by instruction issue as much as by HBM (SIMDs ~85 % busy).
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct cx { v2f v; };
+__device__ __forceinline__ cx mk(float re, float im) { cx r; r.v = v2f{re, im}; return r; }
+__device__ __forceinline__ cx from2(float2 a) { return mk(a.x, a.y); }
+__device__ __forceinline__ float2 to2(cx a) { return make_float2(a.v.x, a.v.y); }
+__device__ __forceinline__ cx operator+(cx a, cx b) { cx r; r.v = a.v + b.v; return r; }
+__device__ __forceinline__ cx operator-(cx a, cx b) { cx r; r.v = a.v - b.v; return r; }
+__device__ __forceinline__ cx cneg(cx a) { cx r; r.v = -a.v; return r; }
+__device__ __forceinline__ cx cconj(cx a) { cx r; r.v = v2f{a.v.x, -a.v.y}; return r; }
+__device__ __forceinline__ cx cmul_mi(cx a) { cx r; r.v = v2f{a.v.y, -a.v.x}; return r; }          // a * (-i)
+__device__ __forceinline__ cx cmul_pi(cx a) { cx r; r.v = v2f{-a.v.y, a.v.x}; return r; }          // a * (+i)
+// a * w = a.xx * (w.x, w.y) + a.yy * (-w.y, w.x)
+__device__ __forceinline__ cx cxmul(cx a, cx w) {
+    cx r;
+    r.v = __builtin_shufflevector(a.v, a.v, 0, 0) * w.v + __builtin_shufflevector(a.v, a.v, 1, 1) * v2f{-w.v.y, w.v.x};
+    return r;
+}
+// conj(w) * a = a.xx * (w.x, -w.y) + a.yy * (w.y, w.x)
+__device__ __forceinline__ cx cxmulc(cx w, cx a) {
+    cx r;
+    r.v = __builtin_shufflevector(a.v, a.v, 0, 0) * v2f{w.v.x, -w.v.y} + __builtin_shufflevector(a.v, a.v, 1, 1) * v2f{w.v.y, w.v.x};
+    return r;
+}
+__device__ __forceinline__ void pbfly2(cx& a, cx& b) { const cx t = a - b; a = a + b; b = t; }
+__device__ __forceinline__ void pbfly4(cx& a0, cx& a1, cx& a2, cx& a3) {
+    const cx t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = cmul_mi(a1 - a3);
+    a0 = t0 + t2; a2 = t0 - t2; a1 = t1 + t3; a3 = t1 - t3;
+}
+// a * exp(-2 pi i j / 32) with a literal root (j constant after unrolling), trivial rotations without multiplies
+__device__ __forceinline__ cx pmul_w32(cx a, int j) {
+    j &= 31;
+    if (j == 0) return a;
+    if (j == 8) return cmul_mi(a);
+    if (j == 16) return cneg(a);
+    if (j == 24) return cmul_pi(a);
+    const float c = cos32(j), s = -cos32(j + 24);      // w = c + i s
+    return cxmul(a, mk(c, s));
+}
+template <int N> struct PFFT;          // in-place forward DFT of N packed register values, natural order out
+template <> struct PFFT<4> {
+    __device__ static __forceinline__ void run(cx (&x)[4]) { pbfly4(x[0], x[1], x[2], x[3]); }
+};
+template <> struct PFFT<8> {
+    __device__ static __forceinline__ void run(cx (&v)[8]) {
+        pbfly4(v[0], v[2], v[4], v[6]);
+        pbfly4(v[1], v[3], v[5], v[7]);
+        const float h = 0.70710678118654752440f;
+        v[3] = cxmul(v[3], mk(h, -h));
+        v[5] = cmul_mi(v[5]);
+        v[7] = cxmul(v[7], mk(-h, -h));
+        pbfly2(v[0], v[1]); pbfly2(v[2], v[3]); pbfly2(v[4], v[5]); pbfly2(v[6], v[7]);
+        const cx x4 = v[1], x1 = v[2], x5 = v[3], x2 = v[4], x6 = v[5], x3 = v[6];
+        v[1] = x1; v[2] = x2; v[3] = x3; v[4] = x4; v[5] = x5; v[6] = x6;
+    }
+};
+template <int N> struct PFFT {         // N = 16, 32: radix-4 decimation in frequency over N/4-point DFTs
+    __device__ static __forceinline__ void run(cx (&x)[N]) {
+        constexpr int M = N / 4;
+        cx z[4][M];
+#pragma unroll
+        for (int r = 0; r < M; ++r) {
+            pbfly4(x[r], x[r + M], x[r + 2 * M], x[r + 3 * M]);
+            z[0][r] = x[r];
+#pragma unroll
+            for (int q = 1; q < 4; ++q) z[q][r] = pmul_w32(x[r + q * M], r * q * (32 / N));
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) PFFT<M>::run(z[q]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int k = 0; k < M; ++k) x[4 * k + q] = z[q][k];
+    }
+};
+// only the middle half of the inputs, x[N/4 .. 3N/4), is non-zero: the first radix-4 layer collapses
+template <int N> struct PFFTHalfIn {
+    __device__ static __forceinline__ void run(cx (&x)[N]) {
+        constexpr int M = N / 4;
+        cx z[4][M];
+#pragma unroll
+        for (int r = 0; r < M; ++r) {
+            const cx a1 = x[r + M], a2 = x[r + 2 * M];
+            const cx t3 = cmul_mi(a1);
+            z[0][r] = a2 + a1;
+            z[1][r] = pmul_w32(t3 - a2, r * (32 / N));
+            z[2][r] = pmul_w32(a2 - a1, r * 2 * (32 / N));
+            z[3][r] = pmul_w32(cneg(a2 + t3), r * 3 * (32 / N));
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) PFFT<M>::run(z[q]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int k = 0; k < M; ++k) x[4 * k + q] = z[q][k];
+    }
+};
+
 // One axis pass, described generally enough for plain, zero-padded and cropped transforms.
 // Columns are enumerated by three indices (k0 fastest, then k1, k2); element j of column k lives at
 //   in  + k0*in_s[0]  + k1*in_s[1]  + k2*in_s[2]  + j*in_sj      (read only for in_lo  <= j < in_hi, else 0)
@@ -382,9 +484,9 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
     }
 
     // ---- stage 1: radix R1 on inputs j = t + k*R2, results (times w_n^{t k}) to the exchange
-    float2 v[R1];
+    cx v[R1];
     {
-        float2 wv[R1];
+        cx wv[R1];
 #pragma unroll
         for (int k = 0; k < R1; ++k) {
             if (HALF_IN && (k < R1 / 4 || k >= 3 * R1 / 4)) continue;        // never read
@@ -392,25 +494,25 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
             // off = all ones (out of range) where the element is not wanted: one bit-field extract + one or
             const unsigned off = stat ? 0u : (unsigned)__builtin_amdgcn_sbfe((int)~ibits, k, 1);
             if (AXIS0) {
-                v[k] = buf_ld<NT_LD>(r_in, l_in | off, (unsigned)(k * R2) * 8u);
-                if (WMODE == 1) wv[k] = buf_ld<false>(r_w, l_w | off, (unsigned)(k * R2) * 8u);
+                v[k] = from2(buf_ld<NT_LD>(r_in, l_in | off, (unsigned)(k * R2) * 8u));
+                if (WMODE == 1) wv[k] = from2(buf_ld<false>(r_w, l_w | off, (unsigned)(k * R2) * 8u));
             } else {
-                v[k] = buf_ld<NT_LD>(make_rsrc(b_in + (int64_t)(k * R2) * d.in_sj), l_in | off, 0);
-                if (WMODE == 1) wv[k] = buf_ld<false>(make_rsrc(b_w + (int64_t)(k * R2) * d.w_sj), l_w | off, 0);
+                v[k] = from2(buf_ld<NT_LD>(make_rsrc(b_in + (int64_t)(k * R2) * d.in_sj), l_in | off, 0));
+                if (WMODE == 1) wv[k] = from2(buf_ld<false>(make_rsrc(b_w + (int64_t)(k * R2) * d.w_sj), l_w | off, 0));
             }
         }
 #pragma unroll
         for (int k = 0; k < R1; ++k) {
             if (HALF_IN && (k < R1 / 4 || k >= 3 * R1 / 4)) continue;
-            if (WMODE == 1) v[k] = cmul(v[k], wv[k]);
-            if (inv) v[k].y = -v[k].y;
+            if (WMODE == 1) v[k] = cxmul(v[k], wv[k]);
+            if (inv) v[k] = cconj(v[k]);
         }
     }
     __syncthreads();            // twiddle table visible (the global loads above are already in flight)
-    if (HALF_IN) RegFFTHalfIn<R1>::run(v);
-    else RegFFT<R1>::run(v);
+    if (HALF_IN) PFFTHalfIn<R1>::run(v);
+    else PFFT<R1>::run(v);
 #pragma unroll
-    for (int k = 1; k < R1; ++k) v[k] = cmul(v[k], tws[t * k]);
+    for (int k = 1; k < R1; ++k) v[k] = cxmul(v[k], from2(tws[t * k]));
 
     // ---- exchange + stage 2 in B2 = R1/16 rounds.  Stage-2 butterfly b2 = t + 16*q needs, from every
     // stage-1 thread b, exactly its output k = b2: round q therefore moves only the outputs
@@ -424,30 +526,31 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
     for (int q = 0; q < B2; ++q) {
         if (q > 0) __syncthreads();             // the previous round's reads are done
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) lw[kk * (AXIS0 ? 1 : W)] = v[16 * q + kk];
+        for (int kk = 0; kk < 16; ++kk) lw[kk * (AXIS0 ? 1 : W)] = to2(v[16 * q + kk]);
         __syncthreads();
-        float2 u[R2];
+        cx u[R2];
 #pragma unroll
-        for (int r = 0; r < R2; ++r) u[r] = lr[r * (AXIS0 ? 17 : 16 * W)];
-        RegFFT<R2>::run(u);
-        float2 wv[R2];          // kept outputs j = t + 16*(q + r*B2): bit q + r*B2 of obits
+        for (int r = 0; r < R2; ++r) u[r] = from2(lr[r * (AXIS0 ? 17 : 16 * W)]);
+        PFFT<R2>::run(u);
+        cx wv[R2];          // kept outputs j = t + 16*(q + r*B2): bit q + r*B2 of obits
         if (WMODE >= 2) {
 #pragma unroll
             for (int r = 0; r < R2; ++r) {
                 if (HALF_OUT && (r < R2 / 4 || r >= 3 * R2 / 4)) continue;
                 const bool stat = !BOXED || HALF_OUT || HALF == 3;
                 const unsigned off = stat ? 0u : (unsigned)__builtin_amdgcn_sbfe((int)~obits, q + r * B2, 1);
-                if (AXIS0) wv[r] = buf_ld<false>(r_w, l_w | off, (unsigned)(q * T + r * R1) * 8u);
-                else wv[r] = buf_ld<false>(make_rsrc(b_w + (int64_t)(q * T + r * R1) * d.w_sj), l_w | off, 0);
+                if (AXIS0) wv[r] = from2(buf_ld<false>(r_w, l_w | off, (unsigned)(q * T + r * R1) * 8u));
+                else wv[r] = from2(buf_ld<false>(make_rsrc(b_w + (int64_t)(q * T + r * R1) * d.w_sj), l_w | off, 0));
             }
         }
 #pragma unroll
         for (int r = 0; r < R2; ++r) {
             if (HALF_OUT && (r < R2 / 4 || r >= 3 * R2 / 4)) continue;          // never stored
             const bool stat = !BOXED || HALF_OUT || HALF == 3;
-            float2 a = u[r];
-            if (inv) a.y = -a.y;
-            if (WMODE >= 2) a = cmulc(wv[r], a);
+            cx ac = u[r];
+            if (inv) ac = cconj(ac);
+            if (WMODE >= 2) ac = cxmulc(wv[r], ac);
+            float2 a = to2(ac);
             const unsigned off = stat ? 0u : (unsigned)__builtin_amdgcn_sbfe((int)~obits, q + r * B2, 1);
             if (SUMW) {
                 // coil combination: the SUMW sub-columns (coils) of a column sit in SUMW consecutive lanes; data-parallel
