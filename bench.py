@@ -35,28 +35,34 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROA
 # arguments are <R1, R2, T, W, AXIS0, WMODE, BOXED, HALF> (indigo_amd/csrc/ig_fft.hip); which instantiation a pass
 # runs depends on the grid layout (bench default: 2 = coils interleaved when the rank holds 2, 4 or 8 coils).
 def kernel_symbols(layout, ncoils):
-    f = "k_fft_2stage<32, 16, 16, 16, %s>"
+    f = "k_fft_2stage<32, 16, 16, %s>"
     m = {
-        "fft_2stage_axis0": f % "true, 0, false, 0",
-        "fft_2stage_axis1": f % "false, 0, false, 0",
-        "fft_2stage_axis2": f % "false, 0, false, 0",
-        # zero-pad-aware passes of the fused ZpadFFT leaf: strided passes with the image half known at compile time
-        # (HALF 1: half input box + run-time output support; HALF 2: run-time input support + half output box)
-        "fft_pad_y": f % "false, 0, true, 1", "fft_pad_z": f % "false, 0, true, 1",
-        "fft_crop_y": f % "false, 0, true, 2", "fft_crop_z": f % "false, 0, true, 2",
+        "fft_2stage_axis0": f % "16, true, 0, false, 0",
+        "fft_2stage_axis1": f % "16, false, 0, false, 0",
+        "fft_2stage_axis2": f % "16, false, 0, false, 0",
         "csrmm_gather": "k_csrmm_gather<8, 8, false, 0>",
     }
     if layout == 2:
-        # coil-summing last pass: WMODE = 3 + log2(coils)
-        m.update({"fft_pad_x": f % "false, 1, true, 3", "fft_crop_x": f % ("false, %d, true, 4" % (3 + ncoils.bit_length() - 1)),
-                  "csrmm_rowlane_conj": "k_csrmm_dense64<%d, true, true>" % ncoils})
+        # Strided passes over the combined (coil, kx) index.  HALF 1: half input box + run-time output support (pad y/z),
+        # HALF 2: run-time input support + half output box (crop z/y); 32-column tiles (W = 32) for the half-input
+        # variants and for the y pass at its 16 MB stride (launch_2stage in ig_fft.hip); the last pass sums the coils
+        # (WMODE = 3 + log2(coils)).
+        m.update({"fft_pad_x": f % "16, false, 1, true, 3",
+                  "fft_pad_y": f % "32, false, 0, true, 1", "fft_pad_z": f % "32, false, 0, true, 1",
+                  "fft_crop_z": f % "16, false, 0, true, 2", "fft_crop_y": f % "32, false, 0, true, 2",
+                  "fft_crop_x": f % ("16, false, %d, true, 4" % (3 + ncoils.bit_length() - 1)),
+                  "csrmm_rowlane_conj": "k_csrmm_dense64<%d, true, true>" % ncoils,
+                  "csrmm_gather": {8: "k_csrmm_gather_v<4, 2, 8, false, 0>", 4: "k_csrmm_gather_v<2, 2, 8, false, 0>",
+                                   2: "k_csrmm_gather_v<2, 1, 8, false, 0>"}.get(ncoils, "k_csrmm_gather")})
     else:
-        m.update({"fft_pad_x": f % "true, 1, true, 3", "fft_crop_x": f % "true, 2, true, 4",
+        m.update({"fft_pad_x": f % "16, true, 1, true, 3", "fft_crop_x": f % "16, true, 2, true, 4",
+                  "fft_pad_y": f % "16, false, 0, true, 1", "fft_pad_z": f % "16, false, 0, true, 1",
+                  "fft_crop_y": f % "16, false, 0, true, 2", "fft_crop_z": f % "16, false, 0, true, 2",
                   "csrmm_rowlane_conj": "k_csrmm_dense64<%d, true, false>" % ncoils})
     return m
 
 
-PMC_SUMMARY = os.path.join("profiles", "r01h_pmc_traffic.json")
+PMC_SUMMARY = os.path.join("profiles", "r01i_pmc_traffic.json")
 
 
 def pmc_traffic(kernel, grid, ncoils, image):
