@@ -853,7 +853,7 @@ int launch_gather(ig_ctx* ctx, int64_t rows, int64_t xrows, int64_t N, int64_t n
     // ... and for wide packed panels with short rows, where a row-slot's 8-byte stores would each hit a different
     // line of Y (config 3's transpose, 64 columns, 3 nonzeros/row: 15.7 ms row-per-lane vs 56.6 ms row-slot; its
     // forward, 27 nonzeros/row, is the other way round: 4.8 vs 17.1 ms)
-    const bool rowlane = ((s.NL == 1 && nnz <= 2 * rows) || (packed && N >= 16 && nnz <= 8 * rows)) &&
+    const bool rowlane = (nnz <= 2 * rows || (packed && N >= 16 && nnz <= 8 * rows)) &&
                          env_flag("INDIGO_HIP_SPMM_ROWLANE", true);
     if (rowlane) {
         ig_prof_scope prof(ctx, CONJ ? "csrmm_rowlane_conj" : "csrmm_rowlane");

@@ -276,6 +276,62 @@ def test_csrmm_edge_cases(hip):
         np.testing.assert_allclose(ya_d.to_host(), A.conj().T @ xa, rtol=RTOL, atol=1e-4)
 
 
+@pytest.mark.parametrize("N", [1, 2, 4, 8])
+def test_csrmm_sparse_rows_and_interleaved_panels(hip, N):
+    """mostly-empty rows with a few very long ones (a transposed gridding matrix in miniature): the dense-lane
+    adjoint, its deferred-row lists, and -- for 2/4/8 columns -- the row-major (coil-interleaved) panel entry points
+    ig_ccsrmm_il / ig_ccsrmm_t_grid_il / ig_csum_il against scipy on the same numbers"""
+    rng = np.random.default_rng(11)
+    T, P = 6000, 50000                                # A: T x P, 9 taps per row; A^T has ~1 nonzero per row
+    cols = np.concatenate([rng.integers(0, P, (T, 8)), rng.integers(100, 104, (T, 1))], axis=1)   # columns 100..103: ~1500 each
+    A = spp.csr_matrix((rand64c(T * 9, seed=1), cols.reshape(-1), np.arange(0, T * 9 + 1, 9)), shape=(T, P))
+    A.sum_duplicates()
+    A_d = hip.csr_matrix(hip, A)
+    x, k = rand64c(P, N, seed=2), rand64c(T, N, seed=3)
+    y_d, z_d = hip.zero_array((T, N), C64), hip.copy_array(np.full((P, N), np.nan, dtype=C64, order='F'))
+    A_d.forward(y_d, hip.copy_array(x))
+    A_d.adjoint(z_d, hip.copy_array(k))
+    ref_f, ref_a = A @ x, A.conj().T @ k
+    assert rel_err(y_d.to_host(), ref_f) < RTOL and rel_err(z_d.to_host(), ref_a) < RTOL
+    if N == 1:
+        return
+    B_d = hip.csr_matrix(hip, A)
+    B_d.set_grid_interleaved(True)
+    il = lambda a: np.asfortranarray(np.ascontiguousarray(a).reshape(-1).reshape(a.shape, order='F'))   # memory (i, c) -> i*N + c
+    un = lambda a: np.asfortranarray(a).reshape(-1, order='F').reshape(a.shape)
+    y_d = hip.zero_array((T, N), C64)
+    B_d.forward(y_d, hip.copy_array(il(x)), alpha=0.5 - 2j)
+    assert rel_err(y_d.to_host(), (0.5 - 2j) * ref_f) < RTOL
+    z_d = hip.copy_array(np.full((P, N), np.nan, dtype=C64, order='F'))
+    B_d.adjoint(z_d, hip.copy_array(k), alpha=2.0)
+    assert rel_err(un(z_d.to_host()), 2.0 * ref_a) < RTOL
+    s_d = hip.copy_array(rand64c(P, 1, seed=4))
+    s0 = s_d.to_host().copy()
+    hip.sum_columns(s_d, z_d, alpha=1j, beta=0.5, interleaved=True)
+    np.testing.assert_allclose(s_d.to_host()[:, 0], 0.5 * s0[:, 0] + 1j * 2.0 * ref_a.sum(axis=1), rtol=1e-4, atol=1e-3)
+    with pytest.raises(AssertionError):
+        B_d.adjoint(z_d, hip.copy_array(k), beta=1.0)             # interleaved adjoint is beta = 0 only
+
+
+def test_interleaved_entry_points_reject_bad_arguments(hip):
+    import ctypes
+    L, ctx = hip._L, hip._ctx
+    a = hip.zero_array((64,), C64)
+    i32 = hip.copy_array(np.zeros(65, dtype=np.int32))
+    vp = lambda d: ctypes.c_void_p(d._arr)
+    # 3 columns: not a power of two
+    assert L.ig_ccsrmm_il(ctx, 4, 4, 3, 0, 1.0, 0.0, vp(a), vp(i32), vp(i32), vp(a), 0.0, 0.0, vp(a), 4) != 0
+    # 16 columns: the interleaved adjoint supports 2, 4, 8
+    assert L.ig_ccsrmm_t_grid_il(ctx, 4, 4, 16, 0, 1.0, 0.0, vp(a), vp(i32), vp(i32), vp(a), 4, vp(a), None, 0, 0) != 0
+    assert b"columns" in L.ig_last_error(ctx)
+    # coil-summing cropped transform needs a layout-2 plan
+    plan, ws = hip._padded_plan((256, 256, 256), (64, 64, 64), (128, 128, 128), 2, 1)
+    assert L.ig_fft_exec_cropped_sum(plan, vp(a), vp(a), vp(a), vp(a), None) != 0
+    # layout 2 with 3 coils is refused at plan time
+    with pytest.raises(RuntimeError):
+        hip._padded_plan((256, 256, 256), (64, 64, 64), (128, 128, 128), 3, 2)
+
+
 def test_csrmm_config1_spmm_example(hip, oracle_backend):
     """BASELINE config 1 (examples/spmm.py scaled up): 1e4 x 1e4, 1 % nnz, 8 RHS, vs the numpy oracle"""
     rng = np.random.default_rng(1)
