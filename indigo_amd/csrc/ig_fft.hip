@@ -10,6 +10,12 @@
 // [outer][n][inner] (inner contiguous), i.e. inner*outer independent
 // "columns" of n elements with stride `inner`.
 //
+//  * two-stage register kernel k_fft_2stage (n = 512 = 32x16, n = 256 = 16x16; every pass of the SENSE path):
+//    a thread loads its 32 (16) inputs straight from HBM, runs a register DFT, hands the results over through LDS
+//    in two 32 KB rounds, runs the second register DFT and stores straight back.  The same kernel serves the
+//    zero-pad-aware forward / cropped inverse transforms (boxes, diagonal weights, k-space support bitmap,
+//    coil-interleaved layouts, coil combination) through one pass descriptor; see PassDesc and the kernel below.
+//
 //  * LDS kernel (n <= 4096 with prime factors in {2,3,5,7}):
 //    a workgroup owns a tile of W neighbouring columns.  The tile is loaded
 //    with coalesced global reads (for axis 0, where a column is a contiguous
@@ -36,8 +42,7 @@
 namespace {
 
 // Non-temporal loads/stores in the 2-stage axis passes (every byte is touched exactly once per pass).
-// A/B on the 256^3 x 8 SENSE eval, same box, same process layout: 21.44 ms (off) -> 20.54 ms (both on);
-// loads alone 20.77, stores alone 20.98.
+// A/B on the 256^3 x 8 SENSE eval: 8.95 ms (either one off) -> 8.58 ms (both on).
 #ifndef IG_FFT_MINWAVES
 #define IG_FFT_MINWAVES 1      // minimum waves per SIMD the 2-stage kernels are compiled for (register cap)
 #endif

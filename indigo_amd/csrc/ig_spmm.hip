@@ -20,6 +20,11 @@
 // get one row per wave, diagonal-like matrices with one column get a row per
 // lane, and in both cases loads of val/col are contiguous across the wave.
 //
+// Besides this row-slot gather (k_csrmm_gather, and k_csrmm_gather_v with 16-byte loads over row-major panels) the
+// file holds the kernels for matrices with mostly empty rows (transposed gridding matrices): k_csrmm_dense64 (64
+// nonzeros per trip, one per lane, LDS segmented sums), k_csrmm_rowlane (a row per lane), the deferred-row kernels for
+// the few very long rows, the panel repacking kernels, and the scatter form of the adjoint.
+//
 // Everything here is bandwidth/latency bound integer+fp32 work: no MFMA.
 #include "ig_common.h"
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
