@@ -375,6 +375,7 @@ struct PassDesc {
     int cw;
     int64_t in_sa, out_sa, w_sa;
     int tile_shift;             // tile_range / tile_bits entries are shared by 2^tile_shift consecutive tiles
+    int xcd_remap;              // filled in by the launcher
     int in_lo, in_hi, out_lo, out_hi;
     int inverse;
     // optional per-tile override of the box along the transform axis (strided passes, W | ext0):
@@ -423,7 +424,14 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
     const int t = AXIS0 ? (tid % T) : (tid / W);
     const int w = AXIS0 ? (tid / T) : (tid % W);
     // ---- the workgroup's tile: W consecutive k0 of one (k1, k2) row; everything below is wave-uniform
-    const unsigned tile = blockIdx.x;
+    // Workgroups are dealt round-robin to the 8 XCDs.  Optionally give each XCD a contiguous range of tiles instead
+    // (INDIGO_HIP_FFT_XCD=1) -- measured 10 % SLOWER on the z passes: with the default dealing all XCDs stream
+    // through the same DRAM pages together, and no tile shares a cache line with another anyway.
+    unsigned tile = blockIdx.x;
+    if (d.xcd_remap) {
+        const unsigned nb = gridDim.x, q = nb >> 3, rem = nb & 7, xcd = tile & 7, idx = tile >> 3;
+        tile = (xcd < rem) ? xcd * (q + 1) + idx : rem * (q + 1) + (xcd - rem) * q + idx;
+    }
     const unsigned tr = tile % d.tpr, rest = tile / d.tpr;
     const unsigned k1 = rest % d.ext1, k2 = rest / d.ext1;
     const int64_t k0u = (int64_t)tr * ((!AXIS0 && d.cw) ? W / d.cw : W);
@@ -805,6 +813,8 @@ int launch_2stage(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d_in, bool ax
     const int64_t blocks = tpr * (d.ncols / d.ext0);           // ncols = ext0 * ext1 * ext2
     IG_REQUIRE(ctx, blocks <= 0x7fffffffLL && d.ext1 <= 0x7fffffffLL, "ig_fft: too many tiles");
     d.tpr = (unsigned)tpr;
+    static const int xcd_remap = getenv("INDIGO_HIP_FFT_XCD") ? atoi(getenv("INDIGO_HIP_FFT_XCD")) : 0;
+    d.xcd_remap = xcd_remap;
     {   // every in-tile byte offset must stay inside the 2 GB descriptor window
         const int64_t lim = 0x7fffffffLL / 8;
         // (strided passes re-base per 16 elements: only 31 element steps plus the tile's lanes must fit)
