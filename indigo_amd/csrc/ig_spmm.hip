@@ -764,7 +764,12 @@ inline Shape pick_shape(int64_t rows, int64_t N, int64_t nnz) {
     Shape s;
     s.CL = pow2_ceil(N, 64);
     const int64_t mean = rows > 0 ? (nnz + rows - 1) / rows : 1;
-    s.NL = pow2_ceil(mean > 0 ? mean : 1, 64 / s.CL);
+    // a lane takes four nonzeros per trip, so 8 nonzero-lanes cover a 32-nonzero row in one trip: more lanes per row
+    // only mean fewer rows per wave (the kernel is latency bound)
+    static const int nl_cap = getenv("INDIGO_HIP_SPMM_NLCAP") ? atoi(getenv("INDIGO_HIP_SPMM_NLCAP")) : 8;
+    int cap = 64 / s.CL;
+    if (nl_cap > 0 && mean <= 4 * nl_cap && cap > nl_cap) cap = nl_cap;
+    s.NL = pow2_ceil(mean > 0 ? mean : 1, cap);
     return s;
 }
 
