@@ -858,7 +858,7 @@ int launch_2stage(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d_in, bool ax
     // the half-output variants spill at that cap and lose on small-stride passes (cropped z pass: +16 %).
     const bool big_stride = (d.in_sj > d.out_sj ? d.in_sj : d.out_sj) * 8 >= (1 << 20);
     if (use_w32 && ax.n == 512 && !axis0 && wmode == 0 && !d.cw && d.ext0 % 32 == 0 &&
-        (half == 1 || half == 3 || ((half == 2 || half == 4) && (big_stride || use_w32 >= 2))) &&
+        (((half == 1 || half == 3) && (big_stride || use_w32 != 3)) || ((half == 2 || half == 4) && (big_stride || use_w32 == 2))) &&
         (!d.tile_range || d.tile_shift >= 1)) {
         // 32-column tiles: 256-byte segments per row, 512 threads, 69.6 KB of LDS (2 workgroups per CU)
         PassDesc d2 = d;
