@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""CG on the SENSE normal equations (the caller of the hot path, SURVEY 8f / indigo/backends/backend.py:639-689):
+iterations per second on the headline problem, next to the bare A^H A evaluation rate.
+
+    python tools/cg_bench.py [iterations]
+"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from indigo_amd.backends import get_backend
+from indigo_amd.sense import SenseProblem, normal_operator
+from indigo_amd.util import rand64c
+
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+B = get_backend("hip")
+p = SenseProblem.synthetic((256,) * 3, 8, nspokes=3617, nreadout=512, width=2, ntable=128, oversamp=2.0, seed=4)
+A = p.build_zpadfft(B)
+AHA = normal_operator(A, lamda=0.01)
+b = A.H * rand64c(A.shape[0], 1, seed=2)            # right-hand side A^H k
+x0 = np.zeros_like(b)
+B.cg(AHA, b, x0.copy(order='F'), maxiter=2)          # warm-up: plans, scratch, transposes
+B.barrier()
+t0 = time.perf_counter()
+hist = B.cg(AHA, b, x0.copy(order='F'), maxiter=iters)
+B.barrier()
+t = time.perf_counter() - t0
+print("CG: %d iterations in %.1f ms -> %.2f ms/iteration (%.1f it/s); relative residual %.3e -> %.3e" % (
+    len(hist), t * 1e3, t * 1e3 / max(len(hist), 1), len(hist) / t, hist[0], hist[-1]))
