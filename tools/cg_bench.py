@@ -26,3 +26,14 @@ B.barrier()
 t = time.perf_counter() - t0
 print("CG: %d iterations in %.1f ms -> %.2f ms/iteration (%.1f it/s); relative residual %.3e -> %.3e" % (
     len(hist), t * 1e3, t * 1e3 / max(len(hist), 1), len(hist) / t, hist[0], hist[-1]))
+
+if os.environ.get("CG_PROFILE"):
+    B.profile(True)
+    B.cg(AHA, b, x0.copy(order='F'), maxiter=iters)
+    B.barrier()
+    B.profile(False)
+    rep = B.profile_report()
+    tot = sum(v['total_ms'] for v in rep.values())
+    print("profiled kernel time per iteration: %.2f ms" % (tot / iters))
+    for k, v in sorted(rep.items(), key=lambda kv: -kv[1]['total_ms']):
+        print("  %-24s %5d launches  avg %7.3f ms  per-iteration %6.3f ms" % (k, v['launches'], v['avg_ms'], v['total_ms'] / iters))
