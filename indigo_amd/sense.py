@@ -261,7 +261,11 @@ def normal_operator(A, lamda=0.0, ncols=1):
     """AHA = A^H A (+ lamda I), with the scratch arena sized for it (examples/pics.py:195)."""
     AHA = A.H * A
     if lamda:
-        AHA = AHA + lamda * A._backend.Eye(A.shape[1])
+        # lamda*I + A^H A rather than A^H A + lamda*I: a Sum evaluates its right child first, with the caller's beta,
+        # and its left child on top (operators.py Sum._eval, reference operators.py:566-567), so this order lets the
+        # adjoint's last leaf run with beta = 0 -- the form its fused kernels (coil combination inside the last
+        # transform pass) take -- and adds lamda*x with one axpby
+        AHA = lamda * A._backend.Eye(A.shape[1]) + AHA
     AHA._name = 'SENSE'
     reserve_for(AHA, ncols)
     return AHA
