@@ -863,7 +863,13 @@ int launch_gather(ig_ctx* ctx, int64_t rows, int64_t xrows, int64_t N, int64_t n
     // ... and for wide packed panels with short rows, where a row-slot's 8-byte stores would each hit a different
     // line of Y (config 3's transpose, 64 columns, 3 nonzeros/row: 15.7 ms row-per-lane vs 56.6 ms row-slot; its
     // forward, 27 nonzeros/row, is the other way round: 4.8 vs 17.1 ms)
-    const bool rowlane = (nnz <= 2 * rows || (packed && N >= 16 && nnz <= 8 * rows)) &&
+    // wide row-major panels (16, 32, 64 columns) with rows of 8+ nonzeros: the vector row-slot kernel below.  (For the
+    // short rows of a transposed gridding matrix it was measured no better than the row-per-lane kernel: 13.0 + 2.1 ms
+    // against 14.9 + 0.7 ms at 64 columns -- that product is bound by its 32-byte result stores.)
+    static const int vw = getenv("INDIGO_HIP_SPMM_VW") ? atoi(getenv("INDIGO_HIP_SPMM_VW")) : 4;
+    const bool wide_v = vw > 0 && packed && sxc == 1 && N == sxr && (N == 64 || N == 32 || N == 16) && !y_il &&
+                        nnz >= 8 * rows && (reinterpret_cast<uintptr_t>(X) & 15u) == 0;
+    const bool rowlane = !wide_v && (nnz <= 2 * rows || (packed && N >= 16 && nnz <= 8 * rows)) &&
                          env_flag("INDIGO_HIP_SPMM_ROWLANE", true);
     if (rowlane) {
         ig_prof_scope prof(ctx, CONJ ? "csrmm_rowlane_conj" : "csrmm_rowlane");
@@ -923,19 +929,27 @@ int launch_gather(ig_ctx* ctx, int64_t rows, int64_t xrows, int64_t N, int64_t n
         ig_prof_scope prof(ctx, CONJ ? "csrmm_gather_conj" : "csrmm_gather");
         // row-major panel of 2, 4 or 8 columns (packed, or the coil-interleaved grid), rows of 8+ nonzeros on average:
         // several rows per wave with 16-byte panel loads (forward gridding, 8 coils: 0.50 ms against 0.97 ms)
-        static const int vw = getenv("INDIGO_HIP_SPMM_VW") ? atoi(getenv("INDIGO_HIP_SPMM_VW")) : 4;
-        if (vw > 0 && packed && sxc == 1 && N == sxr && (N == 8 || N == 4 || N == 2) && nnz >= 8 * rows &&
-            (reinterpret_cast<uintptr_t>(X) & 15u) == 0) {
-#define IG_GV(VW_, CLV_) do {                                                                              \
-            const int rpw_v = 64 / (CLV_ * 8);                                                             \
+        if (wide_v || (vw > 0 && packed && sxc == 1 && N == sxr && (N == 8 || N == 4 || N == 2) &&
+                       nnz >= 8 * rows && (reinterpret_cast<uintptr_t>(X) & 15u) == 0)) {
+#define IG_GV(VW_, CLV_, NL_) do {                                                                         \
+            const int rpw_v = 64 / (CLV_ * NL_);                                                           \
             const int64_t vblocks = ((rows + rpw_v - 1) / rpw_v + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;  \
-            if (b0) hipLaunchKernelGGL((k_csrmm_gather_v<VW_, CLV_, 8, CONJ, 0>), dim3((unsigned)vblocks), dim3(BLK), 0, ctx->stream, \
+            if (b0) hipLaunchKernelGGL((k_csrmm_gather_v<VW_, CLV_, NL_, CONJ, 0>), dim3((unsigned)vblocks), dim3(BLK), 0, ctx->stream, \
                         rows, rowptr, colind, vals, X, sxr, Y, ldy, alpha, beta, xcd, wl, thr_mid, thr_long);   \
-            else    hipLaunchKernelGGL((k_csrmm_gather_v<VW_, CLV_, 8, CONJ, 1>), dim3((unsigned)vblocks), dim3(BLK), 0, ctx->stream, \
+            else    hipLaunchKernelGGL((k_csrmm_gather_v<VW_, CLV_, NL_, CONJ, 1>), dim3((unsigned)vblocks), dim3(BLK), 0, ctx->stream, \
                         rows, rowptr, colind, vals, X, sxr, Y, ldy, alpha, beta, xcd, wl, thr_mid, thr_long); } while (0)
-            if (N == 8) { if (vw >= 8) IG_GV(8, 1); else if (vw >= 4) IG_GV(4, 2); else IG_GV(2, 4); }     // 8 / 4 / 2 rows per wave
-            else if (N == 4) IG_GV(2, 2);                                                                  // 4 rows per wave
-            else IG_GV(2, 1);                                                                              // 8 rows per wave
+            if (N == 8) { if (vw >= 8) IG_GV(8, 1, 8); else if (vw >= 4) IG_GV(4, 2, 8); else IG_GV(2, 4, 8); }   // 8 / 4 / 2 rows per wave
+            else if (N == 4) IG_GV(2, 2, 8);                                                               // 4 rows per wave
+            else if (N == 2) IG_GV(2, 1, 8);                                                               // 8 rows per wave
+            else if (nnz >= 8 * rows) {                       // long rows: spread a row's nonzeros over nonzero-lanes
+                if (N == 16) IG_GV(4, 4, 8);                                                               // 2 rows per wave
+                else if (N == 32) IG_GV(4, 8, 8);                                                          // a wave per row, 32 nonzeros per trip
+                else IG_GV(4, 16, 4);                                                                      // 64 columns: 16 nonzeros per trip
+            } else {                                          // short rows (a transposed gridding matrix): one trip each
+                if (N == 16) IG_GV(4, 4, 1);                                                               // 16 rows per wave
+                else if (N == 32) IG_GV(4, 8, 1);                                                          // 8 rows per wave
+                else IG_GV(4, 16, 1);                                                                      // 4 rows per wave
+            }
 #undef IG_GV
             IG_LAUNCH_CHECK(ctx, "k_csrmm_gather_v");
         } else {
