@@ -546,6 +546,91 @@ k_csrmm_dense64(int64_t M, const int32_t* __restrict__ rowptr, const int32_t* __
     }
 }
 
+// Wide row-major panel (exactly 64 columns, packed), short rows: the adjoint of a gridding matrix applied to a
+// 64-column panel (BASELINE config 3).  A lane per row (k_csrmm_rowlane) gathers 64-byte pieces of 64 different panel
+// rows per instruction and walks its row once per column chunk; here the lanes run along the 64 COLUMNS, so one
+// nonzero is one coalesced 512-byte read, a wave sums 16 consecutive rows one after the other (their nonzeros -- one
+// contiguous CSR range -- are fetched 64 at a time, one per lane, and broadcast), and the workgroup's 64 x 64 result
+// tile goes through LDS so that the stores are 512 contiguous bytes per panel column.
+template <bool CONJ, int BMODE>
+__global__ void __launch_bounds__(BLK)
+k_csrmm_rowtile64(int64_t M, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
+                  const float2* __restrict__ vals, const float2* __restrict__ Xp,
+                  float2* __restrict__ Y, int64_t ldy, float2 alpha, float2 beta,
+                  WorkLists wl, int32_t thr_mid, int32_t thr_long) {
+    __shared__ float2 tile[64][65];
+    __shared__ unsigned char skip[64];                   // row was handed to the deferred-row kernels
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t row0 = (int64_t)blockIdx.x * 64 + wv * 16;      // this wave's 16 rows
+    // row pointers of the 16 rows (+1) in lanes 0..16
+    const int64_t rr = row0 + (lane < 17 ? lane : 16);
+    const int32_t rp = rowptr[rr < M ? rr : M];
+    const int32_t rpn = __shfl_down(rp, 1, 64);
+    const int32_t len = (lane < 16 && row0 + lane < M) ? rpn - rp : 0;
+    bool deferred = false;
+    {
+        const int sub = (int)((blockIdx.x * WAVES_PER_BLOCK + wv) & (WL_SUB - 1));
+        if (wl_append(wl, 0, sub, len > thr_mid && len <= thr_long, (int32_t)(row0 + lane))) deferred = true;
+        if (wl_append(wl, 1, sub, len > thr_long, (int32_t)(row0 + lane))) deferred = true;
+    }
+    if (lane < 16) skip[wv * 16 + lane] = deferred ? 1 : 0;
+    const uint64_t defmask = __ballot(deferred);
+    for (int r = 0; r < 16; ++r) tile[wv * 16 + r][lane] = make_float2(0.f, 0.f);
+    const int32_t P0 = __shfl(rp, 0, 64), P1 = __shfl(rp, 16, 64);
+    float2 acc = make_float2(0.f, 0.f);
+    int cur = 0;                                          // row (0..15) the accumulator belongs to
+    for (int32_t base = P0; base < P1; base += 64) {
+        const int32_t p = base + lane;
+        const bool ok = p < P1;
+        const int32_t k_i = ok ? colind[p] : 0;
+        const float2 v_i = ok ? vals[p] : make_float2(0.f, 0.f);
+        // owner row of nonzero p: the last of the 16 rows whose pointer is <= p
+        int r_i = 0;
+#pragma unroll
+        for (int step = 8; step >= 1; step >>= 1) {
+            const int32_t t = __shfl(rp, r_i + step, 64);
+            if (t <= p) r_i += step;
+        }
+        const int nb = (P1 - base) < 64 ? (P1 - base) : 64;
+        constexpr int UT = 16;                             // independent 512-byte panel-row reads in flight per wave
+        for (int j0 = 0; j0 < nb; j0 += UT) {
+            int32_t kk[UT]; float2 vv[UT], xx[UT]; int rj[UT];
+#pragma unroll
+            for (int u = 0; u < UT; ++u) {
+                const int j = j0 + u < nb ? j0 + u : nb - 1;
+                kk[u] = __shfl(k_i, j, 64);
+                vv[u] = make_float2(__shfl(v_i.x, j, 64), __shfl(v_i.y, j, 64));
+                rj[u] = __shfl(r_i, j, 64);
+                if (j0 + u >= nb) vv[u] = make_float2(0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < UT; ++u) xx[u] = Xp[(int64_t)kk[u] * 64 + lane];
+#pragma unroll
+            for (int u = 0; u < UT; ++u) {
+                if (rj[u] != cur) {                       // wave-uniform: rows change in CSR order
+                    tile[wv * 16 + cur][lane] = acc;
+                    acc = make_float2(0.f, 0.f);
+                    cur = rj[u];
+                }
+                if (!((defmask >> rj[u]) & 1ull)) acc_nz<CONJ>(acc, vv[u], xx[u]);
+            }
+        }
+    }
+    tile[wv * 16 + cur][lane] = acc;
+    __syncthreads();
+    // column-wise stores: wave wv writes columns wv*16 .. +15, lanes = the workgroup's 64 rows
+    const int64_t orow = (int64_t)blockIdx.x * 64 + lane;
+    if (orow < M && !skip[lane]) {
+#pragma unroll 4
+        for (int c = wv * 16; c < wv * 16 + 16; ++c) {
+            float2* yp = Y + (int64_t)c * ldy + out_row(wl.yperm, orow);
+            float2 out = cmul(alpha, tile[lane][c]);
+            if (BMODE == 1) cfma(out, beta, *yp);
+            *yp = out;
+        }
+    }
+}
+
 // (A cooperative variant -- the 64 rows' nonzeros compacted into an LDS list, four lanes per nonzero,
 // per-row LDS accumulators with ds_add_f32 -- was built and measured on the 134M-row transposed gridding
 // matrix: 9.2 ms against 4.3 ms for the kernel above; 3.6 ms of that were the LDS float atomics on
@@ -897,6 +982,16 @@ int launch_gather(ig_ctx* ctx, int64_t rows, int64_t xrows, int64_t N, int64_t n
         static const int unroll = getenv("INDIGO_HIP_SPMM_UNROLL") ? atoi(getenv("INDIGO_HIP_SPMM_UNROLL")) : 2;
         // mostly-empty rows, packed panel of <= 8 columns, beta == 0: the dense-lane kernel
         static const int dense_thr = getenv("INDIGO_HIP_SPMM_DENSE") ? atoi(getenv("INDIGO_HIP_SPMM_DENSE")) : 32;
+        // 64-column packed panel, short rows: lanes along the columns, 64 x 64 result tiles through LDS
+        if (packed && sxc == 1 && N == 64 && sxr == 64 && !y_il && !mask.bits && env_flag("INDIGO_HIP_SPMM_ROWTILE", true)) {
+            const int64_t tblocks = (rows + 63) / 64;
+            IG_REQUIRE(ctx, tblocks <= 0x7fffffffLL, "csrmm: matrix too large for one launch");
+            const int32_t tt = defer ? (thr_long < 512 ? thr_long : 512) : 0x7fffffff;
+            if (b0) hipLaunchKernelGGL((k_csrmm_rowtile64<CONJ, 0>), dim3((unsigned)tblocks), dim3(BLK), 0, ctx->stream,
+                                       rows, rowptr, colind, vals, X, Y, ldy, alpha, beta, wl, tt, thr_long);
+            else    hipLaunchKernelGGL((k_csrmm_rowtile64<CONJ, 1>), dim3((unsigned)tblocks), dim3(BLK), 0, ctx->stream,
+                                       rows, rowptr, colind, vals, X, Y, ldy, alpha, beta, wl, tt, thr_long);
+        } else
         if (dense_thr > 0 && packed && b0 && bufok && nnz <= 2 * rows && N == sxr && (sxr == 8 || sxr == 4 || sxr == 2 || sxr == 1)) {
             const int32_t td = defer ? (thr_long < dense_thr ? thr_long : dense_thr) : 0x7fffffff;
             int64_t dblocks = ((rows + 63) / 64 + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
