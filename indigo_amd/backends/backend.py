@@ -552,10 +552,12 @@ class Backend(object):
 
         Same update sequence as the reference (backend.py:651-689): r = b - A x - lamda x,
         then per iteration one A.eval, five axpby/scale passes, one dot and one norm2.
-        Returns the list of relative residuals.
+        Returns the list of relative residuals.  b_h / x_h may also be device arrays of this backend: x is then
+        updated in place and nothing crosses the host boundary except the two scalars per iteration.
         """
-        x = self.copy_array(x_h, name='x')
-        b = self.copy_array(b_h, name='b')
+        x_dev = isinstance(x_h, self.dndarray)
+        x = x_h if x_dev else self.copy_array(x_h, name='x')
+        b = b_h.copy(name='b') if isinstance(b_h, self.dndarray) else self.copy_array(b_h, name='b')
         Ap = x.copy()
 
         r = b
@@ -575,8 +577,7 @@ class Backend(object):
             self.axpby(1, r, -alpha, Ap)
             r2 = self.pnorm2(r, team)
             beta = r2 / rr
-            self.scale(p, beta)
-            self.axpby(1, p, 1, r)
+            self.axpby(beta, p, 1, r)          # p = beta*p + r in one pass (the reference scales, then adds)
             rr = r2
             resid = float(np.sqrt(rr / r0))
             history.append(resid)
@@ -586,7 +587,8 @@ class Backend(object):
                 break
         else:
             log.info("cg reached maxiter")
-        x.copy_to(x_h)
+        if not x_dev:
+            x.copy_to(x_h)
         return history
 
     def apgd(self, gradf, proxg, alpha, x_h, maxiter=100, team=None):

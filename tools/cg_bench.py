@@ -19,9 +19,11 @@ AHA = normal_operator(A, lamda=0.01)
 b = A.H * rand64c(A.shape[0], 1, seed=2)            # right-hand side A^H k
 x0 = np.zeros_like(b)
 B.cg(AHA, b, x0.copy(order='F'), maxiter=2)          # warm-up: plans, scratch, transposes
+b_d = B.copy_array(b)                                # device-resident right-hand side and iterate
+x_d = B.zero_array(b.shape, b.dtype)
 B.barrier()
 t0 = time.perf_counter()
-hist = B.cg(AHA, b, x0.copy(order='F'), maxiter=iters)
+hist = B.cg(AHA, b_d, x_d, maxiter=iters)
 B.barrier()
 t = time.perf_counter() - t0
 print("CG: %d iterations in %.1f ms -> %.2f ms/iteration (%.1f it/s); relative residual %.3e -> %.3e" % (
