@@ -26,7 +26,7 @@ t0 = time.perf_counter()
 hist = B.cg(AHA, b_d, x_d, maxiter=iters)
 B.barrier()
 t = time.perf_counter() - t0
-print("CG: %d iterations in %.1f ms -> %.2f ms/iteration (%.1f it/s); relative residual %.3e -> %.3e" % (
+print("history:", " ".join("%.3f" % h for h in hist)); print("CG: %d iterations in %.1f ms -> %.2f ms/iteration (%.1f it/s); relative residual %.3e -> %.3e" % (
     len(hist), t * 1e3, t * 1e3 / max(len(hist), 1), len(hist) / t, hist[0], hist[-1]))
 
 if os.environ.get("CG_PROFILE"):
