@@ -845,9 +845,9 @@ int launch_2stage(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d_in, bool ax
     if (use_half && boxed) {
         const bool in_full = d.in_lo <= 0 && d.in_hi >= (int)ax.n, out_full = d.out_lo <= 0 && d.out_hi >= (int)ax.n;
         if (d.in_lo == qn && d.in_hi == 3 * qn && !(d.tile_range && d.tile_range_mode == 2))
-            half = (out_full && !d.tile_range) ? 3 : 1;
+            half = (out_full && !d.tile_range && !d.tile_bits) ? 3 : 1;
         else if (d.out_lo == qn && d.out_hi == 3 * qn && !(d.tile_range && d.tile_range_mode == 1))
-            half = (in_full && !d.tile_range) ? 4 : 2;
+            half = (in_full && !d.tile_range && !d.tile_bits) ? 4 : 2;
         if (wmode == 1 && half != 3) half = 0;      // weighted variants exist for the fully static boxes only
         if (wmode >= 2 && half != 4) half = 0;
         if (((half == 1 || half == 3) && d.inverse) || ((half == 2 || half == 4) && !d.inverse)) half = 0;   // direction is baked in
