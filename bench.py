@@ -1,22 +1,36 @@
 #!/usr/bin/env python3
-"""Headline benchmark: SENSE A^H A evaluations per second (BASELINE.json metric).
+"""Benchmarks of the SENSE hot path on MI355X (BASELINE.json metric and configs).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config {1,2,3,4,5}]
 
-One "step" is one evaluation y = A^H A x of the composed non-Cartesian SENSE
-normal operator (the reference's `-O3` tree: S' -> FFT -> G' -> G'^H -> IFFT -> S'^H;
-by default with S' and the FFT fused into the zero-pad-aware `ZpadFFT` leaf, `--tree o3`
-runs the reference's leaves one by one) on synthetic inputs already resident in HBM: image 256^3, 8 coils, oversampled
-grid 512^3, 3-D radial trajectory with 1,851,904 samples, width-4 (indigo
-width=2) Kaiser-Bessel gridding (BASELINE config 4).  For N > 1 (launched by
-torch.distributed.run, one rank per GPU) the 8 coils are sharded over the ranks
-and each evaluation ends in one RCCL all-reduce of the image: strong scaling.
+Default (`--config 4`, BASELINE.json's metric): one "step" is one evaluation y = A^H A x of the composed
+non-Cartesian SENSE normal operator (the reference's `-O3` tree S' -> FFT -> G' -> G'^H -> IFFT -> S'^H, with S' and
+the FFT fused into the zero-pad-aware `ZpadFFT` leaf; `--tree o3` runs the reference's leaves one by one, `--tree
+recipe` reaches the fused leaf through the reference's own recipe + `FuseZpadFFT`) on synthetic inputs already
+resident in HBM: image 256^3, 8 coils, oversampled grid 512^3, 3-D radial trajectory with 1,851,904 samples,
+width-4 (indigo width=2) Kaiser-Bessel gridding.  For N > 1 (launched by torch.distributed.run, one rank per GPU)
+the coils are sharded over the ranks and each evaluation ends in one RCCL all-reduce of the image: strong scaling.
+
+Other configs (each prints its own JSON line, same contract fields):
+    --config 1   examples/spmm.py: random 1e4 x 1e4 CSR (1 % nnz) x 8 RHS -- the reference's CPU-runnable case
+    --config 2   batched 3-D C2C FFT, 256^3 x 16 (the plain fftn/ifftn contract)
+    --config 3   3-D radial gridding CSR (5e7 nnz) x 64-column panel, forward and adjoint
+    --config 5   SENSE 320^3 x 32 coils on the 512^3 grid (oversampling 1.6), coils sharded over the ranks, 8-coil
+                 chunks on a rank (the reference's `batch` hint); `--shard R/W` times rank R's share of a W-rank
+                 run on one GPU without communication (per-rank cost of a run that cannot be launched here)
+The default run also reports config 5 for the same N in the `config5` object (`--no-config5` skips it), so the
+driver's N = 1, 2, 4, 8 series carries the 32-coil problem's scaling next to the headline's.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline     : the dominant kernel's algorithmic bytes per launch / its average launch duration,
-                 measured live with HIP events on the backend's stream during the timed steps
-  cpu_baseline : the numpy oracle (restatement of the reference's numpy backend) timed on the host
-                 on ONE coil of the same problem, scaled to evals/s (single-threaded, baseline only)
+  roofline         : the dominant kernel: algorithmic (compulsory) bytes per launch / average launch duration measured
+                     live with HIP events on the backend's stream; `traffic` = HBM bytes per launch from the
+                     committed rocprofv3 PMC summary of this same command (profiles/)
+  cpu_baseline     : the numpy oracle (restatement of the reference's numpy backend) timed on the host on ONE coil
+                     of the same problem (warm-up + min of 2), scaled to evals/s; single-threaded, baseline only
+  parity_rel_err   : the benchmarked operator with all coils but one switched off vs that oracle evaluation
+  eval_traffic_*   : bytes the whole evaluation really moves (PMC summary) and the fraction of the 8 TB/s peak that
+                     is; `reference_model_*`: the same evaluation priced with the reference's leaf-by-leaf model
+                      -- a speed-up measure, NOT a roofline fraction (fusion removed those bytes)
 """
 import argparse
 import json
@@ -29,54 +43,54 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+PMC_SUMMARIES = {4: os.path.join("profiles", "r02_cfg4_pmc_traffic.json"),
+                 2: os.path.join("profiles", "r02_cfg2_pmc_traffic.json"),
+                 3: os.path.join("profiles", "r02_cfg3_pmc_traffic.json"),
+                 5: os.path.join("profiles", "r02_cfg5_pmc_traffic.json")}
+PMC_NOTE = " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE x2 per the gfx950 note)"
 
 
-# profile-scope name (call site) -> device kernel symbol as rocprofv3 prints it (512-point axes).  The template
-# arguments are <R1, R2, T, W, AXIS0, WMODE, BOXED, HALF> (indigo_amd/csrc/ig_fft.hip); which instantiation a pass
-# runs depends on the grid layout (bench default: 2 = coils interleaved when the rank holds 2, 4 or 8 coils).
-def kernel_symbols(layout, ncoils):
-    f = "k_fft_2stage<32, 16, 16, %s>"
+# profile-scope name (call site) -> device kernel symbol as rocprofv3 prints it.  The template arguments of the FFT
+# kernel are <R1, R2, T, W, AXIS0, WMODE, BOXED, HALF> (indigo_amd/csrc/ig_fft.hip); which instantiation a pass runs
+# depends on the grid layout, the axis length and whether the image box is the middle half of the axis.
+def kernel_symbols(layout, ncoils, half_box=True, n=512):
+    r1 = 32 if n == 512 else 16
+    f = "k_fft_2stage<%d, 16, 16, %%s>" % r1
     m = {
         "fft_2stage_axis0": f % "16, true, 0, false, 0",
         "fft_2stage_axis1": f % "16, false, 0, false, 0",
         "fft_2stage_axis2": f % "16, false, 0, false, 0",
         "csrmm_gather": "k_csrmm_gather<8, 8, false, 0>",
     }
+    lg = ncoils.bit_length() - 1
     if layout == 2:
-        # Strided passes over the combined (coil, kx) index.  HALF 1: half input box + run-time output support (pad y/z),
-        # HALF 2: run-time input support + half output box (crop z/y); 32-column tiles (W = 32) for the half-input
-        # variants and for the y pass at its 16 MB stride (launch_2stage in ig_fft.hip); the last pass sums the coils
-        # (WMODE = 3 + log2(coils)).
-        m.update({"fft_pad_x": f % "16, false, 1, true, 3",
-                  "fft_pad_y": f % "32, false, 0, true, 1", "fft_pad_z": f % "32, false, 0, true, 1",
-                  "fft_crop_z": f % "16, false, 0, true, 2", "fft_crop_y": f % "32, false, 0, true, 2",
-                  "fft_crop_x": f % ("16, false, %d, true, 4" % (3 + ncoils.bit_length() - 1)),
-                  "csrmm_rowlane_conj": "k_csrmm_dense64<%d, true, true>" % ncoils,
-                  "csrmm_gather": {8: "k_csrmm_gather_v<4, 2, 8, false, 0>", 4: "k_csrmm_gather_v<2, 2, 8, false, 0>",
-                                   2: "k_csrmm_gather_v<2, 1, 8, false, 0>"}.get(ncoils, "k_csrmm_gather")})
-    else:
-        m.update({"fft_pad_x": f % "16, true, 1, true, 3", "fft_crop_x": f % "16, true, 2, true, 4",
-                  "fft_pad_y": f % "16, false, 0, true, 1", "fft_pad_z": f % "16, false, 0, true, 1",
-                  "fft_crop_y": f % "16, false, 0, true, 2", "fft_crop_z": f % "16, false, 0, true, 2",
+        gv = {8: "k_csrmm_gather_v<4, 2, 8, false, 0>", 4: "k_csrmm_gather_v<2, 2, 8, false, 0>",
+              2: "k_csrmm_gather_v<2, 1, 8, false, 0>"}.get(ncoils, "k_csrmm_gather")
+        if half_box and n == 512:
+            m.update({"fft_pad_x": f % "16, false, 1, true, 3",
+                      "fft_pad_y": f % "32, false, 0, true, 1", "fft_pad_z": f % "32, false, 0, true, 1",
+                      "fft_crop_z": f % "16, false, 0, true, 2", "fft_crop_y": f % "32, false, 0, true, 2",
+                      "fft_crop_x": f % ("16, false, %d, true, 4" % (3 + lg))})
+        else:
+            m.update({"fft_pad_x": f % "16, false, 1, true, 0",
+                      "fft_pad_y": f % "16, false, 0, true, 0", "fft_pad_z": f % "16, false, 0, true, 0",
+                      "fft_crop_z": f % "16, false, 0, true, 0", "fft_crop_y": f % "16, false, 0, true, 0",
+                      "fft_crop_x": f % ("16, false, %d, true, 0" % (3 + lg))})
+        m.update({"csrmm_rowlane_conj": "k_csrmm_dense64<%d, true, true>" % ncoils, "csrmm_gather": gv})
+    elif layout == 1:
+        h = (3, 1, 1, 2, 2, 4) if half_box else (0,) * 6
+        m.update({"fft_pad_x": f % ("16, true, 1, true, %d" % h[0]), "fft_pad_y": f % ("16, false, 0, true, %d" % h[1]),
+                  "fft_pad_z": f % ("16, false, 0, true, %d" % h[2]), "fft_crop_z": f % ("16, false, 0, true, %d" % h[3]),
+                  "fft_crop_y": f % ("16, false, 0, true, %d" % h[4]), "fft_crop_x": f % ("16, true, 2, true, %d" % h[5]),
                   "csrmm_rowlane_conj": "k_csrmm_dense64<%d, true, false>" % ncoils})
     return m
 
 
-PMC_SUMMARY = os.path.join("profiles", "r01i_pmc_traffic.json")
-
-
-def pmc_traffic(kernel, grid, ncoils, image):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (profiles/), valid only
-    for the configuration it was taken on (image 256^3, grid 512^3, 8 coils on one GPU); otherwise None.
-    PMC counters cannot be read from inside the benchmark process, so this figure comes from the
-    separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same script."""
-    path = os.path.join(ROOT, PMC_SUMMARY)
-    if not os.path.exists(path) or tuple(grid) != (512, 512, 512) or ncoils != 8 or image != 256:
+def load_pmc(cfg):
+    path = os.path.join(ROOT, PMC_SUMMARIES.get(cfg, ""))
+    if not os.path.isfile(path):
         return None, None
-    d = json.load(open(path)).get(kernel)
-    if not d:
-        return None, None
-    return d["hbm_bytes_per_launch"], PMC_SUMMARY + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE x2 per the gfx950 note)"
+    return json.load(open(path)), PMC_SUMMARIES[cfg] + PMC_NOTE
 
 
 def parse():
@@ -84,192 +98,559 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--image", type=int, default=256, help="image edge (debug: smaller problems)")
-    ap.add_argument("--coils", type=int, default=8)
-    ap.add_argument("--tree", choices=["zpadfft", "o3"], default="zpadfft",
-                    help="zpadfft: S' and the FFT fused into one zero-pad-aware leaf (default); o3: the reference's -O3 leaves")
+    ap.add_argument("--config", type=int, default=4, choices=[1, 2, 3, 4, 5])
+    ap.add_argument("--image", type=int, default=0, help="image edge (debug: smaller problems; default 256 / 320 for config 4 / 5)")
+    ap.add_argument("--coils", type=int, default=0, help="coils (default 8 / 32 for config 4 / 5)")
+    ap.add_argument("--tree", choices=["zpadfft", "o3", "recipe"], default="zpadfft",
+                    help="zpadfft: S' and the FFT fused into one zero-pad-aware leaf (default); o3: the reference's -O3 leaves; "
+                         "recipe: the reference's factories + pics.py recipe + FuseZpadFFT (reaches the same fused leaf)")
     ap.add_argument("--layout", type=int, default=-1, help="grid layout of the fused tree: 1 = (x,z,y) per coil, 2 = coils interleaved "
-                    "(default: 2 when this rank holds 2, 4 or 8 coils, else 1)")
+                    "(default: 2 when this rank holds 2, 4, 8 or more coils, else 1)")
+    ap.add_argument("--shard", default="", help="R/W: time rank R's coils of a W-rank run on this one GPU, no communication")
+    ap.add_argument("--comm", choices=["auto", "rccl", "torch"], default="auto",
+                    help="all-reduce provider for N > 1: the library's own RCCL binding (ig_comm_*), or torch.distributed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-budget", type=float, default=60.0, help="skip the CPU leg if setup says it will exceed this many seconds")
+    ap.add_argument("--no-config5", action="store_true", help="default run: skip the extra config-5 measurement")
+    ap.add_argument("--batch", type=int, default=16, help="config 2: number of volumes")
+    ap.add_argument("--ncol", type=int, default=64, help="config 3: panel columns")
     return ap.parse_args()
 
 
-def log(rank, *a):
-    if rank == 0:
+RANK = int(os.environ.get("RANK", "0"))
+
+
+def log(*a):
+    if RANK == 0:
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, "--gpus must match WORLD_SIZE"
-    comm = None
-    if world > 1:
-        os.environ["INDIGO_HIP_WITH_TORCH"] = "1"
-        import torch
-        import torch.distributed as dist
-        # one rank per GPU over RCCL; INDIGO_BENCH_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal only)
-        dist_backend = os.environ.get("INDIGO_BENCH_DIST_BACKEND", "nccl")
-        local_rank = local_rank % max(torch.cuda.device_count(), 1)
-        torch.cuda.set_device(local_rank)
-        if dist_backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend=dist_backend)
-
-    import numpy as np
-    from indigo_amd.backends import get_backend
-    from indigo_amd.dist import ShardedNormalOperator, TorchComm, coil_range
-    from indigo_amd.sense import SenseProblem, normal_operator
-    from indigo_amd.util import Trace, rand64c
-
-    t_setup = time.time()
-    B = get_backend("hip", device_id=local_rank)
-    if world > 1:
-        comm = TorchComm(B)
-    log(rank, "device:", B.device_name(), "world", world)
-
-    img, C = args.image, args.coils
-    nreadout = 2 * img                                   # samples per spoke = oversampled grid edge
-    nspokes = int(round(3617 * (img / 256.0) ** 2))      # 3617 spokes at 256^3 -> T = 1,851,904
-    p = SenseProblem.synthetic((img,) * 3, C, nspokes=nspokes, nreadout=nreadout, width=2, ntable=128,
-                               oversamp=2.0, seed=4)
-    coils = list(coil_range(C, rank, world))
-    log(rank, "problem: image %d^3, %d coils (%d on this rank), grid %s, T=%d (%.1fs)" % (img, C, len(coils), p.oN, p.T, time.time() - t_setup))
-    fused_fft = args.tree == "zpadfft" and B.supports_padded_fft(p.oN)
-    layout = args.layout if args.layout >= 0 else (2 if len(coils) in (2, 4, 8) else 1)
-    A = p.build_zpadfft(B, coils=coils, layout=layout) if fused_fft else p.build_fused(B, coils=coils)
-    log(rank, "tree:", "KronI(G') * ZpadFFT (S' folded into a zero-pad-aware FFT)" if fused_fft
-        else "-O3: KronI(G') * (KronI(FFT) * S')")
-    c64 = np.dtype('complex64')
-    Nvox = A.shape[1]
-    x = B.copy_array(rand64c(Nvox, 1, seed=1))
-    y = B.zero_array((Nvox, 1), c64)
-    if world > 1:
-        # size the arena for A and A^H on this rank's coils
-        from indigo_amd.transforms import reserve_for
-        reserve_for(A, 1)
-        AHA = ShardedNormalOperator(A, comm)
-    else:
-        AHA = normal_operator(A)
-
-    # one traced evaluation: algorithmic bytes by the reference's own model, and first-touch of all buffers
-    B.trace = Trace()
-    AHA.eval(y, x)
-    B.barrier()
-    ev = B.trace.by_event()
-    alg_bytes_rank = B.trace.total_bytes()
-    B.trace = None
-    log(rank, "setup %.1fs; algorithmic bytes/eval on this rank: %.2f GB %s" % (
-        time.time() - t_setup, alg_bytes_rank / 1e9, {k: round(v['nbytes'] / 1e9, 2) for k, v in ev.items()}))
-    log(rank, "fft plan:", B.fft_describe(p.oN + (len(coils),)))
-
-    for _ in range(args.warmup):
-        AHA.eval(y, x)
+def timed_steps(B, comm, fn, steps, warmup):
+    """W untimed + K timed calls of fn between barrier + stream sync on both sides; returns (seconds of the K steps -- max
+    over ranks --, per-call-site profile of the timed region from stream events)"""
+    for _ in range(warmup):
+        fn()
     B.barrier()
     if comm:
         comm.barrier()
     B.profile(True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        AHA.eval(y, x)
+    for _ in range(steps):
+        fn()
     B.barrier()
     if comm:
         comm.barrier()
-    t1 = time.perf_counter()
+    elapsed = time.perf_counter() - t0
     B.profile(False)
     prof = B.profile_report()
-    elapsed = t1 - t0
     if comm:
         elapsed = comm.max(elapsed)
-    ms_per_step = elapsed / args.steps * 1e3
-    value = args.steps / elapsed
+    return elapsed, prof
 
-    # dominant kernel and its roofline point.  The event brackets are per call site; call sites that launch
-    # the same device kernel (the two strided FFT axes) are merged so the figure matches rocprofv3's row.
-    if fused_fft:
-        # price the fused passes with their exact compulsory bytes (box and k-space support taken into account)
-        exact = p.zpadfft_pass_bytes(len(coils), getattr(p, 'last_support_table', None), fused_sum=(layout == 2))
-        for name, nbytes in exact.items():
-            if name in prof:
-                prof[name]['bytes'] = float(nbytes) * prof[name]['launches']
+
+def roofline_of(prof, symbols, cfg, pick=None):
+    """merge call sites that launch the same device kernel, pick the dominant one, price it"""
     kernels = {}
-    KERNEL_SYMBOL = kernel_symbols(layout if fused_fft else 0, len(coils))
     for name, d in prof.items():
-        sym = KERNEL_SYMBOL.get(name, name)
-        k = kernels.setdefault(sym, dict(launches=0, total_ms=0.0, bytes=0.0))
+        sym = symbols.get(name, name)
+        k = kernels.setdefault(sym, dict(launches=0, total_ms=0.0, bytes=0.0, ref_bytes=0.0, sites=[]))
         k['launches'] += d['launches']
         k['total_ms'] += d['total_ms']
         k['bytes'] += d['bytes']
-    dom = max(kernels, key=lambda k: kernels[k]['total_ms']) if kernels else None
-    roofline = None
-    if dom:
-        d = kernels[dom]
-        avg_ms = d['total_ms'] / d['launches']
-        per_launch_bytes = d['bytes'] / d['launches'] if d['bytes'] else None
-        achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9 if per_launch_bytes else None
-        traffic, traffic_src = pmc_traffic(dom, p.oN, len(coils), img)
-        roofline = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=(achieved / HBM_PEAK_GBS) if achieved else None, traffic=traffic,
-                        traffic_source=traffic_src, avg_launch_ms=avg_ms, launches=d['launches'],
-                        algorithmic_bytes_per_launch=per_launch_bytes)
-    for k in sorted(prof, key=lambda k: -prof[k]['total_ms']):
-        log(rank, "  %-24s %4d launches  avg %8.3f ms  total %9.2f ms" % (k, prof[k]['launches'], prof[k]['avg_ms'], prof[k]['total_ms']))
-    log(rank, "eval: %.3f ms/step, %.2f evals/s; whole-eval algorithmic rate %.0f GB/s per GPU" % (
-        ms_per_step, value, alg_bytes_rank / (ms_per_step * 1e-3) / 1e9))
-
-    cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_baseline = run_cpu_baseline(p, C, log)
-
-    if rank == 0:
-        out = {
-            "metric": "SENSE AHA evals/sec (256^3 x 8-coil non-Cartesian)",
-            "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "complex64 (f32)", "data": "synthetic",
-            "config": {"workload": "non-Cartesian SENSE A^H A, image %d^3, %d coils, grid %d^3 (osf 2), radial T=%d, KB width 4; "
-                                   "-O3 tree S'->FFT->G'->G'^H->IFFT->S'^H" % (img, C, p.oN[0], p.T),
-                       "parallelism": "coil-sharded x%d, one all-reduce per eval" % world if world > 1 else "single GPU",
-                       "grid_layout": (layout if fused_fft else 0),
-                       "algorithmic_GB_per_eval_per_gpu": alg_bytes_rank / 1e9},
-            "roofline": roofline,
-            "cpu_baseline": cpu_baseline,
-            # whole-eval rate in the reference's own bytes model, and the per-call-site breakdown
-            "eval_algorithmic_GBps_per_gpu": alg_bytes_rank / (ms_per_step * 1e-3) / 1e9,
-            "eval_frac_of_hbm_peak": alg_bytes_rank / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "kernels": {k: {"launches_per_eval": v['launches'] / args.steps, "avg_ms": round(v['avg_ms'], 4),
-                            "GBps": round(v['bytes'] / v['launches'] / (v['avg_ms'] * 1e-3) / 1e9, 1) if v['bytes'] else None}
-                        for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['total_ms'])},
-        }
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+        k['ref_bytes'] += d.get('ref_bytes', 0.0)
+        k['sites'].append(name)
+    if not kernels:
+        return None, kernels
+    dom = pick if pick in kernels else max(kernels, key=lambda k: kernels[k]['total_ms'])
+    d = kernels[dom]
+    avg_ms = d['total_ms'] / d['launches']
+    per_launch = d['bytes'] / d['launches'] if d['bytes'] else None
+    achieved = per_launch / (avg_ms * 1e-3) / 1e9 if per_launch else None
+    pmc, src = load_pmc(cfg)
+    traffic = pmc.get(dom, {}).get("hbm_bytes_per_launch") if pmc else None
+    out = dict(bound="hbm", kernel=dom, call_sites=d['sites'], achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+               frac=(achieved / HBM_PEAK_GBS) if achieved else None, traffic=traffic,
+               traffic_source=src if traffic else None, avg_launch_ms=avg_ms, launches=d['launches'],
+               algorithmic_bytes_per_launch=per_launch,
+               bytes_model="compulsory bytes of the pass (box, k-space support and coil sum taken into account), see DESIGN.md 3")
+    if traffic:
+        out["traffic_frac_of_peak"] = traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    if d['ref_bytes']:
+        rb = d['ref_bytes'] / d['launches']
+        out["reference_model"] = dict(bytes_per_launch=rb, equiv_GBps=rb / (avg_ms * 1e-3) / 1e9,
+                                      note="SURVEY 8(d) accounting of the unfused leaf this pass replaces (4*x.nbytes per 3-D "
+                                           "transform / 3 passes; csrmm nnz*12+(M+1)*4+X*read_frac+Y); not a roofline fraction")
+    return out, kernels
 
 
-def run_cpu_baseline(p, C, log):
-    """numpy oracle on ONE coil of the same problem; evals/s = 1 / (C * t_one_coil)."""
+def kernel_table(prof, steps):
+    return {k: {"launches_per_step": v['launches'] / steps, "avg_ms": round(v['avg_ms'], 4),
+                "GBps": round(v['bytes'] / v['launches'] / (v['avg_ms'] * 1e-3) / 1e9, 1) if v['bytes'] else None,
+                "bytes_per_launch": v['bytes'] / v['launches'] if v['bytes'] else None}
+            for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['total_ms'])}
+
+
+def host_info():
+    return dict(host_cores=os.cpu_count(), note="single-threaded: pocketfft and scipy csr_matvecs do not thread; the reference's "
+                                                 "get_max_threads() is 1 (indigo/backends/backend.py:243-244)")
+
+
+# ---------------------------------------------------------------------------------------------------------
+# communication
+# ---------------------------------------------------------------------------------------------------------
+def make_comm(args, B, world, rank, local_rank):
+    """all-reduce provider for world > 1: the library's own RCCL communicator (no torch in the product path); torch's
+    process group only if that cannot be brought up (or --comm torch)"""
+    if world == 1:
+        return None
+    from indigo_amd import dist as igdist
+    if args.comm in ("auto", "rccl") and os.environ.get("INDIGO_BENCH_DIST_BACKEND", "nccl") == "nccl":
+        try:
+            c = igdist.RcclComm(B, rank, world)
+            log("communicator: ig_comm (RCCL through the C ABI), %d ranks" % world)
+            return c
+        except Exception as e:           # noqa: BLE001 -- any failure here falls back to the torch process group, loudly
+            if args.comm == "rccl":
+                raise
+            print("[bench] rank %d: ig_comm bring-up FAILED (%s: %s); falling back to torch.distributed" % (rank, type(e).__name__, e),
+                  file=sys.stderr, flush=True)
+    os.environ["INDIGO_HIP_WITH_TORCH"] = "1"
+    import torch
+    import torch.distributed as dist
+    dist_backend = os.environ.get("INDIGO_BENCH_DIST_BACKEND", "nccl")
+    if dist_backend == "nccl":
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend=dist_backend)     # gloo: several ranks may share one GPU (rehearsal only)
+    log("communicator: torch.distributed (%s), %d ranks" % (dist_backend, world))
+    return igdist.TorchComm(B)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# configs 4 and 5: SENSE A^H A
+# ---------------------------------------------------------------------------------------------------------
+def sense_problem(cfg, img, C):
+    from indigo_amd.sense import SenseProblem
+    if cfg == 4:
+        nreadout = 2 * img                                   # samples per spoke = oversampled grid edge
+        nspokes = int(round(3617 * (img / 256.0) ** 2))      # 3617 spokes at 256^3 -> T = 1,851,904
+        return SenseProblem.synthetic((img,) * 3, C, nspokes=nspokes, nreadout=nreadout, width=2, ntable=128,
+                                      oversamp=2.0, seed=4)
+    # config 5: 320^3 in 512^3 (oversampling 1.6), maps generated per coil so that a rank only materialises its own
+    grid = int(img * 1.6)
+    nspokes = int(round(3617 * (img / 256.0) ** 2))          # 5652 spokes at 320^3 -> T = 2,893,824
+    return SenseProblem.synthetic((img,) * 3, C, nspokes=nspokes, nreadout=grid, width=2, ntable=128,
+                                  oversamp=1.6, seed=5, lazy_maps=True)
+
+
+def run_sense(args, cfg, B, comm, world, rank, steps, warmup, want_cpu, quiet=False):
     import numpy as np
+    from indigo_amd.dist import ShardedNormalOperator, coil_range
     from indigo_amd.sense import normal_operator
+    from indigo_amd.transforms import reserve_for
+    from indigo_amd.util import Trace, rand64c
+
+    t_setup = time.time()
+    img = args.image or (256 if cfg == 4 else 320)
+    C = args.coils or (8 if cfg == 4 else 32)
+    p = sense_problem(cfg, img, C)
+    shard = None
+    if args.shard:
+        r, w = (int(v) for v in args.shard.split("/"))
+        shard = (r, w)
+        coils = list(coil_range(C, r, w))
+    else:
+        coils = list(coil_range(C, rank, world))
+    log("config %d: image %d^3, %d coils (%d here%s), grid %s, T=%d (%.1fs)" % (
+        cfg, img, C, len(coils), " = shard %d/%d" % shard if shard else "", p.oN, p.T, time.time() - t_setup))
+    tree = args.tree if cfg == 4 else "zpadfft"
+    fused_fft = tree in ("zpadfft", "recipe") and B.supports_padded_fft(p.oN)
+    layout = args.layout if args.layout >= 0 else (2 if (len(coils) in (2, 4, 8) or len(coils) > 8) else 1)
+    if tree == "recipe":
+        from indigo_amd.transforms import FuseZpadFFT, sense_recipe
+        A = p.build_tree(B, level=0, coils=coils)
+        for Step in sense_recipe(3) + [FuseZpadFFT]:
+            A = Step().visit(A)
+        layout = FuseZpadFFT.layout_of(A)
+    elif fused_fft:
+        A = p.build_zpadfft(B, coils=coils, layout=layout)
+    else:
+        A = p.build_fused(B, coils=coils)
+        layout = 0
+    nchunks = len(getattr(A, 'children', [])) if type(A).__name__ == "VStack" else 1
+    log("tree:", {"zpadfft": "KronI(G') * ZpadFFT (S' folded into a zero-pad-aware FFT)", "recipe": "reference recipe + FuseZpadFFT",
+                  "o3": "-O3: KronI(G') * (KronI(FFT) * S')"}[tree if fused_fft or tree == "o3" else "o3"],
+        "layout %d, %d chunk(s)" % (layout, nchunks))
+    c64 = np.dtype('complex64')
+    Nvox = A.shape[1]
+    x = B.copy_array(rand64c(Nvox, 1, seed=1))
+    y = B.zero_array((Nvox, 1), c64)
+    if comm is not None:
+        reserve_for(A, 1)
+        AHA = ShardedNormalOperator(A, comm)
+    else:
+        AHA = normal_operator(A)
+
+    # one traced evaluation: algorithmic bytes by the reference's own model, and first touch of all buffers
+    B.trace = Trace()
+    AHA.eval(y, x)
+    B.barrier()
+    trace = B.trace
+    B.trace = None
+    ev = trace.by_event()
+    ref_bytes_rank = trace.total_bytes()
+    log("setup %.1fs; reference-model bytes/eval on this rank: %.2f GB %s" % (
+        time.time() - t_setup, ref_bytes_rank / 1e9, {k: round(v['nbytes'] / 1e9, 2) for k, v in ev.items()}))
+
+    elapsed, prof = timed_steps(B, comm, lambda: AHA.eval(y, x), steps, warmup)
+    ms_per_step = elapsed / steps * 1e3
+    value = steps / elapsed
+
+    # ---- per call site: compulsory bytes (ours) and reference-model bytes (the leaf it replaces)
+    cpr = len(coils) if nchunks == 1 else 8          # coils per chunk seen by one launch
+    half_box = all(2 * b == n for b, n in zip(p.N, p.oN))
+    if fused_fft:
+        exact = p.zpadfft_pass_bytes(cpr, getattr(p, 'last_support_table', None), fused_sum=(layout == 2))
+        for name, nbytes in exact.items():
+            if name in prof:
+                prof[name]['bytes'] = float(nbytes) * prof[name]['launches']
+                # SURVEY 8(d): 4 * x.nbytes per 3-D transform, a third per pass; x = grid x coils
+                prof[name]['ref_bytes'] = 4.0 * np.prod(p.oN) * 8.0 * cpr / 3.0 * prof[name]['launches']
+    csr = {(r['name'], r['forward']): r['nbytes'] for r in trace.records if r['event'] == 'csrmm' and not r.get('fused')}
+    for site, fwd in (("csrmm_gather", True), ("csrmm_rowlane_conj", False), ("csrmm_gather_conj", False)):
+        nb = csr.get(('interp*mod*scale', fwd))
+        if site in prof and nb and not prof[site]['bytes']:
+            prof[site]['bytes'] = float(nb) * prof[site]['launches']      # reference model = the only model for a csrmm
+            prof[site]['ref_bytes'] = prof[site]['bytes']
+    symbols = kernel_symbols(layout if fused_fft else 0, cpr, half_box, p.oN[0])
+    roofline, kernels = roofline_of(prof, symbols, cfg)
+    if not quiet:
+        for k in sorted(prof, key=lambda k: -prof[k]['total_ms']):
+            log("  %-24s %4d launches  avg %8.3f ms  total %9.2f ms  %s" % (
+                k, prof[k]['launches'], prof[k]['avg_ms'], prof[k]['total_ms'],
+                "%6.0f GB/s" % (prof[k]['bytes'] / prof[k]['launches'] / prof[k]['avg_ms'] / 1e6) if prof[k]['bytes'] else ""))
+    log("config %d: %.3f ms/step, %.2f evals/s on %d GPU(s)" % (cfg, ms_per_step, value, world))
+
+    # ---- traffic of the whole evaluation: PMC summary where one exists for this exact configuration, else compulsory bytes
+    comp_bytes = sum(v['bytes'] / steps for v in prof.values())
+    pmc, pmc_src = load_pmc(cfg)
+    traffic_bytes, traffic_src = None, None
+    if pmc and world == 1 and not shard and not args.image and not args.coils and tree == "zpadfft":
+        tot = 0.0
+        for sym, k in kernels.items():
+            if sym in pmc:
+                tot += pmc[sym]["hbm_bytes_per_launch"] * k['launches'] / steps
+        if tot:
+            traffic_bytes, traffic_src = tot, pmc_src
+    if traffic_bytes is None:
+        traffic_bytes, traffic_src = comp_bytes, "sum of the kernels' compulsory bytes (no PMC summary for this configuration)"
+
+    out = {
+        "ms_per_step": ms_per_step, "value": value,
+        "config": {"workload": "non-Cartesian SENSE A^H A, image %d^3, %d coils, grid %d^3 (osf %.2g), radial T=%d, KB width 4; "
+                               "-O3 tree S'->FFT->G'->G'^H->IFFT->S'^H%s" % (img, C, p.oN[0], p.oversamp, p.T,
+                                                                             " (BASELINE config %d)" % cfg),
+                   "parallelism": ("coil-sharded x%d (%d coils per rank), one all-reduce of the image per eval" % (world, len(coils))
+                                   if world > 1 else ("rank %d of %d alone (no communication)" % shard if shard else "single GPU")),
+                   "grid_layout": layout, "tree": tree, "coil_chunks_per_rank": nchunks},
+        "roofline": roofline,
+        "eval_traffic_GB": traffic_bytes / 1e9,
+        "eval_traffic_frac": traffic_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "eval_traffic_source": traffic_src,
+        "eval_compulsory_GB": comp_bytes / 1e9,
+        "reference_model_GB_per_eval_per_gpu": ref_bytes_rank / 1e9,
+        "reference_model_equiv": ref_bytes_rank / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "reference_model_note": "the reference's unfused leaf-by-leaf bytes (SURVEY 8d) / time / 8 TB/s: above 1 because the fusions "
+                                "removed bytes -- a speed-up measure against the 0.6 target (41 evals/s), not a roofline fraction",
+        "kernels": kernel_table(prof, steps),
+    }
+    if comm is not None:
+        out["comm"] = comm.describe()
+    if want_cpu:
+        cpu, parity = cpu_baseline_and_parity(p, C, B, layout if fused_fft else None, y)
+        out["cpu_baseline"] = cpu
+        out["parity_rel_err"] = parity
+    del AHA, A, x, y
+    B._scratch = None
+    p.drop_cache()
+    return out
+
+
+def cpu_baseline_and_parity(p, C, B, layout, y_dev):
+    """numpy oracle on ONE coil of the same problem: warm-up + min of 2 evaluations; evals/s = 1 / (C * t_one_coil).
+    The same oracle result checks the benchmarked operator: coils 1..C-1 switched off, identical kernels."""
+    import numpy as np
+    from indigo_amd.sense import SenseProblem, normal_operator
     from indigo_amd.util import rand64c
     from oracle.np_backend import NumpyBackend
     t0 = time.time()
     O = NumpyBackend()
     A1 = p.build_fused(O, coils=[0])
     AHA1 = normal_operator(A1)
-    x = O.copy_array(rand64c(A1.shape[1], 1, seed=1))
+    xh = rand64c(A1.shape[1], 1, seed=1)
+    x = O.copy_array(xh)
     y = O.zero_array((A1.shape[1], 1), np.dtype('complex64'))
-    t1 = time.perf_counter()
-    AHA1.eval(y, x)
-    t = time.perf_counter() - t1
-    log(0, "cpu baseline: one coil in %.2f s (setup %.1f s)" % (t, t1 - t0 if False else time.time() - t0 - t))
-    return dict(value=1.0 / (C * t), unit="evals/s", cores=1, kind="port",
-                sample="numpy oracle (restatement of indigo/backends/np.py), 1 of %d coils of the same problem, "
-                       "one evaluation (%.1f s), scaled linearly in coils; single-threaded pocketfft + scipy csr_matvecs" % (C, t))
+    times = []
+    for i in range(3):                      # first = warm-up (scipy/pocketfft plan caches, page faults)
+        t1 = time.perf_counter()
+        AHA1.eval(y, x)
+        times.append(time.perf_counter() - t1)
+    t = min(times[1:])
+    log("cpu baseline: one coil, warm-up %.2f s, then %s s (setup %.1f s)" % (times[0], ["%.2f" % v for v in times[1:]], time.time() - t0 - sum(times)))
+    ref = y.to_host()
+    cpu = dict(value=1.0 / (C * t), unit="evals/s", cores=1, kind="port", **host_info(),
+               sample="numpy oracle (restatement of indigo/backends/np.py: np.fft.fftn + scipy csr @), 1 of %d coils of the same problem, "
+                      "1 warm-up + min of 2 evaluations (%.1f s each), scaled linearly in coils" % (C, t))
+    parity = None
+    if layout is not None:
+        zero = np.zeros(p.N, dtype=np.complex64, order='F')
+        q = SenseProblem(p.N, p.coord, lambda c: p.coil_map(c) if c == 0 else zero, width=p.width, ntable=p.ntable,
+                         oversamp=p.oversamp, ncoils=min(C, 8))
+        q._interp_cache = p._interp_cache
+        B._scratch = None
+        A0 = q.build_zpadfft(B, layout=layout)
+        AHA0 = normal_operator(A0)
+        AHA0.eval(y_dev, B.copy_array(xh))
+        got = y_dev.to_host()
+        parity = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+        log("parity: benchmarked operator with coils 1.. switched off vs the oracle's one-coil A^H A: rel. err %.3e" % parity)
+        del A0, AHA0
+        B._scratch = None
+    return cpu, parity
+
+
+def bench_sense(args, world, rank, local_rank):
+    from indigo_amd.backends import get_backend
+    B = get_backend("hip", device_id=local_rank)
+    comm = make_comm(args, B, world, rank, local_rank)
+    log("device:", B.device_name(), "world", world)
+    cfg = args.config
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and not args.shard and cfg == 4
+    res = run_sense(args, cfg, B, comm, world, rank, args.steps, args.warmup, want_cpu)
+    extra5 = None
+    if cfg == 4 and not args.no_config5 and not args.shard and not args.image and not args.coils and args.tree == "zpadfft":
+        try:
+            r5 = run_sense(args, 5, B, comm, world, rank, max(2, min(args.steps, 5)), min(args.warmup, 2), False, quiet=True)
+            extra5 = {"evals_per_s": r5["value"], "ms_per_step": r5["ms_per_step"], "n_gpus": world, "config": r5["config"],
+                      "eval_traffic_frac": r5["eval_traffic_frac"], "kernels": r5["kernels"],
+                      "note": "BASELINE config 5 (320^3 x 32 coils, grid 512^3) at the same N: strong scaling of the 32-coil problem"}
+        except Exception as e:             # noqa: BLE001 -- the extra measurement must not cost the headline its line
+            extra5 = {"error": "%s: %s" % (type(e).__name__, e)}
+            print("[bench] config-5 extra failed on rank %d: %s" % (rank, extra5["error"]), file=sys.stderr, flush=True)
+    if rank == 0:
+        name = ("SENSE AHA evals/sec (256^3 x 8-coil non-Cartesian)" if cfg == 4 and not args.image and not args.coils
+                else "SENSE AHA evals/sec (%s)" % res["config"]["workload"].split(",", 1)[1].split(";")[0].strip())
+        out = {"metric": name, "value": res.pop("value"), "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": res.pop("ms_per_step"), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "dtype": "complex64 (f32)", "data": "synthetic"}
+        out.update(res)
+        out.setdefault("cpu_baseline", None)
+        if extra5 is not None:
+            out["config5"] = extra5
+        print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.close()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# config 2: batched 3-D C2C FFT, 256^3 x 16 (the reference contract Backend.fftn/ifftn, benchmark.py:36-62)
+# ---------------------------------------------------------------------------------------------------------
+def bench_fft(args, local_rank):
+    import numpy as np
+    from indigo_amd.backends import get_backend
+    from indigo_amd.util import rand64c
+    B = get_backend("hip", device_id=local_rank)
+    n = args.image or 256
+    batch = args.batch
+    shape = (n, n, n, batch)
+    c64 = np.dtype('complex64')
+    x = B.empty_array(shape, c64)
+    for j in range(batch):
+        x[:, :, :, j:j + 1].copy_from(rand64c(n, n, n, 1, seed=2 + j))
+    yv = B.zero_array(shape, c64)
+    log("config 2: %s; plan: %s" % (shape, B.fft_describe(shape)))
+    nbytes = x.nbytes
+    elapsed, prof = timed_steps(B, None, lambda: B.fftn(yv, x), args.steps, args.warmup)
+    ms = elapsed / args.steps * 1e3
+    tot_kernel_ms = sum(v['total_ms'] for v in prof.values()) / args.steps
+    pmc, src = load_pmc(2) if n == 256 and batch == 16 else (None, None)
+    traffic = sum(pmc[k]["hbm_bytes_per_launch"] * 1.0 for k in pmc if k.startswith("k_fft")) if pmc else None
+    inv_elapsed, _ = timed_steps(B, None, lambda: B.ifftn(yv, yv), max(2, args.steps // 2), 1)
+    # parity on the spot: volume 3 against numpy
+    B.fftn(yv, x)
+    got = yv[:, :, :, 3:4].to_host()[..., 0]
+    ref = np.fft.fftn(x[:, :, :, 3:4].to_host()[..., 0])
+    perr = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+    cpu = None
+    if not args.no_cpu_baseline:
+        v = x[:, :, :, 0:1].to_host()[..., 0]
+        ts = []
+        for _ in range(3):
+            t1 = time.perf_counter()
+            np.fft.fftn(v)
+            ts.append(time.perf_counter() - t1)
+        cpu = dict(value=1.0 / (batch * min(ts[1:])), unit="transforms/s", cores=1, kind="port", **host_info(),
+                   sample="np.fft.fftn (the reference numpy backend's fftn, np.py:102-115) on 1 of %d volumes, warm-up + min of 2 (%.2f s), scaled" % (batch, min(ts[1:])))
+    out = {"metric": "batched 3-D C2C FFT %d^3 x %d (complex64) transforms/sec" % (n, batch), "value": args.steps / elapsed,
+           "unit": "transforms/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "complex64 (f32)", "data": "synthetic",
+           "config": {"workload": "BASELINE config 2: forward fftn of %d^3 x %d, out of place (Backend.fftn contract)" % (n, batch),
+                      "plan": B.fft_describe(shape), "inverse_in_place_ms": inv_elapsed / max(2, args.steps // 2) * 1e3},
+           "roofline": dict(bound="hbm", kernel="whole transform (%d launches)" % sum(v['launches'] // args.steps for v in prof.values()),
+                            achieved=4.0 * nbytes / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                            frac=4.0 * nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            algorithmic_bytes_per_launch=4.0 * nbytes,
+                            bytes_model="SURVEY 8(d) / benchmark.py:55: 4 * x.nbytes per multi-dimensional transform",
+                            traffic=traffic, traffic_source=src if traffic else None,
+                            traffic_frac_of_peak=(traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                            kernel_ms_per_transform=tot_kernel_ms),
+           "cpu_baseline": cpu, "parity_rel_err": perr, "kernels": kernel_table(prof, args.steps)}
+    print(json.dumps(out), flush=True)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# config 3: 3-D radial gridding CSR (T x 256^3, 27 taps/row, ~5e7 nnz) x 64-column panel (benchmark.py:65-97)
+# ---------------------------------------------------------------------------------------------------------
+def bench_spmm(args, local_rank):
+    import numpy as np
+    import scipy.sparse as spp
+    from scipy.signal.windows import kaiser
+    from indigo_amd.backends import get_backend
+    from indigo_amd.interp import interp_csr_arrays
+    from indigo_amd.sense import radial_trajectory
+    from indigo_amd.util import rand64c, Trace
+    B = get_backend("hip", device_id=local_rank)
+    n = args.image or 256
+    ncol = args.ncol
+    N = (n, n, n)
+    coord = radial_trajectory(int(round(3617 * (n / 256.0) ** 2)), 2 * n, seed=3)
+    T = int(np.prod(coord.shape[1:]))
+    beta = np.pi * np.sqrt(((2 * 2.0 / 2.0) * (2.0 - 0.5)) ** 2 - 0.8)
+    table = kaiser(2 * 128 + 1, beta)[128:]
+    t0 = time.time()
+    indptr, indices, w = interp_csr_arrays(T, N, 2, table, coord.reshape(3, -1, order='F'), dtype=np.float32)
+    G = spp.csr_matrix((w.astype(np.complex64), indices, indptr), shape=(T, n ** 3))
+    S = B.SpMatrix(G, name='gridding')
+    c64 = np.dtype('complex64')
+    P = n ** 3
+    X = B.empty_array((P, ncol), c64)
+    for j0 in range(0, ncol, 8):
+        X[:, j0:j0 + min(8, ncol - j0)].copy_from(rand64c(P, min(8, ncol - j0), seed=100 + j0))
+    Y = B.zero_array((T, ncol), c64)
+    Z = B.zero_array((P, ncol), c64)
+    B.trace = Trace()
+    S.eval(Y, X)
+    S.eval(Z, Y, forward=False)
+    B.barrier()
+    tr = B.trace
+    B.trace = None
+    fb = [r['nbytes'] for r in tr.records if r['forward']][0]
+    ab = [r['nbytes'] for r in tr.records if not r['forward']][0]
+    M = S._matrix_d
+    log("config 3: G %d x %d, nnz %d, col_frac %.3f; reference-model bytes fwd %.2f GB, adj %.2f GB (setup %.1f s)" % (
+        T, P, G.nnz, M._col_frac, fb / 1e9, ab / 1e9, time.time() - t0))
+    elapsed, prof = timed_steps(B, None, lambda: S.eval(Y, X), args.steps, args.warmup)
+    ms = elapsed / args.steps * 1e3
+    a_elapsed, a_prof = timed_steps(B, None, lambda: S.eval(Z, Y, forward=False), args.steps, args.warmup)
+    a_ms = a_elapsed / args.steps * 1e3
+    pmc, src = load_pmc(3) if n == 256 and ncol == 64 else (None, None)
+    traffic = None
+    if pmc:
+        traffic = sum(pmc[k]["hbm_bytes_per_launch"] for k in pmc if k.startswith("k_csrmm_gather") or k.startswith("k_pack"))
+    # parity: column 5 against scipy
+    x5 = X[:, 5:6].to_host()
+    y5 = Y[:, 5:6].to_host()
+    ref = G @ x5
+    perr = float(np.linalg.norm(y5 - ref) / np.linalg.norm(ref))
+    cpu = None
+    if not args.no_cpu_baseline:
+        xs = np.asfortranarray(X[:, 0:8].to_host())
+        ts = []
+        for _ in range(3):
+            t1 = time.perf_counter()
+            G @ xs
+            ts.append(time.perf_counter() - t1)
+        cpu = dict(value=1.0 / (min(ts[1:]) * ncol / 8.0), unit="products/s", cores=1, kind="port", **host_info(),
+                   sample="scipy csr @ dense (np.py:120-127) on 8 of the %d columns, warm-up + min of 2 (%.2f s), scaled" % (ncol, min(ts[1:])))
+    out = {"metric": "gridding CSR (%d x %d^3, nnz %.2e) x %d-column SpMM products/sec" % (T, n, G.nnz, ncol), "value": args.steps / elapsed,
+           "unit": "products/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "complex64 (f32)", "data": "synthetic",
+           "config": {"workload": "BASELINE config 3: forward csrmm through Backend.ccsrmm (column-major panels), adjoint reported beside it",
+                      "col_frac": M._col_frac, "adjoint_ms": a_ms,
+                      "adjoint_GBps_reference_model": ab / (a_ms * 1e-3) / 1e9,
+                      "adjoint_frac_of_peak_reference_model": ab / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+           "roofline": dict(bound="hbm", kernel="forward product (%s)" % " + ".join(sorted(prof)), achieved=fb / (ms * 1e-3) / 1e9,
+                            peak=HBM_PEAK_GBS, unit="GB/s", frac=fb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            algorithmic_bytes_per_launch=fb,
+                            bytes_model="SURVEY 8(d) / operators.py:246-256: nnz*12 + (M+1)*4 + K*n*8*col_frac + M*n*8",
+                            traffic=traffic, traffic_source=src if traffic else None,
+                            traffic_frac_of_peak=(traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None),
+           "cpu_baseline": cpu, "parity_rel_err": perr,
+           "kernels": {"forward": kernel_table(prof, args.steps), "adjoint": kernel_table(a_prof, args.steps)}}
+    print(json.dumps(out), flush=True)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# config 1: examples/spmm.py on the numpy backend (CPU only in the reference); HIP timed beside the oracle
+# ---------------------------------------------------------------------------------------------------------
+def bench_spmm_example(args, local_rank):
+    import numpy as np
+    import scipy.sparse as spp
+    from indigo_amd.backends import get_backend
+    from indigo_amd.util import rand64c
+    from oracle.np_backend import NumpyBackend
+    B = get_backend("hip", device_id=local_rank)
+    A = spp.random(10000, 10000, density=0.01, format='csr', random_state=np.random.default_rng(1), dtype=np.float32).astype(np.complex64)
+    xh = rand64c(10000, 8, seed=1)
+    S = B.SpMatrix(A)
+    x = B.copy_array(xh)
+    y = B.zero_array((10000, 8), np.dtype('complex64'))
+    S.eval(y, x)
+    elapsed, prof = timed_steps(B, None, lambda: S.eval(y, x), max(args.steps, 50), args.warmup)
+    steps = max(args.steps, 50)
+    ms = elapsed / steps * 1e3
+    O = NumpyBackend()
+    So = O.SpMatrix(A)
+    xo, yo = O.copy_array(xh), O.zero_array((10000, 8), np.dtype('complex64'))
+    ts = []
+    for _ in range(11):
+        t1 = time.perf_counter()
+        So.eval(yo, xo)
+        ts.append(time.perf_counter() - t1)
+    perr = float(np.linalg.norm(y.to_host() - yo.to_host()) / np.linalg.norm(yo.to_host()))
+    nbytes = A.nnz * 12 + 10001 * 4 + 10000 * 8 * 8 * 2
+    out = {"metric": "examples/spmm.py: 1e4 x 1e4 CSR (1 % nnz) x 8 RHS SpMM products/sec", "value": steps / elapsed, "unit": "products/s",
+           "n_gpus": 1, "steps": steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "complex64 (f32)", "data": "synthetic",
+           "config": {"workload": "BASELINE config 1 (the reference's CPU-runnable case), forward SpMatrix.eval, nnz %d" % A.nnz},
+           "roofline": dict(bound="hbm", kernel="+".join(sorted(prof)), achieved=nbytes / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                            frac=nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, algorithmic_bytes_per_launch=nbytes, traffic=None,
+                            note="13 MB: launch-latency bound, fits the L2"),
+           "cpu_baseline": dict(value=1.0 / min(ts[1:]), unit="products/s", cores=1, kind="port", **host_info(),
+                                sample="numpy oracle SpMatrix.eval, 1 warm-up + min of 10 (%.2f ms)" % (min(ts[1:]) * 1e3)),
+           "parity_rel_err": perr, "kernels": kernel_table(prof, steps)}
+    print(json.dumps(out), flush=True)
+
+
+def main():
+    args = parse()
+    rank = RANK
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, "--gpus must match WORLD_SIZE"
+    if world > 1 and os.environ.get("INDIGO_BENCH_DIST_BACKEND", "nccl") == "nccl":
+        from indigo_amd import _lib
+        import ctypes
+        n = ctypes.c_int()
+        _lib.lib().ig_device_count(ctypes.byref(n))
+        assert local_rank < n.value, "LOCAL_RANK %d but only %d GPU(s) visible: one rank per GPU" % (local_rank, n.value)
+    elif world > 1:
+        local_rank = 0                      # gloo rehearsal: all ranks share GPU 0
+    if args.config in (4, 5):
+        bench_sense(args, world, rank, local_rank)
+    else:
+        assert world == 1, "configs 1-3 are single-GPU leaf benchmarks"
+        {1: bench_spmm_example, 2: bench_fft, 3: bench_spmm}[args.config](args, local_rank)
 
 
 if __name__ == "__main__":

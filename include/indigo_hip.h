@@ -44,6 +44,7 @@ extern "C" {
 typedef struct ig_ctx   ig_ctx;    /* one device + one stream                */
 typedef struct ig_fft   ig_fft;    /* batched C2C FFT plan                   */
 typedef struct ig_event ig_event;  /* timing event on the context's stream   */
+typedef struct ig_comm  ig_comm;   /* RCCL communicator of one rank (one GPU) */
 
 /* ------------------------------------------------------------------------
  * Context.  Replaces the handle/bring-up code of CudaBackend.__init__
@@ -274,7 +275,42 @@ int  ig_fft_exec_cropped(ig_fft* plan, const void* y, const void* w, void* x, in
  * indigo/operators.py:440-447 VStack._eval_adjoint sums the per-coil results) inside the transform's last pass. */
 int  ig_fft_exec_cropped_sum(ig_fft* plan, const void* y, const void* w, void* x, void* workspace,
                              const int16_t* support);
+/* The same transform in two phases, so that the image can leave the GPU slab by slab while later slabs are still
+ * being transformed (multi-GPU: ig_allreduce_sum_f32_side per slab):
+ *   phase 0          : the z pass over the whole grid (z0, z1 ignored)
+ *   phase 1          : the y pass and the coil-summing x pass for the image planes z0 <= z' < z1 only; writes
+ *                      x[.., .., z0:z1].  Phases 1 over a partition of [0, box_dims[2]) after one phase 0 give exactly
+ *                      ig_fft_exec_cropped_sum.                                                              */
+int  ig_fft_exec_cropped_sum_slab(ig_fft* plan, const void* y, const void* w, void* x, void* workspace,
+                                  const int16_t* support, int phase, int64_t z0, int64_t z1);
 int  ig_fft_destroy(ig_fft* plan);
+
+/* ------------------------------------------------------------------------
+ * Multi-GPU: the one collective of the coil-sharded path.  KronI(C, B) never mixes coils
+ * (indigo/operators.py:374-375); VStack._eval_adjoint sums them (operators.py:440-447).  With the coils
+ * sharded over ranks that sum is finished by ONE all-reduce of the image per A^H A evaluation; CG's vectors
+ * stay replicated, so the reference's pdot/pnorm2 hook (indigo/backends/backend.py:469-479) needs no
+ * collective.  One process per GPU: rank 0 creates an id (ig_comm_unique_id, 128 opaque bytes), hands it to the
+ * other ranks by any out-of-band channel, and every rank calls ig_comm_init_rank (collective).  RCCL is loaded at
+ * run time on the first of these calls (IG_ERR_UNSUPPORTED if it cannot be found); nothing else in the library
+ * needs it.
+ * ---------------------------------------------------------------------- */
+#define IG_COMM_ID_BYTES 128
+int  ig_comm_unique_id(void* id_out /* IG_COMM_ID_BYTES, host */);
+int  ig_comm_init_rank(ig_ctx* ctx, int nranks, int rank, const void* id, ig_comm** out);   /* collective */
+int  ig_comm_info(ig_comm* comm, int* rank, int* nranks, char* rccl_lib, size_t len);
+/* in-place sum over the ranks of nfloats float32 (an image of N complex64 is 2N floats), enqueued on the context's
+ * stream like every other call -- no host synchronisation                                                     */
+int  ig_allreduce_sum_f32(ig_comm* comm, void* buf, int64_t nfloats);
+/* the same on the communicator's own stream, ordered after everything enqueued so far on the context's stream;
+ * ig_comm_join makes the context's stream wait for all such all-reduces (call it before anything reads the buffers) */
+int  ig_allreduce_sum_f32_side(ig_comm* comm, void* buf, int64_t nfloats);
+int  ig_comm_join(ig_comm* comm);
+/* one host double reduced over the ranks (step timing, convergence scalars); synchronous */
+int  ig_allreduce_max_f64_host(ig_comm* comm, double* inout);
+int  ig_allreduce_sum_f64_host(ig_comm* comm, double* inout);
+int  ig_comm_barrier(ig_comm* comm);                                   /* synchronous */
+int  ig_comm_destroy(ig_comm* comm);
 
 #ifdef __cplusplus
 }

@@ -78,6 +78,17 @@ PROTOTYPES = {
     "ig_fft_exec_padded": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ig_fft_exec_cropped": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "ig_fft_exec_cropped_sum": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ig_fft_exec_cropped_sum_slab": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64]),
+    "ig_comm_unique_id":  (c_int, [c_void_p]),
+    "ig_comm_init_rank":  (c_int, [c_void_p, c_int, c_int, c_void_p, POINTER(c_void_p)]),
+    "ig_comm_info":       (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), c_char_p, c_size_t]),
+    "ig_allreduce_sum_f32": (c_int, [c_void_p, c_void_p, c_int64]),
+    "ig_allreduce_sum_f32_side": (c_int, [c_void_p, c_void_p, c_int64]),
+    "ig_comm_join":       (c_int, [c_void_p]),
+    "ig_allreduce_max_f64_host": (c_int, [c_void_p, POINTER(c_double)]),
+    "ig_allreduce_sum_f64_host": (c_int, [c_void_p, POINTER(c_double)]),
+    "ig_comm_barrier":    (c_int, [c_void_p]),
+    "ig_comm_destroy":    (c_int, [c_void_p]),
 }
 
 

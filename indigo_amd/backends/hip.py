@@ -353,18 +353,26 @@ class HipBackend(Backend):
                                                 ctypes.c_void_p(support._arr) if support is not None else None),
                     "ig_fft_exec_cropped")
 
-    def ifft_cropped_sum(self, x, y, w, grid, box_lo, box_dims, workspace, support=None):
+    def ifft_cropped_sum(self, x, y, w, grid, box_lo, box_dims, workspace, support=None, slab=None):
         """x = sum_c conj(w[:, c]) * crop(IFFT(y[:, c])) for a coil-interleaved grid panel y (layout 2): the cropped
-        transform with the coil combination folded into its last pass"""
+        transform with the coil combination folded into its last pass.
+        slab: None = everything; 'z' = only the z pass; (z0, z1) = the y and x passes of the image planes z0..z1-1
+        (after one 'z' call; lets a multi-GPU caller all-reduce finished slabs while later ones are transformed)"""
         C = y.shape[1]
         assert y.dtype == _C64 and x.dtype == _C64 and y.contiguous and x.contiguous and w is not None
         assert x.size == int(np.prod(box_dims))
         plan, ws = self._padded_plan(grid, box_lo, box_dims, C, 2)
         assert workspace.nbytes >= ws
-        self._check(self._L.ig_fft_exec_cropped_sum(plan, ctypes.c_void_p(y._arr), ctypes.c_void_p(w._arr),
-                                                    ctypes.c_void_p(x._arr), ctypes.c_void_p(workspace._arr),
-                                                    ctypes.c_void_p(support._arr) if support is not None else None),
-                    "ig_fft_exec_cropped_sum")
+        sup = ctypes.c_void_p(support._arr) if support is not None else None
+        if slab is None:
+            self._check(self._L.ig_fft_exec_cropped_sum(plan, ctypes.c_void_p(y._arr), ctypes.c_void_p(w._arr),
+                                                        ctypes.c_void_p(x._arr), ctypes.c_void_p(workspace._arr), sup),
+                        "ig_fft_exec_cropped_sum")
+            return
+        phase, z0, z1 = (0, 0, 0) if slab == 'z' else (1, int(slab[0]), int(slab[1]))
+        self._check(self._L.ig_fft_exec_cropped_sum_slab(plan, ctypes.c_void_p(y._arr), ctypes.c_void_p(w._arr),
+                                                         ctypes.c_void_p(x._arr), ctypes.c_void_p(workspace._arr), sup,
+                                                         phase, z0, z1), "ig_fft_exec_cropped_sum_slab")
 
     def sum_columns(self, y, X, alpha=1, beta=0, interleaved=False):
         assert y.dtype == _C64 and X.dtype == _C64 and y.contiguous and y.size == X.shape[0]

@@ -18,7 +18,7 @@ LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "lib", "obj")
 LIBNAME = "libindigo_hip.so"
 
-SOURCES = ["ig_context.hip", "ig_blas.hip", "ig_spmm.hip", "ig_fft.hip"]
+SOURCES = ["ig_context.hip", "ig_blas.hip", "ig_spmm.hip", "ig_fft.hip", "ig_comm.hip"]
 ARCH = "gfx950"
 CXXFLAGS = [
     "--offload-arch=%s" % ARCH, "-O3", "-std=c++17", "-fPIC",
@@ -82,7 +82,7 @@ def build(force=False, verbose=False):
 
     out = lib_path()
     if force or jobs or not _newer(out, objs):
-        run([hipcc, "--offload-arch=%s" % ARCH, "-shared", "-fPIC", "-o", out] + objs)
+        run([hipcc, "--offload-arch=%s" % ARCH, "-shared", "-fPIC", "-o", out] + objs + ["-ldl"])
     return out
 
 

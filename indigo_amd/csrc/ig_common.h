@@ -29,6 +29,7 @@ struct ig_ctx {
     void*        d_xpack     = nullptr;   // SpMM repacked-panel scratch (grown on demand)
     size_t       xpack_bytes = 0;
     int32_t*     d_worklist  = nullptr;   // SpMM deferred-row lists + counters (allocated on first use)
+    bool         fft_w32_attr = false;    // the 32-column FFT kernels' dynamic-LDS opt-in was applied on this device
     // profile mode (ig_prof_enable): every kernel launch is bracketed by two events
     bool                     prof_on = false;
     std::vector<ig_prof_rec> prof;

@@ -52,6 +52,9 @@ static int ig_init_common(int device_id, bool adopt, void* ext_stream, ig_ctx** 
     ctx->device = device_id;
     auto bail = [&](const char* what, hipError_t err) {
         int rc = ig_fail(nullptr, IG_ERR_HIP, "ig_init: %s failed: %s", what, hipGetErrorString(err));
+        if (ctx->d_partials) (void)hipFree(ctx->d_partials);
+        if (ctx->h_result) (void)hipHostFree(ctx->h_result);
+        if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
         delete ctx;
         return rc;
     };

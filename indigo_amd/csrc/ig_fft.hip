@@ -866,13 +866,12 @@ int launch_2stage(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d_in, bool ax
         if (d2.tile_range) d2.tile_shift = d.tile_shift - 1;
         const dim3 g2((unsigned)(d2.tpr * (d.ncols / d.ext0))), b2(512);
         const size_t lds2 = ((size_t)16 * 16 * 32 + 512) * 8;
-        static bool attr_done = false;
-        if (!attr_done) {
+        if (!ctx->fft_w32_attr) {          // per context (= per device): the attribute is a per-device property
             IG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fft_2stage<32, 16, 16, 32, false, 0, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
             IG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fft_2stage<32, 16, 16, 32, false, 0, true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
             IG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fft_2stage<32, 16, 16, 32, false, 0, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
             IG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fft_2stage<32, 16, 16, 32, false, 0, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-            attr_done = true;
+            ctx->fft_w32_attr = true;
         }
         if (half == 1) hipLaunchKernelGGL((k_fft_2stage<32, 16, 16, 32, false, 0, true, 1>), g2, b2, lds2, ctx->stream, d2, ax.d_tw);
         else if (half == 3) hipLaunchKernelGGL((k_fft_2stage<32, 16, 16, 32, false, 0, true, 3>), g2, b2, lds2, ctx->stream, d2, ax.d_tw);
@@ -1216,8 +1215,9 @@ static int exec_padded_layout2(ig_fft* p, const float2* x, int64_t x_bstride, co
     return IG_OK;
 }
 
+// phases: bit 0 = the z pass (whole grid), bit 1 = the y and x passes, restricted to the image planes z0 <= z' < z1
 static int exec_cropped_layout2(ig_fft* p, const float2* y, const float2* w, float2* x, float2* work, const short2* support,
-                                bool sum_coils = false) {
+                                bool sum_coils = false, int phases = 3, int64_t z0 = 0, int64_t z1 = -1) {
     ig_ctx* ctx = p->ctx;
     const int64_t n0 = p->dims[0], n1 = p->dims[1], n2 = p->dims[2];
     const int64_t b0 = p->box_dims[0], b1 = p->box_dims[1], b2 = p->box_dims[2];
@@ -1225,7 +1225,9 @@ static int exec_cropped_layout2(ig_fft* p, const float2* y, const float2* w, flo
     const int64_t vol = n0 * n1 * n2, bvol = b0 * b1 * b2, C = p->batch;
     const int64_t cvol = n0 * b1 * b2;
     float2* L1 = work + (size_t)p->total;
-    {   // pass z: input intact, result into the workspace
+    if (z1 < 0) z1 = b2;
+    const int64_t nz = z1 - z0;                      // image planes the y and x passes cover
+    if (phases & 1) {   // pass z: input intact, result into the workspace
         ig_prof_scope prof(ctx, "fft_crop_z", (double)(vol + n0 * n1 * b2) * C * 8.0);
         PassDesc d{};
         d.in = y; d.out = work; d.in_sj = d.out_sj = C * n0;
@@ -1237,24 +1239,25 @@ static int exec_cropped_layout2(ig_fft* p, const float2* y, const float2* w, flo
         if (support) d.k1_range = support + n1 * (n0 / 16);                         // ky the y pass will never read
         if (int rc = launch_2stage(ctx, p->axis[2], d, false, 0)) return rc;
     }
+    if (!(phases & 2) || nz <= 0) return IG_OK;
     {   // pass y
-        ig_prof_scope prof(ctx, "fft_crop_y", (double)(n0 * n1 * b2 + cvol) * C * 8.0);
+        ig_prof_scope prof(ctx, "fft_crop_y", (double)(n0 * n1 * nz + n0 * b1 * nz) * C * 8.0);
         PassDesc d{};
-        d.in = work + l2 * C * n0; d.in_sj = C * n0 * n2; d.in_s[0] = 1; d.in_s[1] = C * n0;
-        d.out = L1 - l1 * C * n0; d.out_sj = C * n0; d.out_s[0] = 1; d.out_s[1] = C * n0 * b1;
-        d.ext0 = C * n0; d.ext1 = b2; d.ncols = C * n0 * b2;
+        d.in = work + (l2 + z0) * C * n0; d.in_sj = C * n0 * n2; d.in_s[0] = 1; d.in_s[1] = C * n0;
+        d.out = L1 - l1 * C * n0 + z0 * C * n0 * b1; d.out_sj = C * n0; d.out_s[0] = 1; d.out_s[1] = C * n0 * b1;
+        d.ext0 = C * n0; d.ext1 = nz; d.ncols = C * n0 * nz;
         d.in_lo = 0; d.in_hi = (int)n1; d.out_lo = (int)l1; d.out_hi = (int)(l1 + b1); d.inverse = 1;
         if (support) { d.tile_range = support + n1 * (n0 / 16); d.tile_range_mode = 2; d.tile_range_k1 = 0; d.tile_shift = lg2(C); }
         if (int rc = launch_2stage(ctx, p->axis[1], d, false, 0)) return rc;
     }
     if (sum_coils) {   // pass x with the coil combination: x = sum_c conj(w_c) .* crop(...), one image box
-        ig_prof_scope prof(ctx, "fft_crop_x", (double)(cvol + bvol) * C * 8.0 + (double)bvol * 8.0);
+        ig_prof_scope prof(ctx, "fft_crop_x", ((double)(cvol + bvol) * C * 8.0 + (double)bvol * 8.0) * (double)nz / (double)b2);
         PassDesc d{};
         d.cw = (int)C;
-        d.in = L1; d.in_sj = C; d.in_sa = 1; d.in_s[0] = C * n0; d.in_s[1] = C * n0 * b1;
-        d.out = x - l0; d.out_sj = 1; d.out_sa = 0; d.out_s[0] = b0; d.out_s[1] = b0 * b1;
-        d.w = w - l0 * C; d.w_sj = C; d.w_sa = 1; d.w_s[0] = b0 * C; d.w_s[1] = b0 * b1 * C;
-        d.ext0 = b1; d.ext1 = b2; d.ncols = b1 * b2;
+        d.in = L1 + z0 * C * n0 * b1; d.in_sj = C; d.in_sa = 1; d.in_s[0] = C * n0; d.in_s[1] = C * n0 * b1;
+        d.out = x - l0 + z0 * b0 * b1; d.out_sj = 1; d.out_sa = 0; d.out_s[0] = b0; d.out_s[1] = b0 * b1;
+        d.w = w - l0 * C + z0 * b0 * b1 * C; d.w_sj = C; d.w_sa = 1; d.w_s[0] = b0 * C; d.w_s[1] = b0 * b1 * C;
+        d.ext0 = b1; d.ext1 = nz; d.ncols = b1 * nz;
         d.in_lo = 0; d.in_hi = (int)n0; d.out_lo = (int)l0; d.out_hi = (int)(l0 + b0); d.inverse = 1;
         if (int rc = launch_2stage(ctx, p->axis[0], d, false, 3)) return rc;
     } else
@@ -1386,6 +1389,20 @@ int ig_fft_exec_cropped_sum(ig_fft* p, const void* yv, const void* wv, void* xv,
     if (int rc = ig_set_device(ctx)) return rc;
     return exec_cropped_layout2(p, (const float2*)yv, (const float2*)wv, (float2*)xv, (float2*)workspace,
                                 (const short2*)support, true);
+}
+
+int ig_fft_exec_cropped_sum_slab(ig_fft* p, const void* yv, const void* wv, void* xv, void* workspace, const int16_t* support,
+                                 int phase, int64_t z0, int64_t z1) {
+    if (!p) return ig_fail(nullptr, IG_ERR_ARG, "ig_fft_exec_cropped_sum_slab: plan is NULL");
+    ig_ctx* ctx = p->ctx;
+    IG_REQUIRE(ctx, p->padded && p->layout == 2, "ig_fft_exec_cropped_sum_slab: needs a plan of ig_fft_plan_padded with grid_layout 2");
+    IG_REQUIRE(ctx, xv && yv && wv && workspace, "ig_fft_exec_cropped_sum_slab: NULL array");
+    IG_REQUIRE(ctx, phase == 0 || phase == 1, "ig_fft_exec_cropped_sum_slab: phase must be 0 (z pass) or 1 (y and x passes of a slab)");
+    IG_REQUIRE(ctx, phase == 0 || (0 <= z0 && z0 <= z1 && z1 <= p->box_dims[2]),
+               "ig_fft_exec_cropped_sum_slab: slab [%lld, %lld) outside the image's %lld planes", (long long)z0, (long long)z1, (long long)p->box_dims[2]);
+    if (int rc = ig_set_device(ctx)) return rc;
+    return exec_cropped_layout2(p, (const float2*)yv, (const float2*)wv, (float2*)xv, (float2*)workspace,
+                                (const short2*)support, true, phase == 0 ? 1 : 2, z0, z1);
 }
 
 int ig_fft_describe(ig_fft* p, char* buf, size_t len) {

@@ -8,11 +8,23 @@ A^H A x = sum_g A_g^H A_g x is ONE all-reduce (sum) of N complex64 voxels
 per evaluation -- the only collective on the path.  x, and hence all
 CG vectors, stay replicated, so `dot`/`norm2` need no collective.
 
-The collective is `torch.distributed.all_reduce` (backend "nccl" = RCCL over
-xGMI on the GPU box, "gloo" in the CPU tests) on a tensor that aliases the
-backend's device buffer; it is enqueued on the backend's own stream so no host
-synchronisation is needed.  torch is imported lazily and only here.
+Two providers of that all-reduce:
+
+  * `RcclComm`   the library's own binding (`ig_comm_*` in include/indigo_hip.h: RCCL over xGMI, loaded at run
+                 time by libindigo_hip.so).  No torch anywhere in the product path.  The 128-byte communicator
+                 id travels from rank 0 to the others through a file in the node's temp directory (one node, one
+                 launcher: the ranks are siblings, see `_rendezvous_path`).  With it the all-reduce is issued slab
+                 by slab on the communicator's own stream while the cropped transform is still producing later
+                 slabs of the image (`ShardedNormalOperator`, `operators.ZpadFFT._slab_hook`).
+  * `TorchComm`  `torch.distributed.all_reduce` ("nccl" = RCCL on the GPU box, "gloo" in the CPU tests) on a tensor
+                 that aliases the backend's buffer, enqueued on the backend's own stream.  Kept for the CPU tests
+                 (the numpy oracle backend has no RCCL) and as the fallback if RCCL cannot be brought up directly.
 """
+import ctypes
+import os
+import tempfile
+import time
+
 import numpy as np
 
 _C64 = np.dtype('complex64')
@@ -33,8 +45,117 @@ class _DevicePtr(object):
                                              version=2, strides=None)
 
 
+def _rendezvous_path():
+    """Where rank 0 leaves the communicator id.  All ranks of one launch are children of one launcher process
+    (torch.distributed.run's agent, a test's parent): its pid + start time, the rendezvous port and the restart
+    count name the launch uniquely on this node.  INDIGO_COMM_ID_FILE overrides."""
+    if os.environ.get("INDIGO_COMM_ID_FILE"):
+        return os.environ["INDIGO_COMM_ID_FILE"]
+    ppid = os.getppid()
+    try:
+        with open("/proc/%d/stat" % ppid) as f:
+            start = f.read().rsplit(")", 1)[1].split()[19]          # field 22: start time in clock ticks
+    except OSError:
+        start = "0"
+    key = "%d_%s_%s_%s" % (ppid, start, os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"))
+    return os.path.join(tempfile.gettempdir(), "indigo_rccl_id_%s" % key)
+
+
+class RcclComm(object):
+    """Sum all-reduce of a HipBackend array across the ranks through the library's RCCL binding (ig_comm_*)."""
+
+    def __init__(self, backend, rank, world, timeout=120.0):
+        from indigo_amd import _lib
+        self._backend, self.rank, self.world = backend, int(rank), int(world)
+        self._L = backend._L
+        nbytes = 128
+        idbuf = ctypes.create_string_buffer(nbytes)
+        path = _rendezvous_path() if world > 1 else None
+        if rank == 0:
+            _lib.check(self._L.ig_comm_unique_id(idbuf), None, "ig_comm_unique_id")
+            if path:
+                tmp = "%s.%d.tmp" % (path, os.getpid())
+                with open(tmp, "wb") as f:
+                    f.write(idbuf.raw)
+                os.replace(tmp, path)                                # atomic: readers never see a partial id
+        else:
+            t0 = time.time()
+            while True:
+                try:
+                    with open(path, "rb") as f:
+                        raw = f.read()
+                    if len(raw) == nbytes:
+                        break
+                except OSError:
+                    pass
+                if time.time() - t0 > timeout:
+                    raise RuntimeError("RcclComm: rank %d found no communicator id at %s after %.0f s" % (rank, path, timeout))
+                time.sleep(0.02)
+            idbuf = ctypes.create_string_buffer(raw, nbytes)
+        comm = ctypes.c_void_p()
+        backend._check(self._L.ig_comm_init_rank(backend._ctx, self.world, self.rank, idbuf, ctypes.byref(comm)), "ig_comm_init_rank")
+        self._comm = comm
+        self.overlap = os.environ.get("INDIGO_COMM_OVERLAP", "1") != "0"
+        self._pending = False
+        self.barrier()                                               # every rank has read the id
+        if rank == 0 and path:
+            try:
+                os.remove(path)
+            except OSError:
+                pass
+
+    def describe(self):
+        buf = ctypes.create_string_buffer(256)
+        self._L.ig_comm_info(self._comm, None, None, buf, 256)
+        return "ig_comm (C ABI) over %s, %d ranks, slab overlap %s" % (buf.value.decode(), self.world, "on" if self.overlap else "off")
+
+    def allreduce_(self, arr, force=False):
+        """in-place sum over ranks, in order on the backend's stream"""
+        if self.world == 1 and not force:
+            return
+        assert arr.dtype == _C64 and arr.contiguous
+        self._backend._check(self._L.ig_allreduce_sum_f32(self._comm, ctypes.c_void_p(arr._arr), arr.size * 2), "ig_allreduce_sum_f32")
+
+    def allreduce_slab_(self, arr, lo, hi):
+        """sum voxels [lo, hi) of arr over the ranks on the communicator's own stream, after the work enqueued so far"""
+        ptr = arr._arr + lo * 8
+        self._backend._check(self._L.ig_allreduce_sum_f32_side(self._comm, ctypes.c_void_p(ptr), (hi - lo) * 2), "ig_allreduce_sum_f32_side")
+        self._pending = True
+
+    def join(self):
+        if self._pending:
+            self._backend._check(self._L.ig_comm_join(self._comm), "ig_comm_join")
+            self._pending = False
+
+    def barrier(self):
+        self._backend._check(self._L.ig_comm_barrier(self._comm), "ig_comm_barrier")
+
+    def max(self, value):
+        v = ctypes.c_double(float(value))
+        self._backend._check(self._L.ig_allreduce_max_f64_host(self._comm, ctypes.byref(v)), "ig_allreduce_max_f64_host")
+        return v.value
+
+    def allreduce(self, value):
+        """sum of a host float over ranks (the reference's team.allreduce in pdot/pnorm2, backend.py:469-479)"""
+        v = ctypes.c_double(float(value))
+        self._backend._check(self._L.ig_allreduce_sum_f64_host(self._comm, ctypes.byref(v)), "ig_allreduce_sum_f64_host")
+        return v.value
+
+    def close(self):
+        if getattr(self, '_comm', None):
+            self._L.ig_comm_destroy(self._comm)
+            self._comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class TorchComm(object):
     """Sum all-reduce of a backend array across the default torch.distributed process group."""
+    overlap = False
 
     def __init__(self, backend):
         import torch
@@ -48,6 +169,9 @@ class TorchComm(object):
             self._device = torch.device('cuda', backend.device_id)
             self._stream = torch.cuda.ExternalStream(backend.stream, device=self._device)
         self._cache = {}
+
+    def describe(self):
+        return "torch.distributed (%s), %d ranks" % (self._dist.get_backend(), self.world)
 
     def _tensor(self, arr):
         assert arr.dtype == _C64 and arr.contiguous
@@ -73,6 +197,9 @@ class TorchComm(object):
         else:
             self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
 
+    def join(self):
+        pass
+
     def barrier(self):
         if self.world > 1:
             self._dist.barrier()
@@ -86,16 +213,32 @@ class TorchComm(object):
         self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
         return float(t.item())
 
+    def allreduce(self, value):
+        """sum of a host float over ranks (the reference's team.allreduce, backend.py:469-479)"""
+        if self.world == 1:
+            return value
+        t = self._torch.tensor([value], dtype=self._torch.float64, device=self._device if self._on_gpu else 'cpu')
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def close(self):
+        if self._dist.is_initialized():
+            self._dist.destroy_process_group()
+
 
 class ShardedNormalOperator(object):
     """y = sum_g A_g^H A_g x (+ lamda x) with the sum taken by one all-reduce.
 
     `A_local` is the forward operator for this rank's coils (e.g.
-    `SenseProblem.build_fused(backend, coils=coil_range(C, rank, world))`).
+    `SenseProblem.build_zpadfft(backend, coils=coil_range(C, rank, world))`).
     Exposes `eval(y, x)` and `shape` so `Backend.cg` can drive it like any operator.
+
+    With a communicator that has its own stream (`RcclComm`) and a tree that ends in ONE coil-interleaved
+    `ZpadFFT` leaf, the image is all-reduced in `nslabs` z-slabs: slab s crosses xGMI while the y and x passes
+    of slab s+1 run (the z pass, gridding and everything before it cannot overlap: the image does not exist yet).
     """
 
-    def __init__(self, A_local, comm, lamda=0.0):
+    def __init__(self, A_local, comm, lamda=0.0, nslabs=4):
         self._A = A_local
         self._backend = A_local._backend
         self._comm = comm
@@ -104,6 +247,15 @@ class ShardedNormalOperator(object):
         self.shape = (n, n)
         self.dtype = _C64
         self._ksp = None
+        self._leaf = None
+        if getattr(comm, 'overlap', False) and comm.world > 1 and nslabs > 1:
+            from indigo_amd import operators as op
+            r = A_local
+            while isinstance(r, op.Product):
+                r = r.right
+            if isinstance(r, op.ZpadFFT) and r._layout == 2 and hasattr(self._backend, 'ifft_cropped_sum'):
+                self._leaf = r
+                self._nslabs = int(nslabs)
 
     def eval(self, y, x, alpha=1, beta=0, forward=True, left=True):
         assert alpha == 1 and beta == 0, "ShardedNormalOperator computes y = AHA x only"
@@ -112,7 +264,15 @@ class ShardedNormalOperator(object):
         if self._ksp is None or self._ksp.shape != (self._A.shape[0], ncols):
             self._ksp = B.zero_array((self._A.shape[0], ncols), _C64, name='ksp(shard)')
         self._A.eval(self._ksp, x)
-        self._A.eval(y, self._ksp, forward=False)
-        self._comm.allreduce_(y)
+        if self._leaf is not None and ncols == 1:
+            self._leaf._slab_hook = (self._nslabs, self._comm.allreduce_slab_)
+            try:
+                self._A.eval(y, self._ksp, forward=False)
+            finally:
+                self._leaf._slab_hook = None
+            self._comm.join()
+        else:
+            self._A.eval(y, self._ksp, forward=False)
+            self._comm.allreduce_(y)
         if self._lamda:
             B.axpby(1, y, self._lamda, x)

@@ -1,0 +1,162 @@
+"""Assembly of the fused SENSE tree  A = KronI(C, G'_perm) * ZpadFFT  from its ingredients.
+
+Shared by `SenseProblem.build_zpadfft` (which builds the ingredients directly) and by the `FuseZpadFFT`
+transform (which recovers them from the reference's `-O3` tree, examples/pics.py:104-193).  The oversampled
+k-space grid exists only between these two leaves, so its memory order is theirs to choose:
+
+  layout 0   (x, y, z) per coil      the reference's Fortran order
+  layout 1   (x, z, y) per coil      keeps the transform's largest pass at a small stride
+  layout 2   (c, x, z, y)            layout 1 with the coils interleaved below x
+
+and the gridding matrix's columns are renumbered to match.
+"""
+import numpy as np
+import scipy.sparse as spp
+
+_C64 = np.dtype('complex64')
+
+
+def permute_grid_columns(G, oN):
+    """Renumber the columns of a gridding matrix from the (x, y, z) grid order to (x, z, y); sorted CSR."""
+    n0, n1, n2 = (int(n) for n in oN)
+    G = G.tocsr()
+    idx = G.indices.astype(np.int64)
+    kx = idx % n0
+    ky = (idx // n0) % n1
+    kz = idx // (n0 * n1)
+    out = spp.csr_matrix((G.data, (kx + n0 * (kz + n2 * ky)).astype(np.int32), G.indptr), shape=G.shape)
+    out.sort_indices()
+    return out
+
+
+def grid_support(G, oN):
+    """k-space support of a layout-1 gridding matrix G (T x P) as the flat int16 table ig_fft_exec_padded,
+    ig_fft_exec_cropped and ig_ccsrmm_t_grid take.  Three parts:
+      1. [z_lo, z_hi) per (ky, 16-wide kx tile): the kz range outside which no sample touches the grid;
+      2. [y_lo, y_hi) per kx tile: the ky range with a non-empty z range (the transform's y pass);
+      3. 16 uint32 words per (ky, kx tile): bit m of word t is set iff the 16-row segment (kx tile, ky,
+         kz = t + 16*m) holds a nonzero of G.  Segments without a nonzero are never gridded from, never
+         written by the adjoint gridding and read as zero by the cropped transform.
+    A radial trajectory fills a ball (half of the grid cube lies outside) and, away from the centre, leaves
+    gaps between spokes: 30 % of the 16-row segments of the 512^3 grid of the headline problem are flagged."""
+    n0, n1, n2 = (int(n) for n in oN)
+    assert n0 % 16 == 0 and n2 % 16 == 0 and n2 <= 512
+    nt = n0 // 16
+    cols = np.unique(G.indices)
+    kx = cols % n0
+    kz = (cols // n0) % n2
+    ky = cols // (n0 * n2)
+    key = ky * nt + kx // 16
+    bits = np.zeros((n1 * nt, 16), dtype=np.uint32)
+    np.bitwise_or.at(bits, (key, kz % 16), np.uint32(1) << (kz // 16).astype(np.uint32))
+    order = np.argsort(key, kind='stable')
+    key, kz = key[order], kz[order]
+    ranges = np.zeros((n1 * nt + nt, 2), dtype=np.int16)
+    if key.size:
+        starts = np.flatnonzero(np.r_[True, key[1:] != key[:-1]])
+        ranges[key[starts], 0] = np.minimum.reduceat(kz, starts)
+        ranges[key[starts], 1] = np.maximum.reduceat(kz, starts) + 1
+    nonempty = (ranges[:n1 * nt, 1] > ranges[:n1 * nt, 0]).reshape(n1, nt)
+    for t in range(nt):
+        ys = np.flatnonzero(nonempty[:, t])
+        if ys.size:
+            ranges[n1 * nt + t] = (ys[0], ys[-1] + 1)
+    return np.concatenate([ranges.reshape(-1), bits.reshape(-1).view(np.int16)])
+
+
+def split_support(table, oN):
+    """(z ranges (n1*nt, 2), y ranges (nt, 2), segment bits (n1*nt, 16) uint32) views of a support table"""
+    n0, n1, n2 = (int(n) for n in oN)
+    nt = n0 // 16
+    table = np.ascontiguousarray(table, dtype=np.int16).reshape(-1)
+    a, b = 2 * n1 * nt, 2 * (n1 * nt + nt)
+    return table[:a].reshape(-1, 2), table[a:b].reshape(-1, 2), table[b:].view(np.uint32).reshape(n1 * nt, 16)
+
+
+def coil_chunks(Cn, chunk=8):
+    """Split Cn coils into runs the coil-interleaved kernels take (8, then 4, 2; a last odd coil alone)."""
+    out, lo = [], 0
+    for size in (c for c in (16, 8, 4, 2, 1) if c <= chunk):
+        while Cn - lo >= size:
+            out.append((lo, lo + size))
+            lo += size
+    return out
+
+
+def choose_layout(Cn, chunk=8, layout=None):
+    """(layout, chunks) for Cn coils on one rank"""
+    chunks = coil_chunks(Cn, chunk) if Cn > chunk and layout in (None, 2) else [(0, Cn)]
+    if layout is None:      # coils interleaved below the grid where the kernels support it (2, 4 or 8 per rank)
+        layout = 2 if (len(chunks) > 1 or Cn in (2, 4, 8)) else 1
+    return layout, chunks
+
+
+def assemble(backend, Gm, oN, N, weights_of, Cn, layout, chunks, table=None, box_lo=None, row_order=None,
+             name='SENSE-fusedFFT'):
+    """A = KronI(C, G') * ZpadFFT, or a VStack of such trees over coil chunks sharing ONE device copy of G'.
+
+    Gm          gridding matrix (T x P, complex64 CSR) with its columns in the order of `layout` (see
+                permute_grid_columns; layout 2 uses layout 1's numbering)
+    weights_of  (lo, hi) -> weights array box + (hi - lo,) for that run of coils (maps * roll-off * modulation)
+    More coils than a chunk holds (the reference's `batch` hint, indigo/operators.py:15-17,341: evaluate a wide
+    KronI a few columns at a time) become a VStack: the k-space rows come out coil-major exactly as from KronI(C, G'),
+    and the adjoint accumulates the chunks' images (VStack, operators.py:440-447)."""
+    def gridding(interleaved):
+        G = backend.SpMatrix(Gm, name='interp*mod*scale')
+        if interleaved:
+            G._grid_interleaved = True
+        if table is not None:
+            G._grid_support = (table, int(oN[0]), int(oN[2]))
+        if row_order is not None:
+            G._row_order = row_order
+        return G
+
+    G_il = gridding(True) if layout == 2 else None
+    G_pc = None
+    trees = []
+    for lo, hi in chunks:
+        lay = layout if (layout != 2 or hi - lo > 1 or len(chunks) == 1) else 1     # a left-over single coil: per-coil kernels
+        if lay == 2:
+            G = G_il
+        else:
+            G_pc = G_pc or gridding(False)
+            G = G_pc
+        Z = backend.ZpadFFT(oN, N, weights_of(lo, hi), box_lo=box_lo, layout=lay, support=table, name='fft*zpad*apod*maps')
+        trees.append(backend.KronI(hi - lo, G) * Z)
+    A = trees[0] if len(trees) == 1 else backend.VStack(trees, name='coil-chunks')
+    A._name = name
+    return A
+
+
+def decode_zpad_maps(St, C, P, oN):
+    """Recover (box_lo, box_dims, weights) from the stored form of the `-O3` tree's S' factor:
+    St = S'^H as an N x (C*P) CSR whose row i holds, for each coil c, conj(w[i, c]) at column c*P + zrow(i), the
+    zrow(i) enumerating a box of the grid in Fortran order (SenseProblem.fused_maps_T; the reference builds the same
+    matrix from Zpad, FFTc's modulation, the roll-off and the maps, examples/pics.py:104-177).
+    Returns None if the matrix does not have that structure."""
+    St = St.tocsr()
+    St.sort_indices()
+    Nn = St.shape[0]
+    if St.shape[1] != C * P or St.nnz != Nn * C or not np.array_equal(St.indptr, np.arange(0, (Nn + 1) * C, C)):
+        return None
+    cols = St.indices.reshape(Nn, C).astype(np.int64)
+    if not np.array_equal(cols // P, np.broadcast_to(np.arange(C), (Nn, C))):
+        return None
+    pos = cols % P
+    if not (pos == pos[:, :1]).all():
+        return None
+    z = pos[:, 0]
+    n0, n1, n2 = (int(n) for n in oN)
+    kx, ky, kz = z % n0, (z // n0) % n1, z // (n0 * n1)
+    lo = (int(kx.min()), int(ky.min()), int(kz.min()))
+    dims = (int(kx.max()) - lo[0] + 1, int(ky.max()) - lo[1] + 1, int(kz.max()) - lo[2] + 1)
+    if dims[0] * dims[1] * dims[2] != Nn:
+        return None
+    i = np.arange(Nn)
+    ex = lo[0] + i % dims[0]
+    ey = lo[1] + (i // dims[0]) % dims[1]
+    ez = lo[2] + i // (dims[0] * dims[1])
+    if not (np.array_equal(kx, ex) and np.array_equal(ky, ey) and np.array_equal(kz, ez)):
+        return None
+    w = np.conj(St.data.reshape(Nn, C)).astype(_C64)
+    return lo, dims, np.asfortranarray(w).reshape(dims + (C,), order='F')

@@ -369,10 +369,31 @@ class ZpadFFT(MatrixFreeOperator):
                     B.fft_padded(yj.reshape((P, C)), xj, w, self._grid, self._lo, self._box)
                 if alpha != 1:
                     B.scale(yj, alpha)
-            elif self._layout == 2 and alpha == 1 and beta == 0 and hasattr(B, 'ifft_cropped_sum'):
+            elif self._layout == 2 and hasattr(B, 'ifft_cropped_sum'):
                 # coil combination inside the transform's last pass: no per-coil image arrays at all
-                with B.scratch(nbytes=self._ws_bytes()) as ws:
-                    B.ifft_cropped_sum(yj, xj.reshape((P, C)), w, self._grid, self._lo, self._box, ws, self._support())
+                hook = getattr(self, '_slab_hook', None)
+                if alpha == 1 and beta == 0 and hook is not None and ncols == 1:
+                    # multi-GPU: the image leaves slab by slab -- hook(y, lo, hi) all-reduces voxels [lo, hi) of y on the
+                    # communicator's stream while the next slab is still being transformed (indigo_amd/dist.py)
+                    nslabs, fn = hook
+                    b2, plane = self._box[2], self._box[0] * self._box[1]
+                    with B.scratch(nbytes=self._ws_bytes()) as ws:
+                        xg = xj.reshape((P, C))
+                        B.ifft_cropped_sum(yj, xg, w, self._grid, self._lo, self._box, ws, self._support(), slab='z')
+                        edges = [b2 * i // nslabs for i in range(nslabs + 1)]
+                        for z0, z1 in zip(edges[:-1], edges[1:]):
+                            if z1 > z0:
+                                B.ifft_cropped_sum(yj, xg, w, self._grid, self._lo, self._box, ws, self._support(), slab=(z0, z1))
+                                fn(yj, z0 * plane, z1 * plane)
+                elif alpha == 1 and beta == 0:
+                    with B.scratch(nbytes=self._ws_bytes()) as ws:
+                        B.ifft_cropped_sum(yj, xj.reshape((P, C)), w, self._grid, self._lo, self._box, ws, self._support())
+                else:
+                    # (a read-modify-write of y inside the pass was measured slower than this extra axpby over one image)
+                    with B.scratch(shape=(N, 1)) as acc:
+                        with B.scratch(nbytes=self._ws_bytes()) as ws:
+                            B.ifft_cropped_sum(acc, xj.reshape((P, C)), w, self._grid, self._lo, self._box, ws, self._support())
+                        B.axpby(beta, yj, alpha, acc)
             else:
                 with B.scratch(shape=(N, C)) as tmp:
                     with B.scratch(nbytes=self._ws_bytes()) as ws:
@@ -586,10 +607,12 @@ class VStack(CompositeOperator):
                 C.eval(_slice_rows(y, off, off + h), x, alpha=alpha, beta=beta, forward=True, left=left)
                 off += h
         else:
-            self._backend.scale(y, beta)
-            for C in self._children:
+            # y = beta*y + sum_i C_i^H x_i.  The reference scales y by beta and then accumulates every child with
+            # beta = 1 (operators.py:440-447); handing beta to the first child is the same sum without the extra
+            # read-modify-write of y (and lets a leaf take its beta == 0 fast path).
+            for i, C in enumerate(self._children):
                 h = C.shape[0]
-                C.eval(y, _slice_rows(x, off, off + h), alpha=alpha, beta=1, forward=False, left=left)
+                C.eval(y, _slice_rows(x, off, off + h), alpha=alpha, beta=beta if i == 0 else 1, forward=False, left=left)
                 off += h
 
 

@@ -19,6 +19,7 @@ import numpy as np
 import scipy.sparse as spp
 from scipy.signal.windows import kaiser
 
+from indigo_amd import fused
 from indigo_amd import operators as op
 from indigo_amd.interp import interp_csr_arrays
 from indigo_amd.noncart import rolloff3
@@ -42,12 +43,15 @@ def radial_trajectory(nspokes, nreadout, seed=3):
 class SenseProblem(object):
     """Host-side description of one non-Cartesian SENSE reconstruction."""
 
-    def __init__(self, N, coord, maps, width=2, ntable=128, oversamp=2.0):
+    def __init__(self, N, coord, maps, width=2, ntable=128, oversamp=2.0, ncoils=None):
         self.N = tuple(int(n) for n in N)
         self.coord = np.asarray(coord, dtype=np.float64)
         assert self.coord.shape[0] == 3
-        self.maps = maps                              # (N0, N1, N2, C) complex64, F-ordered
-        self.C = int(maps.shape[3])
+        # maps: (N0, N1, N2, C) complex64, F-ordered -- or a callable c -> (N0, N1, N2) map of coil c (with `ncoils`),
+        # so that a rank of a coil-sharded run only ever materialises its own coils (32 coils x 320^3 = 8.4 GB)
+        self.maps = maps
+        self.C = int(ncoils) if callable(maps) else int(maps.shape[3])
+        self._interp_cache = {}
         self.width, self.ntable, self.oversamp = width, int(ntable), float(oversamp)
         self.oN = tuple(int(n * self.oversamp) for n in self.N)
         self.T = int(np.prod(self.coord.shape[1:]))
@@ -57,12 +61,24 @@ class SenseProblem(object):
         self.table = kaiser(2 * self.ntable + 1, self.beta)[self.ntable:]
 
     @classmethod
-    def synthetic(cls, N, C, nspokes, nreadout, width=2, ntable=128, oversamp=2.0, seed=4):
-        """Seeded synthetic problem: radial trajectory + uniform random complex maps."""
+    def synthetic(cls, N, C, nspokes, nreadout, width=2, ntable=128, oversamp=2.0, seed=4, lazy_maps=False):
+        """Seeded synthetic problem: radial trajectory + uniform random complex maps.
+        lazy_maps: coil c's map is generated on demand from the seed (seed, c) instead of one (N, C) array up front."""
         from indigo_amd.util import rand64c
         coord = radial_trajectory(nspokes, nreadout, seed=seed - 1)
+        if lazy_maps:
+            N = tuple(int(n) for n in N)
+            return cls(N, coord, lambda c: rand64c(*N, seed=[seed, int(c)]), width=width, ntable=ntable,
+                       oversamp=oversamp, ncoils=C)
         maps = rand64c(*tuple(N), C, seed=seed)
         return cls(N, coord, maps, width=width, ntable=ntable, oversamp=oversamp)
+
+    def drop_cache(self):
+        self._interp_cache = {}
+
+    def coil_map(self, c):
+        """(N0, N1, N2) sensitivity map of coil c"""
+        return self.maps(c) if callable(self.maps) else self.maps[:, :, :, c]
 
     # -- the reference's route ------------------------------------------------------------
     def build_tree(self, backend, level=0, coils=None):
@@ -70,7 +86,7 @@ class SenseProblem(object):
         F1 = backend.NUFFT(self.ksp_dims, self.N, self.coord, width=self.width, n=self.ntable,
                            oversamp=self.oversamp, dtype=_C64)
         F = backend.KronI(len(coils), F1)
-        S = backend.VStack([backend.Diag(self.maps[:, :, :, c:c + 1]) for c in coils], name='maps')
+        S = backend.VStack([backend.Diag(self.coil_map(c)[..., None]) for c in coils], name='maps')
         A = F * S
         A._name = 'SENSE1'
         if level:
@@ -82,6 +98,8 @@ class SenseProblem(object):
     def fused_interp(self, layout=0):
         """G' = interp * mod * (1/sqrt(P)) as a complex64 CSR (T x P).
         layout=1 indexes the grid columns in (x, z, y) memory order (see operators.ZpadFFT)."""
+        if layout in self._interp_cache:
+            return self._interp_cache[layout]
         P = int(np.prod(self.oN))
         indptr, indices, w = interp_csr_arrays(self.T, self.oN, self.width, self.table,
                                                self.coord.reshape(3, -1, order='F'), dtype=np.float32)
@@ -89,16 +107,11 @@ class SenseProblem(object):
         scale = np.complex64(np.float32(1.0) / np.sqrt(np.float32(P)))
         data = w.astype(_C64) * mod[indices]
         data *= scale
+        G = spp.csr_matrix((data, indices, indptr), shape=(self.T, P))
         if layout == 1:
-            n0, n1, n2 = self.oN
-            kx = indices % n0
-            ky = (indices // n0) % n1
-            kz = indices // (n0 * n1)
-            indices = (kx + n0 * (kz + n2 * ky)).astype(np.int32)
-            G = spp.csr_matrix((data, indices, indptr), shape=(self.T, P))
-            G.sort_indices()
-            return G
-        return spp.csr_matrix((data, indices, indptr), shape=(self.T, P))
+            G = fused.permute_grid_columns(G, self.oN)
+        self._interp_cache[layout] = G            # 0.6 GB per layout at 5e7 nonzeros; drop_cache() releases them
+        return G
 
     def fused_maps_T(self, coils=None):
         """S'^H stored form: CSR of shape (N, C*P) whose adjoint is S' = (I_C (x) mod*zpad*apod) * maps."""
@@ -111,14 +124,13 @@ class SenseProblem(object):
         mod = backend_mod(self.oN).reshape(-1, order='F')[zrows]
         apod = rolloff3(self.oversamp, self.width, self.beta, self.N).reshape(-1, order='F').astype(_C64)
         base = (mod * apod).astype(_C64)                                 # per-voxel factor shared by all coils
-        maps = self.maps.reshape(Nn, self.C, order='F')
         # row i holds, for each coil c, conj(base[i]*maps[i,c]) at column c*P + zrows[i]
         indptr = np.arange(0, (Nn + 1) * Cn, Cn, dtype=np.int64)
         indices = np.empty((Nn, Cn), dtype=np.int32)
         data = np.empty((Nn, Cn), dtype=_C64)
         for j, c in enumerate(coils):
             indices[:, j] = (zrows + j * P).astype(np.int32)
-            data[:, j] = np.conj(base * maps[:, c])
+            data[:, j] = np.conj(base * self.coil_map(c).reshape(Nn, order='F'))
         return spp.csr_matrix((data.reshape(-1), indices.reshape(-1), indptr), shape=(Nn, Cn * P))
 
     def fused_weights(self, coils=None):
@@ -131,50 +143,15 @@ class SenseProblem(object):
         base = (mod * apod).astype(_C64)
         w = np.empty(self.N + (len(coils),), dtype=_C64, order='F')
         for j, c in enumerate(coils):
-            np.multiply(base, self.maps[:, :, :, c], out=w[:, :, :, j])
+            np.multiply(base, self.coil_map(c), out=w[:, :, :, j])
         return w
 
     def grid_support(self, G):
-        """k-space support of a layout-1 gridding matrix G (T x P) as the flat int16 table ig_fft_exec_padded,
-        ig_fft_exec_cropped and ig_ccsrmm_t_grid take.  Three parts:
-          1. [z_lo, z_hi) per (ky, 16-wide kx tile): the kz range outside which no sample touches the grid;
-          2. [y_lo, y_hi) per kx tile: the ky range with a non-empty z range (the transform's y pass);
-          3. 16 uint32 words per (ky, kx tile): bit m of word t is set iff the 16-row segment (kx tile, ky,
-             kz = t + 16*m) holds a nonzero of G.  Segments without a nonzero are never gridded from, never
-             written by the adjoint gridding and read as zero by the cropped transform.
-        A radial trajectory fills a ball (half of the grid cube lies outside) and, away from the centre, leaves
-        gaps between spokes: 30 % of the 16-row segments of the 512^3 grid of the headline problem are flagged."""
-        n0, n1, n2 = self.oN
-        assert n0 % 16 == 0 and n2 % 16 == 0 and n2 <= 512
-        nt = n0 // 16
-        cols = np.unique(G.indices)
-        kx = cols % n0
-        kz = (cols // n0) % n2
-        ky = cols // (n0 * n2)
-        key = ky * nt + kx // 16
-        bits = np.zeros((n1 * nt, 16), dtype=np.uint32)
-        np.bitwise_or.at(bits, (key, kz % 16), np.uint32(1) << (kz // 16).astype(np.uint32))
-        order = np.argsort(key, kind='stable')
-        key, kz = key[order], kz[order]
-        ranges = np.zeros((n1 * nt + nt, 2), dtype=np.int16)
-        if key.size:
-            starts = np.flatnonzero(np.r_[True, key[1:] != key[:-1]])
-            ranges[key[starts], 0] = np.minimum.reduceat(kz, starts)
-            ranges[key[starts], 1] = np.maximum.reduceat(kz, starts) + 1
-        nonempty = (ranges[:n1 * nt, 1] > ranges[:n1 * nt, 0]).reshape(n1, nt)
-        for t in range(nt):
-            ys = np.flatnonzero(nonempty[:, t])
-            if ys.size:
-                ranges[n1 * nt + t] = (ys[0], ys[-1] + 1)
-        return np.concatenate([ranges.reshape(-1), bits.reshape(-1).view(np.int16)])
+        """k-space support table of a layout-1 gridding matrix (see indigo_amd.fused.grid_support)"""
+        return fused.grid_support(G, self.oN)
 
     def split_support(self, table):
-        """(z ranges (n1*nt, 2), y ranges (nt, 2), segment bits (n1*nt, 16) uint32) views of a support table"""
-        n0, n1, n2 = self.oN
-        nt = n0 // 16
-        table = np.ascontiguousarray(table, dtype=np.int16).reshape(-1)
-        a, b = 2 * n1 * nt, 2 * (n1 * nt + nt)
-        return table[:a].reshape(-1, 2), table[a:b].reshape(-1, 2), table[b:].view(np.uint32).reshape(n1 * nt, 16)
+        return fused.split_support(table, self.oN)
 
     def zpadfft_pass_bytes(self, ncoils, table=None, fused_sum=False):
         """Compulsory HBM bytes of each axis pass of the fused transform (layout 1): what the pass must read
@@ -214,32 +191,29 @@ class SenseProblem(object):
         first[nz] = G.indices[G.indptr[nz]]
         return np.argsort(first, kind='stable').astype(np.int32)
 
-    def build_zpadfft(self, backend, coils=None, layout=None, support=None, reorder=False):
+    coil_chunks = staticmethod(fused.coil_chunks)
+
+    def build_zpadfft(self, backend, coils=None, layout=None, support=None, reorder=False, chunk=8):
         """A = KronI(C, G') * ZpadFFT: the `-O3` tree with S' and the FFT fused into one leaf
         (zero-pad aware transform; needs backend.supports_padded_fft(grid)).  The oversampled grid is
         private to this pair of leaves, so it may live in the (x, z, y) order (layout=1) that keeps the
-        transform's largest pass at a small stride; G' is indexed to match."""
+        transform's largest pass at a small stride; G' is indexed to match.
+
+        More coils than `chunk` become a VStack of `chunk`-coil trees that share ONE device copy of G' (and of its
+        transpose and support table): the 512^3 x 32-coil grid of BASELINE config 5 would be 34 GB, a chunk is 8.6 GB
+        and stays the size the kernels were tuned on (indigo_amd.fused.assemble)."""
         coils = list(range(self.C) if coils is None else coils)
         Cn = len(coils)
-        if layout is None:      # coils interleaved below the grid where the kernels support it (2, 4 or 8 per rank)
-            layout = 2 if Cn in (2, 4, 8) else 1
+        layout, chunks = fused.choose_layout(Cn, chunk, layout)
         Gm = self.fused_interp(1 if layout == 2 else layout)      # layout 2 = layout 1 with the coils interleaved below
-        G = backend.SpMatrix(Gm, name='interp*mod*scale')
-        if layout == 2:
-            G._grid_interleaved = True
         table = None
         if (support is None or support) and layout >= 1 and self.oN[0] % 16 == 0:
             # restrict the transform's z pass and the adjoint gridding to the k-space support of G'
             table = self.grid_support(Gm)
-            G._grid_support = (table, self.oN[0], self.oN[2])
         self.last_support_table = table
-        if reorder and Cn <= 8:
-            G._row_order = self.locality_order(Gm)
-        Z = backend.ZpadFFT(self.oN, self.N, self.fused_weights(coils), layout=layout, support=table,
-                            name='fft*zpad*apod*maps')
-        A = backend.KronI(Cn, G) * Z
-        A._name = 'SENSE-fusedFFT'
-        return A
+        order = self.locality_order(Gm) if reorder and Cn <= 8 else None
+        return fused.assemble(backend, Gm, self.oN, self.N, lambda lo, hi: self.fused_weights(coils[lo:hi]), Cn,
+                              layout, chunks, table=table, row_order=order)
 
     def build_fused(self, backend, coils=None):
         coils = list(range(self.C) if coils is None else coils)

@@ -237,6 +237,59 @@ class UseExwriteProperty(Transform):
         return node
 
 
+class FuseZpadFFT(Transform):
+    """KronI(C, G') * (KronI(C, UnscaledFFT) * S')  =>  KronI(C, G'_perm) * ZpadFFT.
+
+    Runs after `sense_recipe(3)` (the reference's `pics.py -O3`, examples/pics.py:179-193).  That recipe leaves the
+    forward operator as two sparse factors around a batched FFT; S' (stored transposed inside an Adjoint by
+    MriGoodAdjoints) is zero-pad * modulation * roll-off * maps -- a box position and one weight per voxel and coil.
+    Where the backend has zero-pad-aware transforms for the grid (`supports_padded_fft`), S' and the FFT collapse into the
+    `ZpadFFT` leaf and G' is renumbered for the leaf's grid order; the result evaluates to the same numbers
+    (tests: golden `-O3` vectors).  Trees that do not match are returned unchanged."""
+    chunk = 8
+
+    def visit_Product(self, node):
+        node = self.generic_visit(node)
+        from indigo_amd import fused
+        from indigo_amd.operators import ZpadFFT    # noqa: F401  (the leaf this pass introduces)
+        L, R = node._children
+        b = node._backend
+        if not (isinstance(L, Kron) and isinstance(L.left, Eye) and isinstance(L.right, SpMatrix) and isinstance(R, Product)):
+            return node
+        F, X = R._children
+        if not (isinstance(F, Kron) and isinstance(F.left, Eye) and isinstance(F.right, UnscaledFFT)):
+            return node
+        C = F.left.shape[0]
+        grid = F.right._ft_shape
+        if L.left.shape[0] != C or len(grid) != 3 or not b.supports_padded_fft(grid):
+            return node
+        if isinstance(X, Adjoint) and isinstance(X.child, SpMatrix):
+            St = X.child._matrix
+        elif isinstance(X, SpMatrix):
+            St = X._matrix.conjugate().transpose()
+        else:
+            return node
+        P = int(np.prod(grid))
+        dec = fused.decode_zpad_maps(St.astype(np.complex64), C, P, grid)
+        if dec is None:
+            log.info("FuseZpadFFT: %s is not a zero-pad * diagonal factor; tree left as is", X._name)
+            return node
+        lo, box, w = dec
+        layout, chunks = fused.choose_layout(C, self.chunk)
+        Gm = L.right._matrix.astype(np.complex64).tocsr()
+        if layout >= 1:
+            Gm = fused.permute_grid_columns(Gm, grid)
+        table = fused.grid_support(Gm, grid) if (layout >= 1 and grid[0] % 16 == 0 and grid[2] % 16 == 0 and grid[2] <= 512) else None
+        A = fused.assemble(b, Gm, grid, box, lambda c0, c1: w[..., c0:c1], C, layout, chunks, table=table, box_lo=lo,
+                           name=node._name)
+        A._fused_layout = layout
+        return A
+
+    @staticmethod
+    def layout_of(node):
+        return getattr(node, '_fused_layout', 0)
+
+
 def sense_recipe(level=3):
     """The pass list of `pics.py -O<level>` (examples/pics.py:179-193)."""
     recipe = []

@@ -1,0 +1,271 @@
+"""BASELINE.json configurations 2-5 at FULL size on the GPU, each against an oracle that shares no code with the
+library: numpy's pocketfft, scipy's csr product and the numpy restatement of the reference backend
+(oracle/np_backend.py).  These are the kernel instantiations bench.py times -- the two-stage FFT kernel on a STRIDED
+512-point axis (R1 = 32, 16- and 32-column tiles, half-box variants), the coil-interleaved gridding kernels, the
+64-column SpMM -- which the small golden-vector cases never reach (reference pattern: test_backends.py:153-210).
+
+Where the full result is too large to compare on the host, linearity restricts it: a SENSE operator whose other
+coils are zero, a k-space panel whose other columns are zero, or a subset of the panel columns.
+Tolerance: 1e-5 relative (L2) in complex64, the north star's bar.
+"""
+import numpy as np
+import pytest
+import scipy.sparse as spp
+
+from conftest import rel_err
+from indigo_amd.sense import SenseProblem, normal_operator
+from indigo_amd.util import rand64c
+
+pytestmark = pytest.mark.gpu
+C64 = np.dtype('complex64')
+RTOL = 1e-5
+
+
+# ---------------------------------------------------------------------------------------
+# plain fftn/ifftn on 512-point axes at a stride (k_fft_2stage<32,16,16,16,false,...>) and config 2
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(4, 512), (48, 512), (16, 512, 2), (16, 512, 8), (2, 3, 512), (32, 16, 512),
+                                   (32, 512, 512), (512, 512, 4), (8, 256), (16, 256, 6), (4, 5, 256)])
+def test_fft_strided_two_stage_axes_vs_numpy(hip, shape):
+    batch = 3
+    x = rand64c(*(shape + (batch,)), seed=sum(shape))
+    x_d = hip.copy_array(x)
+    y_d = hip.zero_array(x.shape, C64)
+    hip.fftn(y_d, x_d)
+    assert "2stage" in hip.fft_describe(x.shape)
+    axes = tuple(range(len(shape)))
+    assert rel_err(y_d.to_host(), np.fft.fftn(x.astype(np.complex128), axes=axes)) < RTOL, hip.fft_describe(x.shape)
+    hip.ifftn(y_d, x_d)
+    assert rel_err(y_d.to_host(), np.fft.ifftn(x.astype(np.complex128), axes=axes) * np.prod(shape)) < RTOL
+
+
+def test_config2_fft_256_cubed_batch16(hip):
+    """BASELINE config 2 as quoted: 256^3 complex64, 16 batches.  Two of the volumes against numpy, all of them by
+    Parseval and the unnormalised round trip; in place and out of place."""
+    n, batch = 256, 16
+    x = rand64c(n, n, n, batch, seed=2)
+    x_d = hip.copy_array(x)
+    y_d = hip.zero_array(x.shape, C64)
+    hip.fftn(y_d, x_d)
+    for j in (0, 11):
+        got = y_d[:, :, :, j:j + 1].to_host()[..., 0]
+        assert rel_err(got, np.fft.fftn(x[..., j])) < RTOL, j
+    e_in, e_out = hip.norm2(x_d), hip.norm2(y_d)
+    np.testing.assert_allclose(e_out, e_in * n ** 3, rtol=1e-5)
+    hip.ifftn(y_d, y_d)                                         # in place, inverse
+    got = y_d[:, :, :, 5:6].to_host()[..., 0]
+    assert rel_err(got / n ** 3, x[..., 5]) < RTOL
+    hip.axpby(1.0 / n ** 3, y_d, -1.0, x_d)
+    assert np.sqrt(hip.norm2(y_d) / e_in) < RTOL
+    del x_d, y_d
+
+
+# ---------------------------------------------------------------------------------------
+# config 3: 3-D radial gridding CSR (T x 256^3, 27 taps per row, 5e7 nonzeros) x 64-column panel
+# ---------------------------------------------------------------------------------------
+def gridding_problem(grid, nspokes, nreadout, seed=3):
+    """SenseProblem used only for its trajectory and gridding matrix (oversamp 1: the grid IS the image)"""
+    from indigo_amd.sense import radial_trajectory
+    coord = radial_trajectory(nspokes, nreadout, seed=seed)
+    return SenseProblem(grid, coord, lambda c: None, width=2, ntable=128, oversamp=1.0, ncoils=1)
+
+
+def test_config3_gridding_csr_times_64_columns(hip):
+    """the workload of BASELINE config 3 (3617 spokes x 512 samples on 256^3, width 2 -> 27 taps), forward and
+    adjoint through the reference's SpMatrix surface, eight of the 64 columns compared with scipy on the host"""
+    from indigo_amd.interp import interp_csr_arrays
+    from scipy.signal.windows import kaiser
+    N, ncol = (256, 256, 256), 64
+    gp = gridding_problem(N, 3617, 512)
+    beta = np.pi * np.sqrt(((2 * 2.0 / 2.0) * (2.0 - 0.5)) ** 2 - 0.8)
+    table = kaiser(2 * 128 + 1, beta)[128:]
+    indptr, indices, w = interp_csr_arrays(gp.T, N, 2, table, gp.coord.reshape(3, -1, order='F'), dtype=np.float32)
+    G = spp.csr_matrix((w.astype(C64), indices, indptr), shape=(gp.T, int(np.prod(N))))
+    assert 4.9e7 < G.nnz < 5.1e7
+    S = hip.SpMatrix(G, name='gridding')
+    P, T = G.shape[1], G.shape[0]
+    cols = [0, 9, 18, 27, 36, 45, 54, 63]
+    # the 8.6 GB panel is generated and uploaded eight columns at a time; the compared columns stay on the host
+    X_d = hip.empty_array((P, ncol), C64)
+    keep = {}
+    for j0 in range(0, ncol, 8):
+        blk = rand64c(P, 8, seed=100 + j0)
+        X_d[:, j0:j0 + 8].copy_from(blk)
+        for j in cols:
+            if j0 <= j < j0 + 8:
+                keep[j] = blk[:, j - j0].copy()
+        del blk
+    Xs = np.stack([keep[j] for j in cols], axis=1)
+    Y_d = hip.zero_array((T, ncol), C64)
+    S.eval(Y_d, X_d)
+    Y = Y_d.to_host()
+    assert rel_err(Y[:, cols], G @ Xs) < RTOL
+    # a second, independent check of ALL columns: column sums commute with the product
+    np.testing.assert_allclose(Y.sum(axis=0)[cols], (G @ Xs).sum(axis=0), rtol=1e-4)
+    del X_d
+    # adjoint: Z = G^H Y (256^3 x 64); compare the same eight columns
+    Z_d = hip.empty_array((P, ncol), C64)
+    S.eval(Z_d, Y_d, forward=False)
+    GH = G.conj().T.tocsr()
+    exp = GH @ Y[:, cols]
+    for i, j in enumerate(cols):
+        got = Z_d[:, j:j + 1].to_host()[:, 0]
+        assert rel_err(got, exp[:, i]) < RTOL, j
+    # beta / alpha on the wide adjoint (a second evaluation accumulates)
+    S.eval(Z_d, Y_d, alpha=0.5, beta=-1.0, forward=False)
+    got = Z_d[:, 27:28].to_host()[:, 0]
+    assert rel_err(got, -0.5 * exp[:, 3]) < RTOL
+    del Z_d, Y_d
+
+
+# ---------------------------------------------------------------------------------------
+# config 4: the headline SENSE problem at full size against the numpy oracle, coil by coil
+# ---------------------------------------------------------------------------------------
+def masked_coils(p, keep):
+    """the same problem with every coil outside `keep` switched off (zero map): the interleaved 8-coil kernels then
+    compute sum_{c in keep} A_c^H A_c x, which the one-coil oracle can check"""
+    zero = np.zeros(p.N, dtype=C64, order='F')
+    q = SenseProblem(p.N, p.coord, lambda c: p.coil_map(c) if c in keep else zero, width=p.width, ntable=p.ntable,
+                     oversamp=p.oversamp, ncoils=p.C)
+    q._interp_cache = p._interp_cache
+    return q
+
+
+def oracle_coil_ops(p, oracle_backend, coils):
+    return {c: p.build_zpadfft(oracle_backend, coils=[c], layout=0, support=False) for c in coils}
+
+
+def test_config4_full_size_vs_numpy_oracle(hip, oracle_backend):
+    """image 256^3, 8 coils, grid 512^3, T = 1,851,904 (what bench.py times, grid layout 2):
+       forward  : k-space columns of coils 0 and 5 == oracle A_c x
+       adjoint  : A^H of a panel that is non-zero in columns 2 and 7 == oracle A_2^H k_2 + A_7^H k_7
+       normal   : A^H A with all coils but one switched off == oracle A_0^H A_0 x
+       one coil : the per-coil kernels a rank of an 8-GPU run uses (layout 1) == the same oracle results"""
+    p = SenseProblem.synthetic((256, 256, 256), 8, nspokes=3617, nreadout=512, width=2, ntable=128, oversamp=2.0, seed=4)
+    hip._scratch = None
+    oracle_backend._scratch = None
+    T, C = p.T, p.C
+    x = rand64c(int(np.prod(p.N)), 1, seed=1)
+    k = np.zeros((T, C), dtype=C64, order='F')
+    k[:, 2] = rand64c(T, seed=2)
+    k[:, 7] = rand64c(T, seed=3)
+    A = p.build_zpadfft(hip)                                   # layout 2, with the k-space support table
+    Ax = (A * x).reshape(T, C, order='F')
+    AHk = A.H * k.reshape(-1, 1, order='F')
+    del A
+    hip._scratch = None
+    A1 = p.build_zpadfft(hip, coils=[0])                       # layout 1, single-column gridding kernels
+    A1x = A1 * x
+    A1Hk = A1.H * np.asfortranarray(k[:, 2:3])                 # (coil 0's weights applied to column 2's data)
+    del A1
+    hip._scratch = None
+    A0 = masked_coils(p, {0}).build_zpadfft(hip)               # the benchmarked operator, coils 1..7 switched off
+    y_d = hip.zero_array((x.shape[0], 1), C64)
+    normal_operator(A0).eval(y_d, hip.copy_array(x))
+    AHA0 = y_d.to_host()
+    del A0, y_d
+    hip._scratch = None
+    # ---- oracle, one coil at a time (numpy pocketfft + scipy csr) ----
+    O = oracle_coil_ops(p, oracle_backend, [0, 5, 2, 7])
+    o0x = O[0] * x
+    assert rel_err(Ax[:, 0:1], o0x) < RTOL
+    assert rel_err(A1x, o0x) < RTOL
+    assert rel_err(AHA0, O[0].H * o0x) < RTOL
+    assert rel_err(A1Hk, O[0].H * np.asfortranarray(k[:, 2:3])) < RTOL
+    del o0x
+    assert rel_err(Ax[:, 5:6], O[5] * x) < RTOL
+    exp = O[2].H * np.asfortranarray(k[:, 2:3]) + O[7].H * np.asfortranarray(k[:, 7:8])
+    assert rel_err(AHk, exp) < RTOL
+    oracle_backend._scratch = None
+    p.drop_cache()
+
+
+# ---------------------------------------------------------------------------------------
+# config 5: image 320^3 in a 512^3 grid (oversampling 1.6), 32 coils in chunks / 4 coils per rank
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("C,layout", [(2, 2), (1, 1)])
+def test_config5_box_320_in_512_leaves_vs_numpy(hip, C, layout):
+    """the zero-pad-aware transforms on the box of config 5 (not the half box: run-time box predicates on a
+    512-point axis), coil 0 against numpy"""
+    grid, box = (512, 512, 512), (320, 320, 320)
+    lo = tuple(m // 2 + int(np.ceil(-n / 2)) for m, n in zip(grid, box))
+    assert lo == (96, 96, 96)
+    P, N = int(np.prod(grid)), int(np.prod(box))
+    hip._scratch = None
+    x = rand64c(N, 1, seed=1)
+    w = rand64c(N, C, seed=2)
+    w_d = hip.copy_array(np.ascontiguousarray(w).reshape(-1)) if layout == 2 else hip.copy_array(w)
+    sl = tuple(slice(l, l + b) for l, b in zip(lo, box))
+    ws = hip.zero_array((hip._fft_padded_workspace(grid, lo, box, C, layout) // 8,), C64)
+    y_d = hip.copy_array(np.full((P, C), np.nan, dtype=C64, order='F'))
+    hip.fft_padded(y_d, hip.copy_array(x), w_d, grid, lo, box, ws, layout)
+    y = y_d.to_host()
+    full = np.zeros(grid, dtype=C64, order='F')
+    full[sl] = (w[:, 0] * x[:, 0]).reshape(box, order='F')
+    ref = np.fft.fftn(full)                                    # (x, y, z)
+    if layout == 2:
+        got = y.reshape(-1, order='F').reshape((C, grid[0], grid[2], grid[1]), order='F')[0].transpose(0, 2, 1)
+    else:
+        got = y[:, 0].reshape((grid[0], grid[2], grid[1]), order='F').transpose(0, 2, 1)
+    assert rel_err(got, ref) < RTOL
+    del full, ref, got
+    # cropped inverse of y itself: crop(IFFT(FFT(pad(w x)))) * conj(w) = P * |w|^2 x  -- and against numpy for coil 0
+    xc_d = hip.copy_array(np.full((N, C), np.nan, dtype=C64, order='F'))
+    hip.ifft_cropped(xc_d, y_d, w_d, grid, lo, box, ws, layout)
+    xc = xc_d.to_host()
+    xc0 = xc.reshape(-1, order='F').reshape(N, C)[:, 0] if layout == 2 else xc[:, 0]
+    assert rel_err(xc0, P * np.abs(w[:, 0]) ** 2 * x[:, 0]) < RTOL
+    del y_d, xc_d, ws
+    hip._scratch = None
+
+
+def test_config5_shard_of_four_coils_vs_oracle(hip, oracle_backend):
+    """what one rank of the 8-GPU run of config 5 evaluates: 4 of the 32 coils of a 320^3 image on the 512^3 grid
+    (fewer spokes than the benchmark, the same grid, box and kernels), against the one-coil numpy oracle"""
+    p = SenseProblem.synthetic((320, 320, 320), 32, nspokes=600, nreadout=512, width=2, ntable=128, oversamp=1.6,
+                               seed=5, lazy_maps=True)
+    assert p.oN == (512, 512, 512)
+    hip._scratch = None
+    oracle_backend._scratch = None
+    coils = [12, 13, 14, 15]                                   # rank 3 of 8
+    A = p.build_zpadfft(hip, coils=coils)
+    T = p.T
+    x = rand64c(int(np.prod(p.N)), 1, seed=1)
+    k = np.zeros((T, 4), dtype=C64, order='F')
+    k[:, 0] = rand64c(T, seed=2)
+    k[:, 3] = rand64c(T, seed=3)
+    Ax = (A * x).reshape(T, 4, order='F')
+    AHk = A.H * k.reshape(-1, 1, order='F')
+    del A
+    hip._scratch = None
+    O = oracle_coil_ops(p, oracle_backend, [12, 13, 15])
+    assert rel_err(Ax[:, 1:2], O[13] * x) < RTOL
+    exp = O[12].H * np.asfortranarray(k[:, 0:1]) + O[15].H * np.asfortranarray(k[:, 3:4])
+    assert rel_err(AHk, exp) < RTOL
+    oracle_backend._scratch = None
+    p.drop_cache()
+
+
+def test_config5_coil_chunks_vs_oracle(hip, oracle_backend):
+    """more coils than one interleaved grid holds: a VStack of chunks sharing one device gridding matrix.
+    Reduced size (image 160^3 in a 256^3 grid, oversampling 1.6, 6 coils in chunks of 2 + an odd 7th alone)."""
+    p = SenseProblem.synthetic((160, 160, 160), 7, nspokes=300, nreadout=256, width=2, ntable=128, oversamp=1.6, seed=5,
+                               lazy_maps=True)
+    assert p.oN == (256, 256, 256)
+    hip._scratch = None
+    oracle_backend._scratch = None
+    A = p.build_zpadfft(hip, chunk=2)
+    from indigo_amd import operators as op
+    assert isinstance(A, op.VStack) and len(A.children) == 4
+    A_o = p.build_zpadfft(oracle_backend, layout=0, support=False)
+    x = rand64c(A.shape[1], 1, seed=1)
+    k = rand64c(A.shape[0], 1, seed=2)
+    assert rel_err(A * x, A_o * x) < RTOL
+    assert rel_err(A.H * k, A_o.H * k) < RTOL
+    AHA = normal_operator(A, lamda=0.3)
+    y_d = hip.zero_array((A.shape[1], 1), C64)
+    AHA.eval(y_d, hip.copy_array(x))
+    exp = A_o.H * (A_o * x) + np.float32(0.3) * x
+    assert rel_err(y_d.to_host(), exp) < RTOL
+    hip._scratch = None
+    oracle_backend._scratch = None

@@ -1,7 +1,12 @@
-"""GPU side of the multi-GPU path, exercised with ONE rank on the one GPU of the test box:
-torch (RCCL) aliases the backend's device buffer through __cuda_array_interface__ and the
-all-reduce is enqueued on the backend's own stream.  Runs in a subprocess because torch must be
-imported before libindigo_hip.so so that both share one HIP runtime."""
+"""GPU side of the multi-GPU path, exercised with ONE rank on the one GPU of the test box.
+
+  * the library's own RCCL communicator (ig_comm_* through ctypes, no torch in the process): bring-up from a
+    128-byte id, in-order all-reduce, slab-by-slab all-reduce on the communicator's stream overlapped with the
+    cropped transform, host-scalar reductions, barrier;
+  * the torch fallback: torch (RCCL) aliases the backend's device buffer through __cuda_array_interface__ and the
+    all-reduce is enqueued on the backend's own stream.
+Both run in subprocesses (the second because torch must be imported before libindigo_hip.so so that both share one
+HIP runtime; the first so that RCCL is loaded by the library alone)."""
 import os
 import subprocess
 import sys
@@ -53,5 +58,62 @@ def test_torch_aliasing_and_stream_ordered_allreduce():
     env = dict(os.environ, REPO_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29517",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-4000:]
+
+
+RCCL_WORKER = r"""
+import os, sys
+sys.path.insert(0, os.environ["REPO_ROOT"])
+import numpy as np
+assert "torch" not in sys.modules
+from indigo_amd.backends import get_backend
+from indigo_amd.dist import RcclComm, ShardedNormalOperator
+from indigo_amd.sense import SenseProblem, normal_operator
+from indigo_amd.util import rand64c
+B = get_backend("hip")
+comm = RcclComm(B, 0, 1)
+print(comm.describe())
+x = rand64c(100003, seed=1)
+d = B.copy_array(x)
+B.scale(d, 2.0)                       # queued on the backend stream ...
+comm.allreduce_(d, force=True)        # ... the collective must see it (same stream); sum over 1 rank = identity
+B.axpby(1, d, 1, B.copy_array(x))     # ... and later work must see the collective's result
+np.testing.assert_allclose(d.to_host(), 3 * x, rtol=1e-6)
+# side-stream all-reduce of two halves, joined before the next kernel
+B.scale(d, 0.5)
+comm.allreduce_slab_(d, 0, 50000)
+comm.allreduce_slab_(d, 50000, 100003)
+comm.join()
+B.scale(d, 2.0)
+np.testing.assert_allclose(d.to_host(), 3 * x, rtol=1e-6)
+assert comm.max(2.5) == 2.5 and comm.allreduce(1.25) == 1.25
+comm.barrier()
+# sharded operator, slab path forced on although there is one rank: == the plain normal operator
+p = SenseProblem.synthetic((128, 128, 128), 4, nspokes=200, nreadout=256, width=2, oversamp=2.0, seed=5)
+A = p.build_zpadfft(B)
+xs = B.copy_array(rand64c(A.shape[1], 1, seed=2))
+c64 = np.dtype("complex64")
+y1, y2 = B.zero_array((A.shape[1], 1), c64), B.zero_array((A.shape[1], 1), c64)
+op = ShardedNormalOperator(A, comm, lamda=0.1, nslabs=5)
+assert op._leaf is None               # one rank: nothing to overlap
+comm.world = 2                        # pretend, to take the slab route (the RCCL communicator still has one rank)
+op = ShardedNormalOperator(A, comm, lamda=0.1, nslabs=5)
+assert op._leaf is not None
+op.eval(y1, xs)
+comm.world = 1
+B._scratch = None
+normal_operator(A, lamda=0.1).eval(y2, xs)
+a, b = y1.to_host(), y2.to_host()
+assert np.linalg.norm(a - b) <= 1e-6 * np.linalg.norm(b), np.linalg.norm(a - b) / np.linalg.norm(b)
+comm.close()
+print("OK")
+"""
+
+
+def test_rccl_communicator_through_the_c_abi():
+    env = dict(os.environ, REPO_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("INDIGO_HIP_WITH_TORCH", None)
+    r = subprocess.run([sys.executable, "-c", RCCL_WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                        text=True, timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-4000:]

@@ -453,3 +453,21 @@ def test_padded_fft_with_support_table(hip):
     exp = A.conj().T @ xs
     assert rel_err(out[inside], exp[inside]) < RTOL
     np.testing.assert_array_equal(out[~inside], sentinel[~inside])
+
+
+def test_fuse_zpadfft_transform_reaches_the_benchmarked_leaf(hip, oracle_backend):
+    """the reference's route (NUFFT / KronI / VStack(Diag) factories, pics.py -O3 recipe) + FuseZpadFFT builds the same
+    fused tree as SenseProblem.build_zpadfft and evaluates like the -O3 tree it came from"""
+    from indigo_amd import operators as op
+    from indigo_amd.transforms import FuseZpadFFT, sense_recipe
+    p = SenseProblem.synthetic((64, 64, 64), 4, nspokes=300, nreadout=128, width=2, oversamp=4.0, seed=4)      # grid 256^3
+    hip._scratch = None
+    A3 = p.build_tree(hip, level=3)
+    x, k = rand64c(A3.shape[1], 1, seed=1), rand64c(A3.shape[0], 1, seed=2)
+    A3x, A3Hk = A3 * x, A3.H * k
+    Af = FuseZpadFFT().visit(p.build_tree(hip, level=3))
+    assert Af.has(op.ZpadFFT) and not Af.has(op.UnscaledFFT) and FuseZpadFFT.layout_of(Af) == 2
+    assert rel_err(Af * x, A3x) < RTOL and rel_err(Af.H * k, A3Hk) < RTOL
+    Ad = p.build_zpadfft(hip)
+    assert rel_err(Af * x, Ad * x) < 1e-6
+    hip._scratch = None

@@ -69,7 +69,7 @@ def test_nufft_apply(prob, oracle_backend):
     assert rel_err(x_d.to_host(), g["nufft_adj"]) < 1e-5
 
 
-@pytest.mark.parametrize("level", [0, 1, 2, 3, "fused", "zpadfft", "zpadfft-xyz", "zpadfft-il"])
+@pytest.mark.parametrize("level", [0, 1, 2, 3, "fused", "zpadfft", "zpadfft-xyz", "zpadfft-il", "zpadfft-chunked"])
 def test_sense_forward_adjoint_normal(prob, oracle_backend, level):
     p, g = prob
     B = oracle_backend
@@ -77,6 +77,11 @@ def test_sense_forward_adjoint_normal(prob, oracle_backend, level):
         B._scratch = None
     if level == "fused":
         A = p.build_fused(B)
+    elif level == "zpadfft-chunked":
+        # more coils than the chunk: VStack of coil-interleaved chunks sharing one gridding matrix (+ a left-over single coil)
+        A = p.build_zpadfft(B, chunk=2)
+        assert isinstance(A, op.VStack) and len(A.children) == (p.C + 1) // 2
+        assert len({id(c.left.right) for c in A.children if getattr(c.left.right, '_grid_interleaved', False)}) <= 1
     elif level in ("zpadfft", "zpadfft-xyz", "zpadfft-il"):
         A = p.build_zpadfft(B, layout={"zpadfft": 1, "zpadfft-xyz": 0, "zpadfft-il": 2}[level])
     else:
@@ -84,7 +89,7 @@ def test_sense_forward_adjoint_normal(prob, oracle_backend, level):
     x, k = g["sense_x"], g["sense_k"]
     assert rel_err(A * x, g["sense_Ax"]) < 1e-5
     assert rel_err(A.H * k, g["sense_AHk"]) < 1e-5
-    if level in (3, "fused", "zpadfft", "zpadfft-xyz", "zpadfft-il"):
+    if level in (3, "fused", "zpadfft", "zpadfft-xyz", "zpadfft-il", "zpadfft-chunked"):
         assert rel_err(A * x, g["sense_O3_Ax"]) < 1e-5
         assert rel_err(A.H * k, g["sense_O3_AHk"]) < 1e-5
     AHA = normal_operator(A, lamda=float(g["lamda"]))
@@ -145,3 +150,59 @@ def test_coil_shards_sum_to_full_adjoint(prob, oracle_backend):
         ks = np.asfortranarray(k[:, coils]).reshape(-1, 1, order='F')
         total = total + A.H * ks
     assert rel_err(total, g["sense_AHk"]) < 1e-5
+
+
+def test_coil_chunks_and_lazy_maps(oracle_backend):
+    assert SenseProblem.coil_chunks(32, 8) == [(0, 8), (8, 16), (16, 24), (24, 32)]
+    assert SenseProblem.coil_chunks(13, 8) == [(0, 8), (8, 12), (12, 13)]
+    assert SenseProblem.coil_chunks(6, 4) == [(0, 4), (4, 6)]
+    # per-coil generated maps (what a rank of a sharded run materialises) give the same operator as the stacked array
+    lazy = SenseProblem.synthetic((12, 10, 8), 5, nspokes=7, nreadout=24, oversamp=1.5, seed=11, lazy_maps=True)
+    full = SenseProblem(lazy.N, lazy.coord, np.stack([lazy.coil_map(c) for c in range(5)], axis=3), oversamp=1.5)
+    B = oracle_backend
+    B._scratch = None
+    x = np.asfortranarray(lazy.coil_map(0).reshape(-1, 1, order='F'))
+    A1, A2 = lazy.build_fused(B, coils=[1, 3]), full.build_fused(B, coils=[1, 3])
+    np.testing.assert_array_equal(A1 * x, A2 * x)
+    A3 = lazy.build_zpadfft(B, chunk=2)
+    A4 = full.build_fused(B)
+    assert rel_err(A3 * x, A4 * x) < 1e-5
+    k = (A4 * x).astype(C64)
+    assert rel_err(A3.H * k, A4.H * k) < 1e-5
+    B._scratch = None
+
+
+def test_fuse_zpadfft_transform_on_the_reference_recipe(prob, oracle_backend):
+    """reference route: factories -> pics.py -O3 recipe -> FuseZpadFFT reaches the fused leaf and evaluates to the
+    golden -O3 vectors; a tree without the S' structure is left alone"""
+    from indigo_amd.transforms import FuseZpadFFT, sense_recipe
+    p, g = prob
+    B = oracle_backend
+    B._scratch = None
+    A = p.build_tree(B, level=0)
+    for Step in sense_recipe(3) + [FuseZpadFFT]:
+        A = Step().visit(A)
+    assert A.has(op.ZpadFFT) and not A.has(op.UnscaledFFT)
+    leaves = [line.split(", ")[1] for line in A.dump().strip().split("\n")]
+    assert leaves.count("SpMatrix") == 1 and leaves.count("ZpadFFT") == 1
+    x, k = g["sense_x"], g["sense_k"]
+    assert rel_err(A * x, g["sense_O3_Ax"]) < 1e-5
+    assert rel_err(A.H * k, g["sense_O3_AHk"]) < 1e-5
+    AHA = normal_operator(A, lamda=float(g["lamda"]))
+    y_d = B.zero_array((A.shape[1], 1), C64)
+    AHA.eval(y_d, B.copy_array(x))
+    assert rel_err(y_d.to_host(), g["sense_AHAx"]) < 1e-5
+    B._scratch = None
+    # the same leaves as the direct builder
+    Ad = p.build_zpadfft(B)
+    assert type(Ad.right).__name__ == type(A.right).__name__ == "ZpadFFT"
+    assert Ad.right._lo == A.right._lo and Ad.right._box == A.right._box and Ad.right._layout == A.right._layout
+    np.testing.assert_allclose(A.right._weights().to_host(), Ad.right._weights().to_host(), rtol=2e-6, atol=1e-9)
+    Ga, Gd = A.left.right._matrix.tocsr(), Ad.left.right._matrix.tocsr()
+    np.testing.assert_array_equal(Ga.indices, Gd.indices)
+    np.testing.assert_allclose(Ga.data, Gd.data, rtol=2e-6, atol=1e-12)
+    # no match: a plain product of two sparse matrices stays as it is
+    import scipy.sparse as spp
+    M = B.SpMatrix(spp.eye(6, dtype=C64).tocsr()) * B.SpMatrix(spp.eye(6, dtype=C64).tocsr())
+    assert FuseZpadFFT().visit(M) is M
+    B._scratch = None
