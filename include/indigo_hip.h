@@ -217,6 +217,19 @@ int  ig_csr_transpose(int64_t M, int64_t K, int64_t nnz,
                       const int32_t* rowptr, const int32_t* colind, const void* vals,
                       int32_t* rowptr_t, int32_t* colind_t, void* vals_t);
 
+/* Host-side construction of the 3-D gridding (interpolation) matrix, CSR.  Replaces the numba loop nest
+ * _interp3_mat / lin_interp (indigo/interp.py:8-80) behind Backend.Interp (indigo/backends/backend.py:392-401):
+ * same arithmetic in the same order in double precision, float32 weights out (the NUFFT factory stores float32,
+ * backend.py:438).  m samples, coord = 3 x m doubles (all x, then all y, then all z) in units of the field of view,
+ * N = grid dims, width = kernel HALF-width, table = ntable samples of the kernel on [0, 1).
+ *   ig_interp3_count : rowptr[0..m]   (number of taps of every sample, prefix-summed)
+ *   ig_interp3_fill  : colind / weights, columns sorted within a row; grid_order 0 numbers the grid (x, y, z) like the
+ *                      reference, 1 numbers it (x, z, y) (the order of the fused transform's grid layouts 1 and 2).
+ * All pointers are HOST memory.                                                                               */
+int  ig_interp3_count(int64_t m, const int64_t* N, double width, const double* coord, int32_t* rowptr);
+int  ig_interp3_fill(int64_t m, const int64_t* N, double width, const double* table, int64_t ntable,
+                     const double* coord, const int32_t* rowptr, int32_t* colind, float* weights, int grid_order);
+
 /* ------------------------------------------------------------------------
  * Batched complex-to-complex FFT.  Replaces Backend.fftn/ifftn
  * (indigo/backends/backend.py:497-512; oracle np.py:102-115; cuFFT plan

@@ -18,7 +18,7 @@ LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "lib", "obj")
 LIBNAME = "libindigo_hip.so"
 
-SOURCES = ["ig_context.hip", "ig_blas.hip", "ig_spmm.hip", "ig_fft.hip", "ig_comm.hip"]
+SOURCES = ["ig_context.hip", "ig_blas.hip", "ig_spmm.hip", "ig_fft.hip", "ig_comm.hip", "ig_interp.hip"]
 ARCH = "gfx950"
 CXXFLAGS = [
     "--offload-arch=%s" % ARCH, "-O3", "-std=c++17", "-fPIC",
@@ -33,6 +33,8 @@ EXTRA_FLAGS = {
     # the SLP vectoriser pairs unrelated scalar butterfly operations into v_pk_* instructions and pays four v_mov per
     # pair to gather the operands (measured: 298 v_mov among 1942 instructions of the 512-point kernel)
     "ig_fft.hip": os.environ.get("INDIGO_FFT_FLAGS", "-fno-slp-vectorize").split(),
+    # host-only double-precision arithmetic that must round like the reference's (numpy / numba): no fused multiply-add
+    "ig_interp.hip": ["-ffp-contract=off"],
 }
 
 
@@ -82,7 +84,7 @@ def build(force=False, verbose=False):
 
     out = lib_path()
     if force or jobs or not _newer(out, objs):
-        run([hipcc, "--offload-arch=%s" % ARCH, "-shared", "-fPIC", "-o", out] + objs + ["-ldl"])
+        run([hipcc, "--offload-arch=%s" % ARCH, "-shared", "-fPIC", "-o", out] + objs + ["-ldl", "-lpthread"])
     return out
 
 

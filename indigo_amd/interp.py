@@ -15,7 +15,7 @@ the caller casts it (the NUFFT factory stores float32 weights as complex64).
 import numpy as np
 import scipy.sparse as spp
 
-__all__ = ['lin_interp', 'interp_mat', 'interp_csr_arrays']
+__all__ = ['lin_interp', 'interp_mat', 'interp_csr_arrays', 'interp_csr_arrays_numpy']
 
 
 def lin_interp(table, x):
@@ -82,8 +82,30 @@ def interp_mat(m, N, width, table, coord, chunk=65536):
     return spp.coo_matrix((ker, (row, col)), shape=(m, int(np.prod(N, dtype=np.int64))))
 
 
-def interp_csr_arrays(m, N, width, table, coord, dtype=np.float32, chunk=65536):
-    """Fast path for large trajectories: CSR arrays (indptr, indices, data) with sorted columns.
+def interp_csr_arrays(m, N, width, table, coord, dtype=np.float32, grid_order=0):
+    """CSR arrays (indptr, indices, data) of the gridding matrix with sorted columns, built by the library's native
+    host routine (ig_interp3_count / ig_interp3_fill: the counterpart of the reference's numba loop).  `grid_order=1`
+    numbers the grid columns (x, z, y) instead of (x, y, z).  Bit-identical to `interp_csr_arrays_numpy`."""
+    import ctypes
+    from indigo_amd import _lib
+    L = _lib.lib()
+    N = tuple(int(n) for n in N)
+    coord = np.ascontiguousarray(np.asarray(coord, dtype=np.float64).reshape(3, -1))
+    assert coord.shape[1] == m
+    table = np.ascontiguousarray(table, dtype=np.float64)
+    dims = (ctypes.c_int64 * 3)(*N)
+    indptr = np.empty(m + 1, dtype=np.int32)
+    _lib.check(L.ig_interp3_count(m, dims, float(width), coord.ctypes.data, indptr.ctypes.data), None, "ig_interp3_count")
+    nnz = int(indptr[-1])
+    indices = np.empty(nnz, dtype=np.int32)
+    data = np.empty(nnz, dtype=np.float32)
+    _lib.check(L.ig_interp3_fill(m, dims, float(width), table.ctypes.data, table.size, coord.ctypes.data, indptr.ctypes.data,
+                                 indices.ctypes.data, data.ctypes.data, int(grid_order)), None, "ig_interp3_fill")
+    return indptr.astype(np.int64), indices, data if dtype == np.float32 else data.astype(dtype)
+
+
+def interp_csr_arrays_numpy(m, N, width, table, coord, dtype=np.float32, chunk=65536):
+    """The same arrays from vectorised numpy (kept as the independent cross-check of the native routine).
 
     Equivalent to `interp_mat(...).tocsr()` + `sort_indices()` whenever no row
     wraps onto the same column twice (true when every N_d exceeds the tap count);
@@ -106,7 +128,7 @@ def interp_csr_arrays(m, N, width, table, coord, dtype=np.float32, chunk=65536):
         cnt = valid.sum(axis=1)
         dup = (key[:, 1:] == key[:, :-1]) & (key[:, 1:] != big)
         if dup.any():
-            raise ValueError("interp_csr_arrays: a row wraps onto one column twice; use interp_mat")
+            raise ValueError("interp_csr_arrays_numpy: a row wraps onto one column twice; use interp_mat")
         keep = np.arange(key.shape[1])[None, :] < cnt[:, None]
         return lo, hi, cnt, key[keep].astype(np.int32), ker[keep].astype(dtype)
 

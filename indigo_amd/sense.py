@@ -101,15 +101,20 @@ class SenseProblem(object):
         if layout in self._interp_cache:
             return self._interp_cache[layout]
         P = int(np.prod(self.oN))
+        n0, n1, n2 = self.oN
+        # the native builder numbers the grid columns in either order (sorted within a row both ways)
         indptr, indices, w = interp_csr_arrays(self.T, self.oN, self.width, self.table,
-                                               self.coord.reshape(3, -1, order='F'), dtype=np.float32)
-        mod = backend_mod(self.oN).reshape(-1, order='F')
+                                               self.coord.reshape(3, -1, order='F'), dtype=np.float32,
+                                               grid_order=1 if layout == 1 else 0)
+        kx = indices % n0
+        if layout == 1:
+            kz, ky = (indices // n0) % n2, indices // (n0 * n2)
+        else:
+            ky, kz = (indices // n0) % n1, indices // (n0 * n1)
         scale = np.complex64(np.float32(1.0) / np.sqrt(np.float32(P)))
-        data = w.astype(_C64) * mod[indices]
+        data = w.astype(_C64) * fftc_mod_at(self.oN, kx, ky, kz)
         data *= scale
         G = spp.csr_matrix((data, indices, indptr), shape=(self.T, P))
-        if layout == 1:
-            G = fused.permute_grid_columns(G, self.oN)
         self._interp_cache[layout] = G            # 0.6 GB per layout at 5e7 nonzeros; drop_cache() releases them
         return G
 
@@ -121,7 +126,7 @@ class SenseProblem(object):
         assert Cn * P < 2 ** 31, "int32 column indices: shard the coils"
         from indigo_amd.backends.backend import Backend
         zrows = Backend.zpad_rows(self.oN, self.N)                       # (Nn,) positions in the padded grid
-        mod = backend_mod(self.oN).reshape(-1, order='F')[zrows]
+        mod = fftc_mod_box(self.oN, self.N).reshape(-1, order='F')
         apod = rolloff3(self.oversamp, self.width, self.beta, self.N).reshape(-1, order='F').astype(_C64)
         base = (mod * apod).astype(_C64)                                 # per-voxel factor shared by all coils
         # row i holds, for each coil c, conj(base[i]*maps[i,c]) at column c*P + zrows[i]
@@ -137,8 +142,7 @@ class SenseProblem(object):
         """w[..., c] = mod(box) * apod * maps[..., c]: the per-voxel, per-coil factor of S' (F-ordered, box + (C,))."""
         coils = list(range(self.C) if coils is None else coils)
         from indigo_amd.backends.backend import Backend
-        zrows = Backend.zpad_rows(self.oN, self.N)
-        mod = backend_mod(self.oN).reshape(-1, order='F')[zrows].reshape(self.N, order='F')
+        mod = fftc_mod_box(self.oN, self.N)
         apod = rolloff3(self.oversamp, self.width, self.beta, self.N).astype(_C64)
         base = (mod * apod).astype(_C64)
         w = np.empty(self.N + (len(coils),), dtype=_C64, order='F')
@@ -229,6 +233,35 @@ class SenseProblem(object):
 def backend_mod(ft_shape):
     from indigo_amd.backends.backend import Backend
     return Backend.fftc_mod(ft_shape, _C64)
+
+
+def _mod_axis_phases(ft_shape):
+    """per-axis terms (idx - c/2) * (c/n), c = n // 2, of the centred FFT's modulation phase (Backend.fftc_mod)"""
+    out = []
+    for n in ft_shape:
+        c = n // 2
+        out.append((np.arange(n) - c / 2.0) * (c / n))
+    return out
+
+
+def fftc_mod_at(ft_shape, kx, ky, kz):
+    """Backend.fftc_mod(ft_shape)[kx, ky, kz] without the full grid: the phase is a sum of per-axis terms, added in
+    the same order (x, then y, then z) and precision as the full-grid formula, so the values are bit-identical."""
+    px, py, pz = _mod_axis_phases(ft_shape)
+    phase = 0 + px[kx]
+    phase += py[ky]
+    phase += pz[kz]
+    return np.exp(1j * 2.0 * np.pi * phase).astype(_C64)
+
+
+def fftc_mod_box(ft_shape, box):
+    """the modulation on the centred box (Backend.Zpad's placement) of the grid, shape `box`"""
+    sl = [slice(m // 2 + int(np.ceil(-n / 2)), m // 2 + int(np.ceil(n / 2))) for m, n in zip(ft_shape, box)]
+    px, py, pz = _mod_axis_phases(ft_shape)
+    phase = 0 + px[sl[0]][:, None, None]
+    phase = phase + py[sl[1]][None, :, None]
+    phase = phase + pz[sl[2]][None, None, :]
+    return np.asfortranarray(np.exp(1j * 2.0 * np.pi * phase).astype(_C64))
 
 
 def normal_operator(A, lamda=0.0, ncols=1):
