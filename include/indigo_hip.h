@@ -217,6 +217,30 @@ int  ig_csr_transpose(int64_t M, int64_t K, int64_t nnz,
                       const int32_t* rowptr, const int32_t* colind, const void* vals,
                       int32_t* rowptr_t, int32_t* colind_t, void* vals_t);
 
+/* ------------------------------------------------------------------------
+ * The remaining leaves of the Backend contract (outside the SENSE tree): matrix of ones, DIA sparse
+ * matrices, dense matrices.  Panels column-major with leading dimensions in elements, as everywhere.
+ *   ig_conemm : Y(MxN) = beta*Y + alpha * ones(M,K) * X(KxN)      Backend.onemm  (indigo/backends/backend.py:528-533;
+ *               oracle np.py:94-97; CUDA cu_onemm _customgpu.cu:15-47)
+ *   ig_cdiamm : adjoint == 0: Y(MxN) = beta*Y + alpha * A   * X(KxN);  adjoint != 0: Y(KxN) = beta*Y + alpha * A^H * X(MxN)
+ *               A is M x K with `ndiag` stored diagonals: data is ld_data x ndiag column-major with
+ *               data[j + d*ld_data] = A[j - offsets[d], j] (scipy's dia_matrix.data transposed, the form the reference
+ *               uploads, backend.py:607-610).  Backend.cdiamm (backend.py:521-526; np.py:129-136; cu_diamm / cu_diammH
+ *               _customgpu.cu:83-143)
+ *   ig_cgemm  : M is rows_m x cols_m dense, column-major, leading dimension ldm; op(M) = M or M^H (adjoint != 0).
+ *               right == 0: Y(r x p) = beta*Y + alpha * op(M)(r x c) * X(c x p)
+ *               right != 0: Y(p x c) = beta*Y + alpha * X(p x r) * op(M)(r x c)
+ *               Backend.cgemm / csymm (backend.py:481-491; np.py:76-90; cuBLAS cgemm/csymm cuda.py:314-392)
+ * ---------------------------------------------------------------------- */
+int  ig_conemm(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, float alpha_re, float alpha_im,
+               const void* X, int64_t ldx, float beta_re, float beta_im, void* Y, int64_t ldy);
+int  ig_cdiamm(ig_ctx* ctx, int adjoint, int64_t M, int64_t K, int64_t N, int64_t ndiag, const int32_t* offsets,
+               const void* data, int64_t ld_data, float alpha_re, float alpha_im, const void* X, int64_t ldx,
+               float beta_re, float beta_im, void* Y, int64_t ldy);
+int  ig_cgemm(ig_ctx* ctx, int adjoint, int right, int64_t rows_m, int64_t cols_m, int64_t p,
+              float alpha_re, float alpha_im, const void* M, int64_t ldm, const void* X, int64_t ldx,
+              float beta_re, float beta_im, void* Y, int64_t ldy);
+
 /* Host-side construction of the 3-D gridding (interpolation) matrix, CSR.  Replaces the numba loop nest
  * _interp3_mat / lin_interp (indigo/interp.py:8-80) behind Backend.Interp (indigo/backends/backend.py:392-401):
  * same arithmetic in the same order in double precision, float32 weights out (the NUFFT factory stores float32,

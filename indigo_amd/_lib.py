@@ -69,6 +69,11 @@ PROTOTYPES = {
                                    POINTER(c_int64), POINTER(c_int64), POINTER(c_int)]),
     "ig_csr_transpose":   (c_int, [c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p]),
+    "ig_conemm":          (c_int, [c_void_p, c_int64, c_int64, c_int64, c_float, c_float, c_void_p, c_int64, c_float, c_float, c_void_p, c_int64]),
+    "ig_cdiamm":          (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64,
+                                   c_float, c_float, c_void_p, c_int64, c_float, c_float, c_void_p, c_int64]),
+    "ig_cgemm":           (c_int, [c_void_p, c_int, c_int, c_int64, c_int64, c_int64, c_float, c_float, c_void_p, c_int64,
+                                   c_void_p, c_int64, c_float, c_float, c_void_p, c_int64]),
     "ig_interp3_count":   (c_int, [c_int64, POINTER(c_int64), c_double, c_void_p, c_void_p]),
     "ig_interp3_fill":    (c_int, [c_int64, POINTER(c_int64), c_double, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
     "ig_fft_plan":        (c_int, [c_void_p, c_int, POINTER(c_int64), c_int64, POINTER(c_void_p), POINTER(c_size_t)]),

@@ -454,16 +454,20 @@ class Backend(object):
         raise NotImplementedError()
 
     def cdiamm(self, y, shape, offsets, data, x, alpha=1.0, beta=0.0, adjoint=True):
-        raise NotImplementedError("DIA matrices are outside the SENSE hot path")
+        """y = beta*y + alpha * op(A) * x for a DIA-stored A (op = ^H when adjoint)"""
+        raise NotImplementedError()
 
     def onemm(self, y, x, alpha=1, beta=0):
-        raise NotImplementedError("One operators are outside the SENSE hot path")
+        """y = beta*y + alpha * ones * x"""
+        raise NotImplementedError()
 
     def cgemm(self, y, M, x, alpha, beta, forward):
-        raise NotImplementedError("dense matrices are outside the SENSE hot path")
+        """y = beta*y + alpha * op(M) * x for a dense M"""
+        raise NotImplementedError()
 
     def csymm(self, y, M, x, alpha, beta, left=True):
-        raise NotImplementedError("dense matrices are outside the SENSE hot path")
+        """dense product with a real symmetric M, from the left or from the right"""
+        raise NotImplementedError()
 
     def max(self, val, arr):
         raise NotImplementedError()
@@ -543,6 +547,36 @@ class Backend(object):
 
         def _type_correct(self, A):
             return A.astype(_C64)
+
+    class dia_matrix(object):
+        """Device-resident sparse matrix in diagonal (DIA) storage (reference backend.py:599-635): `data` is scipy's
+        dia_matrix.data transposed -- one column per stored diagonal -- and `offsets` the diagonals' offsets."""
+
+        def __init__(self, backend, A, name='mat'):
+            assert isinstance(A, spp.dia_matrix)
+            A = A.astype(_C64)
+            self._backend = backend
+            self.data = backend.copy_array(np.asfortranarray(A.data.T), name=name + ".data")
+            self.offsets = backend.copy_array(A.offsets.astype(np.int32), name=name + ".offsets")
+            self.shape = tuple(int(s) for s in A.shape)
+            self.dtype = A.dtype
+            self._row_frac = 1
+            self._col_frac = 1
+            self._exwrite = False
+
+        def forward(self, y, x, alpha=1, beta=0):
+            self._backend.cdiamm(y, self.shape, self.offsets, self.data, x, alpha=alpha, beta=beta, adjoint=False)
+
+        def adjoint(self, y, x, alpha=1, beta=0):
+            self._backend.cdiamm(y, self.shape, self.offsets, self.data, x, alpha=alpha, beta=beta, adjoint=True)
+
+        @property
+        def nbytes(self):
+            return self.offsets.nbytes + self.data.nbytes
+
+        @property
+        def nnz(self):
+            return self.data.size
 
     # ---------------------------------------------------------------------------
     # solvers

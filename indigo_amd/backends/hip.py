@@ -429,6 +429,44 @@ class HipBackend(Backend):
                                  ctypes.c_void_p(y._arr), y._leading_dim)
         self._check(rc, "ig_ccsrmm_t")
 
+    # -- ones / DIA / dense (outside the SENSE tree) ---------------------------------
+    def onemm(self, y, x, alpha=1, beta=0):
+        """y = beta*y + alpha * ones(M, K) * x"""
+        assert x.dtype == _C64 and y.dtype == _C64 and x.shape[1] == y.shape[1]
+        ar, ai = _cplx(alpha)
+        br, bi = _cplx(beta)
+        self._check(self._L.ig_conemm(self._ctx, y.shape[0], x.shape[0], x.shape[1], ar, ai, ctypes.c_void_p(x._arr), x._leading_dim,
+                                      br, bi, ctypes.c_void_p(y._arr), y._leading_dim), "ig_conemm")
+
+    def cdiamm(self, y, shape, offsets, data, x, alpha=1.0, beta=0.0, adjoint=True):
+        assert x.dtype == _C64 and y.dtype == _C64 and data.dtype == _C64 and offsets.dtype == np.int32
+        m, k = shape
+        ar, ai = _cplx(alpha)
+        br, bi = _cplx(beta)
+        self._check(self._L.ig_cdiamm(self._ctx, 1 if adjoint else 0, m, k, x.shape[1], offsets.size, ctypes.c_void_p(offsets._arr),
+                                      ctypes.c_void_p(data._arr), data._leading_dim, ar, ai, ctypes.c_void_p(x._arr), x._leading_dim,
+                                      br, bi, ctypes.c_void_p(y._arr), y._leading_dim), "ig_cdiamm")
+
+    def cgemm(self, y, M, x, alpha=1, beta=0, forward=True, left=True):
+        """y = beta*y + alpha * op(M) * x   (left)   or   beta*y + alpha * x * op(M)   (not left); op = identity / ^H"""
+        assert x.dtype == _C64 and y.dtype == _C64 and M.dtype == _C64 and M.ndim == 2
+        ar, ai = _cplx(alpha)
+        br, bi = _cplx(beta)
+        r, c = M.shape if forward else M.shape[::-1]
+        if left:
+            x2, y2 = x.reshape((c, -1)), y.reshape((r, -1))
+            p = x2.shape[1]
+        else:
+            x2, y2 = x.reshape((-1, r)), y.reshape((-1, c))
+            p = x2.shape[0]
+        self._check(self._L.ig_cgemm(self._ctx, 0 if forward else 1, 0 if left else 1, M.shape[0], M.shape[1], p, ar, ai,
+                                     ctypes.c_void_p(M._arr), M._leading_dim, ctypes.c_void_p(x2._arr), x2._leading_dim,
+                                     br, bi, ctypes.c_void_p(y2._arr), y2._leading_dim), "ig_cgemm")
+
+    def csymm(self, y, M, x, alpha, beta, left=True):
+        """the same product for a real symmetric M (the reference's cublasCsymm call, cuda.py:362-392)"""
+        self.cgemm(y, M, x, alpha, beta, forward=True, left=left)
+
     def inspect(self, csr):
         indptr = np.ascontiguousarray(csr.indptr, dtype=np.int32)
         indices = np.ascontiguousarray(csr.indices, dtype=np.int32)

@@ -18,7 +18,7 @@ LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "lib", "obj")
 LIBNAME = "libindigo_hip.so"
 
-SOURCES = ["ig_context.hip", "ig_blas.hip", "ig_spmm.hip", "ig_fft.hip", "ig_comm.hip", "ig_interp.hip"]
+SOURCES = ["ig_context.hip", "ig_blas.hip", "ig_spmm.hip", "ig_fft.hip", "ig_comm.hip", "ig_interp.hip", "ig_dense.hip"]
 ARCH = "gfx950"
 CXXFLAGS = [
     "--offload-arch=%s" % ARCH, "-O3", "-std=c++17", "-fPIC",

@@ -214,9 +214,10 @@ class SpMatrix(Operator):
 
     def _get_or_create_device_matrix(self):
         if self._matrix_d is None:
-            if self._use_dia:
-                raise NotImplementedError("DIA storage is outside the SENSE hot path")
             self._matrix = self._matrix.astype(_C64)
+            if self._use_dia:
+                self._matrix_d = self._backend.dia_matrix(self._backend, self._matrix.todia(), self._name)
+                return self._matrix_d
             csr = self._matrix.tocsr()
             csr.sort_indices()
             self._matrix_d = self._backend.csr_matrix(self._backend, csr, self._name)
@@ -246,7 +247,7 @@ class SpMatrix(Operator):
         M = self._get_or_create_device_matrix()
         trace = getattr(self._backend, 'trace', None)
         if trace is not None:
-            trace.add('csrmm', nbytes=self.csrmm_bytes(x, y, beta, forward),
+            trace.add('csrmm' if 'csr' in type(M).__name__ else 'diamm', nbytes=self.csrmm_bytes(x, y, beta, forward),
                       nflops=5 * self._matrix.nnz * x.shape[1], shape=x.shape, forward=forward,
                       name=self._name)
         if forward:
@@ -425,14 +426,14 @@ class Eye(MatrixFreeOperator):
 
 
 class One(MatrixFreeOperator):
-    """Matrix of ones (outside the hot path; evaluates through backend.onemm)."""
+    """Matrix of ones (reference operators.py:283-302; evaluates through backend.onemm)."""
 
     def _eval(self, y, x, alpha=1, beta=0, forward=None, left=True):
         self._backend.onemm(y, x, alpha, beta)
 
 
 class DenseMatrix(Operator):
-    """Dense complex64 matrix (outside the hot path; evaluates through backend.cgemm)."""
+    """Dense complex64 matrix (reference operators.py:266-281; evaluates through backend.cgemm)."""
 
     def __init__(self, backend, M, **kwargs):
         super().__init__(backend, **kwargs)

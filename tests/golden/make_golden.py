@@ -365,6 +365,96 @@ def gold_sense(B):
     save("sense", **out)
 
 
+def gold_misc(B):
+    """the leaves outside the SENSE tree: onemm, cdiamm (DIA), cgemm / csymm, and two apgd iterates
+    (reference: np.py:76-97,129-136; backend.py:599-635,691-732; operators One / DenseMatrix / SpMatrix._use_dia)"""
+    out = {}
+    c = np.dtype('complex64')
+    # onemm through the One operator (forward and adjoint are the same product with the shape swapped)
+    i = 0
+    for (M, K, n) in [(7, 5, 1), (23, 45, 8), (130, 64, 3)]:
+        for (alpha, beta) in [(1, 0), (0.5 - 1j, 1.5)]:
+            x, y = rand64c(K, n, seed=700 + i), rand64c(M, n, seed=800 + i)
+            y_d = B.copy_array(y)
+            B.onemm(y_d, B.copy_array(x), alpha, beta)
+            out["one%d_x" % i], out["one%d_y" % i] = x, y
+            out["one%d_ab" % i] = np.array([alpha, beta], dtype=np.complex128)
+            out["one%d_out" % i] = y_d.to_host()
+            i += 1
+    out["one_count"] = np.array(i)
+    # DIA
+    i = 0
+    rng = np.random.default_rng(77)
+    for (M, K, n, offs) in [(23, 45, 1, [0]), (45, 23, 8, [-3, 0, 5]), (23, 45, 9, [-22, 1, 44, 7]), (33, 33, 17, [-1, 0, 1])]:
+        for (alpha, beta) in [(1, 0), (0.5, 1.0), (1.5 - 0.5j, 0.5)]:
+            offsets = np.array(offs, dtype=np.int32)
+            data = rand64c(offsets.size, K, seed=900 + i, order='C')
+            A = spp.dia_matrix((data, offsets), shape=(M, K))
+            A_d = B.dia_matrix(B, A)
+            x, y = rand64c(K, n, seed=910 + i), rand64c(M, n, seed=920 + i)
+            y_d = B.copy_array(y)
+            A_d.forward(y_d, B.copy_array(x), alpha=alpha, beta=beta)
+            xa, ya = rand64c(K, n, seed=930 + i), rand64c(M, n, seed=940 + i)
+            xa_d = B.copy_array(xa)
+            A_d.adjoint(xa_d, B.copy_array(ya), alpha=alpha, beta=beta)
+            out["dia%d_offsets" % i], out["dia%d_data" % i] = offsets, data
+            out["dia%d_shape" % i] = np.array([M, K])
+            out["dia%d_ab" % i] = np.array([alpha, beta], dtype=np.complex128)
+            out["dia%d_x" % i], out["dia%d_y" % i], out["dia%d_fwd" % i] = x, y, y_d.to_host()
+            out["dia%d_xa" % i], out["dia%d_ya" % i], out["dia%d_adj" % i] = xa, ya, xa_d.to_host()
+            i += 1
+    out["dia_count"] = np.array(i)
+    # dense: cgemm forward / adjoint, csymm left / right
+    i = 0
+    for (m, n, k) in [(10, 23, 7), (129, 10, 144), (64, 65, 66)]:
+        for (alpha, beta, forward) in [(1, 0, True), (0.5, 0.5, False), (1 - 2j, 1, True), (0.25j, 0, False)]:
+            Mh = rand64c(m, k, seed=1000 + i)
+            x = rand64c(k if forward else m, n, seed=1010 + i)
+            y = rand64c(m if forward else k, n, seed=1020 + i)
+            y_d = B.copy_array(y)
+            B.cgemm(y_d, B.copy_array(Mh), B.copy_array(x), alpha, beta, forward=forward)
+            out["gemm%d_M" % i], out["gemm%d_x" % i], out["gemm%d_y" % i] = Mh, x, y
+            out["gemm%d_abf" % i] = np.array([alpha, beta, 1.0 if forward else 0.0], dtype=np.complex128)
+            out["gemm%d_out" % i] = y_d.to_host()
+            i += 1
+    out["gemm_count"] = np.array(i)
+    i = 0
+    for (m, k) in [(2, 1), (5, 3), (40, 70)]:
+        for (alpha, beta, left) in [(1, 0, True), (0.5, 1.5, True), (1.5, 0.5, False), (1, 0, False)]:
+            S = rand64c(m, m, seed=1100 + i)
+            S = np.asfortranarray((S + S.T).real.astype(c))
+            x = rand64c(m, k, seed=1110 + i) if left else rand64c(k, m, seed=1110 + i)
+            y = rand64c(m, k, seed=1120 + i) if left else rand64c(k, m, seed=1120 + i)
+            y_d = B.copy_array(y)
+            B.csymm(y_d, B.copy_array(S), B.copy_array(x), alpha, beta, left)
+            out["symm%d_M" % i], out["symm%d_x" % i], out["symm%d_y" % i] = S, x, y
+            out["symm%d_abl" % i] = np.array([alpha, beta, 1.0 if left else 0.0], dtype=np.complex128)
+            out["symm%d_out" % i] = y_d.to_host()
+            i += 1
+    out["symm_count"] = np.array(i)
+    # apgd: min 0.5*||D x - b||^2 + indicator(x >= 0.2 on both parts) with D a diagonal operator
+    m = 57
+    d = (rand64c(m, seed=1200).real + 0.5).astype(c)
+    Dop = B.Diag(d)
+    b = rand64c(m, 1, seed=1201)
+    b_d = B.copy_array(b)
+    tmp = B.zero_array((m, 1), c)
+
+    def gradf(gf, xk):
+        Dop.eval(tmp, xk)
+        B.axpby(1, tmp, -1, b_d)
+        Dop.H.eval(gf, tmp)
+
+    def proxg(xk, alpha):
+        B.max(0.2, xk)
+    for it in (1, 2, 5):
+        x0 = rand64c(m, 1, seed=1202)
+        B.apgd(gradf, proxg, 0.4, x0, maxiter=it)
+        out["apgd_it%d" % it] = x0
+    out["apgd_d"], out["apgd_b"], out["apgd_x0"] = d, b, rand64c(m, 1, seed=1202)
+    save("leaf_misc", **out)
+
+
 def main():
     B = import_reference()
     print("reference backend:", type(B).__module__, type(B).__name__)
@@ -373,6 +463,7 @@ def main():
     gold_fft(B)
     gold_composites(B)
     gold_sense(B)
+    gold_misc(B)
 
 
 if __name__ == "__main__":

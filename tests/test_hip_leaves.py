@@ -428,3 +428,78 @@ def test_fft_config2_shape_properties(hip):
     e = lambda s: np.exp(-2j * np.pi * s * k / n)
     exp = e(1)[:, None, None] * e(2)[None, :, None] * e(3)[None, None, :]
     assert rel_err(y1.to_host()[..., 0], exp) < RTOL
+
+
+# ---------------------------------------------------------------------------------------
+# ones / DIA / dense leaves and apgd (reference test_backends.py:333-361,377-398,440-523)
+# ---------------------------------------------------------------------------------------
+def test_misc_leaves_golden(hip):
+    from conftest import check_misc_leaves
+    check_misc_leaves(hip, RTOL)
+
+
+@pytest.mark.parametrize("m,n,k,alpha,beta,forward", itertools.product([10, 23, 129, 144], [10, 129], [23, 144], [1, 0.5, 0.0],
+                                                                       [0, 0.5], [True, False]))
+def test_cgemm_grid(hip, m, n, k, alpha, beta, forward):
+    y, M, x = rand64c(m, n, seed=1), rand64c(m, k, seed=2), rand64c(k, n, seed=3)
+    if not forward:
+        x, y = y, x
+    exp = alpha * ((M if forward else np.conj(M.T)).astype(np.complex128) @ x) + beta * y
+    y_d = hip.copy_array(y)
+    hip.cgemm(y_d, hip.copy_array(M), hip.copy_array(x), alpha, beta, forward=forward)
+    assert rel_err(y_d.to_host(), exp) < RTOL
+
+
+@pytest.mark.parametrize("m,k,alpha,beta,left", itertools.product([2, 4, 5, 6, 70], [1, 2, 3, 65], [0.0, 0.5, 1.5], [0.0, 1.0, 1.5],
+                                                                  [True, False]))
+def test_csymm_grid(hip, m, k, alpha, beta, left):
+    S = rand64c(m, m, seed=4)
+    S = np.asfortranarray((S + S.T).real.astype(C64))
+    x = rand64c(m, k, seed=5) if left else rand64c(k, m, seed=5)
+    y = rand64c(m, k, seed=6) if left else rand64c(k, m, seed=6)
+    exp = alpha * (S @ x if left else x @ S) + beta * y
+    y_d = hip.copy_array(y)
+    hip.csymm(y_d, hip.copy_array(S), hip.copy_array(x), alpha, beta, left)
+    assert rel_err(y_d.to_host(), exp) < RTOL
+
+
+@pytest.mark.parametrize("M,K,N,alpha,beta,maxoffsets", itertools.product([23, 45, 1000], [45, 23], [1, 8, 9, 17], [0, 0.5, 1.5],
+                                                                          [0, 1.0, 1.5], [1, 2, 4]))
+def test_dia_matrix_grid(hip, M, K, N, alpha, beta, maxoffsets):
+    rng = np.random.default_rng(M * K + N + maxoffsets)
+    offsets = np.array(sorted(set(rng.integers(-K, M + K, size=maxoffsets).tolist())), dtype=np.int32)
+    data = rand64c(offsets.size, K, seed=7, order='C')
+    A = spp.dia_matrix((data, offsets), shape=(M, K))
+    A_d = hip.dia_matrix(hip, A)
+    x, y = rand64c(K, N, seed=8), rand64c(M, N, seed=9)
+    y_d = hip.copy_array(y)
+    A_d.forward(y_d, hip.copy_array(x), alpha=alpha, beta=beta)
+    np.testing.assert_allclose(y_d.to_host(), beta * y + alpha * (A @ x), atol=1e-5, rtol=1e-5)
+    x_d = hip.copy_array(x)
+    A_d.adjoint(x_d, hip.copy_array(y), alpha=alpha, beta=beta)
+    np.testing.assert_allclose(x_d.to_host(), beta * x + alpha * (A.conjugate().transpose() @ y), atol=1e-5, rtol=1e-5)
+    # panels with a leading dimension (views into wider arrays)
+    big = hip.copy_array(rand64c(M + 5, N, seed=10))
+    view = big[2:M + 2, :]
+    view.copy_from(y)
+    A_d.forward(view, hip.copy_array(x), alpha=alpha, beta=beta)
+    np.testing.assert_allclose(view.to_host(), beta * y + alpha * (A @ x), atol=1e-5, rtol=1e-5)
+
+
+def test_one_dense_and_dia_operators(hip, oracle_backend):
+    """One, DenseMatrix and SpMatrix(_use_dia) operators on the GPU == the oracle's (reference test_operators.py:471-489,549-642)"""
+    for B in (hip, oracle_backend):
+        B._scratch = None
+    x = rand64c(40, 6, seed=1)
+    outs = []
+    for B in (hip, oracle_backend):
+        one = B.One((33, 40))
+        D = B.DenseMatrix(rand64c(33, 40, seed=2))
+        S = B.SpMatrix(spp.diags([rand64c(40, seed=3), rand64c(39, seed=4)], offsets=[0, 1]).astype(C64), name='banded')
+        S._use_dia = True
+        T = (one + D) * S
+        k = rand64c(33, 6, seed=5)
+        outs.append((T * x, T.H * k, (0.5 * D).H * k))
+        assert type(S._matrix_d).__name__ == "dia_matrix"
+    for a, b in zip(*outs):
+        assert rel_err(a, b) < RTOL

@@ -148,3 +148,9 @@ def test_native_oracles_agree_with_scipy():
         assert rel_err(Y2, A @ X) < 1e-6
         nzr, nzc, exw = native.ref_native().inspect(A.shape[0], A.shape[1], A.indices, A.indptr)
         assert (nzr, nzc, bool(exw)) == native.c_inspect(A)
+
+
+def test_misc_leaves_against_reference(oracle_backend):
+    """onemm, cdiamm, cgemm, csymm, apgd of the oracle == the reference's numpy backend"""
+    from conftest import check_misc_leaves
+    check_misc_leaves(oracle_backend, 2e-6)
