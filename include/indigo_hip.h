@@ -108,6 +108,22 @@ int  ig_cscal(ig_ctx* ctx, int64_t n, float alpha_re, float alpha_im, void* x); 
 int  ig_cdotc(ig_ctx* ctx, int64_t n, const void* x, const void* y, double out[2]); /* sum conj(x)*y ; synchronous */
 int  ig_scnrm2sq(ig_ctx* ctx, int64_t n, const void* x, double* out);       /* ||x||_2^2 ; synchronous */
 int  ig_cmax(ig_ctx* ctx, int64_t nfloats, float val, void* arr);           /* arr[i] = max(arr[i], val) over floats */
+/* Device-resident solver scalars: the same reductions and updates with their scalar results / factors left in
+ * device memory, so that a Krylov iteration (Backend.cg, indigo/backends/backend.py:666-686: alpha = rr / <p, Ap>,
+ * beta = r2 / rr) enqueues without a single host synchronisation.  ig_scalars hands out the context's block of
+ * doubles (zeroed); any device double pointers may be used.
+ *   ig_cdotc_dev / ig_scnrm2sq_dev : results to d_out[0..1] / d_out[0]
+ *   ig_scalar_ratio : *d_out = scale * *d_num / *d_den            ig_scalar_copy : d_dst[0..count) = d_src[0..count)
+ *   ig_caxpby_dev   : y = (beta_scale * *d_beta) * y + (alpha_scale * *d_alpha) * x   (a NULL pointer stands for 1)
+ *   ig_scalar_read  : device -> host, synchronous (the residual history, every so many iterations)           */
+int  ig_scalars(ig_ctx* ctx, double** d_slots, int* nslots);
+int  ig_cdotc_dev(ig_ctx* ctx, int64_t n, const void* x, const void* y, double* d_out);
+int  ig_scnrm2sq_dev(ig_ctx* ctx, int64_t n, const void* x, double* d_out);
+int  ig_scalar_ratio(ig_ctx* ctx, double* d_out, const double* d_num, const double* d_den, double scale);
+int  ig_scalar_copy(ig_ctx* ctx, double* d_dst, const double* d_src, int64_t count);
+int  ig_scalar_read(ig_ctx* ctx, const double* d_src, int64_t count, double* host);
+int  ig_caxpby_dev(ig_ctx* ctx, int64_t n, const double* d_beta, float beta_scale, void* y,
+                   const double* d_alpha, float alpha_scale, const void* x);
 /* y(rows) = beta*y + alpha * sum_j X[:, j]  for a column-major rows x ncols panel: the coil
  * combination that VStack._eval_adjoint performs with one scale + ncols axpby-like passes
  * (indigo/operators.py:440-447), in one pass.                                              */

@@ -43,6 +43,13 @@ PROTOTYPES = {
     "ig_cdotc":           (c_int, [c_void_p, c_int64, c_void_p, c_void_p, POINTER(c_double)]),
     "ig_scnrm2sq":        (c_int, [c_void_p, c_int64, c_void_p, POINTER(c_double)]),
     "ig_cmax":            (c_int, [c_void_p, c_int64, c_float, c_void_p]),
+    "ig_scalars":         (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int)]),
+    "ig_cdotc_dev":       (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "ig_scnrm2sq_dev":    (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "ig_scalar_ratio":    (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_double]),
+    "ig_scalar_copy":     (c_int, [c_void_p, c_void_p, c_void_p, c_int64]),
+    "ig_scalar_read":     (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "ig_caxpby_dev":      (c_int, [c_void_p, c_int64, c_void_p, c_float, c_void_p, c_void_p, c_float, c_void_p]),
     "ig_csum_cols":       (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_void_p]),
     "ig_csum_il":         (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_float, c_float, c_float, c_float, c_void_p]),
     "ig_ccsrmm_il":       (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64,

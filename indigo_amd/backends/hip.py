@@ -269,6 +269,76 @@ class HipBackend(Backend):
         self._check(self._L.ig_scnrm2sq(self._ctx, x.size, ctypes.c_void_p(x._arr), ctypes.byref(out)), "ig_scnrm2sq")
         return out.value
 
+    # -- CG with device-resident scalars --------------------------------------------------------
+    def _slots(self):
+        if getattr(self, '_scal', None) is None:
+            ptr, n = ctypes.c_void_p(), ctypes.c_int()
+            self._check(self._L.ig_scalars(self._ctx, ctypes.byref(ptr), ctypes.byref(n)), "ig_scalars")
+            self._scal = (ptr.value, n.value)
+        return self._scal
+
+    def cg(self, A, b_h, x_h, lamda=0.0, tol=1e-10, maxiter=100, team=None, check_every=10):
+        """Conjugate gradients with the iteration's scalars kept on the device (same update sequence and the same
+        numbers as Backend.cg / the reference's backend.py:651-689): alpha = rr/<p,Ap> and beta = r2/rr are computed
+        by one-thread kernels from the reductions' device results and read by the axpby kernels from device memory,
+        so an iteration enqueues without a host synchronisation.  The relative residuals are recorded on the device for
+        EVERY iteration and fetched every `check_every` iterations (the only syncs); the tolerance test therefore
+        takes effect at the end of such a block -- up to check_every-1 iterations after the reference would have
+        stopped (`check_every=1` reproduces its stopping iteration exactly).  A `team` (host-scalar all-reduces per
+        iteration, backend.py:469-479) uses the base implementation."""
+        if team is not None or not (hasattr(A, 'eval')):
+            return super().cg(A, b_h, x_h, lamda=lamda, tol=tol, maxiter=maxiter, team=team)
+        base, nslots = self._slots()
+        assert maxiter + 8 <= nslots, "cg: at most %d iterations per call" % (nslots - 8)
+        S = lambda i: ctypes.c_void_p(base + 8 * i)          # slot i (a device double)
+        RR, R0, PAP, ALPHA, R2, BETA, HIST = 0, 1, 2, 4, 5, 6, 8
+        L, ctx = self._L, self._ctx
+        P = lambda a: ctypes.c_void_p(a._arr)
+        x_dev = isinstance(x_h, self.dndarray)
+        x = x_h if x_dev else self.copy_array(x_h, name='x')
+        b = b_h.copy(name='b') if isinstance(b_h, self.dndarray) else self.copy_array(b_h, name='b')
+        assert x.dtype == _C64 and b.dtype == _C64 and x.contiguous and b.contiguous
+        n = x.size
+        Ap = x.copy()
+        r = b
+        A.eval(Ap, x)
+        self.axpby(1, r, -1, Ap)
+        self.axpby(1, r, -lamda, x)
+        p = r.copy(name='p')
+        self._check(L.ig_scnrm2sq_dev(ctx, n, P(r), S(RR)), "ig_scnrm2sq_dev")
+        self._check(L.ig_scalar_copy(ctx, S(R0), S(RR), 1), "ig_scalar_copy")
+        history = []
+        fetched = 0
+        host = (ctypes.c_double * max(maxiter, 1))()
+        it = 0
+        while it < maxiter:
+            A.eval(Ap, p)
+            self.axpby(1, Ap, lamda, p)
+            self._check(L.ig_cdotc_dev(ctx, n, P(p), P(Ap), S(PAP)), "ig_cdotc_dev")
+            self._check(L.ig_scalar_ratio(ctx, S(ALPHA), S(RR), S(PAP), 1.0), "ig_scalar_ratio")       # alpha = rr / Re<p, Ap>
+            self._check(L.ig_caxpby_dev(ctx, n, None, 1.0, P(x), S(ALPHA), 1.0, P(p)), "ig_caxpby_dev")    # x += alpha p
+            self._check(L.ig_caxpby_dev(ctx, n, None, 1.0, P(r), S(ALPHA), -1.0, P(Ap)), "ig_caxpby_dev")  # r -= alpha Ap
+            self._check(L.ig_scnrm2sq_dev(ctx, n, P(r), S(R2)), "ig_scnrm2sq_dev")
+            self._check(L.ig_scalar_ratio(ctx, S(BETA), S(R2), S(RR), 1.0), "ig_scalar_ratio")         # beta = r2 / rr
+            self._check(L.ig_caxpby_dev(ctx, n, S(BETA), 1.0, P(p), None, 1.0, P(r)), "ig_caxpby_dev")     # p = beta p + r
+            self._check(L.ig_scalar_copy(ctx, S(RR), S(R2), 1), "ig_scalar_copy")                      # rr = r2
+            self._check(L.ig_scalar_ratio(ctx, S(HIST + it), S(R2), S(R0), 1.0), "ig_scalar_ratio")    # (resid_it)^2
+            it += 1
+            if it % max(int(check_every), 1) == 0 or it == maxiter:
+                self._check(L.ig_scalar_read(ctx, S(HIST + fetched), it - fetched, ctypes.byref(host, 8 * fetched)), "ig_scalar_read")
+                for j in range(fetched, it):
+                    history.append(float(np.sqrt(host[j])))
+                    log.info("iter %d, residual %g", j, history[-1])
+                fetched = it
+                if min(history) < tol:
+                    log.info("cg reached tolerance")
+                    break
+        else:
+            log.info("cg reached maxiter")
+        if not x_dev:
+            x.copy_to(x_h)
+        return history
+
     def max(self, val, arr):
         """elementwise max on the real and imaginary parts independently"""
         assert arr.dtype == _C64 and arr.contiguous

@@ -23,9 +23,14 @@ inline int grid_for(const ig_ctx* ctx, int64_t work_items) {
 // MODE 1: y = y + a*x        (beta == 1)
 // MODE 2: y = b*y + a*x      (general)
 // MODE 3: y = b*y            (alpha == 0)
+// d_b / d_a (optional): device-resident real factors, b *= *d_b, a *= *d_a -- the scalars of a solver iteration
+// (CG's alpha = rr / <p, Ap>, beta = r2 / rr) never visit the host.
 template <int MODE>
 __global__ void __launch_bounds__(BLK)
-k_caxpby(int64_t n, float2 b, float2* __restrict__ y, float2 a, const float2* __restrict__ x, int vec_ok) {
+k_caxpby(int64_t n, float2 b, float2* __restrict__ y, float2 a, const float2* __restrict__ x, int vec_ok,
+         const double* __restrict__ d_b = nullptr, const double* __restrict__ d_a = nullptr) {
+    if (d_b) { const float f = (float)*d_b; b.x *= f; b.y *= f; }
+    if (d_a) { const float f = (float)*d_a; a.x *= f; a.y *= f; }
     const int64_t tid = (int64_t)blockIdx.x * BLK + threadIdx.x;
     const int64_t nth = (int64_t)gridDim.x * BLK;
     if (vec_ok) {
@@ -216,6 +221,31 @@ k_reduce_final(int nblocks, const double* __restrict__ partials, double* __restr
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// tiny scalar programs on device-resident doubles (one thread): the glue between a solver's reductions and its updates
+__global__ void k_scalar_ratio(double* __restrict__ out, const double* __restrict__ num, const double* __restrict__ den, double scale) {
+    out[0] = scale * num[0] / den[0];
+}
+__global__ void k_scalar_copy(double* __restrict__ dst, const double* __restrict__ src, int count) {
+    for (int i = threadIdx.x; i < count; i += blockDim.x) dst[i] = src[i];
+}
+
+// the same two-kernel deterministic reduction, result left on the device (d_out[0..1]); no host synchronisation
+int reduce_dev(ig_ctx* ctx, bool dot, int64_t n, const void* x, const void* y, double* d_out) {
+    if (int rc = ig_set_device(ctx)) return rc;
+    if (n == 0) { IG_HIP(ctx, hipMemsetAsync(d_out, 0, 2 * sizeof(double), ctx->stream)); return IG_OK; }
+    int g = grid_for(ctx, n);
+    if (g > IG_MAX_RED_BLOCKS) g = IG_MAX_RED_BLOCKS;
+    ig_prof_scope prof(ctx, dot ? "cdotc" : "scnrm2", (double)n * 8.0 * (dot ? 2 : 1));
+    if (dot)
+        hipLaunchKernelGGL(k_reduce<true>, dim3(g), dim3(BLK), 0, ctx->stream, n, (const float2*)x, (const float2*)y, ctx->d_partials);
+    else
+        hipLaunchKernelGGL(k_reduce<false>, dim3(g), dim3(BLK), 0, ctx->stream, n, (const float2*)x, (const float2*)x, ctx->d_partials);
+    IG_LAUNCH_CHECK(ctx, "k_reduce");
+    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(BLK), 0, ctx->stream, g, ctx->d_partials, d_out);
+    IG_LAUNCH_CHECK(ctx, "k_reduce_final");
+    return IG_OK;
+}
+
 int reduce_common(ig_ctx* ctx, bool dot, int64_t n, const void* x, const void* y, double out[2]) {
     if (int rc = ig_set_device(ctx)) return rc;
     if (n == 0) { out[0] = out[1] = 0.0; return IG_OK; }
@@ -270,6 +300,75 @@ int ig_caxpby(ig_ctx* ctx, int64_t n, float br, float bi, void* y, float ar, flo
     else if (b1)  hipLaunchKernelGGL(k_caxpby<1>, dim3(g), dim3(BLK), 0, ctx->stream, n, b, yp, a, xp, vec_ok);
     else          hipLaunchKernelGGL(k_caxpby<2>, dim3(g), dim3(BLK), 0, ctx->stream, n, b, yp, a, xp, vec_ok);
     IG_LAUNCH_CHECK(ctx, "k_caxpby");
+    return IG_OK;
+}
+
+int ig_scalars(ig_ctx* ctx, double** d_slots, int* nslots) {
+    IG_REQUIRE(ctx, ctx && d_slots, "ig_scalars: bad arguments");
+    if (int rc = ig_set_device(ctx)) return rc;
+    if (!ctx->d_scalars) {
+        IG_HIP(ctx, hipMalloc((void**)&ctx->d_scalars, sizeof(double) * IG_NUM_SCALARS));
+        IG_HIP(ctx, hipMemsetAsync(ctx->d_scalars, 0, sizeof(double) * IG_NUM_SCALARS, ctx->stream));
+    }
+    *d_slots = ctx->d_scalars;
+    if (nslots) *nslots = IG_NUM_SCALARS;
+    return IG_OK;
+}
+
+int ig_caxpby_dev(ig_ctx* ctx, int64_t n, const double* d_beta, float beta_scale, void* y,
+                  const double* d_alpha, float alpha_scale, const void* x) {
+    IG_REQUIRE(ctx, ctx != nullptr, "ig_caxpby_dev: ctx is NULL");
+    IG_REQUIRE(ctx, n >= 0, "ig_caxpby_dev: negative length");
+    if (n == 0) return IG_OK;
+    IG_REQUIRE(ctx, y != nullptr && x != nullptr, "ig_caxpby_dev: NULL vector");
+    if (int rc = ig_set_device(ctx)) return rc;
+    const int vec_ok = aligned16(y) && aligned16(x);
+    const int g = grid_for(ctx, vec_ok ? (n + 1) / 2 : n);
+    ig_prof_scope prof(ctx, "caxpby", (double)n * 8.0 * 3);
+    const float2 a = make_float2(alpha_scale, 0.f), b = make_float2(beta_scale, 0.f);
+    if (!d_beta && beta_scale == 1.f)
+        hipLaunchKernelGGL(k_caxpby<1>, dim3(g), dim3(BLK), 0, ctx->stream, n, b, (float2*)y, a, (const float2*)x, vec_ok, d_beta, d_alpha);
+    else
+        hipLaunchKernelGGL(k_caxpby<2>, dim3(g), dim3(BLK), 0, ctx->stream, n, b, (float2*)y, a, (const float2*)x, vec_ok, d_beta, d_alpha);
+    IG_LAUNCH_CHECK(ctx, "k_caxpby(dev)");
+    return IG_OK;
+}
+
+int ig_cdotc_dev(ig_ctx* ctx, int64_t n, const void* x, const void* y, double* d_out) {
+    IG_REQUIRE(ctx, ctx && d_out, "ig_cdotc_dev: bad arguments");
+    IG_REQUIRE(ctx, n >= 0 && (n == 0 || (x && y)), "ig_cdotc_dev: bad vector arguments");
+    return reduce_dev(ctx, true, n, x, y, d_out);
+}
+
+int ig_scnrm2sq_dev(ig_ctx* ctx, int64_t n, const void* x, double* d_out) {
+    IG_REQUIRE(ctx, ctx && d_out, "ig_scnrm2sq_dev: bad arguments");
+    IG_REQUIRE(ctx, n >= 0 && (n == 0 || x), "ig_scnrm2sq_dev: bad vector argument");
+    return reduce_dev(ctx, false, n, x, nullptr, d_out);
+}
+
+int ig_scalar_ratio(ig_ctx* ctx, double* d_out, const double* d_num, const double* d_den, double scale) {
+    IG_REQUIRE(ctx, ctx && d_out && d_num && d_den, "ig_scalar_ratio: bad arguments");
+    if (int rc = ig_set_device(ctx)) return rc;
+    hipLaunchKernelGGL(k_scalar_ratio, dim3(1), dim3(1), 0, ctx->stream, d_out, d_num, d_den, scale);
+    IG_LAUNCH_CHECK(ctx, "k_scalar_ratio");
+    return IG_OK;
+}
+
+int ig_scalar_copy(ig_ctx* ctx, double* d_dst, const double* d_src, int64_t count) {
+    IG_REQUIRE(ctx, ctx && d_dst && d_src && count >= 0 && count <= 4096, "ig_scalar_copy: bad arguments");
+    if (count == 0) return IG_OK;
+    if (int rc = ig_set_device(ctx)) return rc;
+    hipLaunchKernelGGL(k_scalar_copy, dim3(1), dim3(64), 0, ctx->stream, d_dst, d_src, (int)count);
+    IG_LAUNCH_CHECK(ctx, "k_scalar_copy");
+    return IG_OK;
+}
+
+int ig_scalar_read(ig_ctx* ctx, const double* d_src, int64_t count, double* host) {
+    IG_REQUIRE(ctx, ctx && d_src && host && count >= 0, "ig_scalar_read: bad arguments");
+    if (count == 0) return IG_OK;
+    if (int rc = ig_set_device(ctx)) return rc;
+    IG_HIP(ctx, hipMemcpyAsync(host, d_src, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, ctx->stream));
+    IG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return IG_OK;
 }
 

@@ -26,6 +26,7 @@ struct ig_ctx {
     // small device/pinned scratch used by the reductions (dot, nrm2)
     double*      d_partials  = nullptr;   // (IG_MAX_RED_BLOCKS + 1) * 2 doubles
     double*      h_result    = nullptr;   // pinned, 2 doubles
+    double*      d_scalars   = nullptr;   // IG_NUM_SCALARS device-resident doubles for solver scalars (ig_scalars)
     void*        d_xpack     = nullptr;   // SpMM repacked-panel scratch (grown on demand)
     size_t       xpack_bytes = 0;
     int32_t*     d_worklist  = nullptr;   // SpMM deferred-row lists + counters (allocated on first use)
@@ -60,6 +61,7 @@ struct ig_event {
 };
 
 constexpr int IG_MAX_RED_BLOCKS = 2048;
+constexpr int IG_NUM_SCALARS = 1024;
 
 // thread-local error for calls without a context
 std::string& ig_tls_error();

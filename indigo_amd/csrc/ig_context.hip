@@ -91,6 +91,7 @@ void ig_destroy(ig_ctx* ctx) {
     for (ig_prof_rec& r : ctx->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
     if (ctx->d_partials) (void)hipFree(ctx->d_partials);
+    if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
     if (ctx->d_worklist) (void)hipFree(ctx->d_worklist);
     if (ctx->d_xpack) (void)hipFree(ctx->d_xpack);
     if (ctx->h_result) (void)hipHostFree(ctx->h_result);

@@ -471,3 +471,33 @@ def test_fuse_zpadfft_transform_reaches_the_benchmarked_leaf(hip, oracle_backend
     Ad = p.build_zpadfft(hip)
     assert rel_err(Af * x, Ad * x) < 1e-6
     hip._scratch = None
+
+
+def test_cg_with_device_scalars_matches_host_scalar_cg(hip):
+    """HipBackend.cg keeps alpha / beta / the residuals on the device (no host sync inside an iteration); the base
+    Backend.cg is the reference's loop with host scalars (backend.py:639-689): same iterates, same residual history"""
+    from indigo_amd.backends.backend import Backend
+    p = SenseProblem.synthetic((32, 32, 32), 4, nspokes=96, nreadout=64, width=2, oversamp=2.0, seed=4)
+    hip._scratch = None
+    A = p.build_fused(hip)
+    AHA = normal_operator(A, lamda=0.05)
+    b = A.H * rand64c(A.shape[0], 1, seed=2)
+    for iters, every in ((7, 10), (7, 3), (1, 1)):
+        x1 = np.zeros_like(b, order='F')
+        x2 = np.zeros_like(b, order='F')
+        h1 = hip.cg(AHA, b.copy(order='F'), x1, maxiter=iters, check_every=every)
+        h2 = Backend.cg(hip, AHA, b.copy(order='F'), x2, maxiter=iters)
+        assert len(h1) == len(h2) == iters
+        np.testing.assert_allclose(h1, h2, rtol=1e-4)
+        assert rel_err(x1, x2) < 1e-5
+    # tolerance: stops at the end of the block in which it was met
+    x3 = np.zeros_like(b, order='F')
+    h3 = hip.cg(AHA, b.copy(order='F'), x3, tol=h2[0] * 1.5 if len(h2) else 1.0, maxiter=20, check_every=4)
+    assert len(h3) == 4
+    # device-resident b and x: the iterate is updated in place
+    x7 = np.zeros_like(b, order='F')
+    Backend.cg(hip, AHA, b.copy(order='F'), x7, maxiter=7)
+    x_d = hip.zero_array(b.shape, C64)
+    h4 = hip.cg(AHA, hip.copy_array(b), x_d, maxiter=7)
+    assert rel_err(x_d.to_host(), x7) < 1e-5 and len(h4) == 7
+    hip._scratch = None
