@@ -376,6 +376,7 @@ struct PassDesc {
     int64_t in_sa, out_sa, w_sa;
     int tile_shift;             // tile_range / tile_bits entries are shared by 2^tile_shift consecutive tiles
     int xcd_remap;              // filled in by the launcher
+    int cached;                 // plain passes only: no non-temporal hint (the next pass re-reads the data from the Infinity Cache)
     int in_lo, in_hi, out_lo, out_hi;
     int inverse;
     // optional per-tile override of the box along the transform axis (strided passes, W | ext0):
@@ -405,11 +406,14 @@ struct PassDesc {
 //   1: input half, output box at run time      3: input half, output full
 //   2: output half, input box at run time      4: output half, input full
 // Half inputs prune the first butterfly layer; compile-time boxes need no predicates or bounds registers.
-template <int R1, int R2, int T, int W, bool AXIS0, int WMODE, bool BOXED, int HALF>
+// NTH: non-temporal (streaming) hint on the pass's global loads and stores.  Every byte of a pass is touched once, so
+// the hint is on everywhere -- except in the volume-at-a-time schedule of the plain transform (ig_fft_exec), whose
+// passes hand a 134 MB volume to each other through the 256 MB Infinity Cache.
+template <int R1, int R2, int T, int W, bool AXIS0, int WMODE, bool BOXED, int HALF, bool NTH = true>
 __global__ void __launch_bounds__(W * T, (!AXIS0 && R1 == 32 && (W == 32 || HALF == 1 || HALF == 3 || (IG_FFT_CAP4_HALFOUT && WMODE == 0 && (HALF == 2 || HALF == 4)))) ? 4 : IG_FFT_MINWAVES)
 k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
     constexpr int n = R1 * R2, B1 = R2 / T, B2 = R1 / T, NT = W * T;
-    constexpr bool NT_LD = IG_FFT_NT_LOAD, NT_ST = IG_FFT_NT_STORE;
+    constexpr bool NT_LD = IG_FFT_NT_LOAD && NTH, NT_ST = IG_FFT_NT_STORE && NTH;
     constexpr bool HALF_IN = HALF == 1 || HALF == 3, HALF_OUT = HALF == 2 || HALF == 4;
     constexpr int SUMW = WMODE >= 3 ? (1 << (WMODE - 3)) : 0;       // WMODE 3 + log2(coils): 3 -> 1 (no sum), 4 -> 2, 5 -> 4, 6 -> 8, 7 -> 16
     // direction: the half-input variants only serve forward (zero-padded) passes and the half-output variants only
@@ -829,7 +833,9 @@ int launch_2stage(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d_in, bool ax
     hipLaunchKernelGGL((k_fft_2stage<R1_, 16, 16, 16, AX0_, WM_, BX_, HF_>), grid, block, ax.lds_bytes, ctx->stream, d, ax.d_tw)
 #define IG_2S_W(R1_, AX0_)                                                                           \
     do {                                                                                             \
-        if (!boxed && wmode == 0) IG_2S(R1_, AX0_, 0, false, 0);                                     \
+        if (!boxed && wmode == 0) {                                                                  \
+            if (d.cached) hipLaunchKernelGGL((k_fft_2stage<R1_, 16, 16, 16, AX0_, 0, false, 0, false>), grid, block, ax.lds_bytes, ctx->stream, d, ax.d_tw); \
+            else IG_2S(R1_, AX0_, 0, false, 0); }                                                    \
         else if (wmode == 0) {                                                                       \
             if (half == 1) IG_2S(R1_, AX0_, 0, true, 1); else if (half == 2) IG_2S(R1_, AX0_, 0, true, 2);   \
             else if (half == 3) IG_2S(R1_, AX0_, 0, true, 3); else if (half == 4) IG_2S(R1_, AX0_, 0, true, 4); \
@@ -962,6 +968,36 @@ int ig_fft_exec(ig_fft* p, const void* xv, void* yv, int direction, void* worksp
     // the reference's convention books 4 * nbytes per multi-dimensional FFT (benchmark.py:55); each axis
     // pass gets an equal share of it
     const double pass_bytes = live_axes ? 4.0 * (double)p->total * 8.0 / live_axes : 0.0;
+
+    // Volume-at-a-time schedule: when every axis runs the two-stage kernel and one volume fits the Infinity Cache
+    // (256 MB) with room to spare, the three passes run volume by volume without the streaming hint, so passes 2
+    // and 3 find their input on-die and only the first read and the last write of a volume go to HBM.
+    // INDIGO_HIP_FFT_VOLWISE: 0 never, 1 when it fits (default), 2 the same but keeping the streaming hint (for A/B runs)
+    static const int volwise = getenv("INDIGO_HIP_FFT_VOLWISE") ? atoi(getenv("INDIGO_HIP_FFT_VOLWISE")) : 1;
+    const int64_t vol_elems = p->total / p->batch;
+    bool all_2stage = p->rank >= 2;
+    for (int a = 0; a < p->rank; ++a) if (p->axis[a].kind != 3) all_2stage = false;
+    if (volwise && all_2stage && p->batch > 1 && vol_elems * 8 <= (int64_t)160 << 20 && vol_elems * 8 >= (int64_t)8 << 20) {
+        for (int64_t v = 0; v < p->batch; ++v) {
+            const float2* src = (const float2*)xv + v * vol_elems;
+            float2* dst = y + v * vol_elems;
+            for (int a = 0; a < p->rank; ++a) {
+                const AxisPlan& ax = p->axis[a];
+                ig_prof_scope prof(ctx, a == 0 ? "fft_2stage_axis0" : a == 1 ? "fft_2stage_axis1" : "fft_2stage_axis2", pass_bytes / (double)p->batch);
+                const int64_t outer_v = ax.outer / p->batch;            // the batch is the slowest part of every axis's outer index
+                PassDesc d{};
+                d.in = a == 0 ? src : dst; d.out = dst;
+                d.in_sj = d.out_sj = ax.inner;
+                d.ncols = ax.inner * outer_v;
+                if (ax.inner == 1) { d.ext0 = outer_v; d.ext1 = 1; d.in_s[0] = d.out_s[0] = ax.n; }
+                else { d.ext0 = ax.inner; d.ext1 = outer_v; d.in_s[0] = d.out_s[0] = 1; d.in_s[1] = d.out_s[1] = ax.inner * ax.n; }
+                d.in_lo = d.out_lo = 0; d.in_hi = d.out_hi = (int)ax.n; d.inverse = inverse;
+                d.cached = volwise == 1 ? 1 : 0;
+                if (int rc = launch_2stage(ctx, ax, d, ax.inner == 1, 0)) return rc;
+            }
+        }
+        return IG_OK;
+    }
 
     for (int a = 0; a < p->rank; ++a) {
         const AxisPlan& ax = p->axis[a];

@@ -186,6 +186,28 @@ class SenseProblem(object):
             "fft_crop_x": cvol * e + bvol * e + (bvol * 8 if fused_sum else bvol * e),
         }
 
+    def gridding_pass_bytes(self, ncoils, table=None):
+        """Compulsory HBM bytes of the two gridding products of the fused tree for `ncoils` coils: the matrix once, the
+        panel rows that are really touched once, the result once.  The adjoint (a gather over G'^T restricted to the
+        flagged 16-row segments of the support table) reads the transposed matrix's row pointers only inside flagged
+        segments and writes only those segments.  (The reference's model, operators.py:246-256, prices the adjoint
+        with a full read-modify-write of the 8.6 GB grid panel; both figures are reported by bench.py.)"""
+        Gm = self.fused_interp(1)
+        T, P = Gm.shape
+        nnz = Gm.nnz
+        touched = int(np.unique(Gm.indices).size)
+        e = 8 * ncoils
+        if table is not None:
+            _, _, bits = self.split_support(table)
+            sup = int(np.unpackbits(bits.view(np.uint8)).sum()) * 16
+        else:
+            sup = P
+        return {
+            "csrmm_gather": nnz * 12 + (T + 1) * 4 + touched * e + T * e,
+            "csrmm_rowlane_conj": nnz * 12 + (sup + 1) * 4 + T * e + sup * e,
+            "pack_panel": 2 * T * e,
+        }
+
     @staticmethod
     def locality_order(G):
         """Row order of a gridding matrix that keeps spatial neighbours together: samples sorted by the first
