@@ -863,8 +863,11 @@ int launch_2stage(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d_in, bool ax
     // interleaved layout, 16 MB per element: -11...-15 %) and for the half-input variants, which fit 128 VGPRs;
     // the half-output variants spill at that cap and lose on small-stride passes (cropped z pass: +16 %).
     const bool big_stride = (d.in_sj > d.out_sj ? d.in_sj : d.out_sj) * 8 >= (1 << 20);
+    // (use_w32 == 4 also sends boxed passes WITHOUT a compile-time half box -- e.g. the 320-point box of a 512-point axis,
+    // oversampling 1.6 -- to 32-column tiles when one side runs at a huge stride)
+    const bool w32_generic = use_w32 == 4 && boxed && half == 0 && big_stride;
     if (use_w32 && ax.n == 512 && !axis0 && wmode == 0 && !d.cw && d.ext0 % 32 == 0 &&
-        (((half == 1 || half == 3) && (big_stride || use_w32 != 3)) || ((half == 2 || half == 4) && (big_stride || use_w32 == 2))) &&
+        (((half == 1 || half == 3) && (big_stride || use_w32 != 3)) || ((half == 2 || half == 4) && (big_stride || use_w32 == 2)) || w32_generic) &&
         (!d.tile_range || d.tile_shift >= 1)) {
         // 32-column tiles: 256-byte segments per row, 512 threads, 69.6 KB of LDS (2 workgroups per CU)
         PassDesc d2 = d;
@@ -877,9 +880,11 @@ int launch_2stage(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d_in, bool ax
             IG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fft_2stage<32, 16, 16, 32, false, 0, true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
             IG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fft_2stage<32, 16, 16, 32, false, 0, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
             IG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fft_2stage<32, 16, 16, 32, false, 0, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+            IG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fft_2stage<32, 16, 16, 32, false, 0, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
             ctx->fft_w32_attr = true;
         }
-        if (half == 1) hipLaunchKernelGGL((k_fft_2stage<32, 16, 16, 32, false, 0, true, 1>), g2, b2, lds2, ctx->stream, d2, ax.d_tw);
+        if (half == 0) hipLaunchKernelGGL((k_fft_2stage<32, 16, 16, 32, false, 0, true, 0>), g2, b2, lds2, ctx->stream, d2, ax.d_tw);
+        else if (half == 1) hipLaunchKernelGGL((k_fft_2stage<32, 16, 16, 32, false, 0, true, 1>), g2, b2, lds2, ctx->stream, d2, ax.d_tw);
         else if (half == 3) hipLaunchKernelGGL((k_fft_2stage<32, 16, 16, 32, false, 0, true, 3>), g2, b2, lds2, ctx->stream, d2, ax.d_tw);
         else if (half == 2) hipLaunchKernelGGL((k_fft_2stage<32, 16, 16, 32, false, 0, true, 2>), g2, b2, lds2, ctx->stream, d2, ax.d_tw);
         else hipLaunchKernelGGL((k_fft_2stage<32, 16, 16, 32, false, 0, true, 4>), g2, b2, lds2, ctx->stream, d2, ax.d_tw);
@@ -972,8 +977,11 @@ int ig_fft_exec(ig_fft* p, const void* xv, void* yv, int direction, void* worksp
     // Volume-at-a-time schedule: when every axis runs the two-stage kernel and one volume fits the Infinity Cache
     // (256 MB) with room to spare, the three passes run volume by volume without the streaming hint, so passes 2
     // and 3 find their input on-die and only the first read and the last write of a volume go to HBM.
-    // INDIGO_HIP_FFT_VOLWISE: 0 never, 1 when it fits (default), 2 the same but keeping the streaming hint (for A/B runs)
-    static const int volwise = getenv("INDIGO_HIP_FFT_VOLWISE") ? atoi(getenv("INDIGO_HIP_FFT_VOLWISE")) : 1;
+    // INDIGO_HIP_FFT_VOLWISE: 0 never (default), 1 when it fits, 2 the same but keeping the streaming hint (for A/B runs).
+    // Measured on 256^3 x 16: the 48 small launches total 2.20 ms of kernel time against 2.36 ms for the three big
+    // ones (the Infinity Cache does serve passes 2 and 3), but the gaps between 48 dependent launches eat the gain:
+    // 2.45 ms per transform against 2.37 ms.  Off by default.
+    static const int volwise = getenv("INDIGO_HIP_FFT_VOLWISE") ? atoi(getenv("INDIGO_HIP_FFT_VOLWISE")) : 0;
     const int64_t vol_elems = p->total / p->batch;
     bool all_2stage = p->rank >= 2;
     for (int a = 0; a < p->rank; ++a) if (p->axis[a].kind != 3) all_2stage = false;
