@@ -57,7 +57,7 @@ PMC_NOTE = " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_
 # depends on the grid layout, the axis length and whether the image box is the middle half of the axis.
 def kernel_symbols(layout, ncoils, half_box=True, n=512):
     r1 = 32 if n == 512 else 16
-    f = "k_fft_2stage<%d, 16, 16, %%s>" % r1
+    f = "k_fft_2stage<%d, 16, 16, %%s, true>" % r1            # last argument: streaming (non-temporal) hint on
     m = {
         "fft_2stage_axis0": f % "16, true, 0, false, 0",
         "fft_2stage_axis1": f % "16, false, 0, false, 0",
@@ -74,9 +74,11 @@ def kernel_symbols(layout, ncoils, half_box=True, n=512):
                       "fft_crop_z": f % "16, false, 0, true, 2", "fft_crop_y": f % "32, false, 0, true, 2",
                       "fft_crop_x": f % ("16, false, %d, true, 4" % (3 + lg))})
         else:
+            # no compile-time half box (config 5: 320 of 512): run-time box predicates; the y passes (16 MB stride on the
+            # grid side) take 32-column tiles, the z passes 16-column ones
             m.update({"fft_pad_x": f % "16, false, 1, true, 0",
-                      "fft_pad_y": f % "16, false, 0, true, 0", "fft_pad_z": f % "16, false, 0, true, 0",
-                      "fft_crop_z": f % "16, false, 0, true, 0", "fft_crop_y": f % "16, false, 0, true, 0",
+                      "fft_pad_y": f % "32, false, 0, true, 0", "fft_pad_z": f % "16, false, 0, true, 0",
+                      "fft_crop_z": f % "16, false, 0, true, 0", "fft_crop_y": f % "32, false, 0, true, 0",
                       "fft_crop_x": f % ("16, false, %d, true, 0" % (3 + lg))})
         m.update({"csrmm_rowlane_conj": "k_csrmm_dense64<%d, true, true>" % ncoils, "csrmm_gather": gv})
     elif layout == 1:

@@ -30,6 +30,7 @@ struct ig_ctx {
     void*        d_xpack     = nullptr;   // SpMM repacked-panel scratch (grown on demand)
     size_t       xpack_bytes = 0;
     int32_t*     d_worklist  = nullptr;   // SpMM deferred-row lists + counters (allocated on first use)
+    bool         fft3d_attr = false;      // the two-launch 256^3 transform's dynamic-LDS opt-in was applied on this device
     bool         fft_w32_attr = false;    // the 32-column FFT kernels' dynamic-LDS opt-in was applied on this device
     // profile mode (ig_prof_enable): every kernel launch is bracketed by two events
     bool                     prof_on = false;
@@ -133,6 +134,11 @@ __device__ __forceinline__ void buf_st(rsrc_t r, unsigned voff, unsigned soff, f
 typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int buf_ld_i32(rsrc_t r, unsigned voff) {
     return (int)__builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0);
+}
+template <bool NT>
+__device__ __forceinline__ void buf_st_f4(rsrc_t r, unsigned voff, unsigned soff, float4 a) {
+    v4u_t v; v.x = __float_as_uint(a.x); v.y = __float_as_uint(a.y); v.z = __float_as_uint(a.z); v.w = __float_as_uint(a.w);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, NT ? 2 : 0);
 }
 __device__ __forceinline__ float4 buf_ld_f4(rsrc_t r, unsigned voff) {
     const v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);

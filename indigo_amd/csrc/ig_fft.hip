@@ -584,6 +584,216 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
     }
 }
 
+// ---- 256^3 in TWO launches ------------------------------------------------------------------------------------
+// The plain 3-D transform above is three passes = 6 x the volume in HBM traffic; the reference's own accounting
+// (benchmark.py:55) prices a 3-D transform at 4 x.  For 256^3 volumes (BASELINE config 2) two launches suffice if a
+// workgroup owns 16384 elements (2 x 64 registers per thread pair ... 32 complex values per thread, 512 threads) and the
+// y axis is split 64 x 4 between the launches:
+//
+//   launch A, workgroup (z, n2):  the 64 lines y = 4*n1 + n2 of plane z.  y stage 1 (64-point DFT over n1 = 8 x 8), the
+//             inter-stage twiddle w256^(n2 k1), then the full 256-point x transform (4 x 8 x 8).  Lines go out to
+//             y' = k1 + 64*n2: one contiguous 128 KB block per workgroup.  Out of place.
+//   launch B, workgroup (16 x, k1): the 4 rows y' = k1 + 64*n2 for all 256 z.  y stage 2 (4-point DFT over n2, giving
+//             ky = k1 + 64*k2 in place), then the full 256-point z transform (8 x 32).  In place.
+//
+// Every stage is a register DFT on values the thread already holds; between stages the workgroup redistributes through
+// LDS in four 32 KB rounds (launch A: twice across waves and once inside each wave; launch B: once).  All LDS address
+// maps below are conflict-free (one lane per 8-byte slot modulo 64); tools/fft2pass_model.py is a thread-level numpy
+// model of exactly these maps, checked against numpy.fft.fftn.
+constexpr int F3_LDS_ELEMS = 64 * 72;            // largest exchange image (launch A, second exchange)
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ void __launch_bounds__(512, 4)
+k_fft3d_a(const float2* __restrict__ in, float2* __restrict__ out, const float2* __restrict__ tw, int inverse) {
+    extern __shared__ float2 lds[];
+    float2* __restrict__ tws = lds + F3_LDS_ELEMS;
+    const int tid = threadIdx.x;
+    for (int k = tid; k < 256; k += 512) tws[k] = tw[k];
+    const int z = blockIdx.x, n2 = blockIdx.y;
+    const int64_t base = ((int64_t)blockIdx.z << 24) + ((int64_t)z << 16);
+    const int xl = tid & 63, a = tid >> 6;
+    const bool inv = inverse != 0;
+
+    // role 0: lane = x mod 64, wave = a.  v[j][b]: line n1 = a + 8b, x = xl + 64j (a wave load = 512 contiguous bytes)
+    // (buffer loads: descriptor at the wave's first line, one 32-bit lane offset, the (b, j) displacement as a scalar / immediate
+    // offset -- 32 loads in flight without 32 address register pairs)
+    cx v[4][8];
+    {
+        const int a_u = __builtin_amdgcn_readfirstlane(a);              // the wave index is wave-uniform
+        const rsrc_t r_in = make_rsrc(in + base + 256 * n2 + 1024 * a_u);
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j][b] = from2(buf_ld<true>(r_in, (unsigned)xl * 8u, (unsigned)(64 * j + 8192 * b) * 8u));
+                if (inv) v[j][b] = cconj(v[j][b]);
+            }
+    }
+    __syncthreads();                                   // twiddle table visible
+    // y stage 1a: 8-point DFT over b, twiddle w64^(a kb)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        PFFT<8>::run(v[j]);
+#pragma unroll
+        for (int kb = 1; kb < 8; ++kb) v[j][kb] = cxmul(v[j][kb], from2(tws[(4 * a * kb) & 255]));
+    }
+    // exchange 1 (a <-> kb between waves, lane kept): image [a][kb][xl]
+    cx r[4][8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (j) __syncthreads();
+#pragma unroll
+        for (int kb = 0; kb < 8; ++kb) lds[(a * 8 + kb) * 64 + xl] = to2(v[j][kb]);
+        __syncthreads();
+#pragma unroll
+        for (int ap = 0; ap < 8; ++ap) r[j][ap] = from2(lds[(ap * 8 + a) * 64 + xl]);
+    }
+    const int kb = a;                                  // role 1: the wave index now names kb
+    // y stage 1b: 8-point DFT over a -> line k1 = kb + 8 ka; inter-launch twiddle w256^(n2 k1); x stage 1: 4-point DFT over j
+    cx p[8][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) PFFT<8>::run(r[j]);
+#pragma unroll
+    for (int ka = 0; ka < 8; ++ka) {
+        const cx wy = from2(tws[(n2 * (kb + 8 * ka)) & 255]);
+        cx t4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t4[j] = cxmul(r[j][ka], wy);
+        PFFT<4>::run(t4);
+        p[ka][0] = t4[0];
+#pragma unroll
+        for (int kj = 1; kj < 4; ++kj) p[ka][kj] = cxmul(t4[kj], from2(tws[(xl * kj) & 255]));
+    }
+    // exchange 2: image [line][72] (x within a line); role 2 = (c = x mod 8, line): lane = c + 8*(line mod 8), wave = line / 8
+    const int c = tid & 7, l = (tid >> 3) & 7, line = (tid >> 3);
+    cx q[4][8];
+#pragma unroll
+    for (int kj = 0; kj < 4; ++kj) {
+        __syncthreads();
+#pragma unroll
+        for (int ka = 0; ka < 8; ++ka) lds[(kb + 8 * ka) * 72 + xl] = to2(p[ka][kj]);
+        __syncthreads();
+#pragma unroll
+        for (int d = 0; d < 8; ++d) q[kj][d] = from2(lds[line * 72 + c + 8 * d]);
+    }
+    // x stage 2: 8-point DFT over d, twiddle w64^(c kd)
+#pragma unroll
+    for (int kj = 0; kj < 4; ++kj) {
+        PFFT<8>::run(q[kj]);
+#pragma unroll
+        for (int kd = 1; kd < 8; ++kd) q[kj][kd] = cxmul(q[kj][kd], from2(tws[(4 * c * kd) & 255]));
+    }
+    // exchange 3 (c <-> kd among the 8 lanes of a line: inside the wave): image [line][64], swizzled both ways
+    __syncthreads();                                   // the last round of exchange 2 has been read everywhere
+    const int kd3 = c;                                 // role 3: the low lane bits now name kd
+    cx t3[4][8];
+#pragma unroll
+    for (int kj = 0; kj < 4; ++kj) {
+        if (kj) wave_sync();
+#pragma unroll
+        for (int kd = 0; kd < 8; ++kd) lds[line * 64 + 8 * ((c + l) & 7) + ((kd + l) & 7)] = to2(q[kj][kd]);
+        wave_sync();
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) t3[kj][cc] = from2(lds[line * 64 + 8 * ((cc + l) & 7) + ((kd3 + l) & 7)]);
+    }
+    // x stage 3: 8-point DFT over c -> kx = kj + 4 kd + 32 kc; four adjacent kx per thread and kc: two 16-byte stores
+#pragma unroll
+    for (int kj = 0; kj < 4; ++kj) PFFT<8>::run(t3[kj]);
+    const rsrc_t r_out = make_rsrc(out + base + 256 * 64 * n2);
+    const unsigned l_out = (unsigned)(256 * line + 4 * kd3) * 8u;
+#pragma unroll
+    for (int kc = 0; kc < 8; ++kc) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            cx e0 = t3[2 * h][kc], e1 = t3[2 * h + 1][kc];
+            if (inv) { e0 = cconj(e0); e1 = cconj(e1); }
+            buf_st_f4<true>(r_out, l_out, (unsigned)(32 * kc + 2 * h) * 8u, make_float4(e0.v.x, e0.v.y, e1.v.x, e1.v.y));
+        }
+    }
+}
+
+__global__ void __launch_bounds__(512, 4)
+k_fft3d_b(const float2* __restrict__ in, float2* __restrict__ out, const float2* __restrict__ tw, int inverse) {
+    extern __shared__ float2 lds[];
+    float2* __restrict__ tws = lds + F3_LDS_ELEMS;
+    const int tid = threadIdx.x;
+    for (int k = tid; k < 256; k += 512) tws[k] = tw[k];
+    const int xs = blockIdx.x * 16, k1 = blockIdx.y;
+    const int64_t base = ((int64_t)blockIdx.z << 24) + xs;
+    const int w = tid & 15, t = tid >> 4;
+    const bool inv = inverse != 0;
+    // role 0: lane = x, t = z mod 32.  v[k][n2]: z = t + 32k, row y' = k1 + 64 n2
+    cx v[8][4];
+    const unsigned l_io = ((unsigned)w + ((unsigned)t << 16)) * 8u;      // lane part of every address: x + 65536 * (z mod 32)
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int n2 = 0; n2 < 4; ++n2) {
+            // descriptor re-based per (k, n2): a scalar add; the lane offset stays below 16.3 MB
+            v[k][n2] = from2(buf_ld<true>(make_rsrc(in + base + 256 * (k1 + 64 * n2) + ((int64_t)(32 * k) << 16)), l_io, 0));
+            if (inv) v[k][n2] = cconj(v[k][n2]);
+        }
+    __syncthreads();
+    // y stage 2: 4-point DFT over n2 -> ky = k1 + 64 k2;  z stage 1: 8-point DFT over k, twiddle w256^(t kk)
+    // (scheduling fences between the register DFTs: left alone, the scheduler interleaves all twelve of them for
+    // instruction-level parallelism and spills ~75 registers at the kernel's 128-register cap)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { PFFT<4>::run(v[k]); __builtin_amdgcn_sched_barrier(0); }
+    cx twz[8];
+#pragma unroll
+    for (int kk = 1; kk < 8; ++kk) twz[kk] = from2(tws[(t * kk) & 255]);
+    cx u[4][8];
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) u[k2][k] = v[k][k2];
+        PFFT<8>::run(u[k2]);
+#pragma unroll
+        for (int kk = 1; kk < 8; ++kk) u[k2][kk] = cxmul(u[k2][kk], twz[kk]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // exchange: image [t][144] with (kk, x) inside a row; role 1 = (x, kk, k2) collects t = 0..31 in round k2
+    const int kk1 = (tid >> 4) & 7, k21 = tid >> 7;
+    // (two images per round, two rounds: with one image and four rounds the not-yet-sent u and the arriving r are live
+    // together and the kernel spills at its 128-register cap)
+    cx r[32];
+    float2* __restrict__ img1 = lds + F3_LDS_ELEMS + 256;
+#pragma unroll
+    for (int rnd = 0; rnd < 2; ++rnd) {
+        if (rnd) __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            lds[t * 144 + kk * 16 + w] = to2(u[2 * rnd][kk]);
+            img1[t * 144 + kk * 16 + w] = to2(u[2 * rnd + 1][kk]);
+        }
+        __syncthreads();
+        if ((k21 >> 1) == rnd) {
+            const float2* __restrict__ img = (k21 & 1) ? img1 : lds;
+#pragma unroll
+            for (int tt = 0; tt < 32; ++tt) r[tt] = from2(img[tt * 144 + kk1 * 16 + w]);
+        }
+    }
+    // z stage 2: 32-point DFT over t -> kz = kk + 8 rr
+    __builtin_amdgcn_sched_barrier(0);
+    PFFT<32>::run(r);
+    __builtin_amdgcn_sched_barrier(0);
+    // role 1's k2 is wave-uniform (two waves per k2); its kk takes four values per wave and rides in the lane offset
+    const int k2_u = __builtin_amdgcn_readfirstlane(k21);
+    const float2* const ob = out + base + 256 * (k1 + 64 * k2_u);
+    const unsigned l_st = ((unsigned)w + ((unsigned)kk1 << 16)) * 8u;
+#pragma unroll
+    for (int rr = 0; rr < 32; ++rr) {
+        cx e = r[rr];
+        if (inv) e = cconj(e);
+        buf_st<true>(make_rsrc(ob + ((int64_t)(8 * rr) << 16)), l_st, 0, to2(e));
+    }
+}
+
 // AXIS0: inner == 1 (columns are contiguous lines of n elements).
 template <bool AXIS0>
 __global__ void __launch_bounds__(1024)
@@ -736,6 +946,8 @@ struct ig_fft {
     size_t workspace_bytes = 0;
     std::string desc;
     // zero-padded / cropped plans (ig_fft_plan_padded): the image occupies box_lo .. box_lo+box_dims of the grid
+    bool two_launch = false;         // 256^3 volumes: k_fft3d_a + k_fft3d_b instead of three axis passes
+    float2* d_inplace = nullptr;     // lazily allocated staging volume set for in-place calls of the two-launch transform
     bool padded = false;
     int layout = 0;                  // memory order of the grid: 0 = (x, y, z), 1 = (x, z, y)
     int64_t box_lo[3] = {0, 0, 0}, box_dims[3] = {1, 1, 1};
@@ -863,9 +1075,9 @@ int launch_2stage(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d_in, bool ax
     // interleaved layout, 16 MB per element: -11...-15 %) and for the half-input variants, which fit 128 VGPRs;
     // the half-output variants spill at that cap and lose on small-stride passes (cropped z pass: +16 %).
     const bool big_stride = (d.in_sj > d.out_sj ? d.in_sj : d.out_sj) * 8 >= (1 << 20);
-    // (use_w32 == 4 also sends boxed passes WITHOUT a compile-time half box -- e.g. the 320-point box of a 512-point axis,
-    // oversampling 1.6 -- to 32-column tiles when one side runs at a huge stride)
-    const bool w32_generic = use_w32 == 4 && boxed && half == 0 && big_stride;
+    // boxed passes WITHOUT a compile-time half box (e.g. the 320-point box of a 512-point axis, oversampling 1.6) also take
+    // 32-column tiles when one side runs at a huge stride: cropped y pass of config 5 0.85 -> 0.74 ms, padded y pass unchanged
+    const bool w32_generic = use_w32 && use_w32 != 3 && boxed && half == 0 && big_stride;
     if (use_w32 && ax.n == 512 && !axis0 && wmode == 0 && !d.cw && d.ext0 % 32 == 0 &&
         (((half == 1 || half == 3) && (big_stride || use_w32 != 3)) || ((half == 2 || half == 4) && (big_stride || use_w32 == 2)) || w32_generic) &&
         (!d.tile_range || d.tile_shift >= 1)) {
@@ -932,6 +1144,10 @@ int ig_fft_plan(ig_ctx* ctx, int rank, const int64_t* dims, int64_t batch, ig_ff
     }
     p->workspace_bytes = need_ws ? (size_t)p->total * 8 : 0;
     if (workspace_bytes) *workspace_bytes = p->workspace_bytes;
+    {
+        static const int use2 = getenv("INDIGO_HIP_FFT_2LAUNCH") ? atoi(getenv("INDIGO_HIP_FFT_2LAUNCH")) : 1;
+        p->two_launch = use2 && rank == 3 && dims[0] == 256 && dims[1] == 256 && dims[2] == 256 && p->axis[0].kind == 3;
+    }
 
     char buf[256];
     p->desc.clear();
@@ -950,6 +1166,7 @@ int ig_fft_plan(ig_ctx* ctx, int rank, const int64_t* dims, int64_t batch, ig_ff
         }
         p->desc += "; ";
     }
+    if (p->two_launch) p->desc = "two launches (x + y/64 | y/4 + z), 512 threads x 32 values, LDS exchanges; fallback: " + p->desc;
     *plan = p;
     return IG_OK;
 }
@@ -967,6 +1184,34 @@ int ig_fft_exec(ig_fft* p, const void* xv, void* yv, int direction, void* worksp
     const float2* cur = (const float2*)xv;
     float2* y = (float2*)yv;
     float2* work = (float2*)workspace;
+
+    if (p->two_launch) {
+        const size_t lds_bytes = (size_t)(F3_LDS_ELEMS + 256) * sizeof(float2);
+        const float2* src = (const float2*)xv;
+        float2* mid = y;
+        if (xv == yv) {         // launch A cannot run in place: stage through a volume set owned by the plan
+            if (!p->d_inplace) IG_HIP(ctx, hipMalloc((void**)&p->d_inplace, (size_t)p->total * 8));
+            mid = p->d_inplace;
+        }
+        const double half_bytes = 2.0 * (double)p->total * 8.0;        // benchmark.py:55: 4 * nbytes per transform
+        {
+            ig_prof_scope prof(ctx, "fft3d_xy", half_bytes);
+            hipLaunchKernelGGL(k_fft3d_a, dim3(256, 4, (unsigned)p->batch), dim3(512), lds_bytes, ctx->stream, src, mid, p->axis[0].d_tw, inverse);
+            IG_LAUNCH_CHECK(ctx, "k_fft3d_a");
+        }
+        {
+            ig_prof_scope prof(ctx, "fft3d_yz", half_bytes);
+            // (launch B keeps two exchange images: 75.7 KB per workgroup, above the 64 KB a kernel may use without opting in)
+            const size_t lds_b = (size_t)(2 * F3_LDS_ELEMS + 256) * sizeof(float2);
+            if (!ctx->fft3d_attr) {
+                IG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fft3d_b), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+                ctx->fft3d_attr = true;
+            }
+            hipLaunchKernelGGL(k_fft3d_b, dim3(16, 64, (unsigned)p->batch), dim3(512), lds_b, ctx->stream, (const float2*)mid, y, p->axis[0].d_tw, inverse);
+            IG_LAUNCH_CHECK(ctx, "k_fft3d_b");
+        }
+        return IG_OK;
+    }
 
     int live_axes = 0;
     for (int a = 0; a < p->rank; ++a) if (p->axis[a].kind != 2) ++live_axes;
@@ -1461,6 +1706,7 @@ int ig_fft_destroy(ig_fft* p) {
     (void)hipStreamSynchronize(p->ctx->stream);
     for (int a = 0; a < 3; ++a)
         if (p->axis[a].d_tw) (void)hipFree(p->axis[a].d_tw);
+    if (p->d_inplace) (void)hipFree(p->d_inplace);
     delete p;
     return IG_OK;
 }
