@@ -135,10 +135,14 @@ typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int buf_ld_i32(rsrc_t r, unsigned voff) {
     return (int)__builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0);
 }
+// 16-byte store.  No scalar-offset operand on purpose: on gfx950 a 16-byte buffer store with a scalar-REGISTER offset,
+// followed directly by a VALU write of its data registers, stored stale data in the upper lanes of every 16-lane row
+// (measured: the two-launch FFT's imaginary parts); the compiler pads that write-after-read hazard only for
+// immediate offsets.  Fold constant displacements into `voff` (they become the instruction's immediate offset).
 template <bool NT>
-__device__ __forceinline__ void buf_st_f4(rsrc_t r, unsigned voff, unsigned soff, float4 a) {
+__device__ __forceinline__ void buf_st_f4(rsrc_t r, unsigned voff, float4 a) {
     v4u_t v; v.x = __float_as_uint(a.x); v.y = __float_as_uint(a.y); v.z = __float_as_uint(a.z); v.w = __float_as_uint(a.w);
-    __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, NT ? 2 : 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, 0, NT ? 2 : 0);
 }
 __device__ __forceinline__ float4 buf_ld_f4(rsrc_t r, unsigned voff) {
     const v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);

@@ -600,6 +600,18 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
 // LDS in four 32 KB rounds (launch A: twice across waves and once inside each wave; launch B: once).  All LDS address
 // maps below are conflict-free (one lane per 8-byte slot modulo 64); tools/fft2pass_model.py is a thread-level numpy
 // model of exactly these maps, checked against numpy.fft.fftn.
+#ifndef IG_F3B_NT_LD
+#define IG_F3B_NT_LD false    // (launch B without the streaming hint on either side: 1.746 against 1.788 ms per 256^3 x 16 transform)
+#endif
+#ifndef IG_F3B_NT_ST
+#define IG_F3B_NT_ST false
+#endif
+#ifndef IG_F3A_NT_LD
+#define IG_F3A_NT_LD true
+#endif
+#ifndef IG_F3_NT_ST
+#define IG_F3_NT_ST false     // launch A stores 16-byte pieces (two instructions per 128-byte line): no streaming hint on partial lines
+#endif
 constexpr int F3_LDS_ELEMS = 64 * 72;            // largest exchange image (launch A, second exchange)
 
 __device__ __forceinline__ void wave_sync() {
@@ -630,7 +642,7 @@ k_fft3d_a(const float2* __restrict__ in, float2* __restrict__ out, const float2*
         for (int b = 0; b < 8; ++b)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                v[j][b] = from2(buf_ld<true>(r_in, (unsigned)xl * 8u, (unsigned)(64 * j + 8192 * b) * 8u));
+                v[j][b] = from2(buf_ld<IG_F3A_NT_LD>(r_in, (unsigned)xl * 8u, (unsigned)(64 * j + 8192 * b) * 8u));
                 if (inv) v[j][b] = cconj(v[j][b]);
             }
     }
@@ -642,16 +654,23 @@ k_fft3d_a(const float2* __restrict__ in, float2* __restrict__ out, const float2*
 #pragma unroll
         for (int kb = 1; kb < 8; ++kb) v[j][kb] = cxmul(v[j][kb], from2(tws[(4 * a * kb) & 255]));
     }
-    // exchange 1 (a <-> kb between waves, lane kept): image [a][kb][xl]
+    // exchange 1 (a <-> kb between waves, lane kept): image [a][kb][xl], two images (two j) per round
     cx r[4][8];
+    float2* __restrict__ img1 = lds + F3_LDS_ELEMS + 256;         // second image (behind the twiddle table)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (j) __syncthreads();
+    for (int jp = 0; jp < 2; ++jp) {
+        if (jp) __syncthreads();
 #pragma unroll
-        for (int kb = 0; kb < 8; ++kb) lds[(a * 8 + kb) * 64 + xl] = to2(v[j][kb]);
+        for (int kb = 0; kb < 8; ++kb) {
+            lds[(a * 8 + kb) * 64 + xl] = to2(v[2 * jp][kb]);
+            img1[(a * 8 + kb) * 64 + xl] = to2(v[2 * jp + 1][kb]);
+        }
         __syncthreads();
 #pragma unroll
-        for (int ap = 0; ap < 8; ++ap) r[j][ap] = from2(lds[(ap * 8 + a) * 64 + xl]);
+        for (int ap = 0; ap < 8; ++ap) {
+            r[2 * jp][ap] = from2(lds[(ap * 8 + a) * 64 + xl]);
+            r[2 * jp + 1][ap] = from2(img1[(ap * 8 + a) * 64 + xl]);
+        }
     }
     const int kb = a;                                  // role 1: the wave index now names kb
     // y stage 1b: 8-point DFT over a -> line k1 = kb + 8 ka; inter-launch twiddle w256^(n2 k1); x stage 1: 4-point DFT over j
@@ -673,13 +692,19 @@ k_fft3d_a(const float2* __restrict__ in, float2* __restrict__ out, const float2*
     const int c = tid & 7, l = (tid >> 3) & 7, line = (tid >> 3);
     cx q[4][8];
 #pragma unroll
-    for (int kj = 0; kj < 4; ++kj) {
+    for (int jp = 0; jp < 2; ++jp) {
         __syncthreads();
 #pragma unroll
-        for (int ka = 0; ka < 8; ++ka) lds[(kb + 8 * ka) * 72 + xl] = to2(p[ka][kj]);
+        for (int ka = 0; ka < 8; ++ka) {
+            lds[(kb + 8 * ka) * 72 + xl] = to2(p[ka][2 * jp]);
+            img1[(kb + 8 * ka) * 72 + xl] = to2(p[ka][2 * jp + 1]);
+        }
         __syncthreads();
 #pragma unroll
-        for (int d = 0; d < 8; ++d) q[kj][d] = from2(lds[line * 72 + c + 8 * d]);
+        for (int d = 0; d < 8; ++d) {
+            q[2 * jp][d] = from2(lds[line * 72 + c + 8 * d]);
+            q[2 * jp + 1][d] = from2(img1[line * 72 + c + 8 * d]);
+        }
     }
     // x stage 2: 8-point DFT over d, twiddle w64^(c kd)
 #pragma unroll
@@ -693,13 +718,19 @@ k_fft3d_a(const float2* __restrict__ in, float2* __restrict__ out, const float2*
     const int kd3 = c;                                 // role 3: the low lane bits now name kd
     cx t3[4][8];
 #pragma unroll
-    for (int kj = 0; kj < 4; ++kj) {
-        if (kj) wave_sync();
+    for (int jp = 0; jp < 2; ++jp) {
+        if (jp) wave_sync();
 #pragma unroll
-        for (int kd = 0; kd < 8; ++kd) lds[line * 64 + 8 * ((c + l) & 7) + ((kd + l) & 7)] = to2(q[kj][kd]);
+        for (int kd = 0; kd < 8; ++kd) {
+            lds[line * 64 + 8 * ((c + l) & 7) + ((kd + l) & 7)] = to2(q[2 * jp][kd]);
+            img1[line * 64 + 8 * ((c + l) & 7) + ((kd + l) & 7)] = to2(q[2 * jp + 1][kd]);
+        }
         wave_sync();
 #pragma unroll
-        for (int cc = 0; cc < 8; ++cc) t3[kj][cc] = from2(lds[line * 64 + 8 * ((cc + l) & 7) + ((kd3 + l) & 7)]);
+        for (int cc = 0; cc < 8; ++cc) {
+            t3[2 * jp][cc] = from2(lds[line * 64 + 8 * ((cc + l) & 7) + ((kd3 + l) & 7)]);
+            t3[2 * jp + 1][cc] = from2(img1[line * 64 + 8 * ((cc + l) & 7) + ((kd3 + l) & 7)]);
+        }
     }
     // x stage 3: 8-point DFT over c -> kx = kj + 4 kd + 32 kc; four adjacent kx per thread and kc: two 16-byte stores
 #pragma unroll
@@ -712,7 +743,10 @@ k_fft3d_a(const float2* __restrict__ in, float2* __restrict__ out, const float2*
         for (int h = 0; h < 2; ++h) {
             cx e0 = t3[2 * h][kc], e1 = t3[2 * h + 1][kc];
             if (inv) { e0 = cconj(e0); e1 = cconj(e1); }
-            buf_st_f4<true>(r_out, l_out, (unsigned)(32 * kc + 2 * h) * 8u, make_float4(e0.v.x, e0.v.y, e1.v.x, e1.v.y));
+            // the displacement goes into the instruction's immediate offset (lane offset + constant), NOT into the scalar
+            // offset operand: a 16-byte buffer store with a scalar-register offset whose data registers are overwritten by the
+            // next VALU instruction stored stale upper lanes on gfx950 (the compiler only pads that hazard for immediate offsets)
+            buf_st_f4<IG_F3_NT_ST>(r_out, l_out + (unsigned)(32 * kc + 2 * h) * 8u, make_float4(e0.v.x, e0.v.y, e1.v.x, e1.v.y));
         }
     }
 }
@@ -720,77 +754,73 @@ k_fft3d_a(const float2* __restrict__ in, float2* __restrict__ out, const float2*
 __global__ void __launch_bounds__(512, 4)
 k_fft3d_b(const float2* __restrict__ in, float2* __restrict__ out, const float2* __restrict__ tw, int inverse) {
     extern __shared__ float2 lds[];
-    float2* __restrict__ tws = lds + F3_LDS_ELEMS;
+    float2* __restrict__ tws = lds + 2 * F3_LDS_ELEMS;
     const int tid = threadIdx.x;
     for (int k = tid; k < 256; k += 512) tws[k] = tw[k];
     const int xs = blockIdx.x * 16, k1 = blockIdx.y;
     const int64_t base = ((int64_t)blockIdx.z << 24) + xs;
-    const int w = tid & 15, t = tid >> 4;
+    // role 0: h = lane bit 0 picks the rows n2 = h, h + 2 (the other two live in the neighbouring lane); w = x; t = z mod 16
+    const int h = tid & 1, w = (tid >> 1) & 15, t = tid >> 5;
     const bool inv = inverse != 0;
-    // role 0: lane = x, t = z mod 32.  v[k][n2]: z = t + 32k, row y' = k1 + 64 n2
-    cx v[8][4];
-    const unsigned l_io = ((unsigned)w + ((unsigned)t << 16)) * 8u;      // lane part of every address: x + 65536 * (z mod 32)
+    cx v[2][16];                                       // [m][k]: row n2 = h + 2m, z = t + 16k
+    const unsigned l_io = ((unsigned)w + ((unsigned)t << 16) + (unsigned)h * (256u * 64u)) * 8u;   // x + 65536*(z mod 16) + the row of h
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
+    for (int k = 0; k < 16; ++k)
 #pragma unroll
-        for (int n2 = 0; n2 < 4; ++n2) {
-            // descriptor re-based per (k, n2): a scalar add; the lane offset stays below 16.3 MB
-            v[k][n2] = from2(buf_ld<true>(make_rsrc(in + base + 256 * (k1 + 64 * n2) + ((int64_t)(32 * k) << 16)), l_io, 0));
-            if (inv) v[k][n2] = cconj(v[k][n2]);
+        for (int m = 0; m < 2; ++m) {
+            // descriptor re-based per (k, m): a scalar add; the lane offset stays below 8.6 MB
+            v[m][k] = from2(buf_ld<IG_F3B_NT_LD>(make_rsrc(in + base + 256 * (k1 + 128 * m) + ((int64_t)(16 * k) << 16)), l_io, 0));
+            if (inv) v[m][k] = cconj(v[m][k]);
         }
     __syncthreads();
-    // y stage 2: 4-point DFT over n2 -> ky = k1 + 64 k2;  z stage 1: 8-point DFT over k, twiddle w256^(t kk)
-    // (scheduling fences between the register DFTs: left alone, the scheduler interleaves all twelve of them for
-    // instruction-level parallelism and spills ~75 registers at the kernel's 128-register cap)
+    // y stage 2: 4-point DFT over n2 = h + 2m -> ky = k1 + 64 k2, k2 = q + 2h.  In the thread: the sum / difference over m
+    // (q = 0, 1) and the twiddle w4^(h q) = -i for h = q = 1; then one exchange with the neighbouring lane (h ^ 1):
+    // h = 0 keeps own + partner (k2 = q), h = 1 keeps partner - own (k2 = q + 2).
+    cx y[2][16];                                       // [q][k]
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { PFFT<4>::run(v[k]); __builtin_amdgcn_sched_barrier(0); }
-    cx twz[8];
-#pragma unroll
-    for (int kk = 1; kk < 8; ++kk) twz[kk] = from2(tws[(t * kk) & 255]);
-    cx u[4][8];
-#pragma unroll
-    for (int k2 = 0; k2 < 4; ++k2) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) u[k2][k] = v[k][k2];
-        PFFT<8>::run(u[k2]);
-#pragma unroll
-        for (int kk = 1; kk < 8; ++kk) u[k2][kk] = cxmul(u[k2][kk], twz[kk]);
-        __builtin_amdgcn_sched_barrier(0);
+    for (int k = 0; k < 16; ++k) {
+        cx a0 = v[0][k] + v[1][k], a1 = v[0][k] - v[1][k];
+        if (h) a1 = cmul_mi(a1);
+        cx p0, p1;
+        p0.v = v2f{dpp_f<0xB1>(a0.v.x), dpp_f<0xB1>(a0.v.y)};      // quad_perm [1,0,3,2]: the lane with the other h
+        p1.v = v2f{dpp_f<0xB1>(a1.v.x), dpp_f<0xB1>(a1.v.y)};
+        y[0][k] = h ? p0 - a0 : a0 + p0;
+        y[1][k] = h ? p1 - a1 : a1 + p1;
     }
-    // exchange: image [t][144] with (kk, x) inside a row; role 1 = (x, kk, k2) collects t = 0..31 in round k2
-    const int kk1 = (tid >> 4) & 7, k21 = tid >> 7;
-    // (two images per round, two rounds: with one image and four rounds the not-yet-sent u and the arriving r are live
-    // together and the kernel spills at its 128-register cap)
-    cx r[32];
-    float2* __restrict__ img1 = lds + F3_LDS_ELEMS + 256;
+    __builtin_amdgcn_sched_barrier(0);
+    // z stage 1: 16-point DFT over k, twiddle w256^(t kk); exchange (t <-> kk among the threads of one (x, h)); z stage 2:
+    // 16-point DFT over t -> kz = kk + 16 rr.  One round per q: every thread writes 16 and reads 16 values.
+    const int kk1 = t;                                 // role 1: the same thread index now names kk
+    const int k2_base = 2 * h;
+    const unsigned l_st = ((unsigned)w + ((unsigned)kk1 << 16) + (unsigned)k2_base * (256u * 64u)) * 8u;
 #pragma unroll
-    for (int rnd = 0; rnd < 2; ++rnd) {
-        if (rnd) __syncthreads();
+    for (int q = 0; q < 2; ++q) {
+        PFFT<16>::run(y[q]);
+        if (q) __syncthreads();
+        // twiddle and hand over four values at a time; the compiler-level fences keep the scheduler from hoisting all
+        // fifteen twiddle loads (30 registers) above the transform, which spilled y[1] at the 128-register cap
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            lds[t * 144 + kk * 16 + w] = to2(u[2 * rnd][kk]);
-            img1[t * 144 + kk * 16 + w] = to2(u[2 * rnd + 1][kk]);
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int kk = 4 * g; kk < 4 * g + 4; ++kk) {
+                if (kk) y[q][kk] = cxmul(y[q][kk], from2(tws[(t * kk) & 255]));
+                lds[t * 544 + kk * 32 + h * 16 + w] = to2(y[q][kk]);
+            }
+            asm volatile("" ::: "memory");
         }
         __syncthreads();
-        if ((k21 >> 1) == rnd) {
-            const float2* __restrict__ img = (k21 & 1) ? img1 : lds;
+        cx r[16];
 #pragma unroll
-            for (int tt = 0; tt < 32; ++tt) r[tt] = from2(img[tt * 144 + kk1 * 16 + w]);
+        for (int tt = 0; tt < 16; ++tt) r[tt] = from2(lds[tt * 544 + kk1 * 32 + h * 16 + w]);
+        PFFT<16>::run(r);
+        const float2* const ob = out + base + 256 * (k1 + 64 * q);
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            cx e = r[rr];
+            if (inv) e = cconj(e);
+            buf_st<IG_F3B_NT_ST>(make_rsrc(ob + ((int64_t)(16 * rr) << 16)), l_st, 0, to2(e));
         }
-    }
-    // z stage 2: 32-point DFT over t -> kz = kk + 8 rr
-    __builtin_amdgcn_sched_barrier(0);
-    PFFT<32>::run(r);
-    __builtin_amdgcn_sched_barrier(0);
-    // role 1's k2 is wave-uniform (two waves per k2); its kk takes four values per wave and rides in the lane offset
-    const int k2_u = __builtin_amdgcn_readfirstlane(k21);
-    const float2* const ob = out + base + 256 * (k1 + 64 * k2_u);
-    const unsigned l_st = ((unsigned)w + ((unsigned)kk1 << 16)) * 8u;
-#pragma unroll
-    for (int rr = 0; rr < 32; ++rr) {
-        cx e = r[rr];
-        if (inv) e = cconj(e);
-        buf_st<true>(make_rsrc(ob + ((int64_t)(8 * rr) << 16)), l_st, 0, to2(e));
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -1146,7 +1176,7 @@ int ig_fft_plan(ig_ctx* ctx, int rank, const int64_t* dims, int64_t batch, ig_ff
     if (workspace_bytes) *workspace_bytes = p->workspace_bytes;
     {
         static const int use2 = getenv("INDIGO_HIP_FFT_2LAUNCH") ? atoi(getenv("INDIGO_HIP_FFT_2LAUNCH")) : 1;
-        p->two_launch = use2 && rank == 3 && dims[0] == 256 && dims[1] == 256 && dims[2] == 256 && p->axis[0].kind == 3;
+        p->two_launch = use2 > 0 && rank == 3 && dims[0] == 256 && dims[1] == 256 && dims[2] == 256 && p->axis[0].kind == 3;
     }
 
     char buf[256];
@@ -1186,7 +1216,14 @@ int ig_fft_exec(ig_fft* p, const void* xv, void* yv, int direction, void* worksp
     float2* work = (float2*)workspace;
 
     if (p->two_launch) {
-        const size_t lds_bytes = (size_t)(F3_LDS_ELEMS + 256) * sizeof(float2);
+        // two exchange images + the twiddle table: 75.7 KB per workgroup (two workgroups per CU), above the 64 KB a kernel may
+        // use without opting in
+        const size_t lds_b = (size_t)(2 * F3_LDS_ELEMS + 256) * sizeof(float2);
+        if (!ctx->fft3d_attr) {
+            IG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fft3d_a), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+            IG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fft3d_b), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+            ctx->fft3d_attr = true;
+        }
         const float2* src = (const float2*)xv;
         float2* mid = y;
         if (xv == yv) {         // launch A cannot run in place: stage through a volume set owned by the plan
@@ -1194,19 +1231,30 @@ int ig_fft_exec(ig_fft* p, const void* xv, void* yv, int direction, void* worksp
             mid = p->d_inplace;
         }
         const double half_bytes = 2.0 * (double)p->total * 8.0;        // benchmark.py:55: 4 * nbytes per transform
-        {
+        static const int dbg = getenv("INDIGO_HIP_FFT_2LAUNCH") ? atoi(getenv("INDIGO_HIP_FFT_2LAUNCH")) : 1;   // 2: launch A only, 3: launch B only (tools/fft2pass_check.py)
+        if (dbg == 3) mid = const_cast<float2*>(src);
+        if (dbg == 4) {         // volume by volume: launch B of a volume finds launch A's output in the Infinity Cache
+            for (int64_t vv = 0; vv < p->batch; ++vv) {
+                const int64_t o = vv << 24;
+                {
+                    ig_prof_scope prof(ctx, "fft3d_xy", half_bytes / (double)p->batch);
+                    hipLaunchKernelGGL(k_fft3d_a, dim3(256, 4, 1), dim3(512), lds_b, ctx->stream, src + o, mid + o, p->axis[0].d_tw, inverse);
+                }
+                {
+                    ig_prof_scope prof(ctx, "fft3d_yz", half_bytes / (double)p->batch);
+                    hipLaunchKernelGGL(k_fft3d_b, dim3(16, 64, 1), dim3(512), lds_b, ctx->stream, (const float2*)(mid + o), y + o, p->axis[0].d_tw, inverse);
+                }
+            }
+            IG_LAUNCH_CHECK(ctx, "k_fft3d (volume by volume)");
+            return IG_OK;
+        }
+        if (dbg != 3) {
             ig_prof_scope prof(ctx, "fft3d_xy", half_bytes);
-            hipLaunchKernelGGL(k_fft3d_a, dim3(256, 4, (unsigned)p->batch), dim3(512), lds_bytes, ctx->stream, src, mid, p->axis[0].d_tw, inverse);
+            hipLaunchKernelGGL(k_fft3d_a, dim3(256, 4, (unsigned)p->batch), dim3(512), lds_b, ctx->stream, src, mid, p->axis[0].d_tw, inverse);
             IG_LAUNCH_CHECK(ctx, "k_fft3d_a");
         }
-        {
+        if (dbg != 2) {
             ig_prof_scope prof(ctx, "fft3d_yz", half_bytes);
-            // (launch B keeps two exchange images: 75.7 KB per workgroup, above the 64 KB a kernel may use without opting in)
-            const size_t lds_b = (size_t)(2 * F3_LDS_ELEMS + 256) * sizeof(float2);
-            if (!ctx->fft3d_attr) {
-                IG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fft3d_b), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
-                ctx->fft3d_attr = true;
-            }
             hipLaunchKernelGGL(k_fft3d_b, dim3(16, 64, (unsigned)p->batch), dim3(512), lds_b, ctx->stream, (const float2*)mid, y, p->axis[0].d_tw, inverse);
             IG_LAUNCH_CHECK(ctx, "k_fft3d_b");
         }

@@ -60,6 +60,27 @@ def test_config2_fft_256_cubed_batch16(hip):
     del x_d, y_d
 
 
+@pytest.mark.parametrize("batch", [1, 3])
+def test_fft_256_cubed_two_launch_transform(hip, batch):
+    """256^3 volumes take the two-launch transform (x + y/64 | y/4 + z, indigo_amd/csrc/ig_fft.hip k_fft3d_a/_b): forward and
+    inverse, out of place and in place (launch A cannot run in place: the plan stages through its own buffer), vs numpy"""
+    n = 256
+    x = (rand64c(n, n, n, batch, seed=7) - np.complex64(0.5 + 0.5j)).astype(C64)
+    assert "two launches" in hip.fft_describe(x.shape)
+    x_d = hip.copy_array(x)
+    y_d = hip.zero_array(x.shape, C64)
+    hip.fftn(y_d, x_d)
+    np.testing.assert_array_equal(x_d[:, :, :, 0:1].to_host(), x[..., 0:1])        # the input is left alone
+    for j in range(batch):
+        assert rel_err(y_d[:, :, :, j:j + 1].to_host()[..., 0], np.fft.fftn(x[..., j].astype(np.complex128))) < RTOL
+    hip.ifftn(y_d, y_d)                                                            # in place, inverse: n^3 * x
+    assert rel_err(y_d.to_host() / n ** 3, x) < RTOL
+    hip.ifftn(y_d, x_d)                                                            # out of place, inverse
+    assert rel_err(y_d[:, :, :, 0:1].to_host()[..., 0], np.fft.ifftn(x[..., 0].astype(np.complex128)) * n ** 3) < RTOL
+    hip.fftn(x_d, x_d)                                                             # in place, forward
+    assert rel_err(x_d[:, :, :, batch - 1:batch].to_host()[..., 0], np.fft.fftn(x[..., batch - 1].astype(np.complex128))) < RTOL
+
+
 # ---------------------------------------------------------------------------------------
 # config 3: 3-D radial gridding CSR (T x 256^3, 27 taps per row, 5e7 nonzeros) x 64-column panel
 # ---------------------------------------------------------------------------------------

@@ -95,35 +95,38 @@ def pass_a(vol, z, n2, report):
 
 
 def pass_b(mid, xs, k1, report):
-    """y: second stage (radix 4 over n2); z: full 256-point transform.  mid[x][y'][z] holds pass A's output."""
+    """y: second stage (radix 4 over n2, two of the four rows per thread, the other two in the neighbouring lane);
+    z: full 256-point transform (16 x 16).  mid[x][y'][z] holds pass A's output."""
     tid = np.arange(512)
-    w, t = tid & 15, tid >> 4
-    v = np.empty((512, 8, 4), complex)                              # [k][n2]: z = t + 32 k
-    for k in range(8):
-        for n2 in range(4):
-            v[:, k, n2] = mid[xs + w, k1 + 64 * n2, t + 32 * k]
-    y = dft(v, 2)                                                   # radix 4 over n2 -> k2
-    u = dft(y, 1)                                                   # z1: radix 8 over k -> kk
-    kk = np.arange(8)
+    h, w, t = tid & 1, (tid >> 1) & 15, tid >> 5
+    v = np.empty((512, 16, 2), complex)                             # [k][m]: z = t + 16 k, row n2 = h + 2 m
+    for k in range(16):
+        for m in range(2):
+            v[:, k, m] = mid[xs + w, k1 + 64 * (h + 2 * m), t + 16 * k]
+    a = np.stack([v[:, :, 0] + v[:, :, 1], v[:, :, 0] - v[:, :, 1]], axis=2)       # over m -> q
+    a[h == 1, :, 1] *= -1j                                          # w4^(h q)
+    partner = a[tid ^ 1]                                            # quad_perm [1,0,3,2]
+    y = np.where((h == 0)[:, None, None], a + partner, partner - a)  # k2 = q + 2 h
+    u = dft(y, 1)                                                   # z1: radix 16 over k -> kk
+    kk = np.arange(16)
     u *= W[(t[:, None] * kk[None, :]) & 255][:, :, None]            # w256^(t kk)
-    # E (rounds over k2): addr = t*144 + kk*16 + w ; reader role 1: w, kk' = (tid>>4)&7, k2' = tid>>7 reads t = 0..31 in round k2'
-    kk1, k21 = (tid >> 4) & 7, tid >> 7
-    r = np.empty((512, 32), complex)
-    for rnd in range(4):
-        lds = np.full(32 * 144, np.nan, complex)
-        for k in range(8):
-            ad = t * 144 + k * 16 + w
-            report('B.E write', ad)
-            lds[ad] = u[:, k, rnd]
-        sel = k21 == rnd
-        for tt in range(32):
-            ad = tt * 144 + kk1 * 16 + w
-            report('B.E read', ad[sel])
-            r[sel, tt] = lds[ad[sel]]
-    o = dft(r, 1)                                                   # z2: radix 32 over t -> rr ; kz = kk + 8 rr
+    # exchange (rounds over q): addr = t*544 + kk*32 + h*16 + w ; reader role 1 (w, h, kk' = tid>>5) takes t = 0..15
+    kk1 = tid >> 5
     out = np.empty((16, 4, 256), complex)                           # [w][k2][kz]
-    for rr in range(32):
-        out[w, k21, kk1 + 8 * rr] = o[:, rr]
+    for q in range(2):
+        lds = np.full(16 * 544, np.nan, complex)
+        for k in range(16):
+            ad = t * 544 + k * 32 + h * 16 + w
+            report('B.E write', ad)
+            lds[ad] = u[:, k, q]
+        r = np.empty((512, 16), complex)
+        for tt in range(16):
+            ad = tt * 544 + kk1 * 32 + h * 16 + w
+            report('B.E read', ad)
+            r[:, tt] = lds[ad]
+        o = dft(r, 1)                                               # z2: radix 16 over t -> rr ; kz = kk + 16 rr
+        for rr in range(16):
+            out[w, q + 2 * h, kk1 + 16 * rr] = o[:, rr]
     return out
 
 
