@@ -895,12 +895,21 @@ int launch_gather(ig_ctx* ctx, int64_t rows, int64_t xrows, int64_t N, int64_t n
     if (!x_il && ((N >= 2 && N <= 64 && nnz >= xrows) || (xperm && N <= 8)) && env_flag("INDIGO_HIP_SPMM_PACK", true)) {
         const int np = s.CL;             // pow2 >= N, <= 64
         const size_t need = (size_t)xrows * np * 8;
-        if (need <= ((size_t)16 << 30)) {
-            if (ctx->xpack_bytes < need) {
+        // The repack buffer is a per-context scratch that only grows (reported by ig_mem_info, not by the caller's own
+        // accounting): take it only while it is at most a quarter of the free device memory, otherwise -- or if the
+        // allocation fails -- run the product unpacked (slower, same result).
+        bool can_pack = need > 0 && need <= ((size_t)16 << 30);
+        if (can_pack && ctx->xpack_bytes < need) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+            if (need > (free_b + ctx->xpack_bytes) / 4) can_pack = false;
+            else {
                 if (ctx->d_xpack) { IG_HIP(ctx, hipStreamSynchronize(ctx->stream)); IG_HIP(ctx, hipFree(ctx->d_xpack)); ctx->d_xpack = nullptr; ctx->xpack_bytes = 0; }
-                IG_HIP(ctx, hipMalloc((void**)&ctx->d_xpack, need));
-                ctx->xpack_bytes = need;
+                if (hipMalloc((void**)&ctx->d_xpack, need) != hipSuccess) { (void)hipGetLastError(); ctx->d_xpack = nullptr; can_pack = false; }
+                else ctx->xpack_bytes = need;
             }
+        }
+        if (can_pack) {
             ig_prof_scope prof(ctx, "pack_panel", (double)xrows * N * 8.0 + (double)need);
             int64_t g = (xrows * np + BLK - 1) / BLK;
             const int64_t cap = (int64_t)ctx->num_cu * 16;
@@ -921,7 +930,7 @@ int launch_gather(ig_ctx* ctx, int64_t rows, int64_t xrows, int64_t N, int64_t n
             X = xp; sxc = 1; sxr = np; packed = true;
         }
     }
-    IG_REQUIRE(ctx, !xperm || packed, "csrmm: a panel-row permutation needs the packed path (N <= 8, panel <= 1 GiB)");
+    IG_REQUIRE(ctx, !xperm || packed, "csrmm: a panel-row permutation needs the packed path (N <= 8 and room for the repacked panel: a quarter of the free device memory, at most 16 GiB)");
     const int rpw = 64 / (s.CL * s.NL);
     const int64_t waves = (rows + rpw - 1) / rpw;
     const int64_t blocks = (waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;

@@ -61,48 +61,93 @@ def _rendezvous_path():
     return os.path.join(tempfile.gettempdir(), "indigo_rccl_id_%s" % key)
 
 
+def exchange_id(rank, world, make_id, path, nbytes=128, timeout=60.0):
+    """File rendezvous of one launch on one node: rank 0 publishes `make_id()` (nbytes), every other rank reads and
+    acknowledges it, rank 0 waits for all acknowledgements and publishes "go".  Returns the id on every rank.
+
+    The handshake completes BEFORE anyone enters the collective bring-up, so that a rendezvous problem (ranks that are
+    not siblings, an unwritable temp directory) makes EVERY rank raise within `timeout` -- and fall back together --
+    instead of leaving some ranks inside ncclCommInitRank forever."""
+    def wait_for(fn, what):
+        t0 = time.time()
+        while True:
+            v = fn()
+            if v is not None:
+                return v
+            if time.time() - t0 > timeout:
+                raise RuntimeError("rendezvous: rank %d timed out after %.0f s waiting for %s (%s)" % (rank, timeout, what, path))
+            time.sleep(0.02)
+
+    def read(p, n=None):
+        try:
+            with open(p, "rb") as f:
+                raw = f.read()
+            return raw if (n is None or len(raw) == n) else None
+        except OSError:
+            return None
+
+    def publish(p, raw):
+        tmp = "%s.%d.tmp" % (p, os.getpid())
+        with open(tmp, "wb") as f:
+            f.write(raw)
+        os.replace(tmp, p)                                       # atomic: readers never see a partial file
+
+    if rank == 0:
+        raw = make_id()
+        assert len(raw) == nbytes
+        if world > 1:
+            publish(path, raw)
+            for r in range(1, world):
+                wait_for(lambda r=r: read("%s.ack%d" % (path, r)), "the acknowledgement of rank %d" % r)
+            publish(path + ".go", b"go")
+        return raw
+    raw = wait_for(lambda: read(path, nbytes), "the communicator id of rank 0")
+    publish("%s.ack%d" % (path, rank), b"ack")
+    wait_for(lambda: read(path + ".go"), "rank 0's go-ahead")
+    return raw
+
+
+def cleanup_rendezvous(rank, world, path, timeout=10.0):
+    """remove the rendezvous files: every other rank removes its acknowledgement once it has the go-ahead; rank 0 removes
+    the id and the go-ahead once all acknowledgements are gone (so nobody is still looking for them)"""
+    def rm(p):
+        try:
+            os.remove(p)
+        except OSError:
+            pass
+    if rank != 0:
+        rm("%s.ack%d" % (path, rank))
+        return
+    t0 = time.time()
+    while any(os.path.exists("%s.ack%d" % (path, r)) for r in range(1, world)) and time.time() - t0 < timeout:
+        time.sleep(0.02)
+    rm(path)
+    rm(path + ".go")
+
+
 class RcclComm(object):
     """Sum all-reduce of a HipBackend array across the ranks through the library's RCCL binding (ig_comm_*)."""
 
-    def __init__(self, backend, rank, world, timeout=120.0):
+    def __init__(self, backend, rank, world, timeout=60.0):
         from indigo_amd import _lib
         self._backend, self.rank, self.world = backend, int(rank), int(world)
         self._L = backend._L
         nbytes = 128
-        idbuf = ctypes.create_string_buffer(nbytes)
         path = _rendezvous_path() if world > 1 else None
-        if rank == 0:
-            _lib.check(self._L.ig_comm_unique_id(idbuf), None, "ig_comm_unique_id")
-            if path:
-                tmp = "%s.%d.tmp" % (path, os.getpid())
-                with open(tmp, "wb") as f:
-                    f.write(idbuf.raw)
-                os.replace(tmp, path)                                # atomic: readers never see a partial id
-        else:
-            t0 = time.time()
-            while True:
-                try:
-                    with open(path, "rb") as f:
-                        raw = f.read()
-                    if len(raw) == nbytes:
-                        break
-                except OSError:
-                    pass
-                if time.time() - t0 > timeout:
-                    raise RuntimeError("RcclComm: rank %d found no communicator id at %s after %.0f s" % (rank, path, timeout))
-                time.sleep(0.02)
-            idbuf = ctypes.create_string_buffer(raw, nbytes)
+
+        def make_id():
+            buf = ctypes.create_string_buffer(nbytes)
+            _lib.check(self._L.ig_comm_unique_id(buf), None, "ig_comm_unique_id")
+            return buf.raw
+        idbuf = ctypes.create_string_buffer(exchange_id(self.rank, self.world, make_id, path, nbytes, timeout), nbytes)
         comm = ctypes.c_void_p()
         backend._check(self._L.ig_comm_init_rank(backend._ctx, self.world, self.rank, idbuf, ctypes.byref(comm)), "ig_comm_init_rank")
         self._comm = comm
         self.overlap = os.environ.get("INDIGO_COMM_OVERLAP", "1") != "0"
         self._pending = False
-        self.barrier()                                               # every rank has read the id
-        if rank == 0 and path:
-            try:
-                os.remove(path)
-            except OSError:
-                pass
+        self.barrier()                                               # every rank is through the bring-up
+        if path:
+            cleanup_rendezvous(self.rank, self.world, path)
 
     def describe(self):
         buf = ctypes.create_string_buffer(256)

@@ -94,3 +94,36 @@ def test_sharded_normal_operator_two_ranks(tmp_path):
     assert rel_err(r0["y"], g["sense_AHAx"]) < 1e-5
     np.testing.assert_array_equal(r0["cg"], r1["cg"])
     assert rel_err(r0["cg"], g["cg_it3"]) < 1e-4
+
+
+def _rendezvous_worker(rank, world, path, q):
+    from indigo_amd.dist import cleanup_rendezvous, exchange_id
+    try:
+        raw = exchange_id(rank, world, lambda: bytes(range(128)), path, 128, timeout=20.0)
+        q.put((rank, raw))
+        cleanup_rendezvous(rank, world, path)
+    except Exception as e:          # noqa: BLE001
+        q.put((rank, repr(e)))
+
+
+def test_rccl_id_rendezvous_handshake(tmp_path):
+    """the out-of-band channel of the C-ABI communicator (indigo_amd.dist.exchange_id): three sibling processes agree on
+    rank 0's id; a rank whose peers never show up raises within the timeout instead of entering the collective"""
+    import multiprocessing as mp
+    from indigo_amd.dist import exchange_id
+    ctx = mp.get_context("spawn")
+    path = str(tmp_path / "id")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rendezvous_worker, args=(r, 3, path, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=60) for _ in procs)
+    for p in procs:
+        p.join(30)
+    assert got == {0: bytes(range(128)), 1: bytes(range(128)), 2: bytes(range(128))}
+    assert not any(f.name.startswith("id") for f in tmp_path.iterdir()), "rendezvous files are cleaned up"
+    import pytest
+    with pytest.raises(RuntimeError, match="timed out"):
+        exchange_id(1, 2, None, str(tmp_path / "nobody"), 128, timeout=0.3)
+    with pytest.raises(RuntimeError, match="timed out"):
+        exchange_id(0, 2, lambda: bytes(128), str(tmp_path / "alone"), 128, timeout=0.3)
