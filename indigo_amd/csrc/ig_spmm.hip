@@ -36,6 +36,9 @@ namespace {
 
 constexpr int BLK = 256;
 constexpr int WAVES_PER_BLOCK = BLK / 64;
+#ifndef IG_DENSE_MINWAVES
+#define IG_DENSE_MINWAVES 1
+#endif
 
 // Blocks are dealt round-robin to the 8 XCDs (each with a private L2).  Give
 // each XCD a contiguous range of row blocks so neighbouring rows -- which in
@@ -385,7 +388,8 @@ k_csrmm_rowlane(int64_t M, int64_t N,
 // row's lane sums its own run of products (LDS reads, no atomics) and stores as before, 512 contiguous bytes per
 // panel column.  Rows beyond thr_mid go to the deferred-row lists and are skipped here.
 template <int NC, bool CONJ, bool YIL>
-__global__ void __launch_bounds__(BLK)            // (capping it at 64 VGPRs for 8 waves/SIMD spills into scratch: 2x slower)
+__global__ void __launch_bounds__(BLK, IG_DENSE_MINWAVES)     // (74 VGPRs, 6 waves/SIMD.  Measured: a 72-VGPR cap for 7 waves is 4 % SLOWER
+                                                              // (1.68 vs 1.61 ms), a 64-VGPR cap for 8 waves spills and takes 2.69 ms: not occupancy bound)
 k_csrmm_dense64(int64_t M, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
                 const float2* __restrict__ vals, const float2* __restrict__ Xp,
                 float2* __restrict__ Y, int64_t ldy, float2 alpha,
