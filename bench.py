@@ -659,6 +659,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus or world == 1, "--gpus must match WORLD_SIZE"
+    if world > 1 and args.comm != "rccl":
+        # The collective is the library's own RCCL binding (ig_comm_*).  Under `--comm auto` torch is imported FIRST --
+        # before libindigo_hip.so loads -- only so that the fallback to torch.distributed stays possible: torch ships its own
+        # HIP runtime and RCCL, and whichever copy is loaded first must serve both (the library then reuses torch's copies).
+        # `--comm rccl` runs without torch in the process (tests/test_hip_dist.py proves that path).
+        os.environ["INDIGO_HIP_WITH_TORCH"] = "1"
+        import torch                                     # noqa: F401
     if world > 1 and os.environ.get("INDIGO_BENCH_DIST_BACKEND", "nccl") == "nccl":
         from indigo_amd import _lib
         import ctypes
