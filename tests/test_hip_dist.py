@@ -66,7 +66,13 @@ RCCL_WORKER = r"""
 import os, sys
 sys.path.insert(0, os.environ["REPO_ROOT"])
 import numpy as np
-assert "torch" not in sys.modules
+if os.environ.get("TORCH_FIRST") == "1":
+    # bench.py --comm auto: torch (with its own HIP runtime and RCCL copies) is in the process before the library loads;
+    # ig_comm_* must then find and reuse the RCCL copy that is already there
+    os.environ["INDIGO_HIP_WITH_TORCH"] = "1"
+    import torch
+else:
+    assert "torch" not in sys.modules
 from indigo_amd.backends import get_backend
 from indigo_amd.dist import RcclComm, ShardedNormalOperator
 from indigo_amd.sense import SenseProblem, normal_operator
@@ -111,9 +117,12 @@ print("OK")
 """
 
 
-def test_rccl_communicator_through_the_c_abi():
-    env = dict(os.environ, REPO_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+@pytest.mark.parametrize("torch_first", ["0", "1"])
+def test_rccl_communicator_through_the_c_abi(torch_first):
+    env = dict(os.environ, REPO_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", TORCH_FIRST=torch_first)
     env.pop("INDIGO_HIP_WITH_TORCH", None)
     r = subprocess.run([sys.executable, "-c", RCCL_WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                        text=True, timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-4000:]
+    if torch_first == "1":
+        assert "already loaded" in r.stdout, r.stdout[-2000:]          # the library reused torch's RCCL, it did not load a second one
