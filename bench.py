@@ -80,7 +80,8 @@ def kernel_symbols(layout, ncoils, half_box=True, n=512):
                       "fft_pad_y": f % "32, false, 0, true, 0", "fft_pad_z": f % "16, false, 0, true, 0",
                       "fft_crop_z": f % "16, false, 0, true, 0", "fft_crop_y": f % "32, false, 0, true, 0",
                       "fft_crop_x": f % ("16, false, %d, true, 0" % (3 + lg))})
-        m.update({"csrmm_rowlane_conj": "k_csrmm_dense64<%d, true, true>" % ncoils, "csrmm_gather": gv})
+        m.update({"csrmm_rowlane_conj": "k_csrmm_dense64<%d, true, true>" % ncoils, "csrmm_gather": gv,
+                  "csrmm_bricks_conj": "k_grid_bricks<%d>" % ncoils})
     elif layout == 1:
         h = (3, 1, 1, 2, 2, 4) if half_box else (0,) * 6
         m.update({"fft_pad_x": f % ("16, true, 1, true, %d" % h[0]), "fft_pad_y": f % ("16, false, 0, true, %d" % h[1]),
@@ -327,7 +328,7 @@ def run_sense(args, cfg, B, comm, world, rank, steps, warmup, want_cpu, quiet=Fa
                 prof[name]['ref_bytes'] = 4.0 * np.prod(p.oN) * 8.0 * cpr / 3.0 * prof[name]['launches']
     csr = {(r['name'], r['forward']): r['nbytes'] for r in trace.records if r['event'] == 'csrmm' and not r.get('fused')}
     grid_bytes = p.gridding_pass_bytes(cpr, getattr(p, 'last_support_table', None)) if fused_fft else {}
-    for site, fwd in (("csrmm_gather", True), ("csrmm_rowlane_conj", False), ("csrmm_gather_conj", False)):
+    for site, fwd in (("csrmm_gather", True), ("csrmm_rowlane_conj", False), ("csrmm_gather_conj", False), ("csrmm_bricks_conj", False)):
         nb = csr.get(('interp*mod*scale', fwd))
         if site in prof and nb:
             # SpMM GB/s two ways: the reference's model (operators.py:246-256) and the bytes this kernel must move

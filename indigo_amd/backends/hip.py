@@ -585,6 +585,49 @@ class HipBackend(Backend):
             self._support = (self._backend.copy_array(np.ascontiguousarray(table, dtype=np.int16).reshape(-1),
                                                       name=self._name + ".support"), int(n0), int(nm))
 
+        def set_grid_bricks(self, n0, nm, ns, ncols=8, bm=2, bs=2, chunk=4096):
+            """Sort the nonzeros by the 16 x bm x bs brick of the n0 x nm x ns grid their column falls into (native host
+            routine), padded so that a wave instruction (64/ncols entries x ncols panel columns) holds entries of one row
+            only, and keep entries + task list on the device: the adjoint of an `ncols`-column interleaved panel then
+            scatters brick by brick through LDS (ig_ccsrmm_t_bricks) and needs neither the transposed matrix nor its
+            4-bytes-per-grid-point row pointers.  `chunk`: most entries one wave takes; bricks with more are shared."""
+            b = self._backend
+            A = self._host_csr
+            import os
+            if os.environ.get("INDIGO_HIP_BRICK_SHAPE"):          # "bm,bs,chunk": tuning aid
+                bm, bs, chunk = (int(v) for v in os.environ["INDIGO_HIP_BRICK_SHAPE"].split(","))
+            assert A is not None and A.shape[1] == n0 * nm * ns and ncols in (4, 8)
+            unit = 64 // ncols
+            chunk = max(unit, chunk // unit * unit)
+            indptr = np.ascontiguousarray(A.indptr, dtype=np.int32)
+            indices = np.ascontiguousarray(A.indices, dtype=np.int32)
+            data = np.ascontiguousarray(A.data, dtype=_C64)
+            nb = (n0 // 16) * (nm // bm) * (ns // bs)
+            counts = np.zeros(nb, dtype=np.int32)
+            _lib.check(b._L.ig_grid_bricks_count(A.shape[0], indptr.ctypes.data, indices.ctypes.data, n0, nm, ns, bm, bs, unit,
+                                                 counts.ctypes.data), None, "ig_grid_bricks_count")
+            ptr = np.zeros(nb + 1, dtype=np.int64)
+            np.cumsum(counts, out=ptr[1:])
+            entries = np.empty((max(int(ptr[-1]), 1), 4), dtype=np.uint32)
+            _lib.check(b._L.ig_grid_bricks_fill(A.shape[0], indptr.ctypes.data, indices.ctypes.data, data.ctypes.data, n0, nm, ns,
+                                                bm, bs, unit, ptr.ctypes.data, entries.ctypes.data), None, "ig_grid_bricks_fill")
+            # tasks: (brick, lo, hi, shared); entry ranges longer than `chunk` are cut, their bricks marked shared
+            bricks = np.flatnonzero(counts)
+            ntask = (counts[bricks] + chunk - 1) // chunk
+            rep = np.repeat(np.arange(bricks.size), ntask)
+            first = np.concatenate(([0], np.cumsum(ntask)[:-1])) if bricks.size else np.zeros(0, np.int64)
+            part = np.arange(rep.size) - first[rep]
+            lo = ptr[bricks][rep] + part * chunk
+            hi = np.minimum(lo + chunk, ptr[bricks + 1][rep])
+            tasks = np.stack([bricks[rep], lo, hi, (ntask[rep] > 1)], axis=1).astype(np.int32) if rep.size else np.zeros((0, 4), np.int32)
+            tasks = np.ascontiguousarray(tasks[np.argsort(-(tasks[:, 2] - tasks[:, 1]), kind='stable')])     # long tasks first
+            shared = bricks[ntask > 1].astype(np.int32)
+            self._bricks = dict(n0=int(n0), nm=int(nm), bm=int(bm), bs=int(bs), ncols=int(ncols), ntasks=int(tasks.shape[0]),
+                                nshared=int(shared.size), nentries=int(ptr[-1]),
+                                tasks=b.copy_array(tasks.reshape(-1) if tasks.size else np.zeros(4, np.int32), name=self._name + ".brickTasks"),
+                                entries=b.copy_array(entries.reshape(-1), name=self._name + ".brickEntries"),
+                                shared=b.copy_array(shared if shared.size else np.zeros(1, np.int32), name=self._name + ".sharedBricks"))
+
         def set_row_order(self, perm):
             """Store the matrix with its rows in the order `perm` (stored row r = row perm[r] of A), e.g. gridding
             samples sorted by the grid cell they touch: neighbouring rows then gather neighbouring panel rows.
@@ -635,6 +678,21 @@ class HipBackend(Backend):
             b = self._backend
             sup = getattr(self, '_support', None)
             perm = getattr(self, '_perm', None)
+            br = getattr(self, '_bricks', None)
+            if (br is not None and perm is None and beta == 0 and y.contiguous and getattr(self, '_grid_il', False)
+                    and x.shape[1] == br['ncols']):
+                tab = sup[0] if sup is not None else None
+                if tab is None:
+                    y._zero()           # without a support table every row is defined: bricks no sample touches stay zero
+                ar, ai = _cplx(alpha)
+                m, k = self.shape
+                b._check(b._L.ig_ccsrmm_t_bricks(b._ctx, m, k, x.shape[1], ar, ai,
+                                                 ctypes.c_void_p(br['entries']._arr), ctypes.c_void_p(x._arr), x._leading_dim,
+                                                 ctypes.c_void_p(y._arr), ctypes.c_void_p(tab._arr) if tab is not None else None,
+                                                 br['n0'], br['nm'], br['bm'], br['bs'], ctypes.c_void_p(br['tasks']._arr), br['ntasks'],
+                                                 ctypes.c_void_p(br['shared']._arr), br['nshared']),
+                         "ig_ccsrmm_t_bricks")
+                return
             if getattr(self, '_grid_il', False):
                 assert perm is None and beta == 0 and y.contiguous, "interleaved panels: no row order, beta = 0"
                 pt, it, dt = self._transposed()

@@ -30,6 +30,7 @@ struct ig_ctx {
     void*        d_xpack     = nullptr;   // SpMM repacked-panel scratch (grown on demand)
     size_t       xpack_bytes = 0;
     int32_t*     d_worklist  = nullptr;   // SpMM deferred-row lists + counters (allocated on first use)
+    bool         bricks_attr = false;     // the brick-binned gridding kernel's dynamic-LDS opt-in was applied on this device
     bool         fft3d_attr = false;      // the two-launch 256^3 transform's dynamic-LDS opt-in was applied on this device
     bool         fft_w32_attr = false;    // the 32-column FFT kernels' dynamic-LDS opt-in was applied on this device
     // profile mode (ig_prof_enable): every kernel launch is bracketed by two events

@@ -841,6 +841,120 @@ k_pack_panel_tiled(int64_t rows, int64_t N, const float2* __restrict__ X, int64_
     }
 }
 
+// ---- brick-binned adjoint gridding ------------------------------------------------------------------------------
+// Y_il = alpha * G^H X for a gridding matrix G (rows = k-space samples, ~27 taps each, columns = grid points numbered
+// kx + n0*(km + nm*ks)) -- the SCATTER view, made race-free by binning.  The grid is cut into bricks of 16 x BM x BS cells.
+// On the host the nonzeros are sorted by the brick of their column (stable: inside a brick they stay in sample order)
+// into 16-byte entries {sample, cell inside the brick, value}; the entries one sample has in one brick are padded to a
+// multiple of 64/NC, so that ONE wave instruction -- 64/NC entries x NC coils -- only ever holds entries of one sample,
+// i.e. distinct cells.  ONE WAVE owns a brick: it streams the brick's entries (coalesced, no pointer chasing), gathers
+// X[sample, :] and accumulates conj(value) * X into its own LDS image of the brick with plain read-add-write (no other wave
+// touches that image, no two lanes of an instruction share a cell, LDS operations of a wave execute in order), then
+// stores the flagged 16-row segments with coalesced 16-byte stores.  Bricks near the k-space centre hold 10^4..10^5
+// nonzeros: their entry ranges are cut into tasks, each task adds its image into the (pre-zeroed) grid with float atomics.
+//
+// Against the gather over the transpose (k_csrmm_dense64): no 134-M-entry row-pointer array, no per-row segmented sums,
+// no deferred long rows.  Two versions were measured on the way: per-brick SAMPLE lists walked through
+// pairs -> rowptr -> colind/vals (6.7 ms: dependent loads at 8 waves per CU), and a workgroup per brick with LDS float
+// atomics (5.4 ms: ds_add_f32 retires about one lane every four clocks -- 800 M lane-atomics per evaluation).
+struct BrickTask { int32_t brick, lo, hi, shared; };      // entries [lo, hi); shared != 0: several tasks add into this brick
+struct BrickEntry { uint32_t row, cell; float re, im; };  // 16 bytes; cell == 0xffffffff: padding
+
+template <int NC>
+__global__ void __launch_bounds__(BLK)
+k_grid_bricks(const BrickTask* __restrict__ tasks, int ntasks, const BrickEntry* __restrict__ entries,
+              const float2* __restrict__ Xp /* packed rows: [t][NC] */, float2* __restrict__ Y, float2 alpha,
+              const uint32_t* __restrict__ bits, int n0, int nm, int bm_log2, int bs_log2, int nbx, int nbm, int dbg) {
+    extern __shared__ float2 acc_all[];                  // per wave: [cells][NC]
+    constexpr int TPR = 64 / NC;                         // entries per wave instruction
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int task = blockIdx.x * WAVES_PER_BLOCK + wv;
+    if (task >= ntasks) return;                          // (no workgroup barrier below: waves are independent)
+    const BrickTask tk = tasks[task];
+    const int BM = 1 << bm_log2, nseg = 1 << (bm_log2 + bs_log2), ncell = 16 * nseg;
+    float2* __restrict__ acc = acc_all + (size_t)wv * ncell * NC;
+    const int bx = tk.brick % nbx, bmi = (tk.brick / nbx) % nbm, bsi = tk.brick / (nbx * nbm);
+    const int x0 = bx * 16, m0 = bmi << bm_log2, s0 = bsi << bs_log2;
+    for (int e = lane; e < ncell * NC; e += 64) acc[e] = make_float2(0.f, 0.f);
+    const int coil = lane % NC, tsub = lane / NC;
+    // which of the brick's segments are flagged: one bitmap word per lane (segment = lane), in flight with the first entries
+    const int nt = n0 >> 4;
+    uint64_t live_mask = ~0ull;
+    if (bits) {
+        bool lv = false;
+        if (lane < nseg) {
+            const int km = m0 + (lane & (BM - 1)), ks = s0 + (lane >> bm_log2);
+            lv = (bits[((size_t)ks * nt + bx) * 16 + (km & 15)] >> (km >> 4)) & 1u;
+        }
+        live_mask = __ballot(lv);
+    }
+    // Buffer-descriptor loads: the descriptor sits at the task's first entry (offsets stay small whatever the matrix size),
+    // lanes past the end of the task get an out-of-range offset -- no branch, no wait between the loads of a trip.
+    const rsrc_t r_en = make_rsrc(entries + tk.lo), r_x = make_rsrc(Xp);
+    const int32_t nent = tk.hi - tk.lo;
+    for (int32_t base = 0; base < ((dbg & 1) ? 0 : nent); base += 64) {
+        float4 en[NC];
+        float2 xv[NC];
+#pragma unroll
+        for (int r = 0; r < NC; ++r) {
+            const int32_t idx = base + r * TPR + tsub;
+            en[r] = buf_ld_f4(r_en, idx < nent ? (unsigned)idx * 16u : IG_OOB);
+        }
+#pragma unroll
+        for (int r = 0; r < NC; ++r) {
+            const bool ok = base + r * TPR + tsub < nent && __float_as_uint(en[r].y) != 0xffffffffu;
+            xv[r] = buf_ld<false>(r_x, ok ? (__float_as_uint(en[r].x) * (unsigned)NC + (unsigned)coil) * 8u : IG_OOB, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < NC; ++r) {
+            const bool ok = base + r * TPR + tsub < nent && __float_as_uint(en[r].y) != 0xffffffffu;
+            if (ok) {
+                const float vr = en[r].z, vi = en[r].w;
+                float2* a = acc + (int)__float_as_uint(en[r].y) * NC + coil;
+                float2 t = *a;                                        // plain read-add-write: this instruction's entries belong
+                t.x += fmaf(vr, xv[r].x, vi * xv[r].y);               // to one sample (distinct cells), and the image is this wave's
+                t.y += fmaf(vr, xv[r].y, -vi * xv[r].x);              // conj(v) * x
+                *a = t;              // (successive rounds may hit the same cell: the compiler keeps may-alias LDS accesses in order)
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // write the flagged 16-row segments: segment (im, is) = 16 cells x NC coils = NC*128 bytes
+    for (int seg = 0; seg < nseg; ++seg) {
+        const int im = seg & (BM - 1), is = seg >> bm_log2;
+        const int km = m0 + im, ks = s0 + is;
+        if (!((live_mask >> seg) & 1ull) || (dbg & 2)) continue;
+        const float2* src = acc + (size_t)16 * seg * NC;
+        float2* dst = Y + ((int64_t)x0 + (int64_t)n0 * (km + (int64_t)nm * ks)) * NC;
+        for (int e = lane; e < 16 * NC; e += 64) {
+            const float2 o = cmul(alpha, src[e]);
+            if (tk.shared) { unsafeAtomicAdd(&dst[e].x, o.x); unsafeAtomicAdd(&dst[e].y, o.y); }
+            else dst[e] = o;
+        }
+    }
+}
+
+// zero the flagged segments of the bricks that several tasks add into
+template <int NC>
+__global__ void __launch_bounds__(BLK)
+k_grid_bricks_zero(const int32_t* __restrict__ shared_bricks, float2* __restrict__ Y, const uint32_t* __restrict__ bits,
+                   int n0, int nm, int bm_log2, int bs_log2, int nbx, int nbm) {
+    const int brick = shared_bricks[blockIdx.x];
+    const int BM = 1 << bm_log2, nseg = 1 << (bm_log2 + bs_log2);
+    const int bx = brick % nbx, bmi = (brick / nbx) % nbm, bsi = brick / (nbx * nbm);
+    const int x0 = bx * 16, m0 = bmi << bm_log2, s0 = bsi << bs_log2;
+    const int nt = n0 >> 4, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int seg = wv; seg < nseg; seg += WAVES_PER_BLOCK) {
+        const int im = seg & (BM - 1), is = seg >> bm_log2;
+        const int km = m0 + im, ks = s0 + is;
+        if (bits && !((bits[((size_t)ks * nt + bx) * 16 + (km & 15)] >> (km >> 4)) & 1u)) continue;
+        float2* dst = Y + ((int64_t)x0 + (int64_t)n0 * (km + (int64_t)nm * ks)) * NC;
+        for (int e = lane; e < 16 * NC; e += 64) dst[e] = make_float2(0.f, 0.f);
+    }
+}
+
 inline int pow2_ceil(int64_t v, int cap) {
     int p = 1;
     while (p < v && p < cap) p <<= 1;
@@ -1282,6 +1396,145 @@ int ig_ccsrmm_t_grid_il(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, int64_t nn
     return launch_gather<true>(ctx, K, M, N, nnz, rowptr_t, colind_t, (const float2*)vals_t,
                                (const float2*)X, ldx, (float2*)Y_il, K, make_float2(ar, ai), make_float2(0.f, 0.f),
                                mask, nullptr, nullptr, false, true);
+}
+
+namespace {
+inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+inline bool bricks_ok(int64_t n0, int64_t nm, int64_t ns, int bm, int bs, int unit) {
+    return n0 > 0 && nm > 0 && ns > 0 && pow2(bm) && pow2(bs) && bm * bs <= 64 && n0 % 16 == 0 && nm % bm == 0 && ns % bs == 0 &&
+           pow2(unit) && unit <= 64;
+}
+// the bricks one row touches and how many of its nonzeros fall into each (a row touches few bricks: linear search)
+struct RowBricks {
+    int64_t id[64]; int32_t cnt[64]; int n = 0;
+    bool add(int64_t b) {
+        for (int q = 0; q < n; ++q) if (id[q] == b) { ++cnt[q]; return true; }
+        if (n == 64) return false;
+        id[n] = b; cnt[n] = 1; ++n;
+        return true;
+    }
+};
+}  // namespace
+
+int ig_grid_bricks_count(int64_t M, const int32_t* rowptr, const int32_t* colind, int64_t n0, int64_t nm, int64_t ns,
+                         int bm, int bs, int unit, int32_t* brick_entries /* (n0/16)*(nm/bm)*(ns/bs), zero-initialised by this call */) {
+    if (M < 0 || !rowptr || !brick_entries || !bricks_ok(n0, nm, ns, bm, bs, unit))
+        return ig_fail(nullptr, IG_ERR_ARG, "ig_grid_bricks_count: the grid must divide into 16 x bm x bs bricks (powers of two, bm*bs <= 64), unit a power of two <= 64");
+    const int64_t nbx = n0 / 16, nbm = nm / bm, nbs = ns / bs, P = n0 * nm * ns;
+    std::memset(brick_entries, 0, sizeof(int32_t) * (size_t)(nbx * nbm * nbs));
+    for (int64_t t = 0; t < M; ++t) {
+        RowBricks rb;
+        for (int32_t p = rowptr[t]; p < rowptr[t + 1]; ++p) {
+            const int64_t col = colind[p];
+            if (col < 0 || col >= P) return ig_fail(nullptr, IG_ERR_ARG, "ig_grid_bricks_count: column index outside the grid");
+            const int64_t kx = col % n0, km = (col / n0) % nm, ks = col / (n0 * nm);
+            if (!rb.add(kx / 16 + nbx * (km / bm + nbm * (ks / bs))))
+                return ig_fail(nullptr, IG_ERR_UNSUPPORTED, "ig_grid_bricks_count: a row touches more than 64 bricks");
+        }
+        for (int q = 0; q < rb.n; ++q) {
+            const int64_t padded = (rb.cnt[q] + unit - 1) / unit * unit;
+            if ((int64_t)brick_entries[rb.id[q]] + padded > 0x7fffffffLL) return ig_fail(nullptr, IG_ERR_ARG, "ig_grid_bricks_count: a brick exceeds 2^31 entries");
+            brick_entries[rb.id[q]] += (int32_t)padded;
+        }
+    }
+    return IG_OK;
+}
+
+int ig_grid_bricks_fill(int64_t M, const int32_t* rowptr, const int32_t* colind, const void* vals, int64_t n0, int64_t nm, int64_t ns,
+                        int bm, int bs, int unit, const int64_t* brick_ptr /* exclusive prefix sums of the counts, nbricks + 1 */,
+                        void* entries /* brick_ptr[nbricks] x 16 bytes: {uint32 row, uint32 cell in brick, float re, float im} */) {
+    if (M < 0 || !rowptr || !brick_ptr || !bricks_ok(n0, nm, ns, bm, bs, unit) || (rowptr[M] > rowptr[0] && (!colind || !vals || !entries)))
+        return ig_fail(nullptr, IG_ERR_ARG, "ig_grid_bricks_fill: bad arguments");
+    const int64_t nbx = n0 / 16, nbm = nm / bm, nbs = ns / bs, nb = nbx * nbm * nbs;
+    std::vector<int64_t> cursor(brick_ptr, brick_ptr + nb);
+    const float2* v = (const float2*)vals;
+    BrickEntry* out = (BrickEntry*)entries;
+    for (int64_t t = 0; t < M; ++t) {
+        RowBricks rb;
+        int64_t start[64];
+        for (int32_t p = rowptr[t]; p < rowptr[t + 1]; ++p) {
+            const int64_t col = colind[p];
+            const int64_t kx = col % n0, km = (col / n0) % nm, ks = col / (n0 * nm);
+            const int64_t b = kx / 16 + nbx * (km / bm + nbm * (ks / bs));
+            const int before = rb.n;
+            if (!rb.add(b)) return ig_fail(nullptr, IG_ERR_UNSUPPORTED, "ig_grid_bricks_fill: a row touches more than 64 bricks");
+            int q = 0;
+            while (rb.id[q] != b) ++q;
+            if (rb.n > before) start[q] = cursor[b];
+            BrickEntry e;
+            e.row = (uint32_t)t;
+            e.cell = (uint32_t)((kx % 16) + 16 * ((km % bm) + bm * (ks % bs)));
+            e.re = v[p].x; e.im = v[p].y;
+            const int64_t at = start[q] + rb.cnt[q] - 1;
+            if (at >= brick_ptr[b + 1]) return ig_fail(nullptr, IG_ERR_ARG, "ig_grid_bricks_fill: brick_ptr does not come from ig_grid_bricks_count");
+            out[at] = e;
+        }
+        for (int q = 0; q < rb.n; ++q) {            // pad this row's share of each brick to a multiple of `unit`
+            const int64_t padded = (rb.cnt[q] + unit - 1) / unit * unit;
+            for (int64_t i = rb.cnt[q]; i < padded; ++i) {
+                BrickEntry e; e.row = (uint32_t)t; e.cell = 0xffffffffu; e.re = 0.f; e.im = 0.f;
+                out[start[q] + i] = e;
+            }
+            cursor[rb.id[q]] = start[q] + padded;
+        }
+    }
+    return IG_OK;
+}
+
+int ig_ccsrmm_t_bricks(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, float ar, float ai,
+                       const void* entries, const void* X, int64_t ldx, void* Y_il, const int16_t* support, int64_t n0, int64_t nm,
+                       int bm, int bs, const int32_t* tasks, int64_t ntasks, const int32_t* shared_bricks, int64_t nshared) {
+    IG_REQUIRE(ctx, ctx != nullptr, "ig_ccsrmm_t_bricks: ctx is NULL");
+    IG_REQUIRE(ctx, M >= 0 && K >= 0 && M <= 0x7fffffffLL, "ig_ccsrmm_t_bricks: bad dimensions");
+    IG_REQUIRE(ctx, N == 4 || N == 8, "ig_ccsrmm_t_bricks: 4 or 8 columns (got %lld); entries must be padded to 64/N per row and brick", (long long)N);
+    IG_REQUIRE(ctx, (ntasks == 0 || entries) && (M == 0 || X) && (K == 0 || Y_il) && ldx >= M, "ig_ccsrmm_t_bricks: NULL array or short leading dimension");
+    IG_REQUIRE(ctx, n0 > 0 && nm > 0 && K % (n0 * nm) == 0 && K < 0x7fffffffLL && bricks_ok(n0, nm, K / (n0 * nm), bm, bs, 8),
+               "ig_ccsrmm_t_bricks: rows (%lld) are not a grid of n0=%lld x nm=%lld x ... that divides into 16 x %d x %d bricks", (long long)K, (long long)n0, (long long)nm, bm, bs);
+    const int64_t ns = K / (n0 * nm);
+    IG_REQUIRE(ctx, !support || (nm % 16 == 0 && nm <= 512), "ig_ccsrmm_t_bricks: the support table needs nm %% 16 == 0 and nm <= 512");
+    IG_REQUIRE(ctx, ntasks >= 0 && ntasks <= 0x7fffffffLL && (ntasks == 0 || tasks) && nshared >= 0 && (nshared == 0 || shared_bricks), "ig_ccsrmm_t_bricks: bad task list");
+    IG_REQUIRE(ctx, M * N * 8 < 0x7fffffffLL, "ig_ccsrmm_t_bricks: the panel (%lld x %lld) exceeds the 2 GB window of a buffer descriptor", (long long)M, (long long)N);
+    if (K == 0 || ntasks == 0) return IG_OK;
+    if (int rc = ig_set_device(ctx)) return rc;
+    const int64_t nt = n0 / 16;
+    const uint32_t* bits = support ? reinterpret_cast<const uint32_t*>(support + 2 * (ns * nt + nt)) : nullptr;
+    const float2 alpha = make_float2(ar, ai);
+    // the k-space panel as packed rows [t][N] (column-major in, as everywhere at the boundary)
+    const size_t need = (size_t)M * N * 8;
+    if (ctx->xpack_bytes < need) {
+        if (ctx->d_xpack) { IG_HIP(ctx, hipStreamSynchronize(ctx->stream)); IG_HIP(ctx, hipFree(ctx->d_xpack)); ctx->d_xpack = nullptr; ctx->xpack_bytes = 0; }
+        IG_HIP(ctx, hipMalloc((void**)&ctx->d_xpack, need));
+        ctx->xpack_bytes = need;
+    }
+    float2* xp = (float2*)ctx->d_xpack;
+    {
+        ig_prof_scope prof(ctx, "pack_panel", 2.0 * (double)need);
+        int64_t g = (M * N + BLK - 1) / BLK;
+        const int64_t cap = (int64_t)ctx->num_cu * 16;
+        if (g > cap) g = cap;
+        if (N == 4) hipLaunchKernelGGL(k_pack_panel<4>, dim3((unsigned)g), dim3(BLK), 0, ctx->stream, M, N, (const float2*)X, ldx, xp, (const int32_t*)nullptr);
+        else        hipLaunchKernelGGL(k_pack_panel<8>, dim3((unsigned)g), dim3(BLK), 0, ctx->stream, M, N, (const float2*)X, ldx, xp, (const int32_t*)nullptr);
+        IG_LAUNCH_CHECK(ctx, "k_pack_panel");
+    }
+    int bm_log2 = 0, bs_log2 = 0;
+    while ((1 << bm_log2) < bm) ++bm_log2;
+    while ((1 << bs_log2) < bs) ++bs_log2;
+    const int nbx = (int)nt, nbm = (int)(nm / bm);
+    const size_t lds = (size_t)WAVES_PER_BLOCK * 16 * bm * bs * N * 8;          // one brick image per wave
+    IG_REQUIRE(ctx, lds <= 64 * 1024, "ig_ccsrmm_t_bricks: bricks of 16 x %d x %d points x %lld columns need %zu bytes of LDS per workgroup (limit 64 KB)", bm, bs, (long long)N, lds);
+    const unsigned blocks = (unsigned)((ntasks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+    static const int brick_dbg = getenv("INDIGO_HIP_BRICK_DEBUG") ? atoi(getenv("INDIGO_HIP_BRICK_DEBUG")) : 0;   // ablation: 1 no accumulation, 2 no stores
+#define IG_BRICKS(NC_) do {                                                                                                   \
+        if (nshared) {                                                                                                          \
+            ig_prof_scope prof(ctx, "grid_bricks_zero");                                                                        \
+            hipLaunchKernelGGL((k_grid_bricks_zero<NC_>), dim3((unsigned)nshared), dim3(BLK), 0, ctx->stream, shared_bricks, (float2*)Y_il, bits, (int)n0, (int)nm, bm_log2, bs_log2, nbx, nbm); } \
+        ig_prof_scope prof(ctx, "csrmm_bricks_conj");                                                                           \
+        hipLaunchKernelGGL((k_grid_bricks<NC_>), dim3(blocks), dim3(BLK), lds, ctx->stream, (const BrickTask*)tasks, (int)ntasks, (const BrickEntry*)entries, \
+                           (const float2*)xp, (float2*)Y_il, alpha, bits, (int)n0, (int)nm, bm_log2, bs_log2, nbx, nbm, brick_dbg); } while (0)
+    if (N == 8) IG_BRICKS(8); else IG_BRICKS(4);
+#undef IG_BRICKS
+    IG_LAUNCH_CHECK(ctx, "k_grid_bricks");
+    return IG_OK;
 }
 
 int ig_csr_inspect(const int32_t* rowptr, const int32_t* colind, int64_t M, int64_t K,

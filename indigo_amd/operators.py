@@ -229,6 +229,8 @@ class SpMatrix(Operator):
                 self._matrix_d.set_row_order(self._row_order)
             if getattr(self, '_grid_interleaved', False):
                 self._matrix_d.set_grid_interleaved(True)
+            if getattr(self, '_grid_bricks', None) is not None:
+                self._matrix_d.set_grid_bricks(*self._grid_bricks)
         return self._matrix_d
 
     def csrmm_bytes(self, x, y, beta, forward):

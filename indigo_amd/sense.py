@@ -205,6 +205,8 @@ class SenseProblem(object):
         return {
             "csrmm_gather": nnz * 12 + (T + 1) * 4 + touched * e + T * e,
             "csrmm_rowlane_conj": nnz * 12 + (sup + 1) * 4 + T * e + sup * e,
+            # brick-binned scatter: 16-byte entries (their padding is counted by the caller if it knows it), panel, flagged rows
+            "csrmm_bricks_conj": nnz * 16 + T * e + sup * e,
             "pack_panel": 2 * T * e,
         }
 

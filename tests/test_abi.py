@@ -91,3 +91,47 @@ def test_host_transpose_matches_scipy():
         np.testing.assert_array_equal(pt, T.indptr)
         np.testing.assert_array_equal(it, T.indices)
         np.testing.assert_array_equal(dt, T.data)
+
+
+def test_host_grid_brick_binning_matches_definition():
+    """ig_grid_bricks_count / _fill: the nonzeros sorted (stably) by the brick of 16 x bm x bs grid cells of their column, as
+    16-byte entries {row, cell inside the brick, re, im}; the entries of one row in one brick padded to a multiple of `unit`"""
+    L = _lib.lib()
+    rng = np.random.default_rng(11)
+    n0, nm, ns = 32, 16, 32
+    for bm, bs, unit in ((4, 4, 8), (8, 8, 16), (2, 16, 8), (16, 4, 1)):
+        M, P = 300, n0 * nm * ns
+        A = spp.random(M, P, density=0.002, format='csr', random_state=rng).astype(np.complex64)
+        A.data = (A.data.real + 1j * rng.random(A.nnz)).astype(np.complex64)
+        A.sort_indices()
+        indptr, indices, data = A.indptr.astype(np.int32), A.indices.astype(np.int32), np.ascontiguousarray(A.data)
+        nbx, nbm, nbs = n0 // 16, nm // bm, ns // bs
+        counts = np.full(nbx * nbm * nbs, -7, dtype=np.int32)
+        assert L.ig_grid_bricks_count(M, indptr.ctypes.data, indices.ctypes.data, n0, nm, ns, bm, bs, unit, counts.ctypes.data) == 0
+        kx, km, ks = A.indices % n0, (A.indices // n0) % nm, A.indices // (n0 * nm)
+        brick = kx // 16 + nbx * (km // bm + nbm * (ks // bs))
+        cell = kx % 16 + 16 * (km % bm + bm * (ks % bs))
+        rows = np.repeat(np.arange(M), np.diff(A.indptr))
+        # expected stream per brick: rows ascending; a row's entries in CSR order, then padding up to a multiple of unit
+        exp = {}
+        for t in range(M):
+            sel = np.flatnonzero(rows == t)
+            for bb in dict.fromkeys(brick[sel].tolist()):
+                mine = sel[brick[sel] == bb]
+                lst = exp.setdefault(bb, [])
+                lst += [(t, int(cell[i]), complex(A.data[i])) for i in mine]
+                lst += [(t, 0xffffffff, 0j)] * (-len(mine) % unit)
+        np.testing.assert_array_equal(counts, [len(exp.get(bb, [])) for bb in range(counts.size)])
+        ptr = np.zeros(counts.size + 1, dtype=np.int64)
+        np.cumsum(counts, out=ptr[1:])
+        entries = np.zeros((int(ptr[-1]), 4), dtype=np.uint32)
+        assert L.ig_grid_bricks_fill(M, indptr.ctypes.data, indices.ctypes.data, data.ctypes.data, n0, nm, ns, bm, bs, unit,
+                                     ptr.ctypes.data, entries.ctypes.data) == 0
+        for bb, lst in exp.items():
+            got = entries[ptr[bb]:ptr[bb + 1]]
+            np.testing.assert_array_equal(got[:, 0], [e[0] for e in lst])
+            np.testing.assert_array_equal(got[:, 1], [e[1] for e in lst])
+            np.testing.assert_array_equal(got[:, 2:].copy().view(np.complex64)[:, 0], np.array([e[2] for e in lst], dtype=np.complex64))
+    # grids that do not divide into bricks are refused
+    assert L.ig_grid_bricks_count(1, indptr.ctypes.data, indices.ctypes.data, 30, 16, 32, 4, 4, 8, counts.ctypes.data) != 0
+    assert L.ig_grid_bricks_count(1, indptr.ctypes.data, indices.ctypes.data, 32, 16, 24, 4, 16, 8, counts.ctypes.data) != 0
