@@ -22,6 +22,46 @@ log = logging.getLogger(__name__)
 _C64 = np.dtype('complex64')
 
 
+def brick_tasks(counts, ptr, chunk, run, max_bricks=64):
+    """Task list and brick table of ig_ccsrmm_t_bricks (include/indigo_hip.h) from the entries per brick `counts` and their
+    prefix sums `ptr`: table = (brick, end of its entries) per non-empty brick; a brick with more than `chunk` entries is
+    cut into shared tasks of at most `chunk`; the others are grouped into runs of consecutive table rows -- a new run
+    starts when the entry offset crosses a multiple of `run`, after a heavy brick, and after `max_bricks` bricks.  Returns
+    tasks (n, 4) int32 [lo, hi, first table row, rows | shared << 16] sorted longest first, table (nb, 2) int32, and the
+    ids of the shared bricks."""
+    bricks = np.flatnonzero(counts)
+    if bricks.size == 0:
+        return np.zeros((0, 4), np.int32), np.zeros((0, 2), np.int32), np.zeros(0, np.int32)
+    cnt = counts[bricks].astype(np.int64)
+    lo_b, hi_b = ptr[bricks], ptr[bricks + 1]
+    table = np.stack([bricks, hi_b], axis=1).astype(np.int32)
+    heavy = cnt > chunk
+    # runs of light bricks
+    light = np.flatnonzero(~heavy)
+    key = np.cumsum(heavy)[light] * (int(ptr[-1]) // max(run, 1) + 2) + lo_b[light] // max(run, 1)
+    new_run = np.ones(light.size, dtype=bool)
+    new_run[1:] = key[1:] != key[:-1]
+    run_id = np.cumsum(new_run) - 1
+    first_of_run = np.flatnonzero(new_run)
+    rank = np.arange(light.size) - first_of_run[run_id]
+    new_run |= (rank % max_bricks) == 0
+    starts = np.flatnonzero(new_run)
+    ends = np.append(starts[1:], light.size) - 1
+    t_run = np.stack([lo_b[light[starts]], hi_b[light[ends]], light[starts], ends - starts + 1], axis=1) if light.size else np.zeros((0, 4), np.int64)
+    # pieces of heavy bricks
+    hv = np.flatnonzero(heavy)
+    npiece = (cnt[hv] + chunk - 1) // chunk
+    rep = np.repeat(np.arange(hv.size), npiece)
+    firstp = np.concatenate(([0], np.cumsum(npiece)[:-1])) if hv.size else np.zeros(0, np.int64)
+    part = np.arange(rep.size) - firstp[rep]
+    plo = lo_b[hv][rep] + part * chunk
+    phi = np.minimum(plo + chunk, hi_b[hv][rep])
+    t_hv = np.stack([plo, phi, hv[rep], np.full(rep.size, 1 | (1 << 16))], axis=1) if rep.size else np.zeros((0, 4), np.int64)
+    tasks = np.concatenate([t_hv, t_run]).astype(np.int32)
+    tasks = np.ascontiguousarray(tasks[np.argsort(-(tasks[:, 1] - tasks[:, 0]), kind='stable')])
+    return tasks, np.ascontiguousarray(table), bricks[hv].astype(np.int32)
+
+
 def _cplx(v):
     v = complex(v)
     return ctypes.c_float(v.real), ctypes.c_float(v.imag)
@@ -585,18 +625,21 @@ class HipBackend(Backend):
             self._support = (self._backend.copy_array(np.ascontiguousarray(table, dtype=np.int16).reshape(-1),
                                                       name=self._name + ".support"), int(n0), int(nm))
 
-        def set_grid_bricks(self, n0, nm, ns, ncols=8, bm=2, bs=2, chunk=4096):
+        def set_grid_bricks(self, n0, nm, ns, ncols=8, bm=2, bs=2, chunk=4096, run=1024):
             """Sort the nonzeros by the 16 x bm x bs brick of the n0 x nm x ns grid their column falls into (native host
             routine), padded so that a wave instruction (64/ncols entries x ncols panel columns) holds entries of one row
-            only, and keep entries + task list on the device: the adjoint of an `ncols`-column interleaved panel then
-            scatters brick by brick through LDS (ig_ccsrmm_t_bricks) and needs neither the transposed matrix nor its
-            4-bytes-per-grid-point row pointers.  `chunk`: most entries one wave takes; bricks with more are shared."""
+            only, and keep entries + brick table + task list on the device: the adjoint of an `ncols`-column interleaved
+            panel then scatters brick by brick through LDS (ig_ccsrmm_t_bricks) and needs neither the transposed matrix nor
+            its 4-bytes-per-grid-point row pointers.  A task (one wave) is a run of consecutive non-empty bricks of about
+            `run` entries, or a piece of at most `chunk` entries of a heavy brick (more than `chunk` entries: shared)."""
             b = self._backend
             A = self._host_csr
             import os
-            if os.environ.get("INDIGO_HIP_BRICK_SHAPE"):          # "bm,bs,chunk": tuning aid
-                bm, bs, chunk = (int(v) for v in os.environ["INDIGO_HIP_BRICK_SHAPE"].split(","))
-            assert A is not None and A.shape[1] == n0 * nm * ns and ncols in (4, 8)
+            if os.environ.get("INDIGO_HIP_BRICK_SHAPE"):          # "bm,bs,chunk[,run]": tuning aid
+                v = [int(t) for t in os.environ["INDIGO_HIP_BRICK_SHAPE"].split(",")]
+                bm, bs, chunk = v[:3]
+                run = v[3] if len(v) > 3 else run
+            assert A is not None and A.shape[1] == n0 * nm * ns and ncols in (4, 8) and bm * bs <= 32
             unit = 64 // ncols
             chunk = max(unit, chunk // unit * unit)
             indptr = np.ascontiguousarray(A.indptr, dtype=np.int32)
@@ -608,23 +651,15 @@ class HipBackend(Backend):
                                                  counts.ctypes.data), None, "ig_grid_bricks_count")
             ptr = np.zeros(nb + 1, dtype=np.int64)
             np.cumsum(counts, out=ptr[1:])
+            assert ptr[-1] < 2**31, "brick entries are addressed with 32 bits"
             entries = np.empty((max(int(ptr[-1]), 1), 4), dtype=np.uint32)
             _lib.check(b._L.ig_grid_bricks_fill(A.shape[0], indptr.ctypes.data, indices.ctypes.data, data.ctypes.data, n0, nm, ns,
                                                 bm, bs, unit, ptr.ctypes.data, entries.ctypes.data), None, "ig_grid_bricks_fill")
-            # tasks: (brick, lo, hi, shared); entry ranges longer than `chunk` are cut, their bricks marked shared
-            bricks = np.flatnonzero(counts)
-            ntask = (counts[bricks] + chunk - 1) // chunk
-            rep = np.repeat(np.arange(bricks.size), ntask)
-            first = np.concatenate(([0], np.cumsum(ntask)[:-1])) if bricks.size else np.zeros(0, np.int64)
-            part = np.arange(rep.size) - first[rep]
-            lo = ptr[bricks][rep] + part * chunk
-            hi = np.minimum(lo + chunk, ptr[bricks + 1][rep])
-            tasks = np.stack([bricks[rep], lo, hi, (ntask[rep] > 1)], axis=1).astype(np.int32) if rep.size else np.zeros((0, 4), np.int32)
-            tasks = np.ascontiguousarray(tasks[np.argsort(-(tasks[:, 2] - tasks[:, 1]), kind='stable')])     # long tasks first
-            shared = bricks[ntask > 1].astype(np.int32)
+            tasks, table, shared = brick_tasks(counts, ptr, chunk, run, max_bricks=min(64, 256 // (bm * bs)))
             self._bricks = dict(n0=int(n0), nm=int(nm), bm=int(bm), bs=int(bs), ncols=int(ncols), ntasks=int(tasks.shape[0]),
                                 nshared=int(shared.size), nentries=int(ptr[-1]),
                                 tasks=b.copy_array(tasks.reshape(-1) if tasks.size else np.zeros(4, np.int32), name=self._name + ".brickTasks"),
+                                table=b.copy_array(table.reshape(-1) if table.size else np.zeros(2, np.int32), name=self._name + ".brickTable"),
                                 entries=b.copy_array(entries.reshape(-1), name=self._name + ".brickEntries"),
                                 shared=b.copy_array(shared if shared.size else np.zeros(1, np.int32), name=self._name + ".sharedBricks"))
 
@@ -690,7 +725,7 @@ class HipBackend(Backend):
                                                  ctypes.c_void_p(br['entries']._arr), ctypes.c_void_p(x._arr), x._leading_dim,
                                                  ctypes.c_void_p(y._arr), ctypes.c_void_p(tab._arr) if tab is not None else None,
                                                  br['n0'], br['nm'], br['bm'], br['bs'], ctypes.c_void_p(br['tasks']._arr), br['ntasks'],
-                                                 ctypes.c_void_p(br['shared']._arr), br['nshared']),
+                                                 ctypes.c_void_p(br['table']._arr), ctypes.c_void_p(br['shared']._arr), br['nshared']),
                          "ig_ccsrmm_t_bricks")
                 return
             if getattr(self, '_grid_il', False):

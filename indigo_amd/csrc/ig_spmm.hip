@@ -857,83 +857,138 @@ k_pack_panel_tiled(int64_t rows, int64_t N, const float2* __restrict__ X, int64_
 // no deferred long rows.  Two versions were measured on the way: per-brick SAMPLE lists walked through
 // pairs -> rowptr -> colind/vals (6.7 ms: dependent loads at 8 waves per CU), and a workgroup per brick with LDS float
 // atomics (5.4 ms: ds_add_f32 retires about one lane every four clocks -- 800 M lane-atomics per evaluation).
-struct BrickTask { int32_t brick, lo, hi, shared; };      // entries [lo, hi); shared != 0: several tasks add into this brick
+struct BrickTask { int32_t lo, hi, bt, nb_flags; };     // entries [lo, hi) = bricks table[bt .. bt + (nb_flags & 0xffff)); bit 16: shared
+struct BrickRef { int32_t brick, end; };                  // a non-empty brick and where its entries end
 struct BrickEntry { uint32_t row, cell; float re, im; };  // 16 bytes; cell == 0xffffffff: padding
 
+// One wave per task.  A task is a run of consecutive non-empty bricks (about a thousand entries, at most 64 bricks and
+// 256 segments) or a piece of one heavy brick (shared).  The wave keeps ONE brick image in LDS and walks the run: entries
+// are fetched two trips (of 32) ahead and the panel rows they name one trip ahead, so the accumulation never waits for a
+// dependent load; at a brick boundary (wave-uniform test, once per round of 64/NC entries) the image is stored and zeroed.
+// Brick ids, entry ends, grid offsets and segment flags of the run sit one brick per lane and are read with v_readlane.
 template <int NC>
 __global__ void __launch_bounds__(BLK)
-k_grid_bricks(const BrickTask* __restrict__ tasks, int ntasks, const BrickEntry* __restrict__ entries,
-              const float2* __restrict__ Xp /* packed rows: [t][NC] */, float2* __restrict__ Y, float2 alpha,
-              const uint32_t* __restrict__ bits, int n0, int nm, int bm_log2, int bs_log2, int nbx, int nbm, int dbg) {
+k_grid_bricks(const BrickTask* __restrict__ tasks, int ntasks, const BrickRef* __restrict__ btab,
+              const BrickEntry* __restrict__ entries, const float2* __restrict__ Xp /* packed rows: [t][NC] */,
+              float2* __restrict__ Y, float2 alpha, const uint32_t* __restrict__ bits,
+              int n0, int nm, int bm_log2, int bs_log2, int nbx, int nbm, int dbg) {
     extern __shared__ float2 acc_all[];                  // per wave: [cells][NC]
-    constexpr int TPR = 64 / NC;                         // entries per wave instruction
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    constexpr int TPR = 64 / NC;                         // entries per wave instruction (a round)
+    constexpr int IT = 32, R = IT / TPR;                 // entries, rounds per trip
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int task = blockIdx.x * WAVES_PER_BLOCK + wv;
     if (task >= ntasks) return;                          // (no workgroup barrier below: waves are independent)
     const BrickTask tk = tasks[task];
+    const int nb = tk.nb_flags & 0xffff;
+    const bool shared = (tk.nb_flags >> 16) & 1;
+    const int32_t nent = tk.hi - tk.lo;
     const int BM = 1 << bm_log2, nseg = 1 << (bm_log2 + bs_log2), ncell = 16 * nseg;
     float2* __restrict__ acc = acc_all + (size_t)wv * ncell * NC;
-    const int bx = tk.brick % nbx, bmi = (tk.brick / nbx) % nbm, bsi = tk.brick / (nbx * nbm);
-    const int x0 = bx * 16, m0 = bmi << bm_log2, s0 = bsi << bs_log2;
-    for (int e = lane; e < ncell * NC; e += 64) acc[e] = make_float2(0.f, 0.f);
     const int coil = lane % NC, tsub = lane / NC;
-    // which of the brick's segments are flagged: one bitmap word per lane (segment = lane), in flight with the first entries
-    const int nt = n0 >> 4;
-    uint64_t live_mask = ~0ull;
-    if (bits) {
-        bool lv = false;
-        if (lane < nseg) {
-            const int km = m0 + (lane & (BM - 1)), ks = s0 + (lane >> bm_log2);
-            lv = (bits[((size_t)ks * nt + bx) * 16 + (km & 15)] >> (km >> 4)) & 1u;
-        }
-        live_mask = __ballot(lv);
-    }
-    // Buffer-descriptor loads: the descriptor sits at the task's first entry (offsets stay small whatever the matrix size),
-    // lanes past the end of the task get an out-of-range offset -- no branch, no wait between the loads of a trip.
     const rsrc_t r_en = make_rsrc(entries + tk.lo), r_x = make_rsrc(Xp);
-    const int32_t nent = tk.hi - tk.lo;
-    for (int32_t base = 0; base < ((dbg & 1) ? 0 : nent); base += 64) {
-        float4 en[NC];
-        float2 xv[NC];
+
+    float4 en0[R], en1[R], en2[R];
+    float2 x0[R], x1[R];
+    auto load_entries = [&](float4* en, int32_t b0) {
 #pragma unroll
-        for (int r = 0; r < NC; ++r) {
-            const int32_t idx = base + r * TPR + tsub;
+        for (int r = 0; r < R; ++r) {
+            const int32_t idx = b0 + r * TPR + tsub;
             en[r] = buf_ld_f4(r_en, idx < nent ? (unsigned)idx * 16u : IG_OOB);
         }
+    };
+    auto load_rows = [&](float2* xv, const float4* en, int32_t b0) {
 #pragma unroll
-        for (int r = 0; r < NC; ++r) {
-            const bool ok = base + r * TPR + tsub < nent && __float_as_uint(en[r].y) != 0xffffffffu;
+        for (int r = 0; r < R; ++r) {
+            const bool ok = b0 + r * TPR + tsub < nent && __float_as_uint(en[r].y) != 0xffffffffu;
             xv[r] = buf_ld<false>(r_x, ok ? (__float_as_uint(en[r].x) * (unsigned)NC + (unsigned)coil) * 8u : IG_OOB, 0);
         }
+    };
+    load_entries(en0, 0);
+    load_entries(en1, IT);
+
+    // the run's bricks, one per lane
+    int my_end = 0x7fffffff, my_pt = 0, my_bx = 0, my_m0 = 0, my_s0 = 0;
+    if (lane < nb) {
+        const BrickRef br = btab[tk.bt + lane];
+        if (!shared) my_end = br.end - tk.lo;
+        my_bx = br.brick % nbx;
+        my_m0 = ((br.brick / nbx) % nbm) << bm_log2;
+        my_s0 = (br.brick / (nbx * nbm)) << bs_log2;
+        my_pt = my_bx * 16 + n0 * (my_m0 + nm * my_s0);
+    }
+    // ... and which of their segments are flagged: 64 (brick, segment) pairs per pass, four passes in flight
+    uint32_t my_mask = 0xffffffffu;
+    if (bits) {
+        const int nt = n0 >> 4;
+        uint32_t w[4];
 #pragma unroll
-        for (int r = 0; r < NC; ++r) {
-            const bool ok = base + r * TPR + tsub < nent && __float_as_uint(en[r].y) != 0xffffffffu;
-            if (ok) {
-                const float vr = en[r].z, vi = en[r].w;
-                float2* a = acc + (int)__float_as_uint(en[r].y) * NC + coil;
-                float2 t = *a;                                        // plain read-add-write: this instruction's entries belong
-                t.x += fmaf(vr, xv[r].x, vi * xv[r].y);               // to one sample (distinct cells), and the image is this wave's
-                t.y += fmaf(vr, xv[r].y, -vi * xv[r].x);              // conj(v) * x
-                *a = t;              // (successive rounds may hit the same cell: the compiler keeps may-alias LDS accesses in order)
+        for (int p = 0; p < 4; ++p) {
+            const int pair = p * 64 + lane, j = pair >> (bm_log2 + bs_log2), seg = pair & (nseg - 1);
+            const int jbx = __shfl(my_bx, j & 63), jm0 = __shfl(my_m0, j & 63), js0 = __shfl(my_s0, j & 63);
+            const int km = jm0 + (seg & (BM - 1)), ks = js0 + (seg >> bm_log2);
+            w[p] = j < nb ? bits[((size_t)ks * nt + jbx) * 16 + (km & 15)] >> (km >> 4) : 0u;
+        }
+        my_mask = 0u;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const uint64_t bal = __ballot(w[p] & 1u);
+            const int first = (p * 64) >> (bm_log2 + bs_log2), per = 64 >> (bm_log2 + bs_log2);      // bricks of this pass
+            if (lane >= first && lane < first + per)
+                my_mask = (uint32_t)(bal >> ((lane - first) << (bm_log2 + bs_log2))) & (nseg == 32 ? 0xffffffffu : (1u << nseg) - 1u);
+        }
+    }
+    for (int e = lane; e < ncell * NC; e += 64) acc[e] = make_float2(0.f, 0.f);
+    load_rows(x0, en0, 0);
+
+    int cur = 0;
+    int32_t cur_end = __builtin_amdgcn_readlane(my_end, 0);
+    // store the image of brick `cur` (flagged segments: 16 cells x NC coils = NC*128 bytes each) and clear it
+    auto flush = [&]() {
+        const int pt = __builtin_amdgcn_readlane(my_pt, cur);
+        const uint32_t mask = (uint32_t)__builtin_amdgcn_readlane((int)my_mask, cur);
+        for (int seg = 0; seg < nseg; ++seg) {
+            if (!((mask >> seg) & 1u)) continue;
+            const int im = seg & (BM - 1), is = seg >> bm_log2;
+            float2* src = acc + (size_t)16 * seg * NC;
+            float2* dst = Y + ((int64_t)pt + (int64_t)n0 * (im + (int64_t)nm * is)) * NC;
+#pragma unroll
+            for (int e = lane; e < 16 * NC; e += 64) {
+                const float2 o = cmul(alpha, src[e]);
+                if (!(dbg & 2)) {
+                    if (shared) { unsafeAtomicAdd(&dst[e].x, o.x); unsafeAtomicAdd(&dst[e].y, o.y); }
+                    else dst[e] = o;
+                }
+                src[e] = make_float2(0.f, 0.f);
             }
         }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // write the flagged 16-row segments: segment (im, is) = 16 cells x NC coils = NC*128 bytes
-    for (int seg = 0; seg < nseg; ++seg) {
-        const int im = seg & (BM - 1), is = seg >> bm_log2;
-        const int km = m0 + im, ks = s0 + is;
-        if (!((live_mask >> seg) & 1ull) || (dbg & 2)) continue;
-        const float2* src = acc + (size_t)16 * seg * NC;
-        float2* dst = Y + ((int64_t)x0 + (int64_t)n0 * (km + (int64_t)nm * ks)) * NC;
-        for (int e = lane; e < 16 * NC; e += 64) {
-            const float2 o = cmul(alpha, src[e]);
-            if (tk.shared) { unsafeAtomicAdd(&dst[e].x, o.x); unsafeAtomicAdd(&dst[e].y, o.y); }
-            else dst[e] = o;
+        ++cur;
+        cur_end = __builtin_amdgcn_readlane(my_end, cur & 63);
+    };
+
+    for (int32_t base = 0; base < nent; base += IT) {
+        load_entries(en2, base + 2 * IT);
+        load_rows(x1, en1, base + IT);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int32_t start = base + r * TPR;                     // wave-uniform; tasks begin and end on multiples of TPR
+            if (start < nent) {
+                while (start >= cur_end) flush();
+                const uint32_t cell = __float_as_uint(en0[r].y);
+                if (cell != 0xffffffffu && !(dbg & 1)) {
+                    const float vr = en0[r].z, vi = en0[r].w;
+                    float2* a = acc + (int)cell * NC + coil;
+                    float2 t = *a;                                    // plain read-add-write: the entries of a round belong to
+                    t.x += fmaf(vr, x0[r].x, vi * x0[r].y);           // one sample (distinct cells), the image is this wave's,
+                    t.y += fmaf(vr, x0[r].y, -vi * x0[r].x);          // and a wave's LDS operations execute in order.  conj(v) * x
+                    *a = t;
+                }
+            }
         }
+#pragma unroll
+        for (int r = 0; r < R; ++r) { en0[r] = en1[r]; en1[r] = en2[r]; x0[r] = x1[r]; }
     }
+    flush();
 }
 
 // zero the flagged segments of the bricks that several tasks add into
@@ -1483,16 +1538,17 @@ int ig_grid_bricks_fill(int64_t M, const int32_t* rowptr, const int32_t* colind,
 
 int ig_ccsrmm_t_bricks(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, float ar, float ai,
                        const void* entries, const void* X, int64_t ldx, void* Y_il, const int16_t* support, int64_t n0, int64_t nm,
-                       int bm, int bs, const int32_t* tasks, int64_t ntasks, const int32_t* shared_bricks, int64_t nshared) {
+                       int bm, int bs, const int32_t* tasks, int64_t ntasks, const int32_t* brick_table,
+                       const int32_t* shared_bricks, int64_t nshared) {
     IG_REQUIRE(ctx, ctx != nullptr, "ig_ccsrmm_t_bricks: ctx is NULL");
     IG_REQUIRE(ctx, M >= 0 && K >= 0 && M <= 0x7fffffffLL, "ig_ccsrmm_t_bricks: bad dimensions");
     IG_REQUIRE(ctx, N == 4 || N == 8, "ig_ccsrmm_t_bricks: 4 or 8 columns (got %lld); entries must be padded to 64/N per row and brick", (long long)N);
     IG_REQUIRE(ctx, (ntasks == 0 || entries) && (M == 0 || X) && (K == 0 || Y_il) && ldx >= M, "ig_ccsrmm_t_bricks: NULL array or short leading dimension");
-    IG_REQUIRE(ctx, n0 > 0 && nm > 0 && K % (n0 * nm) == 0 && K < 0x7fffffffLL && bricks_ok(n0, nm, K / (n0 * nm), bm, bs, 8),
+    IG_REQUIRE(ctx, n0 > 0 && nm > 0 && K % (n0 * nm) == 0 && K < 0x7fffffffLL && bricks_ok(n0, nm, K / (n0 * nm), bm, bs, 8) && bm * bs <= 32,
                "ig_ccsrmm_t_bricks: rows (%lld) are not a grid of n0=%lld x nm=%lld x ... that divides into 16 x %d x %d bricks", (long long)K, (long long)n0, (long long)nm, bm, bs);
     const int64_t ns = K / (n0 * nm);
     IG_REQUIRE(ctx, !support || (nm % 16 == 0 && nm <= 512), "ig_ccsrmm_t_bricks: the support table needs nm %% 16 == 0 and nm <= 512");
-    IG_REQUIRE(ctx, ntasks >= 0 && ntasks <= 0x7fffffffLL && (ntasks == 0 || tasks) && nshared >= 0 && (nshared == 0 || shared_bricks), "ig_ccsrmm_t_bricks: bad task list");
+    IG_REQUIRE(ctx, ntasks >= 0 && ntasks <= 0x7fffffffLL && (ntasks == 0 || (tasks && brick_table)) && nshared >= 0 && (nshared == 0 || shared_bricks), "ig_ccsrmm_t_bricks: bad task list");
     IG_REQUIRE(ctx, M * N * 8 < 0x7fffffffLL, "ig_ccsrmm_t_bricks: the panel (%lld x %lld) exceeds the 2 GB window of a buffer descriptor", (long long)M, (long long)N);
     if (K == 0 || ntasks == 0) return IG_OK;
     if (int rc = ig_set_device(ctx)) return rc;
@@ -1529,7 +1585,7 @@ int ig_ccsrmm_t_bricks(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, float ar, f
             ig_prof_scope prof(ctx, "grid_bricks_zero");                                                                        \
             hipLaunchKernelGGL((k_grid_bricks_zero<NC_>), dim3((unsigned)nshared), dim3(BLK), 0, ctx->stream, shared_bricks, (float2*)Y_il, bits, (int)n0, (int)nm, bm_log2, bs_log2, nbx, nbm); } \
         ig_prof_scope prof(ctx, "csrmm_bricks_conj");                                                                           \
-        hipLaunchKernelGGL((k_grid_bricks<NC_>), dim3(blocks), dim3(BLK), lds, ctx->stream, (const BrickTask*)tasks, (int)ntasks, (const BrickEntry*)entries, \
+        hipLaunchKernelGGL((k_grid_bricks<NC_>), dim3(blocks), dim3(BLK), lds, ctx->stream, (const BrickTask*)tasks, (int)ntasks, (const BrickRef*)brick_table, (const BrickEntry*)entries, \
                            (const float2*)xp, (float2*)Y_il, alpha, bits, (int)n0, (int)nm, bm_log2, bs_log2, nbx, nbm, brick_dbg); } while (0)
     if (N == 8) IG_BRICKS(8); else IG_BRICKS(4);
 #undef IG_BRICKS

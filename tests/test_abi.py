@@ -135,3 +135,37 @@ def test_host_grid_brick_binning_matches_definition():
     # grids that do not divide into bricks are refused
     assert L.ig_grid_bricks_count(1, indptr.ctypes.data, indices.ctypes.data, 30, 16, 32, 4, 4, 8, counts.ctypes.data) != 0
     assert L.ig_grid_bricks_count(1, indptr.ctypes.data, indices.ctypes.data, 32, 16, 24, 4, 16, 8, counts.ctypes.data) != 0
+
+
+def test_brick_task_list_covers_every_entry_once():
+    """brick_tasks (host side of ig_ccsrmm_t_bricks): runs of consecutive non-empty bricks and pieces of heavy bricks
+    partition the entry stream; a run is exactly the entries of its table rows and respects the brick cap"""
+    from indigo_amd.backends.hip import brick_tasks
+    rng = np.random.default_rng(5)
+    for chunk, run, cap in ((4096, 1024, 64), (64, 8, 64), (128, 1 << 20, 16), (8, 256, 3)):
+        counts = (rng.integers(0, 40, size=5000) * 8 * (rng.random(5000) < 0.6)).astype(np.int32)
+        counts[rng.integers(0, 5000, size=20)] = rng.integers(50, 3000, size=20) * 8
+        ptr = np.zeros(counts.size + 1, dtype=np.int64)
+        np.cumsum(counts, out=ptr[1:])
+        tasks, table, shared = brick_tasks(counts, ptr, chunk, run, max_bricks=cap)
+        np.testing.assert_array_equal(table[:, 0], np.flatnonzero(counts))
+        np.testing.assert_array_equal(table[:, 1], ptr[1:][counts > 0])
+        np.testing.assert_array_equal(shared, np.flatnonzero(counts > chunk))
+        covered = np.zeros(int(ptr[-1]), dtype=np.int32)
+        assert np.all(np.diff(tasks[:, 1] - tasks[:, 0]) <= 0)                     # longest first
+        for lo, hi, bt, nbf in tasks:
+            covered[lo:hi] += 1
+            nb, sh = nbf & 0xffff, nbf >> 16
+            assert hi > lo and lo % 8 == 0 and hi % 8 == 0
+            if sh:
+                b = table[bt, 0]
+                assert nb == 1 and counts[b] > chunk and ptr[b] <= lo and hi <= ptr[b + 1] and hi - lo <= chunk
+            else:
+                assert 1 <= nb <= cap
+                bricks = table[bt:bt + nb, 0]
+                assert np.all(counts[bricks] <= chunk)
+                assert lo == ptr[bricks[0]] and hi == table[bt + nb - 1, 1] == ptr[bricks[-1] + 1]
+                assert counts[bricks[0]:bricks[-1] + 1].sum() == hi - lo              # nothing but empty bricks in between
+        assert np.all(covered == 1)
+    t, tb, sh = brick_tasks(np.zeros(10, np.int32), np.zeros(11, np.int64), 64, 64)
+    assert t.shape == (0, 4) and tb.shape == (0, 2) and sh.size == 0

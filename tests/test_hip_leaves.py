@@ -505,12 +505,14 @@ def test_one_dense_and_dia_operators(hip, oracle_backend):
         assert rel_err(a, b) < RTOL
 
 
-@pytest.mark.parametrize("N,bm,bs,chunk,with_support", [(8, 4, 4, 4096, True), (8, 4, 4, 64, True), (4, 4, 4, 64, True), (4, 4, 8, 4096, False),
-                                                        (8, 2, 8, 4096, False), (8, 1, 1, 8, True)])
-def test_brick_binned_adjoint_gridding(hip, N, bm, bs, chunk, with_support):
+@pytest.mark.parametrize("N,bm,bs,chunk,run,with_support", [(8, 4, 4, 4096, 1024, True), (8, 4, 4, 64, 1024, True), (4, 4, 4, 64, 64, True),
+                                                            (4, 4, 8, 4096, 1024, False), (8, 2, 8, 4096, 1 << 20, False), (8, 1, 1, 8, 256, True),
+                                                            (8, 2, 2, 4096, 1024, True), (8, 2, 2, 128, 8, False), (4, 1, 2, 4096, 1 << 20, True)])
+def test_brick_binned_adjoint_gridding(hip, N, bm, bs, chunk, run, with_support):
     """ig_ccsrmm_t_bricks (scatter through per-wave LDS images, binned by grid bricks) == A^H X from scipy, for interleaved
     result panels of 4 and 8 columns; shared bricks (small chunk: several tasks add into one brick with atomics), rows
-    with more taps than one wave trip, several brick shapes, and the support table (only flagged segments are written)."""
+    with more taps than one wave trip, several brick shapes, runs of one brick up to the 64-brick / 256-segment cap, and
+    the support table (only flagged segments are written)."""
     rng = np.random.default_rng(N * 100 + bm)
     n0, nm, ns = 64, 64, 128
     P, T = n0 * nm * ns, 3000
@@ -537,7 +539,7 @@ def test_brick_binned_adjoint_gridding(hip, N, bm, bs, chunk, with_support):
         flat, _ = support_table_from_segments(seg)
         A_d.set_grid_support(flat, n0, nm)
     A_d.set_grid_interleaved(True)
-    A_d.set_grid_bricks(n0, nm, ns, ncols=N, bm=bm, bs=bs, chunk=chunk)
+    A_d.set_grid_bricks(n0, nm, ns, ncols=N, bm=bm, bs=bs, chunk=chunk, run=run)
     assert A_d._bricks['nshared'] > 0 or chunk >= 4096
     X = rand64c(T, N, seed=5)
     sentinel = np.full((P, N), 9 - 2j, dtype=C64, order='F')
