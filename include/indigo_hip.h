@@ -211,24 +211,27 @@ int  ig_ccsrmm_t_grid_il(ig_ctx* ctx,
  * grid, col = kx + n0*(km + nm*ks) -- what the reference's cu_exw_csrmm_H does under its exwrite promise
  * (indigo/backends/_customgpu.cu:49-81), here made safe for any matrix by binning.  The grid is cut into bricks of
  * 16 x bm x bs points (powers of two, bm*bs <= 64); on the host the nonzeros are sorted by the brick of their column
- * (stable) into 16-byte entries {uint32 row, uint32 cell inside the brick, float re, float im}, the entries one row has in
- * one brick padded with {row, 0xffffffff, 0, 0} to a multiple of `unit` = 64/N (ig_grid_bricks_count: entries per brick;
- * ig_grid_bricks_fill: the entries at the caller's prefix sums; all pointers HOST memory).  `brick_table` (device, int32
+ * (stable) into 12-byte entries {uint32 cell inside the brick, float re, float im}, the entries one row has in one brick
+ * padded with {0xffffffff, 0, 0} to a multiple of `unit` = 64/N, and `round_rows`: the row of every group of `unit`
+ * entries (ig_grid_bricks_count: entries per brick; ig_grid_bricks_fill: entries and round_rows at the caller's prefix
+ * sums; all pointers HOST memory).  `brick_table` (device, int32
  * x 2 per NON-EMPTY brick in brick order: brick id, end of its entries) and `tasks` (device, int32 x 4 per task: lo, hi,
  * first table row, number of table rows | shared << 16; lo and hi multiples of `unit`) give each wave either a run of
  * consecutive whole bricks (at most 64 bricks and 256 / (bm*bs) of them; [lo, hi) is exactly their entries) or a piece of
  * ONE heavy brick, marked shared: its tasks add with float atomics and the brick is listed in `shared_bricks` (zeroed
  * first).  Only the 16-row segments flagged in `support` (third part, as ig_ccsrmm_t_grid; NULL = all segments of bricks
  * that hold a nonzero) are written; everything else is left untouched.  N in {4, 8}; bm*bs <= 32; Y_il row-major; X
- * column-major.  A wave keeps one brick image in LDS, walks its run with the entries prefetched two trips ahead, and
- * accumulates with plain read-add-write in entry order: deterministic except for shared bricks (float atomics).      */
+ * column-major.  A wave keeps one brick image in LDS, walks its run with entries and panel rows requested two trips
+ * ahead (the rows come from round_rows, so no load depends on another), and accumulates with plain read-add-write in
+ * entry order: deterministic except for shared bricks (float atomics).                                              */
 int  ig_grid_bricks_count(int64_t M, const int32_t* rowptr, const int32_t* colind, int64_t n0, int64_t nm, int64_t ns,
                           int bm, int bs, int unit, int32_t* brick_entries);
 int  ig_grid_bricks_fill(int64_t M, const int32_t* rowptr, const int32_t* colind, const void* vals, int64_t n0, int64_t nm,
-                         int64_t ns, int bm, int bs, int unit, const int64_t* brick_ptr, void* entries);
+                         int64_t ns, int bm, int bs, int unit, const int64_t* brick_ptr, void* entries,
+                         uint32_t* round_rows);
 int  ig_ccsrmm_t_bricks(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, float alpha_re, float alpha_im,
-                        const void* entries, const void* X, int64_t ldx, void* Y_il, const int16_t* support,
-                        int64_t n0, int64_t nm, int bm, int bs, const int32_t* tasks, int64_t ntasks,
+                        const void* entries, const uint32_t* round_rows, const void* X, int64_t ldx, void* Y_il,
+                        const int16_t* support, int64_t n0, int64_t nm, int bm, int bs, const int32_t* tasks, int64_t ntasks,
                         const int32_t* brick_table, const int32_t* shared_bricks, int64_t nshared);
 
 /* Locality-ordered variants.  The caller may store A with its ROWS reordered (row r of the stored

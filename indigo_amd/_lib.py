@@ -60,8 +60,8 @@ PROTOTYPES = {
                                     c_void_p, c_int64, c_void_p,
                                     c_void_p, c_int64, c_int64]),
     "ig_grid_bricks_count": (c_int, [c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
-    "ig_grid_bricks_fill": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "ig_ccsrmm_t_bricks": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_float, c_float, c_void_p,
+    "ig_grid_bricks_fill": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "ig_ccsrmm_t_bricks": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_float, c_float, c_void_p, c_void_p,
                                    c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_int64,
                                    c_void_p, c_void_p, c_int64]),
     "ig_ccsrmm":          (c_int, [c_void_p, c_int, c_int, c_int64, c_int64, c_int64, c_int64,

@@ -652,15 +652,18 @@ class HipBackend(Backend):
             ptr = np.zeros(nb + 1, dtype=np.int64)
             np.cumsum(counts, out=ptr[1:])
             assert ptr[-1] < 2**31, "brick entries are addressed with 32 bits"
-            entries = np.empty((max(int(ptr[-1]), 1), 4), dtype=np.uint32)
+            entries = np.empty((max(int(ptr[-1]), 1), 3), dtype=np.uint32)
+            round_rows = np.empty(max(int(ptr[-1]) // unit, 1), dtype=np.uint32)
             _lib.check(b._L.ig_grid_bricks_fill(A.shape[0], indptr.ctypes.data, indices.ctypes.data, data.ctypes.data, n0, nm, ns,
-                                                bm, bs, unit, ptr.ctypes.data, entries.ctypes.data), None, "ig_grid_bricks_fill")
+                                                bm, bs, unit, ptr.ctypes.data, entries.ctypes.data, round_rows.ctypes.data),
+                       None, "ig_grid_bricks_fill")
             tasks, table, shared = brick_tasks(counts, ptr, chunk, run, max_bricks=min(64, 256 // (bm * bs)))
             self._bricks = dict(n0=int(n0), nm=int(nm), bm=int(bm), bs=int(bs), ncols=int(ncols), ntasks=int(tasks.shape[0]),
                                 nshared=int(shared.size), nentries=int(ptr[-1]),
                                 tasks=b.copy_array(tasks.reshape(-1) if tasks.size else np.zeros(4, np.int32), name=self._name + ".brickTasks"),
                                 table=b.copy_array(table.reshape(-1) if table.size else np.zeros(2, np.int32), name=self._name + ".brickTable"),
                                 entries=b.copy_array(entries.reshape(-1), name=self._name + ".brickEntries"),
+                                rounds=b.copy_array(round_rows, name=self._name + ".brickRoundRows"),
                                 shared=b.copy_array(shared if shared.size else np.zeros(1, np.int32), name=self._name + ".sharedBricks"))
 
         def set_row_order(self, perm):
@@ -722,7 +725,7 @@ class HipBackend(Backend):
                 ar, ai = _cplx(alpha)
                 m, k = self.shape
                 b._check(b._L.ig_ccsrmm_t_bricks(b._ctx, m, k, x.shape[1], ar, ai,
-                                                 ctypes.c_void_p(br['entries']._arr), ctypes.c_void_p(x._arr), x._leading_dim,
+                                                 ctypes.c_void_p(br['entries']._arr), ctypes.c_void_p(br['rounds']._arr), ctypes.c_void_p(x._arr), x._leading_dim,
                                                  ctypes.c_void_p(y._arr), ctypes.c_void_p(tab._arr) if tab is not None else None,
                                                  br['n0'], br['nm'], br['bm'], br['bs'], ctypes.c_void_p(br['tasks']._arr), br['ntasks'],
                                                  ctypes.c_void_p(br['table']._arr), ctypes.c_void_p(br['shared']._arr), br['nshared']),

@@ -145,6 +145,12 @@ __device__ __forceinline__ void buf_st_f4(rsrc_t r, unsigned voff, float4 a) {
     v4u_t v; v.x = __float_as_uint(a.x); v.y = __float_as_uint(a.y); v.z = __float_as_uint(a.z); v.w = __float_as_uint(a.w);
     __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, 0, NT ? 2 : 0);
 }
+typedef unsigned int v3u_t __attribute__((ext_vector_type(3)));
+struct u3 { unsigned x, y, z; };
+__device__ __forceinline__ u3 buf_ld_u3(rsrc_t r, unsigned voff) {          // 12 bytes (4-byte aligned)
+    const v3u_t v = __builtin_amdgcn_raw_buffer_load_b96(r, voff, 0, 0);
+    return u3{v.x, v.y, v.z};
+}
 __device__ __forceinline__ float4 buf_ld_f4(rsrc_t r, unsigned voff) {
     const v4u_t v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));

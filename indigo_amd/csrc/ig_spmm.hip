@@ -859,22 +859,32 @@ k_pack_panel_tiled(int64_t rows, int64_t N, const float2* __restrict__ X, int64_
 // atomics (5.4 ms: ds_add_f32 retires about one lane every four clocks -- 800 M lane-atomics per evaluation).
 struct BrickTask { int32_t lo, hi, bt, nb_flags; };     // entries [lo, hi) = bricks table[bt .. bt + (nb_flags & 0xffff)); bit 16: shared
 struct BrickRef { int32_t brick, end; };                  // a non-empty brick and where its entries end
-struct BrickEntry { uint32_t row, cell; float re, im; };  // 16 bytes; cell == 0xffffffff: padding
+struct BrickEntry { uint32_t cell; float re, im; };       // 12 bytes; cell == 0xffffffff: padding
 
 // One wave per task.  A task is a run of consecutive non-empty bricks (about a thousand entries, at most 64 bricks and
-// 256 segments) or a piece of one heavy brick (shared).  The wave keeps ONE brick image in LDS and walks the run: entries
-// are fetched two trips (of 32) ahead and the panel rows they name one trip ahead, so the accumulation never waits for a
-// dependent load; at a brick boundary (wave-uniform test, once per round of 64/NC entries) the image is stored and zeroed.
-// Brick ids, entry ends, grid offsets and segment flags of the run sit one brick per lane and are read with v_readlane.
-template <int NC>
+// 256 segments) or a piece of one heavy brick (shared).  The wave keeps ONE brick image in LDS and walks the run in
+// super-trips of 64 entries.  Loading and accumulating use different lane roles:
+//   * loading: lane e fetches entry e of the super-trip (ONE 12-byte load per lane: 768 useful bytes per instruction), and
+//     lane (r, coil) fetches X[sample of round r, coil] (one load: the 64/TPR panel rows of the super-trip), the samples
+//     coming from `round_rows` a super-trip earlier.  A super-trip in flight costs 6 registers, so entries are requested
+//     three super-trips (192 entries) ahead and panel rows two;
+//   * accumulating: in round r lane (t, coil) takes entry r*TPR + t and X[round r, coil] from the loading lanes with
+//     ds_bpermute and adds conj(v) * x into the image with a plain read-add-write.
+// An earlier form gave every lane of a round its own copy of the entry and the panel value straight from memory: eight
+// times the load instructions (address-unit time) and registers, which capped the prefetch depth at 64 entries.
+// At a brick boundary (wave-uniform test, once per round -- a brick holds at least one round) the image is stored and
+// cleared; with NSEG > 0 the segment loop is unrolled.  Brick ends, grid offsets and segment flags of the run sit one
+// brick per lane (v_readlane).
+template <int NC, int NSEG /* bm * bs, or 0: any */>
 __global__ void __launch_bounds__(BLK)
 k_grid_bricks(const BrickTask* __restrict__ tasks, int ntasks, const BrickRef* __restrict__ btab,
-              const BrickEntry* __restrict__ entries, const float2* __restrict__ Xp /* packed rows: [t][NC] */,
+              const BrickEntry* __restrict__ entries, const uint32_t* __restrict__ round_rows,
+              const float2* __restrict__ Xp /* packed rows: [t][NC] */,
               float2* __restrict__ Y, float2 alpha, const uint32_t* __restrict__ bits,
               int n0, int nm, int bm_log2, int bs_log2, int nbx, int nbm, int dbg) {
     extern __shared__ float2 acc_all[];                  // per wave: [cells][NC]
-    constexpr int TPR = 64 / NC;                         // entries per wave instruction (a round)
-    constexpr int IT = 32, R = IT / TPR;                 // entries, rounds per trip
+    constexpr int TPR = 64 / NC;                         // entries per round (one wave instruction of the accumulation)
+    constexpr int RS = 64 / TPR;                         // rounds per super-trip
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int task = blockIdx.x * WAVES_PER_BLOCK + wv;
@@ -882,111 +892,144 @@ k_grid_bricks(const BrickTask* __restrict__ tasks, int ntasks, const BrickRef* _
     const BrickTask tk = tasks[task];
     const int nb = tk.nb_flags & 0xffff;
     const bool shared = (tk.nb_flags >> 16) & 1;
-    const int32_t nent = tk.hi - tk.lo;
-    const int BM = 1 << bm_log2, nseg = 1 << (bm_log2 + bs_log2), ncell = 16 * nseg;
+    const int32_t nent = tk.hi - tk.lo, nround = nent / TPR;
+    const int BM = 1 << bm_log2, nseg = NSEG ? NSEG : 1 << (bm_log2 + bs_log2), ncell = 16 * nseg;
     float2* __restrict__ acc = acc_all + (size_t)wv * ncell * NC;
-    const int coil = lane % NC, tsub = lane / NC;
-    const rsrc_t r_en = make_rsrc(entries + tk.lo), r_x = make_rsrc(Xp);
+    const int coil = lane % NC, tsub = lane / NC, xround = (lane / NC) % RS;
+    const rsrc_t r_en = make_rsrc(entries + tk.lo), r_rr = make_rsrc(round_rows + tk.lo / TPR), r_x = make_rsrc(Xp);
 
-    float4 en0[R], en1[R], en2[R];
-    float2 x0[R], x1[R];
-    auto load_entries = [&](float4* en, int32_t b0) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int32_t idx = b0 + r * TPR + tsub;
-            en[r] = buf_ld_f4(r_en, idx < nent ? (unsigned)idx * 16u : IG_OOB);
-        }
+    struct Set { u3 en; uint32_t rid; float2 x; };
+    Set s0, s1, s2, s3;
+    // In-order return: a wait for one load is a wait for every older one, so what is needed soonest is requested first --
+    // samples five super-trips ahead, entries three, panel rows two.
+    auto request_samples = [&](Set& s, int st) {
+        const int32_t q = st * RS + xround;
+        s.rid = (uint32_t)buf_ld_i32(r_rr, q < nround ? (unsigned)q * 4u : IG_OOB);
     };
-    auto load_rows = [&](float2* xv, const float4* en, int32_t b0) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const bool ok = b0 + r * TPR + tsub < nent && __float_as_uint(en[r].y) != 0xffffffffu;
-            xv[r] = buf_ld<false>(r_x, ok ? (__float_as_uint(en[r].x) * (unsigned)NC + (unsigned)coil) * 8u : IG_OOB, 0);
-        }
+    auto request_entries = [&](Set& s, int st) {         // (past the end of the task: nothing is fetched)
+        const int32_t idx = st * 64 + lane;
+        s.en = buf_ld_u3(r_en, idx < nent ? (unsigned)idx * 12u : IG_OOB);
     };
-    load_entries(en0, 0);
-    load_entries(en1, IT);
-
+    auto request_rows = [&](Set& s, int st) {            // panel rows of super-trip st (its samples have arrived)
+        const int32_t q = st * RS + xround;
+        s.x = buf_ld<false>(r_x, q < nround ? (s.rid * (unsigned)NC + (unsigned)coil) * 8u : IG_OOB, 0);
+    };
+    request_samples(s0, 0);
+    request_samples(s1, 1);
     // the run's bricks, one per lane
+    const float2 my_ref = buf_ld<false>(make_rsrc(btab + tk.bt), lane < nb ? (unsigned)lane * 8u : IG_OOB, 0);
+    request_entries(s0, 0);
+    request_samples(s2, 2);
+    request_samples(s3, 3);
+    request_entries(s1, 1);
+    request_entries(s2, 2);
+    request_rows(s0, 0);
+    request_samples(s0, 4);
+    request_rows(s1, 1);
     int my_end = 0x7fffffff, my_pt = 0, my_bx = 0, my_m0 = 0, my_s0 = 0;
     if (lane < nb) {
-        const BrickRef br = btab[tk.bt + lane];
-        if (!shared) my_end = br.end - tk.lo;
-        my_bx = br.brick % nbx;
-        my_m0 = ((br.brick / nbx) % nbm) << bm_log2;
-        my_s0 = (br.brick / (nbx * nbm)) << bs_log2;
+        const int brick = (int)__float_as_uint(my_ref.x);
+        if (!shared) my_end = (int)__float_as_uint(my_ref.y) - tk.lo;
+        my_bx = brick % nbx;
+        my_m0 = ((brick / nbx) % nbm) << bm_log2;
+        my_s0 = (brick / (nbx * nbm)) << bs_log2;
         my_pt = my_bx * 16 + n0 * (my_m0 + nm * my_s0);
     }
     // ... and which of their segments are flagged: 64 (brick, segment) pairs per pass, four passes in flight
     uint32_t my_mask = 0xffffffffu;
     if (bits) {
-        const int nt = n0 >> 4;
+        const int nt = n0 >> 4, seg_log2 = bm_log2 + bs_log2;
+        const rsrc_t r_bits = make_rsrc(bits);
         uint32_t w[4];
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            const int pair = p * 64 + lane, j = pair >> (bm_log2 + bs_log2), seg = pair & (nseg - 1);
+            const int pair = p * 64 + lane, j = pair >> seg_log2, seg = pair & (nseg - 1);
             const int jbx = __shfl(my_bx, j & 63), jm0 = __shfl(my_m0, j & 63), js0 = __shfl(my_s0, j & 63);
             const int km = jm0 + (seg & (BM - 1)), ks = js0 + (seg >> bm_log2);
-            w[p] = j < nb ? bits[((size_t)ks * nt + jbx) * 16 + (km & 15)] >> (km >> 4) : 0u;
+            w[p] = (uint32_t)buf_ld_i32(r_bits, j < nb ? (unsigned)((ks * nt + jbx) * 16 + (km & 15)) * 4u : IG_OOB) >> (km >> 4);
         }
         my_mask = 0u;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const uint64_t bal = __ballot(w[p] & 1u);
-            const int first = (p * 64) >> (bm_log2 + bs_log2), per = 64 >> (bm_log2 + bs_log2);      // bricks of this pass
+            const int first = (p * 64) >> seg_log2, per = 64 >> seg_log2;                  // bricks of this pass
             if (lane >= first && lane < first + per)
-                my_mask = (uint32_t)(bal >> ((lane - first) << (bm_log2 + bs_log2))) & (nseg == 32 ? 0xffffffffu : (1u << nseg) - 1u);
+                my_mask = (uint32_t)(bal >> ((lane - first) << seg_log2)) & (nseg == 32 ? 0xffffffffu : (1u << nseg) - 1u);
         }
     }
     for (int e = lane; e < ncell * NC; e += 64) acc[e] = make_float2(0.f, 0.f);
-    load_rows(x0, en0, 0);
 
     int cur = 0;
     int32_t cur_end = __builtin_amdgcn_readlane(my_end, 0);
     // store the image of brick `cur` (flagged segments: 16 cells x NC coils = NC*128 bytes each) and clear it
+    auto flush_segment = [&](int pt, uint32_t mask, int seg) {
+        if (!((mask >> seg) & 1u)) return;
+        const int im = seg & (BM - 1), is = seg >> bm_log2;
+        float2* src = acc + (size_t)16 * seg * NC;
+        float2* dst = Y + ((int64_t)pt + (int64_t)n0 * (im + (int64_t)nm * is)) * NC;
+#pragma unroll
+        for (int e = lane; e < 16 * NC; e += 64) {
+            const float2 o = cmul(alpha, src[e]);
+            // Stores and atomics as asm statements: the compiler's wait-count bookkeeping does not see them.  With ordinary
+            // stores in this (inner) loop it drains every outstanding load before each super-trip (s_waitcnt vmcnt(0):
+            // it cannot bound the number of stores between a load and its use), which undoes the prefetching; not
+            // counting them only makes its counted waits for loads somewhat earlier than necessary.  An 8-byte store
+            // reads its data registers at issue (no write-after-read hazard), and nothing here reads Y back.
+            if (!(dbg & 2)) {
+                if (shared) {
+                    asm volatile("global_atomic_add_f32 %0, %1, off\n\tglobal_atomic_add_f32 %0, %2, off offset:4"
+                                 :: "v"(dst + e), "v"(o.x), "v"(o.y) : "memory");
+                } else {
+                    asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(dst + e), "v"(o) : "memory");
+                }
+            }
+            src[e] = make_float2(0.f, 0.f);
+        }
+    };
     auto flush = [&]() {
         const int pt = __builtin_amdgcn_readlane(my_pt, cur);
         const uint32_t mask = (uint32_t)__builtin_amdgcn_readlane((int)my_mask, cur);
-        for (int seg = 0; seg < nseg; ++seg) {
-            if (!((mask >> seg) & 1u)) continue;
-            const int im = seg & (BM - 1), is = seg >> bm_log2;
-            float2* src = acc + (size_t)16 * seg * NC;
-            float2* dst = Y + ((int64_t)pt + (int64_t)n0 * (im + (int64_t)nm * is)) * NC;
+        if (NSEG) {
 #pragma unroll
-            for (int e = lane; e < 16 * NC; e += 64) {
-                const float2 o = cmul(alpha, src[e]);
-                if (!(dbg & 2)) {
-                    if (shared) { unsafeAtomicAdd(&dst[e].x, o.x); unsafeAtomicAdd(&dst[e].y, o.y); }
-                    else dst[e] = o;
-                }
-                src[e] = make_float2(0.f, 0.f);
-            }
+            for (int seg = 0; seg < (NSEG ? NSEG : 1); ++seg) flush_segment(pt, mask, seg);
+        } else {
+            for (int seg = 0; seg < nseg; ++seg) flush_segment(pt, mask, seg);
         }
         ++cur;
         cur_end = __builtin_amdgcn_readlane(my_end, cur & 63);
     };
-
-    for (int32_t base = 0; base < nent; base += IT) {
-        load_entries(en2, base + 2 * IT);
-        load_rows(x1, en1, base + IT);
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int32_t start = base + r * TPR;                     // wave-uniform; tasks begin and end on multiples of TPR
-            if (start < nent) {
-                while (start >= cur_end) flush();
-                const uint32_t cell = __float_as_uint(en0[r].y);
-                if (cell != 0xffffffffu && !(dbg & 1)) {
-                    const float vr = en0[r].z, vi = en0[r].w;
-                    float2* a = acc + (int)cell * NC + coil;
-                    float2 t = *a;                                    // plain read-add-write: the entries of a round belong to
-                    t.x += fmaf(vr, x0[r].x, vi * x0[r].y);           // one sample (distinct cells), the image is this wave's,
-                    t.y += fmaf(vr, x0[r].y, -vi * x0[r].x);          // and a wave's LDS operations execute in order.  conj(v) * x
-                    *a = t;
-                }
+    // super-trip st: request panel rows two, entries three and samples five super-trips ahead, then accumulate the set `s`
+    auto super_trip = [&](const Set& s, Set& next, Set& rows_ahead, Set& entries_ahead, int st) {
+        const uint32_t e_cell = s.en.x, e_re = s.en.y, e_im = s.en.z;
+        const float x_re = s.x.x, x_im = s.x.y;
+        request_rows(rows_ahead, st + 2);
+        request_entries(entries_ahead, st + 3);
+        request_samples(next, st + 5);                                    // (the samples it held have served their purpose)
+        for (int r = 0; r < RS; ++r) {
+            const int32_t start = st * 64 + r * TPR;                      // wave-uniform; tasks begin and end on multiples of TPR
+            if (start >= nent) break;
+            if (start >= cur_end) flush();                                // (every brick of the table holds at least one round)
+            const int from_e = (r * TPR + tsub) * 4, from_x = (r * NC + coil) * 4;
+            const uint32_t cell = (uint32_t)__builtin_amdgcn_ds_bpermute(from_e, (int)e_cell);
+            const float vr = __int_as_float(__builtin_amdgcn_ds_bpermute(from_e, (int)e_re));
+            const float vi = __int_as_float(__builtin_amdgcn_ds_bpermute(from_e, (int)e_im));
+            const float xr = __int_as_float(__builtin_amdgcn_ds_bpermute(from_x, __float_as_int(x_re)));
+            const float xi = __int_as_float(__builtin_amdgcn_ds_bpermute(from_x, __float_as_int(x_im)));
+            if (cell != 0xffffffffu && !(dbg & 1)) {
+                float2* a = acc + (int)cell * NC + coil;
+                float2 v = *a;                                            // plain read-add-write: the entries of a round belong to
+                v.x += fmaf(vr, xr, vi * xi);                             // one sample (distinct cells), the image is this wave's,
+                v.y += fmaf(vr, xi, -vi * xr);                            // and a wave's LDS operations execute in order.  conj(v) * x
+                *a = v;
             }
         }
-#pragma unroll
-        for (int r = 0; r < R; ++r) { en0[r] = en1[r]; en1[r] = en2[r]; x0[r] = x1[r]; }
+    };
+    const int nst = (nent + 63) / 64;
+    for (int st = 0; st < nst; st += 4) {
+        super_trip(s0, s1, s2, s3, st);                   // (super-trips past the end request and accumulate nothing: no early
+        super_trip(s1, s2, s3, s0, st + 1);               // exits, which would give the loop header a predecessor the
+        super_trip(s2, s3, s0, s1, st + 2);               // compiler's wait-count bookkeeping knows nothing about)
+        super_trip(s3, s0, s1, s2, st + 3);
     }
     flush();
 }
@@ -1497,8 +1540,9 @@ int ig_grid_bricks_count(int64_t M, const int32_t* rowptr, const int32_t* colind
 
 int ig_grid_bricks_fill(int64_t M, const int32_t* rowptr, const int32_t* colind, const void* vals, int64_t n0, int64_t nm, int64_t ns,
                         int bm, int bs, int unit, const int64_t* brick_ptr /* exclusive prefix sums of the counts, nbricks + 1 */,
-                        void* entries /* brick_ptr[nbricks] x 16 bytes: {uint32 row, uint32 cell in brick, float re, float im} */) {
-    if (M < 0 || !rowptr || !brick_ptr || !bricks_ok(n0, nm, ns, bm, bs, unit) || (rowptr[M] > rowptr[0] && (!colind || !vals || !entries)))
+                        void* entries /* brick_ptr[nbricks] x 12 bytes: {uint32 cell in brick, float re, float im} */,
+                        uint32_t* round_rows /* brick_ptr[nbricks] / unit: the row of each group of `unit` entries */) {
+    if (M < 0 || !rowptr || !brick_ptr || !bricks_ok(n0, nm, ns, bm, bs, unit) || (rowptr[M] > rowptr[0] && (!colind || !vals || !entries || !round_rows)))
         return ig_fail(nullptr, IG_ERR_ARG, "ig_grid_bricks_fill: bad arguments");
     const int64_t nbx = n0 / 16, nbm = nm / bm, nbs = ns / bs, nb = nbx * nbm * nbs;
     std::vector<int64_t> cursor(brick_ptr, brick_ptr + nb);
@@ -1517,19 +1561,19 @@ int ig_grid_bricks_fill(int64_t M, const int32_t* rowptr, const int32_t* colind,
             while (rb.id[q] != b) ++q;
             if (rb.n > before) start[q] = cursor[b];
             BrickEntry e;
-            e.row = (uint32_t)t;
             e.cell = (uint32_t)((kx % 16) + 16 * ((km % bm) + bm * (ks % bs)));
             e.re = v[p].x; e.im = v[p].y;
             const int64_t at = start[q] + rb.cnt[q] - 1;
-            if (at >= brick_ptr[b + 1]) return ig_fail(nullptr, IG_ERR_ARG, "ig_grid_bricks_fill: brick_ptr does not come from ig_grid_bricks_count");
+            if (at >= brick_ptr[b + 1] || start[q] % unit) return ig_fail(nullptr, IG_ERR_ARG, "ig_grid_bricks_fill: brick_ptr does not come from ig_grid_bricks_count");
             out[at] = e;
         }
         for (int q = 0; q < rb.n; ++q) {            // pad this row's share of each brick to a multiple of `unit`
             const int64_t padded = (rb.cnt[q] + unit - 1) / unit * unit;
             for (int64_t i = rb.cnt[q]; i < padded; ++i) {
-                BrickEntry e; e.row = (uint32_t)t; e.cell = 0xffffffffu; e.re = 0.f; e.im = 0.f;
+                BrickEntry e; e.cell = 0xffffffffu; e.re = 0.f; e.im = 0.f;
                 out[start[q] + i] = e;
             }
+            for (int64_t i = 0; i < padded; i += unit) round_rows[(start[q] + i) / unit] = (uint32_t)t;
             cursor[rb.id[q]] = start[q] + padded;
         }
     }
@@ -1537,13 +1581,13 @@ int ig_grid_bricks_fill(int64_t M, const int32_t* rowptr, const int32_t* colind,
 }
 
 int ig_ccsrmm_t_bricks(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, float ar, float ai,
-                       const void* entries, const void* X, int64_t ldx, void* Y_il, const int16_t* support, int64_t n0, int64_t nm,
+                       const void* entries, const uint32_t* round_rows, const void* X, int64_t ldx, void* Y_il, const int16_t* support, int64_t n0, int64_t nm,
                        int bm, int bs, const int32_t* tasks, int64_t ntasks, const int32_t* brick_table,
                        const int32_t* shared_bricks, int64_t nshared) {
     IG_REQUIRE(ctx, ctx != nullptr, "ig_ccsrmm_t_bricks: ctx is NULL");
     IG_REQUIRE(ctx, M >= 0 && K >= 0 && M <= 0x7fffffffLL, "ig_ccsrmm_t_bricks: bad dimensions");
     IG_REQUIRE(ctx, N == 4 || N == 8, "ig_ccsrmm_t_bricks: 4 or 8 columns (got %lld); entries must be padded to 64/N per row and brick", (long long)N);
-    IG_REQUIRE(ctx, (ntasks == 0 || entries) && (M == 0 || X) && (K == 0 || Y_il) && ldx >= M, "ig_ccsrmm_t_bricks: NULL array or short leading dimension");
+    IG_REQUIRE(ctx, (ntasks == 0 || (entries && round_rows)) && (M == 0 || X) && (K == 0 || Y_il) && ldx >= M, "ig_ccsrmm_t_bricks: NULL array or short leading dimension");
     IG_REQUIRE(ctx, n0 > 0 && nm > 0 && K % (n0 * nm) == 0 && K < 0x7fffffffLL && bricks_ok(n0, nm, K / (n0 * nm), bm, bs, 8) && bm * bs <= 32,
                "ig_ccsrmm_t_bricks: rows (%lld) are not a grid of n0=%lld x nm=%lld x ... that divides into 16 x %d x %d bricks", (long long)K, (long long)n0, (long long)nm, bm, bs);
     const int64_t ns = K / (n0 * nm);
@@ -1580,14 +1624,16 @@ int ig_ccsrmm_t_bricks(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, float ar, f
     IG_REQUIRE(ctx, lds <= 64 * 1024, "ig_ccsrmm_t_bricks: bricks of 16 x %d x %d points x %lld columns need %zu bytes of LDS per workgroup (limit 64 KB)", bm, bs, (long long)N, lds);
     const unsigned blocks = (unsigned)((ntasks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
     static const int brick_dbg = getenv("INDIGO_HIP_BRICK_DEBUG") ? atoi(getenv("INDIGO_HIP_BRICK_DEBUG")) : 0;   // ablation: 1 no accumulation, 2 no stores
-#define IG_BRICKS(NC_) do {                                                                                                   \
+#define IG_BRICKS(NC_, NSEG_) do {                                                                                            \
         if (nshared) {                                                                                                          \
             ig_prof_scope prof(ctx, "grid_bricks_zero");                                                                        \
             hipLaunchKernelGGL((k_grid_bricks_zero<NC_>), dim3((unsigned)nshared), dim3(BLK), 0, ctx->stream, shared_bricks, (float2*)Y_il, bits, (int)n0, (int)nm, bm_log2, bs_log2, nbx, nbm); } \
         ig_prof_scope prof(ctx, "csrmm_bricks_conj");                                                                           \
-        hipLaunchKernelGGL((k_grid_bricks<NC_>), dim3(blocks), dim3(BLK), lds, ctx->stream, (const BrickTask*)tasks, (int)ntasks, (const BrickRef*)brick_table, (const BrickEntry*)entries, \
+        hipLaunchKernelGGL((k_grid_bricks<NC_, NSEG_>), dim3(blocks), dim3(BLK), lds, ctx->stream, (const BrickTask*)tasks, (int)ntasks, (const BrickRef*)brick_table, (const BrickEntry*)entries, round_rows, \
                            (const float2*)xp, (float2*)Y_il, alpha, bits, (int)n0, (int)nm, bm_log2, bs_log2, nbx, nbm, brick_dbg); } while (0)
-    if (N == 8) IG_BRICKS(8); else IG_BRICKS(4);
+    if (N == 8 && bm * bs == 4) IG_BRICKS(8, 4);
+    else if (N == 8) IG_BRICKS(8, 0);
+    else IG_BRICKS(4, 0);
 #undef IG_BRICKS
     IG_LAUNCH_CHECK(ctx, "k_grid_bricks");
     return IG_OK;

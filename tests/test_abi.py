@@ -95,7 +95,8 @@ def test_host_transpose_matches_scipy():
 
 def test_host_grid_brick_binning_matches_definition():
     """ig_grid_bricks_count / _fill: the nonzeros sorted (stably) by the brick of 16 x bm x bs grid cells of their column, as
-    16-byte entries {row, cell inside the brick, re, im}; the entries of one row in one brick padded to a multiple of `unit`"""
+    12-byte entries {cell inside the brick, re, im}; the entries of one row in one brick padded to a multiple of `unit`, and
+    the row of every group of `unit` entries in round_rows"""
     L = _lib.lib()
     rng = np.random.default_rng(11)
     n0, nm, ns = 32, 16, 32
@@ -124,14 +125,15 @@ def test_host_grid_brick_binning_matches_definition():
         np.testing.assert_array_equal(counts, [len(exp.get(bb, [])) for bb in range(counts.size)])
         ptr = np.zeros(counts.size + 1, dtype=np.int64)
         np.cumsum(counts, out=ptr[1:])
-        entries = np.zeros((int(ptr[-1]), 4), dtype=np.uint32)
+        entries = np.zeros((int(ptr[-1]), 3), dtype=np.uint32)
+        round_rows = np.full(int(ptr[-1]) // unit, 0xdeadbeef, dtype=np.uint32)
         assert L.ig_grid_bricks_fill(M, indptr.ctypes.data, indices.ctypes.data, data.ctypes.data, n0, nm, ns, bm, bs, unit,
-                                     ptr.ctypes.data, entries.ctypes.data) == 0
+                                     ptr.ctypes.data, entries.ctypes.data, round_rows.ctypes.data) == 0
         for bb, lst in exp.items():
             got = entries[ptr[bb]:ptr[bb + 1]]
-            np.testing.assert_array_equal(got[:, 0], [e[0] for e in lst])
-            np.testing.assert_array_equal(got[:, 1], [e[1] for e in lst])
-            np.testing.assert_array_equal(got[:, 2:].copy().view(np.complex64)[:, 0], np.array([e[2] for e in lst], dtype=np.complex64))
+            np.testing.assert_array_equal(np.repeat(round_rows[ptr[bb] // unit:ptr[bb + 1] // unit], unit), [e[0] for e in lst])
+            np.testing.assert_array_equal(got[:, 0], [e[1] for e in lst])
+            np.testing.assert_array_equal(got[:, 1:].copy().view(np.complex64)[:, 0], np.array([e[2] for e in lst], dtype=np.complex64))
     # grids that do not divide into bricks are refused
     assert L.ig_grid_bricks_count(1, indptr.ctypes.data, indices.ctypes.data, 30, 16, 32, 4, 4, 8, counts.ctypes.data) != 0
     assert L.ig_grid_bricks_count(1, indptr.ctypes.data, indices.ctypes.data, 32, 16, 24, 4, 16, 8, counts.ctypes.data) != 0
