@@ -1,5 +1,6 @@
 #!/bin/bash
-# SQ counters of the brick kernel (one --pmc pass per group), summarised per dispatch of k_grid_bricks
+# SQ counters (one --pmc pass per group of four) of the brick gridding kernel and of the padded y/z FFT pass, averaged per dispatch;
+# the sums run over 32 shader engines (SQ_BUSY_CYCLES / 32 = the kernel's duration in clocks)
 set -e
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
