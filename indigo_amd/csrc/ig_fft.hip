@@ -34,6 +34,7 @@
 //
 // The inverse transform is computed as conj(FFT(conj(x))).
 #include "ig_common.h"
+#include "ig_fft_ab.h"
 #include <vector>
 #include <cmath>
 #include <cstring>
@@ -932,8 +933,9 @@ k_fft_generic_stage(const float2* __restrict__ in, float2* __restrict__ out, con
 
 struct AxisPlan {
     int64_t n = 1, inner = 1, outer = 1;
-    int kind = 2;                      // 0 LDS kernel, 1 generic stages, 2 nothing to do (n == 1)
+    int kind = 2;                      // 0 LDS kernel, 1 generic stages, 2 nothing to do (n == 1), 3 two-stage (256, 512), 4 two-stage A x B
     int nstages = 0;
+    int ab_A = 0, ab_B = 0;            // kind 4: n = A * B (ig_fft_ab.h)
     Radices rad{};
     std::vector<int64_t> gen_radices;  // generic path may carry large prime radices
     int W = 16, T = 1;
@@ -985,6 +987,37 @@ struct ig_fft {
 
 namespace {
 
+// ---- two-stage A x B passes (ig_fft_ab.h): the instantiated splits ------------------------------------------------
+#define IG_AB_LIST(X) X(15, 18, 1) X(16, 18, 1) X(16, 20, 1) X(18, 20, 2) X(16, 24, 2) X(14, 28, 2) X(20, 20, 2) \
+                      X(18, 24, 2) X(20, 24, 2) X(24, 24, 2) X(24, 25, 2) X(20, 32, 2)
+bool ab_split(int64_t n, int& A, int& B) {
+#define IG_AB_CASE(A_, B_, R_) if (n == (A_) * (B_)) { A = A_; B = B_; return true; }
+    IG_AB_LIST(IG_AB_CASE)
+#undef IG_AB_CASE
+    return false;
+}
+size_t ab_lds(int64_t n, bool axis0) {
+#define IG_AB_CASE(A_, B_, R_) if (n == (A_) * (B_)) return axis0 ? anyfft::ab_lds_bytes<A_, B_, R_, true>() : anyfft::ab_lds_bytes<A_, B_, R_, false>();
+    IG_AB_LIST(IG_AB_CASE)
+#undef IG_AB_CASE
+    return 0;
+}
+int launch_ab(ig_ctx* ctx, const AxisPlan& ax, const float2* in, float2* out, int inverse) {
+    const int64_t ncols = ax.inner * ax.outer;
+    const int64_t blocks = (ncols + anyfft::AB_W - 1) / anyfft::AB_W;
+    IG_REQUIRE(ctx, blocks <= 0x7fffffffLL, "ig_fft_exec: too many tiles");
+    const dim3 grid((unsigned)blocks), block((unsigned)(anyfft::AB_W * ax.ab_B));
+#define IG_AB_CASE(A_, B_, R_)                                                                                              \
+    if (ax.n == (A_) * (B_)) {                                                                                              \
+        if (ax.inner == 1) hipLaunchKernelGGL((anyfft::k_fft_ab<A_, B_, R_, true>), grid, block, ax.lds_bytes, ctx->stream, in, out, ax.d_tw, ax.inner, ncols, inverse); \
+        else hipLaunchKernelGGL((anyfft::k_fft_ab<A_, B_, R_, false>), grid, block, ax.lds_bytes, ctx->stream, in, out, ax.d_tw, ax.inner, ncols, inverse);             \
+    } else
+    IG_AB_LIST(IG_AB_CASE) { return ig_fail(ctx, IG_ERR_UNSUPPORTED, "ig_fft_exec: no A x B kernel for n = %lld", (long long)ax.n); }
+#undef IG_AB_CASE
+    IG_LAUNCH_CHECK(ctx, "k_fft_ab");
+    return IG_OK;
+}
+
 int plan_axis(ig_ctx* ctx, ig_fft* p, int a) {
     AxisPlan& ax = p->axis[a];
     ax.n = p->dims[a];
@@ -1005,7 +1038,19 @@ int plan_axis(ig_ctx* ctx, ig_fft* p, int a) {
         ax.lds_bytes = ((size_t)16 * 17 * ax.W + ax.n) * 8;     // one exchange round (padded rows, x passes) + the twiddle table
         // 36 KB of dynamic LDS: below the 64 KB every kernel may use without an attribute
     }
-    bool lds_ok = !two_stage && !force_generic && ax.n <= LDS_NMAX && factor_lds(ax.n, rad, ns);
+    // lengths with a register-resident A x B split (the oversampled grids of the reference's example and their like)
+    const int use_ab = getenv("INDIGO_HIP_FFT_AB") ? atoi(getenv("INDIGO_HIP_FFT_AB")) : 1;     // (read per plan: the tests flip it)
+    bool ab = false;
+    if (!two_stage && !force_generic && use_ab) {
+        int A = 0, B = 0;
+        if (ab_split(ax.n, A, B)) {
+            ab = true;
+            ax.kind = 4; ax.ab_A = A; ax.ab_B = B; ax.W = anyfft::AB_W; ax.T = B; ax.nstages = 2;
+            ax.rad.r[0] = A; ax.rad.r[1] = B;
+            ax.lds_bytes = ab_lds(ax.n, ax.inner == 1);
+        }
+    }
+    bool lds_ok = !ab && !two_stage && !force_generic && ax.n <= LDS_NMAX && factor_lds(ax.n, rad, ns);
     if (lds_ok) {
         int T = 1;
         for (int s = 0; s < ns; ++s) {
@@ -1033,7 +1078,7 @@ int plan_axis(ig_ctx* ctx, ig_fft* p, int a) {
             }
         }
     }
-    if (!lds_ok && !two_stage) {
+    if (!lds_ok && !two_stage && !ab) {
         ax.kind = 1;
         factor_generic(ax.n, ax.gen_radices);
         ax.nstages = (int)ax.gen_radices.size();
@@ -1184,9 +1229,9 @@ int ig_fft_plan(ig_ctx* ctx, int rank, const int64_t* dims, int64_t batch, ig_ff
     for (int a = 0; a < rank; ++a) {
         const AxisPlan& ax = p->axis[a];
         if (ax.kind == 2) { snprintf(buf, sizeof(buf), "axis%d n=1 skip; ", a); p->desc += buf; continue; }
-        snprintf(buf, sizeof(buf), "axis%d n=%lld %s", a, (long long)ax.n, ax.kind == 0 ? "lds" : ax.kind == 3 ? "2stage" : "generic");
+        snprintf(buf, sizeof(buf), "axis%d n=%lld %s", a, (long long)ax.n, ax.kind == 0 ? "lds" : ax.kind == 3 ? "2stage" : ax.kind == 4 ? "AxB" : "generic");
         p->desc += buf;
-        if (ax.kind == 0 || ax.kind == 3) {
+        if (ax.kind == 0 || ax.kind == 3 || ax.kind == 4) {
             snprintf(buf, sizeof(buf), " W=%d T=%d lds=%zuB radices=", ax.W, ax.T, ax.lds_bytes);
             p->desc += buf;
             for (int s = 0; s < ax.nstages; ++s) { snprintf(buf, sizeof(buf), s ? "x%d" : "%d", ax.rad.r[s]); p->desc += buf; }
@@ -1317,6 +1362,10 @@ int ig_fft_exec(ig_fft* p, const void* xv, void* yv, int direction, void* worksp
             d.in_s[2] = d.out_s[2] = 0;
             d.in_lo = d.out_lo = 0; d.in_hi = d.out_hi = (int)ax.n; d.inverse = inverse;
             if (int rc = launch_2stage(ctx, ax, d, ax.inner == 1, 0)) return rc;
+            cur = y;
+        } else if (ax.kind == 4) {
+            ig_prof_scope prof(ctx, a == 0 ? "fft_ab_axis0" : a == 1 ? "fft_ab_axis1" : "fft_ab_axis2", pass_bytes);
+            if (int rc = launch_ab(ctx, ax, cur, y, inverse)) return rc;
             cur = y;
         } else if (ax.kind == 0) {
             ig_prof_scope prof(ctx, a == 0 ? "fft_lds_axis0" : a == 1 ? "fft_lds_axis1" : "fft_lds_axis2", pass_bytes);

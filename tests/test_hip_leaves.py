@@ -391,6 +391,37 @@ def test_fft_shapes(hip, shape):
     _check_fft(hip, tuple(shape), 3, seed=sum(shape))
 
 
+AB_LENGTHS = [270, 288, 320, 360, 384, 392, 400, 432, 480, 576, 600, 640]
+
+
+@pytest.mark.parametrize("n", AB_LENGTHS)
+def test_fft_two_stage_any_length(hip, n):
+    """the register-resident A x B passes (ig_fft_ab.h; lengths of the reference's example grids, examples/pics.py:87-90)
+    against numpy: as contiguous lines (ragged last tile: 21 lines), as a strided middle axis, as a strided last axis with
+    5 columns, forward + inverse + in place; and the same transform through the LDS kernel"""
+    assert "AxB" in hip.fft_describe((n, 3))
+    _check_fft(hip, (n,), 21, seed=n)
+    _check_fft(hip, (6, n), 3, seed=n + 1)
+    _check_fft(hip, (5, 3, n), 2, seed=n + 2)
+
+
+def test_fft_two_stage_any_length_3d_and_lds_agreement(hip, monkeypatch):
+    """three different A x B lengths in one 3-D transform (axis 0 contiguous, axes 1 and 2 strided, batch 2) against numpy, and
+    against the multi-stage LDS kernel on the same data"""
+    from indigo_amd.backends import get_backend
+    shape = (320, 270, 288)
+    _check_fft(hip, shape, 2, seed=7)
+    x = rand64c(*(shape + (1,)), seed=8)
+    y_d = hip.zero_array(x.shape, C64)
+    hip.fftn(y_d, hip.copy_array(x))
+    monkeypatch.setenv("INDIGO_HIP_FFT_AB", "0")
+    other = get_backend("hip")
+    assert "AxB" not in other.fft_describe(x.shape) and "lds" in other.fft_describe(x.shape)
+    z_d = other.zero_array(x.shape, C64)
+    other.fftn(z_d, other.copy_array(x))
+    assert rel_err(z_d.to_host(), y_d.to_host()) < 1e-6
+
+
 def test_fft_generic_path_matches_lds_path(hip, monkeypatch):
     """the global-memory fallback and the LDS kernels compute the same transform"""
     from indigo_amd.backends import get_backend
