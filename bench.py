@@ -81,7 +81,7 @@ def kernel_symbols(layout, ncoils, half_box=True, n=512):
                       "fft_crop_z": f % "16, false, 0, true, 0", "fft_crop_y": f % "32, false, 0, true, 0",
                       "fft_crop_x": f % ("16, false, %d, true, 0" % (3 + lg))})
         m.update({"csrmm_rowlane_conj": "k_csrmm_dense64<%d, true, true>" % ncoils, "csrmm_gather": gv,
-                  "csrmm_bricks_conj": "k_grid_bricks<%d>" % ncoils})
+                  "csrmm_bricks_conj": "k_grid_bricks<%d, %d>" % (ncoils, 4 if ncoils == 8 else 0)})
     elif layout == 1:
         h = (3, 1, 1, 2, 2, 4) if half_box else (0,) * 6
         m.update({"fft_pad_x": f % ("16, true, 1, true, %d" % h[0]), "fft_pad_y": f % ("16, false, 0, true, %d" % h[1]),

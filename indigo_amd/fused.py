@@ -111,11 +111,13 @@ def assemble(backend, Gm, oN, N, weights_of, Cn, layout, chunks, table=None, box
             G._grid_support = (table, int(oN[0]), int(oN[2]))
         if row_order is not None:
             G._row_order = row_order
-        elif (interleaved and bricks_cols == 8 and os.environ.get("INDIGO_HIP_SPMM_BRICKS", "1") != "0"
+        elif (interleaved and os.environ.get("INDIGO_HIP_SPMM_BRICKS", "1") != "0"
+              and (bricks_cols == 8 or (bricks_cols == 4 and os.environ.get("INDIGO_HIP_SPMM_BRICKS", "1") != "8"))
               and int(oN[2]) % 4 == 0 and int(oN[1]) % 4 == 0):
             # adjoint gridding by grid bricks (a scatter binned on the host) instead of a gather over the transposed matrix.
-            # Measured: 8 coils 1.60 ms against 1.82 ms (gather + its deferred long rows); 4 coils 1.15 against 1.05 ms
-            # (the padding unit doubles): only the 8-coil trees take it.
+            # Measured (config 4): 8 coils 0.91 ms against 1.82 ms (gather + its deferred long rows); 4 coils 0.68 against
+            # 1.05 ms.  Two coils or one would pad every sample's share of a brick to 32 / 64 entries: they keep the gather.
+            # INDIGO_HIP_SPMM_BRICKS: 0 never, 8 only the 8-coil trees.
             G._grid_bricks = (int(oN[0]), int(oN[2]), int(oN[1]), bricks_cols)
         return G
 

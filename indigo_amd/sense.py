@@ -205,8 +205,9 @@ class SenseProblem(object):
         return {
             "csrmm_gather": nnz * 12 + (T + 1) * 4 + touched * e + T * e,
             "csrmm_rowlane_conj": nnz * 12 + (sup + 1) * 4 + T * e + sup * e,
-            # brick-binned scatter: 16-byte entries (their padding is counted by the caller if it knows it), panel, flagged rows
-            "csrmm_bricks_conj": nnz * 16 + T * e + sup * e,
+            # brick-binned scatter: 12 bytes per nonzero (cell + value; the padding and the row list of the binned format
+            # are overhead, not compulsory), the panel, the flagged rows
+            "csrmm_bricks_conj": nnz * 12 + T * e + sup * e,
             "pack_panel": 2 * T * e,
         }
 
