@@ -234,6 +234,15 @@ int  ig_ccsrmm_t_bricks(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, float alph
                         const int16_t* support, int64_t n0, int64_t nm, int bm, int bs, const int32_t* tasks, int64_t ntasks,
                         const int32_t* brick_table, const int32_t* shared_bricks, int64_t nshared);
 
+/* The same scatter for the reference's own panel layout, 64 columns: Y(K x 64, column-major, ldy) = alpha * A^H * X(M x 64,
+ * column-major, ldx) for ANY CSR matrix with K a multiple of 16 (beta == 0: Y is zeroed first).  Bricks are 16 consecutive
+ * rows of Y: ig_grid_bricks_count / _fill with (n0, nm, ns) = (K, 1, 1), bm = bs = 1, unit = 1 give `entries` (12 bytes:
+ * {row of Y inside the brick, re, im}) and `entry_rows` (= round_rows: the row of X of every entry), both on the device here;
+ * brick_table / tasks as for ig_ccsrmm_t_bricks (at most 64 bricks per run).  M * 512 < 2^31.  BASELINE config 3's adjoint.   */
+int  ig_ccsrmm_t_bricks_wide(ig_ctx* ctx, int64_t M, int64_t K, float alpha_re, float alpha_im,
+                             const void* entries, const uint32_t* entry_rows, const void* X, int64_t ldx, void* Y, int64_t ldy,
+                             const int32_t* tasks, int64_t ntasks, const int32_t* brick_table);
+
 /* Locality-ordered variants.  The caller may store A with its ROWS reordered (row r of the stored
  * matrix is row perm[r] of A; e.g. k-space samples sorted by the grid cell they touch, so that
  * neighbouring rows gather neighbouring panel rows and share cache lines):
@@ -247,6 +256,18 @@ int  ig_ccsrmm_rowperm(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, int64_t nnz
                        float beta_re, float beta_im,
                        void* Y, int64_t ldy,
                        const int32_t* yrow_perm);
+
+/* Forward product over a SUBSET of the panel's rows: colind_c indexes the list `xrows` (device, nxrows ascending row
+ * numbers of X) instead of X itself, i.e. Y = beta*Y + alpha * A' * X[xrows, :] with A' = A restricted to its non-empty
+ * columns.  The repacking pass of a wide panel then reads and writes only the rows some nonzero touches (a gridding
+ * matrix touches 30 % of its 256^3 grid: BASELINE config 3, col_frac of operators.py:246-256).  2 <= N <= 64.        */
+int  ig_ccsrmm_xrows(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, int64_t nnz,
+                     float alpha_re, float alpha_im,
+                     const void* vals, const int32_t* colind_c, const int32_t* rowptr,
+                     const void* X, int64_t ldx,
+                     float beta_re, float beta_im,
+                     void* Y, int64_t ldy,
+                     const int32_t* xrows, int64_t nxrows);
 
 /* Host-side structure analysis.  Replaces `inspect`
  * (indigo/backends/_customcpu.c:179-215): number of non-empty rows / columns

@@ -74,6 +74,11 @@ PROTOTYPES = {
                                    c_float, c_float, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_int64, c_float, c_float, c_void_p, c_int64,
                                    c_void_p, c_int64, c_int64, c_void_p]),
+    "ig_ccsrmm_t_bricks_wide": (c_int, [c_void_p, c_int64, c_int64, c_float, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                                        c_void_p, c_int64, c_void_p]),
+    "ig_ccsrmm_xrows":    (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64,
+                                   c_float, c_float, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_int64, c_float, c_float, c_void_p, c_int64, c_void_p, c_int64]),
     "ig_ccsrmm_rowperm":  (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64,
                                    c_float, c_float, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_int64, c_float, c_float, c_void_p, c_int64, c_void_p]),

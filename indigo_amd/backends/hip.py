@@ -12,6 +12,7 @@ without the built library raises RuntimeError.
 """
 import ctypes
 import logging
+import os
 
 import numpy as np
 
@@ -22,13 +23,13 @@ log = logging.getLogger(__name__)
 _C64 = np.dtype('complex64')
 
 
-def brick_tasks(counts, ptr, chunk, run, max_bricks=64):
+def brick_tasks(counts, ptr, chunk, run, max_bricks=64, longest_first=True):
     """Task list and brick table of ig_ccsrmm_t_bricks (include/indigo_hip.h) from the entries per brick `counts` and their
     prefix sums `ptr`: table = (brick, end of its entries) per non-empty brick; a brick with more than `chunk` entries is
     cut into shared tasks of at most `chunk`; the others are grouped into runs of consecutive table rows -- a new run
     starts when the entry offset crosses a multiple of `run`, after a heavy brick, and after `max_bricks` bricks.  Returns
-    tasks (n, 4) int32 [lo, hi, first table row, rows | shared << 16] sorted longest first, table (nb, 2) int32, and the
-    ids of the shared bricks."""
+    tasks (n, 4) int32 [lo, hi, first table row, rows | shared << 16] sorted longest first (or, longest_first=False, in
+    brick order), table (nb, 2) int32, and the ids of the shared bricks."""
     bricks = np.flatnonzero(counts)
     if bricks.size == 0:
         return np.zeros((0, 4), np.int32), np.zeros((0, 2), np.int32), np.zeros(0, np.int32)
@@ -58,7 +59,8 @@ def brick_tasks(counts, ptr, chunk, run, max_bricks=64):
     phi = np.minimum(plo + chunk, hi_b[hv][rep])
     t_hv = np.stack([plo, phi, hv[rep], np.full(rep.size, 1 | (1 << 16))], axis=1) if rep.size else np.zeros((0, 4), np.int64)
     tasks = np.concatenate([t_hv, t_run]).astype(np.int32)
-    tasks = np.ascontiguousarray(tasks[np.argsort(-(tasks[:, 1] - tasks[:, 0]), kind='stable')])
+    order = np.argsort(-(tasks[:, 1] - tasks[:, 0]), kind='stable') if longest_first else np.argsort(tasks[:, 0], kind='stable')
+    tasks = np.ascontiguousarray(tasks[order])
     return tasks, np.ascontiguousarray(table), bricks[hv].astype(np.int32)
 
 
@@ -666,6 +668,42 @@ class HipBackend(Backend):
                                 rounds=b.copy_array(round_rows, name=self._name + ".brickRoundRows"),
                                 shared=b.copy_array(shared if shared.size else np.zeros(1, np.int32), name=self._name + ".sharedBricks"))
 
+        def _wide_bricks(self):
+            """The matrix binned by bricks of 16 consecutive columns, 12-byte entries {column inside the brick, re, im} + their rows:
+            the format of ig_ccsrmm_t_bricks_wide (adjoint of a 64-column column-major panel as a scatter through LDS).
+            Built on first use; None when the matrix does not qualify (a row touching more than 64 bricks)."""
+            wb = getattr(self, '_wide', False)
+            if wb is not False:
+                return wb
+            b = self._backend
+            m, k = self.shape
+            if self._host_csr is not None:
+                indptr, indices, data = self._host_csr.indptr, self._host_csr.indices, self._host_csr.data
+            else:
+                indptr, indices, data = self.rowPtrs.to_host(), self.colInds.to_host(), self.values.to_host()
+            indptr = np.ascontiguousarray(indptr, dtype=np.int32)
+            indices = np.ascontiguousarray(indices, dtype=np.int32)
+            data = np.ascontiguousarray(data, dtype=_C64)
+            counts = np.zeros(k // 16, dtype=np.int32)
+            rc = b._L.ig_grid_bricks_count(m, indptr.ctypes.data, indices.ctypes.data, k, 1, 1, 1, 1, 1, counts.ctypes.data)
+            if rc != 0:
+                self._wide = None
+                return None
+            ptr = np.zeros(counts.size + 1, dtype=np.int64)
+            np.cumsum(counts, out=ptr[1:])
+            e12 = np.empty((max(int(ptr[-1]), 1), 3), dtype=np.uint32)
+            rows = np.empty(max(int(ptr[-1]), 1), dtype=np.uint32)
+            _lib.check(b._L.ig_grid_bricks_fill(m, indptr.ctypes.data, indices.ctypes.data, data.ctypes.data, k, 1, 1, 1, 1, 1,
+                                                ptr.ctypes.data, e12.ctypes.data, rows.ctypes.data), None, "ig_grid_bricks_fill")
+            wt = [int(t) for t in os.environ.get("INDIGO_HIP_WIDE_TASKS", "4096,1024,1").split(",")]      # piece, run, longest first
+            tasks, table, _ = brick_tasks(counts, ptr, wt[0], wt[1], max_bricks=64, longest_first=bool(wt[2]))
+            self._wide = dict(ntasks=int(tasks.shape[0]),
+                              tasks=b.copy_array(tasks.reshape(-1) if tasks.size else np.zeros(4, np.int32), name=self._name + ".wideTasks"),
+                              table=b.copy_array(table.reshape(-1) if table.size else np.zeros(2, np.int32), name=self._name + ".wideTable"),
+                              entries=b.copy_array(e12.reshape(-1), name=self._name + ".wideEntries"),
+                              rows=b.copy_array(rows, name=self._name + ".wideEntryRows"))
+            return self._wide
+
         def set_row_order(self, perm):
             """Store the matrix with its rows in the order `perm` (stored row r = row perm[r] of A), e.g. gridding
             samples sorted by the grid cell they touch: neighbouring rows then gather neighbouring panel rows.
@@ -696,6 +734,28 @@ class HipBackend(Backend):
                                            ctypes.c_void_p(self.values._arr), ctypes.c_void_p(self.colInds._arr),
                                            ctypes.c_void_p(self.rowPtrs._arr), ctypes.c_void_p(x._arr), br, bi,
                                            ctypes.c_void_p(y._arr), y._leading_dim), "ig_ccsrmm_il")
+                return
+            if perm is None and 16 <= x.shape[1] <= 64 and self._col_frac <= 0.6 \
+                    and self.values.size >= self.shape[1] and os.environ.get("INDIGO_HIP_SPMM_XROWS", "1") != "0":
+                # a wide panel of which the matrix touches a fraction of the rows (a gridding matrix: 30 % of its grid):
+                # the panel is repacked row-major anyway -- repack only the touched rows (ig_ccsrmm_xrows)
+                self._check_panels(y, x, self.values)
+                b = self._backend
+                sub = getattr(self, '_xrows', None)
+                if sub is None:
+                    indices = self._host_csr.indices if self._host_csr is not None else self.colInds.to_host()
+                    touched = np.unique(indices).astype(np.int32)
+                    compact = np.searchsorted(touched, indices).astype(np.int32)
+                    sub = self._xrows = (b.copy_array(touched, name=self._name + ".touchedCols"),
+                                         b.copy_array(compact, name=self._name + ".compactColInds"))
+                ar, ai = _cplx(alpha)
+                br, bi = _cplx(beta)
+                m, k = self.shape
+                b._check(b._L.ig_ccsrmm_xrows(b._ctx, m, k, x.shape[1], self.values.size, ar, ai,
+                                              ctypes.c_void_p(self.values._arr), ctypes.c_void_p(sub[1]._arr),
+                                              ctypes.c_void_p(self.rowPtrs._arr), ctypes.c_void_p(x._arr), x._leading_dim,
+                                              br, bi, ctypes.c_void_p(y._arr), y._leading_dim,
+                                              ctypes.c_void_p(sub[0]._arr), sub[0].size), "ig_ccsrmm_xrows")
                 return
             if perm is None:
                 return super().forward(y, x, alpha=alpha, beta=beta)
@@ -731,6 +791,19 @@ class HipBackend(Backend):
                                                  ctypes.c_void_p(br['table']._arr), ctypes.c_void_p(br['shared']._arr), br['nshared']),
                          "ig_ccsrmm_t_bricks")
                 return
+            if (x.shape[1] == 64 and beta == 0 and perm is None and not getattr(self, '_grid_il', False) and self.shape[1] % 16 == 0
+                    and self.shape[1] > 0 and self.shape[0] * 512 < 2 ** 31 and self.values.size >= self.shape[1] // 4
+                    and os.environ.get("INDIGO_HIP_SPMM_WIDE_BRICKS", "1") != "0"):
+                # 64 columns at the reference boundary (BASELINE config 3): scatter through LDS brick images
+                wb = self._wide_bricks()
+                if wb is not None:
+                    ar, ai = _cplx(alpha)
+                    m, k = self.shape
+                    b._check(b._L.ig_ccsrmm_t_bricks_wide(b._ctx, m, k, ar, ai, ctypes.c_void_p(wb['entries']._arr), ctypes.c_void_p(wb['rows']._arr),
+                                                          ctypes.c_void_p(x._arr), x._leading_dim, ctypes.c_void_p(y._arr), y._leading_dim,
+                                                          ctypes.c_void_p(wb['tasks']._arr), wb['ntasks'], ctypes.c_void_p(wb['table']._arr)),
+                             "ig_ccsrmm_t_bricks_wide")
+                    return
             if getattr(self, '_grid_il', False):
                 assert perm is None and beta == 0 and y.contiguous, "interleaved panels: no row order, beta = 0"
                 pt, it, dt = self._transposed()

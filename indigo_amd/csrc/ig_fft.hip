@@ -989,7 +989,7 @@ namespace {
 
 // ---- two-stage A x B passes (ig_fft_ab.h): the instantiated splits ------------------------------------------------
 #define IG_AB_LIST(X) X(15, 18, 1) X(16, 18, 1) X(16, 20, 1) X(18, 20, 2) X(16, 24, 2) X(14, 28, 2) X(20, 20, 2) \
-                      X(18, 24, 2) X(20, 24, 2) X(24, 24, 2) X(24, 25, 2) X(20, 32, 2)
+                      X(18, 24, 2) X(20, 24, 2) X(24, 24, 2) X(24, 25, 2) X(20, 32, 2) X(16, 32, 2) X(16, 16, 1)
 bool ab_split(int64_t n, int& A, int& B) {
 #define IG_AB_CASE(A_, B_, R_) if (n == (A_) * (B_)) { A = A_; B = B_; return true; }
     IG_AB_LIST(IG_AB_CASE)
@@ -1030,7 +1030,8 @@ int plan_axis(ig_ctx* ctx, ig_fft* p, int a) {
     Radices rad{};
     int ns = 0;
     const char* e2 = getenv("INDIGO_HIP_FFT_2STAGE");
-    const bool two_stage = !force_generic && !(e2 && e2[0] == '0') && (ax.n == 512 || ax.n == 256) &&
+    const bool prefer_ab = getenv("INDIGO_HIP_FFT_AB") && atoi(getenv("INDIGO_HIP_FFT_AB")) == 2;      // A/B runs: 256 / 512 through k_fft_ab
+    const bool two_stage = !force_generic && !prefer_ab && !(e2 && e2[0] == '0') && (ax.n == 512 || ax.n == 256) &&
                            32 * ax.inner * 8 < 0x7fffffffLL;              // 2 GB descriptor window per 16 elements of a column
     if (two_stage) {
         ax.kind = 3; ax.W = 16; ax.T = 16; ax.nstages = 2;

@@ -1034,6 +1034,121 @@ k_grid_bricks(const BrickTask* __restrict__ tasks, int ntasks, const BrickRef* _
     flush();
 }
 
+// ---- the same scatter for a 64-column panel at the reference boundary (column-major Y) -----------------------------
+// Y(K x 64, column-major) = alpha * A^H X for any CSR whose K is a multiple of 16: bricks of 16 consecutive rows of Y,
+// 12-byte entries {row of Y inside the brick, re, im} in brick order plus the row of X of every entry (no padding: a round
+// is ONE entry, the 64 lanes are the 64 columns).  Entries and rows arrive through the scalar cache (wave-uniform
+// addresses: s_load; rows three groups of four ahead, payloads one), the packed X row of an entry is one 512-byte wave
+// load at a scalar offset (two groups ahead), the brick image [16][64 (+1)] sits in LDS, and a finished brick goes out as
+// full 128-byte lines (lanes = 16 rows x 4 columns).  Y is zeroed first (beta == 0: rows no nonzero touches are zero);
+// pieces of heavy bricks add with float atomics.
+constexpr int WIDE_LD = 65;                 // image row stride in float2: conflict-free both as [cell][lane] and transposed
+
+__global__ void __launch_bounds__(BLK)
+k_bricks_wide64(const BrickTask* __restrict__ tasks, int ntasks, const BrickRef* __restrict__ btab,
+                const BrickEntry* __restrict__ entries, const uint32_t* __restrict__ entry_rows,
+                const float2* __restrict__ Xp /* [row][64] */,
+                float2* __restrict__ Y, int64_t ldy, float2 alpha, int xcd_order) {
+    __shared__ float2 acc_all[WAVES_PER_BLOCK * 16 * WIDE_LD];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // xcd_order (INDIGO_HIP_WIDE_XCD=1, off by default): workgroups go round-robin to the 8 XCDs; giving each XCD a contiguous
+    // eighth of a spatially ordered task list keeps the bricks of adjacent planes -- which share X rows -- behind one L2.
+    // Measured on BASELINE config 3: 5.0 ms against 3.3 ms for longest-first tasks in dispatch order: a k-space ball has
+    // most of its nonzeros in the central slabs, and an eighth of the GRID is not an eighth of the WORK.
+    const int per_xcd = (gridDim.x + 7) / 8;
+    const int blk = xcd_order ? (int)(blockIdx.x % 8) * per_xcd + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    const int task = blk * WAVES_PER_BLOCK + wv;
+    if (blk >= (int)gridDim.x || task >= ntasks) return;
+    const BrickTask tk = tasks[task];
+    const int nb = tk.nb_flags & 0xffff;
+    const bool shared = (tk.nb_flags >> 16) & 1;
+    const int32_t nent = tk.hi - tk.lo;
+    float2* __restrict__ acc = acc_all + wv * 16 * WIDE_LD;
+    const BrickEntry* __restrict__ en = entries + tk.lo;
+    const uint32_t* __restrict__ er = entry_rows + tk.lo;
+    const rsrc_t r_x = make_rsrc(Xp);
+
+    struct Pay { BrickEntry e[4]; };
+    struct Rows { uint32_t r[4]; };
+    Pay pa, pb, pc;
+    Rows ra, rb, rc;
+    float2 xa[4], xb[4], xc[4];
+    auto fetch_rows = [&](Rows& g, int gi) {             // wave-uniform addresses: scalar loads
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const int32_t idx = gi * 4 + i; g.r[i] = er[idx < nent ? idx : nent - 1]; }
+    };
+    auto fetch_pay = [&](Pay& g, int gi) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const int32_t idx = gi * 4 + i; g.e[i] = en[idx < nent ? idx : nent - 1]; }
+    };
+    auto request = [&](float2* x, const Rows& g, int gi) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            x[i] = buf_ld<false>(r_x, gi * 4 + i < nent ? (unsigned)lane * 8u : IG_OOB, g.r[i] * 512u);
+    };
+    fetch_rows(ra, 0);
+    fetch_rows(rb, 1);
+    fetch_rows(rc, 2);
+    fetch_pay(pa, 0);
+    const float2 my_ref = buf_ld<false>(make_rsrc(btab + tk.bt), lane < nb ? (unsigned)lane * 8u : IG_OOB, 0);
+    for (int e = lane; e < 16 * WIDE_LD; e += 64) acc[e] = make_float2(0.f, 0.f);
+    request(xa, ra, 0);
+    request(xb, rb, 1);
+    int my_end = 0x7fffffff;
+    if (lane < nb && !shared) my_end = (int)__float_as_uint(my_ref.y) - tk.lo;
+    const int my_row0 = (int)__float_as_uint(my_ref.x) * 16;
+
+    int cur = 0;
+    int32_t cur_end = __builtin_amdgcn_readlane(my_end, 0);
+    auto flush = [&]() {
+        const int row0 = __builtin_amdgcn_readlane(my_row0, cur);
+        const int cell = lane & 15, cg = lane >> 4;
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int col = cg + 4 * i;
+            float2* a = acc + cell * WIDE_LD + col;
+            const float2 o = cmul(alpha, *a);
+            float2* dst = Y + (int64_t)col * ldy + row0 + cell;           // 16 lanes = one 128-byte line of column `col`
+            if (shared) {
+                asm volatile("global_atomic_add_f32 %0, %1, off\n\tglobal_atomic_add_f32 %0, %2, off offset:4"
+                             :: "v"(dst), "v"(o.x), "v"(o.y) : "memory");
+            } else {
+                asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(dst), "v"(o) : "memory");
+            }
+            *a = make_float2(0.f, 0.f);
+        }
+        ++cur;
+        cur_end = __builtin_amdgcn_readlane(my_end, cur & 63);
+    };
+    // group gi: request the X rows of group gi + 2, fetch the rows of gi + 3 and the payloads of gi + 1, accumulate gi
+    auto body = [&](const Pay& p, Pay& pnext, const float2* x, float2* x2, const Rows& r2, Rows& r3, int gi) {
+        request(x2, r2, gi + 2);
+        fetch_rows(r3, gi + 3);
+        fetch_pay(pnext, gi + 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int32_t idx = gi * 4 + i;
+            if (idx < nent) {
+                if (idx >= cur_end) flush();
+                const float vr = p.e[i].re, vi = p.e[i].im;
+                float2* a = acc + (int)p.e[i].cell * WIDE_LD + lane;
+                float2 t = *a;
+                t.x += fmaf(vr, x[i].x, vi * x[i].y);                     // conj(v) * x
+                t.y += fmaf(vr, x[i].y, -vi * x[i].x);
+                *a = t;
+            }
+        }
+    };
+    const int ngroup = (nent + 3) / 4;
+    for (int gi = 0; gi < ngroup; gi += 3) {             // (groups past the end do nothing: no early exit, see k_grid_bricks)
+        body(pa, pb, xa, xc, rc, ra, gi);
+        body(pb, pc, xb, xa, ra, rb, gi + 1);
+        body(pc, pa, xc, xb, rb, rc, gi + 2);
+    }
+    flush();
+}
+
 // zero the flagged segments of the bricks that several tasks add into
 template <int NC>
 __global__ void __launch_bounds__(BLK)
@@ -1108,7 +1223,7 @@ int launch_gather(ig_ctx* ctx, int64_t rows, int64_t xrows, int64_t N, int64_t n
     // Packing costs one read + one write of the panel (16 B per element) and turns nnz*N scattered 8-byte gathers
     // (each pulling a 32..64-byte sector) into nnz contiguous N*8-byte ones: worth it once every panel row is
     // gathered at least about once (nnz >= xrows); always for small hot panels.
-    if (!x_il && ((N >= 2 && N <= 64 && nnz >= xrows) || (xperm && N <= 8)) && env_flag("INDIGO_HIP_SPMM_PACK", true)) {
+    if (!x_il && ((N >= 2 && N <= 64 && nnz >= xrows) || (xperm && N <= 64)) && env_flag("INDIGO_HIP_SPMM_PACK", true)) {
         const int np = s.CL;             // pow2 >= N, <= 64
         const size_t need = (size_t)xrows * np * 8;
         // The repack buffer is a per-context scratch that only grows (reported by ig_mem_info, not by the caller's own
@@ -1146,7 +1261,7 @@ int launch_gather(ig_ctx* ctx, int64_t rows, int64_t xrows, int64_t N, int64_t n
             X = xp; sxc = 1; sxr = np; packed = true;
         }
     }
-    IG_REQUIRE(ctx, !xperm || packed, "csrmm: a panel-row permutation needs the packed path (N <= 8 and room for the repacked panel: a quarter of the free device memory, at most 16 GiB)");
+    IG_REQUIRE(ctx, !xperm || packed, "csrmm: a panel-row list needs the packed path (2..64 columns and room for the repacked panel: a quarter of the free device memory, at most 16 GiB)");
     const int rpw = 64 / (s.CL * s.NL);
     const int64_t waves = (rows + rpw - 1) / rpw;
     const int64_t blocks = (waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
@@ -1443,6 +1558,21 @@ int ig_ccsrmm_rowperm(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, int64_t nnz,
                                 GridMask{nullptr, 0, 0}, yrow_perm, nullptr);
 }
 
+int ig_ccsrmm_xrows(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, int64_t nnz,
+                    float ar, float ai, const void* vals, const int32_t* colind_c, const int32_t* rowptr,
+                    const void* X, int64_t ldx, float br, float bi, void* Y, int64_t ldy,
+                    const int32_t* xrows, int64_t nxrows) {
+    IG_REQUIRE(ctx, ctx != nullptr, "ig_ccsrmm_xrows: ctx is NULL");
+    if (int rc = check_panel_args(ctx, "ig_ccsrmm_xrows", K, M, N, nnz, vals, colind_c, rowptr, X, ldx, Y, ldy)) return rc;
+    IG_REQUIRE(ctx, nxrows >= 0 && nxrows <= K && (nxrows == 0 || xrows), "ig_ccsrmm_xrows: bad row list");
+    IG_REQUIRE(ctx, N >= 2 && N <= 64 || N == 0, "ig_ccsrmm_xrows: 2..64 panel columns (the subset is gathered while the panel is repacked)");
+    if (N == 0 || M == 0) return IG_OK;
+    if (int rc = ig_set_device(ctx)) return rc;
+    return launch_gather<false>(ctx, M, nxrows, N, nnz, rowptr, colind_c, (const float2*)vals,
+                                (const float2*)X, ldx, (float2*)Y, ldy, make_float2(ar, ai), make_float2(br, bi),
+                                GridMask{nullptr, 0, 0}, nullptr, xrows);
+}
+
 int ig_ccsrmm_t_grid(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, int64_t nnz,
                      float ar, float ai, const void* vals_t, const int32_t* colind_t, const int32_t* rowptr_t,
                      const void* X, int64_t ldx, float br, float bi, void* Y, int64_t ldy,
@@ -1636,6 +1766,48 @@ int ig_ccsrmm_t_bricks(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, float ar, f
     else IG_BRICKS(4, 0);
 #undef IG_BRICKS
     IG_LAUNCH_CHECK(ctx, "k_grid_bricks");
+    return IG_OK;
+}
+
+int ig_ccsrmm_t_bricks_wide(ig_ctx* ctx, int64_t M, int64_t K, float ar, float ai,
+                            const void* entries, const uint32_t* entry_rows, const void* X, int64_t ldx, void* Y, int64_t ldy,
+                            const int32_t* tasks, int64_t ntasks, const int32_t* brick_table) {
+    IG_REQUIRE(ctx, ctx != nullptr, "ig_ccsrmm_t_bricks_wide: ctx is NULL");
+    const int64_t N = 64;
+    IG_REQUIRE(ctx, M >= 0 && K >= 0 && K % 16 == 0 && K <= 0x7fffffffLL, "ig_ccsrmm_t_bricks_wide: K (%lld) must be a multiple of 16", (long long)K);
+    IG_REQUIRE(ctx, (ntasks == 0 || (entries && entry_rows && tasks && brick_table)) && (M == 0 || X) && (K == 0 || Y) && ldx >= M && ldy >= K,
+               "ig_ccsrmm_t_bricks_wide: NULL array or short leading dimension");
+    IG_REQUIRE(ctx, ntasks >= 0 && ntasks <= 0x7fffffffLL, "ig_ccsrmm_t_bricks_wide: bad task list");
+    IG_REQUIRE(ctx, M * N * 8 < 0x7fffffffLL, "ig_ccsrmm_t_bricks_wide: the panel (%lld x 64) exceeds the 2 GB window of a buffer descriptor", (long long)M);
+    if (K == 0) return IG_OK;
+    if (int rc = ig_set_device(ctx)) return rc;
+    {
+        ig_prof_scope prof(ctx, "bricks_wide_zero", (double)K * N * 8.0);
+        if (ldy == K) IG_HIP(ctx, hipMemsetAsync(Y, 0, (size_t)K * N * 8, ctx->stream));
+        else IG_HIP(ctx, hipMemset2DAsync(Y, (size_t)ldy * 8, 0, (size_t)K * 8, (size_t)N, ctx->stream));
+    }
+    if (ntasks == 0 || M == 0) return IG_OK;
+    const size_t need = (size_t)M * N * 8;
+    if (ctx->xpack_bytes < need) {
+        if (ctx->d_xpack) { IG_HIP(ctx, hipStreamSynchronize(ctx->stream)); IG_HIP(ctx, hipFree(ctx->d_xpack)); ctx->d_xpack = nullptr; ctx->xpack_bytes = 0; }
+        IG_HIP(ctx, hipMalloc((void**)&ctx->d_xpack, need));
+        ctx->xpack_bytes = need;
+    }
+    float2* xp = (float2*)ctx->d_xpack;
+    {
+        ig_prof_scope prof(ctx, "pack_panel", 2.0 * (double)need);
+        int64_t gt = (M + 63) / 64;
+        const int64_t cap = (int64_t)ctx->num_cu * 16;
+        if (gt > cap) gt = cap;
+        hipLaunchKernelGGL(k_pack_panel_tiled<64>, dim3((unsigned)gt), dim3(BLK), 0, ctx->stream, M, N, (const float2*)X, ldx, xp, (const int32_t*)nullptr);
+        IG_LAUNCH_CHECK(ctx, "k_pack_panel");
+    }
+    ig_prof_scope prof(ctx, "csrmm_bricks_wide_conj");
+    const unsigned blocks = (unsigned)((((ntasks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK) + 7) / 8 * 8);      // a multiple of 8: see the XCD order
+    static const int wide_xcd = getenv("INDIGO_HIP_WIDE_XCD") ? atoi(getenv("INDIGO_HIP_WIDE_XCD")) : 0;
+    hipLaunchKernelGGL(k_bricks_wide64, dim3(blocks), dim3(BLK), 0, ctx->stream, (const BrickTask*)tasks, (int)ntasks, (const BrickRef*)brick_table,
+                       (const BrickEntry*)entries, entry_rows, (const float2*)xp, (float2*)Y, ldy, make_float2(ar, ai), wide_xcd);
+    IG_LAUNCH_CHECK(ctx, "k_bricks_wide64");
     return IG_OK;
 }
 

@@ -169,5 +169,7 @@ def test_brick_task_list_covers_every_entry_once():
                 assert lo == ptr[bricks[0]] and hi == table[bt + nb - 1, 1] == ptr[bricks[-1] + 1]
                 assert counts[bricks[0]:bricks[-1] + 1].sum() == hi - lo              # nothing but empty bricks in between
         assert np.all(covered == 1)
+        ordered, table2, _ = brick_tasks(counts, ptr, chunk, run, max_bricks=cap, longest_first=False)
+        assert np.all(np.diff(ordered[:, 0]) > 0) and sorted(map(tuple, ordered)) == sorted(map(tuple, tasks))     # same tasks, entry order
     t, tb, sh = brick_tasks(np.zeros(10, np.int32), np.zeros(11, np.int64), 64, 64)
     assert t.shape == (0, 4) and tb.shape == (0, 2) and sh.size == 0

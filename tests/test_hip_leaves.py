@@ -203,6 +203,86 @@ def test_csr_matrix_vs_scipy(hip, M, K, n, density):
     hip.adjoint_policy = "transpose"
 
 
+@pytest.mark.parametrize("K,alpha,ld_pad,dense_blob", [(4096, 1, 0, False), (20000 // 16 * 16, 0.5 - 0.25j, 5, True), (64, 2, 0, False)])
+def test_wide_panel_adjoint_by_bricks(hip, monkeypatch, K, alpha, ld_pad, dense_blob):
+    """ig_ccsrmm_t_bricks_wide: A^H X for a 64-column column-major panel as a scatter binned by 16-row bricks of the result --
+    against scipy in double precision and against the gather route; rows no nonzero touches come out zero over a
+    sentinel; a dense blob of columns makes heavy bricks (pieces adding with atomics); sliced panels (padded leading dimension)"""
+    M = 5000
+    rng = np.random.default_rng(K)
+    rows = np.repeat(np.arange(M), 27)
+    cols = rng.integers(0, K, size=rows.size)
+    if dense_blob:
+        hot = rng.integers(1000, 1040, size=rows.size)                    # 40 hot columns: > 4096 entries per brick
+        cols = np.where(rng.random(rows.size) < 0.5, hot, cols)
+    cols[rows % 7 == 0] = (cols[rows % 7 == 0] // 3) * 3                   # some structure, duplicates summed
+    A = spp.csr_matrix((rand64c(rows.size, seed=1), (rows, cols)), shape=(M, K))
+    A.sum_duplicates(); A.sort_indices()
+    A_d = hip.csr_matrix(hip, A)
+    xfull = rand64c(M + ld_pad, 64, seed=2)
+    yfull = np.full((K + ld_pad, 64), 7 - 3j, dtype=C64, order='F')
+    x_d = hip.copy_array(xfull)[0:M, :]
+    y_d = hip.copy_array(yfull)[0:K, :]
+    A_d.adjoint(y_d, x_d, alpha=alpha)
+    assert A_d._wide is not None and A_d._wide['ntasks'] > 0
+    exp = alpha * (A.conj().T.astype(np.complex128) @ xfull[:M].astype(np.complex128))
+    got = y_d.to_host()
+    assert rel_err(got, exp) < RTOL
+    untouched = np.setdiff1d(np.arange(K), np.unique(A.indices))
+    assert np.all(got[untouched] == 0)
+    monkeypatch.setenv("INDIGO_HIP_SPMM_WIDE_BRICKS", "0")
+    B_d = hip.csr_matrix(hip, A)
+    y2 = hip.copy_array(yfull)[0:K, :]
+    B_d.adjoint(y2, x_d, alpha=alpha)
+    assert getattr(B_d, '_wide', False) is False
+    assert rel_err(y2.to_host(), got) < 1e-5
+    # beta != 0 keeps the contract through the gather route
+    monkeypatch.delenv("INDIGO_HIP_SPMM_WIDE_BRICKS")
+    y3 = hip.copy_array(yfull)[0:K, :]
+    A_d.adjoint(y3, x_d, alpha=alpha, beta=0.5)
+    assert rel_err(y3.to_host(), exp + 0.5 * yfull[:K]) < RTOL
+
+
+@pytest.mark.parametrize("n,frac,alpha,beta,ld_pad", [(64, 0.3, 1, 0, 0), (64, 0.05, 0.5 - 1j, 1.5, 7), (32, 0.5, 1, 1, 0), (16, 0.3, 2, 0, 3),
+                                                     (17, 0.3, 1, 0.5j, 0), (48, 0.6, 1, 0, 0)])
+def test_wide_panel_forward_over_touched_rows(hip, monkeypatch, n, frac, alpha, beta, ld_pad):
+    """ig_ccsrmm_xrows: a wide panel (16..64 columns) of which the matrix touches a fraction of the rows -- only those are
+    repacked; same product as scipy and as the whole-panel route, with alpha/beta and sliced (padded leading dimension)
+    panels, also after the adjoint has consumed the host copy of the matrix"""
+    M, K = 3000, 20000
+    rng = np.random.default_rng(n * 10 + int(frac * 100))
+    cols_used = np.sort(rng.choice(K, size=int(K * frac), replace=False))
+    rows = np.repeat(np.arange(M), 27)
+    cols = cols_used[rng.integers(0, cols_used.size, size=rows.size)]
+    A = spp.csr_matrix((rand64c(rows.size, seed=1), (rows, cols)), shape=(M, K))
+    A.sum_duplicates(); A.sort_indices()
+    A_d = hip.csr_matrix(hip, A)
+    assert A_d._col_frac <= 0.6
+    xfull = rand64c(K + ld_pad, n, seed=2)
+    yfull = rand64c(M + ld_pad, n, seed=3)
+    x_d = hip.copy_array(xfull)[0:K, :]
+    y_d = hip.copy_array(yfull)[0:M, :]
+    A_d.forward(y_d, x_d, alpha=alpha, beta=beta)
+    assert getattr(A_d, '_xrows', None) is not None and A_d._xrows[0].size == np.unique(A.indices).size
+    exp = alpha * (A.astype(np.complex128) @ xfull[:K].astype(np.complex128)) + beta * yfull[:M]
+    assert rel_err(y_d.to_host(), exp) < RTOL
+    # the whole-panel route gives the same
+    monkeypatch.setenv("INDIGO_HIP_SPMM_XROWS", "0")
+    B_d = hip.csr_matrix(hip, A)
+    y2 = hip.copy_array(yfull)[0:M, :]
+    B_d.forward(y2, x_d, alpha=alpha, beta=beta)
+    assert getattr(B_d, '_xrows', None) is None
+    assert rel_err(y2.to_host(), y_d.to_host()) < 1e-6
+    monkeypatch.delenv("INDIGO_HIP_SPMM_XROWS")
+    # adjoint first (the host copy goes into the transpose), then the forward: the column list comes from the device copy
+    C_d = hip.csr_matrix(hip, A)
+    xa = hip.copy_array(rand64c(M, 2, seed=4))
+    C_d.adjoint(hip.zero_array((K, 2), C64), xa)
+    y3 = hip.copy_array(yfull)[0:M, :]
+    C_d.forward(y3, x_d, alpha=alpha, beta=beta)
+    assert rel_err(y3.to_host(), exp) < RTOL
+
+
 @pytest.mark.parametrize("M,n,K,alpha,beta", itertools.product([23, 45], [1, 8, 17], [18, 19], [0.0, 0.5, 1.5], [0.0, 1.0, 1.5]))
 def test_exwrite_csr_matrix(hip, M, n, K, alpha, beta):
     """at most one nonzero per column (reference test_backends.py:213-243)"""
