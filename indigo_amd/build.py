@@ -59,7 +59,7 @@ def _hipcc():
 def build(force=False, verbose=False):
     """Compile every HIP translation unit and link the shared library.  Returns its path."""
     os.makedirs(OBJDIR, exist_ok=True)
-    headers = [os.path.join(INCLUDE, "indigo_hip.h"), os.path.join(CSRC, "ig_common.h")]
+    headers = [os.path.join(INCLUDE, "indigo_hip.h")] + sorted(os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h"))
     hipcc = _hipcc()
     jobs = []
     objs = []

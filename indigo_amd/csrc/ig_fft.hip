@@ -988,7 +988,7 @@ struct ig_fft {
 namespace {
 
 // ---- two-stage A x B passes (ig_fft_ab.h): the instantiated splits ------------------------------------------------
-#define IG_AB_LIST(X) X(15, 18, 1) X(16, 18, 1) X(16, 20, 1) X(18, 20, 2) X(16, 24, 2) X(14, 28, 2) X(20, 20, 2) \
+#define IG_AB_LIST(X) X(10, 16, 1) X(12, 16, 1) X(14, 16, 1) X(15, 16, 1) X(15, 18, 1) X(16, 18, 1) X(16, 20, 1) X(18, 20, 2) X(16, 24, 2) X(14, 28, 2) X(20, 20, 2) \
                       X(18, 24, 2) X(20, 24, 2) X(24, 24, 2) X(24, 25, 2) X(20, 32, 2) X(16, 32, 2) X(16, 16, 1)
 bool ab_split(int64_t n, int& A, int& B) {
 #define IG_AB_CASE(A_, B_, R_) if (n == (A_) * (B_)) { A = A_; B = B_; return true; }

@@ -1,4 +1,4 @@
-// Two-stage axis passes for transform lengths n = A * B that are not powers of two (320, 432, 480, 640, ...: the
+// Two-stage axis passes for transform lengths n = A * B that are not powers of two (160 ... 640: 320, 432, 480, 640 are the
 // oversampled grids of the reference's own example, examples/pics.py:87-90 -- 640/480, 270/208, 432/308, 288/208, 400/308,
 // 600/480, 392/308).  Same shape as the power-of-two kernel k_fft_2stage (ig_fft.hip) -- a column lives in the registers
 // of B threads, one LDS exchange between two register-resident DFTs, one read and one write of every element per pass --

@@ -471,7 +471,7 @@ def test_fft_shapes(hip, shape):
     _check_fft(hip, tuple(shape), 3, seed=sum(shape))
 
 
-AB_LENGTHS = [270, 288, 320, 360, 384, 392, 400, 432, 480, 576, 600, 640]
+AB_LENGTHS = [160, 192, 224, 240, 270, 288, 320, 360, 384, 392, 400, 432, 480, 576, 600, 640]
 
 
 @pytest.mark.parametrize("n", AB_LENGTHS)
