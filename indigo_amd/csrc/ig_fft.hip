@@ -1117,8 +1117,11 @@ int launch_2stage(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d_in, bool ax
                    "ig_fft: axis stride too large for the two-stage kernel");
     }
     const dim3 grid((unsigned)blocks), block((unsigned)(ax.W * ax.T));
+    // INDIGO_HIP_FFT_LDSPAD (bytes, experiment): extra dynamic LDS per workgroup of the 16-column kernels, to LOWER the number of
+    // workgroups per CU (38.9 KB -> 4 per CU; +14 KB -> 3): how much of a pass's speed is occupancy
+    static const size_t lds_pad = getenv("INDIGO_HIP_FFT_LDSPAD") ? (size_t)atoi(getenv("INDIGO_HIP_FFT_LDSPAD")) : 0;
 #define IG_2S(R1_, AX0_, WM_, BX_, HF_)                                                             \
-    hipLaunchKernelGGL((k_fft_2stage<R1_, 16, 16, 16, AX0_, WM_, BX_, HF_>), grid, block, ax.lds_bytes, ctx->stream, d, ax.d_tw)
+    hipLaunchKernelGGL((k_fft_2stage<R1_, 16, 16, 16, AX0_, WM_, BX_, HF_>), grid, block, ax.lds_bytes + lds_pad, ctx->stream, d, ax.d_tw)
 #define IG_2S_W(R1_, AX0_)                                                                           \
     do {                                                                                             \
         if (!boxed && wmode == 0) {                                                                  \
