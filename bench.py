@@ -580,11 +580,26 @@ def bench_spmm(args, local_rank):
     traffic = None
     if pmc:
         traffic = sum(pmc[k]["hbm_bytes_per_launch"] for k in pmc if k.startswith("k_csrmm_gather") or k.startswith("k_pack"))
-    # parity: column 5 against scipy
+    a_traffic = None
+    ktab_f, ktab_a = kernel_table(prof, args.steps), kernel_table(a_prof, args.steps)
+    if pmc:
+        # (the repacking kernel serves both directions under one name and the zero-fill is a runtime kernel: no per-site PMC figure)
+        sym = {"csrmm_gather": "k_csrmm_gather", "csrmm_bricks_wide_conj": "k_bricks_wide64"}
+        for tab in (ktab_f, ktab_a):
+            for site, ent in tab.items():
+                ks = [k for k in pmc if isinstance(pmc[k], dict) and sym.get(site) and k.startswith(sym[site])]
+                if ks and ent.get("avg_ms"):
+                    ent["pmc_bytes_per_launch"] = pmc[ks[0]]["hbm_bytes_per_launch"]
+                    ent["pmc_GBps"] = round(pmc[ks[0]]["hbm_bytes_per_launch"] / (ent["avg_ms"] * 1e-3) / 1e9, 1)
+        a_traffic = sum(e.get("pmc_bytes_per_launch", e.get("bytes_per_launch") or 0.0) * e["launches_per_step"] for e in ktab_a.values()) or None
+    # parity: column 5 against scipy, forward and adjoint
     x5 = X[:, 5:6].to_host()
     y5 = Y[:, 5:6].to_host()
     ref = G @ x5
     perr = float(np.linalg.norm(y5 - ref) / np.linalg.norm(ref))
+    z5 = Z[:, 5:6].to_host()
+    refa = G.conj().T.astype(np.complex128) @ y5.astype(np.complex128)
+    perr_a = float(np.linalg.norm(z5 - refa) / np.linalg.norm(refa))
     cpu = None
     if not args.no_cpu_baseline:
         xs = np.asfortranarray(X[:, 0:8].to_host())
@@ -601,7 +616,10 @@ def bench_spmm(args, local_rank):
            "config": {"workload": "BASELINE config 3: forward csrmm through Backend.ccsrmm (column-major panels), adjoint reported beside it",
                       "col_frac": M._col_frac, "adjoint_ms": a_ms,
                       "adjoint_GBps_reference_model": ab / (a_ms * 1e-3) / 1e9,
-                      "adjoint_frac_of_peak_reference_model": ab / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                      "adjoint_frac_of_peak_reference_model": ab / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      "adjoint_traffic": a_traffic,
+                      "adjoint_traffic_frac_of_peak": (a_traffic / (a_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if a_traffic else None,
+                      "adjoint_parity_rel_err_vs_float64": perr_a},
            "roofline": dict(bound="hbm", kernel="forward product (%s)" % " + ".join(sorted(prof)), achieved=fb / (ms * 1e-3) / 1e9,
                             peak=HBM_PEAK_GBS, unit="GB/s", frac=fb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             algorithmic_bytes_per_launch=fb,
@@ -609,7 +627,7 @@ def bench_spmm(args, local_rank):
                             traffic=traffic, traffic_source=src if traffic else None,
                             traffic_frac_of_peak=(traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None),
            "cpu_baseline": cpu, "parity_rel_err": perr,
-           "kernels": {"forward": kernel_table(prof, args.steps), "adjoint": kernel_table(a_prof, args.steps)}}
+           "kernels": {"forward": ktab_f, "adjoint": ktab_a}}
     print(json.dumps(out), flush=True)
 
 
