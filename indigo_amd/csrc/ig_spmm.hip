@@ -845,18 +845,21 @@ k_pack_panel_tiled(int64_t rows, int64_t N, const float2* __restrict__ X, int64_
 // Y_il = alpha * G^H X for a gridding matrix G (rows = k-space samples, ~27 taps each, columns = grid points numbered
 // kx + n0*(km + nm*ks)) -- the SCATTER view, made race-free by binning.  The grid is cut into bricks of 16 x BM x BS cells.
 // On the host the nonzeros are sorted by the brick of their column (stable: inside a brick they stay in sample order)
-// into 16-byte entries {sample, cell inside the brick, value}; the entries one sample has in one brick are padded to a
-// multiple of 64/NC, so that ONE wave instruction -- 64/NC entries x NC coils -- only ever holds entries of one sample,
-// i.e. distinct cells.  ONE WAVE owns a brick: it streams the brick's entries (coalesced, no pointer chasing), gathers
-// X[sample, :] and accumulates conj(value) * X into its own LDS image of the brick with plain read-add-write (no other wave
-// touches that image, no two lanes of an instruction share a cell, LDS operations of a wave execute in order), then
-// stores the flagged 16-row segments with coalesced 16-byte stores.  Bricks near the k-space centre hold 10^4..10^5
-// nonzeros: their entry ranges are cut into tasks, each task adds its image into the (pre-zeroed) grid with float atomics.
+// into 12-byte entries {cell inside the brick, value}; the entries one sample has in one brick are padded to a multiple of
+// 64/NC -- a ROUND: one wave instruction of the accumulation, 64/NC entries x NC coils, only ever holds entries of one
+// sample, i.e. distinct cells -- and the sample of every round goes into a separate list (round_rows).  A WAVE owns a run of
+// consecutive non-empty bricks: it streams their entries (coalesced, no pointer chasing, nothing depends on a previous
+// load), gathers X[sample, :] and accumulates conj(value) * X into ONE LDS image of the current brick with plain
+// read-add-write (no other wave touches that image, no two lanes of an instruction share a cell, LDS operations of a wave
+// execute in order), and at each brick boundary stores the flagged 16-row segments (512-byte wave stores) and clears the
+// image.  Bricks near the k-space centre hold 10^4..10^5 nonzeros: their entry ranges are cut into pieces, each piece adds
+// its image into the (pre-zeroed) grid with float atomics.
 //
 // Against the gather over the transpose (k_csrmm_dense64): no 134-M-entry row-pointer array, no per-row segmented sums,
-// no deferred long rows.  Two versions were measured on the way: per-brick SAMPLE lists walked through
-// pairs -> rowptr -> colind/vals (6.7 ms: dependent loads at 8 waves per CU), and a workgroup per brick with LDS float
-// atomics (5.4 ms: ds_add_f32 retires about one lane every four clocks -- 800 M lane-atomics per evaluation).
+// no deferred long rows.  Measured on the way (BASELINE config 4, 8 coils; the gather took 1.82 ms): per-brick SAMPLE lists
+// walked through pairs -> rowptr -> colind/vals (6.7 ms: dependent loads at 8 waves per CU); a workgroup per brick with LDS
+// float atomics (5.4 ms: ds_add_f32 retires about one lane every four clocks); a wave per brick, every lane loading its own
+// copy of the entry and the X value (1.60 ms); runs of bricks (1.31 ms); the form below (0.91 ms).
 struct BrickTask { int32_t lo, hi, bt, nb_flags; };     // entries [lo, hi) = bricks table[bt .. bt + (nb_flags & 0xffff)); bit 16: shared
 struct BrickRef { int32_t brick, end; };                  // a non-empty brick and where its entries end
 struct BrickEntry { uint32_t cell; float re, im; };       // 12 bytes; cell == 0xffffffff: padding
