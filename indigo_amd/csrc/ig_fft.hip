@@ -1156,7 +1156,9 @@ int launch_2stage(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d_in, bool ax
     const bool big_stride = (d.in_sj > d.out_sj ? d.in_sj : d.out_sj) * 8 >= (1 << 20);
     // boxed passes WITHOUT a compile-time half box (e.g. the 320-point box of a 512-point axis, oversampling 1.6) also take
     // 32-column tiles when one side runs at a huge stride: cropped y pass of config 5 0.85 -> 0.74 ms, padded y pass unchanged
-    const bool w32_generic = use_w32 && use_w32 != 3 && boxed && half == 0 && big_stride;
+    // ... and so do plain (unboxed) passes at a huge stride, through the same run-time-box variant: the z pass of a plain 512^3
+    // transform steps 2 MB per element (3.82 -> 3.08 ms for 512^3 x 8; INDIGO_HIP_FFT_W32=5 keeps them on 16 columns)
+    const bool w32_generic = use_w32 && use_w32 != 3 && (boxed || use_w32 != 5) && half == 0 && big_stride;
     if (use_w32 && ax.n == 512 && !axis0 && wmode == 0 && !d.cw && d.ext0 % 32 == 0 &&
         (((half == 1 || half == 3) && (big_stride || use_w32 != 3)) || ((half == 2 || half == 4) && (big_stride || use_w32 == 2)) || w32_generic) &&
         (!d.tile_range || d.tile_shift >= 1)) {

@@ -39,6 +39,21 @@ def test_fft_strided_two_stage_axes_vs_numpy(hip, shape):
     assert rel_err(y_d.to_host(), np.fft.ifftn(x.astype(np.complex128), axes=axes) * np.prod(shape)) < RTOL
 
 
+def test_fft_plain_512_axis_at_a_huge_stride_vs_numpy(hip):
+    """a plain (unboxed) 512-point axis 1 MB per element apart takes the 32-column run-time-box variant: (256, 512, 512) against
+    numpy, forward and inverse, one volume"""
+    shape = (256, 512, 512)
+    x = rand64c(*(shape + (1,)), seed=9)
+    x_d = hip.copy_array(x)
+    y_d = hip.zero_array(x.shape, C64)
+    hip.fftn(y_d, x_d)
+    ref = np.fft.fftn(x[..., 0].astype(np.complex128))
+    assert rel_err(y_d.to_host()[..., 0], ref) < RTOL
+    hip.ifftn(y_d, y_d)                                         # in place, inverse: back to n * x
+    assert rel_err(y_d.to_host() / np.prod(shape), x) < RTOL
+    del x_d, y_d
+
+
 def test_config2_fft_256_cubed_batch16(hip):
     """BASELINE config 2 as quoted: 256^3 complex64, 16 batches.  Two of the volumes against numpy, all of them by
     Parseval and the unnormalised round trip; in place and out of place."""
