@@ -533,7 +533,7 @@ class Backend(object):
             is the same either way)."""
             pass
 
-        def set_grid_bricks(self, n0, nm, ns, ncols=8, bm=2, bs=2, chunk=4096):
+        def set_grid_bricks(self, n0, nm, ns, ncols=8, bm=2, bs=2, chunk=4096, run=4096):
             """Hint: the columns index an n0 x nm x ns grid (col = kx + n0*(km + nm*ks)); the adjoint product may bin the rows
             by grid bricks and scatter race-free.  Backends may ignore it."""
             pass

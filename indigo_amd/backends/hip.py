@@ -627,7 +627,7 @@ class HipBackend(Backend):
             self._support = (self._backend.copy_array(np.ascontiguousarray(table, dtype=np.int16).reshape(-1),
                                                       name=self._name + ".support"), int(n0), int(nm))
 
-        def set_grid_bricks(self, n0, nm, ns, ncols=8, bm=2, bs=2, chunk=4096, run=1024):
+        def set_grid_bricks(self, n0, nm, ns, ncols=8, bm=2, bs=2, chunk=4096, run=4096):
             """Sort the nonzeros by the 16 x bm x bs brick of the n0 x nm x ns grid their column falls into (native host
             routine), padded so that a wave instruction (64/ncols entries x ncols panel columns) holds entries of one row
             only, and keep entries + brick table + task list on the device: the adjoint of an `ncols`-column interleaved
