@@ -320,14 +320,16 @@ def run_sense(args, cfg, B, comm, world, rank, steps, warmup, want_cpu, quiet=Fa
     cpr = len(coils) if nchunks == 1 else 8          # coils per chunk seen by one launch
     half_box = all(2 * b == n for b, n in zip(p.N, p.oN))
     if fused_fft:
-        exact = p.zpadfft_pass_bytes(cpr, getattr(p, 'last_support_table', None), fused_sum=(layout == 2))
+        sup_tab, sup_tile = getattr(p, 'last_support_fine', None) or (getattr(p, 'last_support_table', None), 16)
+        exact = p.zpadfft_pass_bytes(cpr, sup_tab, fused_sum=(layout == 2), tile=sup_tile)
         for name, nbytes in exact.items():
             if name in prof:
                 prof[name]['bytes'] = float(nbytes) * prof[name]['launches']
                 # 4 * x.nbytes per 3-D transform, a third per pass; x = grid x coils
                 prof[name]['ref_bytes'] = 4.0 * np.prod(p.oN) * 8.0 * cpr / 3.0 * prof[name]['launches']
     csr = {(r['name'], r['forward']): r['nbytes'] for r in trace.records if r['event'] == 'csrmm' and not r.get('fused')}
-    grid_bytes = p.gridding_pass_bytes(cpr, getattr(p, 'last_support_table', None)) if fused_fft else {}
+    sup_tab, sup_tile = getattr(p, 'last_support_fine', None) or (getattr(p, 'last_support_table', None), 16)
+    grid_bytes = p.gridding_pass_bytes(cpr, sup_tab, tile=sup_tile) if fused_fft else {}
     for site, fwd in (("csrmm_gather", True), ("csrmm_rowlane_conj", False), ("csrmm_gather_conj", False), ("csrmm_bricks_conj", False)):
         nb = csr.get(('interp*mod*scale', fwd))
         if site in prof and nb:

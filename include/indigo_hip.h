@@ -220,7 +220,9 @@ int  ig_ccsrmm_t_grid_il(ig_ctx* ctx,
  * consecutive whole bricks (at most 64 bricks and 256 / (bm*bs) of them; [lo, hi) is exactly their entries) or a piece of
  * ONE heavy brick, marked shared: its tasks add with float atomics and the brick is listed in `shared_bricks` (zeroed
  * first).  Only the 16-row segments flagged in `support` (third part, as ig_ccsrmm_t_grid; NULL = all segments of bricks
- * that hold a nonzero) are written; everything else is left untouched.  N in {4, 8}; bm*bs <= 32; Y_il row-major; X
+ * that hold a nonzero) are written; everything else is left untouched.  `support_tile` = kx points per entry of the support
+ * table (16 as built for ig_ccsrmm_t_grid; 8 or 4: a finer table, see ig_fft_set_support_tile -- segments are then 8 / 4
+ * grid rows).  N in {4, 8}; (16/support_tile)*bm*bs <= 32; Y_il row-major; X
  * column-major.  A wave keeps one brick image in LDS, walks its run with entries and panel rows requested two trips
  * ahead (the rows come from round_rows, so no load depends on another), and accumulates with plain read-add-write in
  * entry order: deterministic except for shared bricks (float atomics).                                              */
@@ -232,7 +234,7 @@ int  ig_grid_bricks_fill(int64_t M, const int32_t* rowptr, const int32_t* colind
 int  ig_ccsrmm_t_bricks(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, float alpha_re, float alpha_im,
                         const void* entries, const uint32_t* round_rows, const void* X, int64_t ldx, void* Y_il,
                         const int16_t* support, int64_t n0, int64_t nm, int bm, int bs, const int32_t* tasks, int64_t ntasks,
-                        const int32_t* brick_table, const int32_t* shared_bricks, int64_t nshared);
+                        const int32_t* brick_table, const int32_t* shared_bricks, int64_t nshared, int support_tile);
 
 /* The same scatter for the reference's own panel layout, 64 columns: Y(K x 64, column-major, ldy) = alpha * A^H * X(M x 64,
  * column-major, ldx) for ANY CSR matrix with K a multiple of 16 (beta == 0: Y is zeroed first).  Bricks are 16 consecutive
@@ -366,6 +368,10 @@ int  ig_fft_plan_padded(ig_ctx* ctx, const int64_t* dims, const int64_t* box_lo,
  * read); the cropped transform reads only flagged segments (everything else counts as zero and may hold
  * anything).  A radial trajectory covers a ball (52 % of the cube) with gaps between its outer spokes:
  * 30 % of the segments of the 512^3 grid of the 256^3 SENSE problem are flagged.                  */
+/* Granularity of the k-space support table of a coil-interleaved (layout 2) padded plan: `tile` kx points per table entry
+ * (16 by default; 8, 4 or 2 as long as coils * tile >= 16).  The table then has n0/tile entries per (ky) row in each of its
+ * three parts; a finer table flags fewer grid bytes (BASELINE config 4: 30.5 % of the grid at 16, 22.2 % at 8, 16.4 % at 4).   */
+int  ig_fft_set_support_tile(ig_fft* plan, int tile);
 int  ig_fft_exec_padded(ig_fft* plan, const void* x, int64_t x_bstride, const void* w, void* y, void* workspace,
                         const int16_t* support);
 int  ig_fft_exec_cropped(ig_fft* plan, const void* y, const void* w, void* x, int64_t x_bstride, void* workspace,

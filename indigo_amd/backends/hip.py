@@ -424,26 +424,30 @@ class HipBackend(Backend):
     def supports_padded_fft(self, grid):
         return len(grid) == 3 and all(int(n) in (256, 512) for n in grid)
 
-    def _padded_plan(self, grid, box_lo, box_dims, batch, layout=0):
-        key = ('padded', tuple(grid), tuple(box_lo), tuple(box_dims), int(batch), int(layout))
+    supports_support_tile = True          # ZpadFFT / the brick scatter take support tables of 8 or 4 kx points per entry
+
+    def _padded_plan(self, grid, box_lo, box_dims, batch, layout=0, support_tile=16):
+        key = ('padded', tuple(grid), tuple(box_lo), tuple(box_dims), int(batch), int(layout), int(support_tile))
         if key not in self._plans:
             a3 = ctypes.c_int64 * 3
             plan, ws = ctypes.c_void_p(), ctypes.c_size_t()
             self._check(self._L.ig_fft_plan_padded(self._ctx, a3(*grid), a3(*box_lo), a3(*box_dims), int(batch),
                                                    int(layout), ctypes.byref(plan), ctypes.byref(ws)),
                         "ig_fft_plan_padded%s" % (key,))
+            if int(support_tile) != 16:
+                self._check(self._L.ig_fft_set_support_tile(plan, int(support_tile)), "ig_fft_set_support_tile")
             self._plans[key] = (plan, ws.value)
         return self._plans[key]
 
     def _fft_padded_workspace(self, grid, box_lo, box_dims, batch, layout=0):
         return self._padded_plan(grid, box_lo, box_dims, batch, layout)[1]
 
-    def fft_padded(self, y, x, w, grid, box_lo, box_dims, workspace=None, layout=0, support=None):
+    def fft_padded(self, y, x, w, grid, box_lo, box_dims, workspace=None, layout=0, support=None, support_tile=16):
         C = y.shape[1]
         assert y.dtype == _C64 and x.dtype == _C64 and y.contiguous and x.contiguous
         assert y.shape[0] == int(np.prod(grid)) and x.size == int(np.prod(box_dims))
         assert w is None or (w.contiguous and w.size == x.size * C)
-        plan, ws = self._padded_plan(grid, box_lo, box_dims, C, layout)
+        plan, ws = self._padded_plan(grid, box_lo, box_dims, C, layout, support_tile)
         assert layout == 0 or (workspace is not None and workspace.nbytes >= ws)
         self._check(self._L.ig_fft_exec_padded(plan, ctypes.c_void_p(x._arr), 0,
                                                ctypes.c_void_p(w._arr) if w is not None else None,
@@ -452,11 +456,11 @@ class HipBackend(Backend):
                                                ctypes.c_void_p(support._arr) if support is not None else None),
                     "ig_fft_exec_padded")
 
-    def ifft_cropped(self, xc, y, w, grid, box_lo, box_dims, workspace, layout=0, support=None):
+    def ifft_cropped(self, xc, y, w, grid, box_lo, box_dims, workspace, layout=0, support=None, support_tile=16):
         C = y.shape[1]
         assert y.dtype == _C64 and xc.dtype == _C64 and y.contiguous and xc.contiguous
         assert xc.shape == (int(np.prod(box_dims)), C) and (layout != 2 or xc.contiguous)
-        plan, ws = self._padded_plan(grid, box_lo, box_dims, C, layout)
+        plan, ws = self._padded_plan(grid, box_lo, box_dims, C, layout, support_tile)
         assert workspace.nbytes >= ws
         self._check(self._L.ig_fft_exec_cropped(plan, ctypes.c_void_p(y._arr),
                                                 ctypes.c_void_p(w._arr) if w is not None else None,
@@ -465,7 +469,7 @@ class HipBackend(Backend):
                                                 ctypes.c_void_p(support._arr) if support is not None else None),
                     "ig_fft_exec_cropped")
 
-    def ifft_cropped_sum(self, x, y, w, grid, box_lo, box_dims, workspace, support=None, slab=None):
+    def ifft_cropped_sum(self, x, y, w, grid, box_lo, box_dims, workspace, support=None, slab=None, support_tile=16):
         """x = sum_c conj(w[:, c]) * crop(IFFT(y[:, c])) for a coil-interleaved grid panel y (layout 2): the cropped
         transform with the coil combination folded into its last pass.
         slab: None = everything; 'z' = only the z pass; (z0, z1) = the y and x passes of the image planes z0..z1-1
@@ -473,7 +477,7 @@ class HipBackend(Backend):
         C = y.shape[1]
         assert y.dtype == _C64 and x.dtype == _C64 and y.contiguous and x.contiguous and w is not None
         assert x.size == int(np.prod(box_dims))
-        plan, ws = self._padded_plan(grid, box_lo, box_dims, C, 2)
+        plan, ws = self._padded_plan(grid, box_lo, box_dims, C, 2, support_tile)
         assert workspace.nbytes >= ws
         sup = ctypes.c_void_p(support._arr) if support is not None else None
         if slab is None:
@@ -627,6 +631,12 @@ class HipBackend(Backend):
             self._support = (self._backend.copy_array(np.ascontiguousarray(table, dtype=np.int16).reshape(-1),
                                                       name=self._name + ".support"), int(n0), int(nm))
 
+        def set_grid_support_fine(self, table, tile):
+            """a support table with `tile` (8 or 4) kx points per entry: what the brick scatter writes by (the gather routes keep
+            the 16-point table of set_grid_support; a reader with the finer table reads a subset of what they write)"""
+            self._support_fine = (self._backend.copy_array(np.ascontiguousarray(table, dtype=np.int16).reshape(-1),
+                                                           name=self._name + ".supportFine"), int(tile))
+
         def set_grid_bricks(self, n0, nm, ns, ncols=8, bm=2, bs=2, chunk=4096, run=4096):
             """Sort the nonzeros by the 16 x bm x bs brick of the n0 x nm x ns grid their column falls into (native host
             routine), padded so that a wave instruction (64/ncols entries x ncols panel columns) holds entries of one row
@@ -659,7 +669,9 @@ class HipBackend(Backend):
             _lib.check(b._L.ig_grid_bricks_fill(A.shape[0], indptr.ctypes.data, indices.ctypes.data, data.ctypes.data, n0, nm, ns,
                                                 bm, bs, unit, ptr.ctypes.data, entries.ctypes.data, round_rows.ctypes.data),
                        None, "ig_grid_bricks_fill")
-            tasks, table, shared = brick_tasks(counts, ptr, chunk, run, max_bricks=min(64, 256 // (bm * bs)))
+            fine = getattr(self, '_support_fine', None)
+            nseg = (16 // (fine[1] if fine is not None else 16)) * bm * bs          # segments per brick (the kernel looks up 256 per run)
+            tasks, table, shared = brick_tasks(counts, ptr, chunk, run, max_bricks=min(64, 256 // nseg))
             self._bricks = dict(n0=int(n0), nm=int(nm), bm=int(bm), bs=int(bs), ncols=int(ncols), ntasks=int(tasks.shape[0]),
                                 nshared=int(shared.size), nentries=int(ptr[-1]),
                                 tasks=b.copy_array(tasks.reshape(-1) if tasks.size else np.zeros(4, np.int32), name=self._name + ".brickTasks"),
@@ -779,7 +791,8 @@ class HipBackend(Backend):
             br = getattr(self, '_bricks', None)
             if (br is not None and perm is None and beta == 0 and y.contiguous and getattr(self, '_grid_il', False)
                     and x.shape[1] == br['ncols']):
-                tab = sup[0] if sup is not None else None
+                fine = getattr(self, '_support_fine', None)
+                tab, tile = (fine[0], fine[1]) if fine is not None else (sup[0] if sup is not None else None, 16)
                 if tab is None:
                     y._zero()           # without a support table every row is defined: bricks no sample touches stay zero
                 ar, ai = _cplx(alpha)
@@ -788,7 +801,7 @@ class HipBackend(Backend):
                                                  ctypes.c_void_p(br['entries']._arr), ctypes.c_void_p(br['rounds']._arr), ctypes.c_void_p(x._arr), x._leading_dim,
                                                  ctypes.c_void_p(y._arr), ctypes.c_void_p(tab._arr) if tab is not None else None,
                                                  br['n0'], br['nm'], br['bm'], br['bs'], ctypes.c_void_p(br['tasks']._arr), br['ntasks'],
-                                                 ctypes.c_void_p(br['table']._arr), ctypes.c_void_p(br['shared']._arr), br['nshared']),
+                                                 ctypes.c_void_p(br['table']._arr), ctypes.c_void_p(br['shared']._arr), br['nshared'], tile),
                          "ig_ccsrmm_t_bricks")
                 return
             if (x.shape[1] == 64 and beta == 0 and perm is None and not getattr(self, '_grid_il', False) and self.shape[1] % 16 == 0

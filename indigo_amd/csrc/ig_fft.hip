@@ -982,6 +982,7 @@ struct ig_fft {
     float2* d_inplace = nullptr;     // lazily allocated staging volume set for in-place calls of the two-launch transform
     bool padded = false;
     int layout = 0;                  // memory order of the grid: 0 = (x, y, z), 1 = (x, z, y)
+    int support_tile = 16;           // kx points per entry of the k-space support table (layout 2: ig_fft_set_support_tile)
     int64_t box_lo[3] = {0, 0, 0}, box_dims[3] = {1, 1, 1};
 };
 
@@ -1565,6 +1566,8 @@ static int exec_padded_layout2(ig_fft* p, const float2* x, int64_t x_bstride, co
                                const short2* support) {
     ig_ctx* ctx = p->ctx;
     const int64_t n0 = p->dims[0], n1 = p->dims[1], n2 = p->dims[2];
+    const int64_t snt = n0 / p->support_tile;                        // support entries per grid row
+    const int sshift = lg2((int)(p->batch * p->support_tile / 16));    // 16-column tiles per support entry
     // (a one-row pitch on the z axis, to break the 16 MB power-of-two stride of the y pass, was measured: no gain once
     // the y pass runs on 32-column tiles)
     const int64_t b0 = p->box_dims[0], b1 = p->box_dims[1], b2 = p->box_dims[2];
@@ -1590,7 +1593,7 @@ static int exec_padded_layout2(ig_fft* p, const float2* x, int64_t x_bstride, co
         d.out = y + l2 * C * n0; d.out_sj = C * n0 * n2; d.out_s[0] = 1; d.out_s[1] = C * n0;
         d.ext0 = C * n0; d.ext1 = b2; d.ncols = C * n0 * b2;
         d.in_lo = (int)l1; d.in_hi = (int)(l1 + b1); d.out_lo = 0; d.out_hi = (int)n1; d.inverse = 0;
-        if (support) { d.tile_range = support + n1 * (n0 / 16); d.tile_range_mode = 1; d.tile_range_k1 = 0; d.tile_shift = lg2(C); }
+        if (support) { d.tile_range = support + n1 * snt; d.tile_range_mode = 1; d.tile_range_k1 = 0; d.tile_shift = sshift; }
         if (int rc = launch_2stage(ctx, p->axis[1], d, false, 0)) return rc;
     }
     {   // pass z: columns (c + C*kx, ky), in place
@@ -1600,8 +1603,8 @@ static int exec_padded_layout2(ig_fft* p, const float2* x, int64_t x_bstride, co
         d.in_s[0] = d.out_s[0] = 1; d.in_s[1] = d.out_s[1] = C * n0 * n2;
         d.ext0 = C * n0; d.ext1 = n1; d.ncols = C * n0 * n1;
         d.in_lo = (int)l2; d.in_hi = (int)(l2 + b2); d.out_lo = 0; d.out_hi = (int)n2; d.inverse = 0;
-        d.tile_range = support; d.tile_range_mode = 1; d.tile_range_k1 = n0 / 16; d.tile_shift = lg2(C);
-        if (support) d.tile_bits = reinterpret_cast<const uint32_t*>(support + n1 * (n0 / 16) + n0 / 16);
+        d.tile_range = support; d.tile_range_mode = 1; d.tile_range_k1 = snt; d.tile_shift = sshift;
+        if (support) d.tile_bits = reinterpret_cast<const uint32_t*>(support + n1 * snt + snt);
         if (int rc = launch_2stage(ctx, p->axis[2], d, false, 0)) return rc;
     }
     return IG_OK;
@@ -1612,6 +1615,8 @@ static int exec_cropped_layout2(ig_fft* p, const float2* y, const float2* w, flo
                                 bool sum_coils = false, int phases = 3, int64_t z0 = 0, int64_t z1 = -1) {
     ig_ctx* ctx = p->ctx;
     const int64_t n0 = p->dims[0], n1 = p->dims[1], n2 = p->dims[2];
+    const int64_t snt = n0 / p->support_tile;                        // support entries per grid row
+    const int sshift = lg2((int)(p->batch * p->support_tile / 16));    // 16-column tiles per support entry
     const int64_t b0 = p->box_dims[0], b1 = p->box_dims[1], b2 = p->box_dims[2];
     const int64_t l0 = p->box_lo[0], l1 = p->box_lo[1], l2 = p->box_lo[2];
     const int64_t vol = n0 * n1 * n2, bvol = b0 * b1 * b2, C = p->batch;
@@ -1626,9 +1631,9 @@ static int exec_cropped_layout2(ig_fft* p, const float2* y, const float2* w, flo
         d.in_s[0] = d.out_s[0] = 1; d.in_s[1] = d.out_s[1] = C * n0 * n2;
         d.ext0 = C * n0; d.ext1 = n1; d.ncols = C * n0 * n1;
         d.in_lo = 0; d.in_hi = (int)n2; d.out_lo = (int)l2; d.out_hi = (int)(l2 + b2); d.inverse = 1;
-        d.tile_range = support; d.tile_range_mode = 2; d.tile_range_k1 = n0 / 16; d.tile_shift = lg2(C);
-        if (support) d.tile_bits = reinterpret_cast<const uint32_t*>(support + n1 * (n0 / 16) + n0 / 16);
-        if (support) d.k1_range = support + n1 * (n0 / 16);                         // ky the y pass will never read
+        d.tile_range = support; d.tile_range_mode = 2; d.tile_range_k1 = snt; d.tile_shift = sshift;
+        if (support) d.tile_bits = reinterpret_cast<const uint32_t*>(support + n1 * snt + snt);
+        if (support) d.k1_range = support + n1 * snt;                         // ky the y pass will never read
         if (int rc = launch_2stage(ctx, p->axis[2], d, false, 0)) return rc;
     }
     if (!(phases & 2) || nz <= 0) return IG_OK;
@@ -1639,7 +1644,7 @@ static int exec_cropped_layout2(ig_fft* p, const float2* y, const float2* w, flo
         d.out = L1 - l1 * C * n0 + z0 * C * n0 * b1; d.out_sj = C * n0; d.out_s[0] = 1; d.out_s[1] = C * n0 * b1;
         d.ext0 = C * n0; d.ext1 = nz; d.ncols = C * n0 * nz;
         d.in_lo = 0; d.in_hi = (int)n1; d.out_lo = (int)l1; d.out_hi = (int)(l1 + b1); d.inverse = 1;
-        if (support) { d.tile_range = support + n1 * (n0 / 16); d.tile_range_mode = 2; d.tile_range_k1 = 0; d.tile_shift = lg2(C); }
+        if (support) { d.tile_range = support + n1 * snt; d.tile_range_mode = 2; d.tile_range_k1 = 0; d.tile_shift = sshift; }
         if (int rc = launch_2stage(ctx, p->axis[1], d, false, 0)) return rc;
     }
     if (sum_coils) {   // pass x with the coil combination: x = sum_c conj(w_c) .* crop(...), one image box
@@ -1664,6 +1669,16 @@ static int exec_cropped_layout2(ig_fft* p, const float2* y, const float2* w, flo
         d.in_lo = 0; d.in_hi = (int)n0; d.out_lo = (int)l0; d.out_hi = (int)(l0 + b0); d.inverse = 1;
         if (int rc = launch_2stage(ctx, p->axis[0], d, false, w ? 2 : 0)) return rc;
     }
+    return IG_OK;
+}
+
+int ig_fft_set_support_tile(ig_fft* p, int tile) {
+    if (!p) return ig_fail(nullptr, IG_ERR_ARG, "ig_fft_set_support_tile: plan is NULL");
+    ig_ctx* ctx = p->ctx;
+    IG_REQUIRE(ctx, p->padded && p->layout == 2, "ig_fft_set_support_tile: a zero-padded plan of the coil-interleaved layout");
+    IG_REQUIRE(ctx, (tile == 2 || tile == 4 || tile == 8 || tile == 16) && p->batch * tile >= 16 && p->dims[0] % tile == 0,
+               "ig_fft_set_support_tile: tile %d (2, 4, 8 or 16 kx points; coils * tile >= 16)", tile);
+    p->support_tile = tile;
     return IG_OK;
 }
 

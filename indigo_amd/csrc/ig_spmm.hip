@@ -884,7 +884,7 @@ k_grid_bricks(const BrickTask* __restrict__ tasks, int ntasks, const BrickRef* _
               const BrickEntry* __restrict__ entries, const uint32_t* __restrict__ round_rows,
               const float2* __restrict__ Xp /* packed rows: [t][NC] */,
               float2* __restrict__ Y, float2 alpha, const uint32_t* __restrict__ bits,
-              int n0, int nm, int bm_log2, int bs_log2, int nbx, int nbm, int dbg) {
+              int n0, int nm, int bm_log2, int bs_log2, int nbx, int nbm, int dbg, int st_log2 /* log2(cells per segment) */) {
     extern __shared__ float2 acc_all[];                  // per wave: [cells][NC]
     constexpr int TPR = 64 / NC;                         // entries per round (one wave instruction of the accumulation)
     constexpr int RS = 64 / TPR;                         // rounds per super-trip
@@ -896,7 +896,10 @@ k_grid_bricks(const BrickTask* __restrict__ tasks, int ntasks, const BrickRef* _
     const int nb = tk.nb_flags & 0xffff;
     const bool shared = (tk.nb_flags >> 16) & 1;
     const int32_t nent = tk.hi - tk.lo, nround = nent / TPR;
-    const int BM = 1 << bm_log2, nseg = NSEG ? NSEG : 1 << (bm_log2 + bs_log2), ncell = 16 * nseg;
+    // a segment = 2^st_log2 consecutive cells of one grid row (the support table's granularity: 16, 8 or 4 kx points);
+    // segment index inside a brick: s = xs + XS*(im + BM*is) with XS = 16 >> st_log2 segments per brick row
+    const int xs_log2 = 4 - st_log2, seg_log2 = xs_log2 + bm_log2 + bs_log2;
+    const int BM = 1 << bm_log2, nseg = NSEG ? NSEG : 1 << seg_log2, ncell = 16 << (bm_log2 + bs_log2);
     float2* __restrict__ acc = acc_all + (size_t)wv * ncell * NC;
     const int coil = lane % NC, tsub = lane / NC, xround = (lane / NC) % RS;
     const rsrc_t r_en = make_rsrc(entries + tk.lo), r_rr = make_rsrc(round_rows + tk.lo / TPR), r_x = make_rsrc(Xp);
@@ -941,15 +944,16 @@ k_grid_bricks(const BrickTask* __restrict__ tasks, int ntasks, const BrickRef* _
     // ... and which of their segments are flagged: 64 (brick, segment) pairs per pass, four passes in flight
     uint32_t my_mask = 0xffffffffu;
     if (bits) {
-        const int nt = n0 >> 4, seg_log2 = bm_log2 + bs_log2;
+        const int nt = n0 >> st_log2;                    // support entries per grid row
         const rsrc_t r_bits = make_rsrc(bits);
         uint32_t w[4];
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int pair = p * 64 + lane, j = pair >> seg_log2, seg = pair & (nseg - 1);
             const int jbx = __shfl(my_bx, j & 63), jm0 = __shfl(my_m0, j & 63), js0 = __shfl(my_s0, j & 63);
-            const int km = jm0 + (seg & (BM - 1)), ks = js0 + (seg >> bm_log2);
-            w[p] = (uint32_t)buf_ld_i32(r_bits, j < nb ? (unsigned)((ks * nt + jbx) * 16 + (km & 15)) * 4u : IG_OOB) >> (km >> 4);
+            const int xs = seg & ((1 << xs_log2) - 1), im = (seg >> xs_log2) & (BM - 1), is = seg >> (xs_log2 + bm_log2);
+            const int km = jm0 + im, ks = js0 + is;
+            w[p] = (uint32_t)buf_ld_i32(r_bits, j < nb ? (unsigned)((ks * nt + (jbx << xs_log2) + xs) * 16 + (km & 15)) * 4u : IG_OOB) >> (km >> 4);
         }
         my_mask = 0u;
 #pragma unroll
@@ -967,11 +971,12 @@ k_grid_bricks(const BrickTask* __restrict__ tasks, int ntasks, const BrickRef* _
     // store the image of brick `cur` (flagged segments: 16 cells x NC coils = NC*128 bytes each) and clear it
     auto flush_segment = [&](int pt, uint32_t mask, int seg) {
         if (!((mask >> seg) & 1u)) return;
-        const int im = seg & (BM - 1), is = seg >> bm_log2;
-        float2* src = acc + (size_t)16 * seg * NC;
-        float2* dst = Y + ((int64_t)pt + (int64_t)n0 * (im + (int64_t)nm * is)) * NC;
-#pragma unroll
-        for (int e = lane; e < 16 * NC; e += 64) {
+        const int xs = seg & ((1 << xs_log2) - 1), im = (seg >> xs_log2) & (BM - 1), is = seg >> (xs_log2 + bm_log2);
+        const int cell0 = (xs << st_log2) + 16 * (im + BM * is);          // first cell of the segment in the image
+        float2* src = acc + (size_t)cell0 * NC;
+        float2* dst = Y + ((int64_t)pt + (xs << st_log2) + (int64_t)n0 * (im + (int64_t)nm * is)) * NC;
+        const int nel = NC << st_log2;                                    // float2 values of the segment (128 for 16 cells x 8 coils)
+        for (int e = lane; e < nel; e += 64) {
             const float2 o = cmul(alpha, src[e]);
             // Stores and atomics as asm statements: the compiler's wait-count bookkeeping does not see them.  With ordinary
             // stores in this (inner) loop it drains every outstanding load before each super-trip (s_waitcnt vmcnt(0):
@@ -1156,18 +1161,19 @@ k_bricks_wide64(const BrickTask* __restrict__ tasks, int ntasks, const BrickRef*
 template <int NC>
 __global__ void __launch_bounds__(BLK)
 k_grid_bricks_zero(const int32_t* __restrict__ shared_bricks, float2* __restrict__ Y, const uint32_t* __restrict__ bits,
-                   int n0, int nm, int bm_log2, int bs_log2, int nbx, int nbm) {
+                   int n0, int nm, int bm_log2, int bs_log2, int nbx, int nbm, int st_log2) {
     const int brick = shared_bricks[blockIdx.x];
-    const int BM = 1 << bm_log2, nseg = 1 << (bm_log2 + bs_log2);
+    const int xs_log2 = 4 - st_log2;
+    const int BM = 1 << bm_log2, nseg = 1 << (xs_log2 + bm_log2 + bs_log2);
     const int bx = brick % nbx, bmi = (brick / nbx) % nbm, bsi = brick / (nbx * nbm);
     const int x0 = bx * 16, m0 = bmi << bm_log2, s0 = bsi << bs_log2;
-    const int nt = n0 >> 4, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nt = n0 >> st_log2, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int seg = wv; seg < nseg; seg += WAVES_PER_BLOCK) {
-        const int im = seg & (BM - 1), is = seg >> bm_log2;
+        const int xs = seg & ((1 << xs_log2) - 1), im = (seg >> xs_log2) & (BM - 1), is = seg >> (xs_log2 + bm_log2);
         const int km = m0 + im, ks = s0 + is;
-        if (bits && !((bits[((size_t)ks * nt + bx) * 16 + (km & 15)] >> (km >> 4)) & 1u)) continue;
-        float2* dst = Y + ((int64_t)x0 + (int64_t)n0 * (km + (int64_t)nm * ks)) * NC;
-        for (int e = lane; e < 16 * NC; e += 64) dst[e] = make_float2(0.f, 0.f);
+        if (bits && !((bits[((size_t)ks * nt + (bx << xs_log2) + xs) * 16 + (km & 15)] >> (km >> 4)) & 1u)) continue;
+        float2* dst = Y + ((int64_t)x0 + (xs << st_log2) + (int64_t)n0 * (km + (int64_t)nm * ks)) * NC;
+        for (int e = lane; e < (NC << st_log2); e += 64) dst[e] = make_float2(0.f, 0.f);
     }
 }
 
@@ -1716,7 +1722,7 @@ int ig_grid_bricks_fill(int64_t M, const int32_t* rowptr, const int32_t* colind,
 int ig_ccsrmm_t_bricks(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, float ar, float ai,
                        const void* entries, const uint32_t* round_rows, const void* X, int64_t ldx, void* Y_il, const int16_t* support, int64_t n0, int64_t nm,
                        int bm, int bs, const int32_t* tasks, int64_t ntasks, const int32_t* brick_table,
-                       const int32_t* shared_bricks, int64_t nshared) {
+                       const int32_t* shared_bricks, int64_t nshared, int support_tile) {
     IG_REQUIRE(ctx, ctx != nullptr, "ig_ccsrmm_t_bricks: ctx is NULL");
     IG_REQUIRE(ctx, M >= 0 && K >= 0 && M <= 0x7fffffffLL, "ig_ccsrmm_t_bricks: bad dimensions");
     IG_REQUIRE(ctx, N == 4 || N == 8, "ig_ccsrmm_t_bricks: 4 or 8 columns (got %lld); entries must be padded to 64/N per row and brick", (long long)N);
@@ -1725,12 +1731,16 @@ int ig_ccsrmm_t_bricks(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, float ar, f
                "ig_ccsrmm_t_bricks: rows (%lld) are not a grid of n0=%lld x nm=%lld x ... that divides into 16 x %d x %d bricks", (long long)K, (long long)n0, (long long)nm, bm, bs);
     const int64_t ns = K / (n0 * nm);
     IG_REQUIRE(ctx, !support || (nm % 16 == 0 && nm <= 512), "ig_ccsrmm_t_bricks: the support table needs nm %% 16 == 0 and nm <= 512");
+    IG_REQUIRE(ctx, support_tile == 16 || support_tile == 8 || support_tile == 4, "ig_ccsrmm_t_bricks: support_tile %d (kx points per entry of the support table: 16, 8 or 4)", support_tile);
+    IG_REQUIRE(ctx, (16 / support_tile) * bm * bs <= 32, "ig_ccsrmm_t_bricks: at most 32 segments per brick (%d x %d x %d)", 16 / support_tile, bm, bs);
+    const int st_log2 = support_tile == 16 ? 4 : support_tile == 8 ? 3 : 2;
     IG_REQUIRE(ctx, ntasks >= 0 && ntasks <= 0x7fffffffLL && (ntasks == 0 || (tasks && brick_table)) && nshared >= 0 && (nshared == 0 || shared_bricks), "ig_ccsrmm_t_bricks: bad task list");
     IG_REQUIRE(ctx, M * N * 8 < 0x7fffffffLL, "ig_ccsrmm_t_bricks: the panel (%lld x %lld) exceeds the 2 GB window of a buffer descriptor", (long long)M, (long long)N);
     if (K == 0 || ntasks == 0) return IG_OK;
     if (int rc = ig_set_device(ctx)) return rc;
     const int64_t nt = n0 / 16;
-    const uint32_t* bits = support ? reinterpret_cast<const uint32_t*>(support + 2 * (ns * nt + nt)) : nullptr;
+    const int64_t snt = n0 / support_tile;                                // support entries per grid row
+    const uint32_t* bits = support ? reinterpret_cast<const uint32_t*>(support + 2 * (ns * snt + snt)) : nullptr;
     const float2 alpha = make_float2(ar, ai);
     // the k-space panel as packed rows [t][N] (column-major in, as everywhere at the boundary)
     const size_t need = (size_t)M * N * 8;
@@ -1760,11 +1770,13 @@ int ig_ccsrmm_t_bricks(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, float ar, f
 #define IG_BRICKS(NC_, NSEG_) do {                                                                                            \
         if (nshared) {                                                                                                          \
             ig_prof_scope prof(ctx, "grid_bricks_zero");                                                                        \
-            hipLaunchKernelGGL((k_grid_bricks_zero<NC_>), dim3((unsigned)nshared), dim3(BLK), 0, ctx->stream, shared_bricks, (float2*)Y_il, bits, (int)n0, (int)nm, bm_log2, bs_log2, nbx, nbm); } \
+            hipLaunchKernelGGL((k_grid_bricks_zero<NC_>), dim3((unsigned)nshared), dim3(BLK), 0, ctx->stream, shared_bricks, (float2*)Y_il, bits, (int)n0, (int)nm, bm_log2, bs_log2, nbx, nbm, st_log2); } \
         ig_prof_scope prof(ctx, "csrmm_bricks_conj");                                                                           \
         hipLaunchKernelGGL((k_grid_bricks<NC_, NSEG_>), dim3(blocks), dim3(BLK), lds, ctx->stream, (const BrickTask*)tasks, (int)ntasks, (const BrickRef*)brick_table, (const BrickEntry*)entries, round_rows, \
-                           (const float2*)xp, (float2*)Y_il, alpha, bits, (int)n0, (int)nm, bm_log2, bs_log2, nbx, nbm, brick_dbg); } while (0)
-    if (N == 8 && bm * bs == 4) IG_BRICKS(8, 4);
+                           (const float2*)xp, (float2*)Y_il, alpha, bits, (int)n0, (int)nm, bm_log2, bs_log2, nbx, nbm, brick_dbg, st_log2); } while (0)
+    const int nseg_total = (16 / support_tile) * bm * bs;
+    if (N == 8 && nseg_total == 4) IG_BRICKS(8, 4);
+    else if (N == 8 && nseg_total == 8) IG_BRICKS(8, 8);
     else if (N == 8) IG_BRICKS(8, 0);
     else IG_BRICKS(4, 0);
 #undef IG_BRICKS

@@ -225,6 +225,8 @@ class SpMatrix(Operator):
                 self._matrix_d._exwrite = False
             if getattr(self, '_grid_support', None) is not None:
                 self._matrix_d.set_grid_support(*self._grid_support)
+            if getattr(self, '_grid_support_fine', None) is not None and hasattr(self._matrix_d, 'set_grid_support_fine'):
+                self._matrix_d.set_grid_support_fine(*self._grid_support_fine)
             if getattr(self, '_row_order', None) is not None:
                 self._matrix_d.set_row_order(self._row_order)
             if getattr(self, '_grid_interleaved', False):
@@ -301,13 +303,15 @@ class ZpadFFT(MatrixFreeOperator):
     with dense arrays, and tests pin both to the reference's S' + FFT composition.
     """
 
-    def __init__(self, backend, grid_shape, box_shape, weights, box_lo=None, layout=0, support=None, **kwargs):
+    def __init__(self, backend, grid_shape, box_shape, weights, box_lo=None, layout=0, support=None, support_tile=16, **kwargs):
         # memory order of the output grids: 0 = (x, y, z) per coil, 1 = (x, z, y) per coil, 2 = (c, x, z, y) coils interleaved
         self._layout = int(layout)
         # optional k-space support table (layout 1): int16 [z_lo, z_hi) per (kx tile of 16, ky); outside it the
         # forward grid is left unwritten and the adjoint's input is taken as zero (see ig_fft_exec_padded)
         self._support_h = None if support is None else np.ascontiguousarray(support, dtype=np.int16)
         self._support_d = None
+        # kx points per entry of the support table (layout 2 on backends that take a finer table: ig_fft_set_support_tile)
+        self._tile_kw = {} if int(support_tile) == 16 else {'support_tile': int(support_tile)}
         self._grid = tuple(int(s) for s in grid_shape)
         self._box = tuple(int(s) for s in box_shape)
         assert len(self._grid) == 3 and len(self._box) == 3
@@ -367,7 +371,7 @@ class ZpadFFT(MatrixFreeOperator):
                 if self._layout:
                     with B.scratch(nbytes=self._ws_bytes()) as ws:
                         B.fft_padded(yj.reshape((P, C)), xj, w, self._grid, self._lo, self._box, ws, self._layout,
-                                     self._support())
+                                     self._support(), **self._tile_kw)
                 else:
                     B.fft_padded(yj.reshape((P, C)), xj, w, self._grid, self._lo, self._box)
                 if alpha != 1:
@@ -382,26 +386,26 @@ class ZpadFFT(MatrixFreeOperator):
                     b2, plane = self._box[2], self._box[0] * self._box[1]
                     with B.scratch(nbytes=self._ws_bytes()) as ws:
                         xg = xj.reshape((P, C))
-                        B.ifft_cropped_sum(yj, xg, w, self._grid, self._lo, self._box, ws, self._support(), slab='z')
+                        B.ifft_cropped_sum(yj, xg, w, self._grid, self._lo, self._box, ws, self._support(), slab='z', **self._tile_kw)
                         edges = [b2 * i // nslabs for i in range(nslabs + 1)]
                         for z0, z1 in zip(edges[:-1], edges[1:]):
                             if z1 > z0:
-                                B.ifft_cropped_sum(yj, xg, w, self._grid, self._lo, self._box, ws, self._support(), slab=(z0, z1))
+                                B.ifft_cropped_sum(yj, xg, w, self._grid, self._lo, self._box, ws, self._support(), slab=(z0, z1), **self._tile_kw)
                                 fn(yj, z0 * plane, z1 * plane)
                 elif alpha == 1 and beta == 0:
                     with B.scratch(nbytes=self._ws_bytes()) as ws:
-                        B.ifft_cropped_sum(yj, xj.reshape((P, C)), w, self._grid, self._lo, self._box, ws, self._support())
+                        B.ifft_cropped_sum(yj, xj.reshape((P, C)), w, self._grid, self._lo, self._box, ws, self._support(), **self._tile_kw)
                 else:
                     # (a read-modify-write of y inside the pass was measured slower than this extra axpby over one image)
                     with B.scratch(shape=(N, 1)) as acc:
                         with B.scratch(nbytes=self._ws_bytes()) as ws:
-                            B.ifft_cropped_sum(acc, xj.reshape((P, C)), w, self._grid, self._lo, self._box, ws, self._support())
+                            B.ifft_cropped_sum(acc, xj.reshape((P, C)), w, self._grid, self._lo, self._box, ws, self._support(), **self._tile_kw)
                         B.axpby(beta, yj, alpha, acc)
             else:
                 with B.scratch(shape=(N, C)) as tmp:
                     with B.scratch(nbytes=self._ws_bytes()) as ws:
                         B.ifft_cropped(tmp, xj.reshape((P, C)), w, self._grid, self._lo, self._box, ws, self._layout,
-                                       self._support())
+                                       self._support(), **self._tile_kw)
                     if self._layout == 2:
                         B.sum_columns(yj, tmp, alpha=alpha, beta=beta, interleaved=True)
                     else:

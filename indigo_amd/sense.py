@@ -150,43 +150,43 @@ class SenseProblem(object):
             np.multiply(base, self.coil_map(c), out=w[:, :, :, j])
         return w
 
-    def grid_support(self, G):
+    def grid_support(self, G, tile=16):
         """k-space support table of a layout-1 gridding matrix (see indigo_amd.fused.grid_support)"""
-        return fused.grid_support(G, self.oN)
+        return fused.grid_support(G, self.oN, tile)
 
-    def split_support(self, table):
-        return fused.split_support(table, self.oN)
+    def split_support(self, table, tile=16):
+        return fused.split_support(table, self.oN, tile)
 
-    def zpadfft_pass_bytes(self, ncoils, table=None, fused_sum=False):
+    def zpadfft_pass_bytes(self, ncoils, table=None, fused_sum=False, tile=16):
         """Compulsory HBM bytes of each axis pass of the fused transform (layout 1): what the pass must read
         plus what it must write, given the image box and -- if present -- the k-space support table.
         These are the per-launch "algorithmic bytes" bench.py prices the fused passes with (the reference
         has no equivalent kernels; the rocprofv3 PMC traffic agrees with these figures)."""
         n0, n1, n2 = self.oN
         b0, b1, b2 = self.N
-        C, nt = ncoils, n0 // 16
+        C, nt = ncoils, n0 // tile                  # `tile` kx points per support-table entry
         bvol, cvol, vol = b0 * b1 * b2, n0 * b1 * b2, n0 * n1 * n2
         if table is None:
             z_sup, z_tiles = vol, n1 * nt
             ylen = np.full(nt, n1, dtype=np.int64)
         else:
-            zr, yr, bits = self.split_support(table)
-            z_sup = int(np.unpackbits(bits.view(np.uint8)).sum()) * 16     # grid points in flagged segments, per coil
+            zr, yr, bits = self.split_support(table, tile)
+            z_sup = int(np.unpackbits(bits.view(np.uint8)).sum()) * tile   # grid points in flagged segments, per coil
             z_tiles = int(np.count_nonzero(zr[:, 1] > zr[:, 0]))           # (kx tile, ky) columns with any support
             ylen = (yr[:, 1].astype(np.int64) - yr[:, 0]).clip(0)
-        y_sup = int(ylen.sum()) * 16 * b2            # points the y pass produces / consumes on its grid side
+        y_sup = int(ylen.sum()) * tile * b2          # points the y pass produces / consumes on its grid side
         e = 8 * C
         return {
             "fft_pad_x": bvol * 8 + bvol * e + cvol * e,
             "fft_pad_y": cvol * e + y_sup * e,
-            "fft_pad_z": z_tiles * 16 * b2 * e + z_sup * e,
+            "fft_pad_z": z_tiles * tile * b2 * e + z_sup * e,
             "fft_crop_z": z_sup * e + y_sup * e,            # writes every column the y pass will read (zeros where the hull is empty)
             "fft_crop_y": y_sup * e + cvol * e,
             # (fused_sum: the coil combination happens inside the pass -- one image box is written, not one per coil)
             "fft_crop_x": cvol * e + bvol * e + (bvol * 8 if fused_sum else bvol * e),
         }
 
-    def gridding_pass_bytes(self, ncoils, table=None):
+    def gridding_pass_bytes(self, ncoils, table=None, tile=16):
         """Compulsory HBM bytes of the two gridding products of the fused tree for `ncoils` coils: the matrix once, the
         panel rows that are really touched once, the result once.  The adjoint (a gather over G'^T restricted to the
         flagged 16-row segments of the support table) reads the transposed matrix's row pointers only inside flagged
@@ -198,8 +198,8 @@ class SenseProblem(object):
         touched = int(np.unique(Gm.indices).size)
         e = 8 * ncoils
         if table is not None:
-            _, _, bits = self.split_support(table)
-            sup = int(np.unpackbits(bits.view(np.uint8)).sum()) * 16
+            _, _, bits = self.split_support(table, tile)
+            sup = int(np.unpackbits(bits.view(np.uint8)).sum()) * tile
         else:
             sup = P
         return {
@@ -241,8 +241,10 @@ class SenseProblem(object):
             table = self.grid_support(Gm)
         self.last_support_table = table
         order = self.locality_order(Gm) if reorder and Cn <= 8 else None
-        return fused.assemble(backend, Gm, self.oN, self.N, lambda lo, hi: self.fused_weights(coils[lo:hi]), Cn,
-                              layout, chunks, table=table, row_order=order)
+        A = fused.assemble(backend, Gm, self.oN, self.N, lambda lo, hi: self.fused_weights(coils[lo:hi]), Cn,
+                           layout, chunks, table=table, row_order=order)
+        self.last_support_fine = getattr(A, '_support_fine', None)       # (table, tile) when the tree took a finer table
+        return A
 
     def build_fused(self, backend, coils=None):
         coils = list(range(self.C) if coils is None else coils)

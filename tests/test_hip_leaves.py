@@ -618,7 +618,8 @@ def test_one_dense_and_dia_operators(hip, oracle_backend):
 
 @pytest.mark.parametrize("N,bm,bs,chunk,run,with_support", [(8, 4, 4, 4096, 1024, True), (8, 4, 4, 64, 1024, True), (4, 4, 4, 64, 64, True),
                                                             (4, 4, 8, 4096, 1024, False), (8, 2, 8, 4096, 1 << 20, False), (8, 1, 1, 8, 256, True),
-                                                            (8, 2, 2, 4096, 1024, True), (8, 2, 2, 128, 8, False), (4, 1, 2, 4096, 1 << 20, True)])
+                                                            (8, 2, 2, 4096, 1024, True), (8, 2, 2, 128, 8, False), (4, 1, 2, 4096, 1 << 20, True),
+                                                            (8, 2, 2, 4096, 4096, 8), (8, 2, 2, 64, 512, 4), (4, 2, 2, 4096, 1024, 8), (8, 4, 2, 4096, 1024, 8)])
 def test_brick_binned_adjoint_gridding(hip, N, bm, bs, chunk, run, with_support):
     """ig_ccsrmm_t_bricks (scatter through per-wave LDS images, binned by grid bricks) == A^H X from scipy, for interleaved
     result panels of 4 and 8 columns; shared bricks (small chunk: several tasks add into one brick with atomics), rows
@@ -642,13 +643,18 @@ def test_brick_binned_adjoint_gridding(hip, N, bm, bs, chunk, run, with_support)
     A = spp.csr_matrix((rand64c(rows.size, seed=3), (rows, cols)), shape=(T, P))
     A.sort_indices()
     A_d = hip.csr_matrix(hip, A)
+    tile = 16
     if with_support:
-        seg = np.zeros((ns, nm, n0 // 16), dtype=bool)                     # [ks][km][kx tile]
+        tile = with_support if with_support in (4, 8) else 16              # kx points per entry of the support table
+        seg = np.zeros((ns, nm, n0 // tile), dtype=bool)                   # [ks][km][kx tile]
         uc = np.unique(A.indices)
-        seg[uc // (n0 * nm), (uc // n0) % nm, (uc % n0) // 16] = True
+        seg[uc // (n0 * nm), (uc // n0) % nm, (uc % n0) // tile] = True
         from test_hip_operators import support_table_from_segments
         flat, _ = support_table_from_segments(seg)
-        A_d.set_grid_support(flat, n0, nm)
+        if tile == 16:
+            A_d.set_grid_support(flat, n0, nm)
+        else:
+            A_d.set_grid_support_fine(flat, tile)
     A_d.set_grid_interleaved(True)
     A_d.set_grid_bricks(n0, nm, ns, ncols=N, bm=bm, bs=bs, chunk=chunk, run=run)
     assert A_d._bricks['nshared'] > 0 or chunk >= 4096
@@ -659,7 +665,7 @@ def test_brick_binned_adjoint_gridding(hip, N, bm, bs, chunk, run, with_support)
     got = y_d.to_host().reshape(-1, order='F').reshape(P, N)              # row-major (interleaved) memory
     exp = (0.5 - 0.25j) * (A.conj().T.astype(np.complex128) @ X.astype(np.complex128))
     if with_support:
-        inside = np.repeat(seg, 16, axis=2).reshape(-1)                   # kx fastest, then km, then ks
+        inside = np.repeat(seg, tile, axis=2).reshape(-1)                 # kx fastest, then km, then ks
         assert rel_err(got[inside], exp[inside]) < RTOL
         np.testing.assert_array_equal(got[~inside], sentinel[~inside])    # rows outside the support are not touched
         assert np.abs(exp[~inside]).max() == 0

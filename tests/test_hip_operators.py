@@ -455,6 +455,61 @@ def test_padded_fft_with_support_table(hip):
     np.testing.assert_array_equal(out[~inside], sentinel[~inside])
 
 
+@pytest.mark.parametrize("C,tile", [(4, 8), (8, 8), (8, 4), (8, 2), (2, 8), (4, 16)])
+def test_padded_fft_with_a_finer_support_table_layout2(hip, C, tile):
+    """ig_fft_set_support_tile: the coil-interleaved transform with a support table of `tile` kx points per entry (coils * tile
+    >= 16): the padded transform defines exactly the flagged segments (everything else keeps the sentinel outside the image
+    planes), the cropped ones (per-coil and coil-summing) read everything else as zero -- against the same transforms
+    without a table"""
+    grid, box, layout = (256, 256, 256), (128, 128, 128), 2
+    lo = tuple(m // 2 + int(np.ceil(-n / 2)) for m, n in zip(grid, box))
+    n0, n1, n2 = grid
+    P, N = int(np.prod(grid)), int(np.prod(box))
+    rng = np.random.default_rng(100 * C + tile)
+    nt = n0 // tile
+    zlo = rng.integers(0, 200, (n1, 1, nt))
+    zhi = zlo + rng.integers(0, 57, (n1, 1, nt))
+    kzv = np.arange(n2)[None, :, None]
+    seg = (kzv >= zlo) & (kzv < zhi) & (rng.random((n1, n2, nt)) < 0.6)
+    seg[:30, :, ::2] = False
+    seg[220:, :, ::3] = False
+    flat_table, table = support_table_from_segments(seg)
+    sup = hip.copy_array(flat_table)
+    inside = np.repeat(seg, tile, axis=2).reshape(-1)                         # rows kx + n0*(kz + n2*ky)
+    x, w = rand64c(N, 1, seed=1), rand64c(N, C, seed=2)
+    w_il = hip.copy_array(np.ascontiguousarray(w).reshape(-1))                # interleaved weights: w[i*C + c]
+    ws = hip.zero_array((hip._fft_padded_workspace(grid, lo, box, C, layout) // 8,), C64)
+
+    def rows(a_d):                                                           # (P, C) row-major view of an interleaved panel
+        return a_d.to_host().reshape(-1, order='F').reshape(P, C)
+    full_d = hip.zero_array((P, C), C64)
+    hip.fft_padded(full_d, hip.copy_array(x), w_il, grid, lo, box, ws, layout)
+    y_d = hip.copy_array(np.full((P, C), 7 - 3j, dtype=C64, order='F'))
+    hip.fft_padded(y_d, hip.copy_array(x), w_il, grid, lo, box, ws, layout, sup, support_tile=tile)
+    y, full = rows(y_d), rows(full_d)
+    np.testing.assert_array_equal(y[inside], full[inside])
+    z_in_box = np.zeros(n2, bool)
+    z_in_box[lo[2]:lo[2] + box[2]] = True                                     # (planes z in the box hold pass-y intermediates)
+    zmask = np.broadcast_to(z_in_box[None, :, None], (n0, n2, n1)).reshape(-1, order='F')
+    assert np.all(y[~inside & ~zmask] == 7 - 3j)                              # nothing outside the support is written
+    # cropped transforms: garbage outside the support does not matter
+    k = rand64c(P * C, seed=3).reshape(P, C)
+    k_clean, k_dirty = k.copy(), k.copy()
+    k_clean[~inside] = 0
+    k_dirty[~inside] = np.nan
+
+    def il(a):
+        return hip.copy_array(a.reshape(-1)).reshape((P, C))
+    a_d, b_d = hip.zero_array((N, C), C64), hip.zero_array((N, C), C64)
+    hip.ifft_cropped(a_d, il(k_clean), w_il, grid, lo, box, ws, layout)
+    hip.ifft_cropped(b_d, il(k_dirty), w_il, grid, lo, box, ws, layout, sup, support_tile=tile)
+    assert rel_err(b_d.to_host(), a_d.to_host()) < 1e-6
+    s1, s2 = hip.zero_array((N, 1), C64), hip.zero_array((N, 1), C64)
+    hip.ifft_cropped_sum(s1, il(k_clean), w_il, grid, lo, box, ws)
+    hip.ifft_cropped_sum(s2, il(k_dirty), w_il, grid, lo, box, ws, sup, support_tile=tile)
+    assert rel_err(s2.to_host(), s1.to_host()) < 1e-6
+
+
 def test_fuse_zpadfft_transform_reaches_the_benchmarked_leaf(hip, oracle_backend):
     """the reference's route (NUFFT / KronI / VStack(Diag) factories, pics.py -O3 recipe) + FuseZpadFFT builds the same
     fused tree as SenseProblem.build_zpadfft and evaluates like the -O3 tree it came from"""

@@ -206,3 +206,30 @@ def test_fuse_zpadfft_transform_on_the_reference_recipe(prob, oracle_backend):
     M = B.SpMatrix(spp.eye(6, dtype=C64).tocsr()) * B.SpMatrix(spp.eye(6, dtype=C64).tocsr())
     assert FuseZpadFFT().visit(M) is M
     B._scratch = None
+
+
+def test_support_tables_of_every_granularity_cover_the_touched_cells():
+    """fused.grid_support(tile): every grid cell a nonzero of G' touches lies in a flagged segment; the flagged set of a finer
+    table is a subset of the coarser one's (what a gather route writes by the 16-point table is a superset of what a reader
+    with the 8-point table reads); hulls contain the flagged rows; the finer the table, the fewer grid points it flags"""
+    from indigo_amd import fused
+    p = SenseProblem.synthetic((16, 16, 16), 2, nspokes=40, nreadout=32, width=2, oversamp=2.0, seed=3)      # grid 32^3
+    G = p.fused_interp(1)
+    n0, n1, n2 = p.oN
+    cols = np.unique(G.indices)
+    prev, prev_count = None, None
+    for tile in (2, 4, 8, 16):
+        table = fused.grid_support(G, p.oN, tile)
+        zr, yr, bits = fused.split_support(table, p.oN, tile)
+        nt = n0 // tile
+        m = np.arange(n2 // 16, dtype=np.uint32)
+        seg = ((bits.reshape(n1, nt, 16)[:, :, :, None] >> m) & 1).astype(bool)      # (ky, tile, t, m): kz = t + 16 m
+        seg = seg.transpose(0, 3, 2, 1).reshape(n1, n2, nt)                              # (ky, kz, tile)
+        rows = np.repeat(seg, tile, axis=2).reshape(-1)                                  # kx + n0*(kz + n2*ky)
+        assert rows[cols].all()
+        if prev is not None:
+            assert not (prev & ~rows).any() and prev_count <= rows.sum()                 # finer subset of coarser
+        prev, prev_count = rows, rows.sum()
+        ky, kz, tt = np.nonzero(seg)
+        assert np.all(zr[ky * nt + tt, 0] <= kz) and np.all(kz < zr[ky * nt + tt, 1])  # z hull per (ky, tile)
+        assert np.all(yr[tt, 0] <= ky) and np.all(ky < yr[tt, 1])                      # y hull per tile
