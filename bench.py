@@ -55,7 +55,7 @@ PMC_NOTE = " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_
 # profile-scope name (call site) -> device kernel symbol as rocprofv3 prints it.  The template arguments of the FFT
 # kernel are <R1, R2, T, W, AXIS0, WMODE, BOXED, HALF> (indigo_amd/csrc/ig_fft.hip); which instantiation a pass runs
 # depends on the grid layout, the axis length and whether the image box is the middle half of the axis.
-def kernel_symbols(layout, ncoils, half_box=True, n=512):
+def kernel_symbols(layout, ncoils, half_box=True, n=512, support_tile=16):
     r1 = 32 if n == 512 else 16
     f = "k_fft_2stage<%d, 16, 16, %%s, true>" % r1            # last argument: streaming (non-temporal) hint on
     m = {
@@ -81,7 +81,8 @@ def kernel_symbols(layout, ncoils, half_box=True, n=512):
                       "fft_crop_z": f % "16, false, 0, true, 0", "fft_crop_y": f % "32, false, 0, true, 0",
                       "fft_crop_x": f % ("16, false, %d, true, 0" % (3 + lg))})
         m.update({"csrmm_rowlane_conj": "k_csrmm_dense64<%d, true, true>" % ncoils, "csrmm_gather": gv,
-                  "csrmm_bricks_conj": "k_grid_bricks<%d, %d>" % (ncoils, 4 if ncoils == 8 else 0)})
+                  # (second argument: segments per 16 x 2 x 2 brick, unrolled for the 8-coil kernel)
+                  "csrmm_bricks_conj": "k_grid_bricks<%d, %d>" % (ncoils, (16 // support_tile) * 4 if ncoils == 8 else 0)})
     elif layout == 1:
         h = (3, 1, 1, 2, 2, 4) if half_box else (0,) * 6
         m.update({"fft_pad_x": f % ("16, true, 1, true, %d" % h[0]), "fft_pad_y": f % ("16, false, 0, true, %d" % h[1]),
@@ -338,7 +339,7 @@ def run_sense(args, cfg, B, comm, world, rank, steps, warmup, want_cpu, quiet=Fa
             prof[site]['bytes'] = float(grid_bytes.get(site, nb)) * prof[site]['launches']
     if "pack_panel" in prof and "pack_panel" in grid_bytes:
         prof["pack_panel"]['bytes'] = float(grid_bytes["pack_panel"]) * prof["pack_panel"]['launches']
-    symbols = kernel_symbols(layout if fused_fft else 0, cpr, half_box, p.oN[0])
+    symbols = kernel_symbols(layout if fused_fft else 0, cpr, half_box, p.oN[0], sup_tile if fused_fft else 16)
     roofline, kernels = roofline_of(prof, symbols, cfg)
     if not quiet:
         for k in sorted(prof, key=lambda k: -prof[k]['total_ms']):
