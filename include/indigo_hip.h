@@ -357,8 +357,9 @@ int  ig_fft_describe(ig_fft* plan, char* buf, size_t len);   /* kernel / radix s
  * by the cropped transform; sum the coils with ig_csum_il).                                         */
 int  ig_fft_plan_padded(ig_ctx* ctx, const int64_t* dims, const int64_t* box_lo, const int64_t* box_dims,
                         int64_t batch, int grid_layout, ig_fft** plan, size_t* workspace_bytes);
-/* support (optional, grid_layout 1 only; may be NULL): the k-space support of the gridding matrix that
- * consumes / produced Y, one contiguous int16 buffer in three parts (nt = n0/16 kx tiles):
+/* support (optional, grid_layouts 1 and 2; may be NULL): the k-space support of the gridding matrix that
+ * consumes / produced Y, one contiguous int16 buffer in three parts (nt = n0/16 kx tiles; layout 2 plans may switch to
+ * tiles of 8, 4 or 2 kx points with ig_fft_set_support_tile -- read 16 below as that tile):
  *   1. n1*nt pairs  [z_lo, z_hi)  at 2*(ky*nt + kx/16): the kz hull of the tile's column (empty: skip it);
  *   2. nt pairs     [y_lo, y_hi)  per kx tile: the ky range outside which every z hull is empty (y pass);
  *   3. n1*nt*16 uint32 words (4-byte aligned, every pair before it being 4 bytes):
