@@ -16,8 +16,8 @@ f = glob.glob("$OUT/g$i/**/c_counter_collection.csv", recursive=True)[0]
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
 for r in csv.DictReader(open(f)):
     k = r["Kernel_Name"]
-    if "k_grid_bricks<" in k or "k_fft_2stage<32, 16, 16, 32, false, 0, true, 1" in k:
-        k = "bricks" if "k_grid_bricks<" in k else "fft"
+    if "k_grid_bricks<" in k or "k_fft_2stage<32, 16, 16, 32, false, 0, true, 1" in k or "k_fft_2stage<32, 16, 16, 16, false, 0, true, 2" in k:
+        k = "bricks" if "k_grid_bricks<" in k else "fft_pad_yz(W32,half-in)" if "true, 1" in k else "fft_crop_z(W16,half-out)"
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[(k, r["Counter_Name"])] += 1
 for k in acc:
     print(k, {c: round(v / n[(k, c)]) for c, v in acc[k].items()})
