@@ -634,6 +634,9 @@ class HipBackend(Backend):
         def set_grid_support_fine(self, table, tile):
             """a support table with `tile` (8 or 4) kx points per entry: what the brick scatter writes by (the gather routes keep
             the 16-point table of set_grid_support; a reader with the finer table reads a subset of what they write)"""
+            assert getattr(self, '_bricks', None) is None, \
+                "set_grid_support_fine must come before set_grid_bricks: the runs of bricks are sized for the table's segments"
+            assert int(tile) in (4, 8, 16)
             self._support_fine = (self._backend.copy_array(np.ascontiguousarray(table, dtype=np.int16).reshape(-1),
                                                            name=self._name + ".supportFine"), int(tile))
 
