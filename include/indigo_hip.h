@@ -217,7 +217,7 @@ int  ig_ccsrmm_t_grid_il(ig_ctx* ctx,
  * sums; all pointers HOST memory).  `brick_table` (device, int32
  * x 2 per NON-EMPTY brick in brick order: brick id, end of its entries) and `tasks` (device, int32 x 4 per task: lo, hi,
  * first table row, number of table rows | shared << 16; lo and hi multiples of `unit`) give each wave either a run of
- * consecutive whole bricks (at most 64 bricks and 256 / (bm*bs) of them; [lo, hi) is exactly their entries) or a piece of
+ * consecutive whole bricks (at most 64 bricks and 512 segments; [lo, hi) is exactly their entries) or a piece of
  * ONE heavy brick, marked shared: its tasks add with float atomics and the brick is listed in `shared_bricks` (zeroed
  * first).  Only the 16-row segments flagged in `support` (third part, as ig_ccsrmm_t_grid; NULL = all segments of bricks
  * that hold a nonzero) are written; everything else is left untouched.  `support_tile` = kx points per entry of the support

@@ -673,8 +673,8 @@ class HipBackend(Backend):
                                                 bm, bs, unit, ptr.ctypes.data, entries.ctypes.data, round_rows.ctypes.data),
                        None, "ig_grid_bricks_fill")
             fine = getattr(self, '_support_fine', None)
-            nseg = (16 // (fine[1] if fine is not None else 16)) * bm * bs          # segments per brick (the kernel looks up 256 per run)
-            tasks, table, shared = brick_tasks(counts, ptr, chunk, run, max_bricks=min(64, 256 // nseg))
+            nseg = (16 // (fine[1] if fine is not None else 16)) * bm * bs          # segments per brick (the kernel looks up 512 per run)
+            tasks, table, shared = brick_tasks(counts, ptr, chunk, run, max_bricks=min(64, 512 // nseg))
             self._bricks = dict(n0=int(n0), nm=int(nm), bm=int(bm), bs=int(bs), ncols=int(ncols), ntasks=int(tasks.shape[0]),
                                 nshared=int(shared.size), nentries=int(ptr[-1]),
                                 tasks=b.copy_array(tasks.reshape(-1) if tasks.size else np.zeros(4, np.int32), name=self._name + ".brickTasks"),

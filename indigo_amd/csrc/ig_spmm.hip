@@ -864,8 +864,8 @@ struct BrickTask { int32_t lo, hi, bt, nb_flags; };     // entries [lo, hi) = br
 struct BrickRef { int32_t brick, end; };                  // a non-empty brick and where its entries end
 struct BrickEntry { uint32_t cell; float re, im; };       // 12 bytes; cell == 0xffffffff: padding
 
-// One wave per task.  A task is a run of consecutive non-empty bricks (about a thousand entries, at most 64 bricks and
-// 256 segments) or a piece of one heavy brick (shared).  The wave keeps ONE brick image in LDS and walks the run in
+// One wave per task.  A task is a run of consecutive non-empty bricks (a few thousand entries, at most 64 bricks and
+// 512 segments) or a piece of one heavy brick (shared).  The wave keeps ONE brick image in LDS and walks the run in
 // super-trips of 64 entries.  Loading and accumulating use different lane roles:
 //   * loading: lane e fetches entry e of the super-trip (ONE 12-byte load per lane: 768 useful bytes per instruction), and
 //     lane (r, coil) fetches X[sample of round r, coil] (one load: the 64/TPR panel rows of the super-trip), the samples
@@ -941,14 +941,14 @@ k_grid_bricks(const BrickTask* __restrict__ tasks, int ntasks, const BrickRef* _
         my_s0 = (brick / (nbx * nbm)) << bs_log2;
         my_pt = my_bx * 16 + n0 * (my_m0 + nm * my_s0);
     }
-    // ... and which of their segments are flagged: 64 (brick, segment) pairs per pass, four passes in flight
+    // ... and which of their segments are flagged: 64 (brick, segment) pairs per pass, eight passes in flight
     uint32_t my_mask = 0xffffffffu;
     if (bits) {
         const int nt = n0 >> st_log2;                    // support entries per grid row
         const rsrc_t r_bits = make_rsrc(bits);
-        uint32_t w[4];
+        uint32_t w[8];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < 8; ++p) {
             const int pair = p * 64 + lane, j = pair >> seg_log2, seg = pair & (nseg - 1);
             const int jbx = __shfl(my_bx, j & 63), jm0 = __shfl(my_m0, j & 63), js0 = __shfl(my_s0, j & 63);
             const int xs = seg & ((1 << xs_log2) - 1), im = (seg >> xs_log2) & (BM - 1), is = seg >> (xs_log2 + bm_log2);
@@ -957,7 +957,7 @@ k_grid_bricks(const BrickTask* __restrict__ tasks, int ntasks, const BrickRef* _
         }
         my_mask = 0u;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < 8; ++p) {
             const uint64_t bal = __ballot(w[p] & 1u);
             const int first = (p * 64) >> seg_log2, per = 64 >> seg_log2;                  // bricks of this pass
             if (lane >= first && lane < first + per)
