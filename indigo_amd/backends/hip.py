@@ -662,8 +662,13 @@ class HipBackend(Backend):
             data = np.ascontiguousarray(A.data, dtype=_C64)
             nb = (n0 // 16) * (nm // bm) * (ns // bs)
             counts = np.zeros(nb, dtype=np.int32)
-            _lib.check(b._L.ig_grid_bricks_count(A.shape[0], indptr.ctypes.data, indices.ctypes.data, n0, nm, ns, bm, bs, unit,
-                                                 counts.ctypes.data), None, "ig_grid_bricks_count")
+            if b._L.ig_grid_bricks_count(A.shape[0], indptr.ctypes.data, indices.ctypes.data, n0, nm, ns, bm, bs, unit,
+                                         counts.ctypes.data) != 0:
+                # e.g. a row that touches more than 64 bricks (very wide gridding kernels): the gather over the transpose serves it
+                log.info("%s: no brick-binned format (%s); the adjoint keeps the gather route", self._name,
+                         _lib.last_error(None) if hasattr(_lib, 'last_error') else "ig_grid_bricks_count failed")
+                self._bricks = None
+                return
             ptr = np.zeros(nb + 1, dtype=np.int64)
             np.cumsum(counts, out=ptr[1:])
             assert ptr[-1] < 2**31, "brick entries are addressed with 32 bits"

@@ -203,6 +203,27 @@ def test_csr_matrix_vs_scipy(hip, M, K, n, density):
     hip.adjoint_policy = "transpose"
 
 
+def test_brick_format_declined_for_rows_that_touch_too_many_bricks(hip):
+    """a row spread over more than 64 bricks has no brick-binned format: set_grid_bricks declines and the adjoint of the
+    interleaved panel is served by the gather over the transpose"""
+    n0, nm, ns = 64, 64, 64
+    P, T = n0 * nm * ns, 50
+    rng = np.random.default_rng(4)
+    rows = np.repeat(np.arange(T), 200)
+    cols = rng.integers(0, P, size=rows.size)                               # 200 nonzeros all over the grid per row
+    A = spp.csr_matrix((rand64c(rows.size, seed=1), (rows, cols)), shape=(T, P))
+    A.sum_duplicates(); A.sort_indices()
+    A_d = hip.csr_matrix(hip, A)
+    A_d.set_grid_interleaved(True)
+    A_d.set_grid_bricks(n0, nm, ns, ncols=8)
+    assert A_d._bricks is None
+    X = rand64c(T, 8, seed=2)
+    y_d = hip.zero_array((P, 8), C64)
+    A_d.adjoint(y_d, hip.copy_array(X))
+    got = y_d.to_host().reshape(-1, order='F').reshape(P, 8)
+    assert rel_err(got, A.conj().T.astype(np.complex128) @ X.astype(np.complex128)) < RTOL
+
+
 @pytest.mark.parametrize("K,alpha,ld_pad,dense_blob", [(4096, 1, 0, False), (20000 // 16 * 16, 0.5 - 0.25j, 5, True), (64, 2, 0, False)])
 def test_wide_panel_adjoint_by_bricks(hip, monkeypatch, K, alpha, ld_pad, dense_blob):
     """ig_ccsrmm_t_bricks_wide: A^H X for a 64-column column-major panel as a scatter binned by 16-row bricks of the result --
