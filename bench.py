@@ -369,7 +369,8 @@ def run_sense(args, cfg, B, comm, world, rank, steps, warmup, want_cpu, quiet=Fa
                                                                              " (BASELINE config %d)" % cfg),
                    "parallelism": ("coil-sharded x%d (%d coils per rank), one all-reduce of the image per eval" % (world, len(coils))
                                    if world > 1 else ("rank %d of %d alone (no communication)" % shard if shard else "single GPU")),
-                   "grid_layout": layout, "tree": tree, "coil_chunks_per_rank": nchunks},
+                   "grid_layout": layout, "tree": tree, "coil_chunks_per_rank": nchunks,
+                   "support_table_kx_points_per_entry": (sup_tile if sup_tab is not None else None)},
         "roofline": roofline,
         "eval_traffic_GB": traffic_bytes / 1e9,
         "eval_traffic_frac": traffic_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
