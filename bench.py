@@ -8,8 +8,9 @@ non-Cartesian SENSE normal operator (the reference's `-O3` tree S' -> FFT -> G' 
 the FFT fused into the zero-pad-aware `ZpadFFT` leaf; `--tree o3` runs the reference's leaves one by one, `--tree
 recipe` reaches the fused leaf through the reference's own recipe + `FuseZpadFFT`) on synthetic inputs already
 resident in HBM: image 256^3, 8 coils, oversampled grid 512^3, 3-D radial trajectory with 1,851,904 samples,
-width-4 (indigo width=2) Kaiser-Bessel gridding.  For N > 1 (launched by torch.distributed.run, one rank per GPU)
-the coils are sharded over the ranks and each evaluation ends in one RCCL all-reduce of the image: strong scaling.
+width-4 (indigo width=2) Kaiser-Bessel gridding.  For N > 1 (one rank per GPU: launched by
+torch.distributed.run, or -- a plain `python bench.py --gpus N` -- by this script itself, which then starts the N ranks as
+child processes) the coils are sharded over the ranks and each evaluation ends in one RCCL all-reduce of the image: strong scaling.
 
 Other configs (each prints its own JSON line, same contract fields):
     --config 1   examples/spmm.py: random 1e4 x 1e4 CSR (1 % nnz) x 8 RHS -- the reference's CPU-runnable case
@@ -99,6 +100,16 @@ def load_pmc(cfg):
     return json.load(open(path)), PMC_SUMMARIES[cfg] + PMC_NOTE
 
 
+def pmc_stale(pmc, symbols=()):
+    """True when a committed PMC summary no longer describes the kernels that just ran: it was collected from other kernel
+    sources (tools/pmc_summary.py records their hash), or a kernel symbol it is asked for is not in it"""
+    if not pmc:
+        return None
+    from indigo_amd.build import source_hash
+    meta = pmc.get("_meta") or {}
+    return meta.get("csrc_sha16") != source_hash() or any(s not in pmc for s in symbols)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -117,9 +128,14 @@ def parse():
                     help="all-reduce provider for N > 1: the library's own RCCL binding (ig_comm_*), or torch.distributed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config5", action="store_true", help="default run: skip the extra config-5 measurement")
+    ap.add_argument("--no-leaf-configs", action="store_true", help="default run at N = 1: skip the extra config-2 / config-3 measurements")
     ap.add_argument("--batch", type=int, default=16, help="config 2: number of volumes")
     ap.add_argument("--ncol", type=int, default=64, help="config 3: panel columns")
-    return ap.parse_args()
+    ap.add_argument("--no-extras", action="store_true", help="only the selected config: --no-config5 --no-leaf-configs (profiling runs)")
+    args = ap.parse_args()
+    if args.no_extras:
+        args.no_config5 = args.no_leaf_configs = True
+    return args
 
 
 RANK = int(os.environ.get("RANK", "0"))
@@ -180,6 +196,7 @@ def roofline_of(prof, symbols, cfg, pick=None):
                bytes_model="compulsory bytes of the pass (box, k-space support and coil sum taken into account), see DESIGN.md 3")
     if traffic:
         out["traffic_frac_of_peak"] = traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    out["traffic_stale"] = pmc_stale(pmc, [dom])
     if d['ref_bytes']:
         rb = d['ref_bytes'] / d['launches']
         out["reference_model"] = dict(bytes_per_launch=rb, equiv_GBps=rb / (avg_ms * 1e-3) / 1e9,
@@ -375,6 +392,7 @@ def run_sense(args, cfg, B, comm, world, rank, steps, warmup, want_cpu, quiet=Fa
         "eval_traffic_GB": traffic_bytes / 1e9,
         "eval_traffic_frac": traffic_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
         "eval_traffic_source": traffic_src,
+        "eval_traffic_stale": pmc_stale(pmc, [k for k in kernels if k.startswith("k_")]) if (pmc and traffic_src == pmc_src) else None,
         "eval_compulsory_GB": comp_bytes / 1e9,
         "reference_model_GB_per_eval_per_gpu": ref_bytes_rank / 1e9,
         "reference_model_equiv": ref_bytes_rank / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -463,6 +481,24 @@ def bench_sense(args, world, rank, local_rank):
         except Exception as e:             # noqa: BLE001 -- the extra measurement must not cost the headline its line
             extra5 = {"error": "%s: %s" % (type(e).__name__, e)}
             print("[bench] config-5 extra failed on rank %d: %s" % (rank, extra5["error"]), file=sys.stderr, flush=True)
+    leaves = {}
+    if rank == 0 and world == 1 and cfg == 4 and not args.no_leaf_configs and not args.shard and not args.image and not args.coils \
+            and args.tree == "zpadfft":
+        # the other half of BASELINE.json's metric ("SpMM HBM GB/s vs peak") and the plain FFT contract, in the same driver-run
+        # line: BASELINE configs 2 and 3 with their own roofline / cpu_baseline / parity objects (`--config 2|3` alone prints
+        # the same objects as full lines)
+        import copy
+        for c, fn in ((2, bench_fft), (3, bench_spmm)):
+            a2 = copy.copy(args)
+            a2.config, a2.image, a2.steps, a2.warmup = c, 0, max(5, min(args.steps, 10)), min(args.warmup, 3)
+            try:
+                B._scratch = None
+                r = fn(a2, local_rank, B)
+                leaves["config%d" % c] = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "config", "roofline",
+                                                          "cpu_baseline", "parity_rel_err", "kernels")}
+            except Exception as e:             # noqa: BLE001 -- an extra must not cost the headline its line
+                leaves["config%d" % c] = {"error": "%s: %s" % (type(e).__name__, e)}
+                print("[bench] config-%d extra failed: %s" % (c, leaves["config%d" % c]["error"]), file=sys.stderr, flush=True)
     if rank == 0:
         name = ("SENSE AHA evals/sec (256^3 x 8-coil non-Cartesian)" if cfg == 4 and not args.image and not args.coils
                 else "SENSE AHA evals/sec (%s)" % res["config"]["workload"].split(",", 1)[1].split(";")[0].strip())
@@ -473,6 +509,7 @@ def bench_sense(args, world, rank, local_rank):
         out.setdefault("cpu_baseline", None)
         if extra5 is not None:
             out["config5"] = extra5
+        out.update(leaves)
         print(json.dumps(out), flush=True)
     if comm is not None:
         comm.close()
@@ -481,11 +518,11 @@ def bench_sense(args, world, rank, local_rank):
 # ---------------------------------------------------------------------------------------------------------
 # config 2: batched 3-D C2C FFT, 256^3 x 16 (the reference contract Backend.fftn/ifftn, benchmark.py:36-62)
 # ---------------------------------------------------------------------------------------------------------
-def bench_fft(args, local_rank):
+def bench_fft(args, local_rank, B=None):
     import numpy as np
     from indigo_amd.backends import get_backend
     from indigo_amd.util import rand64c
-    B = get_backend("hip", device_id=local_rank)
+    B = B or get_backend("hip", device_id=local_rank)
     n = args.image or 256
     batch = args.batch
     shape = (n, n, n, batch)
@@ -528,17 +565,18 @@ def bench_fft(args, local_rank):
                             frac=4.0 * nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             algorithmic_bytes_per_launch=4.0 * nbytes,
                             bytes_model="SURVEY 8(d) / benchmark.py:55: 4 * x.nbytes per multi-dimensional transform",
-                            traffic=traffic, traffic_source=src if traffic else None,
+                            traffic=traffic, traffic_source=src if traffic else None, traffic_stale=pmc_stale(pmc),
                             traffic_frac_of_peak=(traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                             kernel_ms_per_transform=tot_kernel_ms),
            "cpu_baseline": cpu, "parity_rel_err": perr, "kernels": kernel_table(prof, args.steps)}
-    print(json.dumps(out), flush=True)
+    del x, yv
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------
 # config 3: 3-D radial gridding CSR (T x 256^3, 27 taps/row, ~5e7 nnz) x 64-column panel (benchmark.py:65-97)
 # ---------------------------------------------------------------------------------------------------------
-def bench_spmm(args, local_rank):
+def bench_spmm(args, local_rank, B=None):
     import numpy as np
     import scipy.sparse as spp
     from scipy.signal.windows import kaiser
@@ -546,7 +584,7 @@ def bench_spmm(args, local_rank):
     from indigo_amd.interp import interp_csr_arrays
     from indigo_amd.sense import radial_trajectory
     from indigo_amd.util import rand64c, Trace
-    B = get_backend("hip", device_id=local_rank)
+    B = B or get_backend("hip", device_id=local_rank)
     n = args.image or 256
     ncol = args.ncol
     N = (n, n, n)
@@ -628,11 +666,12 @@ def bench_spmm(args, local_rank):
                             peak=HBM_PEAK_GBS, unit="GB/s", frac=fb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             algorithmic_bytes_per_launch=fb,
                             bytes_model="SURVEY 8(d) / operators.py:246-256: nnz*12 + (M+1)*4 + K*n*8*col_frac + M*n*8",
-                            traffic=traffic, traffic_source=src if traffic else None,
+                            traffic=traffic, traffic_source=src if traffic else None, traffic_stale=pmc_stale(pmc),
                             traffic_frac_of_peak=(traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None),
            "cpu_baseline": cpu, "parity_rel_err": perr,
            "kernels": {"forward": ktab_f, "adjoint": ktab_a}}
-    print(json.dumps(out), flush=True)
+    del X, Y, Z, S
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -674,15 +713,98 @@ def bench_spmm_example(args, local_rank):
            "cpu_baseline": dict(value=1.0 / min(ts[1:]), unit="products/s", cores=1, kind="port", **host_info(),
                                 sample="numpy oracle SpMatrix.eval, 1 warm-up + min of 10 (%.2f ms)" % (min(ts[1:]) * 1e3)),
            "parity_rel_err": perr, "kernels": kernel_table(prof, steps)}
-    print(json.dumps(out), flush=True)
+    return out
+
+
+def visible_gpu_count():
+    """GPUs of this node WITHOUT initialising the HIP runtime in this process (the launcher must stay clear of the GPU: it
+    starts the ranks as child processes): KFD topology nodes with compute units, cut down by a *_VISIBLE_DEVICES list."""
+    n = 0
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for node in os.listdir(base):
+            with open(os.path.join(base, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except OSError:
+        return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        if os.environ.get(var, "").strip():
+            n = min(n, len([v for v in os.environ[var].split(",") if v.strip()]))
+    return n
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` started without a launcher: this process becomes the launcher.  It never touches the GPU;
+    it starts N fresh ranks of this same script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as torch.distributed.run would
+    set them, the RCCL id file in a private directory), relays rank 0's JSON line, and fails if any rank does."""
+    import shutil
+    import socket
+    import subprocess
+    import tempfile
+    n = args.gpus
+    rehearsal = os.environ.get("INDIGO_BENCH_DIST_BACKEND", "nccl") != "nccl"       # gloo: all ranks on GPU 0
+    have = visible_gpu_count()
+    if not rehearsal and have is not None and have < n:
+        print("[bench] --gpus %d but this node shows %d GPU(s): one rank per GPU" % (n, have), file=sys.stderr, flush=True)
+        sys.exit(2)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    rdv = tempfile.mkdtemp(prefix="indigo_bench_")
+    procs = []
+    rc = 0
+    try:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), INDIGO_COMM_ID_FILE=os.path.join(rdv, "rccl_id"),
+                       INDIGO_BENCH_LAUNCHER="self")
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+        print("[bench] launcher: started %d ranks (pids %s)" % (n, [p.pid for p in procs]), file=sys.stderr, flush=True)
+        out0 = None
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                if r == 0 and out0 is None:
+                    # (rank 0 prints one line at the very end: reading its pipe to EOF is the wait)
+                    try:
+                        out0, _ = procs[0].communicate(timeout=0.5)
+                    except subprocess.TimeoutExpired:
+                        pass
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code
+                    print("[bench] launcher: rank %d exited with %d; stopping the others" % (r, code), file=sys.stderr, flush=True)
+                    for q in pending:
+                        procs[q].terminate()
+            time.sleep(0.2)
+        if out0:
+            sys.stdout.write(out0.decode())
+            sys.stdout.flush()
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        shutil.rmtree(rdv, ignore_errors=True)
+    sys.exit(rc if rc else 0)
 
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and not args.shard:
+        assert args.config in (4, 5), "configs 1-3 are single-GPU leaf benchmarks"
+        self_launch(args)
     rank = RANK
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, "--gpus must match WORLD_SIZE"
+    assert world == args.gpus, "--gpus %d but WORLD_SIZE is %d" % (args.gpus, world)
     if world > 1 and args.comm != "rccl":
         # The collective is the library's own RCCL binding (ig_comm_*).  Under `--comm auto` torch is imported FIRST --
         # before libindigo_hip.so loads -- only so that the fallback to torch.distributed stays possible: torch ships its own
@@ -702,7 +824,7 @@ def main():
         bench_sense(args, world, rank, local_rank)
     else:
         assert world == 1, "configs 1-3 are single-GPU leaf benchmarks"
-        {1: bench_spmm_example, 2: bench_fft, 3: bench_spmm}[args.config](args, local_rank)
+        print(json.dumps({1: bench_spmm_example, 2: bench_fft, 3: bench_spmm}[args.config](args, local_rank)), flush=True)
 
 
 if __name__ == "__main__":

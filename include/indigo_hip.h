@@ -113,13 +113,18 @@ int  ig_cmax(ig_ctx* ctx, int64_t nfloats, float val, void* arr);           /* a
  * beta = r2 / rr) enqueues without a single host synchronisation.  ig_scalars hands out the context's block of
  * doubles (zeroed); any device double pointers may be used.
  *   ig_cdotc_dev / ig_scnrm2sq_dev : results to d_out[0..1] / d_out[0]
- *   ig_scalar_ratio : *d_out = scale * *d_num / *d_den            ig_scalar_copy : d_dst[0..count) = d_src[0..count)
+ *   ig_scalar_ratio : *d_out = scale * *d_num / *d_den (0 when *d_den == 0)   ig_scalar_copy : d_dst[0..count) = d_src[0..count)
+ *   ig_scalar_ratio_gated : the same, forced to 0 once *d_gate_num < gate_tol * *d_gate_den (a solver's step length after
+ *                     its residual passed the tolerance: iterations enqueued beyond convergence become no-ops; the
+ *                     reference breaks out of its loop on the host instead, backend.py:683-685)
  *   ig_caxpby_dev   : y = (beta_scale * *d_beta) * y + (alpha_scale * *d_alpha) * x   (a NULL pointer stands for 1)
  *   ig_scalar_read  : device -> host, synchronous (the residual history, every so many iterations)           */
 int  ig_scalars(ig_ctx* ctx, double** d_slots, int* nslots);
 int  ig_cdotc_dev(ig_ctx* ctx, int64_t n, const void* x, const void* y, double* d_out);
 int  ig_scnrm2sq_dev(ig_ctx* ctx, int64_t n, const void* x, double* d_out);
 int  ig_scalar_ratio(ig_ctx* ctx, double* d_out, const double* d_num, const double* d_den, double scale);
+int  ig_scalar_ratio_gated(ig_ctx* ctx, double* d_out, const double* d_num, const double* d_den, double scale,
+                           const double* d_gate_num, const double* d_gate_den, double gate_tol);
 int  ig_scalar_copy(ig_ctx* ctx, double* d_dst, const double* d_src, int64_t count);
 int  ig_scalar_read(ig_ctx* ctx, const double* d_src, int64_t count, double* host);
 int  ig_caxpby_dev(ig_ctx* ctx, int64_t n, const double* d_beta, float beta_scale, void* y,
@@ -333,6 +338,10 @@ int  ig_fft_plan(ig_ctx* ctx, int rank, const int64_t* dims, int64_t batch,
 int  ig_fft_exec(ig_fft* plan, const void* x, void* y, int direction /* -1 fwd, +1 inv */,
                  void* workspace /* >= workspace_bytes, may be NULL if 0 */);
 int  ig_fft_describe(ig_fft* plan, char* buf, size_t len);   /* kernel / radix schedule, for logs and tests */
+/* Bytes of workspace that make an IN-PLACE ig_fft_exec (x == y) as fast as an out-of-place one (>= the plan's
+ * workspace_bytes).  The two-launch 256^3 transform cannot run in place and stages through it; called in place without a
+ * workspace it runs the three in-place axis passes instead.  The library never allocates device memory inside an exec. */
+int  ig_fft_inplace_workspace(ig_fft* plan, size_t* bytes);
 
 /* Zero-padded forward / cropped inverse 3-D transforms: the fusion of the reference's
  * Zpad . diag . FFT chain (indigo/backends/backend.py:371-387 Zpad, :355-369 FFTc, :403-442 NUFFT;

@@ -47,6 +47,7 @@ PROTOTYPES = {
     "ig_cdotc_dev":       (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "ig_scnrm2sq_dev":    (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "ig_scalar_ratio":    (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_double]),
+    "ig_scalar_ratio_gated": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_double]),
     "ig_scalar_copy":     (c_int, [c_void_p, c_void_p, c_void_p, c_int64]),
     "ig_scalar_read":     (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "ig_caxpby_dev":      (c_int, [c_void_p, c_int64, c_void_p, c_float, c_void_p, c_void_p, c_float, c_void_p]),
@@ -97,6 +98,7 @@ PROTOTYPES = {
     "ig_fft_plan":        (c_int, [c_void_p, c_int, POINTER(c_int64), c_int64, POINTER(c_void_p), POINTER(c_size_t)]),
     "ig_fft_exec":        (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ig_fft_describe":    (c_int, [c_void_p, c_char_p, c_size_t]),
+    "ig_fft_inplace_workspace": (c_int, [c_void_p, POINTER(c_size_t)]),
     "ig_fft_destroy":     (c_int, [c_void_p]),
     "ig_fft_plan_padded": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), c_int64, c_int,
                                    POINTER(c_void_p), POINTER(c_size_t)]),

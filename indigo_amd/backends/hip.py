@@ -90,8 +90,8 @@ class HipBackend(Backend):
 
     def __del__(self):
         try:
-            for plan, _ in getattr(self, '_plans', {}).values():
-                self._L.ig_fft_destroy(plan)
+            for entry in getattr(self, '_plans', {}).values():
+                self._L.ig_fft_destroy(entry[0])
             if getattr(self, '_ctx', None):
                 self._L.ig_destroy(self._ctx)
                 self._ctx = None
@@ -324,16 +324,18 @@ class HipBackend(Backend):
         numbers as Backend.cg / the reference's backend.py:651-689): alpha = rr/<p,Ap> and beta = r2/rr are computed
         by one-thread kernels from the reductions' device results and read by the axpby kernels from device memory,
         so an iteration enqueues without a host synchronisation.  The relative residuals are recorded on the device for
-        EVERY iteration and fetched every `check_every` iterations (the only syncs); the tolerance test therefore
-        takes effect at the end of such a block -- up to check_every-1 iterations after the reference would have
-        stopped (`check_every=1` reproduces its stopping iteration exactly).  A `team` (host-scalar all-reduces per
-        iteration, backend.py:469-479) uses the base implementation."""
+        EVERY iteration and fetched every `check_every` iterations (the only syncs).  The reference leaves its loop the
+        moment resid < tol (backend.py:683-685); here up to check_every-1 further iterations are already enqueued by
+        then, so the step length is gated on the device: once rr/r0 < tol^2 (or <p,Ap> == 0: an exactly converged
+        system) alpha is 0 and those iterations leave x and r alone.  The returned history ends at the first residual
+        below tol, like the reference's.  A `team` (host-scalar all-reduces per iteration, backend.py:469-479) uses the
+        base implementation."""
         if team is not None or not (hasattr(A, 'eval')):
             return super().cg(A, b_h, x_h, lamda=lamda, tol=tol, maxiter=maxiter, team=team)
         base, nslots = self._slots()
-        assert maxiter + 8 <= nslots, "cg: at most %d iterations per call" % (nslots - 8)
         S = lambda i: ctypes.c_void_p(base + 8 * i)          # slot i (a device double)
         RR, R0, PAP, ALPHA, R2, BETA, HIST = 0, 1, 2, 4, 5, 6, 8
+        cap = nslots - HIST                                  # history slots: a ring, fetched before it wraps
         L, ctx = self._L, self._ctx
         P = lambda a: ctypes.c_void_p(a._arr)
         x_dev = isinstance(x_h, self.dndarray)
@@ -351,31 +353,36 @@ class HipBackend(Backend):
         self._check(L.ig_scalar_copy(ctx, S(R0), S(RR), 1), "ig_scalar_copy")
         history = []
         fetched = 0
-        host = (ctypes.c_double * max(maxiter, 1))()
+        every = max(1, min(int(check_every), cap))
+        host = (ctypes.c_double * every)()
+        tol2 = float(tol) ** 2
         it = 0
-        while it < maxiter:
+        done = False
+        while it < maxiter and not done:
             A.eval(Ap, p)
             self.axpby(1, Ap, lamda, p)
             self._check(L.ig_cdotc_dev(ctx, n, P(p), P(Ap), S(PAP)), "ig_cdotc_dev")
-            self._check(L.ig_scalar_ratio(ctx, S(ALPHA), S(RR), S(PAP), 1.0), "ig_scalar_ratio")       # alpha = rr / Re<p, Ap>
+            # alpha = rr / Re<p, Ap>; zero once rr / r0 < tol^2 (the reference has left its loop by then)
+            self._check(L.ig_scalar_ratio_gated(ctx, S(ALPHA), S(RR), S(PAP), 1.0, S(RR), S(R0), tol2), "ig_scalar_ratio_gated")
             self._check(L.ig_caxpby_dev(ctx, n, None, 1.0, P(x), S(ALPHA), 1.0, P(p)), "ig_caxpby_dev")    # x += alpha p
             self._check(L.ig_caxpby_dev(ctx, n, None, 1.0, P(r), S(ALPHA), -1.0, P(Ap)), "ig_caxpby_dev")  # r -= alpha Ap
             self._check(L.ig_scnrm2sq_dev(ctx, n, P(r), S(R2)), "ig_scnrm2sq_dev")
             self._check(L.ig_scalar_ratio(ctx, S(BETA), S(R2), S(RR), 1.0), "ig_scalar_ratio")         # beta = r2 / rr
             self._check(L.ig_caxpby_dev(ctx, n, S(BETA), 1.0, P(p), None, 1.0, P(r)), "ig_caxpby_dev")     # p = beta p + r
             self._check(L.ig_scalar_copy(ctx, S(RR), S(R2), 1), "ig_scalar_copy")                      # rr = r2
-            self._check(L.ig_scalar_ratio(ctx, S(HIST + it), S(R2), S(R0), 1.0), "ig_scalar_ratio")    # (resid_it)^2
+            self._check(L.ig_scalar_ratio(ctx, S(HIST + it % every), S(R2), S(R0), 1.0), "ig_scalar_ratio")   # (resid_it)^2
             it += 1
-            if it % max(int(check_every), 1) == 0 or it == maxiter:
-                self._check(L.ig_scalar_read(ctx, S(HIST + fetched), it - fetched, ctypes.byref(host, 8 * fetched)), "ig_scalar_read")
-                for j in range(fetched, it):
+            if it - fetched == every or it == maxiter:
+                self._check(L.ig_scalar_read(ctx, S(HIST), it - fetched, host), "ig_scalar_read")
+                for j in range(it - fetched):
                     history.append(float(np.sqrt(host[j])))
-                    log.info("iter %d, residual %g", j, history[-1])
+                    log.info("iter %d, residual %g", fetched + j, history[-1])
+                    if history[-1] < tol:
+                        log.info("cg reached tolerance")
+                        done = True
+                        break
                 fetched = it
-                if min(history) < tol:
-                    log.info("cg reached tolerance")
-                    break
-        else:
+        if not done:
             log.info("cg reached maxiter")
         if not x_dev:
             x.copy_to(x_h)
@@ -396,14 +403,18 @@ class HipBackend(Backend):
             plan, ws = ctypes.c_void_p(), ctypes.c_size_t()
             self._check(self._L.ig_fft_plan(self._ctx, len(dims), c_dims, x_shape[-1],
                                             ctypes.byref(plan), ctypes.byref(ws)), "ig_fft_plan%s" % (x_shape,))
-            self._plans[x_shape] = (plan, ws.value)
+            ws_in = ctypes.c_size_t()
+            self._check(self._L.ig_fft_inplace_workspace(plan, ctypes.byref(ws_in)), "ig_fft_inplace_workspace")
+            self._plans[x_shape] = (plan, ws.value, ws_in.value)
         return self._plans[x_shape]
 
     def _fft_workspace_size(self, x_shape):
-        return self._get_or_create_plan(x_shape)[1]
+        """bytes of scratch an UnscaledFFT of this shape may take (operators.UnscaledFFT._mem_usage / ScratchUsage): the
+        in-place figure, so that a tree sized by it never allocates inside an evaluation"""
+        return self._get_or_create_plan(x_shape)[2]
 
     def fft_describe(self, x_shape):
-        plan, _ = self._get_or_create_plan(x_shape)
+        plan = self._get_or_create_plan(x_shape)[0]
         buf = ctypes.create_string_buffer(1024)
         self._check(self._L.ig_fft_describe(plan, buf, 1024), "ig_fft_describe")
         return buf.value.decode()
@@ -411,7 +422,9 @@ class HipBackend(Backend):
     def _fft(self, y, x, direction):
         assert x.dtype == _C64 and y.dtype == _C64, "only complex64 is supported"
         assert x.shape == y.shape and x.contiguous and y.contiguous
-        plan, ws = self._get_or_create_plan(x.shape)
+        plan, ws, ws_inplace = self._get_or_create_plan(x.shape)
+        if x._arr == y._arr:
+            ws = ws_inplace
         if ws:
             with self.scratch(nbytes=ws) as tmp:
                 rc = self._L.ig_fft_exec(plan, ctypes.c_void_p(x._arr), ctypes.c_void_p(y._arr), direction,

@@ -38,6 +38,18 @@ EXTRA_FLAGS = {
 }
 
 
+def source_hash():
+    """sha256 (16 hex digits) over the kernel sources and headers the library is built from: recorded beside measurements
+    that are only valid for these exact kernels (the rocprofv3 PMC summaries under profiles/, tools/pmc_summary.py)"""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(CSRC)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(CSRC, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def lib_path():
     return os.path.join(LIBDIR, LIBNAME)
 

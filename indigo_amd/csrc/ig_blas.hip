@@ -223,7 +223,16 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 // tiny scalar programs on device-resident doubles (one thread): the glue between a solver's reductions and its updates
 __global__ void k_scalar_ratio(double* __restrict__ out, const double* __restrict__ num, const double* __restrict__ den, double scale) {
-    out[0] = scale * num[0] / den[0];
+    const double d = den[0];
+    out[0] = d == 0.0 ? 0.0 : scale * num[0] / d;         // 0/0 of an exactly converged solver: a zero step, not NaN
+}
+// the same, forced to zero once gate_num < gate_tol * gate_den (CG: the step length after the residual passed the tolerance,
+// so that iterations enqueued beyond convergence leave x and r alone)
+__global__ void k_scalar_ratio_gated(double* __restrict__ out, const double* __restrict__ num, const double* __restrict__ den, double scale,
+                                     const double* __restrict__ gate_num, const double* __restrict__ gate_den, double gate_tol) {
+    const double d = den[0];
+    const bool stop = !(gate_num[0] >= gate_tol * gate_den[0]);
+    out[0] = (d == 0.0 || stop) ? 0.0 : scale * num[0] / d;
 }
 __global__ void k_scalar_copy(double* __restrict__ dst, const double* __restrict__ src, int count) {
     for (int i = threadIdx.x; i < count; i += blockDim.x) dst[i] = src[i];
@@ -351,6 +360,15 @@ int ig_scalar_ratio(ig_ctx* ctx, double* d_out, const double* d_num, const doubl
     if (int rc = ig_set_device(ctx)) return rc;
     hipLaunchKernelGGL(k_scalar_ratio, dim3(1), dim3(1), 0, ctx->stream, d_out, d_num, d_den, scale);
     IG_LAUNCH_CHECK(ctx, "k_scalar_ratio");
+    return IG_OK;
+}
+
+int ig_scalar_ratio_gated(ig_ctx* ctx, double* d_out, const double* d_num, const double* d_den, double scale,
+                          const double* d_gate_num, const double* d_gate_den, double gate_tol) {
+    IG_REQUIRE(ctx, ctx && d_out && d_num && d_den && d_gate_num && d_gate_den, "ig_scalar_ratio_gated: bad arguments");
+    if (int rc = ig_set_device(ctx)) return rc;
+    hipLaunchKernelGGL(k_scalar_ratio_gated, dim3(1), dim3(1), 0, ctx->stream, d_out, d_num, d_den, scale, d_gate_num, d_gate_den, gate_tol);
+    IG_LAUNCH_CHECK(ctx, "k_scalar_ratio_gated");
     return IG_OK;
 }
 

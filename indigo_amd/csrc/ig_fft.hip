@@ -979,7 +979,7 @@ struct ig_fft {
     std::string desc;
     // zero-padded / cropped plans (ig_fft_plan_padded): the image occupies box_lo .. box_lo+box_dims of the grid
     bool two_launch = false;         // 256^3 volumes: k_fft3d_a + k_fft3d_b instead of three axis passes
-    float2* d_inplace = nullptr;     // lazily allocated staging volume set for in-place calls of the two-launch transform
+    size_t inplace_workspace_bytes = 0;   // two-launch transform called in place: staging volumes in the CALLER's workspace (ig_fft_inplace_workspace)
     bool padded = false;
     int layout = 0;                  // memory order of the grid: 0 = (x, y, z), 1 = (x, z, y)
     int support_tile = 16;           // kx points per entry of the k-space support table (layout 2: ig_fft_set_support_tile)
@@ -1229,6 +1229,7 @@ int ig_fft_plan(ig_ctx* ctx, int rank, const int64_t* dims, int64_t batch, ig_ff
     {
         static const int use2 = getenv("INDIGO_HIP_FFT_2LAUNCH") ? atoi(getenv("INDIGO_HIP_FFT_2LAUNCH")) : 1;
         p->two_launch = use2 > 0 && rank == 3 && dims[0] == 256 && dims[1] == 256 && dims[2] == 256 && p->axis[0].kind == 3;
+        if (p->two_launch) p->inplace_workspace_bytes = (size_t)p->total * 8;
     }
 
     char buf[256];
@@ -1267,7 +1268,10 @@ int ig_fft_exec(ig_fft* p, const void* xv, void* yv, int direction, void* worksp
     float2* y = (float2*)yv;
     float2* work = (float2*)workspace;
 
-    if (p->two_launch) {
+    // launch A cannot run in place: an in-place call stages through the caller's workspace (ig_fft_inplace_workspace bytes);
+    // without one it takes the three axis passes below, which do run in place -- the library allocates nothing behind the
+    // caller's back
+    if (p->two_launch && !(xv == yv && !workspace)) {
         // two exchange images + the twiddle table: 75.7 KB per workgroup (two workgroups per CU), above the 64 KB a kernel may
         // use without opting in
         const size_t lds_b = (size_t)(2 * F3_LDS_ELEMS + 256) * sizeof(float2);
@@ -1278,10 +1282,7 @@ int ig_fft_exec(ig_fft* p, const void* xv, void* yv, int direction, void* worksp
         }
         const float2* src = (const float2*)xv;
         float2* mid = y;
-        if (xv == yv) {         // launch A cannot run in place: stage through a volume set owned by the plan
-            if (!p->d_inplace) IG_HIP(ctx, hipMalloc((void**)&p->d_inplace, (size_t)p->total * 8));
-            mid = p->d_inplace;
-        }
+        if (xv == yv) mid = (float2*)workspace;
         const double half_bytes = 2.0 * (double)p->total * 8.0;        // benchmark.py:55: 4 * nbytes per transform
         static const int dbg = getenv("INDIGO_HIP_FFT_2LAUNCH") ? atoi(getenv("INDIGO_HIP_FFT_2LAUNCH")) : 1;   // 2: launch A only, 3: launch B only (tools/fft2pass_check.py)
         if (dbg == 3) mid = const_cast<float2*>(src);
@@ -1812,6 +1813,12 @@ int ig_fft_exec_cropped_sum_slab(ig_fft* p, const void* yv, const void* wv, void
                                 (const short2*)support, true, phase == 0 ? 1 : 2, z0, z1);
 }
 
+int ig_fft_inplace_workspace(ig_fft* p, size_t* bytes) {
+    if (!p || !bytes) return ig_fail(nullptr, IG_ERR_ARG, "ig_fft_inplace_workspace: bad arguments");
+    *bytes = p->inplace_workspace_bytes > p->workspace_bytes ? p->inplace_workspace_bytes : p->workspace_bytes;
+    return IG_OK;
+}
+
 int ig_fft_describe(ig_fft* p, char* buf, size_t len) {
     if (!p || !buf || len == 0) return ig_fail(nullptr, IG_ERR_ARG, "ig_fft_describe: bad arguments");
     snprintf(buf, len, "%s", p->desc.c_str());
@@ -1824,7 +1831,6 @@ int ig_fft_destroy(ig_fft* p) {
     (void)hipStreamSynchronize(p->ctx->stream);
     for (int a = 0; a < 3; ++a)
         if (p->axis[a].d_tw) (void)hipFree(p->axis[a].d_tw);
-    if (p->d_inplace) (void)hipFree(p->d_inplace);
     delete p;
     return IG_OK;
 }

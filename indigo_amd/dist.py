@@ -21,6 +21,7 @@ Two providers of that all-reduce:
                  (the numpy oracle backend has no RCCL) and as the fallback if RCCL cannot be brought up directly.
 """
 import ctypes
+import hashlib
 import os
 import tempfile
 import time
@@ -61,13 +62,51 @@ def _rendezvous_path():
     return os.path.join(tempfile.gettempdir(), "indigo_rccl_id_%s" % key)
 
 
+def _nonce(raw):
+    return hashlib.sha256(raw).hexdigest()[:32].encode()
+
+
+def _publish(p, raw):
+    """atomic, exclusive: a fresh temp file (O_EXCL | O_NOFOLLOW: never through a planted link), renamed over p"""
+    tmp = "%s.%d.tmp" % (p, os.getpid())
+    try:
+        os.remove(tmp)
+    except OSError:
+        pass
+    fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
+    with os.fdopen(fd, "wb") as f:
+        f.write(raw)
+    os.replace(tmp, p)                                       # readers never see a partial file
+
+
+def _read(p, n=None):
+    try:
+        with open(p, "rb") as f:
+            raw = f.read()
+        return raw if (n is None or len(raw) == n) else None
+    except OSError:
+        return None
+
+
+def _remove_rendezvous_files(path, world):
+    for p in [path, path + ".go"] + ["%s.ack%d" % (path, r) for r in range(1, world)]:
+        try:
+            os.remove(p)
+        except OSError:
+            pass
+
+
 def exchange_id(rank, world, make_id, path, nbytes=128, timeout=60.0):
     """File rendezvous of one launch on one node: rank 0 publishes `make_id()` (nbytes), every other rank reads and
     acknowledges it, rank 0 waits for all acknowledgements and publishes "go".  Returns the id on every rank.
 
     The handshake completes BEFORE anyone enters the collective bring-up, so that a rendezvous problem (ranks that are
     not siblings, an unwritable temp directory) makes EVERY rank raise within `timeout` -- and fall back together --
-    instead of leaving some ranks inside ncclCommInitRank forever."""
+    instead of leaving some ranks inside ncclCommInitRank forever.
+
+    Left-overs of an earlier launch under the same name cannot be mistaken for this one: rank 0 removes them before it
+    publishes, acknowledgements and the go-ahead carry a nonce derived from the id, and a reader that acknowledged a
+    stale id keeps re-reading until the go-ahead matches what it acknowledged.  A rank that fails removes its own files."""
     def wait_for(fn, what):
         t0 = time.time()
         while True:
@@ -78,33 +117,41 @@ def exchange_id(rank, world, make_id, path, nbytes=128, timeout=60.0):
                 raise RuntimeError("rendezvous: rank %d timed out after %.0f s waiting for %s (%s)" % (rank, timeout, what, path))
             time.sleep(0.02)
 
-    def read(p, n=None):
-        try:
-            with open(p, "rb") as f:
-                raw = f.read()
-            return raw if (n is None or len(raw) == n) else None
-        except OSError:
-            return None
-
-    def publish(p, raw):
-        tmp = "%s.%d.tmp" % (p, os.getpid())
-        with open(tmp, "wb") as f:
-            f.write(raw)
-        os.replace(tmp, p)                                       # atomic: readers never see a partial file
-
     if rank == 0:
         raw = make_id()
         assert len(raw) == nbytes
         if world > 1:
-            publish(path, raw)
-            for r in range(1, world):
-                wait_for(lambda r=r: read("%s.ack%d" % (path, r)), "the acknowledgement of rank %d" % r)
-            publish(path + ".go", b"go")
+            _remove_rendezvous_files(path, world)
+            nonce = _nonce(raw)
+            try:
+                _publish(path, raw)
+                for r in range(1, world):
+                    wait_for(lambda r=r: True if _read("%s.ack%d" % (path, r)) == nonce else None,
+                             "the acknowledgement of rank %d" % r)
+                _publish(path + ".go", nonce)
+            except BaseException:
+                _remove_rendezvous_files(path, world)
+                raise
         return raw
-    raw = wait_for(lambda: read(path, nbytes), "the communicator id of rank 0")
-    publish("%s.ack%d" % (path, rank), b"ack")
-    wait_for(lambda: read(path + ".go"), "rank 0's go-ahead")
-    return raw
+    ack = "%s.ack%d" % (path, rank)
+    state = {}
+
+    def step():
+        raw = _read(path, nbytes)
+        if raw is None:
+            return None
+        if state.get("raw") != raw:                          # first sight of an id, or rank 0 replaced a stale one
+            state["raw"] = raw
+            _publish(ack, _nonce(raw))
+        return raw if _read(path + ".go") == _nonce(raw) else None
+    try:
+        return wait_for(step, "rank 0's communicator id and go-ahead")
+    except BaseException:
+        try:
+            os.remove(ack)
+        except OSError:
+            pass
+        raise
 
 
 def cleanup_rendezvous(rank, world, path, timeout=10.0):
@@ -121,8 +168,7 @@ def cleanup_rendezvous(rank, world, path, timeout=10.0):
     t0 = time.time()
     while any(os.path.exists("%s.ack%d" % (path, r)) for r in range(1, world)) and time.time() - t0 < timeout:
         time.sleep(0.02)
-    rm(path)
-    rm(path + ".go")
+    _remove_rendezvous_files(path, world)
 
 
 class RcclComm(object):
@@ -141,13 +187,15 @@ class RcclComm(object):
             return buf.raw
         idbuf = ctypes.create_string_buffer(exchange_id(self.rank, self.world, make_id, path, nbytes, timeout), nbytes)
         comm = ctypes.c_void_p()
-        backend._check(self._L.ig_comm_init_rank(backend._ctx, self.world, self.rank, idbuf, ctypes.byref(comm)), "ig_comm_init_rank")
-        self._comm = comm
-        self.overlap = os.environ.get("INDIGO_COMM_OVERLAP", "1") != "0"
-        self._pending = False
-        self.barrier()                                               # every rank is through the bring-up
-        if path:
-            cleanup_rendezvous(self.rank, self.world, path)
+        try:
+            backend._check(self._L.ig_comm_init_rank(backend._ctx, self.world, self.rank, idbuf, ctypes.byref(comm)), "ig_comm_init_rank")
+            self._comm = comm
+            self.overlap = os.environ.get("INDIGO_COMM_OVERLAP", "1") != "0"
+            self._pending = False
+            self.barrier()                                           # every rank is through the bring-up
+        finally:
+            if path:
+                cleanup_rendezvous(self.rank, self.world, path, timeout=10.0 if getattr(self, '_comm', None) else 0.0)
 
     def describe(self):
         buf = ctypes.create_string_buffer(256)
@@ -295,7 +343,11 @@ class ShardedNormalOperator(object):
         self._leaf = None
         if getattr(comm, 'overlap', False) and comm.world > 1 and nslabs > 1:
             from indigo_amd import operators as op
+            # the leaf that writes y LAST in the adjoint: the rightmost factor of the tree, or -- for a VStack of coil chunks,
+            # whose adjoint accumulates its children's images in order (operators.VStack._eval) -- of its last child
             r = A_local
+            if isinstance(r, op.VStack):
+                r = r.children[-1]
             while isinstance(r, op.Product):
                 r = r.right
             if isinstance(r, op.ZpadFFT) and r._layout == 2 and hasattr(self._backend, 'ifft_cropped_sum'):
@@ -310,12 +362,27 @@ class ShardedNormalOperator(object):
             self._ksp = B.zero_array((self._A.shape[0], ncols), _C64, name='ksp(shard)')
         self._A.eval(self._ksp, x)
         if self._leaf is not None and ncols == 1:
-            self._leaf._slab_hook = (self._nslabs, self._comm.allreduce_slab_)
+            # The leaf all-reduces the image slab by slab (ZpadFFT._slab_hook).  Whether it really did is CHECKED: the hook
+            # records the voxel ranges it reduced, and unless they tile [0, N) exactly once the whole image is reduced here
+            # instead (a tree whose last writer took another branch would otherwise return the rank-local partial sum).
+            done = []
+
+            def hook(arr, lo, hi):
+                self._comm.allreduce_slab_(arr, lo, hi)
+                done.append((lo, hi))
+            self._leaf._slab_hook = (self._nslabs, hook)
             try:
                 self._A.eval(y, self._ksp, forward=False)
             finally:
                 self._leaf._slab_hook = None
             self._comm.join()
+            done.sort()
+            covered = bool(done) and done[0][0] == 0 and done[-1][1] == self.shape[1] and \
+                all(a[1] == b[0] for a, b in zip(done[:-1], done[1:]))
+            if not covered:
+                assert not done, "slab all-reduce covered only part of the image: %s" % (done,)
+                self._leaf = None                   # this tree does not take the slab route: plain all-reduce from now on
+                self._comm.allreduce_(y)
         else:
             self._A.eval(y, self._ksp, forward=False)
             self._comm.allreduce_(y)

@@ -162,30 +162,50 @@ def decode_zpad_maps(St, C, P, oN):
     St = S'^H as an N x (C*P) CSR whose row i holds, for each coil c, conj(w[i, c]) at column c*P + zrow(i), the
     zrow(i) enumerating a box of the grid in Fortran order (SenseProblem.fused_maps_T; the reference builds the same
     matrix from Zpad, FFTc's modulation, the roll-off and the maps, examples/pics.py:104-177).
+    Entries may be MISSING: scipy's sparse products drop exact zeros, so coil maps that vanish outside the body (masked
+    ESPIRiT maps) leave rows with fewer than C entries, or none -- a missing (voxel, coil) entry is a weight of 0.  The box
+    is then recovered from the rows that are present: i = ix + d0*(iy + d1*iz) with (kx, ky, kz) = lo + (ix, iy, iz).
     Returns None if the matrix does not have that structure."""
     St = St.tocsr()
     St.sort_indices()
     Nn = St.shape[0]
-    if St.shape[1] != C * P or St.nnz != Nn * C or not np.array_equal(St.indptr, np.arange(0, (Nn + 1) * C, C)):
+    if St.shape[1] != C * P or St.nnz == 0:
         return None
-    cols = St.indices.reshape(Nn, C).astype(np.int64)
-    if not np.array_equal(cols // P, np.broadcast_to(np.arange(C), (Nn, C))):
+    rows = np.repeat(np.arange(Nn, dtype=np.int64), np.diff(St.indptr))
+    cols = St.indices.astype(np.int64)
+    coil, pos = cols // P, cols % P
+    # one grid position per row (all its coils at the same point), at most one entry per (row, coil)
+    first = St.indptr[:-1][np.diff(St.indptr) > 0]
+    present = np.flatnonzero(np.diff(St.indptr) > 0)
+    zrow = np.full(Nn, -1, dtype=np.int64)
+    zrow[present] = pos[first]
+    if not np.array_equal(pos, zrow[rows]):
         return None
-    pos = cols % P
-    if not (pos == pos[:, :1]).all():
+    if rows.size > 1 and np.any((rows[1:] == rows[:-1]) & (coil[1:] <= coil[:-1])):
         return None
-    z = pos[:, 0]
     n0, n1, n2 = (int(n) for n in oN)
+    z = zrow[present]
     kx, ky, kz = z % n0, (z // n0) % n1, z // (n0 * n1)
-    lo = (int(kx.min()), int(ky.min()), int(kz.min()))
-    dims = (int(kx.max()) - lo[0] + 1, int(ky.max()) - lo[1] + 1, int(kz.max()) - lo[2] + 1)
+    if St.nnz == Nn * C:
+        dims = (int(kx.max() - kx.min()) + 1, int(ky.max() - ky.min()) + 1, int(kz.max() - kz.min()) + 1)
+    else:
+        # present rows only: solve i = kx + d0*ky + d0*d1*kz + const for the box's pitches
+        Amat = np.stack([ky, kz, np.ones_like(ky)], axis=1).astype(np.float64)
+        if np.linalg.matrix_rank(Amat) < 3:
+            return None
+        sol = np.linalg.lstsq(Amat, (present - kx).astype(np.float64), rcond=None)[0]
+        d0, d01 = int(round(sol[0])), int(round(sol[1]))
+        if d0 < 1 or d01 < d0 or d01 % d0 or Nn % d01:
+            return None
+        dims = (d0, d01 // d0, Nn // d01)
     if dims[0] * dims[1] * dims[2] != Nn:
         return None
-    i = np.arange(Nn)
-    ex = lo[0] + i % dims[0]
-    ey = lo[1] + (i // dims[0]) % dims[1]
-    ez = lo[2] + i // (dims[0] * dims[1])
-    if not (np.array_equal(kx, ex) and np.array_equal(ky, ey) and np.array_equal(kz, ez)):
+    ix, iy, iz = present % dims[0], (present // dims[0]) % dims[1], present // (dims[0] * dims[1])
+    lo = (int(kx[0] - ix[0]), int(ky[0] - iy[0]), int(kz[0] - iz[0]))
+    if not (np.array_equal(kx, lo[0] + ix) and np.array_equal(ky, lo[1] + iy) and np.array_equal(kz, lo[2] + iz)):
         return None
-    w = np.conj(St.data.reshape(Nn, C)).astype(_C64)
+    if min(lo) < 0 or lo[0] + dims[0] > n0 or lo[1] + dims[1] > n1 or lo[2] + dims[2] > n2:
+        return None
+    w = np.zeros((Nn, C), dtype=_C64)
+    w[rows, coil] = np.conj(St.data)
     return lo, dims, np.asfortranarray(w).reshape(dims + (C,), order='F')

@@ -21,6 +21,7 @@ Leaves report the reference's own algorithmic-bytes model to `backend.trace`
 when one is attached (operators.py:246-259, :319-334, :351-353); nothing here
 synchronises the device.
 """
+import contextlib
 import io
 import numpy as np
 import scipy.sparse as spp
@@ -379,19 +380,25 @@ class ZpadFFT(MatrixFreeOperator):
             elif self._layout == 2 and hasattr(B, 'ifft_cropped_sum'):
                 # coil combination inside the transform's last pass: no per-coil image arrays at all
                 hook = getattr(self, '_slab_hook', None)
-                if alpha == 1 and beta == 0 and hook is not None and ncols == 1:
+                if alpha == 1 and hook is not None and ncols == 1:
                     # multi-GPU: the image leaves slab by slab -- hook(y, lo, hi) all-reduces voxels [lo, hi) of y on the
-                    # communicator's stream while the next slab is still being transformed (indigo_amd/dist.py)
+                    # communicator's stream while the next slab is still being transformed (indigo_amd/dist.py).  beta != 0
+                    # (the last coil chunk of a VStack: y already holds the earlier chunks' images): the slab goes through
+                    # an accumulator and is added to y before it leaves.
                     nslabs, fn = hook
                     b2, plane = self._box[2], self._box[0] * self._box[1]
-                    with B.scratch(nbytes=self._ws_bytes()) as ws:
-                        xg = xj.reshape((P, C))
-                        B.ifft_cropped_sum(yj, xg, w, self._grid, self._lo, self._box, ws, self._support(), slab='z', **self._tile_kw)
-                        edges = [b2 * i // nslabs for i in range(nslabs + 1)]
-                        for z0, z1 in zip(edges[:-1], edges[1:]):
-                            if z1 > z0:
-                                B.ifft_cropped_sum(yj, xg, w, self._grid, self._lo, self._box, ws, self._support(), slab=(z0, z1), **self._tile_kw)
-                                fn(yj, z0 * plane, z1 * plane)
+                    with (B.scratch(shape=(N, 1)) if beta != 0 else contextlib.nullcontext()) as acc:
+                        with B.scratch(nbytes=self._ws_bytes()) as ws:
+                            xg = xj.reshape((P, C))
+                            dst = acc if beta != 0 else yj
+                            B.ifft_cropped_sum(dst, xg, w, self._grid, self._lo, self._box, ws, self._support(), slab='z', **self._tile_kw)
+                            edges = [b2 * i // nslabs for i in range(nslabs + 1)]
+                            for z0, z1 in zip(edges[:-1], edges[1:]):
+                                if z1 > z0:
+                                    B.ifft_cropped_sum(dst, xg, w, self._grid, self._lo, self._box, ws, self._support(), slab=(z0, z1), **self._tile_kw)
+                                    if beta != 0:
+                                        B.axpby(beta, yj[z0 * plane:z1 * plane], 1, acc[z0 * plane:z1 * plane])
+                                    fn(yj, z0 * plane, z1 * plane)
                 elif alpha == 1 and beta == 0:
                     with B.scratch(nbytes=self._ws_bytes()) as ws:
                         B.ifft_cropped_sum(yj, xj.reshape((P, C)), w, self._grid, self._lo, self._box, ws, self._support(), **self._tile_kw)

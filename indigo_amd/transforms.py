@@ -272,7 +272,7 @@ class FuseZpadFFT(Transform):
         P = int(np.prod(grid))
         dec = fused.decode_zpad_maps(St.astype(np.complex64), C, P, grid)
         if dec is None:
-            log.info("FuseZpadFFT: %s is not a zero-pad * diagonal factor; tree left as is", X._name)
+            log.warning("FuseZpadFFT: %s is not a zero-pad * diagonal factor; the tree keeps the unfused -O3 leaves (S' csrmm + dense FFT)", X._name)
             return node
         lo, box, w = dec
         layout, chunks = fused.choose_layout(C, self.chunk)

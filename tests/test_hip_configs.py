@@ -315,3 +315,60 @@ def test_config5_coil_chunks_vs_oracle(hip, oracle_backend):
     assert rel_err(y_d.to_host(), exp) < RTOL
     hip._scratch = None
     oracle_backend._scratch = None
+
+
+def test_config5_as_benchmarked_on_one_gpu(hip, oracle_backend):
+    """BASELINE config 5 the way bench.py runs it at N = 1: image 320^3 on the 512^3 grid at full T = 2,893,824, 32 coils as a
+    VStack of four 8-coil chunks sharing one gridding matrix.  Reaches the 8-coil kernels on the run-time 320-of-512 box
+    (the coil-summing x pass, the 8-coil brick scatter) that the per-rank shapes above do not.
+       one 8-coil chunk : forward column of coil 3, adjoint of a panel non-zero in columns 1 and 6, A^H A with seven coils
+                          switched off -- against the one-coil numpy oracle / its double-precision evaluation
+       four chunks      : A^H A of the 32-coil VStack with only coils 3 and 20 (chunks 0 and 2) switched on"""
+    from oracle.precise import CoilOperatorF64
+    p = SenseProblem.synthetic((320, 320, 320), 32, nspokes=5652, nreadout=512, width=2, ntable=128, oversamp=1.6,
+                               seed=5, lazy_maps=True)
+    assert p.oN == (512, 512, 512) and p.T == 2893824
+    hip._scratch = None
+    oracle_backend._scratch = None
+    T = p.T
+    x = rand64c(int(np.prod(p.N)), 1, seed=1)
+    k = np.zeros((T, 8), dtype=C64, order='F')
+    k[:, 1] = rand64c(T, seed=2)
+    k[:, 6] = rand64c(T, seed=3)
+    A = p.build_zpadfft(hip, coils=range(8))
+    from indigo_amd import operators as op
+    assert not isinstance(A, op.VStack)
+    Ax3 = (A * x).reshape(T, 8, order='F')[:, 3:4].copy()
+    AHk = A.H * k.reshape(-1, 1, order='F')
+    del A
+    hip._scratch = None
+    y_d = hip.zero_array((x.shape[0], 1), C64)
+    A0 = masked_coils(p, {3}).build_zpadfft(hip, coils=range(8))
+    normal_operator(A0).eval(y_d, hip.copy_array(x))
+    AHA3 = y_d.to_host()
+    del A0
+    hip._scratch = None
+    q = masked_coils(p, {3, 20})
+    A32 = q.build_zpadfft(hip)
+    assert isinstance(A32, op.VStack) and len(A32.children) == 4
+    normal_operator(A32).eval(y_d, hip.copy_array(x))
+    AHA_2of32 = y_d.to_host()
+    del A32, y_d
+    hip._scratch = None
+    # ---- oracle ----
+    O = oracle_coil_ops(p, oracle_backend, [3, 1, 6])
+    o3x = O[3] * x
+    assert rel_err(Ax3, o3x) < RTOL
+    exp = O[1].H * np.asfortranarray(k[:, 1:2]) + O[6].H * np.asfortranarray(k[:, 6:7])
+    assert rel_err(AHk, exp) < RTOL
+    del exp
+    e3 = CoilOperatorF64(p, 3).normal(x).reshape(-1, 1)
+    o_aha = O[3].H * o3x
+    oracle_own = rel_err(o_aha, e3)
+    assert rel_err(AHA3, e3) < RTOL, "8-coil chunk, A^H A vs the double-precision evaluation"
+    assert rel_err(AHA3, o_aha) < oracle_own + RTOL
+    del O, o_aha, o3x
+    oracle_backend._scratch = None
+    e20 = CoilOperatorF64(p, 20).normal(x).reshape(-1, 1)
+    assert rel_err(AHA_2of32, e3 + e20) < RTOL, "four-chunk VStack: the chunks' images accumulate"
+    p.drop_cache()

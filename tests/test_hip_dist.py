@@ -112,6 +112,38 @@ B._scratch = None
 normal_operator(A, lamda=0.1).eval(y2, xs)
 a, b = y1.to_host(), y2.to_host()
 assert np.linalg.norm(a - b) <= 1e-6 * np.linalg.norm(b), np.linalg.norm(a - b) / np.linalg.norm(b)
+# a rank with more coils than one interleaved grid holds: a VStack of chunks.  The LAST chunk's leaf all-reduces slab by slab
+# (its slabs are added to the earlier chunks' images first: beta = 1 inside the hook)
+del A, op
+B._scratch = None
+A = p.build_zpadfft(B, chunk=2)
+from indigo_amd import operators as ops
+assert isinstance(A, ops.VStack) and len(A.children) == 2
+comm.world = 2
+op = ShardedNormalOperator(A, comm, lamda=0.1, nslabs=3)
+assert op._leaf is A.children[-1].right
+op.eval(y1, xs)
+comm.world = 1
+B._scratch = None
+normal_operator(A, lamda=0.1).eval(y2, xs)
+a, b = y1.to_host(), y2.to_host()
+assert np.linalg.norm(a - b) <= 1e-6 * np.linalg.norm(b), np.linalg.norm(a - b) / np.linalg.norm(b)
+# a tree whose last writer does not take the slab branch: the coverage check falls back to ONE plain all-reduce
+calls = []
+orig = comm.allreduce_
+comm.allreduce_ = lambda arr, force=False: (calls.append(arr.size), orig(arr, force=True))
+comm.world = 2
+op = ShardedNormalOperator(A, comm, nslabs=3)
+op._leaf = A.children[0].right           # (wrong on purpose: chunk 0's leaf runs with beta = 0 FIRST, then chunk 1 overwrites nothing it reduced)
+op._leaf = type("NoHook", (), {"_slab_hook": None})()    # a leaf that never calls the hook
+op.eval(y1, xs)
+comm.world = 1
+assert calls == [y1.size] and op._leaf is None, calls
+a = y1.to_host()
+B._scratch = None
+normal_operator(A).eval(y2, xs)
+b = y2.to_host()
+assert np.linalg.norm(a - b) <= 1e-6 * np.linalg.norm(b)
 comm.close()
 print("OK")
 """

@@ -545,10 +545,24 @@ def test_cg_with_device_scalars_matches_host_scalar_cg(hip):
         assert len(h1) == len(h2) == iters
         np.testing.assert_allclose(h1, h2, rtol=1e-4)
         assert rel_err(x1, x2) < 1e-5
-    # tolerance: stops at the end of the block in which it was met
+    # tolerance: the history ends at the first residual below tol, and the iterations already enqueued behind it (the rest of
+    # the block of four) are no-ops on the device: the iterate is the reference's, which breaks out at once (backend.py:683-685)
     x3 = np.zeros_like(b, order='F')
-    h3 = hip.cg(AHA, b.copy(order='F'), x3, tol=h2[0] * 1.5 if len(h2) else 1.0, maxiter=20, check_every=4)
-    assert len(h3) == 4
+    x3r = np.zeros_like(b, order='F')
+    h_ref = Backend.cg(hip, AHA, b.copy(order='F'), x3r, tol=h2[0] * 1.5, maxiter=20)
+    h3 = hip.cg(AHA, b.copy(order='F'), x3, tol=h2[0] * 1.5, maxiter=20, check_every=4)
+    assert len(h3) == len(h_ref) == 1
+    assert rel_err(x3, x3r) < 1e-6
+    # an exactly solvable system (A = I): the residual reaches 0 in one step, <p, Ap> = 0 afterwards -- no NaN may appear
+    n = b.shape[0]
+    xe = np.zeros_like(b, order='F')
+    he = hip.cg(hip.Eye(n), b.copy(order='F'), xe, tol=1e-10, maxiter=25, check_every=10)
+    assert len(he) == 1 and he[0] == 0.0
+    assert np.isfinite(xe).all() and rel_err(xe, b) < 1e-6
+    # more iterations than the context has history slots: the ring is fetched before it wraps (the reference takes any maxiter)
+    xl = np.zeros_like(b, order='F')
+    hl = hip.cg(2.0 * hip.Eye(n), b.copy(order='F'), xl, tol=0.0, maxiter=1100, check_every=2000)
+    assert len(hl) == 1100 and np.isfinite(xl).all() and rel_err(xl, 0.5 * b) < 1e-6
     # device-resident b and x: the iterate is updated in place
     x7 = np.zeros_like(b, order='F')
     Backend.cg(hip, AHA, b.copy(order='F'), x7, maxiter=7)

@@ -154,3 +154,30 @@ def test_misc_leaves_against_reference(oracle_backend):
     """onemm, cdiamm, cgemm, csymm, apgd of the oracle == the reference's numpy backend"""
     from conftest import check_misc_leaves
     check_misc_leaves(oracle_backend, 2e-6)
+
+
+def test_double_precision_arbiter_against_reference_goldens():
+    """oracle/precise.py (the complex128 arbiter of the full-size GPU tests) evaluates the reference's operator: its one-coil
+    A_c, A_c^H and A_c^H A_c, summed over the coils, reproduce what the reference computed from the same inputs (sense.npz:
+    A x, A^H k, A^H A x + lamda x; and, with unit maps, the NUFFT leaf alone)."""
+    from indigo_amd.sense import SenseProblem
+    from oracle.precise import CoilOperatorF64
+    g = golden("sense")
+    C, width, ntab, osf, ro, tr = g["params"]
+    N = tuple(int(n) for n in g["N"])
+    p = SenseProblem(N, g["coord"], np.asfortranarray(g["maps"]), width=int(width), ntable=int(ntab), oversamp=float(osf))
+    T, C = p.T, p.C
+    ops = [CoilOperatorF64(p, c) for c in range(C)]
+    x, k = g["sense_x"][:, 0], g["sense_k"][:, 0]
+    Ax = np.concatenate([o.forward(x) for o in ops])                          # coil-major rows, as KronI(C, .) stacks them
+    assert rel_err(Ax, g["sense_Ax"][:, 0]) < TOL
+    AHk = sum(o.adjoint(k[c * T:(c + 1) * T]) for c, o in enumerate(ops))
+    assert rel_err(AHk, g["sense_AHk"][:, 0]) < TOL
+    AHAx = sum(o.normal(x) for o in ops) + float(g["lamda"]) * x
+    assert rel_err(AHAx, g["sense_AHAx"][:, 0]) < TOL
+    # the NUFFT leaf: unit maps
+    q = SenseProblem(N, g["coord"], np.ones(N + (1,), dtype=C64, order='F'), width=int(width), ntable=int(ntab), oversamp=float(osf))
+    F = CoilOperatorF64(q, 0)
+    for j in range(g["nufft_x"].shape[1]):
+        assert rel_err(F.forward(g["nufft_x"][:, j]), g["nufft_fwd"][:, j]) < TOL
+        assert rel_err(F.adjoint(g["nufft_k"][:, j]), g["nufft_adj"][:, j]) < TOL

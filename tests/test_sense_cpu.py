@@ -208,6 +208,50 @@ def test_fuse_zpadfft_transform_on_the_reference_recipe(prob, oracle_backend):
     B._scratch = None
 
 
+def test_fuse_zpadfft_with_masked_maps(prob, oracle_backend):
+    """coil maps that vanish outside the body (masked ESPIRiT maps): the recipe's scipy products drop the exact zeros, so
+    S' has fewer than C entries in most rows and none in many -- including whole boundary planes of the image box.
+    FuseZpadFFT must still recognise the factor (missing entry = weight 0) and evaluate to the unfused -O3 tree."""
+    from indigo_amd import fused
+    from indigo_amd.transforms import FuseZpadFFT, sense_recipe
+    p, g = prob
+    B = oracle_backend
+    B._scratch = None
+    maps = np.asfortranarray(g["maps"]).copy(order='F')
+    n0, n1, n2, C = maps.shape
+    xx, yy, zz = np.meshgrid(np.arange(n0), np.arange(n1), np.arange(n2), indexing='ij')
+    ball = ((xx - n0 / 2) ** 2 + (yy - n1 / 2) ** 2 + (zz - n2 / 2) ** 2) < (0.36 * min(n0, n1, n2)) ** 2
+    maps[~ball] = 0                                   # outside the body: every coil; boundary planes vanish entirely
+    maps[:, : n1 // 2, :, 1] = 0                      # coil 1 sees half of it
+    q = SenseProblem(p.N, p.coord, maps, width=p.width, ntable=p.ntable, oversamp=p.oversamp)
+    A3 = q.build_tree(B, level=3)
+    St = [n for n in _leaves(A3) if isinstance(n, op.SpMatrix)][-1]._matrix
+    assert St.nnz < int(np.prod(p.N)) * C              # entries really are missing
+    Af = FuseZpadFFT().visit(q.build_tree(B, level=3))
+    assert Af.has(op.ZpadFFT) and not Af.has(op.UnscaledFFT)
+    assert Af.right._box == p.N
+    x, k = g["sense_x"], g["sense_k"]
+    assert rel_err(Af * x, A3 * x) < 2e-6
+    assert rel_err(Af.H * k, A3.H * k) < 2e-6
+    # not a zero-pad * diagonal factor: one entry moved to another grid point
+    P = int(np.prod(p.oN))
+    Ss = (St if St.shape[1] == C * P else St.conjugate().transpose()).tocsr().astype(C64)
+    Ss.sort_indices()
+    assert fused.decode_zpad_maps(Ss, C, P, p.oN) is not None
+    r = int(np.flatnonzero(np.diff(Ss.indptr) > 1)[0])
+    bad = Ss.copy()
+    bad.indices[bad.indptr[r]] -= 1
+    assert fused.decode_zpad_maps(bad, C, P, p.oN) is None
+    B._scratch = None
+
+
+def _leaves(node):
+    kids = getattr(node, '_children', None)
+    if not kids:
+        return [node]
+    return [l for c in kids for l in _leaves(c)]
+
+
 def test_support_tables_of_every_granularity_cover_the_touched_cells():
     """fused.grid_support(tile): every grid cell a nonzero of G' touches lies in a flagged segment; the flagged set of a finer
     table is a subset of the coarser one's (what a gather route writes by the 16-point table is a superset of what a reader

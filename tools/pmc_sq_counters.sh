@@ -9,7 +9,7 @@ mkdir -p $OUT
 i=0
 for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU" "SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_LDS_BANK_CONFLICT" "SQ_INSTS_SMEM SQ_ACTIVE_INST_VMEM SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp -d $OUT/g$i -o c --output-format csv -- python3 bench.py --no-cpu-baseline --no-config5 --steps 2 --warmup 1 > /dev/null 2> $OUT/g$i.log || { tail -5 $OUT/g$i.log; continue; }
+  rocprofv3 --pmc $grp -d $OUT/g$i -o c --output-format csv -- python3 bench.py --no-cpu-baseline --no-extras --steps 2 --warmup 1 > /dev/null 2> $OUT/g$i.log || { tail -5 $OUT/g$i.log; continue; }
   python3 - <<PY
 import csv, glob, collections
 f = glob.glob("$OUT/g$i/**/c_counter_collection.csv", recursive=True)[0]

@@ -11,6 +11,7 @@ counters need separate passes (TCC slot budget), hence two input files.
 import collections
 import csv
 import json
+import os
 import re
 import sys
 
@@ -41,8 +42,13 @@ def main():
         out[k] = dict(launches=max(len(f), len(w)), read_bytes_per_launch=rd, write_bytes_per_launch=wr,
                       hbm_bytes_per_launch=(rd or 0) + (wr or 0),
                       note="FETCH_SIZE x2 (gfx950 correction) x1024; WRITE_SIZE x1024")
+    rows = dict(out)
+    # what these figures are valid for: the exact kernel sources (bench.py reports `traffic_stale` when they differ)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from indigo_amd.build import source_hash
+    out["_meta"] = dict(csrc_sha16=source_hash(), kernels=sorted(rows))
     json.dump(out, open(sys.argv[3], "w"), indent=1)
-    for k, v in out.items():
+    for k, v in rows.items():
         print("%-60s %4d launches  read %8.3f GB  write %8.3f GB" % (
             k[:60], v["launches"], (v["read_bytes_per_launch"] or 0) / 1e9, (v["write_bytes_per_launch"] or 0) / 1e9))
 

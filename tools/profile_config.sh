@@ -10,9 +10,9 @@ cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- python3 bench.py --no-cpu-baseline --no-config5 "$@" > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
-rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o f --output-format csv -- python3 bench.py --no-cpu-baseline --no-config5 --steps 3 --warmup 1 "$@" > /dev/null 2> $OUT/fetch.log
-rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o w --output-format csv -- python3 bench.py --no-cpu-baseline --no-config5 --steps 3 --warmup 1 "$@" > /dev/null 2> $OUT/write.log
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o s --output-format csv -- python3 bench.py --no-cpu-baseline --no-extras "$@" > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
+rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o f --output-format csv -- python3 bench.py --no-cpu-baseline --no-extras --steps 3 --warmup 1 "$@" > /dev/null 2> $OUT/fetch.log
+rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o w --output-format csv -- python3 bench.py --no-cpu-baseline --no-extras --steps 3 --warmup 1 "$@" > /dev/null 2> $OUT/write.log
 S=$(find $OUT/stats -name 's_kernel_stats.csv' | head -1)
 F=$(find $OUT/fetch -name 'f_counter_collection.csv' | head -1)
 W=$(find $OUT/write -name 'w_counter_collection.csv' | head -1)
