@@ -245,10 +245,12 @@ int  ig_ccsrmm_t_bricks(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, float alph
  * column-major, ldx) for ANY CSR matrix with K a multiple of 16 (beta == 0: Y is zeroed first).  Bricks are 16 consecutive
  * rows of Y: ig_grid_bricks_count / _fill with (n0, nm, ns) = (K, 1, 1), bm = bs = 1, unit = 1 give `entries` (12 bytes:
  * {row of Y inside the brick, re, im}) and `entry_rows` (= round_rows: the row of X of every entry), both on the device here;
- * brick_table / tasks as for ig_ccsrmm_t_bricks (at most 64 bricks per run).  M * 512 < 2^31.  BASELINE config 3's adjoint.   */
+ * brick_table / tasks as for ig_ccsrmm_t_bricks (at most 64 bricks per run).  M * 512 < 2^31.  BASELINE config 3's adjoint.
+ * owned_tiles (optional, device): one bit per 16-row tile of Y, set iff exactly one NON-shared task holds the tile's brick --
+ *   that task stores the whole tile, only the other tiles are zeroed first (NULL: all of Y is zeroed first).               */
 int  ig_ccsrmm_t_bricks_wide(ig_ctx* ctx, int64_t M, int64_t K, float alpha_re, float alpha_im,
                              const void* entries, const uint32_t* entry_rows, const void* X, int64_t ldx, void* Y, int64_t ldy,
-                             const int32_t* tasks, int64_t ntasks, const int32_t* brick_table);
+                             const int32_t* tasks, int64_t ntasks, const int32_t* brick_table, const uint32_t* owned_tiles);
 
 /* Locality-ordered variants.  The caller may store A with its ROWS reordered (row r of the stored
  * matrix is row perm[r] of A; e.g. k-space samples sorted by the grid cell they touch, so that

@@ -728,9 +728,19 @@ class HipBackend(Backend):
             rows = np.empty(max(int(ptr[-1]), 1), dtype=np.uint32)
             _lib.check(b._L.ig_grid_bricks_fill(m, indptr.ctypes.data, indices.ctypes.data, data.ctypes.data, k, 1, 1, 1, 1, 1,
                                                 ptr.ctypes.data, e12.ctypes.data, rows.ctypes.data), None, "ig_grid_bricks_fill")
-            wt = [int(t) for t in os.environ.get("INDIGO_HIP_WIDE_TASKS", "4096,1024,1").split(",")]      # piece, run, longest first
-            tasks, table, _ = brick_tasks(counts, ptr, wt[0], wt[1], max_bricks=64, longest_first=bool(wt[2]))
+            # tasks: pieces of at most 4096 entries of a heavy brick, runs of about 1024 entries of consecutive bricks, longest first.
+            # Measured on BASELINE config 3 and rejected (round 3, profiles/r03_cfg3_sweep_*.txt): bricks in index order or in a
+            # (y, z)-blocked order of the grid, with chunks of 4..64 consecutive workgroups dealt to one XCD so that the bricks that
+            # need the same rows of X meet behind one L2 -- 3.7..4.2 ms against 3.35 ms, and the same 9.7 GB of re-fetched rows by
+            # the PMC counters: a brick takes a wave ~25 us, a line lives ~7 us in a 4 MB L2 that 0.5 TB/s stream through.
+            tasks, table, shared = brick_tasks(counts, ptr, 4096, 1024, max_bricks=64, longest_first=True)
+            # tiles some task stores in full: the non-empty bricks that are not cut into shared pieces
+            owned = np.zeros(k // 16, dtype=bool)
+            owned[table[:, 0]] = True
+            owned[shared] = False
+            bits = np.packbits(np.concatenate([owned, np.zeros((-owned.size) % 32, dtype=bool)]), bitorder='little').view(np.uint32)
             self._wide = dict(ntasks=int(tasks.shape[0]),
+                              owned=b.copy_array(bits, name=self._name + ".wideOwnedTiles"),
                               tasks=b.copy_array(tasks.reshape(-1) if tasks.size else np.zeros(4, np.int32), name=self._name + ".wideTasks"),
                               table=b.copy_array(table.reshape(-1) if table.size else np.zeros(2, np.int32), name=self._name + ".wideTable"),
                               entries=b.copy_array(e12.reshape(-1), name=self._name + ".wideEntries"),
@@ -835,7 +845,8 @@ class HipBackend(Backend):
                     m, k = self.shape
                     b._check(b._L.ig_ccsrmm_t_bricks_wide(b._ctx, m, k, ar, ai, ctypes.c_void_p(wb['entries']._arr), ctypes.c_void_p(wb['rows']._arr),
                                                           ctypes.c_void_p(x._arr), x._leading_dim, ctypes.c_void_p(y._arr), y._leading_dim,
-                                                          ctypes.c_void_p(wb['tasks']._arr), wb['ntasks'], ctypes.c_void_p(wb['table']._arr)),
+                                                          ctypes.c_void_p(wb['tasks']._arr), wb['ntasks'], ctypes.c_void_p(wb['table']._arr),
+                                                          ctypes.c_void_p(wb['owned']._arr)),
                              "ig_ccsrmm_t_bricks_wide")
                     return
             if getattr(self, '_grid_il', False):

@@ -257,6 +257,138 @@ k_csrmm_gather_v(int64_t M, const int32_t* __restrict__ rowptr, const int32_t* _
     }
 }
 
+// 64-column row-major panel (packed), rows of some tens of nonzeros (a gridding matrix: 27): a wave computes a TILE of 16
+// consecutive rows, one row after the other.  What the one-row-per-wave form above pays three dependent round trips for
+// (row pointers -> indices / values -> panel rows), this one overlaps: the 17 row pointers of the tile are one load, the
+// indices and values of row j + 1 are requested before the panel rows of row j are waited for, and consecutive rows --
+// consecutive samples of a trajectory, half a grid cell apart -- gather mostly the same panel rows within a microsecond of
+// each other, i.e. out of the L1 / L2 instead of HBM.  Lane (c, i): panel columns 4c .. 4c+3 (two 16-byte loads), nonzero
+// lane i of 4; a pass covers 32 nonzeros of a row.  The 16 x 64 results go through an LDS tile and leave as full 128-byte
+// lines of the column-major result (lanes = 16 rows x 4 columns).  Rows beyond thr_long nonzeros go to the workgroup-per-row
+// list as everywhere else.
+template <bool CONJ, int BMODE>
+__global__ void __launch_bounds__(BLK)
+k_csrmm_gather_tile64(int64_t M, int64_t nnz, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
+                      const float2* __restrict__ vals, const float2* __restrict__ X /* [row][64] */,
+                      float2* __restrict__ Y, int64_t ldy, float2 alpha, float2 beta, int xcd_remap,
+                      WorkLists wl, int32_t thr_long) {
+    constexpr int TLD = 65, U = 8;
+    __shared__ float2 tile_all[WAVES_PER_BLOCK * 16 * TLD];
+    const int lane = threadIdx.x & 63, c = lane & 15, i = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t blk = xcd_remap ? xcd_block(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
+    const int64_t wave = blk * WAVES_PER_BLOCK + wv;
+    const int64_t row0 = wave * 16;
+    if (row0 >= M) return;
+    float2* __restrict__ tile = tile_all + wv * 16 * TLD;
+    int32_t myp;
+    {
+        int64_t r = row0 + (lane < 16 ? lane : 16);
+        if (r > M) r = M;
+        myp = rowptr[r];
+    }
+    const float4* __restrict__ X4 = reinterpret_cast<const float4*>(X) + c * 2;
+    const int32_t last = (int32_t)(nnz - 1);
+    auto load_idx = [&](int32_t a, int32_t b, int32_t (&kk)[U], float2 (&vv)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int32_t pu = a + i + 4 * u;
+            const bool ok = pu < b;
+            int32_t q = ok ? pu : b - 1;                 // a slot past the row's end re-reads its last nonzero (a cache hit) with value 0
+            q = q < 0 ? 0 : (q > last ? last : q);
+            kk[u] = colind[q];
+            const float2 t = vals[q];
+            vv[u] = ok ? t : make_float2(0.f, 0.f);
+        }
+    };
+    auto gather = [&](const int32_t (&kk)[U], const float2 (&vv)[U], float2 (&acc)[4]) {
+        float4 x4[U][2];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            x4[u][0] = X4[(int64_t)kk[u] * 32];
+            x4[u][1] = X4[(int64_t)kk[u] * 32 + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            acc_nz<CONJ>(acc[0], vv[u], make_float2(x4[u][0].x, x4[u][0].y));
+            acc_nz<CONJ>(acc[1], vv[u], make_float2(x4[u][0].z, x4[u][0].w));
+            acc_nz<CONJ>(acc[2], vv[u], make_float2(x4[u][1].x, x4[u][1].y));
+            acc_nz<CONJ>(acc[3], vv[u], make_float2(x4[u][1].z, x4[u][1].w));
+        }
+    };
+    unsigned skip = 0;                                   // bit j: row j is someone else's (deferred), or lies past M
+    int32_t p0 = __builtin_amdgcn_readlane(myp, 0), p1 = __builtin_amdgcn_readlane(myp, 1);
+    int32_t k[U];
+    float2 v[U];
+    load_idx(p0, p1, k, v);
+#pragma unroll 1
+    for (int j = 0; j < 16; ++j) {
+        const int32_t q0 = p1, q1 = __builtin_amdgcn_readlane(myp, j + 2 > 16 ? 16 : j + 2);
+        bool deferred = false;
+        if (p1 - p0 > thr_long) {
+            const bool mine = wl_append(wl, 1, (int)(wave & (WL_SUB - 1)), lane == 0, (int32_t)(row0 + j));
+            deferred = __builtin_amdgcn_readfirstlane((int)mine) != 0;
+        }
+        if (deferred || row0 + j >= M) skip |= 1u << j;
+        float2 acc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = make_float2(0.f, 0.f);
+        int32_t kn[U];
+        float2 vn[U];
+        if (!deferred) {
+            // (program order = issue order: the panel rows of row j, then the indices of row j + 1, and the multiply-adds
+            // below only wait for the former -- loads return in order)
+            float4 x4[U][2];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                x4[u][0] = X4[(int64_t)k[u] * 32];
+                x4[u][1] = X4[(int64_t)k[u] * 32 + 1];
+            }
+            load_idx(q0, q1, kn, vn);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                acc_nz<CONJ>(acc[0], v[u], make_float2(x4[u][0].x, x4[u][0].y));
+                acc_nz<CONJ>(acc[1], v[u], make_float2(x4[u][0].z, x4[u][0].w));
+                acc_nz<CONJ>(acc[2], v[u], make_float2(x4[u][1].x, x4[u][1].y));
+                acc_nz<CONJ>(acc[3], v[u], make_float2(x4[u][1].z, x4[u][1].w));
+            }
+            for (int32_t pp = p0 + 4 * U; pp < p1; pp += 4 * U) {        // rows of more than 32 nonzeros: further passes
+                int32_t k2[U];
+                float2 v2[U];
+                load_idx(pp, p1, k2, v2);
+                gather(k2, v2, acc);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc[u].x += __shfl_xor(acc[u].x, 16, 64); acc[u].y += __shfl_xor(acc[u].y, 16, 64);
+                acc[u].x += __shfl_xor(acc[u].x, 32, 64); acc[u].y += __shfl_xor(acc[u].y, 32, 64);
+            }
+        } else {
+            load_idx(q0, q1, kn, vn);
+        }
+        if (i == 0) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) tile[j * TLD + 4 * c + u] = acc[u];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { k[u] = kn[u]; v[u] = vn[u]; }
+        p0 = q0; p1 = q1;
+    }
+    // the tile leaves as 128-byte lines: lane = (row in tile, column group)
+    const int cell = lane & 15, cg = lane >> 4;
+    const bool keep = !((skip >> cell) & 1u);
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int col = cg + 4 * it;
+        float2 out = cmul(alpha, tile[cell * TLD + col]);
+        float2* dst = Y + (int64_t)col * ldy + row0 + cell;
+        if (keep) {
+            if (BMODE == 1) cfma(out, beta, *dst);
+            *dst = out;
+        }
+    }
+}
+
 // Row-per-lane variant for matrices whose rows are mostly empty or very short (mean <= 1 nonzero per
 // row, e.g. the transposed gridding matrix: 89 % empty rows).  A lane owns a row and keeps NC panel
 // columns in registers, so a wave covers 64 rows, every store instruction writes 512 contiguous bytes
@@ -1056,16 +1188,11 @@ __global__ void __launch_bounds__(BLK)
 k_bricks_wide64(const BrickTask* __restrict__ tasks, int ntasks, const BrickRef* __restrict__ btab,
                 const BrickEntry* __restrict__ entries, const uint32_t* __restrict__ entry_rows,
                 const float2* __restrict__ Xp /* [row][64] */,
-                float2* __restrict__ Y, int64_t ldy, float2 alpha, int xcd_order) {
+                float2* __restrict__ Y, int64_t ldy, float2 alpha) {
     __shared__ float2 acc_all[WAVES_PER_BLOCK * 16 * WIDE_LD];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // xcd_order (INDIGO_HIP_WIDE_XCD=1, off by default): workgroups go round-robin to the 8 XCDs; giving each XCD a contiguous
-    // eighth of a spatially ordered task list keeps the bricks of adjacent planes -- which share X rows -- behind one L2.
-    // Measured on BASELINE config 3: 5.0 ms against 3.3 ms for longest-first tasks in dispatch order: a k-space ball has
-    // most of its nonzeros in the central slabs, and an eighth of the GRID is not an eighth of the WORK.
-    const int per_xcd = (gridDim.x + 7) / 8;
-    const int blk = xcd_order ? (int)(blockIdx.x % 8) * per_xcd + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    const int blk = (int)blockIdx.x;
     const int task = blk * WAVES_PER_BLOCK + wv;
     if (blk >= (int)gridDim.x || task >= ntasks) return;
     const BrickTask tk = tasks[task];
@@ -1155,6 +1282,29 @@ k_bricks_wide64(const BrickTask* __restrict__ tasks, int ntasks, const BrickRef*
         body(pc, pa, xc, xb, rb, rc, gi + 2);
     }
     flush();
+}
+
+// Zero the 16-row tiles of a column-major K x 64 result that no single task owns (bit clear in `owned`: tiles no nonzero
+// touches, which beta == 0 defines as zero, and the heavy tiles several tasks add into): the owning task of every other tile
+// stores all of its 16 x 64 values itself, so nothing is written twice.  A workgroup takes 4096 rows of every column.
+__global__ void __launch_bounds__(BLK)
+k_wide_zero_unowned(const uint32_t* __restrict__ owned, float2* __restrict__ Y, int64_t ldy, int64_t K) {
+    const int64_t r0 = (int64_t)blockIdx.x * 4096;
+    const int tid = threadIdx.x;
+    uint32_t own[8];          // this thread's eight 16-byte pieces q = tid + 256 u cover rows 2 q, 2 q + 1: tile q / 8
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int64_t tile = (r0 >> 4) + ((tid + 256 * u) >> 3);
+        own[u] = (tile << 4) < K ? ((owned[tile >> 5] >> (tile & 31)) & 1u) : 1u;
+    }
+    typedef float v4f_t __attribute__((ext_vector_type(4)));
+    const v4f_t z = {0.f, 0.f, 0.f, 0.f};
+    for (int col = 0; col < 64; ++col) {
+        v4f_t* __restrict__ dst = reinterpret_cast<v4f_t*>(Y + (int64_t)col * ldy + r0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (!own[u]) __builtin_nontemporal_store(z, dst + tid + 256 * u);
+    }
 }
 
 // zero the flagged segments of the bricks that several tasks add into
@@ -1388,6 +1538,15 @@ int launch_gather(ig_ctx* ctx, int64_t rows, int64_t xrows, int64_t N, int64_t n
             else if (nnz >= 8 * rows) {                       // long rows: spread a row's nonzeros over nonzero-lanes
                 if (N == 16) IG_GV(4, 4, 8);                                                               // 2 rows per wave
                 else if (N == 32) IG_GV(4, 8, 8);                                                          // a wave per row, 32 nonzeros per trip
+                else if (!wl.yperm && nnz <= 0x7fffffffLL && env_flag("INDIGO_HIP_SPMM_TILE64", true)) {
+                    // 64 columns: tiles of 16 rows per wave, software-pipelined (k_csrmm_gather_tile64)
+                    const int64_t tblocks = ((rows + 15) / 16 + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+                    IG_REQUIRE(ctx, tblocks <= 0x7fffffffLL, "csrmm: matrix too large for one launch");
+                    if (b0) hipLaunchKernelGGL((k_csrmm_gather_tile64<CONJ, 0>), dim3((unsigned)tblocks), dim3(BLK), 0, ctx->stream,
+                                rows, nnz, rowptr, colind, vals, X, Y, ldy, alpha, beta, xcd, wl, thr_long);
+                    else    hipLaunchKernelGGL((k_csrmm_gather_tile64<CONJ, 1>), dim3((unsigned)tblocks), dim3(BLK), 0, ctx->stream,
+                                rows, nnz, rowptr, colind, vals, X, Y, ldy, alpha, beta, xcd, wl, thr_long);
+                }
                 else IG_GV(4, 16, 4);                                                                      // 64 columns: 16 nonzeros per trip
             } else {                                          // short rows (a transposed gridding matrix): one trip each
                 if (N == 16) IG_GV(4, 4, 1);                                                               // 16 rows per wave
@@ -1677,14 +1836,12 @@ int ig_grid_bricks_count(int64_t M, const int32_t* rowptr, const int32_t* colind
     return IG_OK;
 }
 
-int ig_grid_bricks_fill(int64_t M, const int32_t* rowptr, const int32_t* colind, const void* vals, int64_t n0, int64_t nm, int64_t ns,
-                        int bm, int bs, int unit, const int64_t* brick_ptr /* exclusive prefix sums of the counts, nbricks + 1 */,
-                        void* entries /* brick_ptr[nbricks] x 12 bytes: {uint32 cell in brick, float re, float im} */,
-                        uint32_t* round_rows /* brick_ptr[nbricks] / unit: the row of each group of `unit` entries */) {
-    if (M < 0 || !rowptr || !brick_ptr || !bricks_ok(n0, nm, ns, bm, bs, unit) || (rowptr[M] > rowptr[0] && (!colind || !vals || !entries || !round_rows)))
+static int bricks_fill(int64_t M, const int32_t* rowptr, const int32_t* colind, const void* vals, int64_t n0, int64_t nm, int64_t ns,
+                       int bm, int bs, int unit, const int64_t* brick_start, const int64_t* brick_end, void* entries, uint32_t* round_rows) {
+    if (M < 0 || !rowptr || !brick_start || !brick_end || !bricks_ok(n0, nm, ns, bm, bs, unit) || (rowptr[M] > rowptr[0] && (!colind || !vals || !entries || !round_rows)))
         return ig_fail(nullptr, IG_ERR_ARG, "ig_grid_bricks_fill: bad arguments");
     const int64_t nbx = n0 / 16, nbm = nm / bm, nbs = ns / bs, nb = nbx * nbm * nbs;
-    std::vector<int64_t> cursor(brick_ptr, brick_ptr + nb);
+    std::vector<int64_t> cursor(brick_start, brick_start + nb);
     const float2* v = (const float2*)vals;
     BrickEntry* out = (BrickEntry*)entries;
     for (int64_t t = 0; t < M; ++t) {
@@ -1703,7 +1860,7 @@ int ig_grid_bricks_fill(int64_t M, const int32_t* rowptr, const int32_t* colind,
             e.cell = (uint32_t)((kx % 16) + 16 * ((km % bm) + bm * (ks % bs)));
             e.re = v[p].x; e.im = v[p].y;
             const int64_t at = start[q] + rb.cnt[q] - 1;
-            if (at >= brick_ptr[b + 1] || start[q] % unit) return ig_fail(nullptr, IG_ERR_ARG, "ig_grid_bricks_fill: brick_ptr does not come from ig_grid_bricks_count");
+            if (at >= brick_end[b] || start[q] % unit) return ig_fail(nullptr, IG_ERR_ARG, "ig_grid_bricks_fill: the brick offsets do not come from ig_grid_bricks_count");
             out[at] = e;
         }
         for (int q = 0; q < rb.n; ++q) {            // pad this row's share of each brick to a multiple of `unit`
@@ -1717,6 +1874,14 @@ int ig_grid_bricks_fill(int64_t M, const int32_t* rowptr, const int32_t* colind,
         }
     }
     return IG_OK;
+}
+
+int ig_grid_bricks_fill(int64_t M, const int32_t* rowptr, const int32_t* colind, const void* vals, int64_t n0, int64_t nm, int64_t ns,
+                        int bm, int bs, int unit, const int64_t* brick_ptr /* exclusive prefix sums of the counts, nbricks + 1 */,
+                        void* entries /* brick_ptr[nbricks] x 12 bytes: {uint32 cell in brick, float re, float im} */,
+                        uint32_t* round_rows /* brick_ptr[nbricks] / unit: the row of each group of `unit` entries */) {
+    if (!brick_ptr) return ig_fail(nullptr, IG_ERR_ARG, "ig_grid_bricks_fill: bad arguments");
+    return bricks_fill(M, rowptr, colind, vals, n0, nm, ns, bm, bs, unit, brick_ptr, brick_ptr + 1, entries, round_rows);
 }
 
 int ig_ccsrmm_t_bricks(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, float ar, float ai,
@@ -1786,7 +1951,7 @@ int ig_ccsrmm_t_bricks(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, float ar, f
 
 int ig_ccsrmm_t_bricks_wide(ig_ctx* ctx, int64_t M, int64_t K, float ar, float ai,
                             const void* entries, const uint32_t* entry_rows, const void* X, int64_t ldx, void* Y, int64_t ldy,
-                            const int32_t* tasks, int64_t ntasks, const int32_t* brick_table) {
+                            const int32_t* tasks, int64_t ntasks, const int32_t* brick_table, const uint32_t* owned_tiles) {
     IG_REQUIRE(ctx, ctx != nullptr, "ig_ccsrmm_t_bricks_wide: ctx is NULL");
     const int64_t N = 64;
     IG_REQUIRE(ctx, M >= 0 && K >= 0 && K % 16 == 0 && K <= 0x7fffffffLL, "ig_ccsrmm_t_bricks_wide: K (%lld) must be a multiple of 16", (long long)K);
@@ -1796,7 +1961,12 @@ int ig_ccsrmm_t_bricks_wide(ig_ctx* ctx, int64_t M, int64_t K, float ar, float a
     IG_REQUIRE(ctx, M * N * 8 < 0x7fffffffLL, "ig_ccsrmm_t_bricks_wide: the panel (%lld x 64) exceeds the 2 GB window of a buffer descriptor", (long long)M);
     if (K == 0) return IG_OK;
     if (int rc = ig_set_device(ctx)) return rc;
-    {
+    if (owned_tiles && ntasks > 0 && M > 0 && (reinterpret_cast<uintptr_t>(Y) & 15u) == 0 && ldy % 2 == 0) {
+        // every tile is written exactly once: here if no task owns it, by its owner's flush otherwise
+        ig_prof_scope prof(ctx, "bricks_wide_zero");
+        hipLaunchKernelGGL(k_wide_zero_unowned, dim3((unsigned)((K + 4095) / 4096)), dim3(BLK), 0, ctx->stream, owned_tiles, (float2*)Y, ldy, K);
+        IG_LAUNCH_CHECK(ctx, "k_wide_zero_unowned");
+    } else {
         ig_prof_scope prof(ctx, "bricks_wide_zero", (double)K * N * 8.0);
         if (ldy == K) IG_HIP(ctx, hipMemsetAsync(Y, 0, (size_t)K * N * 8, ctx->stream));
         else IG_HIP(ctx, hipMemset2DAsync(Y, (size_t)ldy * 8, 0, (size_t)K * 8, (size_t)N, ctx->stream));
@@ -1818,10 +1988,9 @@ int ig_ccsrmm_t_bricks_wide(ig_ctx* ctx, int64_t M, int64_t K, float ar, float a
         IG_LAUNCH_CHECK(ctx, "k_pack_panel");
     }
     ig_prof_scope prof(ctx, "csrmm_bricks_wide_conj");
-    const unsigned blocks = (unsigned)((((ntasks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK) + 7) / 8 * 8);      // a multiple of 8: see the XCD order
-    static const int wide_xcd = getenv("INDIGO_HIP_WIDE_XCD") ? atoi(getenv("INDIGO_HIP_WIDE_XCD")) : 0;
+    const unsigned blocks = (unsigned)((ntasks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
     hipLaunchKernelGGL(k_bricks_wide64, dim3(blocks), dim3(BLK), 0, ctx->stream, (const BrickTask*)tasks, (int)ntasks, (const BrickRef*)brick_table,
-                       (const BrickEntry*)entries, entry_rows, (const float2*)xp, (float2*)Y, ldy, make_float2(ar, ai), wide_xcd);
+                       (const BrickEntry*)entries, entry_rows, (const float2*)xp, (float2*)Y, ldy, make_float2(ar, ai));
     IG_LAUNCH_CHECK(ctx, "k_bricks_wide64");
     return IG_OK;
 }

@@ -699,3 +699,29 @@ def test_brick_binned_adjoint_gridding(hip, N, bm, bs, chunk, run, with_support)
     got2 = y2.to_host().reshape(-1, order='F').reshape(P, 2)
     exp2 = A.conj().T.astype(np.complex128) @ X2.astype(np.complex128)
     assert rel_err(got2[inside] if with_support else got2, exp2[inside] if with_support else exp2) < RTOL
+
+
+@pytest.mark.parametrize("alpha,beta,ld_pad", [(1, 0, 0), (0.5 - 1j, 1.5, 5)])
+def test_wide_panel_forward_ragged_rows(hip, alpha, beta, ld_pad):
+    """the 16-row-tile gather (k_csrmm_gather_tile64: 64 columns, software-pipelined over the rows of a tile): rows of every
+    length -- empty ones, more than one pass (> 32 nonzeros), a few beyond the long-row threshold (> 256: handed to the
+    workgroup-per-row kernel, their tile slots skipped) -- and a row count that is not a multiple of 16"""
+    M, K = 1003, 6000
+    rng = np.random.default_rng(11)
+    lens = rng.integers(0, 80, size=M)
+    lens[[5, 300, 1002]] = [700, 300, 257]
+    lens[[0, 17, 18, 19, 640]] = 0
+    rows = np.repeat(np.arange(M), lens)
+    cols = rng.integers(0, K, size=rows.size)
+    A = spp.csr_matrix((rand64c(rows.size, seed=1), (rows, cols)), shape=(M, K))
+    A.sum_duplicates(); A.sort_indices()
+    A_d = hip.csr_matrix(hip, A)
+    xfull = rand64c(K + ld_pad, 64, seed=2)
+    yfull = rand64c(M + ld_pad, 64, seed=3)
+    x_d = hip.copy_array(xfull)[0:K, :]
+    y_d = hip.copy_array(yfull)[0:M, :]
+    A_d.forward(y_d, x_d, alpha=alpha, beta=beta)
+    exp = alpha * (A.astype(np.complex128) @ xfull[:K].astype(np.complex128)) + beta * yfull[:M]
+    assert rel_err(y_d.to_host(), exp) < RTOL
+    if ld_pad:
+        np.testing.assert_array_equal(hip.copy_array(yfull)[M:, :].to_host(), yfull[M:])      # (rows past M of the parent are not ours)
