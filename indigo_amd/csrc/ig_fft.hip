@@ -56,6 +56,9 @@ namespace {
 #ifndef IG_FFT_NT_STORE
 #define IG_FFT_NT_STORE 1
 #endif
+#ifndef IG_FFT_GROUP_SKIP
+#define IG_FFT_GROUP_SKIP 1     // wave-uniform skipping of loads / stores no lane wants (support bitmap, boxes)
+#endif
 constexpr int MAX_STAGES = 16;
 constexpr int E = 8;                 // complex elements a thread holds per LDS stage
 constexpr int LDS_NMAX = 4096;
@@ -416,6 +419,7 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
     constexpr int n = R1 * R2, B1 = R2 / T, B2 = R1 / T, NT = W * T;
     constexpr bool NT_LD = IG_FFT_NT_LOAD && NTH, NT_ST = IG_FFT_NT_STORE && NTH;
     constexpr bool HALF_IN = HALF == 1 || HALF == 3, HALF_OUT = HALF == 2 || HALF == 4;
+    constexpr bool GROUP_SKIP = IG_FFT_GROUP_SKIP != 0;
     constexpr int SUMW = WMODE >= 3 ? (1 << (WMODE - 3)) : 0;       // WMODE 3 + log2(coils): 3 -> 1 (no sum), 4 -> 2, 5 -> 4, 6 -> 8, 7 -> 16
     // direction: the half-input variants only serve forward (zero-padded) passes and the half-output variants only
     // inverse (cropped) ones, so their conjugations are sign modifiers, not a select per element
@@ -441,12 +445,23 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
     const unsigned k1 = rest % d.ext1, k2 = rest / d.ext1;
     const int64_t k0u = (int64_t)tr * ((!AXIS0 && d.cw) ? W / d.cw : W);
     int in_lo = d.in_lo, in_hi = d.in_hi, out_lo = d.out_lo, out_hi = d.out_hi;
+    // The tile's support records -- ky hull of its kx tile, z range, segment bitmap word of this thread -- are three
+    // INDEPENDENT loads (all addressed by the tile index alone): request them together, test afterwards.  Tested one after
+    // the other (load, early return, next load ...) they were three dependent round trips at the head of every workgroup,
+    // before the first grid row could be asked for.
+    short2 k1r = make_short2(0, 0x7fff), trg = make_short2(0, 0x7fff);
+    uint32_t zb = 0xffffffffu;
+    if (BOXED && !AXIS0) {
+        const int64_t tidx = (int64_t)k1 * d.tile_range_k1 + (tr >> d.tile_shift);
+        if (d.k1_range) k1r = d.k1_range[tr >> d.tile_shift];
+        if (d.tile_range) trg = d.tile_range[tidx];
+        if (d.tile_bits) zb = d.tile_bits[tidx * 16 + t];
+    }
     if (BOXED && !AXIS0 && d.k1_range) {
-        const short2 r = d.k1_range[tr >> d.tile_shift];
-        if ((int)k1 < r.x || (int)k1 >= r.y) return;
+        if ((int)k1 < k1r.x || (int)k1 >= k1r.y) return;
     }
     if (BOXED && !AXIS0 && d.tile_range) {
-        const short2 r = d.tile_range[(int64_t)k1 * d.tile_range_k1 + (tr >> d.tile_shift)];
+        const short2 r = trg;
         if (d.tile_range_mode == 1) {
             out_lo = out_lo > r.x ? out_lo : r.x;
             out_hi = out_hi < r.y ? out_hi : r.y;
@@ -496,9 +511,22 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
         ibits = below(ceil16(in_hi - t)) & ~below(ceil16(in_lo - t));
         obits = below(ceil16(out_hi - t)) & ~below(ceil16(out_lo - t));
         if (!AXIS0 && d.tile_bits) {
-            const uint32_t zb = d.tile_bits[((int64_t)k1 * d.tile_range_k1 + (tr >> d.tile_shift)) * 16 + t];
             if (d.tile_range_mode == 1) obits &= zb; else ibits &= zb;
         }
+    }
+    // Wave-uniform version of the input mask (the OR over the wave's 64 / W values of t): where a bit is clear NO lane of the
+    // wave wants that element, and the load instruction itself is skipped by a scalar branch -- a k-space column is
+    // mostly unflagged rows (72 % on the headline problem), and an instruction whose lanes are all out of range still
+    // costs its issue slot and its pass through the address unit.
+    // (loads only.  The same scalar branches around the STORES of the padded z pass cost it its register allocation -- 172
+    // bytes of spills at the 128-register cap -- and predicating them through the execution mask instead, one opaque
+    // v_and / v_cmp / s_and_saveexec / store / s_mov exec block per element, was measured slower than the out-of-range
+    // offsets: padded y pass 1.08 -> 1.14 ms, padded z pass 1.21 -> 1.24 ms, config 5 41.9 -> 44.3 ms.)
+    uint32_t gin = 0xffffffffu;
+    if (BOXED && !AXIS0 && GROUP_SKIP && !HALF_IN && HALF != 4) {
+        gin = 0;
+#pragma unroll
+        for (int l = 0; l < 64; l += W) gin |= (uint32_t)__builtin_amdgcn_readlane((int)ibits, l);
     }
 
     // ---- stage 1: radix R1 on inputs j = t + k*R2, results (times w_n^{t k}) to the exchange
@@ -511,6 +539,7 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
             const bool stat = !BOXED || HALF_IN || HALF == 4;                 // box known at compile time
             // off = all ones (out of range) where the element is not wanted: one bit-field extract + one or
             const unsigned off = stat ? 0u : (unsigned)__builtin_amdgcn_sbfe((int)~ibits, k, 1);
+            if (!stat && !AXIS0 && GROUP_SKIP && !((gin >> k) & 1u)) { v[k] = mk(0.f, 0.f); if (WMODE == 1) wv[k] = mk(0.f, 0.f); continue; }
             if (AXIS0) {
                 v[k] = from2(buf_ld<NT_LD>(r_in, l_in | off, (unsigned)(k * R2) * 8u));
                 if (WMODE == 1) wv[k] = from2(buf_ld<false>(r_w, l_w | off, (unsigned)(k * R2) * 8u));
