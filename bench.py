@@ -66,7 +66,16 @@ def kernel_symbols(layout, ncoils, half_box=True, n=512, support_tile=16):
         "csrmm_gather": "k_csrmm_gather<8, 8, false, 0>",
     }
     lg = ncoils.bit_length() - 1
-    if layout == 2:
+    ab = {160: "10, 16, 1", 192: "12, 16, 1", 240: "15, 16, 1", 320: "16, 20, 1", 384: "16, 24, 2", 400: "20, 20, 2", 432: "18, 24, 2", 480: "20, 24, 2", 640: "20, 32, 2"}
+    if layout == 2 and n in ab:
+        # the reference driver's own grids: zero-pad-aware passes on the A x B kernel <A, B, ROUNDS, WMODE> (ig_fft_ab.h)
+        g = "anyfft::k_fft_ab_desc<%s, %%d>" % ab[n]
+        m.update({"fft_pad_x": g % 1, "fft_pad_y": g % 0, "fft_pad_z": g % 0, "fft_crop_z": g % 0, "fft_crop_y": g % 0, "fft_crop_x": g % (3 + lg)})
+        gv = {8: "k_csrmm_gather_v<4, 2, 8, false, 0>", 4: "k_csrmm_gather_v<2, 2, 8, false, 0>",
+              2: "k_csrmm_gather_v<2, 1, 8, false, 0>"}.get(ncoils, "k_csrmm_gather")
+        m.update({"csrmm_rowlane_conj": "k_csrmm_dense64<%d, true, true>" % ncoils, "csrmm_gather": gv,
+                  "csrmm_bricks_conj": "k_grid_bricks<%d, %d>" % (ncoils, 4 if ncoils == 8 else 0)})
+    elif layout == 2:
         gv = {8: "k_csrmm_gather_v<4, 2, 8, false, 0>", 4: "k_csrmm_gather_v<2, 2, 8, false, 0>",
               2: "k_csrmm_gather_v<2, 1, 8, false, 0>"}.get(ncoils, "k_csrmm_gather")
         if half_box and n == 512:
@@ -118,6 +127,8 @@ def parse():
     ap.add_argument("--config", type=int, default=4, choices=[1, 2, 3, 4, 5])
     ap.add_argument("--image", type=int, default=0, help="image edge (debug: smaller problems; default 256 / 320 for config 4 / 5)")
     ap.add_argument("--coils", type=int, default=0, help="coils (default 8 / 32 for config 4 / 5)")
+    ap.add_argument("--osf", type=float, default=0.0, help="config 4: oversampling factor of the gridding (default 2.0; 1.25 puts the 256^3 "
+                    "image on the 320^3 grid the reference's own driver would pick, examples/pics.py:87-90)")
     ap.add_argument("--tree", choices=["zpadfft", "o3", "recipe"], default="zpadfft",
                     help="zpadfft: S' and the FFT fused into one zero-pad-aware leaf (default); o3: the reference's -O3 leaves; "
                          "recipe: the reference's factories + pics.py recipe + FuseZpadFFT (reaches the same fused leaf)")
@@ -257,13 +268,14 @@ def make_comm(args, B, world, rank, local_rank):
 # ---------------------------------------------------------------------------------------------------------
 # configs 4 and 5: SENSE A^H A
 # ---------------------------------------------------------------------------------------------------------
-def sense_problem(cfg, img, C):
+def sense_problem(cfg, img, C, osf=0.0):
     from indigo_amd.sense import SenseProblem
     if cfg == 4:
-        nreadout = 2 * img                                   # samples per spoke = oversampled grid edge
-        nspokes = int(round(3617 * (img / 256.0) ** 2))      # 3617 spokes at 256^3 -> T = 1,851,904
+        osf = osf or 2.0
+        nreadout = int(img * osf)                            # samples per spoke = oversampled grid edge
+        nspokes = int(round(3617 * (img / 256.0) ** 2))      # 3617 spokes at 256^3 -> T = 1,851,904 at oversampling 2
         return SenseProblem.synthetic((img,) * 3, C, nspokes=nspokes, nreadout=nreadout, width=2, ntable=128,
-                                      oversamp=2.0, seed=4)
+                                      oversamp=osf, seed=4)
     # config 5: 320^3 in 512^3 (oversampling 1.6), maps generated per coil so that a rank only materialises its own
     grid = int(img * 1.6)
     nspokes = int(round(3617 * (img / 256.0) ** 2))          # 5652 spokes at 320^3 -> T = 2,893,824
@@ -281,7 +293,7 @@ def run_sense(args, cfg, B, comm, world, rank, steps, warmup, want_cpu, quiet=Fa
     t_setup = time.time()
     img = args.image or (256 if cfg == 4 else 320)
     C = args.coils or (8 if cfg == 4 else 32)
-    p = sense_problem(cfg, img, C)
+    p = sense_problem(cfg, img, C, args.osf if cfg == 4 else 0.0)
     shard = None
     if args.shard:
         r, w = (int(v) for v in args.shard.split("/"))
@@ -292,7 +304,7 @@ def run_sense(args, cfg, B, comm, world, rank, steps, warmup, want_cpu, quiet=Fa
     log("config %d: image %d^3, %d coils (%d here%s), grid %s, T=%d (%.1fs)" % (
         cfg, img, C, len(coils), " = shard %d/%d" % shard if shard else "", p.oN, p.T, time.time() - t_setup))
     tree = args.tree if cfg == 4 else "zpadfft"
-    fused_fft = tree in ("zpadfft", "recipe") and B.supports_padded_fft(p.oN)
+    fused_fft = tree in ("zpadfft", "recipe") and B.supports_padded_fft(p.oN, len(coils))
     layout = args.layout if args.layout >= 0 else (2 if (len(coils) in (2, 4, 8) or len(coils) > 8) else 1)
     if tree == "recipe":
         from indigo_amd.transforms import FuseZpadFFT, sense_recipe
@@ -369,7 +381,7 @@ def run_sense(args, cfg, B, comm, world, rank, steps, warmup, want_cpu, quiet=Fa
     comp_bytes = sum(v['bytes'] / steps for v in prof.values())
     pmc, pmc_src = load_pmc(cfg)
     traffic_bytes, traffic_src = None, None
-    if pmc and world == 1 and not shard and not args.image and not args.coils and tree == "zpadfft":
+    if pmc and world == 1 and not shard and not args.image and not args.coils and not args.osf and tree == "zpadfft":
         tot = 0.0
         for sym, k in kernels.items():
             if sym in pmc:
@@ -472,7 +484,7 @@ def bench_sense(args, world, rank, local_rank):
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and not args.shard and cfg == 4
     res = run_sense(args, cfg, B, comm, world, rank, args.steps, args.warmup, want_cpu)
     extra5 = None
-    if cfg == 4 and not args.no_config5 and not args.shard and not args.image and not args.coils and args.tree == "zpadfft":
+    if cfg == 4 and not args.no_config5 and not args.shard and not args.image and not args.coils and not args.osf and args.tree == "zpadfft":
         try:
             r5 = run_sense(args, 5, B, comm, world, rank, max(2, min(args.steps, 5)), min(args.warmup, 2), False, quiet=True)
             extra5 = {"evals_per_s": r5["value"], "ms_per_step": r5["ms_per_step"], "n_gpus": world, "config": r5["config"],
@@ -482,7 +494,7 @@ def bench_sense(args, world, rank, local_rank):
             extra5 = {"error": "%s: %s" % (type(e).__name__, e)}
             print("[bench] config-5 extra failed on rank %d: %s" % (rank, extra5["error"]), file=sys.stderr, flush=True)
     leaves = {}
-    if rank == 0 and world == 1 and cfg == 4 and not args.no_leaf_configs and not args.shard and not args.image and not args.coils \
+    if rank == 0 and world == 1 and cfg == 4 and not args.no_leaf_configs and not args.shard and not args.image and not args.coils and not args.osf \
             and args.tree == "zpadfft":
         # the other half of BASELINE.json's metric ("SpMM HBM GB/s vs peak") and the plain FFT contract, in the same driver-run
         # line: BASELINE configs 2 and 3 with their own roofline / cpu_baseline / parity objects (`--config 2|3` alone prints
@@ -500,7 +512,7 @@ def bench_sense(args, world, rank, local_rank):
                 leaves["config%d" % c] = {"error": "%s: %s" % (type(e).__name__, e)}
                 print("[bench] config-%d extra failed: %s" % (c, leaves["config%d" % c]["error"]), file=sys.stderr, flush=True)
     if rank == 0:
-        name = ("SENSE AHA evals/sec (256^3 x 8-coil non-Cartesian)" if cfg == 4 and not args.image and not args.coils
+        name = ("SENSE AHA evals/sec (256^3 x 8-coil non-Cartesian)" if cfg == 4 and not args.image and not args.coils and not args.osf
                 else "SENSE AHA evals/sec (%s)" % res["config"]["workload"].split(",", 1)[1].split(";")[0].strip())
         out = {"metric": name, "value": res.pop("value"), "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": res.pop("ms_per_step"), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,

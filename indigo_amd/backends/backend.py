@@ -447,7 +447,8 @@ class Backend(object):
         """y = beta*y + alpha * sum_j X[:, j]  (interleaved: X's memory holds element (i, j) at i*ncols + j)"""
         raise NotImplementedError()
 
-    def supports_padded_fft(self, grid):
+    def supports_padded_fft(self, grid, ncoils=None):
+        """whether `fft_padded` / `ifft_cropped[_sum]` exist for this oversampled grid (and, if given, this many coils)"""
         return False
 
     def ccsrmm(self, y, A_shape, A_indx, A_ptr, A_vals, x, alpha=1, beta=0, adjoint=False, exwrite=False):

@@ -434,8 +434,23 @@ class HipBackend(Backend):
         self._check(rc, "ig_fft_exec")
 
     # fused zero-pad / crop transforms (operators.ZpadFFT)
-    def supports_padded_fft(self, grid):
-        return len(grid) == 3 and all(int(n) in (256, 512) for n in grid)
+    PADDED_AXES_POW2 = (256, 512)
+    PADDED_AXES_AB = (160, 192, 240, 320, 384, 400, 432, 480, 640)       # k_fft_ab_desc instantiations (ig_fft.hip: IG_ABD_LIST)
+
+    def supports_padded_fft(self, grid, ncoils=None):
+        """256- and 512-point axes in every grid layout; the reference driver's own oversampled grids (320 ... 640,
+        examples/pics.py:87-90, and smaller ones: 160 ... 640) in the coil-interleaved layout, i.e. for coil counts that split into chunks of 2, 4, 8 or 16"""
+        from indigo_amd import fused
+        if len(grid) != 3:
+            return False
+        if all(int(n) in self.PADDED_AXES_POW2 for n in grid):
+            return True
+        if not all(int(n) in self.PADDED_AXES_POW2 + self.PADDED_AXES_AB for n in grid):
+            return False
+        if ncoils is None:
+            return True
+        layout, chunks = fused.choose_layout(int(ncoils), 8, None)
+        return layout == 2 and all(hi - lo >= 2 for lo, hi in chunks)
 
     supports_support_tile = True          # ZpadFFT / the brick scatter take support tables of 8 or 4 kx points per entry
 

@@ -358,45 +358,6 @@ template <int N> struct PFFTHalfIn {
     }
 };
 
-// One axis pass, described generally enough for plain, zero-padded and cropped transforms.
-// Columns are enumerated by three indices (k0 fastest, then k1, k2); element j of column k lives at
-//   in  + k0*in_s[0]  + k1*in_s[1]  + k2*in_s[2]  + j*in_sj      (read only for in_lo  <= j < in_hi, else 0)
-//   out + k0*out_s[0] + k1*out_s[1] + k2*out_s[2] + j*out_sj     (stored only for out_lo <= j < out_hi)
-// The base pointers are pre-offset on the host (index origins of boxes / compact arrays), so they may
-// point outside the buffers; they are only dereferenced inside the boxes.  Optional diagonal weights
-// `w` (same indexing, own strides): WMODE 1 multiplies the inputs by w, WMODE 2 the outputs by conj(w); WMODE
-// 3 + log2(cw) additionally sums the weighted outputs over the cw sub-columns of a column (SENSE coil combination)
-// and stores the sum once, through the addressing of sub-column 0.
-struct PassDesc {
-    const float2* in; float2* out; const float2* w;
-    int64_t in_sj, out_sj, w_sj;
-    int64_t in_s[3], out_s[3], w_s[3];
-    int64_t ext0, ext1, ncols;
-    unsigned tpr;               // tiles per (k1, k2) row = ceil(ext0 / W); filled in by the launcher
-    // Optional split of a tile's W lanes (strided passes): cw > 0 makes lane w address sub-column a = w % cw (element
-    // strides in_sa / out_sa / w_sa) of column k0 = tile*(W/cw) + w/cw, i.e. a tile is W/cw columns of cw contiguous
-    // sub-columns.  The coil-interleaved grid layout uses it for its x passes (cw = coils, columns = lines).
-    int cw;
-    int64_t in_sa, out_sa, w_sa;
-    int tile_shift;             // tile_range / tile_bits entries are shared by 2^tile_shift consecutive tiles
-    int xcd_remap;              // filled in by the launcher
-    int cached;                 // plain passes only: no non-temporal hint (the next pass re-reads the data from the Infinity Cache)
-    int in_lo, in_hi, out_lo, out_hi;
-    int inverse;
-    // optional per-tile override of the box along the transform axis (strided passes, W | ext0):
-    // tile_range[k1 * (ext0 / W) + k0 / W] = (lo, hi); mode 1 narrows the OUTPUT box (tiles with an empty
-    // range are skipped altogether), mode 2 narrows the INPUT box (everything outside reads as zero)
-    const short2* tile_range;
-    int tile_range_mode;
-    int64_t tile_range_k1;      // table row stride per k1 (tiles per row), or 0 if the ranges do not depend on k1
-    // optional refinement of tile_range (same mode, same indexing, 16 words per tile): bit m of word t is set iff
-    // element j = t + 16*m of the tile's columns is needed (mode 1) / was ever written (mode 2)
-    const uint32_t* tile_bits;
-    // optional: tiles whose k1 lies outside k1_range[tile >> tile_shift] = [lo, hi) are skipped altogether (the
-    // cropped z pass: the y pass that follows never reads ky outside the kx tile's ky hull)
-    const short2* k1_range;
-};
-
 // Two-stage kernel for n = R1*R2 (256 = 16x16, 512 = 32x16): the whole column lives in registers
 // twice -- stage 1 reads its R1 inputs straight from global memory, stage 2 writes its R2 outputs
 // straight back -- with ONE LDS exchange in between (Stockham index map, inter-stage twiddles applied
@@ -1010,6 +971,7 @@ struct ig_fft {
     bool two_launch = false;         // 256^3 volumes: k_fft3d_a + k_fft3d_b instead of three axis passes
     size_t inplace_workspace_bytes = 0;   // two-launch transform called in place: staging volumes in the CALLER's workspace (ig_fft_inplace_workspace)
     bool padded = false;
+    bool has_ab_axis = false;        // a zero-padded plan with an A x B axis (320 ... 640): no k-space support table
     int layout = 0;                  // memory order of the grid: 0 = (x, y, z), 1 = (x, z, y)
     int support_tile = 16;           // kx points per entry of the k-space support table (layout 2: ig_fft_set_support_tile)
     int64_t box_lo[3] = {0, 0, 0}, box_dims[3] = {1, 1, 1};
@@ -1227,6 +1189,58 @@ int launch_2stage(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d_in, bool ax
 #undef IG_2S
     IG_LAUNCH_CHECK(ctx, "k_fft_2stage");
     return IG_OK;
+}
+
+// ---- zero-pad-aware passes on A x B axes (k_fft_ab_desc): the lengths with a descriptor-driven instantiation -------------
+#define IG_ABD_LIST(X) X(10, 16, 1) X(12, 16, 1) X(15, 16, 1) X(16, 20, 1) X(16, 24, 2) X(20, 20, 2) X(18, 24, 2) X(20, 24, 2) X(20, 32, 2)   /* 160 192 240 320 384 400 432 480 640 */
+bool abd_supported(int64_t n) {
+#define IG_ABD_CASE(A_, B_, R_) if (n == (A_) * (B_)) return true;
+    IG_ABD_LIST(IG_ABD_CASE)
+#undef IG_ABD_CASE
+    return false;
+}
+int launch_ab_desc(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d_in, int wmode) {
+    PassDesc d = d_in;
+    if (d.ncols == 0) return IG_OK;
+    IG_REQUIRE(ctx, !d.tile_range && !d.tile_bits && !d.k1_range, "ig_fft: the k-space support table needs 256- or 512-point axes");
+    IG_REQUIRE(ctx, !d.cw || (d.cw <= anyfft::AB_W && anyfft::AB_W % d.cw == 0), "ig_fft: bad lane split");
+    const int64_t cpt = d.cw ? anyfft::AB_W / d.cw : anyfft::AB_W;
+    const int64_t tpr = (d.ext0 + cpt - 1) / cpt;
+    const int64_t blocks = tpr * (d.ncols / d.ext0);
+    IG_REQUIRE(ctx, blocks <= 0x7fffffffLL && d.ext1 <= 0x7fffffffLL, "ig_fft: too many tiles");
+    d.tpr = (unsigned)tpr;
+    {   // a thread's lane offset reaches (B - 1) element steps + the tile's lanes: inside the 2 GB descriptor window
+        const int64_t lim = 0x7fffffffLL / 8, reach = ax.ab_B - 1;
+        const int64_t span_in = reach * d.in_sj + 15 * d.in_s[0] + 15 * d.in_sa, span_out = reach * d.out_sj + 15 * d.out_s[0] + 15 * d.out_sa;
+        const int64_t span_w = wmode ? reach * d.w_sj + 15 * d.w_s[0] + 15 * d.w_sa : 0;
+        IG_REQUIRE(ctx, d.in_sj >= 0 && d.out_sj >= 0 && d.in_s[0] >= 0 && d.out_s[0] >= 0 && span_in < lim && span_out < lim && span_w < lim,
+                   "ig_fft: axis stride too large for the two-stage kernel");
+    }
+    int wm = wmode;
+    if (wmode == 3) {
+        IG_REQUIRE(ctx, d.cw == 2 || d.cw == 4 || d.cw == 8 || d.cw == 16, "ig_fft: the coil-summing A x B pass takes 2, 4, 8 or 16 interleaved coils");
+        wm = d.cw == 2 ? 4 : d.cw == 4 ? 5 : d.cw == 8 ? 6 : 7;
+    }
+    const dim3 grid((unsigned)blocks), block((unsigned)(anyfft::AB_W * ax.ab_B));
+#define IG_ABD_WM(A_, B_, R_, WM_) hipLaunchKernelGGL((anyfft::k_fft_ab_desc<A_, B_, R_, WM_>), grid, block, (anyfft::ab_lds_bytes<A_, B_, R_, false>()), ctx->stream, d, ax.d_tw)
+#define IG_ABD_CASE(A_, B_, R_)                                                                             \
+    if (ax.n == (A_) * (B_)) {                                                                              \
+        switch (wm) { case 0: IG_ABD_WM(A_, B_, R_, 0); break; case 1: IG_ABD_WM(A_, B_, R_, 1); break; case 2: IG_ABD_WM(A_, B_, R_, 2); break; \
+                      case 4: IG_ABD_WM(A_, B_, R_, 4); break; case 5: IG_ABD_WM(A_, B_, R_, 5); break; case 6: IG_ABD_WM(A_, B_, R_, 6); break; \
+                      default: IG_ABD_WM(A_, B_, R_, 7); break; }                                           \
+    } else
+    IG_ABD_LIST(IG_ABD_CASE) { return ig_fail(ctx, IG_ERR_UNSUPPORTED, "ig_fft: no zero-pad-aware kernel for n = %lld", (long long)ax.n); }
+#undef IG_ABD_CASE
+#undef IG_ABD_WM
+    IG_LAUNCH_CHECK(ctx, "k_fft_ab_desc");
+    return IG_OK;
+}
+
+// one pass of a zero-padded / cropped transform: the power-of-two kernel or the A x B one, by the axis plan
+int launch_pass(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d, bool axis0, int wmode) {
+    if (ax.kind == 3) return launch_2stage(ctx, ax, d, axis0, wmode);
+    IG_REQUIRE(ctx, ax.kind == 4 && !axis0, "ig_fft: a zero-padded pass on an axis without a two-stage kernel");
+    return launch_ab_desc(ctx, ax, d, wmode);
 }
 
 }  // namespace
@@ -1470,12 +1484,15 @@ int ig_fft_plan_padded(ig_ctx* ctx, const int64_t* dims, const int64_t* box_lo, 
     if (rc != IG_OK) return rc;
     ig_fft* p = *plan;
     for (int a = 0; a < 3; ++a) {
-        if (p->axis[a].kind != 3) {
+        const bool ab_ok = p->axis[a].kind == 4 && abd_supported(dims[a]) && grid_layout == 2 && batch >= 2;
+        if (p->axis[a].kind != 3 && !ab_ok) {
             ig_fft_destroy(p);
             *plan = nullptr;
             return ig_fail(ctx, IG_ERR_UNSUPPORTED,
-                           "ig_fft_plan_padded: grid axis %d has length %lld; the padded path needs 256 or 512", a, (long long)dims[a]);
+                           "ig_fft_plan_padded: grid axis %d has length %lld; the padded path needs 256 or 512 -- or, with 2, 4, 8 or 16 "
+                           "coil-interleaved batch members (grid_layout 2), 160, 192, 240, 320, 384, 400, 432, 480 or 640", a, (long long)dims[a]);
         }
+        if (ab_ok) p->has_ab_axis = true;
         p->box_lo[a] = box_lo[a];
         p->box_dims[a] = box_dims[a];
     }
@@ -1614,7 +1631,7 @@ static int exec_padded_layout2(ig_fft* p, const float2* x, int64_t x_bstride, co
         d.out = L1; d.out_sj = C; d.out_sa = 1; d.out_s[0] = C * n0; d.out_s[1] = C * n0 * b1;
         d.ext0 = b1; d.ext1 = b2; d.ncols = b1 * b2;
         d.in_lo = (int)l0; d.in_hi = (int)(l0 + b0); d.out_lo = 0; d.out_hi = (int)n0; d.inverse = 0;
-        if (int rc = launch_2stage(ctx, p->axis[0], d, false, w ? 1 : 0)) return rc;
+        if (int rc = launch_pass(ctx, p->axis[0], d, false, w ? 1 : 0)) return rc;
     }
     {   // pass y: columns (c + C*kx, z')
         ig_prof_scope prof(ctx, "fft_pad_y", (double)(cvol + n0 * n1 * b2) * C * 8.0);
@@ -1624,7 +1641,7 @@ static int exec_padded_layout2(ig_fft* p, const float2* x, int64_t x_bstride, co
         d.ext0 = C * n0; d.ext1 = b2; d.ncols = C * n0 * b2;
         d.in_lo = (int)l1; d.in_hi = (int)(l1 + b1); d.out_lo = 0; d.out_hi = (int)n1; d.inverse = 0;
         if (support) { d.tile_range = support + n1 * snt; d.tile_range_mode = 1; d.tile_range_k1 = 0; d.tile_shift = sshift; }
-        if (int rc = launch_2stage(ctx, p->axis[1], d, false, 0)) return rc;
+        if (int rc = launch_pass(ctx, p->axis[1], d, false, 0)) return rc;
     }
     {   // pass z: columns (c + C*kx, ky), in place
         ig_prof_scope prof(ctx, "fft_pad_z", (double)(n0 * n1 * b2 + vol) * C * 8.0);
@@ -1635,7 +1652,7 @@ static int exec_padded_layout2(ig_fft* p, const float2* x, int64_t x_bstride, co
         d.in_lo = (int)l2; d.in_hi = (int)(l2 + b2); d.out_lo = 0; d.out_hi = (int)n2; d.inverse = 0;
         d.tile_range = support; d.tile_range_mode = 1; d.tile_range_k1 = snt; d.tile_shift = sshift;
         if (support) d.tile_bits = reinterpret_cast<const uint32_t*>(support + n1 * snt + snt);
-        if (int rc = launch_2stage(ctx, p->axis[2], d, false, 0)) return rc;
+        if (int rc = launch_pass(ctx, p->axis[2], d, false, 0)) return rc;
     }
     return IG_OK;
 }
@@ -1664,7 +1681,7 @@ static int exec_cropped_layout2(ig_fft* p, const float2* y, const float2* w, flo
         d.tile_range = support; d.tile_range_mode = 2; d.tile_range_k1 = snt; d.tile_shift = sshift;
         if (support) d.tile_bits = reinterpret_cast<const uint32_t*>(support + n1 * snt + snt);
         if (support) d.k1_range = support + n1 * snt;                         // ky the y pass will never read
-        if (int rc = launch_2stage(ctx, p->axis[2], d, false, 0)) return rc;
+        if (int rc = launch_pass(ctx, p->axis[2], d, false, 0)) return rc;
     }
     if (!(phases & 2) || nz <= 0) return IG_OK;
     {   // pass y
@@ -1675,7 +1692,7 @@ static int exec_cropped_layout2(ig_fft* p, const float2* y, const float2* w, flo
         d.ext0 = C * n0; d.ext1 = nz; d.ncols = C * n0 * nz;
         d.in_lo = 0; d.in_hi = (int)n1; d.out_lo = (int)l1; d.out_hi = (int)(l1 + b1); d.inverse = 1;
         if (support) { d.tile_range = support + n1 * snt; d.tile_range_mode = 2; d.tile_range_k1 = 0; d.tile_shift = sshift; }
-        if (int rc = launch_2stage(ctx, p->axis[1], d, false, 0)) return rc;
+        if (int rc = launch_pass(ctx, p->axis[1], d, false, 0)) return rc;
     }
     if (sum_coils) {   // pass x with the coil combination: x = sum_c conj(w_c) .* crop(...), one image box
         ig_prof_scope prof(ctx, "fft_crop_x", ((double)(cvol + bvol) * C * 8.0 + (double)bvol * 8.0) * (double)nz / (double)b2);
@@ -1686,7 +1703,7 @@ static int exec_cropped_layout2(ig_fft* p, const float2* y, const float2* w, flo
         d.w = w - l0 * C + z0 * b0 * b1 * C; d.w_sj = C; d.w_sa = 1; d.w_s[0] = b0 * C; d.w_s[1] = b0 * b1 * C;
         d.ext0 = b1; d.ext1 = nz; d.ncols = b1 * nz;
         d.in_lo = 0; d.in_hi = (int)n0; d.out_lo = (int)l0; d.out_hi = (int)(l0 + b0); d.inverse = 1;
-        if (int rc = launch_2stage(ctx, p->axis[0], d, false, 3)) return rc;
+        if (int rc = launch_pass(ctx, p->axis[0], d, false, 3)) return rc;
     } else
     {   // pass x: interleaved compact rows -> interleaved compact image box, times conj(w)
         ig_prof_scope prof(ctx, "fft_crop_x", (double)(cvol + bvol + (w ? bvol : 0)) * C * 8.0);
@@ -1697,7 +1714,7 @@ static int exec_cropped_layout2(ig_fft* p, const float2* y, const float2* w, flo
         d.w = w ? w - l0 * C : nullptr; d.w_sj = C; d.w_sa = 1; d.w_s[0] = b0 * C; d.w_s[1] = b0 * b1 * C;
         d.ext0 = b1; d.ext1 = b2; d.ncols = b1 * b2;
         d.in_lo = 0; d.in_hi = (int)n0; d.out_lo = (int)l0; d.out_hi = (int)(l0 + b0); d.inverse = 1;
-        if (int rc = launch_2stage(ctx, p->axis[0], d, false, w ? 2 : 0)) return rc;
+        if (int rc = launch_pass(ctx, p->axis[0], d, false, w ? 2 : 0)) return rc;
     }
     return IG_OK;
 }
@@ -1705,7 +1722,7 @@ static int exec_cropped_layout2(ig_fft* p, const float2* y, const float2* w, flo
 int ig_fft_set_support_tile(ig_fft* p, int tile) {
     if (!p) return ig_fail(nullptr, IG_ERR_ARG, "ig_fft_set_support_tile: plan is NULL");
     ig_ctx* ctx = p->ctx;
-    IG_REQUIRE(ctx, p->padded && p->layout == 2, "ig_fft_set_support_tile: a zero-padded plan of the coil-interleaved layout");
+    IG_REQUIRE(ctx, p->padded && p->layout == 2 && !p->has_ab_axis, "ig_fft_set_support_tile: a zero-padded plan of the coil-interleaved layout with 256- or 512-point axes");
     IG_REQUIRE(ctx, (tile == 2 || tile == 4 || tile == 8 || tile == 16) && p->batch * tile >= 16 && p->dims[0] % tile == 0,
                "ig_fft_set_support_tile: tile %d (2, 4, 8 or 16 kx points; coils * tile >= 16)", tile);
     p->support_tile = tile;
@@ -1719,6 +1736,7 @@ int ig_fft_exec_padded(ig_fft* p, const void* xv, int64_t x_bstride, const void*
     IG_REQUIRE(ctx, p->padded, "ig_fft_exec_padded: plan was not made by ig_fft_plan_padded");
     IG_REQUIRE(ctx, xv && yv, "ig_fft_exec_padded: NULL array");
     IG_REQUIRE(ctx, p->layout == 0 || workspace, "ig_fft_exec_padded: grid layouts 1 and 2 need the workspace");
+    IG_REQUIRE(ctx, !support || !p->has_ab_axis, "ig_fft_exec_padded: the k-space support table needs 256- or 512-point grid axes");
     if (int rc = ig_set_device(ctx)) return rc;
     IG_REQUIRE(ctx, !support || p->layout >= 1, "ig_fft_exec_padded: a support table needs grid layout 1 or 2");
     if (p->layout == 2)
@@ -1771,6 +1789,7 @@ int ig_fft_exec_cropped(ig_fft* p, const void* yv, const void* wv, void* xv, int
     ig_ctx* ctx = p->ctx;
     IG_REQUIRE(ctx, p->padded, "ig_fft_exec_cropped: plan was not made by ig_fft_plan_padded");
     IG_REQUIRE(ctx, xv && yv && workspace, "ig_fft_exec_cropped: NULL array");
+    IG_REQUIRE(ctx, !support || !p->has_ab_axis, "ig_fft_exec_cropped: the k-space support table needs 256- or 512-point grid axes");
     if (int rc = ig_set_device(ctx)) return rc;
     IG_REQUIRE(ctx, !support || p->layout >= 1, "ig_fft_exec_cropped: a support table needs grid layout 1 or 2");
     if (p->layout == 2)
@@ -1823,6 +1842,7 @@ int ig_fft_exec_cropped_sum(ig_fft* p, const void* yv, const void* wv, void* xv,
     ig_ctx* ctx = p->ctx;
     IG_REQUIRE(ctx, p->padded && p->layout == 2, "ig_fft_exec_cropped_sum: needs a plan of ig_fft_plan_padded with grid_layout 2");
     IG_REQUIRE(ctx, xv && yv && wv && workspace, "ig_fft_exec_cropped_sum: NULL array");
+    IG_REQUIRE(ctx, !support || !p->has_ab_axis, "ig_fft_exec_cropped_sum: the k-space support table needs 256- or 512-point grid axes");
     if (int rc = ig_set_device(ctx)) return rc;
     return exec_cropped_layout2(p, (const float2*)yv, (const float2*)wv, (float2*)xv, (float2*)workspace,
                                 (const short2*)support, true);
@@ -1837,6 +1857,7 @@ int ig_fft_exec_cropped_sum_slab(ig_fft* p, const void* yv, const void* wv, void
     IG_REQUIRE(ctx, phase == 0 || phase == 1, "ig_fft_exec_cropped_sum_slab: phase must be 0 (z pass) or 1 (y and x passes of a slab)");
     IG_REQUIRE(ctx, phase == 0 || (0 <= z0 && z0 <= z1 && z1 <= p->box_dims[2]),
                "ig_fft_exec_cropped_sum_slab: slab [%lld, %lld) outside the image's %lld planes", (long long)z0, (long long)z1, (long long)p->box_dims[2]);
+    IG_REQUIRE(ctx, !support || !p->has_ab_axis, "ig_fft_exec_cropped_sum_slab: the k-space support table needs 256- or 512-point grid axes");
     if (int rc = ig_set_device(ctx)) return rc;
     return exec_cropped_layout2(p, (const float2*)yv, (const float2*)wv, (float2*)xv, (float2*)workspace,
                                 (const short2*)support, true, phase == 0 ? 1 : 2, z0, z1);

@@ -12,9 +12,49 @@
 //
 // A <= B and as close as the factors allow (16 x 20, 18 x 24, 20 x 24, 20 x 32, ...), so at most a third of the
 // threads idle in the second DFT; the memory side stays balanced (B threads load A values, A threads store B).
-// Plain passes only (the fftn / ifftn contract, backend.py:497-509); the zero-pad-aware SENSE passes need n in {256, 512}.
+// k_fft_ab: plain passes (the fftn / ifftn contract, backend.py:497-509); k_fft_ab_desc: the zero-pad-aware SENSE passes.
 #pragma once
 #include <type_traits>
+
+// One axis pass, described generally enough for plain, zero-padded and cropped transforms.
+// Columns are enumerated by three indices (k0 fastest, then k1, k2); element j of column k lives at
+//   in  + k0*in_s[0]  + k1*in_s[1]  + k2*in_s[2]  + j*in_sj      (read only for in_lo  <= j < in_hi, else 0)
+//   out + k0*out_s[0] + k1*out_s[1] + k2*out_s[2] + j*out_sj     (stored only for out_lo <= j < out_hi)
+// The base pointers are pre-offset on the host (index origins of boxes / compact arrays), so they may
+// point outside the buffers; they are only dereferenced inside the boxes.  Optional diagonal weights
+// `w` (same indexing, own strides): WMODE 1 multiplies the inputs by w, WMODE 2 the outputs by conj(w); WMODE
+// 3 + log2(cw) additionally sums the weighted outputs over the cw sub-columns of a column (SENSE coil combination)
+// and stores the sum once, through the addressing of sub-column 0.
+struct PassDesc {
+    const float2* in; float2* out; const float2* w;
+    int64_t in_sj, out_sj, w_sj;
+    int64_t in_s[3], out_s[3], w_s[3];
+    int64_t ext0, ext1, ncols;
+    unsigned tpr;               // tiles per (k1, k2) row = ceil(ext0 / W); filled in by the launcher
+    // Optional split of a tile's W lanes (strided passes): cw > 0 makes lane w address sub-column a = w % cw (element
+    // strides in_sa / out_sa / w_sa) of column k0 = tile*(W/cw) + w/cw, i.e. a tile is W/cw columns of cw contiguous
+    // sub-columns.  The coil-interleaved grid layout uses it for its x passes (cw = coils, columns = lines).
+    int cw;
+    int64_t in_sa, out_sa, w_sa;
+    int tile_shift;             // tile_range / tile_bits entries are shared by 2^tile_shift consecutive tiles
+    int xcd_remap;              // filled in by the launcher
+    int cached;                 // plain passes only: no non-temporal hint (the next pass re-reads the data from the Infinity Cache)
+    int in_lo, in_hi, out_lo, out_hi;
+    int inverse;
+    // optional per-tile override of the box along the transform axis (strided passes, W | ext0):
+    // tile_range[k1 * (ext0 / W) + k0 / W] = (lo, hi); mode 1 narrows the OUTPUT box (tiles with an empty
+    // range are skipped altogether), mode 2 narrows the INPUT box (everything outside reads as zero)
+    const short2* tile_range;
+    int tile_range_mode;
+    int64_t tile_range_k1;      // table row stride per k1 (tiles per row), or 0 if the ranges do not depend on k1
+    // optional refinement of tile_range (same mode, same indexing, 16 words per tile): bit m of word t is set iff
+    // element j = t + 16*m of the tile's columns is needed (mode 1) / was ever written (mode 2)
+    const uint32_t* tile_bits;
+    // optional: tiles whose k1 lies outside k1_range[tile >> tile_shift] = [lo, hi) are skipped altogether (the
+    // cropped z pass: the y pass that follows never reads ky outside the kx tile's ky hull)
+    const short2* k1_range;
+};
+
 
 namespace anyfft {
 
@@ -228,6 +268,130 @@ k_fft_ab(const float2* __restrict__ x, float2* __restrict__ y, const float2* __r
                     if (inv) e.y = -e.y;
                     dst[(int64_t)(A * k2) * sj] = e;
                 }
+            }
+        }
+    }
+}
+
+// ---- the same pass through a PassDesc: zero-padded / cropped / weighted / coil-summing passes for n = A * B -----------------
+// What k_fft_2stage does for the 256 / 512-point axes of the SENSE transform, for the oversampled grids of the reference's own
+// driver (320, 384, 400, 432, 480, 640: examples/pics.py:87-90): inputs outside [in_lo, in_hi) are zeros that are never
+// loaded, outputs outside [out_lo, out_hi) are never stored (buffer-descriptor range checks, no branches per element; whole
+// load instructions no lane of the wave wants are skipped by a scalar branch), WMODE 1 multiplies the inputs by the weights,
+// 2 the outputs by their conjugates, 3 + log2(cw) also sums the cw sub-columns (coils) of a column with DPP adds; `cw` splits
+// a tile's 16 lanes into 16 / cw columns x cw sub-columns (the x passes of the coil-interleaved layout).  Strided passes only
+// (every pass of that layout is one); no k-space support table (its 16 x 32-bit words index 512 rows).
+template <int CTRL>
+__device__ __forceinline__ float ab_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ int ab_ceil_div_clamp(int num, int den, int hi) {       // ceil(num / den) clamped to [0, hi]
+    if (num <= 0) return 0;
+    const int q = (num + den - 1) / den;
+    return q > hi ? hi : q;
+}
+
+template <int A, int B, int ROUNDS, int WMODE>
+__global__ void __launch_bounds__(AB_W * B)
+k_fft_ab_desc(PassDesc d, const float2* __restrict__ tw) {
+    constexpr int N = A * B, AR = (A + ROUNDS - 1) / ROUNDS;
+    constexpr int SUMW = WMODE >= 3 ? (1 << (WMODE - 3)) : 0;
+    static_assert(A <= 32 && B <= 32, "element masks are 32-bit words");
+    extern __shared__ float2 lds[];
+    float2* __restrict__ tws = lds + AR * B * AB_W;
+    const int tid = threadIdx.x;
+    for (int k = tid; k < N; k += AB_W * B) tws[k] = tw[k];
+    const int b = tid / AB_W, w = tid % AB_W;
+    const bool inv = d.inverse != 0;
+    // the workgroup's tile: 16 consecutive k0 (or 16 / cw columns x cw sub-columns) of one (k1, k2) row
+    const unsigned tile = blockIdx.x;
+    const unsigned tr = tile % d.tpr, rest = tile / d.tpr;
+    const unsigned k1i = rest % d.ext1, k2i = rest / d.ext1;
+    const int64_t k0u = (int64_t)tr * (d.cw ? AB_W / d.cw : AB_W);
+    const float2* const b_in = d.in + (k0u * d.in_s[0] + (int64_t)k1i * d.in_s[1] + (int64_t)k2i * d.in_s[2]);
+    float2* const b_out = d.out + (k0u * d.out_s[0] + (int64_t)k1i * d.out_s[1] + (int64_t)k2i * d.out_s[2]);
+    const float2* const b_w = WMODE ? d.w + (k0u * d.w_s[0] + (int64_t)k1i * d.w_s[1] + (int64_t)k2i * d.w_s[2]) : nullptr;
+    const unsigned isj = (unsigned)d.in_sj, osj = (unsigned)d.out_sj, wsj = (unsigned)d.w_sj;
+    bool valid;
+    unsigned l_in, l_out, l_w;
+    if (d.cw) {
+        const unsigned a = (unsigned)w % (unsigned)d.cw, yl = (unsigned)w / (unsigned)d.cw;
+        valid = k0u + yl < d.ext0;
+        l_in = (a * (unsigned)d.in_sa + yl * (unsigned)d.in_s[0] + (unsigned)b * isj) * 8u;
+        l_out = (a * (unsigned)d.out_sa + yl * (unsigned)d.out_s[0] + (unsigned)b * osj) * 8u;
+        l_w = (a * (unsigned)d.w_sa + yl * (unsigned)d.w_s[0] + (unsigned)b * wsj) * 8u;
+    } else {
+        valid = k0u + w < d.ext0;
+        l_in = ((unsigned)w * (unsigned)d.in_s[0] + (unsigned)b * isj) * 8u;
+        l_out = ((unsigned)w * (unsigned)d.out_s[0] + (unsigned)b * osj) * 8u;
+        l_w = ((unsigned)w * (unsigned)d.w_s[0] + (unsigned)b * wsj) * 8u;
+    }
+    if (!valid) l_in = l_out = l_w = IG_OOB;
+    if (!WMODE) l_w = IG_OOB;
+    if (SUMW && (w % SUMW) != 0) l_out = IG_OOB;            // only a column's first sub-column stores the coil sum
+    // element j = b + B a <-> bit a of ibits (stage 1 loads); output k = b + A k2 <-> bit k2 of obits (stage 2 stores, b < A)
+    auto below = [](int h) -> uint32_t { return h >= 32 ? 0xffffffffu : ((1u << h) - 1u); };
+    const uint32_t ibits = below(ab_ceil_div_clamp(d.in_hi - b, B, A)) & ~below(ab_ceil_div_clamp(d.in_lo - b, B, A));
+    const uint32_t obits = below(ab_ceil_div_clamp(d.out_hi - b, A, B)) & ~below(ab_ceil_div_clamp(d.out_lo - b, A, B));
+    uint32_t gin = 0;                                          // wave-uniform: elements SOME lane of this wave wants
+#pragma unroll
+    for (int l = 0; l < 64; l += AB_W) gin |= (uint32_t)__builtin_amdgcn_readlane((int)ibits, l);
+
+    float2 v[A];
+    {
+        float2 wv[A];
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+            if (!((gin >> a) & 1u)) { v[a] = make_float2(0.f, 0.f); if (WMODE == 1) wv[a] = make_float2(0.f, 0.f); continue; }
+            const unsigned off = (unsigned)__builtin_amdgcn_sbfe((int)~ibits, a, 1);
+            v[a] = buf_ld<true>(make_rsrc(b_in + (int64_t)(B * a) * d.in_sj), l_in | off, 0);
+            if (WMODE == 1) wv[a] = buf_ld<false>(make_rsrc(b_w + (int64_t)(B * a) * d.w_sj), l_w | off, 0);
+        }
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+            if (WMODE == 1) v[a] = make_float2(fmaf(v[a].x, wv[a].x, -v[a].y * wv[a].y), fmaf(v[a].x, wv[a].y, v[a].y * wv[a].x));
+            if (inv) v[a].y = -v[a].y;
+        }
+    }
+    RegDFT<A>::run(v);
+    __syncthreads();                                   // the twiddle table is in place
+#pragma unroll
+    for (int k1 = 1; k1 < A; ++k1) {
+        const float2 t = tws[b * k1];
+        v[k1] = make_float2(fmaf(v[k1].x, t.x, -v[k1].y * t.y), fmaf(v[k1].x, t.y, v[k1].y * t.x));
+    }
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        if (r) __syncthreads();
+#pragma unroll
+        for (int k1 = 0; k1 < A; ++k1)
+            if (k1 >= r * AR && k1 < (r + 1) * AR) lds[ab_slot<AR, B, false>(k1 - r * AR, b, w)] = v[k1];
+        __syncthreads();
+        const int k1 = b;                              // stage 2: this thread's output residue
+        if (k1 >= r * AR && k1 < (r + 1) * AR && k1 < A) {
+            float2 u[B];
+#pragma unroll
+            for (int bb = 0; bb < B; ++bb) u[bb] = lds[ab_slot<AR, B, false>(k1 - r * AR, bb, w)];
+            RegDFT<B>::run(u);
+            float2 wv[B];
+            if (WMODE >= 2) {
+#pragma unroll
+                for (int k2 = 0; k2 < B; ++k2) {
+                    const unsigned off = (unsigned)__builtin_amdgcn_sbfe((int)~obits, k2, 1);
+                    wv[k2] = buf_ld<false>(make_rsrc(b_w + (int64_t)(A * k2) * d.w_sj), l_w | off, 0);
+                }
+            }
+#pragma unroll
+            for (int k2 = 0; k2 < B; ++k2) {
+                float2 e = u[k2];
+                if (inv) e.y = -e.y;
+                if (WMODE >= 2) e = make_float2(fmaf(wv[k2].x, e.x, wv[k2].y * e.y), fmaf(wv[k2].x, e.y, -wv[k2].y * e.x));      // conj(w) * e
+                if (SUMW >= 2)  { e.x += ab_dpp<0xB1>(e.x);  e.y += ab_dpp<0xB1>(e.y); }      // quad_perm [1,0,3,2]
+                if (SUMW >= 4)  { e.x += ab_dpp<0x4E>(e.x);  e.y += ab_dpp<0x4E>(e.y); }      // quad_perm [2,3,0,1]
+                if (SUMW >= 8)  { e.x += ab_dpp<0x104>(e.x); e.y += ab_dpp<0x104>(e.y); }     // row_shl:4
+                if (SUMW >= 16) { e.x += ab_dpp<0x108>(e.x); e.y += ab_dpp<0x108>(e.y); }     // row_shl:8
+                const unsigned off = (unsigned)__builtin_amdgcn_sbfe((int)~obits, k2, 1);
+                buf_st<true>(make_rsrc(b_out + (int64_t)(A * k2) * d.out_sj), l_out | off, 0, e);
             }
         }
     }

@@ -66,6 +66,12 @@ def grid_support(G, oN, tile=16):
     return np.concatenate([ranges.reshape(-1), bits.reshape(-1).view(np.int16)])
 
 
+def support_table_ok(oN):
+    """the k-space support table (16 words of up to 32 bits per tile: one bit per row of a 256- or 512-point axis) exists for
+    these grids only; others run without one (every grid row is written and read)"""
+    return all(int(n) in (256, 512) for n in oN)
+
+
 def split_support(table, oN, tile=16):
     """(z ranges (n1*nt, 2), y ranges (nt, 2), segment bits (n1*nt, 16) uint32) views of a support table"""
     n0, n1, n2 = (int(n) for n in oN)

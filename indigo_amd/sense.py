@@ -236,7 +236,7 @@ class SenseProblem(object):
         layout, chunks = fused.choose_layout(Cn, chunk, layout)
         Gm = self.fused_interp(1 if layout == 2 else layout)      # layout 2 = layout 1 with the coils interleaved below
         table = None
-        if (support is None or support) and layout >= 1 and self.oN[0] % 16 == 0:
+        if (support is None or support) and layout >= 1 and self.oN[0] % 16 == 0 and (support or fused.support_table_ok(self.oN)):
             # restrict the transform's z pass and the adjoint gridding to the k-space support of G'
             table = self.grid_support(Gm)
         self.last_support_table = table

@@ -261,7 +261,7 @@ class FuseZpadFFT(Transform):
             return node
         C = F.left.shape[0]
         grid = F.right._ft_shape
-        if L.left.shape[0] != C or len(grid) != 3 or not b.supports_padded_fft(grid):
+        if L.left.shape[0] != C or len(grid) != 3 or not b.supports_padded_fft(grid, C):
             return node
         if isinstance(X, Adjoint) and isinstance(X.child, SpMatrix):
             St = X.child._matrix
@@ -279,7 +279,7 @@ class FuseZpadFFT(Transform):
         Gm = L.right._matrix.astype(np.complex64).tocsr()
         if layout >= 1:
             Gm = fused.permute_grid_columns(Gm, grid)
-        table = fused.grid_support(Gm, grid) if (layout >= 1 and grid[0] % 16 == 0 and grid[2] % 16 == 0 and grid[2] <= 512) else None
+        table = fused.grid_support(Gm, grid) if (layout >= 1 and fused.support_table_ok(grid)) else None
         A = fused.assemble(b, Gm, grid, box, lambda c0, c1: w[..., c0:c1], C, layout, chunks, table=table, box_lo=lo,
                            name=node._name)
         A._fused_layout = layout

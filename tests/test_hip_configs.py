@@ -372,3 +372,77 @@ def test_config5_as_benchmarked_on_one_gpu(hip, oracle_backend):
     e20 = CoilOperatorF64(p, 20).normal(x).reshape(-1, 1)
     assert rel_err(AHA_2of32, e3 + e20) < RTOL, "four-chunk VStack: the chunks' images accumulate"
     p.drop_cache()
+
+
+# ---------------------------------------------------------------------------------------
+# the reference driver's own oversampled grids (examples/pics.py:87-90: 320 ... 640, not powers of two): zero-pad-aware
+# passes on the A x B two-stage kernel (k_fft_ab_desc), coil-interleaved layout
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("grid,box,C", [((320, 320, 320), (256, 256, 256), 8), ((480, 384, 640), (360, 300, 500), 2),
+                                        ((400, 432, 512), (300, 310, 256), 4)])
+def test_padded_transforms_on_non_power_of_two_grids_vs_numpy(hip, grid, box, C):
+    """fft_padded / ifft_cropped / ifft_cropped_sum (layout 2) on grids whose axes are 320 ... 640 points long (and mixed
+    with 512): one coil of the forward grid against numpy, the cropped inverse and the coil combination against their
+    closed forms and numpy"""
+    lo = tuple(m // 2 + int(np.ceil(-n / 2)) for m, n in zip(grid, box))
+    P, N = int(np.prod(grid)), int(np.prod(box))
+    assert hip.supports_padded_fft(grid, C)
+    hip._scratch = None
+    x = rand64c(N, 1, seed=1)
+    w = rand64c(N, C, seed=2)
+    w_d = hip.copy_array(np.ascontiguousarray(w).reshape(-1))
+    sl = tuple(slice(l, l + b) for l, b in zip(lo, box))
+    ws = hip.zero_array((hip._fft_padded_workspace(grid, lo, box, C, 2) // 8,), C64)
+    y_d = hip.copy_array(np.full((P, C), np.nan, dtype=C64, order='F'))
+    hip.fft_padded(y_d, hip.copy_array(x), w_d, grid, lo, box, ws, 2)
+    y = y_d.to_host().reshape(-1, order='F').reshape((C, grid[0], grid[2], grid[1]), order='F')        # (c, x, z, y)
+    for c in (0, C - 1):
+        full = np.zeros(grid, dtype=C64, order='F')
+        full[sl] = (w[:, c] * x[:, 0]).reshape(box, order='F')
+        ref = np.fft.fftn(full)
+        assert rel_err(y[c].transpose(0, 2, 1), ref) < RTOL, c
+        del full, ref
+    del y
+    # cropped inverse of the grid just made: conj(w_c) * crop(IFFT(FFT(pad(w_c x)))) = P |w_c|^2 x
+    xc_d = hip.copy_array(np.full((N, C), np.nan, dtype=C64, order='F'))
+    hip.ifft_cropped(xc_d, y_d, w_d, grid, lo, box, ws, 2)
+    xc = xc_d.to_host().reshape(-1, order='F').reshape(N, C)
+    assert rel_err(xc, P * np.abs(w) ** 2 * x) < RTOL
+    # ... and with the coil combination inside the last pass
+    xs_d = hip.copy_array(np.full((N, 1), np.nan, dtype=C64, order='F'))
+    hip.ifft_cropped_sum(xs_d, y_d, w_d, grid, lo, box, ws)
+    assert rel_err(xs_d.to_host(), P * (np.abs(w) ** 2).sum(axis=1, keepdims=True) * x) < RTOL
+    # an arbitrary grid (not a transform of anything zero-padded): coil 0 against numpy's inverse
+    g = rand64c(P, C, seed=3)
+    g_d = hip.copy_array(np.ascontiguousarray(g).reshape(-1)).reshape((P, C))
+    hip.ifft_cropped(xc_d, g_d, w_d, grid, lo, box, ws, 2)
+    vol = g[:, 0].reshape((grid[0], grid[2], grid[1]), order='F').transpose(0, 2, 1)                       # memory (x, z, y) -> (x, y, z)
+    ref = (np.fft.ifftn(vol) * P)[sl].reshape(-1, order='F') * np.conj(w[:, 0])
+    got = xc_d.to_host().reshape(-1, order='F').reshape(N, C)[:, 0]
+    assert rel_err(got, ref) < RTOL
+    del y_d, xc_d, xs_d, g_d, ws
+    hip._scratch = None
+
+
+def test_sense_on_the_reference_drivers_grid_vs_oracle(hip, oracle_backend):
+    """image 256^3 on a 320^3 grid (oversampling 1.25, the reference driver's choice of grid, examples/pics.py:87-90): the fused
+    leaf on the A x B passes, 4 coils, forward / adjoint / normal operator against the numpy oracle"""
+    p = SenseProblem.synthetic((256, 256, 256), 4, nspokes=400, nreadout=320, width=2, ntable=128, oversamp=1.25, seed=6)
+    assert p.oN == (320, 320, 320)
+    hip._scratch = None
+    oracle_backend._scratch = None
+    A = p.build_zpadfft(hip)
+    from indigo_amd import operators as op
+    assert A.has(op.ZpadFFT) and A.right._layout == 2 and A.right._support_h is None
+    x = rand64c(A.shape[1], 1, seed=1)
+    k = rand64c(A.shape[0], 1, seed=2)
+    A_o = p.build_zpadfft(oracle_backend, layout=0, support=False)
+    assert rel_err(A * x, A_o * x) < RTOL
+    assert rel_err(A.H * k, A_o.H * k) < RTOL
+    y_d = hip.zero_array((A.shape[1], 1), C64)
+    normal_operator(A, lamda=0.2).eval(y_d, hip.copy_array(x))
+    exp = A_o.H * (A_o * x) + np.float32(0.2) * x
+    assert rel_err(y_d.to_host(), exp) < RTOL
+    hip._scratch = None
+    oracle_backend._scratch = None
+    p.drop_cache()

@@ -1,7 +1,7 @@
 """The reconstruction driver (indigo_amd/pics.py; reference examples/pics.py) end to end on the MI355X backend: a synthetic
 radial scan, the reference's recipe at -O3 plus FuseZpadFFT (the benchmarked leaf: grid 256^3, two interleaved coils), CG --
 against the same driver on the numpy oracle backend, against the unfused -O3 leaves, and against the phantom.  A second scan
-at osf 1.25 (grid 160 = 10 x 16: the register-resident A x B transform passes and the plain -O3 leaves)."""
+at osf 1.25 (grid 160 = 10 x 16: the fused leaf on the zero-pad-aware A x B passes)."""
 import os
 
 import numpy as np
@@ -53,15 +53,26 @@ def test_pics_on_the_gpu_matches_the_oracle_backend(tmp_path, hip, oracle_backen
     assert np.linalg.norm(scale * x - t) < 0.1 * np.linalg.norm(t)
 
 
-def test_pics_on_a_non_power_of_two_grid(tmp_path, hip, oracle_backend):
-    N, C = (128, 128, 128), 3
+def test_pics_on_a_non_power_of_two_grid(tmp_path, hip, oracle_backend, caplog):
+    """the reference driver's own kind of grid (oversampling 1.25: 160 = 10 x 16 points): FuseZpadFFT takes the fused leaf on
+    the A x B zero-pad-aware passes (4 coils interleaved); same image as the unfused -O3 leaves, the unoptimised tree and the
+    oracle backend"""
+    import logging
+    N, C = (128, 128, 128), 4
     path, img = _scan(tmp_path, hip, N, C, nro=160, nsp=300, osf=1.25, width=3)
-    assert "AxB" in hip.fft_describe((160, 160, 160, C))
+    assert "AxB" in hip.fft_describe((160, 160, 160, C)) and hip.supports_padded_fft((160, 160, 160), C)
     args = ["-i", "4", "--osf", "1.25", "--width", "3", "--lamda", "1e-3", "--debug", "40", path]
-    out = pics.main(["-O", "3"] + args, backend=hip)       # FuseZpadFFT leaves this tree alone (grid 160 has no fused transform)
+    with caplog.at_level(logging.INFO, logger="indigo_amd.pics"):
+        out = pics.main(["-O", "3"] + args, backend=hip)
+    tree = [r.getMessage() for r in caplog.records if r.getMessage().startswith("tree:")][-1]
+    assert "ZpadFFT" in tree and "UnscaledFFT" not in tree, tree
+    plain = pics.main(["-O", "3", "--no-fuse"] + args, backend=hip)
+    assert _rel(out, plain) < 2e-4
     oracle_backend._scratch = None
-    ref = pics.main(["-O", "3"] + args, backend=oracle_backend)
+    ref = pics.main(["-O", "3", "--no-fuse"] + args, backend=oracle_backend)
     oracle_backend._scratch = None
     assert _rel(out, ref) < 1e-3
     base = pics.main(["-O", "0"] + args, backend=hip)
     assert _rel(out, base) < 2e-4
+    # three coils split into a pair and a single one: the single coil has no interleaved layout, the tree keeps its -O3 leaves
+    assert not hip.supports_padded_fft((160, 160, 160), 3)
