@@ -58,7 +58,7 @@ PMC_NOTE = " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_
 # depends on the grid layout, the axis length and whether the image box is the middle half of the axis.
 def kernel_symbols(layout, ncoils, half_box=True, n=512, support_tile=16):
     r1 = 32 if n == 512 else 16
-    f = "k_fft_2stage<%d, 16, 16, %%s, true>" % r1            # last argument: streaming (non-temporal) hint on
+    f = "k_fft_2stage<%d, 16, 16, %%s>" % r1
     m = {
         "fft_2stage_axis0": f % "16, true, 0, false, 0",
         "fft_2stage_axis1": f % "16, false, 0, false, 0",

@@ -61,6 +61,13 @@ int  ig_sync(ig_ctx* ctx);                          /* synchronous: waits for th
 void* ig_stream(ig_ctx* ctx);                       /* the hipStream_t, for interop          */
 int  ig_device_name(ig_ctx* ctx, char* buf, size_t len);
 int  ig_mem_info(ig_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
+/* Plan options, read when a plan is made.  "fft.kernels": 0 = every kernel (default), 1 = no register-resident A x B passes
+ * (160 ... 640-point axes take the multi-stage LDS kernel), 2 = only the one-stage-per-launch generic kernel -- the
+ * fallback kernels stay testable on sizes the fast ones would take.  Unknown names are an error.                          */
+int  ig_set_option(ig_ctx* ctx, const char* name, int64_t value);
+/* Device memory the library holds on its own for this context (the SpMM kernels' repacked-panel buffer, deferred-row lists,
+ * reduction scratch, solver scalars): what Backend.mem_usage() adds to the arrays the caller allocated.                    */
+int  ig_library_bytes(ig_ctx* ctx, size_t* bytes);
 
 /* ------------------------------------------------------------------------
  * Device memory.  Replaces CudaBackend.dndarray._malloc/_free/_zero/_copy*

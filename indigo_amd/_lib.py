@@ -28,6 +28,8 @@ PROTOTYPES = {
     "ig_stream":          (c_void_p, [c_void_p]),
     "ig_device_name":     (c_int, [c_void_p, c_char_p, c_size_t]),
     "ig_mem_info":        (c_int, [c_void_p, POINTER(c_size_t), POINTER(c_size_t)]),
+    "ig_set_option":      (c_int, [c_void_p, c_char_p, c_int64]),
+    "ig_library_bytes":   (c_int, [c_void_p, POINTER(c_size_t)]),
     "ig_malloc":          (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
     "ig_free":            (c_int, [c_void_p, c_void_p]),
     "ig_memset0":         (c_int, [c_void_p, c_void_p, c_size_t]),

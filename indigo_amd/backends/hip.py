@@ -87,6 +87,14 @@ class HipBackend(Backend):
         # 'transpose': adjoint of a non-exwrite matrix gathers through a cached CSR of A^T (deterministic)
         # 'atomic'   : adjoint scatters with float atomics straight from A's CSR (no extra memory)
         self.adjoint_policy = 'transpose'
+        # Format choices of this backend's matrices and fused trees (defaults = the measured best; tests switch routes off to
+        # reach the fallback kernels):
+        #   bricks        coil counts whose interleaved adjoint gridding is the brick-binned scatter (others: gather over G'^T)
+        #   support_tile  kx points per entry of the fine k-space support table of coil-interleaved trees (16: one table only)
+        #   brick_shape   (grid lines, slabs, heavy-brick piece, entries per run) of the binned format
+        #   xrows         wide panels (16..64 columns): repack only the panel rows the matrix touches (forward)
+        #   wide_bricks   64-column column-major panels: brick scatter through LDS (adjoint)
+        self.tuning = dict(bricks=(4, 8), support_tile=8, brick_shape=(2, 2, 4096, 4096), xrows=True, wide_bricks=True)
 
     def __del__(self):
         try:
@@ -115,6 +123,21 @@ class HipBackend(Backend):
         buf = ctypes.create_string_buffer(256)
         self._check(self._L.ig_device_name(self._ctx, buf, 256), "ig_device_name")
         return buf.value.decode()
+
+    def set_option(self, name, value):
+        """plan options of the library (ig_set_option): 'fft.kernels' = 0 all kernels, 1 no A x B passes, 2 generic stages only;
+        takes effect for plans made afterwards (cached plans are dropped)"""
+        self._check(self._L.ig_set_option(self._ctx, name.encode(), int(value)), "ig_set_option(%s)" % name)
+        for entry in self._plans.values():
+            self._L.ig_fft_destroy(entry[0])
+        self._plans = dict()
+
+    def mem_usage(self):
+        """bytes of device memory in use through this backend: the arrays it handed out (Backend.mem_usage, backend.py:249)
+        plus what the library holds on its own (the SpMM kernels' repacked-panel buffer, work lists, reduction scratch)"""
+        own = ctypes.c_size_t()
+        self._check(self._L.ig_library_bytes(self._ctx, ctypes.byref(own)), "ig_library_bytes")
+        return super().mem_usage() + own.value
 
     def mem_info(self):
         free, total = ctypes.c_size_t(), ctypes.c_size_t()
@@ -677,11 +700,6 @@ class HipBackend(Backend):
             `run` entries, or a piece of at most `chunk` entries of a heavy brick (more than `chunk` entries: shared)."""
             b = self._backend
             A = self._host_csr
-            import os
-            if os.environ.get("INDIGO_HIP_BRICK_SHAPE"):          # "bm,bs,chunk[,run]": tuning aid
-                v = [int(t) for t in os.environ["INDIGO_HIP_BRICK_SHAPE"].split(",")]
-                bm, bs, chunk = v[:3]
-                run = v[3] if len(v) > 3 else run
             assert A is not None and A.shape[1] == n0 * nm * ns and ncols in (4, 8) and bm * bs <= 32
             unit = 64 // ncols
             chunk = max(unit, chunk // unit * unit)
@@ -794,7 +812,7 @@ class HipBackend(Backend):
                                            ctypes.c_void_p(y._arr), y._leading_dim), "ig_ccsrmm_il")
                 return
             if perm is None and 16 <= x.shape[1] <= 64 and self._col_frac <= 0.6 \
-                    and self.values.size >= self.shape[1] and os.environ.get("INDIGO_HIP_SPMM_XROWS", "1") != "0":
+                    and self.values.size >= self.shape[1] and self._backend.tuning['xrows']:
                 # a wide panel of which the matrix touches a fraction of the rows (a gridding matrix: 30 % of its grid):
                 # the panel is repacked row-major anyway -- repack only the touched rows (ig_ccsrmm_xrows)
                 self._check_panels(y, x, self.values)
@@ -852,7 +870,7 @@ class HipBackend(Backend):
                 return
             if (x.shape[1] == 64 and beta == 0 and perm is None and not getattr(self, '_grid_il', False) and self.shape[1] % 16 == 0
                     and self.shape[1] > 0 and self.shape[0] * 512 < 2 ** 31 and self.values.size >= self.shape[1] // 4
-                    and os.environ.get("INDIGO_HIP_SPMM_WIDE_BRICKS", "1") != "0"):
+                    and b.tuning['wide_bricks']):
                 # 64 columns at the reference boundary (BASELINE config 3): scatter through LDS brick images
                 wb = self._wide_bricks()
                 if wb is not None:

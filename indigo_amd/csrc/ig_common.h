@@ -30,6 +30,9 @@ struct ig_ctx {
     void*        d_xpack     = nullptr;   // SpMM repacked-panel scratch (grown on demand)
     size_t       xpack_bytes = 0;
     int32_t*     d_worklist  = nullptr;   // SpMM deferred-row lists + counters (allocated on first use)
+    // plan options (ig_set_option): which transform kernels a NEW plan may use.  0 = all; 1 = no register-resident A x B passes
+    // (their lengths fall back to the multi-stage LDS kernel); 2 = only the one-stage-per-launch generic kernel
+    int          opt_fft_kernels = 0;
     bool         bricks_attr = false;     // the brick-binned gridding kernel's dynamic-LDS opt-in was applied on this device
     bool         fft3d_attr = false;      // the two-launch 256^3 transform's dynamic-LDS opt-in was applied on this device
     bool         fft_w32_attr = false;    // the 32-column FFT kernels' dynamic-LDS opt-in was applied on this device

@@ -121,6 +121,25 @@ int ig_device_name(ig_ctx* ctx, char* buf, size_t len) {
     return IG_OK;
 }
 
+int ig_set_option(ig_ctx* ctx, const char* name, int64_t value) {
+    IG_REQUIRE(ctx, ctx && name, "ig_set_option: bad arguments");
+    if (std::string(name) == "fft.kernels") {
+        IG_REQUIRE(ctx, value >= 0 && value <= 2, "ig_set_option: fft.kernels is 0 (all), 1 (no A x B passes) or 2 (generic stages only)");
+        ctx->opt_fft_kernels = (int)value;
+        return IG_OK;
+    }
+    return ig_fail(ctx, IG_ERR_ARG, "ig_set_option: unknown option '%s'", name);
+}
+
+int ig_library_bytes(ig_ctx* ctx, size_t* bytes) {
+    IG_REQUIRE(ctx, ctx && bytes, "ig_library_bytes: bad arguments");
+    // device memory the library itself holds for this context: the repacked-panel buffer of the SpMM kernels (grown on
+    // demand), the deferred-row lists, the reduction scratch and the solver scalars
+    *bytes = ctx->xpack_bytes + (ctx->d_worklist ? sizeof(int32_t) * 2 * (size_t)(1u << 20) + 2 * 32 * sizeof(uint32_t) : 0) +
+             (ctx->d_partials ? (size_t)(IG_MAX_RED_BLOCKS + 1) * 2 * sizeof(double) : 0) + (ctx->d_scalars ? sizeof(double) * IG_NUM_SCALARS : 0);
+    return IG_OK;
+}
+
 int ig_mem_info(ig_ctx* ctx, size_t* free_bytes, size_t* total_bytes) {
     IG_REQUIRE(ctx, ctx && free_bytes && total_bytes, "ig_mem_info: bad arguments");
     if (int rc = ig_set_device(ctx)) return rc;

@@ -371,14 +371,12 @@ template <int N> struct PFFTHalfIn {
 //   1: input half, output box at run time      3: input half, output full
 //   2: output half, input box at run time      4: output half, input full
 // Half inputs prune the first butterfly layer; compile-time boxes need no predicates or bounds registers.
-// NTH: non-temporal (streaming) hint on the pass's global loads and stores.  Every byte of a pass is touched once, so
-// the hint is on everywhere -- except in the volume-at-a-time schedule of the plain transform (ig_fft_exec), whose
-// passes hand a 134 MB volume to each other through the 256 MB Infinity Cache.
-template <int R1, int R2, int T, int W, bool AXIS0, int WMODE, bool BOXED, int HALF, bool NTH = true>
+// Loads and stores carry the non-temporal (streaming) hint: every byte of a pass is touched exactly once.
+template <int R1, int R2, int T, int W, bool AXIS0, int WMODE, bool BOXED, int HALF>
 __global__ void __launch_bounds__(W * T, (!AXIS0 && R1 == 32 && (W == 32 || HALF == 1 || HALF == 3 || (IG_FFT_CAP4_HALFOUT && WMODE == 0 && (HALF == 2 || HALF == 4)))) ? 4 : IG_FFT_MINWAVES)
 k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
     constexpr int n = R1 * R2, B1 = R2 / T, B2 = R1 / T, NT = W * T;
-    constexpr bool NT_LD = IG_FFT_NT_LOAD && NTH, NT_ST = IG_FFT_NT_STORE && NTH;
+    constexpr bool NT_LD = IG_FFT_NT_LOAD != 0, NT_ST = IG_FFT_NT_STORE != 0;
     constexpr bool HALF_IN = HALF == 1 || HALF == 3, HALF_OUT = HALF == 2 || HALF == 4;
     constexpr bool GROUP_SKIP = IG_FFT_GROUP_SKIP != 0;
     constexpr int SUMW = WMODE >= 3 ? (1 << (WMODE - 3)) : 0;       // WMODE 3 + log2(coils): 3 -> 1 (no sum), 4 -> 2, 5 -> 4, 6 -> 8, 7 -> 16
@@ -394,14 +392,10 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
     const int t = AXIS0 ? (tid % T) : (tid / W);
     const int w = AXIS0 ? (tid / T) : (tid % W);
     // ---- the workgroup's tile: W consecutive k0 of one (k1, k2) row; everything below is wave-uniform
-    // Workgroups are dealt round-robin to the 8 XCDs.  Optionally give each XCD a contiguous range of tiles instead
-    // (INDIGO_HIP_FFT_XCD=1) -- measured 10 % SLOWER on the z passes: with the default dealing all XCDs stream
-    // through the same DRAM pages together, and no tile shares a cache line with another anyway.
-    unsigned tile = blockIdx.x;
-    if (d.xcd_remap) {
-        const unsigned nb = gridDim.x, q = nb >> 3, rem = nb & 7, xcd = tile & 7, idx = tile >> 3;
-        tile = (xcd < rem) ? xcd * (q + 1) + idx : rem * (q + 1) + (xcd - rem) * q + idx;
-    }
+    // (Workgroups are dealt round-robin to the 8 XCDs.  Giving each XCD a contiguous range of tiles instead was measured
+    // 10 % SLOWER on the z passes: with the default dealing all XCDs stream through the same DRAM pages together, and no
+    // tile shares a cache line with another anyway.)
+    const unsigned tile = blockIdx.x;
     const unsigned tr = tile % d.tpr, rest = tile / d.tpr;
     const unsigned k1 = rest % d.ext1, k2 = rest / d.ext1;
     const int64_t k0u = (int64_t)tr * ((!AXIS0 && d.cw) ? W / d.cw : W);
@@ -1018,12 +1012,10 @@ int plan_axis(ig_ctx* ctx, ig_fft* p, int a) {
     ax.outer = p->total / (ax.n * ax.inner);
     if (ax.n == 1) { ax.kind = 2; return IG_OK; }
 
-    const bool force_generic = getenv("INDIGO_HIP_FFT_GENERIC") && getenv("INDIGO_HIP_FFT_GENERIC")[0] == '1';
+    const bool force_generic = ctx->opt_fft_kernels == 2;
     Radices rad{};
     int ns = 0;
-    const char* e2 = getenv("INDIGO_HIP_FFT_2STAGE");
-    const bool prefer_ab = getenv("INDIGO_HIP_FFT_AB") && atoi(getenv("INDIGO_HIP_FFT_AB")) == 2;      // A/B runs: 256 / 512 through k_fft_ab
-    const bool two_stage = !force_generic && !prefer_ab && !(e2 && e2[0] == '0') && (ax.n == 512 || ax.n == 256) &&
+    const bool two_stage = !force_generic && (ax.n == 512 || ax.n == 256) &&
                            32 * ax.inner * 8 < 0x7fffffffLL;              // 2 GB descriptor window per 16 elements of a column
     if (two_stage) {
         ax.kind = 3; ax.W = 16; ax.T = 16; ax.nstages = 2;
@@ -1032,7 +1024,7 @@ int plan_axis(ig_ctx* ctx, ig_fft* p, int a) {
         // 36 KB of dynamic LDS: below the 64 KB every kernel may use without an attribute
     }
     // lengths with a register-resident A x B split (the oversampled grids of the reference's example and their like)
-    const int use_ab = getenv("INDIGO_HIP_FFT_AB") ? atoi(getenv("INDIGO_HIP_FFT_AB")) : 1;     // (read per plan: the tests flip it)
+    const bool use_ab = ctx->opt_fft_kernels == 0;
     bool ab = false;
     if (!two_stage && !force_generic && use_ab) {
         int A = 0, B = 0;
@@ -1097,8 +1089,6 @@ int launch_2stage(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d_in, bool ax
     const int64_t blocks = tpr * (d.ncols / d.ext0);           // ncols = ext0 * ext1 * ext2
     IG_REQUIRE(ctx, blocks <= 0x7fffffffLL && d.ext1 <= 0x7fffffffLL, "ig_fft: too many tiles");
     d.tpr = (unsigned)tpr;
-    static const int xcd_remap = getenv("INDIGO_HIP_FFT_XCD") ? atoi(getenv("INDIGO_HIP_FFT_XCD")) : 0;
-    d.xcd_remap = xcd_remap;
     {   // every in-tile byte offset must stay inside the 2 GB descriptor window
         const int64_t lim = 0x7fffffffLL / 8;
         // (strided passes re-base per 16 elements: only 31 element steps plus the tile's lanes must fit)
@@ -1109,16 +1099,11 @@ int launch_2stage(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d_in, bool ax
                    "ig_fft: axis stride too large for the two-stage kernel");
     }
     const dim3 grid((unsigned)blocks), block((unsigned)(ax.W * ax.T));
-    // INDIGO_HIP_FFT_LDSPAD (bytes, experiment): extra dynamic LDS per workgroup of the 16-column kernels, to LOWER the number of
-    // workgroups per CU (38.9 KB -> 4 per CU; +14 KB -> 3): how much of a pass's speed is occupancy
-    static const size_t lds_pad = getenv("INDIGO_HIP_FFT_LDSPAD") ? (size_t)atoi(getenv("INDIGO_HIP_FFT_LDSPAD")) : 0;
 #define IG_2S(R1_, AX0_, WM_, BX_, HF_)                                                             \
-    hipLaunchKernelGGL((k_fft_2stage<R1_, 16, 16, 16, AX0_, WM_, BX_, HF_>), grid, block, ax.lds_bytes + lds_pad, ctx->stream, d, ax.d_tw)
+    hipLaunchKernelGGL((k_fft_2stage<R1_, 16, 16, 16, AX0_, WM_, BX_, HF_>), grid, block, ax.lds_bytes, ctx->stream, d, ax.d_tw)
 #define IG_2S_W(R1_, AX0_)                                                                           \
     do {                                                                                             \
-        if (!boxed && wmode == 0) {                                                                  \
-            if (d.cached) hipLaunchKernelGGL((k_fft_2stage<R1_, 16, 16, 16, AX0_, 0, false, 0, false>), grid, block, ax.lds_bytes, ctx->stream, d, ax.d_tw); \
-            else IG_2S(R1_, AX0_, 0, false, 0); }                                                    \
+        if (!boxed && wmode == 0) IG_2S(R1_, AX0_, 0, false, 0);                                     \
         else if (wmode == 0) {                                                                       \
             if (half == 1) IG_2S(R1_, AX0_, 0, true, 1); else if (half == 2) IG_2S(R1_, AX0_, 0, true, 2);   \
             else if (half == 3) IG_2S(R1_, AX0_, 0, true, 3); else if (half == 4) IG_2S(R1_, AX0_, 0, true, 4); \
@@ -1128,10 +1113,9 @@ int launch_2stage(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d_in, bool ax
     } while (0)
     const bool boxed = d.tile_range || !(d.in_lo <= 0 && d.in_hi >= (int)ax.n && d.out_lo <= 0 && d.out_hi >= (int)ax.n);
     // the image box of a 2x-oversampled grid sits at [n/4, 3n/4): compile-time-pruned variants
-    static const int use_half = getenv("INDIGO_HIP_FFT_HALF") ? atoi(getenv("INDIGO_HIP_FFT_HALF")) : 1;
     const int qn = (int)ax.n / 4;
     int half = 0;
-    if (use_half && boxed) {
+    if (boxed) {
         const bool in_full = d.in_lo <= 0 && d.in_hi >= (int)ax.n, out_full = d.out_lo <= 0 && d.out_hi >= (int)ax.n;
         if (d.in_lo == qn && d.in_hi == 3 * qn && !(d.tile_range && d.tile_range_mode == 2))
             half = (out_full && !d.tile_range && !d.tile_bits) ? 3 : 1;
@@ -1141,7 +1125,6 @@ int launch_2stage(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d_in, bool ax
         if (wmode >= 2 && half != 4) half = 0;
         if (((half == 1 || half == 3) && d.inverse) || ((half == 2 || half == 4) && !d.inverse)) half = 0;   // direction is baked in
     }
-    static const int use_w32 = getenv("INDIGO_HIP_FFT_W32") ? atoi(getenv("INDIGO_HIP_FFT_W32")) : 1;
     // 32-column tiles (256-byte segments) pay where a side of the pass runs at a huge stride (y passes of the
     // interleaved layout, 16 MB per element: -11...-15 %) and for the half-input variants, which fit 128 VGPRs;
     // the half-output variants spill at that cap and lose on small-stride passes (cropped z pass: +16 %).
@@ -1149,10 +1132,10 @@ int launch_2stage(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d_in, bool ax
     // boxed passes WITHOUT a compile-time half box (e.g. the 320-point box of a 512-point axis, oversampling 1.6) also take
     // 32-column tiles when one side runs at a huge stride: cropped y pass of config 5 0.85 -> 0.74 ms, padded y pass unchanged
     // ... and so do plain (unboxed) passes at a huge stride, through the same run-time-box variant: the z pass of a plain 512^3
-    // transform steps 2 MB per element (3.82 -> 3.08 ms for 512^3 x 8; INDIGO_HIP_FFT_W32=5 keeps them on 16 columns)
-    const bool w32_generic = use_w32 && use_w32 != 3 && (boxed || use_w32 != 5) && half == 0 && big_stride;
-    if (use_w32 && ax.n == 512 && !axis0 && wmode == 0 && !d.cw && d.ext0 % 32 == 0 &&
-        (((half == 1 || half == 3) && (big_stride || use_w32 != 3)) || ((half == 2 || half == 4) && (big_stride || use_w32 == 2)) || w32_generic) &&
+    // transform steps 2 MB per element (3.82 -> 3.08 ms for 512^3 x 8)
+    const bool w32_generic = half == 0 && big_stride;
+    if (ax.n == 512 && !axis0 && wmode == 0 && !d.cw && d.ext0 % 32 == 0 &&
+        (half == 1 || half == 3 || ((half == 2 || half == 4) && big_stride) || w32_generic) &&
         (!d.tile_range || d.tile_shift >= 1)) {
         // 32-column tiles: 256-byte segments per row, 512 threads, 69.6 KB of LDS (2 workgroups per CU)
         PassDesc d2 = d;
@@ -1269,11 +1252,8 @@ int ig_fft_plan(ig_ctx* ctx, int rank, const int64_t* dims, int64_t batch, ig_ff
     }
     p->workspace_bytes = need_ws ? (size_t)p->total * 8 : 0;
     if (workspace_bytes) *workspace_bytes = p->workspace_bytes;
-    {
-        static const int use2 = getenv("INDIGO_HIP_FFT_2LAUNCH") ? atoi(getenv("INDIGO_HIP_FFT_2LAUNCH")) : 1;
-        p->two_launch = use2 > 0 && rank == 3 && dims[0] == 256 && dims[1] == 256 && dims[2] == 256 && p->axis[0].kind == 3;
-        if (p->two_launch) p->inplace_workspace_bytes = (size_t)p->total * 8;
-    }
+    p->two_launch = rank == 3 && dims[0] == 256 && dims[1] == 256 && dims[2] == 256 && p->axis[0].kind == 3;
+    if (p->two_launch) p->inplace_workspace_bytes = (size_t)p->total * 8;
 
     char buf[256];
     p->desc.clear();
@@ -1327,29 +1307,12 @@ int ig_fft_exec(ig_fft* p, const void* xv, void* yv, int direction, void* worksp
         float2* mid = y;
         if (xv == yv) mid = (float2*)workspace;
         const double half_bytes = 2.0 * (double)p->total * 8.0;        // benchmark.py:55: 4 * nbytes per transform
-        static const int dbg = getenv("INDIGO_HIP_FFT_2LAUNCH") ? atoi(getenv("INDIGO_HIP_FFT_2LAUNCH")) : 1;   // 2: launch A only, 3: launch B only (tools/fft2pass_check.py)
-        if (dbg == 3) mid = const_cast<float2*>(src);
-        if (dbg == 4) {         // volume by volume: launch B of a volume finds launch A's output in the Infinity Cache
-            for (int64_t vv = 0; vv < p->batch; ++vv) {
-                const int64_t o = vv << 24;
-                {
-                    ig_prof_scope prof(ctx, "fft3d_xy", half_bytes / (double)p->batch);
-                    hipLaunchKernelGGL(k_fft3d_a, dim3(256, 4, 1), dim3(512), lds_b, ctx->stream, src + o, mid + o, p->axis[0].d_tw, inverse);
-                }
-                {
-                    ig_prof_scope prof(ctx, "fft3d_yz", half_bytes / (double)p->batch);
-                    hipLaunchKernelGGL(k_fft3d_b, dim3(16, 64, 1), dim3(512), lds_b, ctx->stream, (const float2*)(mid + o), y + o, p->axis[0].d_tw, inverse);
-                }
-            }
-            IG_LAUNCH_CHECK(ctx, "k_fft3d (volume by volume)");
-            return IG_OK;
-        }
-        if (dbg != 3) {
+        {
             ig_prof_scope prof(ctx, "fft3d_xy", half_bytes);
             hipLaunchKernelGGL(k_fft3d_a, dim3(256, 4, (unsigned)p->batch), dim3(512), lds_b, ctx->stream, src, mid, p->axis[0].d_tw, inverse);
             IG_LAUNCH_CHECK(ctx, "k_fft3d_a");
         }
-        if (dbg != 2) {
+        {
             ig_prof_scope prof(ctx, "fft3d_yz", half_bytes);
             hipLaunchKernelGGL(k_fft3d_b, dim3(16, 64, (unsigned)p->batch), dim3(512), lds_b, ctx->stream, (const float2*)mid, y, p->axis[0].d_tw, inverse);
             IG_LAUNCH_CHECK(ctx, "k_fft3d_b");
@@ -1363,39 +1326,9 @@ int ig_fft_exec(ig_fft* p, const void* xv, void* yv, int direction, void* worksp
     // pass gets an equal share of it
     const double pass_bytes = live_axes ? 4.0 * (double)p->total * 8.0 / live_axes : 0.0;
 
-    // Volume-at-a-time schedule: when every axis runs the two-stage kernel and one volume fits the Infinity Cache
-    // (256 MB) with room to spare, the three passes run volume by volume without the streaming hint, so passes 2
-    // and 3 find their input on-die and only the first read and the last write of a volume go to HBM.
-    // INDIGO_HIP_FFT_VOLWISE: 0 never (default), 1 when it fits, 2 the same but keeping the streaming hint (for A/B runs).
-    // Measured on 256^3 x 16: the 48 small launches total 2.20 ms of kernel time against 2.36 ms for the three big
-    // ones (the Infinity Cache does serve passes 2 and 3), but the gaps between 48 dependent launches eat the gain:
-    // 2.45 ms per transform against 2.37 ms.  Off by default.
-    static const int volwise = getenv("INDIGO_HIP_FFT_VOLWISE") ? atoi(getenv("INDIGO_HIP_FFT_VOLWISE")) : 0;
-    const int64_t vol_elems = p->total / p->batch;
-    bool all_2stage = p->rank >= 2;
-    for (int a = 0; a < p->rank; ++a) if (p->axis[a].kind != 3) all_2stage = false;
-    if (volwise && all_2stage && p->batch > 1 && vol_elems * 8 <= (int64_t)160 << 20 && vol_elems * 8 >= (int64_t)8 << 20) {
-        for (int64_t v = 0; v < p->batch; ++v) {
-            const float2* src = (const float2*)xv + v * vol_elems;
-            float2* dst = y + v * vol_elems;
-            for (int a = 0; a < p->rank; ++a) {
-                const AxisPlan& ax = p->axis[a];
-                ig_prof_scope prof(ctx, a == 0 ? "fft_2stage_axis0" : a == 1 ? "fft_2stage_axis1" : "fft_2stage_axis2", pass_bytes / (double)p->batch);
-                const int64_t outer_v = ax.outer / p->batch;            // the batch is the slowest part of every axis's outer index
-                PassDesc d{};
-                d.in = a == 0 ? src : dst; d.out = dst;
-                d.in_sj = d.out_sj = ax.inner;
-                d.ncols = ax.inner * outer_v;
-                if (ax.inner == 1) { d.ext0 = outer_v; d.ext1 = 1; d.in_s[0] = d.out_s[0] = ax.n; }
-                else { d.ext0 = ax.inner; d.ext1 = outer_v; d.in_s[0] = d.out_s[0] = 1; d.in_s[1] = d.out_s[1] = ax.inner * ax.n; }
-                d.in_lo = d.out_lo = 0; d.in_hi = d.out_hi = (int)ax.n; d.inverse = inverse;
-                d.cached = volwise == 1 ? 1 : 0;
-                if (int rc = launch_2stage(ctx, ax, d, ax.inner == 1, 0)) return rc;
-            }
-        }
-        return IG_OK;
-    }
-
+    // (Measured and rejected: a volume-at-a-time schedule whose passes hand a 134 MB volume to each other through the 256 MB
+    // Infinity Cache -- the kernels themselves ran 7 % faster on 256^3 x 16, but 48 small dependent launches lost more than
+    // that in the gaps between them: 2.45 against 2.37 ms.)
     for (int a = 0; a < p->rank; ++a) {
         const AxisPlan& ax = p->axis[a];
         if (ax.kind == 2) continue;

@@ -37,8 +37,6 @@ struct PassDesc {
     int cw;
     int64_t in_sa, out_sa, w_sa;
     int tile_shift;             // tile_range / tile_bits entries are shared by 2^tile_shift consecutive tiles
-    int xcd_remap;              // filled in by the launcher
-    int cached;                 // plain passes only: no non-temporal hint (the next pass re-reads the data from the Infinity Cache)
     int in_lo, in_hi, out_lo, out_hi;
     int inverse;
     // optional per-tile override of the box along the transform axis (strided passes, W | ext0):

@@ -1016,7 +1016,7 @@ k_grid_bricks(const BrickTask* __restrict__ tasks, int ntasks, const BrickRef* _
               const BrickEntry* __restrict__ entries, const uint32_t* __restrict__ round_rows,
               const float2* __restrict__ Xp /* packed rows: [t][NC] */,
               float2* __restrict__ Y, float2 alpha, const uint32_t* __restrict__ bits,
-              int n0, int nm, int bm_log2, int bs_log2, int nbx, int nbm, int dbg, int st_log2 /* log2(cells per segment) */) {
+              int n0, int nm, int bm_log2, int bs_log2, int nbx, int nbm, int st_log2 /* log2(cells per segment) */) {
     extern __shared__ float2 acc_all[];                  // per wave: [cells][NC]
     constexpr int TPR = 64 / NC;                         // entries per round (one wave instruction of the accumulation)
     constexpr int RS = 64 / TPR;                         // rounds per super-trip
@@ -1115,7 +1115,7 @@ k_grid_bricks(const BrickTask* __restrict__ tasks, int ntasks, const BrickRef* _
             // it cannot bound the number of stores between a load and its use), which undoes the prefetching; not
             // counting them only makes its counted waits for loads somewhat earlier than necessary.  An 8-byte store
             // reads its data registers at issue (no write-after-read hazard), and nothing here reads Y back.
-            if (!(dbg & 2)) {
+            {
                 if (shared) {
                     asm volatile("global_atomic_add_f32 %0, %1, off\n\tglobal_atomic_add_f32 %0, %2, off offset:4"
                                  :: "v"(dst + e), "v"(o.x), "v"(o.y) : "memory");
@@ -1155,7 +1155,7 @@ k_grid_bricks(const BrickTask* __restrict__ tasks, int ntasks, const BrickRef* _
             const float vi = __int_as_float(__builtin_amdgcn_ds_bpermute(from_e, (int)e_im));
             const float xr = __int_as_float(__builtin_amdgcn_ds_bpermute(from_x, __float_as_int(x_re)));
             const float xi = __int_as_float(__builtin_amdgcn_ds_bpermute(from_x, __float_as_int(x_im)));
-            if (cell != 0xffffffffu && !(dbg & 1)) {
+            if (cell != 0xffffffffu) {
                 float2* a = acc + (int)cell * NC + coil;
                 float2 v = *a;                                            // plain read-add-write: the entries of a round belong to
                 v.x += fmaf(vr, xr, vi * xi);                             // one sample (distinct cells), the image is this wave's,
@@ -1341,17 +1341,11 @@ inline Shape pick_shape(int64_t rows, int64_t N, int64_t nnz) {
     const int64_t mean = rows > 0 ? (nnz + rows - 1) / rows : 1;
     // a lane takes four nonzeros per trip, so 8 nonzero-lanes cover a 32-nonzero row in one trip: more lanes per row
     // only mean fewer rows per wave (the kernel is latency bound)
-    static const int nl_cap = getenv("INDIGO_HIP_SPMM_NLCAP") ? atoi(getenv("INDIGO_HIP_SPMM_NLCAP")) : 8;
+    constexpr int nl_cap = 8;
     int cap = 64 / s.CL;
     if (nl_cap > 0 && mean <= 4 * nl_cap && cap > nl_cap) cap = nl_cap;
     s.NL = pow2_ceil(mean > 0 ? mean : 1, cap);
     return s;
-}
-
-inline bool env_flag(const char* name, bool dflt) {
-    const char* e = getenv(name);
-    if (!e || !*e) return dflt;
-    return e[0] != '0';
 }
 
 constexpr uint32_t WL_CAP = 1u << 20;
@@ -1382,7 +1376,7 @@ int launch_gather(ig_ctx* ctx, int64_t rows, int64_t xrows, int64_t N, int64_t n
     // Packing costs one read + one write of the panel (16 B per element) and turns nnz*N scattered 8-byte gathers
     // (each pulling a 32..64-byte sector) into nnz contiguous N*8-byte ones: worth it once every panel row is
     // gathered at least about once (nnz >= xrows); always for small hot panels.
-    if (!x_il && ((N >= 2 && N <= 64 && nnz >= xrows) || (xperm && N <= 64)) && env_flag("INDIGO_HIP_SPMM_PACK", true)) {
+    if (!x_il && ((N >= 2 && N <= 64 && nnz >= xrows) || (xperm && N <= 64))) {
         const int np = s.CL;             // pow2 >= N, <= 64
         const size_t need = (size_t)xrows * np * 8;
         // The repack buffer is a per-context scratch that only grows (reported by ig_mem_info, not by the caller's own
@@ -1425,11 +1419,11 @@ int launch_gather(ig_ctx* ctx, int64_t rows, int64_t xrows, int64_t N, int64_t n
     const int64_t waves = (rows + rpw - 1) / rpw;
     const int64_t blocks = (waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     IG_REQUIRE(ctx, blocks <= 0x7fffffffLL, "csrmm: matrix too large for one launch (%lld blocks)", (long long)blocks);
-    const int xcd = env_flag("INDIGO_HIP_SPMM_XCD", true) ? 1 : 0;
+    const int xcd = 1;          // every XCD gets a contiguous range of row blocks (xcd_block)
     const bool b0 = (beta.x == 0.f && beta.y == 0.f);
 
     // row deferral thresholds (nonzeros): a wave-per-row pass only pays when the slot is narrower than a wave
-    const bool defer = env_flag("INDIGO_HIP_SPMM_DEFER", true);
+    const bool defer = true;
     const int nlw = 64 / s.CL;
     const int32_t thr_long = defer ? 256 * nlw : 0x7fffffff;
     const int32_t thr_mid = !defer ? 0x7fffffff : (nlw > s.NL ? 16 * s.NL : thr_long);
@@ -1450,11 +1444,10 @@ int launch_gather(ig_ctx* ctx, int64_t rows, int64_t xrows, int64_t N, int64_t n
     // wide row-major panels (16, 32, 64 columns) with rows of 8+ nonzeros: the vector row-slot kernel below.  (For the
     // short rows of a transposed gridding matrix it was measured no better than the row-per-lane kernel: 13.0 + 2.1 ms
     // against 14.9 + 0.7 ms at 64 columns -- that product is bound by its 32-byte result stores.)
-    static const int vw = getenv("INDIGO_HIP_SPMM_VW") ? atoi(getenv("INDIGO_HIP_SPMM_VW")) : 4;
+    constexpr int vw = 4;
     const bool wide_v = vw > 0 && packed && sxc == 1 && N == sxr && (N == 64 || N == 32 || N == 16) && !y_il &&
                         nnz >= 8 * rows && (reinterpret_cast<uintptr_t>(X) & 15u) == 0;
-    const bool rowlane = !wide_v && (nnz <= 2 * rows || (packed && N >= 16 && nnz <= 8 * rows)) &&
-                         env_flag("INDIGO_HIP_SPMM_ROWLANE", true);
+    const bool rowlane = !wide_v && (nnz <= 2 * rows || (packed && N >= 16 && nnz <= 8 * rows));
     if (rowlane) {
         ig_prof_scope prof(ctx, CONJ ? "csrmm_rowlane_conj" : "csrmm_rowlane");
         const int64_t rblocks = (rows + BLK - 1) / BLK;
@@ -1468,9 +1461,7 @@ int launch_gather(ig_ctx* ctx, int64_t rows, int64_t xrows, int64_t N, int64_t n
 #define IG_ROWLANE(NC_)                                                                            \
     do {                                                                                           \
         if (packed && b0 && NC_ >= 2 && bufok) {                                                   \
-            if (unroll >= 4) IG_ROWLANE_L(NC_, 0, true, 4, true);                                  \
-            else if (unroll == 2) IG_ROWLANE_L(NC_, 0, true, 2, true);                             \
-            else IG_ROWLANE_L(NC_, 0, true, 1, true);                                              \
+            IG_ROWLANE_L(NC_, 0, true, 2, true);          /* two nonzeros per trip */             \
         } else if (packed && b0) IG_ROWLANE_L(NC_, 0, true, 1, false);                             \
         else if (packed) IG_ROWLANE_L(NC_, 1, true, 1, false);                                     \
         else if (b0) IG_ROWLANE_L(NC_, 0, false, 1, false);                                        \
@@ -1478,11 +1469,10 @@ int launch_gather(ig_ctx* ctx, int64_t rows, int64_t xrows, int64_t N, int64_t n
     } while (0)
         // buffer-descriptor loads need every array inside a 2 GB window
         const bool bufok = packed && nnz * 8 < 0x7fffffffLL && xrows * sxr * 8 < 0x7fffffffLL;
-        static const int unroll = getenv("INDIGO_HIP_SPMM_UNROLL") ? atoi(getenv("INDIGO_HIP_SPMM_UNROLL")) : 2;
         // mostly-empty rows, packed panel of <= 8 columns, beta == 0: the dense-lane kernel
-        static const int dense_thr = getenv("INDIGO_HIP_SPMM_DENSE") ? atoi(getenv("INDIGO_HIP_SPMM_DENSE")) : 32;
+        constexpr int dense_thr = 32;
         // 64-column packed panel, short rows: lanes along the columns, 64 x 64 result tiles through LDS
-        if (packed && sxc == 1 && N == 64 && sxr == 64 && !y_il && !mask.bits && env_flag("INDIGO_HIP_SPMM_ROWTILE", true)) {
+        if (packed && sxc == 1 && N == 64 && sxr == 64 && !y_il && !mask.bits) {
             const int64_t tblocks = (rows + 63) / 64;
             IG_REQUIRE(ctx, tblocks <= 0x7fffffffLL, "csrmm: matrix too large for one launch");
             const int32_t tt = defer ? (thr_long < 512 ? thr_long : 512) : 0x7fffffff;
@@ -1496,14 +1486,12 @@ int launch_gather(ig_ctx* ctx, int64_t rows, int64_t xrows, int64_t N, int64_t n
             int64_t dblocks = ((rows + 63) / 64 + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
             // One task per wave by default: the hardware dispatcher balances the very uneven tasks better than a
             // static stride does (1.39 ms against 1.91 ms with 8 persistent workgroups per CU on the SENSE matrix).
-            static const int dense_wgs = getenv("INDIGO_HIP_SPMM_DENSE_WGS") ? atoi(getenv("INDIGO_HIP_SPMM_DENSE_WGS")) : 0;
-            if (dense_wgs > 0 && dblocks > (int64_t)ctx->num_cu * dense_wgs) dblocks = (int64_t)ctx->num_cu * dense_wgs;
             IG_REQUIRE(ctx, dblocks <= 0x7fffffffLL, "csrmm: matrix too large for one launch");
 #define IG_DENSE(NC_) do { if (y_il) hipLaunchKernelGGL((k_csrmm_dense64<NC_, CONJ, true>), dim3((unsigned)dblocks), dim3(BLK), 0, ctx->stream, \
                                          rows, rowptr, colind, vals, X, Y, ldy, alpha, wl, td, thr_long, mask, dense_co);           \
                            else hipLaunchKernelGGL((k_csrmm_dense64<NC_, CONJ, false>), dim3((unsigned)dblocks), dim3(BLK), 0, ctx->stream, \
                                          rows, rowptr, colind, vals, X, Y, ldy, alpha, wl, td, thr_long, mask, dense_co); } while (0)
-            static const int dense_co = getenv("INDIGO_HIP_SPMM_DENSE_CO") ? atoi(getenv("INDIGO_HIP_SPMM_DENSE_CO")) : 1;
+            constexpr int dense_co = 1;
             if (sxr == 8) IG_DENSE(8); else if (sxr == 4) IG_DENSE(4); else if (sxr == 2) IG_DENSE(2);
             else hipLaunchKernelGGL((k_csrmm_dense64<1, CONJ, false>), dim3((unsigned)dblocks), dim3(BLK), 0, ctx->stream,
                                     rows, rowptr, colind, vals, X, Y, ldy, alpha, wl, td, thr_long, mask, dense_co);
@@ -1538,7 +1526,7 @@ int launch_gather(ig_ctx* ctx, int64_t rows, int64_t xrows, int64_t N, int64_t n
             else if (nnz >= 8 * rows) {                       // long rows: spread a row's nonzeros over nonzero-lanes
                 if (N == 16) IG_GV(4, 4, 8);                                                               // 2 rows per wave
                 else if (N == 32) IG_GV(4, 8, 8);                                                          // a wave per row, 32 nonzeros per trip
-                else if (!wl.yperm && nnz <= 0x7fffffffLL && env_flag("INDIGO_HIP_SPMM_TILE64", true)) {
+                else if (!wl.yperm && nnz <= 0x7fffffffLL) {
                     // 64 columns: tiles of 16 rows per wave, software-pipelined (k_csrmm_gather_tile64)
                     const int64_t tblocks = ((rows + 15) / 16 + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
                     IG_REQUIRE(ctx, tblocks <= 0x7fffffffLL, "csrmm: matrix too large for one launch");
@@ -1648,7 +1636,7 @@ int launch_scatter(ig_ctx* ctx, int64_t M, int64_t N, int64_t nnz,
     const int64_t waves = (M + rpw - 1) / rpw;
     const int64_t blocks = (waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     IG_REQUIRE(ctx, blocks <= 0x7fffffffLL, "csrmm: matrix too large for one launch (%lld blocks)", (long long)blocks);
-    const int xcd = env_flag("INDIGO_HIP_SPMM_XCD", true) ? 1 : 0;
+    const int xcd = 1;          // every XCD gets a contiguous range of row blocks (xcd_block)
     ig_prof_scope prof(ctx, ATOMIC ? "csrmm_scatter_atomic" : "csrmm_scatter_exwrite");
 #define IG_SCATTER(CL_, NL_)                                                                       \
     hipLaunchKernelGGL((k_csrmm_scatter<CL_, NL_, ATOMIC>), dim3((unsigned)blocks), dim3(BLK), 0,  \
@@ -1931,14 +1919,13 @@ int ig_ccsrmm_t_bricks(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, float ar, f
     const size_t lds = (size_t)WAVES_PER_BLOCK * 16 * bm * bs * N * 8;          // one brick image per wave
     IG_REQUIRE(ctx, lds <= 64 * 1024, "ig_ccsrmm_t_bricks: bricks of 16 x %d x %d points x %lld columns need %zu bytes of LDS per workgroup (limit 64 KB)", bm, bs, (long long)N, lds);
     const unsigned blocks = (unsigned)((ntasks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
-    static const int brick_dbg = getenv("INDIGO_HIP_BRICK_DEBUG") ? atoi(getenv("INDIGO_HIP_BRICK_DEBUG")) : 0;   // ablation: 1 no accumulation, 2 no stores
 #define IG_BRICKS(NC_, NSEG_) do {                                                                                            \
         if (nshared) {                                                                                                          \
             ig_prof_scope prof(ctx, "grid_bricks_zero");                                                                        \
             hipLaunchKernelGGL((k_grid_bricks_zero<NC_>), dim3((unsigned)nshared), dim3(BLK), 0, ctx->stream, shared_bricks, (float2*)Y_il, bits, (int)n0, (int)nm, bm_log2, bs_log2, nbx, nbm, st_log2); } \
         ig_prof_scope prof(ctx, "csrmm_bricks_conj");                                                                           \
         hipLaunchKernelGGL((k_grid_bricks<NC_, NSEG_>), dim3(blocks), dim3(BLK), lds, ctx->stream, (const BrickTask*)tasks, (int)ntasks, (const BrickRef*)brick_table, (const BrickEntry*)entries, round_rows, \
-                           (const float2*)xp, (float2*)Y_il, alpha, bits, (int)n0, (int)nm, bm_log2, bs_log2, nbx, nbm, brick_dbg, st_log2); } while (0)
+                           (const float2*)xp, (float2*)Y_il, alpha, bits, (int)n0, (int)nm, bm_log2, bs_log2, nbx, nbm, st_log2); } while (0)
     const int nseg_total = (16 / support_tile) * bm * bs;
     if (N == 8 && nseg_total == 4) IG_BRICKS(8, 4);
     else if (N == 8 && nseg_total == 8) IG_BRICKS(8, 8);

@@ -174,7 +174,7 @@ def cleanup_rendezvous(rank, world, path, timeout=10.0):
 class RcclComm(object):
     """Sum all-reduce of a HipBackend array across the ranks through the library's RCCL binding (ig_comm_*)."""
 
-    def __init__(self, backend, rank, world, timeout=60.0):
+    def __init__(self, backend, rank, world, timeout=60.0, overlap=True):
         from indigo_amd import _lib
         self._backend, self.rank, self.world = backend, int(rank), int(world)
         self._L = backend._L
@@ -190,7 +190,7 @@ class RcclComm(object):
         try:
             backend._check(self._L.ig_comm_init_rank(backend._ctx, self.world, self.rank, idbuf, ctypes.byref(comm)), "ig_comm_init_rank")
             self._comm = comm
-            self.overlap = os.environ.get("INDIGO_COMM_OVERLAP", "1") != "0"
+            self.overlap = bool(overlap)     # slab-by-slab all-reduce on the communicator's own stream (ShardedNormalOperator)
             self._pending = False
             self.barrier()                                           # every rank is through the bring-up
         finally:

@@ -10,8 +10,6 @@ k-space grid exists only between these two leaves, so its memory order is theirs
 
 and the gridding matrix's columns are renumbered to match.
 """
-import os
-
 import numpy as np
 import scipy.sparse as spp
 
@@ -109,6 +107,8 @@ def assemble(backend, Gm, oN, N, weights_of, Cn, layout, chunks, table=None, box
     More coils than a chunk holds (the reference's `batch` hint, indigo/operators.py:15-17,341: evaluate a wide
     KronI a few columns at a time) become a VStack: the k-space rows come out coil-major exactly as from KronI(C, G'),
     and the adjoint accumulates the chunks' images (VStack, operators.py:440-447)."""
+    tuning = getattr(backend, 'tuning', {})          # format choices of the backend (HipBackend.tuning)
+
     def gridding(interleaved):
         G = backend.SpMatrix(Gm, name='interp*mod*scale')
         if interleaved:
@@ -119,14 +119,11 @@ def assemble(backend, Gm, oN, N, weights_of, Cn, layout, chunks, table=None, box
             G._grid_support_fine = fine
         if row_order is not None:
             G._row_order = row_order
-        elif (interleaved and os.environ.get("INDIGO_HIP_SPMM_BRICKS", "1") != "0"
-              and (bricks_cols == 8 or (bricks_cols == 4 and os.environ.get("INDIGO_HIP_SPMM_BRICKS", "1") != "8"))
-              and int(oN[2]) % 4 == 0 and int(oN[1]) % 4 == 0):
+        elif interleaved and bricks_cols in tuning.get('bricks', ()) and int(oN[2]) % 4 == 0 and int(oN[1]) % 4 == 0:
             # adjoint gridding by grid bricks (a scatter binned on the host) instead of a gather over the transposed matrix.
             # Measured (config 4): 8 coils 0.91 ms against 1.82 ms (gather + its deferred long rows); 4 coils 0.68 against
             # 1.05 ms.  Two coils or one would pad every sample's share of a brick to 32 / 64 entries: they keep the gather.
-            # INDIGO_HIP_SPMM_BRICKS: 0 never, 8 only the 8-coil trees.
-            G._grid_bricks = (int(oN[0]), int(oN[2]), int(oN[1]), bricks_cols)
+            G._grid_bricks = (int(oN[0]), int(oN[2]), int(oN[1]), bricks_cols) + tuple(tuning.get('brick_shape', (2, 2, 4096, 4096)))
         return G
 
     sizes = {hi - lo for lo, hi in chunks if hi - lo > 1}
@@ -136,7 +133,7 @@ def assemble(backend, Gm, oN, N, weights_of, Cn, layout, chunks, table=None, box
     # 16-point table: whatever they write is a superset of what a reader with the finer table reads.
     # (measured on the headline problem: 7.80 ms at 16, 7.52 ms at 8; at 4 the scatter's 16 segments per brick spill.  coils * tile
     # >= 32 keeps the transform's 32-column tiles, which need two tiles per table entry.)
-    tile = int(os.environ.get("INDIGO_HIP_SUPPORT_TILE", "8"))
+    tile = int(tuning.get('support_tile', 8))
     fine = None
     if (table is not None and layout == 2 and tile in (4, 8) and bricks_cols * tile >= 32 and len(sizes) == 0
             and getattr(backend, 'supports_support_tile', False)):

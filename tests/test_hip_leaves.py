@@ -251,14 +251,14 @@ def test_wide_panel_adjoint_by_bricks(hip, monkeypatch, K, alpha, ld_pad, dense_
     assert rel_err(got, exp) < RTOL
     untouched = np.setdiff1d(np.arange(K), np.unique(A.indices))
     assert np.all(got[untouched] == 0)
-    monkeypatch.setenv("INDIGO_HIP_SPMM_WIDE_BRICKS", "0")
+    monkeypatch.setitem(hip.tuning, "wide_bricks", False)
     B_d = hip.csr_matrix(hip, A)
     y2 = hip.copy_array(yfull)[0:K, :]
     B_d.adjoint(y2, x_d, alpha=alpha)
     assert getattr(B_d, '_wide', False) is False
     assert rel_err(y2.to_host(), got) < 1e-5
     # beta != 0 keeps the contract through the gather route
-    monkeypatch.delenv("INDIGO_HIP_SPMM_WIDE_BRICKS")
+    monkeypatch.setitem(hip.tuning, "wide_bricks", True)
     y3 = hip.copy_array(yfull)[0:K, :]
     A_d.adjoint(y3, x_d, alpha=alpha, beta=0.5)
     assert rel_err(y3.to_host(), exp + 0.5 * yfull[:K]) < RTOL
@@ -288,13 +288,13 @@ def test_wide_panel_forward_over_touched_rows(hip, monkeypatch, n, frac, alpha, 
     exp = alpha * (A.astype(np.complex128) @ xfull[:K].astype(np.complex128)) + beta * yfull[:M]
     assert rel_err(y_d.to_host(), exp) < RTOL
     # the whole-panel route gives the same
-    monkeypatch.setenv("INDIGO_HIP_SPMM_XROWS", "0")
+    monkeypatch.setitem(hip.tuning, "xrows", False)
     B_d = hip.csr_matrix(hip, A)
     y2 = hip.copy_array(yfull)[0:M, :]
     B_d.forward(y2, x_d, alpha=alpha, beta=beta)
     assert getattr(B_d, '_xrows', None) is None
     assert rel_err(y2.to_host(), y_d.to_host()) < 1e-6
-    monkeypatch.delenv("INDIGO_HIP_SPMM_XROWS")
+    monkeypatch.setitem(hip.tuning, "xrows", True)
     # adjoint first (the host copy goes into the transpose), then the forward: the column list comes from the device copy
     C_d = hip.csr_matrix(hip, A)
     xa = hip.copy_array(rand64c(M, 2, seed=4))
@@ -515,8 +515,8 @@ def test_fft_two_stage_any_length_3d_and_lds_agreement(hip, monkeypatch):
     x = rand64c(*(shape + (1,)), seed=8)
     y_d = hip.zero_array(x.shape, C64)
     hip.fftn(y_d, hip.copy_array(x))
-    monkeypatch.setenv("INDIGO_HIP_FFT_AB", "0")
     other = get_backend("hip")
+    other.set_option("fft.kernels", 1)                     # plans of this context: no A x B passes
     assert "AxB" not in other.fft_describe(x.shape) and "lds" in other.fft_describe(x.shape)
     z_d = other.zero_array(x.shape, C64)
     other.fftn(z_d, other.copy_array(x))
@@ -529,9 +529,11 @@ def test_fft_generic_path_matches_lds_path(hip, monkeypatch):
     x = rand64c(24, 20, 16, 2, seed=9)
     y_d = hip.zero_array(x.shape, C64)
     hip.fftn(y_d, hip.copy_array(x))
-    monkeypatch.setenv("INDIGO_HIP_FFT_GENERIC", "1")
     other = get_backend("hip")
+    other.set_option("fft.kernels", 2)                     # plans of this context: the one-stage-per-launch kernel only
     assert "generic" in other.fft_describe(x.shape)
+    with pytest.raises(RuntimeError, match="unknown option"):
+        other.set_option("no.such.option", 1)
     z_d = other.zero_array(x.shape, C64)
     other.fftn(z_d, other.copy_array(x))
     assert rel_err(z_d.to_host(), y_d.to_host()) < 1e-6

@@ -62,7 +62,7 @@ def test_pics_on_a_non_power_of_two_grid(tmp_path, hip, oracle_backend, caplog):
     path, img = _scan(tmp_path, hip, N, C, nro=160, nsp=300, osf=1.25, width=3)
     assert "AxB" in hip.fft_describe((160, 160, 160, C)) and hip.supports_padded_fft((160, 160, 160), C)
     args = ["-i", "4", "--osf", "1.25", "--width", "3", "--lamda", "1e-3", "--debug", "40", path]
-    with caplog.at_level(logging.INFO, logger="indigo_amd.pics"):
+    with caplog.at_level(logging.INFO, logger="pics"):
         out = pics.main(["-O", "3"] + args, backend=hip)
     tree = [r.getMessage() for r in caplog.records if r.getMessage().startswith("tree:")][-1]
     assert "ZpadFFT" in tree and "UnscaledFFT" not in tree, tree
