@@ -339,8 +339,9 @@ def run_sense(args, cfg, B, comm, world, rank, steps, warmup, want_cpu, quiet=Fa
     B.trace = None
     ev = trace.by_event()
     ref_bytes_rank = trace.total_bytes()
+    setup_s = time.time() - t_setup
     log("setup %.1fs; reference-model bytes/eval on this rank: %.2f GB %s" % (
-        time.time() - t_setup, ref_bytes_rank / 1e9, {k: round(v['nbytes'] / 1e9, 2) for k, v in ev.items()}))
+        setup_s, ref_bytes_rank / 1e9, {k: round(v['nbytes'] / 1e9, 2) for k, v in ev.items()}))
 
     elapsed, prof = timed_steps(B, comm, lambda: AHA.eval(y, x), steps, warmup)
     ms_per_step = elapsed / steps * 1e3
@@ -392,7 +393,7 @@ def run_sense(args, cfg, B, comm, world, rank, steps, warmup, want_cpu, quiet=Fa
         traffic_bytes, traffic_src = comp_bytes, "sum of the kernels' compulsory bytes (no PMC summary for this configuration)"
 
     out = {
-        "ms_per_step": ms_per_step, "value": value,
+        "ms_per_step": ms_per_step, "value": value, "setup_s": round(setup_s, 2),
         "config": {"workload": "non-Cartesian SENSE A^H A, image %d^3, %d coils, grid %d^3 (osf %.2g), radial T=%d, KB width 4; "
                                "-O3 tree S'->FFT->G'->G'^H->IFFT->S'^H%s" % (img, C, p.oN[0], p.oversamp, p.T,
                                                                              " (BASELINE config %d)" % cfg),
@@ -487,7 +488,7 @@ def bench_sense(args, world, rank, local_rank):
     if cfg == 4 and not args.no_config5 and not args.shard and not args.image and not args.coils and not args.osf and args.tree == "zpadfft":
         try:
             r5 = run_sense(args, 5, B, comm, world, rank, max(2, min(args.steps, 5)), min(args.warmup, 2), False, quiet=True)
-            extra5 = {"evals_per_s": r5["value"], "ms_per_step": r5["ms_per_step"], "n_gpus": world, "config": r5["config"],
+            extra5 = {"evals_per_s": r5["value"], "ms_per_step": r5["ms_per_step"], "setup_s": r5["setup_s"], "n_gpus": world, "config": r5["config"],
                       "eval_traffic_frac": r5["eval_traffic_frac"], "kernels": r5["kernels"],
                       "note": "BASELINE config 5 (320^3 x 32 coils, grid 512^3) at the same N: strong scaling of the 32-coil problem"}
         except Exception as e:             # noqa: BLE001 -- the extra measurement must not cost the headline its line

@@ -333,6 +333,17 @@ int  ig_cgemm(ig_ctx* ctx, int adjoint, int right, int64_t rows_m, int64_t cols_
 int  ig_interp3_count(int64_t m, const int64_t* N, double width, const double* coord, int32_t* rowptr);
 int  ig_interp3_fill(int64_t m, const int64_t* N, double width, const double* table, int64_t ntable,
                      const double* coord, const int32_t* rowptr, int32_t* colind, float* weights, int grid_order);
+/* The same matrix with COMPLEX values (float)w * exp(2 pi i (phase_x[kx] + phase_y[ky] + phase_z[kz])) * scale: interpolation
+ * times the centred transform's modulation (Backend.FFTc, indigo/backends/backend.py:355-369) and normalisation -- the G'
+ * factor of the -O3 SENSE tree (examples/pics.py:104-177) in one pass.  phase_x/y/z: N[0] / N[1] / N[2] doubles (turns).   */
+int  ig_interp3_fill_modulated(int64_t m, const int64_t* N, double width, const double* table, int64_t ntable,
+                               const double* coord, const int32_t* rowptr, int32_t* colind, void* values, int grid_order,
+                               const double* phase_x, const double* phase_y, const double* phase_z, double scale);
+/* k-space support table (host) of a gridding matrix whose columns number the grid as kx + n0*(kz + n2*ky): for every
+ * (ky, kx tile of `tile` points) the kz hull and one bit per kz that holds a nonzero, and the ky hull of every kx tile --
+ * the table ig_fft_exec_padded / _cropped and the gridding kernels take.  table: 2*(n1*nt + nt) int16 + n1*nt*16 uint32,
+ * nt = n0 / tile.  n2 a multiple of 16, at most 512.                                                                   */
+int  ig_grid_support(int64_t nnz, const int32_t* colind, int64_t n0, int64_t n1, int64_t n2, int tile, int16_t* table);
 
 /* ------------------------------------------------------------------------
  * Batched complex-to-complex FFT.  Replaces Backend.fftn/ifftn

@@ -97,6 +97,9 @@ PROTOTYPES = {
                                    c_void_p, c_int64, c_float, c_float, c_void_p, c_int64]),
     "ig_interp3_count":   (c_int, [c_int64, POINTER(c_int64), c_double, c_void_p, c_void_p]),
     "ig_interp3_fill":    (c_int, [c_int64, POINTER(c_int64), c_double, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
+    "ig_grid_support":    (c_int, [c_int64, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
+    "ig_interp3_fill_modulated": (c_int, [c_int64, POINTER(c_int64), c_double, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                          c_void_p, c_void_p, c_void_p, c_double]),
     "ig_fft_plan":        (c_int, [c_void_p, c_int, POINTER(c_int64), c_int64, POINTER(c_void_p), POINTER(c_size_t)]),
     "ig_fft_exec":        (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ig_fft_describe":    (c_int, [c_void_p, c_char_p, c_size_t]),

@@ -820,7 +820,9 @@ class HipBackend(Backend):
                 sub = getattr(self, '_xrows', None)
                 if sub is None:
                     indices = self._host_csr.indices if self._host_csr is not None else self.colInds.to_host()
-                    touched = np.unique(indices).astype(np.int32)
+                    mark = np.zeros(self.shape[1], dtype=bool)
+                    mark[indices] = True
+                    touched = np.flatnonzero(mark).astype(np.int32)
                     compact = np.searchsorted(touched, indices).astype(np.int32)
                     sub = self._xrows = (b.copy_array(touched, name=self._name + ".touchedCols"),
                                          b.copy_array(compact, name=self._name + ".compactColInds"))

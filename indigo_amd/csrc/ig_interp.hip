@@ -88,9 +88,16 @@ int ig_interp3_count(int64_t m, const int64_t* N, double width, const double* co
     return IG_OK;
 }
 
-int ig_interp3_fill(int64_t m, const int64_t* N, double width, const double* table, int64_t ntable,
-                    const double* coord, const int32_t* rowptr, int32_t* colind, float* weights, int grid_order) {
-    if (m < 0 || !N || !coord || !rowptr || !table || ntable < 2 || !(width > 0) || (rowptr[m] > 0 && (!colind || !weights)))
+}  // extern "C"
+
+// weights: float32 interpolation weights -- or, with per-axis phase tables (phase_x/y/z: N0 / N1 / N2 doubles), complex64
+// values  (float)w * (complex64)exp(2 pi i (phase_x[kx] + phase_y[ky] + phase_z[kz])) * (float)scale  in `cvalues`: the gridding
+// matrix times the centred transform's modulation and normalisation (the G' factor of the reference's -O3 SENSE tree,
+// examples/pics.py:104-177) without three more passes over 5e7 nonzeros in numpy
+static int interp3_fill(int64_t m, const int64_t* N, double width, const double* table, int64_t ntable,
+                        const double* coord, const int32_t* rowptr, int32_t* colind, float* weights, int grid_order,
+                        const double* phase_x, const double* phase_y, const double* phase_z, double scale, float2* cvalues) {
+    if (m < 0 || !N || !coord || !rowptr || !table || ntable < 2 || !(width > 0) || (rowptr[m] > 0 && (!colind || (!weights && !cvalues))))
         return ig_fail(nullptr, IG_ERR_ARG, "ig_interp3_fill: bad arguments");
     if (grid_order != 0 && grid_order != 1)
         return ig_fail(nullptr, IG_ERR_ARG, "ig_interp3_fill: grid_order must be 0 (x, y, z) or 1 (x, z, y)");
@@ -138,12 +145,96 @@ int ig_interp3_fill(int64_t m, const int64_t* N, double width, const double* tab
                 for (size_t q = 1; q < row.size(); ++q) if (row[q].first == row[q - 1].first) bad = 2;   // a row wraps onto one column twice
             }
             int32_t* ci = colind + rowptr[i];
-            float* wv = weights + rowptr[i];
-            for (size_t q = 0; q < row.size(); ++q) { ci[q] = row[q].first; wv[q] = row[q].second; }
+            for (size_t q = 0; q < row.size(); ++q) ci[q] = row[q].first;
+            if (weights) {
+                float* wv = weights + rowptr[i];
+                for (size_t q = 0; q < row.size(); ++q) wv[q] = row[q].second;
+            }
+            if (cvalues) {
+                float2* cv = cvalues + rowptr[i];
+                const float sc = (float)scale;
+                for (size_t q = 0; q < row.size(); ++q) {
+                    const int64_t col = row[q].first;
+                    const int64_t kx = col % n0, k1 = (col / n0) % (grid_order == 0 ? n1 : n2), k2 = col / (n0 * (grid_order == 0 ? n1 : n2));
+                    const int64_t ky = grid_order == 0 ? k1 : k2, kz = grid_order == 0 ? k2 : k1;
+                    // the phase summed x, then y, then z in double, as Backend.fftc_mod adds its per-axis terms
+                    double ph = 0.0 + phase_x[kx];
+                    ph += phase_y[ky];
+                    ph += phase_z[kz];
+                    const double a = 6.283185307179586 * ph;
+                    const float mr = (float)std::cos(a), mi = (float)std::sin(a);
+                    const float w = row[q].second;
+                    cv[q] = make_float2((w * mr) * sc, (w * mi) * sc);
+                }
+            }
         }
     });
     if (bad == 1) return ig_fail(nullptr, IG_ERR_ARG, "ig_interp3_fill: rowptr does not come from ig_interp3_count on the same inputs");
     if (bad == 2) return ig_fail(nullptr, IG_ERR_UNSUPPORTED, "ig_interp3_fill: a row wraps onto the same column twice (grid smaller than the kernel)");
+    return IG_OK;
+}
+
+extern "C" {
+
+int ig_interp3_fill(int64_t m, const int64_t* N, double width, const double* table, int64_t ntable,
+                    const double* coord, const int32_t* rowptr, int32_t* colind, float* weights, int grid_order) {
+    return interp3_fill(m, N, width, table, ntable, coord, rowptr, colind, weights, grid_order, nullptr, nullptr, nullptr, 1.0, nullptr);
+}
+
+int ig_interp3_fill_modulated(int64_t m, const int64_t* N, double width, const double* table, int64_t ntable,
+                              const double* coord, const int32_t* rowptr, int32_t* colind, void* values, int grid_order,
+                              const double* phase_x, const double* phase_y, const double* phase_z, double scale) {
+    if (!phase_x || !phase_y || !phase_z || !values) return ig_fail(nullptr, IG_ERR_ARG, "ig_interp3_fill_modulated: bad arguments");
+    return interp3_fill(m, N, width, table, ntable, coord, rowptr, colind, nullptr, grid_order, phase_x, phase_y, phase_z, scale, (float2*)values);
+}
+
+// k-space support table of a gridding matrix whose columns number an n0 x n2 x n1 grid as kx + n0*(kz + n2*ky) (grid layouts
+// 1 and 2 of the fused transform): one pass over the column indices sets the segment bits, the hulls follow from the bits.
+// Layout of `table` (int16): [z_lo, z_hi) per (ky, kx tile), [y_lo, y_hi) per kx tile, then 16 uint32 words per (ky, kx tile)
+// -- bit m of word t is set iff segment (kx tile, ky, kz = t + 16 m) holds a nonzero.  (indigo_amd/fused.py:grid_support.)
+int ig_grid_support(int64_t nnz, const int32_t* colind, int64_t n0, int64_t n1, int64_t n2, int tile, int16_t* table) {
+    if (nnz < 0 || (nnz > 0 && !colind) || !table || n0 < 1 || n1 < 1 || n2 < 1 || n2 > 512 || n2 % 16 || tile < 1 || n0 % tile)
+        return ig_fail(nullptr, IG_ERR_ARG, "ig_grid_support: bad arguments (n2 a multiple of 16, at most 512; tile divides n0)");
+    const int64_t nt = n0 / tile, ne = n1 * nt;
+    int16_t* zr = table;
+    int16_t* yr = table + 2 * ne;
+    uint32_t* bits = reinterpret_cast<uint32_t*>(table + 2 * (ne + nt));
+    std::fill(table, table + 2 * (ne + nt), (int16_t)0);
+    std::fill(bits, bits + ne * 16, 0u);
+    int bad = 0;
+    parallel_rows(nnz, [&](int64_t lo, int64_t hi) {
+        int32_t last = -1;
+        for (int64_t p = lo; p < hi; ++p) {
+            const int32_t col = colind[p];
+            if (col == last) continue;
+            last = col;
+            const int64_t kx = col % n0, kz = (col / n0) % n2, ky = col / (n0 * n2);
+            if (col < 0 || ky >= n1) { bad = 1; continue; }
+            uint32_t* w = bits + (ky * nt + kx / tile) * 16 + (kz & 15);
+            const uint32_t m = 1u << (kz >> 4);
+            if (!(__atomic_load_n(w, __ATOMIC_RELAXED) & m)) __atomic_fetch_or(w, m, __ATOMIC_RELAXED);
+        }
+    });
+    if (bad) return ig_fail(nullptr, IG_ERR_ARG, "ig_grid_support: column index outside the grid");
+    parallel_rows(ne, [&](int64_t lo, int64_t hi) {
+        for (int64_t e = lo; e < hi; ++e) {
+            int zlo = 1 << 30, zhi = -1;
+            for (int t = 0; t < 16; ++t) {
+                const uint32_t w = bits[e * 16 + t];
+                if (!w) continue;
+                const int first = __builtin_ctz(w), lastb = 31 - __builtin_clz(w);
+                zlo = std::min(zlo, t + 16 * first);
+                zhi = std::max(zhi, t + 16 * lastb);
+            }
+            if (zhi >= 0) { zr[2 * e] = (int16_t)zlo; zr[2 * e + 1] = (int16_t)(zhi + 1); }
+        }
+    });
+    for (int64_t t = 0; t < nt; ++t) {
+        int ylo = -1, yhi = -1;
+        for (int64_t ky = 0; ky < n1; ++ky)
+            if (zr[2 * (ky * nt + t) + 1] > zr[2 * (ky * nt + t)]) { if (ylo < 0) ylo = (int)ky; yhi = (int)ky; }
+        if (ylo >= 0) { yr[2 * t] = (int16_t)ylo; yr[2 * t + 1] = (int16_t)(yhi + 1); }
+    }
     return IG_OK;
 }
 

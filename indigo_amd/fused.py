@@ -29,7 +29,35 @@ def permute_grid_columns(G, oN):
     return out
 
 
+def touched_columns(G):
+    """sorted indices of the columns of G that hold a nonzero (the grid points a gridding matrix touches); one flag pass
+    instead of a sort of all column indices, cached on the matrix"""
+    c = getattr(G, '_ig_touched_columns', None)
+    if c is None:
+        mark = np.zeros(G.shape[1], dtype=bool)
+        mark[G.indices] = True
+        c = np.flatnonzero(mark)
+        try:
+            G._ig_touched_columns = c
+        except AttributeError:
+            pass
+    return c
+
+
 def grid_support(G, oN, tile=16):
+    """k-space support table of a layout-1 gridding matrix (see grid_support_numpy for the format): the library's native
+    host routine, one threaded pass over the column indices (ig_grid_support)"""
+    from indigo_amd import _lib
+    n0, n1, n2 = (int(n) for n in oN)
+    assert n0 % 16 == 0 and n2 % 16 == 0 and n2 <= 512 and tile in (2, 4, 8, 16)
+    nt = n0 // tile
+    idx = np.ascontiguousarray(G.indices, dtype=np.int32)
+    table = np.empty(2 * (n1 * nt + nt) + 2 * n1 * nt * 16, dtype=np.int16)
+    _lib.check(_lib.lib().ig_grid_support(idx.size, idx.ctypes.data, n0, n1, n2, int(tile), table.ctypes.data), None, "ig_grid_support")
+    return table
+
+
+def grid_support_numpy(G, oN, tile=16):
     """k-space support of a layout-1 gridding matrix G (T x P) as the flat int16 table ig_fft_exec_padded,
     ig_fft_exec_cropped and ig_ccsrmm_t_grid take.  Three parts:
       1. [z_lo, z_hi) per (ky, 16-wide kx tile): the kz range outside which no sample touches the grid;
@@ -42,7 +70,7 @@ def grid_support(G, oN, tile=16):
     n0, n1, n2 = (int(n) for n in oN)
     assert n0 % 16 == 0 and n2 % 16 == 0 and n2 <= 512 and tile in (2, 4, 8, 16)
     nt = n0 // tile               # `tile` kx points per entry (16 unless the caller asked for a finer table, see ig_fft_set_support_tile)
-    cols = np.unique(G.indices)
+    cols = touched_columns(G)
     kx = cols % n0
     kz = (cols // n0) % n2
     ky = cols // (n0 * n2)

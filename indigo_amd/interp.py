@@ -104,6 +104,31 @@ def interp_csr_arrays(m, N, width, table, coord, dtype=np.float32, grid_order=0)
     return indptr.astype(np.int64), indices, data if dtype == np.float32 else data.astype(dtype)
 
 
+def interp_csr_modulated(m, N, width, table, coord, phases, scale, grid_order=0):
+    """CSR arrays (indptr, indices, complex64 data) of  interp * diag(exp(2 pi i (px[kx] + py[ky] + pz[kz]))) * scale  -- the
+    gridding matrix times the centred transform's modulation and normalisation (G' of the -O3 SENSE tree) -- in one native
+    pass (ig_interp3_fill_modulated); `phases` = per-axis phase tables in turns (sense._mod_axis_phases)."""
+    import ctypes
+    from indigo_amd import _lib
+    L = _lib.lib()
+    N = tuple(int(n) for n in N)
+    coord = np.ascontiguousarray(np.asarray(coord, dtype=np.float64).reshape(3, -1))
+    assert coord.shape[1] == m
+    table = np.ascontiguousarray(table, dtype=np.float64)
+    px, py, pz = (np.ascontiguousarray(ph, dtype=np.float64) for ph in phases)
+    assert (px.size, py.size, pz.size) == N
+    dims = (ctypes.c_int64 * 3)(*N)
+    indptr = np.empty(m + 1, dtype=np.int32)
+    _lib.check(L.ig_interp3_count(m, dims, float(width), coord.ctypes.data, indptr.ctypes.data), None, "ig_interp3_count")
+    nnz = int(indptr[-1])
+    indices = np.empty(nnz, dtype=np.int32)
+    data = np.empty(nnz, dtype=np.complex64)
+    _lib.check(L.ig_interp3_fill_modulated(m, dims, float(width), table.ctypes.data, table.size, coord.ctypes.data, indptr.ctypes.data,
+                                           indices.ctypes.data, data.ctypes.data, int(grid_order), px.ctypes.data, py.ctypes.data,
+                                           pz.ctypes.data, float(scale)), None, "ig_interp3_fill_modulated")
+    return indptr, indices, data
+
+
 def interp_csr_arrays_numpy(m, N, width, table, coord, dtype=np.float32, chunk=65536):
     """The same arrays from vectorised numpy (kept as the independent cross-check of the native routine).
 

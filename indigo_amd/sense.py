@@ -21,7 +21,7 @@ from scipy.signal.windows import kaiser
 
 from indigo_amd import fused
 from indigo_amd import operators as op
-from indigo_amd.interp import interp_csr_arrays
+from indigo_amd.interp import interp_csr_arrays, interp_csr_modulated
 from indigo_amd.noncart import rolloff3
 from indigo_amd.transforms import sense_recipe, reserve_for
 
@@ -70,7 +70,20 @@ class SenseProblem(object):
             N = tuple(int(n) for n in N)
             return cls(N, coord, lambda c: rand64c(*N, seed=[seed, int(c)]), width=width, ntable=ntable,
                        oversamp=oversamp, ncoils=C)
-        maps = rand64c(*tuple(N), C, seed=seed)
+        # coil c's map comes from the seed (seed, c) either way; here all of them are generated up front, a few threads sharing
+        # the coils (each with its own generator)
+        N = tuple(int(n) for n in N)
+        maps = np.empty(N + (C,), dtype=_C64, order='F')
+
+        def one(c):
+            maps[:, :, :, c] = rand64c(*N, seed=[seed, int(c)])
+        if C > 1 and int(np.prod(N)) >= 1 << 20:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=min(8, C)) as ex:
+                list(ex.map(one, range(C)))
+        else:
+            for c in range(C):
+                one(c)
         return cls(N, coord, maps, width=width, ntable=ntable, oversamp=oversamp)
 
     def drop_cache(self):
@@ -102,18 +115,11 @@ class SenseProblem(object):
             return self._interp_cache[layout]
         P = int(np.prod(self.oN))
         n0, n1, n2 = self.oN
-        # the native builder numbers the grid columns in either order (sorted within a row both ways)
-        indptr, indices, w = interp_csr_arrays(self.T, self.oN, self.width, self.table,
-                                               self.coord.reshape(3, -1, order='F'), dtype=np.float32,
-                                               grid_order=1 if layout == 1 else 0)
-        kx = indices % n0
-        if layout == 1:
-            kz, ky = (indices // n0) % n2, indices // (n0 * n2)
-        else:
-            ky, kz = (indices // n0) % n1, indices // (n0 * n1)
-        scale = np.complex64(np.float32(1.0) / np.sqrt(np.float32(P)))
-        data = w.astype(_C64) * fftc_mod_at(self.oN, kx, ky, kz)
-        data *= scale
+        # the native builder numbers the grid columns in either order (sorted within a row both ways) and applies the centred
+        # transform's modulation and the 1/sqrt(P) in the same pass (ig_interp3_fill_modulated)
+        scale = np.float32(1.0) / np.sqrt(np.float32(P))
+        indptr, indices, data = interp_csr_modulated(self.T, self.oN, self.width, self.table, self.coord.reshape(3, -1, order='F'),
+                                                     _mod_axis_phases(self.oN), scale, grid_order=1 if layout == 1 else 0)
         G = spp.csr_matrix((data, indices, indptr), shape=(self.T, P))
         self._interp_cache[layout] = G            # 0.6 GB per layout at 5e7 nonzeros; drop_cache() releases them
         return G
@@ -146,8 +152,16 @@ class SenseProblem(object):
         apod = rolloff3(self.oversamp, self.width, self.beta, self.N).astype(_C64)
         base = (mod * apod).astype(_C64)
         w = np.empty(self.N + (len(coils),), dtype=_C64, order='F')
-        for j, c in enumerate(coils):
-            np.multiply(base, self.coil_map(c), out=w[:, :, :, j])
+
+        def one(jc):
+            np.multiply(base, self.coil_map(jc[1]), out=w[:, :, :, jc[0]])
+        if len(coils) > 1 and base.size >= 1 << 20:      # numpy releases the GIL in the multiply: a few threads share the coils
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=min(8, len(coils))) as ex:
+                list(ex.map(one, enumerate(coils)))
+        else:
+            for jc in enumerate(coils):
+                one(jc)
         return w
 
     def grid_support(self, G, tile=16):
@@ -195,7 +209,7 @@ class SenseProblem(object):
         Gm = self.fused_interp(1)
         T, P = Gm.shape
         nnz = Gm.nnz
-        touched = int(np.unique(Gm.indices).size)
+        touched = int(fused.touched_columns(Gm).size)
         e = 8 * ncoils
         if table is not None:
             _, _, bits = self.split_support(table, tile)
@@ -282,13 +296,11 @@ def fftc_mod_at(ft_shape, kx, ky, kz):
 
 
 def fftc_mod_box(ft_shape, box):
-    """the modulation on the centred box (Backend.Zpad's placement) of the grid, shape `box`"""
+    """the modulation on the centred box (Backend.Zpad's placement) of the grid, shape `box`.  The phase is a sum of per-axis
+    terms: the product of three per-axis exponentials (complex128, rounded once) replaces 1.7e7 complex exponentials."""
     sl = [slice(m // 2 + int(np.ceil(-n / 2)), m // 2 + int(np.ceil(n / 2))) for m, n in zip(ft_shape, box)]
-    px, py, pz = _mod_axis_phases(ft_shape)
-    phase = 0 + px[sl[0]][:, None, None]
-    phase = phase + py[sl[1]][None, :, None]
-    phase = phase + pz[sl[2]][None, None, :]
-    return np.asfortranarray(np.exp(1j * 2.0 * np.pi * phase).astype(_C64))
+    ex, ey, ez = (np.exp(1j * 2.0 * np.pi * ph[s]) for ph, s in zip(_mod_axis_phases(ft_shape), sl))
+    return np.asfortranarray((ex[:, None, None] * ey[None, :, None] * ez[None, None, :]).astype(_C64))
 
 
 def normal_operator(A, lamda=0.0, ncols=1):

@@ -264,6 +264,7 @@ def test_support_tables_of_every_granularity_cover_the_touched_cells():
     prev, prev_count = None, None
     for tile in (2, 4, 8, 16):
         table = fused.grid_support(G, p.oN, tile)
+        np.testing.assert_array_equal(table, fused.grid_support_numpy(G, p.oN, tile))     # native builder == numpy formulation
         zr, yr, bits = fused.split_support(table, p.oN, tile)
         nt = n0 // tile
         m = np.arange(n2 // 16, dtype=np.uint32)
