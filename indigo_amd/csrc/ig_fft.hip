@@ -473,12 +473,13 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
     // wave wants that element, and the load instruction itself is skipped by a scalar branch -- a k-space column is
     // mostly unflagged rows (72 % on the headline problem), and an instruction whose lanes are all out of range still
     // costs its issue slot and its pass through the address unit.
-    // (loads only.  The same scalar branches around the STORES of the padded z pass cost it its register allocation -- 172
+    // (Unweighted passes only: the weighted run-time-box x pass went from 155 to 198 registers with them -- three waves per SIMD
+    // to two, 1.08 -> 1.86 ms on config 5.  Loads only: the same scalar branches around the STORES of the padded z pass cost it its register allocation -- 172
     // bytes of spills at the 128-register cap -- and predicating them through the execution mask instead, one opaque
     // v_and / v_cmp / s_and_saveexec / store / s_mov exec block per element, was measured slower than the out-of-range
     // offsets: padded y pass 1.08 -> 1.14 ms, padded z pass 1.21 -> 1.24 ms, config 5 41.9 -> 44.3 ms.)
     uint32_t gin = 0xffffffffu;
-    if (BOXED && !AXIS0 && GROUP_SKIP && !HALF_IN && HALF != 4) {
+    if (BOXED && !AXIS0 && GROUP_SKIP && WMODE == 0 && !HALF_IN && HALF != 4) {
         gin = 0;
 #pragma unroll
         for (int l = 0; l < 64; l += W) gin |= (uint32_t)__builtin_amdgcn_readlane((int)ibits, l);
@@ -494,7 +495,7 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
             const bool stat = !BOXED || HALF_IN || HALF == 4;                 // box known at compile time
             // off = all ones (out of range) where the element is not wanted: one bit-field extract + one or
             const unsigned off = stat ? 0u : (unsigned)__builtin_amdgcn_sbfe((int)~ibits, k, 1);
-            if (!stat && !AXIS0 && GROUP_SKIP && !((gin >> k) & 1u)) { v[k] = mk(0.f, 0.f); if (WMODE == 1) wv[k] = mk(0.f, 0.f); continue; }
+            if (!stat && !AXIS0 && GROUP_SKIP && WMODE == 0 && !((gin >> k) & 1u)) { v[k] = mk(0.f, 0.f); continue; }
             if (AXIS0) {
                 v[k] = from2(buf_ld<NT_LD>(r_in, l_in | off, (unsigned)(k * R2) * 8u));
                 if (WMODE == 1) wv[k] = from2(buf_ld<false>(r_w, l_w | off, (unsigned)(k * R2) * 8u));
