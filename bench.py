@@ -46,10 +46,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-PMC_SUMMARIES = {4: os.path.join("profiles", "r02_cfg4_pmc_traffic.json"),
-                 2: os.path.join("profiles", "r02_cfg2_pmc_traffic.json"),
-                 3: os.path.join("profiles", "r02_cfg3_pmc_traffic.json"),
-                 5: os.path.join("profiles", "r02_cfg5_pmc_traffic.json")}
+PMC_SUMMARIES = {4: os.path.join("profiles", "r03_cfg4_pmc_traffic.json"),
+                 2: os.path.join("profiles", "r03_cfg2_pmc_traffic.json"),
+                 3: os.path.join("profiles", "r03_cfg3_pmc_traffic.json"),
+                 5: os.path.join("profiles", "r03_cfg5_pmc_traffic.json")}
 PMC_NOTE = " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE x2 per the gfx950 note)"
 
 
@@ -639,7 +639,7 @@ def bench_spmm(args, local_rank, B=None):
     ktab_f, ktab_a = kernel_table(prof, args.steps), kernel_table(a_prof, args.steps)
     if pmc:
         # (the repacking kernel serves both directions under one name and the zero-fill is a runtime kernel: no per-site PMC figure)
-        sym = {"csrmm_gather": "k_csrmm_gather", "csrmm_bricks_wide_conj": "k_bricks_wide64"}
+        sym = {"csrmm_gather": "k_csrmm_gather", "csrmm_bricks_wide_conj": "k_bricks_wide64", "bricks_wide_zero": "k_wide_zero_unowned"}
         for tab in (ktab_f, ktab_a):
             for site, ent in tab.items():
                 ks = [k for k in pmc if isinstance(pmc[k], dict) and sym.get(site) and k.startswith(sym[site])]
