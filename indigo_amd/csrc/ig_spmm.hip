@@ -260,34 +260,34 @@ k_csrmm_gather_v(int64_t M, const int32_t* __restrict__ rowptr, const int32_t* _
     }
 }
 
-// 64-column row-major panel (packed), rows of some tens of nonzeros (a gridding matrix: 27): a wave computes a TILE of 16
-// consecutive rows, one row after the other.  What the one-row-per-wave form above pays three dependent round trips for
-// (row pointers -> indices / values -> panel rows), this one overlaps: the 17 row pointers of the tile are one load, the
-// indices and values of row j + 1 are requested before the panel rows of row j are waited for, and consecutive rows --
-// consecutive samples of a trajectory, half a grid cell apart -- gather mostly the same panel rows within a microsecond of
-// each other, i.e. out of the L1 / L2 instead of HBM.  Lane (c, i): panel columns 4c .. 4c+3 (two 16-byte loads), nonzero
-// lane i of 4; a pass covers 32 nonzeros of a row.  The 16 x 64 results go through an LDS tile and leave as full 128-byte
-// lines of the column-major result (lanes = 16 rows x 4 columns).  Rows beyond thr_long nonzeros go to the workgroup-per-row
-// list as everywhere else.
+// 64-column row-major panel (packed), rows of some tens of nonzeros (a gridding matrix: 27): a workgroup computes a TILE of 64
+// consecutive rows, wave w the rows w, w + 4, w + 8, ... one after the other.  What the one-row-per-wave form above pays three
+// dependent round trips for (row pointers -> indices / values -> panel rows), this one overlaps: a wave's 17 pairs of row
+// pointers are one load, the indices and values of its next row are requested before the panel rows of the current one are
+// waited for.  The four waves work on four CONSECUTIVE rows at any time -- consecutive samples of a trajectory, half a grid
+// cell apart, gather mostly the same panel rows -- so their requests meet in the CU's L1 (a first version gave every wave 16
+// consecutive rows of its own: 14.3 GB from HBM by the PMC counters instead of 6.4, the reuse a row apart in time instead of
+// side by side).  Lane (c, i): panel columns 4c .. 4c+3 (two 16-byte loads), nonzero lane i of 4; a pass covers 28 nonzeros of
+// a row.  The 64 x 64 results go through an LDS tile and leave as full 128-byte lines of the column-major result (lanes = 16
+// rows x 4 columns).  Rows beyond thr_long nonzeros go to the workgroup-per-row list as everywhere else.
 template <bool CONJ, int BMODE>
 __global__ void __launch_bounds__(BLK)
 k_csrmm_gather_tile64(int64_t M, int64_t nnz, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
                       const float2* __restrict__ vals, const float2* __restrict__ X /* [row][64] */,
                       float2* __restrict__ Y, int64_t ldy, float2 alpha, float2 beta, int xcd_remap,
                       WorkLists wl, int32_t thr_long) {
-    constexpr int TLD = 65, U = 8;
-    __shared__ float2 tile_all[WAVES_PER_BLOCK * 16 * TLD];
+    constexpr int TLD = 65, U = 7;          // 28 nonzeros per pass: a 27-tap gridding row in one, four idle slots fewer than at 8
+    __shared__ float2 tile[64 * TLD];
     const int lane = threadIdx.x & 63, c = lane & 15, i = lane >> 4;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t blk = xcd_remap ? xcd_block(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
-    const int64_t wave = blk * WAVES_PER_BLOCK + wv;
-    const int64_t row0 = wave * 16;
+    const int64_t row0 = blk * 64;
     if (row0 >= M) return;
-    float2* __restrict__ tile = tile_all + wv * 16 * TLD;
+    // lanes 2j / 2j + 1 hold the row pointers p0 / p1 of this wave's j-th row, row0 + wv + 4j
     int32_t myp;
     {
-        int64_t r = row0 + (lane < 16 ? lane : 16);
-        if (r > M) r = M;
+        int64_t r = row0 + wv + 4 * (lane >> 1) + (lane & 1);
+        if (lane >= 32 || r > M) r = M;
         myp = rowptr[r];
     }
     const float4* __restrict__ X4 = reinterpret_cast<const float4*>(X) + c * 2;
@@ -319,28 +319,31 @@ k_csrmm_gather_tile64(int64_t M, int64_t nnz, const int32_t* __restrict__ rowptr
             acc_nz<CONJ>(acc[3], vv[u], make_float2(x4[u][1].z, x4[u][1].w));
         }
     };
-    unsigned skip = 0;                                   // bit j: row j is someone else's (deferred), or lies past M
+    unsigned skip = 0;                                   // bit j: this wave's j-th row is someone else's (deferred), or lies past M
     int32_t p0 = __builtin_amdgcn_readlane(myp, 0), p1 = __builtin_amdgcn_readlane(myp, 1);
     int32_t k[U];
     float2 v[U];
     load_idx(p0, p1, k, v);
 #pragma unroll 1
     for (int j = 0; j < 16; ++j) {
-        const int32_t q0 = p1, q1 = __builtin_amdgcn_readlane(myp, j + 2 > 16 ? 16 : j + 2);
+        const int jn = j + 1 < 16 ? j + 1 : 15;
+        int32_t q0 = __builtin_amdgcn_readlane(myp, 2 * jn), q1 = __builtin_amdgcn_readlane(myp, 2 * jn + 1);
+        if (j == 15) q1 = q0;                            // nothing after the last row
+        const int64_t row = row0 + wv + 4 * j;
         bool deferred = false;
-        if (p1 - p0 > thr_long) {
-            const bool mine = wl_append(wl, 1, (int)(wave & (WL_SUB - 1)), lane == 0, (int32_t)(row0 + j));
+        if (p1 - p0 > thr_long && row < M) {
+            const bool mine = wl_append(wl, 1, (int)((blk * 4 + wv) & (WL_SUB - 1)), lane == 0, (int32_t)row);
             deferred = __builtin_amdgcn_readfirstlane((int)mine) != 0;
         }
-        if (deferred || row0 + j >= M) skip |= 1u << j;
+        if (deferred || row >= M) skip |= 1u << j;
         float2 acc[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) acc[u] = make_float2(0.f, 0.f);
         int32_t kn[U];
         float2 vn[U];
         if (!deferred) {
-            // (program order = issue order: the panel rows of row j, then the indices of row j + 1, and the multiply-adds
-            // below only wait for the former -- loads return in order)
+            // (program order = issue order: the panel rows of this row, then the indices of the wave's next row, and the
+            // multiply-adds below only wait for the former -- loads return in order)
             float4 x4[U][2];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -355,7 +358,7 @@ k_csrmm_gather_tile64(int64_t M, int64_t nnz, const int32_t* __restrict__ rowptr
                 acc_nz<CONJ>(acc[2], v[u], make_float2(x4[u][1].x, x4[u][1].y));
                 acc_nz<CONJ>(acc[3], v[u], make_float2(x4[u][1].z, x4[u][1].w));
             }
-            for (int32_t pp = p0 + 4 * U; pp < p1; pp += 4 * U) {        // rows of more than 32 nonzeros: further passes
+            for (int32_t pp = p0 + 4 * U; pp < p1; pp += 4 * U) {        // rows of more than 28 nonzeros: further passes
                 int32_t k2[U];
                 float2 v2[U];
                 load_idx(pp, p1, k2, v2);
@@ -371,20 +374,25 @@ k_csrmm_gather_tile64(int64_t M, int64_t nnz, const int32_t* __restrict__ rowptr
         }
         if (i == 0) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) tile[j * TLD + 4 * c + u] = acc[u];
+            for (int u = 0; u < 4; ++u) tile[(wv + 4 * j) * TLD + 4 * c + u] = acc[u];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) { k[u] = kn[u]; v[u] = vn[u]; }
         p0 = q0; p1 = q1;
     }
-    // the tile leaves as 128-byte lines: lane = (row in tile, column group)
+    // which of the tile's 64 rows are to be stored: wave w's bit j is row w + 4j
+    __shared__ unsigned skip_all[4];
+    if (lane == 0) skip_all[wv] = skip;
+    __syncthreads();
+    // the tile leaves as 128-byte lines: wave w stores rows 16w .. 16w + 15, lane = (row in that group, column group)
     const int cell = lane & 15, cg = lane >> 4;
-    const bool keep = !((skip >> cell) & 1u);
+    const int tr = 16 * wv + cell;                           // row of the tile; computed by wave tr & 3 as its (tr >> 2)-th row
+    const bool keep = !((skip_all[tr & 3] >> (tr >> 2)) & 1u);
 #pragma unroll 4
     for (int it = 0; it < 16; ++it) {
         const int col = cg + 4 * it;
-        float2 out = cmul(alpha, tile[cell * TLD + col]);
-        float2* dst = Y + (int64_t)col * ldy + row0 + cell;
+        float2 out = cmul(alpha, tile[tr * TLD + col]);
+        float2* dst = Y + (int64_t)col * ldy + row0 + tr;
         if (keep) {
             if (BMODE == 1) cfma(out, beta, *dst);
             *dst = out;
@@ -1530,8 +1538,8 @@ int launch_gather(ig_ctx* ctx, int64_t rows, int64_t xrows, int64_t N, int64_t n
                 if (N == 16) IG_GV(4, 4, 8);                                                               // 2 rows per wave
                 else if (N == 32) IG_GV(4, 8, 8);                                                          // a wave per row, 32 nonzeros per trip
                 else if (!wl.yperm && nnz <= 0x7fffffffLL) {
-                    // 64 columns: tiles of 16 rows per wave, software-pipelined (k_csrmm_gather_tile64)
-                    const int64_t tblocks = ((rows + 15) / 16 + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+                    // 64 columns: tiles of 64 rows per workgroup, software-pipelined (k_csrmm_gather_tile64)
+                    const int64_t tblocks = (rows + 63) / 64;
                     IG_REQUIRE(ctx, tblocks <= 0x7fffffffLL, "csrmm: matrix too large for one launch");
                     if (b0) hipLaunchKernelGGL((k_csrmm_gather_tile64<CONJ, 0>), dim3((unsigned)tblocks), dim3(BLK), 0, ctx->stream,
                                 rows, nnz, rowptr, colind, vals, X, Y, ldy, alpha, beta, xcd, wl, thr_long);
