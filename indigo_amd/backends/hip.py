@@ -91,10 +91,12 @@ class HipBackend(Backend):
         # reach the fallback kernels):
         #   bricks        coil counts whose interleaved adjoint gridding is the brick-binned scatter (others: gather over G'^T)
         #   support_tile  kx points per entry of the fine k-space support table of coil-interleaved trees (16: one table only)
-        #   brick_shape   (grid lines, slabs, heavy-brick piece, entries per run) of the binned format
+        #   brick_shape   per coil count: (grid lines, slabs, heavy-brick piece, entries per run) of the binned format.  Four coils
+        #                 pad a sample's share of a brick to 16 entries: bricks of 16 x 2 x 4 cells waste less than 16 x 2 x 2 (0.61
+        #                 against 0.68 ms; profiles/r03_brick_shape_sweep.txt)
         #   xrows         wide panels (16..64 columns): repack only the panel rows the matrix touches (forward)
         #   wide_bricks   64-column column-major panels: brick scatter through LDS (adjoint)
-        self.tuning = dict(bricks=(4, 8), support_tile=8, brick_shape=(2, 2, 4096, 4096), xrows=True, wide_bricks=True)
+        self.tuning = dict(bricks=(4, 8), support_tile=8, brick_shape={8: (2, 2, 4096, 4096), 4: (2, 4, 4096, 4096)}, xrows=True, wide_bricks=True)
 
     def __del__(self):
         try:

@@ -151,7 +151,9 @@ def assemble(backend, Gm, oN, N, weights_of, Cn, layout, chunks, table=None, box
             # adjoint gridding by grid bricks (a scatter binned on the host) instead of a gather over the transposed matrix.
             # Measured (config 4): 8 coils 0.91 ms against 1.82 ms (gather + its deferred long rows); 4 coils 0.68 against
             # 1.05 ms.  Two coils or one would pad every sample's share of a brick to 32 / 64 entries: they keep the gather.
-            G._grid_bricks = (int(oN[0]), int(oN[2]), int(oN[1]), bricks_cols) + tuple(tuning.get('brick_shape', (2, 2, 4096, 4096)))
+            shape = tuning.get('brick_shape', {})
+            shape = shape.get(bricks_cols, (2, 2, 4096, 4096)) if isinstance(shape, dict) else shape
+            G._grid_bricks = (int(oN[0]), int(oN[2]), int(oN[1]), bricks_cols) + tuple(shape)
         return G
 
     sizes = {hi - lo for lo, hi in chunks if hi - lo > 1}
