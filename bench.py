@@ -27,7 +27,7 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                      live with HIP events on the backend's stream; `traffic` = HBM bytes per launch from the
                      committed rocprofv3 PMC summary of this same command (profiles/)
   cpu_baseline     : the numpy oracle (restatement of the reference's numpy backend) timed on the host on ONE coil
-                     of the same problem (warm-up + min of 2), scaled to evals/s; single-threaded, baseline only
+                     of the same problem (warm-up + min of 3), scaled to evals/s; single-threaded, baseline only
   parity_rel_err   : the benchmarked operator with all coils but one switched off vs that oracle evaluation and vs a
                      double-precision evaluation of the same operator (the complex64 oracle is itself only good to
                      ~2.6e-5 on this DC-heavy input, oracle/precise.py)
@@ -440,7 +440,7 @@ def cpu_baseline_and_parity(p, C, B, layout, y_dev):
     x = O.copy_array(xh)
     y = O.zero_array((A1.shape[1], 1), np.dtype('complex64'))
     times = []
-    for i in range(3):                      # first = warm-up (scipy/pocketfft plan caches, page faults)
+    for i in range(4):                      # first = warm-up (scipy/pocketfft plan caches, page faults); ~25 s of CPU work in all
         t1 = time.perf_counter()
         AHA1.eval(y, x)
         times.append(time.perf_counter() - t1)
@@ -449,7 +449,7 @@ def cpu_baseline_and_parity(p, C, B, layout, y_dev):
     ref = y.to_host()
     cpu = dict(value=1.0 / (C * t), unit="evals/s", cores=1, kind="port", **host_info(),
                sample="numpy oracle (restatement of indigo/backends/np.py: np.fft.fftn + scipy csr @), 1 of %d coils of the same problem, "
-                      "1 warm-up + min of 2 evaluations (%.1f s each), scaled linearly in coils" % (C, t))
+                      "1 warm-up + min of 3 evaluations (%.1f s each), scaled linearly in coils" % (C, t))
     parity = None
     if layout is not None:
         zero = np.zeros(p.N, dtype=np.complex64, order='F')

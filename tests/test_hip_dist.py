@@ -158,3 +158,64 @@ def test_rccl_communicator_through_the_c_abi(torch_first):
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-4000:]
     if torch_first == "1":
         assert "already loaded" in r.stdout, r.stdout[-2000:]          # the library reused torch's RCCL, it did not load a second one
+
+
+TWO_RANK_WORKER = r"""
+import os, sys
+sys.path.insert(0, os.environ["REPO_ROOT"])
+import numpy as np
+from indigo_amd.backends import get_backend
+from indigo_amd.dist import RcclComm, ShardedNormalOperator, coil_range
+from indigo_amd.sense import SenseProblem, normal_operator
+from indigo_amd.util import rand64c
+rank, world = int(os.environ["RANK"]), 2
+B = get_backend("hip", device_id=rank)
+comm = RcclComm(B, rank, world)
+p = SenseProblem.synthetic((128, 128, 128), 8, nspokes=200, nreadout=256, width=2, oversamp=2.0, seed=5)
+c64 = np.dtype("complex64")
+xs = B.copy_array(rand64c(int(np.prod(p.N)), 1, seed=2))
+A = p.build_zpadfft(B, coils=coil_range(8, rank, world))
+y = B.zero_array((A.shape[1], 1), c64)
+op = ShardedNormalOperator(A, comm, lamda=0.1, nslabs=4)
+assert op._leaf is not None                 # the slab route, for real this time
+op.eval(y, xs)
+got = y.to_host()
+B._scratch = None
+del A, op
+Afull = p.build_zpadfft(B)                  # the unsharded operator on this rank's GPU
+y2 = B.zero_array((Afull.shape[1], 1), c64)
+normal_operator(Afull, lamda=0.1).eval(y2, xs)
+ref = y2.to_host()
+err = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+assert err < 1e-5, err
+comm.barrier()
+comm.close()
+print("OK rank", rank, err)
+"""
+
+
+def test_two_rccl_ranks_against_the_unsharded_operator(tmp_path):
+    """two processes, two GPUs, the library's own RCCL communicator: the coil-sharded normal operator with the slab-overlapped
+    all-reduce equals the unsharded one on every rank.  Needs two GPUs: skipped on the one-GPU boxes this suite usually runs on."""
+    import ctypes
+    from indigo_amd import _lib
+    n = ctypes.c_int()
+    _lib.lib().ig_device_count(ctypes.byref(n))
+    if n.value < 2:
+        pytest.skip("needs two GPUs (this box has %d)" % n.value)
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, REPO_ROOT=ROOT, RANK=str(rank), WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   INDIGO_COMM_ID_FILE=str(tmp_path / "rccl_id"))
+        env.pop("INDIGO_HIP_WITH_TORCH", None)
+        procs.append(subprocess.Popen([sys.executable, "-c", TWO_RANK_WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("two-rank RCCL workers timed out")
+        outs.append(o)
+    assert all(p.returncode == 0 and "OK rank" in o for p, o in zip(procs, outs)), "\n".join(o[-3000:] for o in outs)
