@@ -90,7 +90,7 @@ def kernel_symbols(layout, ncoils, half_box=True, n=512, support_tile=16):
                       "fft_pad_y": f % "32, false, 0, true, 0", "fft_pad_z": f % "16, false, 0, true, 0",
                       "fft_crop_z": f % "16, false, 0, true, 0", "fft_crop_y": f % "32, false, 0, true, 0",
                       "fft_crop_x": f % ("16, false, %d, true, 0" % (3 + lg))})
-        m.update({"csrmm_rowlane_conj": "k_csrmm_dense64<%d, true, true>" % ncoils, "csrmm_gather": gv,
+        m.update({"csrmm_rowlane_conj": "k_csrmm_dense64<%d, true, true>" % ncoils, "csrmm_gather": gv, "csrmm_slots_conj": "k_grid_slots<%d>" % ncoils,
                   # (second argument: segments per 16 x 2 x 2 brick, unrolled for the 8-coil kernel)
                   "csrmm_bricks_conj": "k_grid_bricks<%d, %d>" % (ncoils, (16 // support_tile) * 4 if ncoils == 8 else 0)})
     elif layout == 1:
@@ -98,7 +98,7 @@ def kernel_symbols(layout, ncoils, half_box=True, n=512, support_tile=16):
         m.update({"fft_pad_x": f % ("16, true, 1, true, %d" % h[0]), "fft_pad_y": f % ("16, false, 0, true, %d" % h[1]),
                   "fft_pad_z": f % ("16, false, 0, true, %d" % h[2]), "fft_crop_z": f % ("16, false, 0, true, %d" % h[3]),
                   "fft_crop_y": f % ("16, false, 0, true, %d" % h[4]), "fft_crop_x": f % ("16, true, 2, true, %d" % h[5]),
-                  "csrmm_rowlane_conj": "k_csrmm_dense64<%d, true, false>" % ncoils})
+                  "csrmm_rowlane_conj": "k_csrmm_dense64<%d, true, false>" % ncoils, "csrmm_slots_conj": "k_grid_slots<%d>" % ncoils})
     return m
 
 
@@ -361,7 +361,8 @@ def run_sense(args, cfg, B, comm, world, rank, steps, warmup, want_cpu, quiet=Fa
     csr = {(r['name'], r['forward']): r['nbytes'] for r in trace.records if r['event'] == 'csrmm' and not r.get('fused')}
     sup_tab, sup_tile = getattr(p, 'last_support_fine', None) or (getattr(p, 'last_support_table', None), 16)
     grid_bytes = p.gridding_pass_bytes(cpr, sup_tab, tile=sup_tile) if fused_fft else {}
-    for site, fwd in (("csrmm_gather", True), ("csrmm_rowlane_conj", False), ("csrmm_gather_conj", False), ("csrmm_bricks_conj", False)):
+    for site, fwd in (("csrmm_gather", True), ("csrmm_rowlane_conj", False), ("csrmm_gather_conj", False), ("csrmm_bricks_conj", False),
+                      ("csrmm_slots_conj", False)):
         nb = csr.get(('interp*mod*scale', fwd))
         if site in prof and nb:
             # SpMM GB/s two ways: the reference's model (operators.py:246-256) and the bytes this kernel must move

@@ -248,6 +248,19 @@ int  ig_ccsrmm_t_bricks(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, float alph
                         const int16_t* support, int64_t n0, int64_t nm, int bm, int bs, const int32_t* tasks, int64_t ntasks,
                         const int32_t* brick_table, const int32_t* shared_bricks, int64_t nshared, int support_tile);
 
+/* The brick scatter for interleaved panels of 1, 2 or 4 columns (the ranks of a coil-sharded run that hold few coils): a
+ * lane is an ENTRY and loops over the columns; race-freedom comes from the ORDER of the entries.  ig_grid_slots_build (host)
+ * reorders the unpadded brick format (ig_grid_bricks_count / _fill with unit = 1) inside every brick by (occurrence of the
+ * cell, cell) and cuts it into SLOTS of at most 64 entries with distinct cells: 16-byte entries {cell, re, im, row of X},
+ * slots per brick, nslots + 1 offsets (slot_ptr: room for nentries + 1).  ig_ccsrmm_t_slots runs it: tasks / brick_table /
+ * shared_bricks as for ig_ccsrmm_t_bricks with slots in place of entries.  No padding, no transposed matrix.              */
+int  ig_grid_slots_build(int64_t nbricks, const int64_t* brick_ptr, const void* entries12, const uint32_t* entry_rows, int ncell,
+                         void* entries16, int32_t* brick_slots, int32_t* slot_ptr, int64_t* nslots);
+int  ig_ccsrmm_t_slots(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, float alpha_re, float alpha_im,
+                       const void* entries16, const int32_t* slot_ptr, const void* X, int64_t ldx, void* Y_il,
+                       const int16_t* support, int64_t n0, int64_t nm, int bm, int bs, const int32_t* tasks, int64_t ntasks,
+                       const int32_t* brick_table, const int32_t* shared_bricks, int64_t nshared, int support_tile);
+
 /* The same scatter for the reference's own panel layout, 64 columns: Y(K x 64, column-major, ldy) = alpha * A^H * X(M x 64,
  * column-major, ldx) for ANY CSR matrix with K a multiple of 16 (beta == 0: Y is zeroed first).  Bricks are 16 consecutive
  * rows of Y: ig_grid_bricks_count / _fill with (n0, nm, ns) = (K, 1, 1), bm = bs = 1, unit = 1 give `entries` (12 bytes:

@@ -77,6 +77,9 @@ PROTOTYPES = {
                                    c_float, c_float, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_int64, c_float, c_float, c_void_p, c_int64,
                                    c_void_p, c_int64, c_int64, c_void_p]),
+    "ig_grid_slots_build": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, POINTER(c_int64)]),
+    "ig_ccsrmm_t_slots":  (c_int, [c_void_p, c_int64, c_int64, c_int64, c_float, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
+                                   c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int]),
     "ig_ccsrmm_t_bricks_wide": (c_int, [c_void_p, c_int64, c_int64, c_float, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                         c_void_p, c_int64, c_void_p, c_void_p]),
     "ig_fft_set_support_tile": (c_int, [c_void_p, c_int]),

@@ -96,7 +96,9 @@ class HipBackend(Backend):
         #                 against 0.68 ms; profiles/r03_brick_shape_sweep.txt)
         #   xrows         wide panels (16..64 columns): repack only the panel rows the matrix touches (forward)
         #   wide_bricks   64-column column-major panels: brick scatter through LDS (adjoint)
-        self.tuning = dict(bricks=(4, 8), support_tile=8, brick_shape={8: (2, 2, 4096, 4096), 4: (2, 4, 4096, 4096)}, xrows=True, wide_bricks=True)
+        #   slots         coil counts whose adjoint gridding is the slot-format scatter (ig_ccsrmm_t_slots): the ranks of a coil-sharded
+        #                 run with one or two coils
+        self.tuning = dict(bricks=(4, 8), slots=(1, 2), slot_shape=(4, 4, 256, 64), support_tile=8, brick_shape={8: (2, 2, 4096, 4096), 4: (2, 4, 4096, 4096)}, xrows=True, wide_bricks=True)
 
     def __del__(self):
         try:
@@ -736,6 +738,51 @@ class HipBackend(Backend):
                                 rounds=b.copy_array(round_rows, name=self._name + ".brickRoundRows"),
                                 shared=b.copy_array(shared if shared.size else np.zeros(1, np.int32), name=self._name + ".sharedBricks"))
 
+        def set_grid_slots(self, n0, nm, ns, ncols=1, bm=2, bs=2, chunk=256, run=128):
+            """The slot format of ig_ccsrmm_t_slots for an `ncols`-column panel (1, 2 or 4): the nonzeros binned by 16 x bm x bs
+            bricks of the n0 x nm x ns grid WITHOUT padding (ig_grid_bricks_count / _fill, unit 1), reordered inside every brick so
+            that a slot of at most 64 entries never holds a cell twice (ig_grid_slots_build), tasks = runs of about `run` slots
+            of consecutive bricks, heavy bricks (more than `chunk` slots) cut into shared pieces."""
+            b = self._backend
+            A = self._host_csr
+            assert A is not None and A.shape[1] == n0 * nm * ns and ncols in (1, 2, 4)
+            indptr = np.ascontiguousarray(A.indptr, dtype=np.int32)
+            indices = np.ascontiguousarray(A.indices, dtype=np.int32)
+            data = np.ascontiguousarray(A.data, dtype=_C64)
+            nb = (n0 // 16) * (nm // bm) * (ns // bs)
+            counts = np.zeros(nb, dtype=np.int32)
+            if b._L.ig_grid_bricks_count(A.shape[0], indptr.ctypes.data, indices.ctypes.data, n0, nm, ns, bm, bs, 1, counts.ctypes.data) != 0 \
+                    or int(counts.sum(dtype=np.int64)) * 16 >= 2 ** 31:
+                log.info("%s: no slot format; the adjoint keeps the gather route", self._name)
+                self._slots = None
+                return
+            ptr = np.zeros(nb + 1, dtype=np.int64)
+            np.cumsum(counts, out=ptr[1:])
+            nent = int(ptr[-1])
+            e12 = np.empty((max(nent, 1), 3), dtype=np.uint32)
+            rows = np.empty(max(nent, 1), dtype=np.uint32)
+            _lib.check(b._L.ig_grid_bricks_fill(A.shape[0], indptr.ctypes.data, indices.ctypes.data, data.ctypes.data, n0, nm, ns, bm, bs, 1,
+                                                ptr.ctypes.data, e12.ctypes.data, rows.ctypes.data), None, "ig_grid_bricks_fill")
+            e16 = np.empty((max(nent, 1), 4), dtype=np.uint32)
+            brick_slots = np.zeros(nb, dtype=np.int32)
+            slot_ptr = np.empty(nent + 1, dtype=np.int32)
+            nslots = ctypes.c_int64()
+            _lib.check(b._L.ig_grid_slots_build(nb, ptr.ctypes.data, e12.ctypes.data, rows.ctypes.data, 16 * bm * bs, e16.ctypes.data,
+                                                brick_slots.ctypes.data, slot_ptr.ctypes.data, ctypes.byref(nslots)), None, "ig_grid_slots_build")
+            del e12, rows
+            sptr = np.zeros(nb + 1, dtype=np.int64)
+            np.cumsum(brick_slots, out=sptr[1:])
+            sup = getattr(self, '_support', None)
+            nseg = bm * bs                                    # (the 16-point support table: one segment per brick row)
+            tasks, table, shared = brick_tasks(brick_slots, sptr, chunk, run, max_bricks=min(64, 512 // nseg))
+            self._slots = dict(n0=int(n0), nm=int(nm), bm=int(bm), bs=int(bs), ncols=int(ncols), ntasks=int(tasks.shape[0]),
+                               nshared=int(shared.size), nslots=int(nslots.value), nentries=nent,
+                               tasks=b.copy_array(tasks.reshape(-1) if tasks.size else np.zeros(4, np.int32), name=self._name + ".slotTasks"),
+                               table=b.copy_array(table.reshape(-1) if table.size else np.zeros(2, np.int32), name=self._name + ".slotTable"),
+                               entries=b.copy_array(e16.reshape(-1), name=self._name + ".slotEntries"),
+                               slot_ptr=b.copy_array(slot_ptr[:int(nslots.value) + 1].copy(), name=self._name + ".slotPtr"),
+                               shared=b.copy_array(shared if shared.size else np.zeros(1, np.int32), name=self._name + ".slotSharedBricks"))
+
         def _wide_bricks(self):
             """The matrix binned by bricks of 16 consecutive columns, 12-byte entries {column inside the brick, re, im} + their rows:
             the format of ig_ccsrmm_t_bricks_wide (adjoint of a 64-column column-major panel as a scatter through LDS).
@@ -871,6 +918,19 @@ class HipBackend(Backend):
                                                  br['n0'], br['nm'], br['bm'], br['bs'], ctypes.c_void_p(br['tasks']._arr), br['ntasks'],
                                                  ctypes.c_void_p(br['table']._arr), ctypes.c_void_p(br['shared']._arr), br['nshared'], tile),
                          "ig_ccsrmm_t_bricks")
+                return
+            sl = getattr(self, '_slots', None)
+            if sl is not None and perm is None and beta == 0 and y.contiguous and x.shape[1] == sl['ncols'] and sl['ntasks'] > 0:
+                tab = sup[0] if sup is not None else None
+                if tab is None:
+                    y._zero()
+                ar, ai = _cplx(alpha)
+                m, k = self.shape
+                b._check(b._L.ig_ccsrmm_t_slots(b._ctx, m, k, x.shape[1], ar, ai, ctypes.c_void_p(sl['entries']._arr), ctypes.c_void_p(sl['slot_ptr']._arr),
+                                                ctypes.c_void_p(x._arr), x._leading_dim, ctypes.c_void_p(y._arr),
+                                                ctypes.c_void_p(tab._arr) if tab is not None else None, sl['n0'], sl['nm'], sl['bm'], sl['bs'],
+                                                ctypes.c_void_p(sl['tasks']._arr), sl['ntasks'], ctypes.c_void_p(sl['table']._arr),
+                                                ctypes.c_void_p(sl['shared']._arr), sl['nshared'], 16), "ig_ccsrmm_t_slots")
                 return
             if (x.shape[1] == 64 and beta == 0 and perm is None and not getattr(self, '_grid_il', False) and self.shape[1] % 16 == 0
                     and self.shape[1] > 0 and self.shape[0] * 512 < 2 ** 31 and self.values.size >= self.shape[1] // 4

@@ -1185,6 +1185,149 @@ k_grid_bricks(const BrickTask* __restrict__ tasks, int ntasks, const BrickRef* _
     flush();
 }
 
+// ---- the brick scatter for panels of 1, 2 or 4 columns: SLOTS instead of rounds ------------------------------------------
+// With NC columns a round holds 64 / NC entries of ONE sample, and a sample leaves ~6 entries in a 16 x 2 x 2 brick: at 4 columns
+// the padded format is 2.3x the nonzeros, at 2 and 1 it would be 5x and 11x -- which is why the ranks of a coil-sharded run
+// that hold one or two coils used to gather over the transposed matrix instead (0.77 - 0.83 ms of their 2.2 - 3.1 ms).
+// Here a lane is an ENTRY and loops over the NC columns itself.  What makes a wave instruction race-free is the order of
+// the entries: the host sorts every brick's entries by (occurrence of their cell, cell) -- the k-th nonzero that falls on a
+// cell goes into group k -- so a group never holds a cell twice; a SLOT is a group (or a piece of at most 64 entries of one).
+// No padding at all: 16-byte entries {cell, re, im, sample} and one int32 offset per slot.  The lanes of a slot are often few
+// (a brick a single trajectory crosses has many cells hit twice or thrice: 5 slots of ~18 entries), but a slot is ~30
+// instructions and there are few of them.  Entries are requested two slots ahead, the panel rows of their samples one.
+struct SlotEntry { uint32_t cell; float re, im; uint32_t row; };
+
+template <int NC>
+__global__ void __launch_bounds__(BLK)
+k_grid_slots(const BrickTask* __restrict__ tasks, int ntasks, const BrickRef* __restrict__ btab,
+             const int32_t* __restrict__ slot_ptr, const SlotEntry* __restrict__ entries,
+             const float2* __restrict__ Xp /* packed rows: [t][NC] */, float2* __restrict__ Y, float2 alpha,
+             const uint32_t* __restrict__ bits, int n0, int nm, int bm_log2, int bs_log2, int nbx, int nbm, int st_log2) {
+    extern __shared__ float2 acc_all[];                  // per wave: [cells][NC]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int task = blockIdx.x * WAVES_PER_BLOCK + wv;
+    if (task >= ntasks) return;
+    const BrickTask tk = tasks[task];
+    const int nb = tk.nb_flags & 0xffff;
+    const bool shared = (tk.nb_flags >> 16) & 1;
+    const int32_t nslot = tk.hi - tk.lo;
+    const int xs_log2 = 4 - st_log2, seg_log2 = xs_log2 + bm_log2 + bs_log2;
+    const int BM = 1 << bm_log2, nseg = 1 << seg_log2, ncell = 16 << (bm_log2 + bs_log2);
+    float2* __restrict__ acc = acc_all + (size_t)wv * ncell * NC;
+    // the run's bricks, one per lane: where each ends (in slots of this task), its first grid point, its flagged segments
+    const float2 my_ref = buf_ld<false>(make_rsrc(btab + tk.bt), lane < nb ? (unsigned)lane * 8u : IG_OOB, 0);
+    int my_end = 0x7fffffff, my_pt = 0, my_bx = 0, my_m0 = 0, my_s0 = 0;
+    if (lane < nb) {
+        const int brick = (int)__float_as_uint(my_ref.x);
+        if (!shared) my_end = (int)__float_as_uint(my_ref.y) - tk.lo;
+        my_bx = brick % nbx;
+        my_m0 = ((brick / nbx) % nbm) << bm_log2;
+        my_s0 = (brick / (nbx * nbm)) << bs_log2;
+        my_pt = my_bx * 16 + n0 * (my_m0 + nm * my_s0);
+    }
+    uint32_t my_mask = 0xffffffffu;
+    if (bits) {
+        const int nt = n0 >> st_log2;
+        const rsrc_t r_bits = make_rsrc(bits);
+        uint32_t w[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int pair = p * 64 + lane, j = pair >> seg_log2, seg = pair & (nseg - 1);
+            const int jbx = __shfl(my_bx, j & 63), jm0 = __shfl(my_m0, j & 63), js0 = __shfl(my_s0, j & 63);
+            const int xs = seg & ((1 << xs_log2) - 1), im = (seg >> xs_log2) & (BM - 1), is = seg >> (xs_log2 + bm_log2);
+            const int km = jm0 + im, ks = js0 + is;
+            w[p] = (uint32_t)buf_ld_i32(r_bits, j < nb ? (unsigned)((ks * nt + (jbx << xs_log2) + xs) * 16 + (km & 15)) * 4u : IG_OOB) >> (km >> 4);
+        }
+        my_mask = 0u;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const uint64_t bal = __ballot(w[p] & 1u);
+            const int first = (p * 64) >> seg_log2, per = 64 >> seg_log2;
+            if (lane >= first && lane < first + per)
+                my_mask = (uint32_t)(bal >> ((lane - first) << seg_log2)) & (nseg == 32 ? 0xffffffffu : (1u << nseg) - 1u);
+        }
+    }
+    for (int e = lane; e < ncell * NC; e += 64) acc[e] = make_float2(0.f, 0.f);
+
+    int cur = 0;
+    int32_t cur_end = __builtin_amdgcn_readlane(my_end, 0);
+    auto flush = [&]() {
+        const int pt = __builtin_amdgcn_readlane(my_pt, cur);
+        const uint32_t mask = (uint32_t)__builtin_amdgcn_readlane((int)my_mask, cur);
+        for (int seg = 0; seg < nseg; ++seg) {
+            if (!((mask >> seg) & 1u)) continue;
+            const int xs = seg & ((1 << xs_log2) - 1), im = (seg >> xs_log2) & (BM - 1), is = seg >> (xs_log2 + bm_log2);
+            const int cell0 = (xs << st_log2) + 16 * (im + BM * is);
+            float2* src = acc + (size_t)cell0 * NC;
+            float2* dst = Y + ((int64_t)pt + (xs << st_log2) + (int64_t)n0 * (im + (int64_t)nm * is)) * NC;
+            const int nel = NC << st_log2;
+            for (int e = lane; e < nel; e += 64) {
+                const float2 o = cmul(alpha, src[e]);
+                if (shared) {
+                    asm volatile("global_atomic_add_f32 %0, %1, off\n\tglobal_atomic_add_f32 %0, %2, off offset:4"
+                                 :: "v"(dst + e), "v"(o.x), "v"(o.y) : "memory");
+                } else {
+                    asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(dst + e), "v"(o) : "memory");
+                }
+                src[e] = make_float2(0.f, 0.f);
+            }
+        }
+        ++cur;
+        cur_end = __builtin_amdgcn_readlane(my_end, cur & 63);
+    };
+
+    // slot offsets: lane l holds slot_ptr[tk.lo + base + l] for a window of 64 slots (63 usable: a slot needs its end too)
+    const rsrc_t r_sp = make_rsrc(slot_ptr + tk.lo), r_en = make_rsrc(entries), r_x = make_rsrc(Xp);
+    struct XV { float2 v[NC]; };
+    auto load_entry = [&](int32_t off, int32_t n) -> SlotEntry {
+        const float4 q = buf_ld_f4(r_en, lane < n ? (unsigned)(off + lane) * 16u : IG_OOB);
+        SlotEntry e;
+        e.cell = lane < n ? __float_as_uint(q.x) : 0xffffffffu; e.re = q.y; e.im = q.z; e.row = __float_as_uint(q.w);
+        return e;
+    };
+    auto load_x = [&](const SlotEntry& e) -> XV {
+        XV x;
+        const unsigned o = e.cell != 0xffffffffu ? e.row * (unsigned)(NC * 8) : IG_OOB;
+        if (NC == 1) x.v[0] = buf_ld<false>(r_x, o, 0);
+        else {
+#pragma unroll
+            for (int c = 0; c < NC; c += 2) {
+                const float4 q = buf_ld_f4(r_x, o == IG_OOB ? IG_OOB : o + (unsigned)c * 8u);
+                x.v[c] = make_float2(q.x, q.y); x.v[c + 1] = make_float2(q.z, q.w);
+            }
+        }
+        return x;
+    };
+    for (int32_t base = 0; base < nslot; base += 63) {
+        const int32_t left = nslot - base, cnt = left < 63 ? left : 63;           // slots of this window
+        const int32_t sp = buf_ld_i32(r_sp, lane <= cnt ? (unsigned)(base + lane) * 4u : IG_OOB);
+        auto slot_off = [&](int i) { return __builtin_amdgcn_readlane(sp, i); };
+        SlotEntry e0 = load_entry(slot_off(0), slot_off(1) - slot_off(0));
+        SlotEntry e1 = cnt > 1 ? load_entry(slot_off(1), slot_off(2) - slot_off(1)) : SlotEntry{0xffffffffu, 0.f, 0.f, 0u};
+        XV x0 = load_x(e0);
+#pragma unroll 1
+        for (int i = 0; i < cnt; ++i) {
+            SlotEntry e2{0xffffffffu, 0.f, 0.f, 0u};
+            if (i + 2 < cnt) e2 = load_entry(slot_off(i + 2), slot_off(i + 3) - slot_off(i + 2));
+            const XV x1 = load_x(e1);                                            // (an empty slot: every lane out of range)
+            if (base + i >= cur_end) flush();                                   // this slot belongs to the next brick
+            if (e0.cell != 0xffffffffu) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    float2* a = acc + (int)e0.cell * NC + c;
+                    float2 t = *a;                                               // the cells of a slot are distinct
+                    t.x += fmaf(e0.re, x0.v[c].x, e0.im * x0.v[c].y);            // conj(v) * x
+                    t.y += fmaf(e0.re, x0.v[c].y, -e0.im * x0.v[c].x);
+                    *a = t;
+                }
+            }
+            e0 = e1; e1 = e2; x0 = x1;
+        }
+    }
+    flush();
+}
+
 // ---- the same scatter for a 64-column panel at the reference boundary (column-major Y) -----------------------------
 // Y(K x 64, column-major) = alpha * A^H X for any CSR whose K is a multiple of 16: bricks of 16 consecutive rows of Y,
 // 12-byte entries {row of Y inside the brick, re, im} in brick order plus the row of X of every entry (no padding: a round
@@ -2012,6 +2155,141 @@ int ig_ccsrmm_t_bricks(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, float ar, f
     else IG_BRICKS(4, 0);
 #undef IG_BRICKS
     IG_LAUNCH_CHECK(ctx, "k_grid_bricks");
+    return IG_OK;
+}
+
+// Slot format of k_grid_slots from the UNPADDED brick format (ig_grid_bricks_count / _fill with unit = 1: entries12 in brick
+// order, entry_rows = the sample of every entry, brick_ptr = prefix sums): inside every brick the entries are reordered by
+// (occurrence of their cell, cell) and cut into slots of at most 64.  Outputs: entries16 (one per entry), brick_slots (slots
+// per brick), slot_ptr (nslots + 1 offsets into entries16; sized nentries + 1 by the caller), *nslots.
+int ig_grid_slots_build(int64_t nbricks, const int64_t* brick_ptr, const void* entries12, const uint32_t* entry_rows, int ncell,
+                        void* entries16, int32_t* brick_slots, int32_t* slot_ptr, int64_t* nslots) {
+    if (nbricks < 0 || !brick_ptr || ncell < 1 || ncell > 1024 || !brick_slots || !slot_ptr || !nslots ||
+        (brick_ptr[nbricks] > 0 && (!entries12 || !entry_rows || !entries16)) || brick_ptr[nbricks] > 0x7fffffffLL)
+        return ig_fail(nullptr, IG_ERR_ARG, "ig_grid_slots_build: bad arguments");
+    const BrickEntry* in = (const BrickEntry*)entries12;
+    SlotEntry* out = (SlotEntry*)entries16;
+    const int nt = brick_threads(nbricks * 8);
+    const int64_t per = (nbricks + nt - 1) / nt;
+    int bad = 0;
+    // pass 1: slots per brick (the group sizes: how many cells are hit at least k + 1 times)
+    run_threads(nt, [&](int th) {
+        std::vector<int32_t> mult((size_t)ncell), gsize;
+        const int64_t lo = std::min<int64_t>(nbricks, th * per), hi = std::min<int64_t>(nbricks, lo + per);
+        for (int64_t b = lo; b < hi; ++b) {
+            const int64_t p0 = brick_ptr[b], p1 = brick_ptr[b + 1];
+            if (p1 == p0) { brick_slots[b] = 0; continue; }
+            std::fill(mult.begin(), mult.end(), 0);
+            gsize.clear();
+            for (int64_t p = p0; p < p1; ++p) {
+                const uint32_t c = in[p].cell;
+                if (c >= (uint32_t)ncell) { bad = 1; continue; }
+                const int k = mult[c]++;
+                if ((size_t)k >= gsize.size()) gsize.push_back(0);
+                ++gsize[k];
+            }
+            int64_t ns = 0;
+            for (int32_t g : gsize) ns += (g + 63) / 64;
+            brick_slots[b] = (int32_t)ns;
+        }
+    });
+    if (bad) return ig_fail(nullptr, IG_ERR_ARG, "ig_grid_slots_build: a cell index outside the brick");
+    std::vector<int64_t> first((size_t)nbricks + 1, 0);
+    for (int64_t b = 0; b < nbricks; ++b) first[b + 1] = first[b] + brick_slots[b];
+    if (first[nbricks] > 0x7fffffffLL) return ig_fail(nullptr, IG_ERR_ARG, "ig_grid_slots_build: more than 2^31 - 1 slots");
+    *nslots = first[nbricks];
+    // pass 2: reorder and emit the slot offsets
+    run_threads(nt, [&](int th) {
+        std::vector<int32_t> mult((size_t)ncell), gstart;
+        std::vector<int32_t> gsize;
+        const int64_t lo = std::min<int64_t>(nbricks, th * per), hi = std::min<int64_t>(nbricks, lo + per);
+        for (int64_t b = lo; b < hi; ++b) {
+            const int64_t p0 = brick_ptr[b], p1 = brick_ptr[b + 1];
+            if (p1 == p0) continue;
+            std::fill(mult.begin(), mult.end(), 0);
+            gsize.clear();
+            for (int64_t p = p0; p < p1; ++p) {
+                const int k = mult[in[p].cell]++;
+                if ((size_t)k >= gsize.size()) gsize.push_back(0);
+                ++gsize[k];
+            }
+            gstart.assign(gsize.size() + 1, 0);
+            for (size_t k = 0; k < gsize.size(); ++k) gstart[k + 1] = gstart[k] + gsize[k];
+            int64_t s = first[b];
+            for (size_t k = 0; k < gsize.size(); ++k)
+                for (int32_t o = 0; o < gsize[k]; o += 64) slot_ptr[s++] = (int32_t)(p0 + gstart[k] + o);
+            std::fill(mult.begin(), mult.end(), 0);
+            std::vector<int32_t> cursor(gstart.begin(), gstart.end() - 1);
+            for (int64_t p = p0; p < p1; ++p) {
+                const int k = mult[in[p].cell]++;
+                SlotEntry e; e.cell = in[p].cell; e.re = in[p].re; e.im = in[p].im; e.row = entry_rows[p];
+                out[p0 + cursor[k]++] = e;
+            }
+        }
+    });
+    slot_ptr[first[nbricks]] = (int32_t)brick_ptr[nbricks];
+    return IG_OK;
+}
+
+// Y_il(grid x N, rows interleaved) = alpha * G^H X for N = 1, 2 or 4 columns through the slot format (k_grid_slots); tasks and
+// brick_table as for ig_ccsrmm_t_bricks with SLOTS in place of entries.  support / shared_bricks as there.
+int ig_ccsrmm_t_slots(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, float ar, float ai,
+                      const void* entries16, const int32_t* slot_ptr, const void* X, int64_t ldx, void* Y_il, const int16_t* support,
+                      int64_t n0, int64_t nm, int bm, int bs, const int32_t* tasks, int64_t ntasks, const int32_t* brick_table,
+                      const int32_t* shared_bricks, int64_t nshared, int support_tile) {
+    IG_REQUIRE(ctx, ctx != nullptr, "ig_ccsrmm_t_slots: ctx is NULL");
+    IG_REQUIRE(ctx, M >= 0 && K >= 0 && M <= 0x7fffffffLL, "ig_ccsrmm_t_slots: bad dimensions");
+    IG_REQUIRE(ctx, N == 1 || N == 2 || N == 4, "ig_ccsrmm_t_slots: 1, 2 or 4 columns (got %lld)", (long long)N);
+    IG_REQUIRE(ctx, (ntasks == 0 || (entries16 && slot_ptr)) && (M == 0 || X) && (K == 0 || Y_il) && ldx >= M, "ig_ccsrmm_t_slots: NULL array or short leading dimension");
+    IG_REQUIRE(ctx, n0 > 0 && nm > 0 && K % (n0 * nm) == 0 && K < 0x7fffffffLL && bricks_ok(n0, nm, K / (n0 * nm), bm, bs, 1) && bm * bs <= 32,
+               "ig_ccsrmm_t_slots: rows (%lld) are not a grid of n0=%lld x nm=%lld x ... that divides into 16 x %d x %d bricks", (long long)K, (long long)n0, (long long)nm, bm, bs);
+    const int64_t ns = K / (n0 * nm);
+    IG_REQUIRE(ctx, !support || (nm % 16 == 0 && nm <= 512), "ig_ccsrmm_t_slots: the support table needs nm %% 16 == 0 and nm <= 512");
+    IG_REQUIRE(ctx, support_tile == 16 || support_tile == 8 || support_tile == 4, "ig_ccsrmm_t_slots: support_tile %d", support_tile);
+    IG_REQUIRE(ctx, (16 / support_tile) * bm * bs <= 32, "ig_ccsrmm_t_slots: at most 32 segments per brick");
+    const int st_log2 = support_tile == 16 ? 4 : support_tile == 8 ? 3 : 2;
+    IG_REQUIRE(ctx, ntasks >= 0 && ntasks <= 0x7fffffffLL && (ntasks == 0 || (tasks && brick_table)) && nshared >= 0 && (nshared == 0 || shared_bricks), "ig_ccsrmm_t_slots: bad task list");
+    IG_REQUIRE(ctx, M * N * 8 < 0x7fffffffLL, "ig_ccsrmm_t_slots: the panel exceeds the 2 GB window of a buffer descriptor");
+    if (K == 0 || ntasks == 0) return IG_OK;
+    if (int rc = ig_set_device(ctx)) return rc;
+    const int64_t snt = n0 / support_tile;
+    const uint32_t* bits = support ? reinterpret_cast<const uint32_t*>(support + 2 * (ns * snt + snt)) : nullptr;
+    const float2 alpha = make_float2(ar, ai);
+    // the k-space panel as packed rows [t][N] (one column: it already is)
+    const float2* xp = (const float2*)X;
+    if (N > 1) {
+        const size_t need = (size_t)M * N * 8;
+        if (ctx->xpack_bytes < need) {
+            if (ctx->d_xpack) { IG_HIP(ctx, hipStreamSynchronize(ctx->stream)); IG_HIP(ctx, hipFree(ctx->d_xpack)); ctx->d_xpack = nullptr; ctx->xpack_bytes = 0; }
+            IG_HIP(ctx, hipMalloc((void**)&ctx->d_xpack, need));
+            ctx->xpack_bytes = need;
+        }
+        ig_prof_scope prof(ctx, "pack_panel", 2.0 * (double)need);
+        int64_t g = (M * N + BLK - 1) / BLK;
+        const int64_t cap = (int64_t)ctx->num_cu * 16;
+        if (g > cap) g = cap;
+        if (N == 2) hipLaunchKernelGGL(k_pack_panel<2>, dim3((unsigned)g), dim3(BLK), 0, ctx->stream, M, N, (const float2*)X, ldx, (float2*)ctx->d_xpack, (const int32_t*)nullptr);
+        else        hipLaunchKernelGGL(k_pack_panel<4>, dim3((unsigned)g), dim3(BLK), 0, ctx->stream, M, N, (const float2*)X, ldx, (float2*)ctx->d_xpack, (const int32_t*)nullptr);
+        IG_LAUNCH_CHECK(ctx, "k_pack_panel");
+        xp = (const float2*)ctx->d_xpack;
+    }
+    int bm_log2 = 0, bs_log2 = 0;
+    while ((1 << bm_log2) < bm) ++bm_log2;
+    while ((1 << bs_log2) < bs) ++bs_log2;
+    const int nbx = (int)(n0 / 16), nbm = (int)(nm / bm);
+    const size_t lds = (size_t)WAVES_PER_BLOCK * 16 * bm * bs * N * 8;
+    IG_REQUIRE(ctx, lds <= 64 * 1024, "ig_ccsrmm_t_slots: brick images need %zu bytes of LDS per workgroup (limit 64 KB)", lds);
+    const unsigned blocks = (unsigned)((ntasks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+#define IG_SLOTS(NC_) do {                                                                                                      \
+        if (nshared) {                                                                                                          \
+            ig_prof_scope prof(ctx, "grid_bricks_zero");                                                                        \
+            hipLaunchKernelGGL((k_grid_bricks_zero<NC_>), dim3((unsigned)nshared), dim3(BLK), 0, ctx->stream, shared_bricks, (float2*)Y_il, bits, (int)n0, (int)nm, bm_log2, bs_log2, nbx, nbm, st_log2); } \
+        ig_prof_scope prof(ctx, "csrmm_slots_conj");                                                                            \
+        hipLaunchKernelGGL((k_grid_slots<NC_>), dim3(blocks), dim3(BLK), lds, ctx->stream, (const BrickTask*)tasks, (int)ntasks, (const BrickRef*)brick_table, slot_ptr, (const SlotEntry*)entries16, \
+                           xp, (float2*)Y_il, alpha, bits, (int)n0, (int)nm, bm_log2, bs_log2, nbx, nbm, st_log2); } while (0)
+    if (N == 1) IG_SLOTS(1); else if (N == 2) IG_SLOTS(2); else IG_SLOTS(4);
+#undef IG_SLOTS
+    IG_LAUNCH_CHECK(ctx, "k_grid_slots");
     return IG_OK;
 }
 

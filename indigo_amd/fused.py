@@ -154,6 +154,9 @@ def assemble(backend, Gm, oN, N, weights_of, Cn, layout, chunks, table=None, box
             shape = tuning.get('brick_shape', {})
             shape = shape.get(bricks_cols, (2, 2, 4096, 4096)) if isinstance(shape, dict) else shape
             G._grid_bricks = (int(oN[0]), int(oN[2]), int(oN[1]), bricks_cols) + tuple(shape)
+        elif (bricks_cols if interleaved else 1) in tuning.get('slots', ()) and int(oN[2]) % 4 == 0 and int(oN[1]) % 4 == 0 and int(oN[0]) % 16 == 0:
+            # 1, 2 (or 4) columns: the same scatter with SLOTS in place of rounds (ig_ccsrmm_t_slots) -- no padding, no G'^T
+            G._grid_slots = (int(oN[0]), int(oN[2]), int(oN[1]), bricks_cols if interleaved else 1) + tuple(tuning.get('slot_shape', (4, 4, 256, 64)))
         return G
 
     sizes = {hi - lo for lo, hi in chunks if hi - lo > 1}

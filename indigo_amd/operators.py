@@ -234,6 +234,8 @@ class SpMatrix(Operator):
                 self._matrix_d.set_grid_interleaved(True)
             if getattr(self, '_grid_bricks', None) is not None:
                 self._matrix_d.set_grid_bricks(*self._grid_bricks)
+            if getattr(self, '_grid_slots', None) is not None and hasattr(self._matrix_d, 'set_grid_slots'):
+                self._matrix_d.set_grid_slots(*self._grid_slots)
         return self._matrix_d
 
     def csrmm_bytes(self, x, y, beta, forward):

@@ -222,6 +222,8 @@ class SenseProblem(object):
             # brick-binned scatter: 12 bytes per nonzero (cell + value; the padding and the row list of the binned format
             # are overhead, not compulsory), the panel, the flagged rows
             "csrmm_bricks_conj": nnz * 12 + T * e + sup * e,
+            # slot-format scatter (1- and 2-coil ranks): 16 bytes per nonzero (cell, value, sample), the panel, the flagged rows
+            "csrmm_slots_conj": nnz * 16 + T * e + sup * e,
             "pack_panel": 2 * T * e,
         }
 

@@ -703,6 +703,57 @@ def test_brick_binned_adjoint_gridding(hip, N, bm, bs, chunk, run, with_support)
     assert rel_err(got2[inside] if with_support else got2, exp2[inside] if with_support else exp2) < RTOL
 
 
+@pytest.mark.parametrize("N,bm,bs,chunk,run,with_support", [(1, 4, 4, 256, 64, True), (2, 4, 4, 256, 64, True), (1, 2, 2, 4, 8, True),
+                                                            (2, 4, 4, 2, 64, False), (4, 2, 4, 256, 96, True), (1, 4, 8, 256, 1 << 20, False),
+                                                            (2, 1, 1, 256, 3, True), (4, 4, 4, 8, 64, False)])
+def test_slot_format_adjoint_gridding(hip, N, bm, bs, chunk, run, with_support):
+    """ig_ccsrmm_t_slots (the brick scatter for 1, 2 and 4 interleaved columns: a lane is an entry, the entries of a brick
+    reordered so that a slot never holds a cell twice) == A^H X from scipy: a dense blob of samples (cells hit hundreds of times:
+    many slots per brick, shared bricks with atomics at a small chunk), rows with more taps than a slot holds cells of their
+    brick, several brick shapes, runs from a few slots up to the brick cap, with and without the support table."""
+    rng = np.random.default_rng(N * 100 + bm)
+    n0, nm, ns = 64, 64, 128
+    P, T = n0 * nm * ns, 3000
+    centre = rng.integers(0, P, size=40)
+    rows, cols = [], []
+    for t in range(T):
+        ntap = 70 if t % 97 == 0 else 27
+        base = centre[t % 40] if t % 3 else rng.integers(0, P)
+        off = rng.integers(-3, 4, size=(ntap, 3))
+        kx, km, ks = base % n0, (base // n0) % nm, base // (n0 * nm)
+        c = np.unique(((kx + off[:, 0]) % n0) + n0 * (((km + off[:, 1]) % nm) + nm * ((ks + off[:, 2]) % ns)))
+        rows.append(np.full(c.size, t)); cols.append(c)
+    rows, cols = np.concatenate(rows), np.concatenate(cols)
+    A = spp.csr_matrix((rand64c(rows.size, seed=3), (rows, cols)), shape=(T, P))
+    A.sort_indices()
+    A_d = hip.csr_matrix(hip, A)
+    if with_support:
+        seg = np.zeros((ns, nm, n0 // 16), dtype=bool)
+        uc = np.unique(A.indices)
+        seg[uc // (n0 * nm), (uc // n0) % nm, (uc % n0) // 16] = True
+        from test_hip_operators import support_table_from_segments
+        flat, _ = support_table_from_segments(seg)
+        A_d.set_grid_support(flat, n0, nm)
+    if N > 1:
+        A_d.set_grid_interleaved(True)
+    A_d.set_grid_slots(n0, nm, ns, ncols=N, bm=bm, bs=bs, chunk=chunk, run=run)
+    sl = A_d._slots
+    assert sl is not None and sl['nentries'] == A.nnz and 0 < sl['nslots'] <= A.nnz
+    assert sl['nshared'] > 0 or chunk >= 256
+    X = rand64c(T, N, seed=5)
+    sentinel = np.full((P, N), 9 - 2j, dtype=C64, order='F')
+    y_d = hip.copy_array(sentinel)
+    A_d.adjoint(y_d, hip.copy_array(X), alpha=0.5 - 0.25j)
+    got = y_d.to_host().reshape(-1, order='F').reshape(P, N)              # row-major (interleaved) memory
+    exp = (0.5 - 0.25j) * (A.conj().T.astype(np.complex128) @ X.astype(np.complex128))
+    if with_support:
+        inside = np.repeat(seg, 16, axis=2).reshape(-1)
+        assert rel_err(got[inside], exp[inside]) < RTOL
+        np.testing.assert_array_equal(got[~inside], sentinel[~inside])    # rows outside the support are not touched
+    else:
+        assert rel_err(got, exp) < RTOL
+
+
 @pytest.mark.parametrize("alpha,beta,ld_pad", [(1, 0, 0), (0.5 - 1j, 1.5, 5)])
 def test_wide_panel_forward_ragged_rows(hip, alpha, beta, ld_pad):
     """the 16-row-tile gather (k_csrmm_gather_tile64: 64 columns, software-pipelined over the rows of a tile): rows of every
