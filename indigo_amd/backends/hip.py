@@ -772,8 +772,8 @@ class HipBackend(Backend):
             del e12, rows
             sptr = np.zeros(nb + 1, dtype=np.int64)
             np.cumsum(brick_slots, out=sptr[1:])
-            sup = getattr(self, '_support', None)
-            nseg = bm * bs                                    # (the 16-point support table: one segment per brick row)
+            fine = getattr(self, '_support_fine', None)
+            nseg = (16 // (fine[1] if fine is not None else 16)) * bm * bs      # segments per brick (the kernel looks up 512 per run)
             tasks, table, shared = brick_tasks(brick_slots, sptr, chunk, run, max_bricks=min(64, 512 // nseg))
             self._slots = dict(n0=int(n0), nm=int(nm), bm=int(bm), bs=int(bs), ncols=int(ncols), ntasks=int(tasks.shape[0]),
                                nshared=int(shared.size), nslots=int(nslots.value), nentries=nent,
@@ -921,7 +921,8 @@ class HipBackend(Backend):
                 return
             sl = getattr(self, '_slots', None)
             if sl is not None and perm is None and beta == 0 and y.contiguous and x.shape[1] == sl['ncols'] and sl['ntasks'] > 0:
-                tab = sup[0] if sup is not None else None
+                fine = getattr(self, '_support_fine', None)
+                tab, tile = (fine[0], fine[1]) if fine is not None else (sup[0] if sup is not None else None, 16)
                 if tab is None:
                     y._zero()
                 ar, ai = _cplx(alpha)
@@ -930,7 +931,7 @@ class HipBackend(Backend):
                                                 ctypes.c_void_p(x._arr), x._leading_dim, ctypes.c_void_p(y._arr),
                                                 ctypes.c_void_p(tab._arr) if tab is not None else None, sl['n0'], sl['nm'], sl['bm'], sl['bs'],
                                                 ctypes.c_void_p(sl['tasks']._arr), sl['ntasks'], ctypes.c_void_p(sl['table']._arr),
-                                                ctypes.c_void_p(sl['shared']._arr), sl['nshared'], 16), "ig_ccsrmm_t_slots")
+                                                ctypes.c_void_p(sl['shared']._arr), sl['nshared'], tile), "ig_ccsrmm_t_slots")
                 return
             if (x.shape[1] == 64 and beta == 0 and perm is None and not getattr(self, '_grid_il', False) and self.shape[1] % 16 == 0
                     and self.shape[1] > 0 and self.shape[0] * 512 < 2 ** 31 and self.values.size >= self.shape[1] // 4

@@ -2239,7 +2239,7 @@ int ig_ccsrmm_t_slots(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, float ar, fl
                       const int32_t* shared_bricks, int64_t nshared, int support_tile) {
     IG_REQUIRE(ctx, ctx != nullptr, "ig_ccsrmm_t_slots: ctx is NULL");
     IG_REQUIRE(ctx, M >= 0 && K >= 0 && M <= 0x7fffffffLL, "ig_ccsrmm_t_slots: bad dimensions");
-    IG_REQUIRE(ctx, N == 1 || N == 2 || N == 4, "ig_ccsrmm_t_slots: 1, 2 or 4 columns (got %lld)", (long long)N);
+    IG_REQUIRE(ctx, N == 1 || N == 2 || N == 4, "ig_ccsrmm_t_slots: 1, 2 or 4 columns (got %lld; at 8 the round format of ig_ccsrmm_t_bricks is faster: 0.77 against 1.28 ms)", (long long)N);
     IG_REQUIRE(ctx, (ntasks == 0 || (entries16 && slot_ptr)) && (M == 0 || X) && (K == 0 || Y_il) && ldx >= M, "ig_ccsrmm_t_slots: NULL array or short leading dimension");
     IG_REQUIRE(ctx, n0 > 0 && nm > 0 && K % (n0 * nm) == 0 && K < 0x7fffffffLL && bricks_ok(n0, nm, K / (n0 * nm), bm, bs, 1) && bm * bs <= 32,
                "ig_ccsrmm_t_slots: rows (%lld) are not a grid of n0=%lld x nm=%lld x ... that divides into 16 x %d x %d bricks", (long long)K, (long long)n0, (long long)nm, bm, bs);
