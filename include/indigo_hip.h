@@ -433,6 +433,10 @@ int  ig_fft_exec_cropped_sum(ig_fft* plan, const void* y, const void* w, void* x
  *                      ig_fft_exec_cropped_sum.                                                              */
 int  ig_fft_exec_cropped_sum_slab(ig_fft* plan, const void* y, const void* w, void* x, void* workspace,
                                   const int16_t* support, int phase, int64_t z0, int64_t z1);
+/* The same slab-by-slab schedule for the per-coil grid layout 1 (the one-coil ranks of a coil-sharded run): phase 0 = the z
+ * pass, phase 1 = the y and x passes of the image planes z0 <= z' < z1 into x (as ig_fft_exec_cropped).                   */
+int  ig_fft_exec_cropped_slab(ig_fft* plan, const void* y, const void* w, void* x, int64_t x_bstride, void* workspace,
+                              const int16_t* support, int phase, int64_t z0, int64_t z1);
 int  ig_fft_destroy(ig_fft* plan);
 
 /* ------------------------------------------------------------------------

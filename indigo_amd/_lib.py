@@ -114,6 +114,7 @@ PROTOTYPES = {
     "ig_fft_exec_cropped": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "ig_fft_exec_cropped_sum": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ig_fft_exec_cropped_sum_slab": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64]),
+    "ig_fft_exec_cropped_slab": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int64, c_int64]),
     "ig_comm_unique_id":  (c_int, [c_void_p]),
     "ig_comm_init_rank":  (c_int, [c_void_p, c_int, c_int, c_void_p, POINTER(c_void_p)]),
     "ig_comm_info":       (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), c_char_p, c_size_t]),

@@ -511,12 +511,23 @@ class HipBackend(Backend):
                                                ctypes.c_void_p(support._arr) if support is not None else None),
                     "ig_fft_exec_padded")
 
-    def ifft_cropped(self, xc, y, w, grid, box_lo, box_dims, workspace, layout=0, support=None, support_tile=16):
+    def ifft_cropped(self, xc, y, w, grid, box_lo, box_dims, workspace, layout=0, support=None, support_tile=16, slab=None):
+        """xc[:, c] = conj(w[:, c]) * crop(IFFT(y[:, c])).  slab (grid layout 1 only): 'z' = only the z pass; (z0, z1) = the y and x
+        passes of the image planes z0..z1-1 (after one 'z' call) -- the one-coil ranks of a coil-sharded run all-reduce finished
+        slabs while later ones are transformed"""
         C = y.shape[1]
         assert y.dtype == _C64 and xc.dtype == _C64 and y.contiguous and xc.contiguous
         assert xc.shape == (int(np.prod(box_dims)), C) and (layout != 2 or xc.contiguous)
         plan, ws = self._padded_plan(grid, box_lo, box_dims, C, layout, support_tile)
         assert workspace.nbytes >= ws
+        if slab is not None:
+            assert layout == 1
+            phase, z0, z1 = (0, 0, 0) if slab == 'z' else (1, int(slab[0]), int(slab[1]))
+            self._check(self._L.ig_fft_exec_cropped_slab(plan, ctypes.c_void_p(y._arr), ctypes.c_void_p(w._arr) if w is not None else None,
+                                                         ctypes.c_void_p(xc._arr), xc.shape[0], ctypes.c_void_p(workspace._arr),
+                                                         ctypes.c_void_p(support._arr) if support is not None else None, phase, z0, z1),
+                        "ig_fft_exec_cropped_slab")
+            return
         self._check(self._L.ig_fft_exec_cropped(plan, ctypes.c_void_p(y._arr),
                                                 ctypes.c_void_p(w._arr) if w is not None else None,
                                                 ctypes.c_void_p(xc._arr), xc.shape[0],

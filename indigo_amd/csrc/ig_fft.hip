@@ -1490,8 +1490,9 @@ static int exec_padded_layout1(ig_fft* p, const float2* x, int64_t x_bstride, co
     return IG_OK;
 }
 
+// phases: bit 0 = the z pass (whole grid), bit 1 = the y and x passes, restricted to the image planes z0 <= z' < z1
 static int exec_cropped_layout1(ig_fft* p, const float2* y, const float2* w, float2* x, int64_t x_bstride, float2* work,
-                                const short2* support) {
+                                const short2* support, int phases = 3, int64_t z0 = 0, int64_t z1 = -1) {
     ig_ctx* ctx = p->ctx;
     const int64_t n0 = p->dims[0], n1 = p->dims[1], n2 = p->dims[2];
     const int64_t b0 = p->box_dims[0], b1 = p->box_dims[1], b2 = p->box_dims[2];
@@ -1499,7 +1500,9 @@ static int exec_cropped_layout1(ig_fft* p, const float2* y, const float2* w, flo
     const int64_t vol = n0 * n1 * n2, bvol = b0 * b1 * b2, C = p->batch;
     const int64_t cvol = n0 * b1 * b2;
     float2* L1 = work + (size_t)p->total;
-    {   // pass z: all columns (kx, ky), keep z in box, stride n0; input intact, result into the workspace
+    if (z1 < 0) z1 = b2;
+    const int64_t nz = z1 - z0;                      // image planes the y and x passes cover
+    if (phases & 1) {   // pass z: all columns (kx, ky), keep z in box, stride n0; input intact, result into the workspace
         ig_prof_scope prof(ctx, "fft_crop_z", (double)(vol + n0 * n1 * b2) * C * 8.0);
         PassDesc d{};
         d.in = y; d.out = work; d.in_sj = d.out_sj = n0;
@@ -1511,23 +1514,24 @@ static int exec_cropped_layout1(ig_fft* p, const float2* y, const float2* w, flo
         if (support) d.k1_range = support + n1 * (n0 / 16);                         // ky the y pass will never read
         if (int rc = launch_2stage(ctx, p->axis[2], d, false, 0)) return rc;
     }
+    if (!(phases & 2) || nz <= 0) return IG_OK;
     {   // pass y: columns (kx, z'), grid in (stride n0*n2), compact out, keep y in box
-        ig_prof_scope prof(ctx, "fft_crop_y", (double)(n0 * n1 * b2 + cvol) * C * 8.0);
+        ig_prof_scope prof(ctx, "fft_crop_y", (double)(n0 * n1 * nz + n0 * b1 * nz) * C * 8.0);
         PassDesc d{};
-        d.in = work + l2 * n0; d.in_sj = n0 * n2; d.in_s[0] = 1; d.in_s[1] = n0; d.in_s[2] = vol;
-        d.out = L1 - l1 * n0; d.out_sj = n0; d.out_s[0] = 1; d.out_s[1] = n0 * b1; d.out_s[2] = cvol;
-        d.ext0 = n0; d.ext1 = b2; d.ncols = n0 * b2 * C;
+        d.in = work + (l2 + z0) * n0; d.in_sj = n0 * n2; d.in_s[0] = 1; d.in_s[1] = n0; d.in_s[2] = vol;
+        d.out = L1 - l1 * n0 + z0 * n0 * b1; d.out_sj = n0; d.out_s[0] = 1; d.out_s[1] = n0 * b1; d.out_s[2] = cvol;
+        d.ext0 = n0; d.ext1 = nz; d.ncols = n0 * nz * C;
         d.in_lo = 0; d.in_hi = (int)n1; d.out_lo = (int)l1; d.out_hi = (int)(l1 + b1); d.inverse = 1;
         if (support) { d.tile_range = support + n1 * (n0 / 16); d.tile_range_mode = 2; d.tile_range_k1 = 0; }
         if (int rc = launch_2stage(ctx, p->axis[1], d, false, 0)) return rc;
     }
     {   // pass x: compact rows, keep x in box, times conj(w), into the compact image array
-        ig_prof_scope prof(ctx, "fft_crop_x", (double)(cvol + bvol + (w ? bvol : 0)) * C * 8.0);
+        ig_prof_scope prof(ctx, "fft_crop_x", (double)(cvol + bvol + (w ? bvol : 0)) * C * 8.0 * (double)nz / (double)b2);
         PassDesc d{};
-        d.in = L1; d.in_sj = 1; d.in_s[0] = n0; d.in_s[1] = n0 * b1; d.in_s[2] = cvol;
-        d.out = x - l0; d.out_sj = 1; d.out_s[0] = b0; d.out_s[1] = b0 * b1; d.out_s[2] = x_bstride;
-        d.w = w ? w - l0 : nullptr; d.w_sj = 1; d.w_s[0] = b0; d.w_s[1] = b0 * b1; d.w_s[2] = bvol;
-        d.ext0 = b1; d.ext1 = b2; d.ncols = b1 * b2 * C;
+        d.in = L1 + z0 * n0 * b1; d.in_sj = 1; d.in_s[0] = n0; d.in_s[1] = n0 * b1; d.in_s[2] = cvol;
+        d.out = x - l0 + z0 * b0 * b1; d.out_sj = 1; d.out_s[0] = b0; d.out_s[1] = b0 * b1; d.out_s[2] = x_bstride;
+        d.w = w ? w - l0 + z0 * b0 * b1 : nullptr; d.w_sj = 1; d.w_s[0] = b0; d.w_s[1] = b0 * b1; d.w_s[2] = bvol;
+        d.ext0 = b1; d.ext1 = nz; d.ncols = b1 * nz * C;
         d.in_lo = 0; d.in_hi = (int)n0; d.out_lo = (int)l0; d.out_hi = (int)(l0 + b0); d.inverse = 1;
         if (int rc = launch_2stage(ctx, p->axis[0], d, true, w ? 2 : 0)) return rc;
     }
@@ -1769,6 +1773,20 @@ int ig_fft_exec_cropped(ig_fft* p, const void* yv, const void* wv, void* xv, int
         if (int rc = launch_2stage(ctx, p->axis[0], d, true, w ? 2 : 0)) return rc;
     }
     return IG_OK;
+}
+
+int ig_fft_exec_cropped_slab(ig_fft* p, const void* yv, const void* wv, void* xv, int64_t x_bstride, void* workspace,
+                             const int16_t* support, int phase, int64_t z0, int64_t z1) {
+    if (!p) return ig_fail(nullptr, IG_ERR_ARG, "ig_fft_exec_cropped_slab: plan is NULL");
+    ig_ctx* ctx = p->ctx;
+    IG_REQUIRE(ctx, p->padded && p->layout == 1, "ig_fft_exec_cropped_slab: needs a plan of ig_fft_plan_padded with grid_layout 1 (layout 2: ig_fft_exec_cropped_sum_slab)");
+    IG_REQUIRE(ctx, xv && yv && workspace, "ig_fft_exec_cropped_slab: NULL array");
+    IG_REQUIRE(ctx, phase == 0 || phase == 1, "ig_fft_exec_cropped_slab: phase must be 0 (z pass) or 1 (y and x passes of a slab)");
+    IG_REQUIRE(ctx, phase == 0 || (0 <= z0 && z0 <= z1 && z1 <= p->box_dims[2]),
+               "ig_fft_exec_cropped_slab: slab [%lld, %lld) outside the image's %lld planes", (long long)z0, (long long)z1, (long long)p->box_dims[2]);
+    if (int rc = ig_set_device(ctx)) return rc;
+    return exec_cropped_layout1(p, (const float2*)yv, (const float2*)wv, (float2*)xv, x_bstride, (float2*)workspace,
+                                (const short2*)support, phase == 0 ? 1 : 2, z0, z1);
 }
 
 int ig_fft_exec_cropped_sum(ig_fft* p, const void* yv, const void* wv, void* xv, void* workspace, const int16_t* support) {

@@ -350,7 +350,7 @@ class ShardedNormalOperator(object):
                 r = r.children[-1]
             while isinstance(r, op.Product):
                 r = r.right
-            if isinstance(r, op.ZpadFFT) and r._layout == 2 and hasattr(self._backend, 'ifft_cropped_sum'):
+            if isinstance(r, op.ZpadFFT) and hasattr(self._backend, 'ifft_cropped_sum') and (r._layout == 2 or (r._layout == 1 and r._C == 1)):
                 self._leaf = r
                 self._nslabs = int(nslabs)
 

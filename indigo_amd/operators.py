@@ -410,6 +410,20 @@ class ZpadFFT(MatrixFreeOperator):
                         with B.scratch(nbytes=self._ws_bytes()) as ws:
                             B.ifft_cropped_sum(acc, xj.reshape((P, C)), w, self._grid, self._lo, self._box, ws, self._support(), **self._tile_kw)
                         B.axpby(beta, yj, alpha, acc)
+            elif (self._layout == 1 and C == 1 and alpha == 1 and beta == 0 and ncols == 1 and getattr(self, '_slab_hook', None) is not None
+                  and hasattr(B, 'ifft_cropped_sum')):
+                # one coil on a rank of a coil-sharded run (per-coil grid layout): the image IS the cropped transform of the one
+                # column -- written straight into y, slab by slab, every finished slab handed to the all-reduce hook
+                nslabs, fn = self._slab_hook
+                b2, plane = self._box[2], self._box[0] * self._box[1]
+                with B.scratch(nbytes=self._ws_bytes()) as ws:
+                    xg = xj.reshape((P, C))
+                    B.ifft_cropped(yj, xg, w, self._grid, self._lo, self._box, ws, 1, self._support(), slab='z')
+                    edges = [b2 * i // nslabs for i in range(nslabs + 1)]
+                    for z0, z1 in zip(edges[:-1], edges[1:]):
+                        if z1 > z0:
+                            B.ifft_cropped(yj, xg, w, self._grid, self._lo, self._box, ws, 1, self._support(), slab=(z0, z1))
+                            fn(yj, z0 * plane, z1 * plane)
             else:
                 with B.scratch(shape=(N, C)) as tmp:
                     with B.scratch(nbytes=self._ws_bytes()) as ws:

@@ -128,6 +128,23 @@ B._scratch = None
 normal_operator(A, lamda=0.1).eval(y2, xs)
 a, b = y1.to_host(), y2.to_host()
 assert np.linalg.norm(a - b) <= 1e-6 * np.linalg.norm(b), np.linalg.norm(a - b) / np.linalg.norm(b)
+# a rank with ONE coil (per-coil grid layout 1): the cropped transform writes the image slab by slab too
+del A, op
+B._scratch = None
+A = p.build_zpadfft(B, coils=[2])
+assert A.right._layout == 1 and A.right._C == 1
+comm.world = 2
+op = ShardedNormalOperator(A, comm, lamda=0.1, nslabs=3)
+assert op._leaf is A.right
+op.eval(y1, xs)
+comm.world = 1
+B._scratch = None
+normal_operator(A, lamda=0.1).eval(y2, xs)
+a, b = y1.to_host(), y2.to_host()
+assert np.linalg.norm(a - b) <= 1e-6 * np.linalg.norm(b), np.linalg.norm(a - b) / np.linalg.norm(b)
+del A, op
+B._scratch = None
+A = p.build_zpadfft(B, chunk=2)
 # a tree whose last writer does not take the slab branch: the coverage check falls back to ONE plain all-reduce
 calls = []
 orig = comm.allreduce_
