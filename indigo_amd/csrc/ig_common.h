@@ -135,6 +135,26 @@ __device__ __forceinline__ void buf_st(rsrc_t r, unsigned voff, unsigned soff, f
     __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, NT ? 2 : 0);
 }
 
+// An 8-byte buffer store that is SKIPPED -- by a scalar branch inside one opaque block, so the compiler sees no control flow and
+// allocates registers as before -- when the wave-uniform flag `wanted` is 0: no lane of the wave keeps the element
+// (the lanes that do not are out of range anyway), and a store whose lanes are all out of range would still take its issue slot
+// and its pass through the address unit.  A store reads its data registers at issue; nothing here reads the target back.
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4i_t make_rsrc_words(const void* p) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    return v4i_t{(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xffffu), (int)IG_OOB, 0x00020000};
+}
+template <bool NT>
+__device__ __forceinline__ void buf_st_gated(v4i_t r, unsigned voff, float2 a, unsigned wanted /* wave-uniform: 0 = skip */) {
+    v2u_t v; v.x = __float_as_uint(a.x); v.y = __float_as_uint(a.y);
+    if (NT)
+        asm volatile("s_cmp_eq_u32 %3, 0\n\ts_cbranch_scc1 .Lig_st_skip%=\n\tbuffer_store_dwordx2 %0, %1, %2, 0 offen nt\n.Lig_st_skip%=:"
+                     :: "v"(v), "v"(voff), "s"(r), "s"(wanted) : "scc", "memory");
+    else
+        asm volatile("s_cmp_eq_u32 %3, 0\n\ts_cbranch_scc1 .Lig_st_skip%=\n\tbuffer_store_dwordx2 %0, %1, %2, 0 offen\n.Lig_st_skip%=:"
+                     :: "v"(v), "v"(voff), "s"(r), "s"(wanted) : "scc", "memory");
+}
+
 typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int buf_ld_i32(rsrc_t r, unsigned voff) {
     return (int)__builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0);

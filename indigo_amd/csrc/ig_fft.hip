@@ -56,6 +56,9 @@ namespace {
 #ifndef IG_FFT_NT_STORE
 #define IG_FFT_NT_STORE 1
 #endif
+#ifndef IG_FFT_GATE_STORES
+#define IG_FFT_GATE_STORES 1    // scalar-gated stores (one opaque asm block each) on unweighted passes with a run-time output box
+#endif
 #ifndef IG_FFT_GROUP_SKIP
 #define IG_FFT_GROUP_SKIP 1     // wave-uniform skipping of loads / stores no lane wants (support bitmap, boxes)
 #endif
@@ -474,15 +477,24 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
     // mostly unflagged rows (72 % on the headline problem), and an instruction whose lanes are all out of range still
     // costs its issue slot and its pass through the address unit.
     // (Unweighted passes only: the weighted run-time-box x pass went from 155 to 198 registers with them -- three waves per SIMD
-    // to two, 1.08 -> 1.86 ms on config 5.  Loads only: the same scalar branches around the STORES of the padded z pass cost it its register allocation -- 172
-    // bytes of spills at the 128-register cap -- and predicating them through the execution mask instead, one opaque
-    // v_and / v_cmp / s_and_saveexec / store / s_mov exec block per element, was measured slower than the out-of-range
-    // offsets: padded y pass 1.08 -> 1.14 ms, padded z pass 1.21 -> 1.24 ms, config 5 41.9 -> 44.3 ms.)
+    // to two, 1.08 -> 1.86 ms on config 5.  C++ branches around the STORES of the padded z pass cost it its register
+    // allocation -- 172 bytes of spills at the 128-register cap -- and predicating them through the execution mask, one opaque
+    // v_and / v_cmp / s_and_saveexec / store / s_mov exec block per element, was slower than the out-of-range offsets
+    // (padded y pass 1.08 -> 1.14 ms, config 5 41.9 -> 44.3 ms).  What works for the stores is the scalar branch INSIDE one
+    // opaque block per store, buf_st_gated below: no control flow for the compiler, padded z pass 1.21 -> 1.14 ms.)
     uint32_t gin = 0xffffffffu;
     if (BOXED && !AXIS0 && GROUP_SKIP && WMODE == 0 && !HALF_IN && HALF != 4) {
         gin = 0;
 #pragma unroll
         for (int l = 0; l < 64; l += W) gin |= (uint32_t)__builtin_amdgcn_readlane((int)ibits, l);
+    }
+    // the same for the stores of unweighted passes with a run-time output box -- as ONE opaque block per store (buf_st_gated)
+    constexpr bool GATE_ST = IG_FFT_GATE_STORES && GROUP_SKIP && BOXED && !AXIS0 && WMODE == 0 && !HALF_OUT && HALF != 3;
+    uint32_t gout = 0xffffffffu;
+    if (GATE_ST) {
+        gout = 0;
+#pragma unroll
+        for (int l = 0; l < 64; l += W) gout |= (uint32_t)__builtin_amdgcn_readlane((int)obits, l);
     }
 
     // ---- stage 1: radix R1 on inputs j = t + k*R2, results (times w_n^{t k}) to the exchange
@@ -565,6 +577,7 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
                 if (SUMW >= 16) { a.x += dpp_f<0x108>(a.x); a.y += dpp_f<0x108>(a.y); }     // row_shl:8
             }
             if (AXIS0) buf_st<NT_ST>(r_out, l_out | off, (unsigned)(q * T + r * R1) * 8u, a);
+            else if (GATE_ST) buf_st_gated<NT_ST>(make_rsrc_words(b_out + (int64_t)(q * T + r * R1) * d.out_sj), l_out | off, a, (gout >> (q + r * B2)) & 1u);
             else buf_st<NT_ST>(make_rsrc(b_out + (int64_t)(q * T + r * R1) * d.out_sj), l_out | off, 0, a);
         }
     }
