@@ -1140,8 +1140,9 @@ int launch_2stage(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d_in, bool ax
         if (((half == 1 || half == 3) && d.inverse) || ((half == 2 || half == 4) && !d.inverse)) half = 0;   // direction is baked in
     }
     // 32-column tiles (256-byte segments) pay where a side of the pass runs at a huge stride (y passes of the
-    // interleaved layout, 16 MB per element: -11...-15 %) and for the half-input variants, which fit 128 VGPRs;
-    // the half-output variants spill at that cap and lose on small-stride passes (cropped z pass: +16 %).
+    // interleaved layout, 16 MB per element: -11...-15 %), for the half-input variants, which fit 128 VGPRs, and -- since
+    // round 3 skips the load instructions no lane wants -- for the half-output variants too (cropped z pass 1.28 -> 1.20 ms;
+    // before that skip the wider tile lost there: 1.63 against 1.50 ms).
     const bool big_stride = (d.in_sj > d.out_sj ? d.in_sj : d.out_sj) * 8 >= (1 << 20);
     // boxed passes WITHOUT a compile-time half box (e.g. the 320-point box of a 512-point axis, oversampling 1.6) also take
     // 32-column tiles when one side runs at a huge stride: cropped y pass of config 5 0.85 -> 0.74 ms, padded y pass unchanged
@@ -1149,7 +1150,7 @@ int launch_2stage(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d_in, bool ax
     // transform steps 2 MB per element (3.82 -> 3.08 ms for 512^3 x 8)
     const bool w32_generic = half == 0 && big_stride;
     if (ax.n == 512 && !axis0 && wmode == 0 && !d.cw && d.ext0 % 32 == 0 &&
-        (half == 1 || half == 3 || ((half == 2 || half == 4) && big_stride) || w32_generic) &&
+        (half == 1 || half == 3 || half == 2 || half == 4 || w32_generic) &&
         (!d.tile_range || d.tile_shift >= 1)) {
         // 32-column tiles: 256-byte segments per row, 512 threads, 69.6 KB of LDS (2 workgroups per CU)
         PassDesc d2 = d;
