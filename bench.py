@@ -81,7 +81,7 @@ def kernel_symbols(layout, ncoils, half_box=True, n=512, support_tile=16):
         if half_box and n == 512:
             m.update({"fft_pad_x": f % "16, false, 1, true, 3",
                       "fft_pad_y": f % "32, false, 0, true, 1", "fft_pad_z": f % "32, false, 0, true, 1",
-                      "fft_crop_z": f % "16, false, 0, true, 2", "fft_crop_y": f % "32, false, 0, true, 2",
+                      "fft_crop_z": f % "32, false, 0, true, 2", "fft_crop_y": f % "32, false, 0, true, 2",
                       "fft_crop_x": f % ("16, false, %d, true, 4" % (3 + lg))})
         else:
             # no compile-time half box (config 5: 320 of 512): run-time box predicates; the y passes (16 MB stride on the
@@ -95,9 +95,10 @@ def kernel_symbols(layout, ncoils, half_box=True, n=512, support_tile=16):
                   "csrmm_bricks_conj": "k_grid_bricks<%d, %d>" % (ncoils, (16 // support_tile) * 4 if ncoils == 8 else 0)})
     elif layout == 1:
         h = (3, 1, 1, 2, 2, 4) if half_box else (0,) * 6
-        m.update({"fft_pad_x": f % ("16, true, 1, true, %d" % h[0]), "fft_pad_y": f % ("16, false, 0, true, %d" % h[1]),
-                  "fft_pad_z": f % ("16, false, 0, true, %d" % h[2]), "fft_crop_z": f % ("16, false, 0, true, %d" % h[3]),
-                  "fft_crop_y": f % ("16, false, 0, true, %d" % h[4]), "fft_crop_x": f % ("16, true, 2, true, %d" % h[5]),
+        w = 32 if (half_box and n == 512) else 16         # compile-time half box: 32-column tiles (launch_2stage, ig_fft.hip)
+        m.update({"fft_pad_x": f % ("16, true, 1, true, %d" % h[0]), "fft_pad_y": f % ("%d, false, 0, true, %d" % (w, h[1])),
+                  "fft_pad_z": f % ("%d, false, 0, true, %d" % (w, h[2])), "fft_crop_z": f % ("%d, false, 0, true, %d" % (w, h[3])),
+                  "fft_crop_y": f % ("%d, false, 0, true, %d" % (w, h[4])), "fft_crop_x": f % ("16, true, 2, true, %d" % h[5]),
                   "csrmm_rowlane_conj": "k_csrmm_dense64<%d, true, false>" % ncoils, "csrmm_slots_conj": "k_grid_slots<%d>" % ncoils})
     return m
 
