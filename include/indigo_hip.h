@@ -271,6 +271,17 @@ int  ig_ccsrmm_t_slots(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, float alpha
 int  ig_ccsrmm_t_bricks_wide(ig_ctx* ctx, int64_t M, int64_t K, float alpha_re, float alpha_im,
                              const void* entries, const uint32_t* entry_rows, const void* X, int64_t ldx, void* Y, int64_t ldy,
                              const int32_t* tasks, int64_t ntasks, const int32_t* brick_table, const uint32_t* owned_tiles);
+/* ... with bricks of 16 x bm x bs points of a grid n0 x nm x (K / n0 / nm) whose first axis runs fastest along the rows of Y
+ * (bm * bs = 2 or 4; bm = bs = 1 is the call above).  Entries from ig_grid_bricks_count / _fill with that geometry and
+ * unit = 4 (cell = x + 16 (m + bm s)): a row's share of a brick is a whole number of QUADS, entry_rows holds one row per quad,
+ * padding entries must name a valid cell (< 16 bm bs; the caller replaces the fill's 0xffffffff) with weight zero; task and
+ * brick boundaries are multiples of four entries.  One row of X is loaded per quad, and a 27-tap gridding row falls into 4.5
+ * such bricks instead of 10 bricks of 16 rows.  The brick image lives in registers (k_bricks_wide64r).  owned_tiles as above:
+ * a brick a single non-shared task holds stores all of its bm * bs tiles.                                                  */
+int  ig_ccsrmm_t_bricks_wide_grid(ig_ctx* ctx, int64_t M, int64_t K, float alpha_re, float alpha_im,
+                                  const void* entries, const uint32_t* entry_rows, const void* X, int64_t ldx, void* Y, int64_t ldy,
+                                  const int32_t* tasks, int64_t ntasks, const int32_t* brick_table, const uint32_t* owned_tiles,
+                                  int64_t n0, int64_t nm, int bm, int bs);
 
 /* Locality-ordered variants.  The caller may store A with its ROWS reordered (row r of the stored
  * matrix is row perm[r] of A; e.g. k-space samples sorted by the grid cell they touch, so that

@@ -82,6 +82,8 @@ PROTOTYPES = {
                                    c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int]),
     "ig_ccsrmm_t_bricks_wide": (c_int, [c_void_p, c_int64, c_int64, c_float, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                         c_void_p, c_int64, c_void_p, c_void_p]),
+    "ig_ccsrmm_t_bricks_wide_grid": (c_int, [c_void_p, c_int64, c_int64, c_float, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                                             c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int]),
     "ig_fft_set_support_tile": (c_int, [c_void_p, c_int]),
     "ig_ccsrmm_xrows":    (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64,
                                    c_float, c_float, c_void_p, c_void_p, c_void_p,

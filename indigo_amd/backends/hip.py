@@ -98,7 +98,8 @@ class HipBackend(Backend):
         #   wide_bricks   64-column column-major panels: brick scatter through LDS (adjoint)
         #   slots         coil counts whose adjoint gridding is the slot-format scatter (ig_ccsrmm_t_slots): the ranks of a coil-sharded
         #                 run with one or two coils
-        self.tuning = dict(bricks=(4, 8), slots=(1, 2), slot_shape=(4, 4, 256, 64), support_tile=8, brick_shape={8: (2, 2, 4096, 4096), 4: (2, 4, 4096, 4096)}, xrows=True, wide_bricks=True)
+        self.tuning = dict(bricks=(4, 8), slots=(1, 2), slot_shape=(4, 4, 256, 64), support_tile=8, brick_shape={8: (2, 2, 4096, 4096), 4: (2, 4, 4096, 4096)}, xrows=True, wide_bricks=True,
+                           wide_brick_shape=(2, 2), wide_task_shape=(4096, 1024))
 
     def __del__(self):
         try:
@@ -794,10 +795,26 @@ class HipBackend(Backend):
                                slot_ptr=b.copy_array(slot_ptr[:int(nslots.value) + 1].copy(), name=self._name + ".slotPtr"),
                                shared=b.copy_array(shared if shared.size else np.zeros(1, np.int32), name=self._name + ".slotSharedBricks"))
 
+        def set_grid_dims(self, n0, nm, ns):
+            """Hint: the columns of the matrix are the points of an n0 x nm x ns grid, n0 running fastest (a gridding matrix).
+            The wide adjoint then bins by bricks of 16 x 2 x 2 points instead of 16 consecutive columns."""
+            assert int(n0) * int(nm) * int(ns) == self.shape[1]
+            self._grid_dims = (int(n0), int(nm), int(ns))
+            self._wide = False
+
+        def _guess_grid_dims(self):
+            """(n, n, n) when the column count is a cube with n a multiple of 32, else None.  Only a grouping of the columns:
+            a wrong guess costs speed, never correctness (rows that touch more than 64 bricks decline the format)."""
+            k = self.shape[1]
+            n = int(round(k ** (1.0 / 3.0)))
+            return (n, n, n) if n > 0 and n ** 3 == k and n % 32 == 0 else None
+
         def _wide_bricks(self):
-            """The matrix binned by bricks of 16 consecutive columns, 12-byte entries {column inside the brick, re, im} + their rows:
-            the format of ig_ccsrmm_t_bricks_wide (adjoint of a 64-column column-major panel as a scatter through LDS).
-            Built on first use; None when the matrix does not qualify (a row touching more than 64 bricks)."""
+            """The matrix binned by bricks, 12-byte entries {column inside the brick, re, im} + their rows: the format of
+            ig_ccsrmm_t_bricks_wide[_grid] (adjoint of a 64-column column-major panel as a scatter).  Bricks are 16 x bm x bs
+            points of the grid the columns form (set_grid_dims, or a cube guessed from the column count; tuning
+            'wide_brick_shape'), else 16 consecutive columns.  Built on first use; None when the matrix does not qualify
+            (a row touching more than 64 bricks)."""
             wb = getattr(self, '_wide', False)
             if wb is not False:
                 return wb
@@ -810,29 +827,53 @@ class HipBackend(Backend):
             indptr = np.ascontiguousarray(indptr, dtype=np.int32)
             indices = np.ascontiguousarray(indices, dtype=np.int32)
             data = np.ascontiguousarray(data, dtype=_C64)
-            counts = np.zeros(k // 16, dtype=np.int32)
-            rc = b._L.ig_grid_bricks_count(m, indptr.ctypes.data, indices.ctypes.data, k, 1, 1, 1, 1, 1, counts.ctypes.data)
-            if rc != 0:
+            dims = getattr(self, '_grid_dims', None) or self._guess_grid_dims()
+            bm, bs = b.tuning.get('wide_brick_shape', (2, 2))
+            geoms = []
+            if dims is not None and bm * bs > 1 and dims[0] % 16 == 0 and dims[1] % bm == 0 and dims[2] % bs == 0:
+                geoms.append((dims[0], dims[1], dims[2], bm, bs))
+            geoms.append((k, 1, 1, 1, 1))
+            for n0, nm, ns, bm, bs in geoms:
+                nbx, nbm = n0 // 16, nm // bm
+                # grid bricks: a row's share of a brick padded to QUADS (one panel row is loaded per four entries)
+                unit = 4 if bm * bs > 1 else 1
+                counts = np.zeros(nbx * nbm * (ns // bs), dtype=np.int32)
+                if b._L.ig_grid_bricks_count(m, indptr.ctypes.data, indices.ctypes.data, n0, nm, ns, bm, bs, unit, counts.ctypes.data) == 0:
+                    break
+            else:
                 self._wide = None
                 return None
             ptr = np.zeros(counts.size + 1, dtype=np.int64)
             np.cumsum(counts, out=ptr[1:])
             e12 = np.empty((max(int(ptr[-1]), 1), 3), dtype=np.uint32)
-            rows = np.empty(max(int(ptr[-1]), 1), dtype=np.uint32)
-            _lib.check(b._L.ig_grid_bricks_fill(m, indptr.ctypes.data, indices.ctypes.data, data.ctypes.data, k, 1, 1, 1, 1, 1,
+            rows = np.empty(max(int(ptr[-1]) // unit, 1), dtype=np.uint32)
+            _lib.check(b._L.ig_grid_bricks_fill(m, indptr.ctypes.data, indices.ctypes.data, data.ctypes.data, n0, nm, ns, bm, bs, unit,
                                                 ptr.ctypes.data, e12.ctypes.data, rows.ctypes.data), None, "ig_grid_bricks_fill")
+            if unit > 1 and ptr[-1] > 0:
+                # padding entries (weight zero) take the cell of the real entry before them: whatever the panel row holds
+                # (an infinity times zero) lands on a cell the sample touches anyway
+                cell = e12[:int(ptr[-1]), 0]
+                last_real = np.maximum.accumulate(np.where(cell != 0xffffffff, np.arange(cell.size), 0))
+                cell[:] = cell[last_real]
             # tasks: pieces of at most 4096 entries of a heavy brick, runs of about 1024 entries of consecutive bricks, longest first.
             # Measured on BASELINE config 3 and rejected (round 3, profiles/r03_cfg3_sweep_*.txt): bricks in index order or in a
             # (y, z)-blocked order of the grid, with chunks of 4..64 consecutive workgroups dealt to one XCD so that the bricks that
             # need the same rows of X meet behind one L2 -- 3.7..4.2 ms against 3.35 ms, and the same 9.7 GB of re-fetched rows by
             # the PMC counters: a brick takes a wave ~25 us, a line lives ~7 us in a 4 MB L2 that 0.5 TB/s stream through.
-            tasks, table, shared = brick_tasks(counts, ptr, 4096, 1024, max_bricks=64, longest_first=True)
-            # tiles some task stores in full: the non-empty bricks that are not cut into shared pieces
+            chunk, run = (max(4, int(v) // 4 * 4) for v in b.tuning.get('wide_task_shape', (4096, 1024)))
+            tasks, table, shared = brick_tasks(counts, ptr, chunk, run, max_bricks=64, longest_first=True)
+            # tiles (16 rows of the result) some task stores in full: those of the non-empty bricks that are not cut into shared pieces
+            owned_b = np.zeros(counts.size, dtype=bool)
+            owned_b[table[:, 0]] = True
+            owned_b[shared] = False
+            ob = np.flatnonzero(owned_b).astype(np.int64)
+            bx, bmi, bsi = ob % nbx, (ob // nbx) % nbm, ob // (nbx * nbm)
             owned = np.zeros(k // 16, dtype=bool)
-            owned[table[:, 0]] = True
-            owned[shared] = False
+            for im in range(bm):
+                for is_ in range(bs):
+                    owned[bx + nbx * ((bmi * bm + im) + nm * (bsi * bs + is_))] = True
             bits = np.packbits(np.concatenate([owned, np.zeros((-owned.size) % 32, dtype=bool)]), bitorder='little').view(np.uint32)
-            self._wide = dict(ntasks=int(tasks.shape[0]),
+            self._wide = dict(ntasks=int(tasks.shape[0]), geom=(n0, nm, bm, bs),
                               owned=b.copy_array(bits, name=self._name + ".wideOwnedTiles"),
                               tasks=b.copy_array(tasks.reshape(-1) if tasks.size else np.zeros(4, np.int32), name=self._name + ".wideTasks"),
                               table=b.copy_array(table.reshape(-1) if table.size else np.zeros(2, np.int32), name=self._name + ".wideTable"),
@@ -952,11 +993,12 @@ class HipBackend(Backend):
                 if wb is not None:
                     ar, ai = _cplx(alpha)
                     m, k = self.shape
-                    b._check(b._L.ig_ccsrmm_t_bricks_wide(b._ctx, m, k, ar, ai, ctypes.c_void_p(wb['entries']._arr), ctypes.c_void_p(wb['rows']._arr),
-                                                          ctypes.c_void_p(x._arr), x._leading_dim, ctypes.c_void_p(y._arr), y._leading_dim,
-                                                          ctypes.c_void_p(wb['tasks']._arr), wb['ntasks'], ctypes.c_void_p(wb['table']._arr),
-                                                          ctypes.c_void_p(wb['owned']._arr)),
-                             "ig_ccsrmm_t_bricks_wide")
+                    n0, nm, bm, bs = wb['geom']
+                    b._check(b._L.ig_ccsrmm_t_bricks_wide_grid(b._ctx, m, k, ar, ai, ctypes.c_void_p(wb['entries']._arr), ctypes.c_void_p(wb['rows']._arr),
+                                                               ctypes.c_void_p(x._arr), x._leading_dim, ctypes.c_void_p(y._arr), y._leading_dim,
+                                                               ctypes.c_void_p(wb['tasks']._arr), wb['ntasks'], ctypes.c_void_p(wb['table']._arr),
+                                                               ctypes.c_void_p(wb['owned']._arr), n0, nm, bm, bs),
+                             "ig_ccsrmm_t_bricks_wide_grid")
                     return
             if getattr(self, '_grid_il', False):
                 assert perm is None and beta == 0 and y.contiguous, "interleaved panels: no row order, beta = 0"

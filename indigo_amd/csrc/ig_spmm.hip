@@ -1438,6 +1438,223 @@ k_bricks_wide64(const BrickTask* __restrict__ tasks, int ntasks, const BrickRef*
     flush();
 }
 
+// The same scatter with the brick image in REGISTERS (round 3).  The 16-row bricks above fetch a row of X once per ENTRY
+// (the L1 serves the repeats: 16 tag look-ups per 512-byte wave load, 1.0 G of them per launch) and once per (sample, brick)
+// group from HBM -- ten groups per sample for a 27-tap gridding kernel, 9.7 GB of the launch's 15.6.  Bigger bricks need fewer
+// groups (16 x 2 x 2 grid points: 4.5 per sample) but 33 KB of LDS per wave.  Here
+//   * lane c keeps column c of the whole brick in 128 VGPRs (v[128 + 2 cell] = re, v[129 + 2 cell] = im), and because the cell
+//     of an entry is wave-uniform the accumulation addresses them through the VGPR index mode: M0 = {third source and
+//     destination relative, index 2 cell}, four multiply-adds per entry, no LDS traffic, no read-after-write through memory;
+//   * entries come in QUADS: a sample's share of a brick is padded to a multiple of four (ig_grid_bricks_fill, unit 4; the
+//     padding repeats a real cell with weight zero) and ONE panel row is loaded per quad -- 13 M wave loads instead of 50 M;
+//     brick boundaries fall between quads.
+// How it is written:
+//   * The compiler never sees the image or the panel rows: the kernel caps its own allocation at v0..v71 (amdgpu_num_vgpr),
+//     v72..v79 hold two trips of entries in flight, v80..v103 twelve panel rows, and every access to v72..v255 is an
+//     assembly block with literal register numbers.  (Handing the image to the compiler as four 32-register operands made it
+//     copy whole tuples at every join of the control flow; leaving the loads to it kept one group in flight.)
+//   * Loads return in order, so "at most 11 younger loads outstanding" means the row about to be used has arrived, whatever
+//     else -- the trips' loads, the stores of a flush -- is in flight.
+//   * The index mode is switched on ONCE, with no operand relative (M0[15:12] = 0: the compiler's code runs unchanged; it never
+//     writes M0 in this kernel); a block that addresses the image writes M0 itself and clears it again.
+//   * Entries do not come through the scalar cache (at the eight waves per CU that 256 registers allow, every miss stalled a
+//     wave for a trip to HBM): lane e of the wave loads entry e of a TRIP of 48 (12 quads), two trips ahead; wave-uniform
+//     values are read out with v_readlane (constant lane numbers) when their turn comes.  The rows sit in a second stream
+//     shifted by the look-ahead of 11 quads, so quad k of a trip requests with lane k.
+//   * A wave issues one instruction per four clocks whatever its kind, and two waves per SIMD hide little: the loop is
+//     written for instruction count.
+// The flush goes tile by tile (16 rows of Y) through the [16][65] LDS image of the kernel above, full lines out.
+template <int K, int END>
+__device__ __forceinline__ void wide_img_zero() {
+    if constexpr (K < END) {
+        asm volatile("v_mov_b64 v[%0:%1], 0" :: "i"(128 + 2 * K), "i"(129 + 2 * K));
+        wide_img_zero<K + 1, END>();
+    }
+}
+
+template <int NT /* 16-row tiles per brick: bm * bs = 2, 4 */>
+__global__ void __launch_bounds__(BLK) __attribute__((amdgpu_num_vgpr(72)))
+k_bricks_wide64r(const BrickTask* __restrict__ tasks, int ntasks, const BrickRef* __restrict__ btab,
+                 const BrickEntry* __restrict__ entries, const uint32_t* __restrict__ quad_rows,
+                 const float2* __restrict__ Xp /* [row][64] */, float2* __restrict__ Y, int64_t ldy, float2 alpha,
+                 int n0, int nm, int bm_log2, int bs_log2, int nbx, int nbm) {
+    __shared__ float2 acc_all[WAVES_PER_BLOCK * 16 * WIDE_LD];
+    asm volatile("" ::: "v255");                          // the kernel owns 256 VGPRs
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int blk = (int)blockIdx.x;
+    const int task = blk * WAVES_PER_BLOCK + wv;
+    if (blk >= (int)gridDim.x || task >= ntasks) return;
+    const BrickTask tk = tasks[task];
+    const int nb = tk.nb_flags & 0xffff;
+    const bool shared = (tk.nb_flags >> 16) & 1;
+    const int32_t nent = tk.hi - tk.lo;                   // a multiple of 4
+    const int32_t nquad = nent >> 2;
+    float2* __restrict__ acc = acc_all + wv * 16 * WIDE_LD;
+    asm volatile("s_set_gpr_idx_on %0, 0x0" :: "s"(0));
+    rsrc_t r_en = make_rsrc(entries + tk.lo);            // (not const: operands of assembly blocks inside generic lambdas)
+    rsrc_t r_qr = make_rsrc(quad_rows + (tk.lo >> 2));
+    rsrc_t r_x = make_rsrc(Xp);
+
+    constexpr int TRIP = 48, TQ = TRIP / 4;               // entries / quads per trip
+    constexpr int AHEAD = TQ - 1;                         // a panel row is requested 11 quads before its entries are used
+    struct Trip { uint32_t m0w; float re, im; uint32_t rowoff; };             // lane e: entry e; lane q: the row of quad q + AHEAD
+    // raw trips in flight: slot A = v[72:75], slot B = v[76:79]
+    auto load_raw = [&](auto slot, int ti) __attribute__((always_inline)) {
+        constexpr int R = 72 + 4 * decltype(slot)::value;
+        const int32_t e = ti * TRIP + lane, q = ti * TQ + lane + AHEAD;
+        const unsigned oe = (lane < TRIP && e < nent) ? (unsigned)e * 12u : IG_OOB;
+        const unsigned oq = (lane < TQ && q < nquad) ? (unsigned)q * 4u : IG_OOB;           // (past the end: row 0, never used)
+        const rsrc_t ren = r_en, rqr = r_qr;             // (copies: a generic lambda does not capture a variable only an asm operand names)
+        asm volatile("buffer_load_dwordx3 v[%0:%1], %3, %4, 0 offen\n\t"
+                     "buffer_load_dword v[%2], %5, %6, 0 offen"
+                     :: "i"(R), "i"(R + 2), "i"(R + 3), "v"(oe), "s"(ren), "v"(oq), "s"(rqr) : "memory");
+    };
+    auto cook_a = [&]() __attribute__((always_inline)) {                        // slot A -> the words the loop reads with v_readlane
+        uint32_t c, re, im, row;
+        asm volatile("v_mov_b32 %0, v72\n\tv_mov_b32 %1, v73\n\tv_mov_b32 %2, v74\n\tv_mov_b32 %3, v75" : "=v"(c), "=v"(re), "=v"(im), "=v"(row));
+        Trip t;
+        t.m0w = ((c & (16u * NT - 1u)) * 2u) | 0xC000u;                       // M0: third source and destination relative, index 2 cell
+        t.re = __uint_as_float(re); t.im = __uint_as_float(im);
+        t.rowoff = row * 512u;
+        return t;
+    };
+    load_raw(std::integral_constant<int, 0>{}, 0);
+    load_raw(std::integral_constant<int, 1>{}, 1);
+    const float2 my_ref = buf_ld<false>(make_rsrc(btab + tk.bt), lane < nb ? (unsigned)lane * 8u : IG_OOB, 0);
+    wide_img_zero<0, 16 * NT>();
+    const unsigned x_voff = (unsigned)lane * 8u;
+    // the panel row whose byte offset sits in lane `ql` of `src` -> buffer KF (v[80 + 2 KF], v[81 + 2 KF])
+    auto request = [&](auto kf, auto ql, uint32_t src) __attribute__((always_inline)) {
+        constexpr int KF = decltype(kf)::value;
+        const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)src, decltype(ql)::value);
+        const rsrc_t rx = r_x;
+        const unsigned vo = x_voff;
+        // (s_nop: five wait states between a VALU writing an SGPR and a memory instruction reading it)
+        asm volatile("s_nop 4\n\tbuffer_load_dwordx2 v[%0:%1], %2, %3, %4 offen" :: "i"(80 + 2 * KF), "i"(81 + 2 * KF), "v"(vo), "s"(rx), "s"(o) : "memory");
+    };
+    // quads 0 .. 10: their rows are not in the shifted stream
+    {
+        const uint32_t first = (uint32_t)buf_ld_i32(r_qr, (lane < AHEAD && lane < nquad) ? (unsigned)lane * 4u : IG_OOB) * 512u;
+        auto pro = [&](auto k) __attribute__((always_inline)) { request(k, k, first); };
+        pro(std::integral_constant<int, 0>{}); pro(std::integral_constant<int, 1>{}); pro(std::integral_constant<int, 2>{});
+        pro(std::integral_constant<int, 3>{}); pro(std::integral_constant<int, 4>{}); pro(std::integral_constant<int, 5>{});
+        pro(std::integral_constant<int, 6>{}); pro(std::integral_constant<int, 7>{}); pro(std::integral_constant<int, 8>{});
+        pro(std::integral_constant<int, 9>{}); pro(std::integral_constant<int, 10>{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    Trip tc = cook_a();
+    asm volatile("v_mov_b32 v72, v76\n\tv_mov_b32 v73, v77\n\tv_mov_b32 v74, v78\n\tv_mov_b32 v75, v79" ::: "memory");
+    Trip tn = cook_a();
+    load_raw(std::integral_constant<int, 0>{}, 2);
+    load_raw(std::integral_constant<int, 1>{}, 3);
+    int my_end = 0x7fffffff;
+    if (lane < nb && !shared) my_end = (int)__float_as_uint(my_ref.y) - tk.lo;
+    int my_row0;                                          // first row of Y of the brick's tile (0, 0)
+    {
+        const int b = (int)__float_as_uint(my_ref.x);
+        const int bx = b % nbx, bmi = (b / nbx) % nbm, bsi = b / (nbx * nbm);
+        my_row0 = bx * 16 + n0 * ((bmi << bm_log2) + nm * (bsi << bs_log2));
+    }
+    const int tile_cell = lane & 15, tile_cg = lane >> 4;
+
+    int cur = 0;
+    int32_t cur_end = __builtin_amdgcn_readlane(my_end, 0);
+    auto tile_out = [&](int q, int row00) __attribute__((always_inline)) {       // the LDS image (tile q of the brick) -> Y
+        const int row0 = row00 + n0 * ((q & ((1 << bm_log2) - 1)) + nm * (q >> bm_log2));
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int col = tile_cg + 4 * i;
+            const float2 o = cmul(alpha, acc[tile_cell * WIDE_LD + col]);
+            float2* dst = Y + (int64_t)col * ldy + row0 + tile_cell;        // 16 lanes = one 128-byte line of column `col`
+            if (shared) {
+                asm volatile("global_atomic_add_f32 %0, %1, off\n\tglobal_atomic_add_f32 %0, %2, off offset:4"
+                             :: "v"(dst), "v"(o.x), "v"(o.y) : "memory");
+            } else {
+                asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(dst), "v"(o) : "memory");
+            }
+        }
+    };
+    auto flush = [&]() __attribute__((always_inline)) {
+        const int row00 = __builtin_amdgcn_readlane(my_row0, cur);
+#pragma unroll 1
+        for (int q = 0; q < NT; ++q) {                   // a run-time loop: the kernel holds one flush site per quad of a trip
+            // tile q of the image (registers v[128 + 32 q ...]) -> LDS, read through the index mode (first source relative)
+            uint32_t any = 0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float t[16];
+                asm volatile("s_mov_b32 m0, %16\n\ts_nop 0\n\t"
+                             "v_mov_b32 %0, v128\n\tv_mov_b32 %1, v129\n\tv_mov_b32 %2, v130\n\tv_mov_b32 %3, v131\n\t"
+                             "v_mov_b32 %4, v132\n\tv_mov_b32 %5, v133\n\tv_mov_b32 %6, v134\n\tv_mov_b32 %7, v135\n\t"
+                             "v_mov_b32 %8, v136\n\tv_mov_b32 %9, v137\n\tv_mov_b32 %10, v138\n\tv_mov_b32 %11, v139\n\t"
+                             "v_mov_b32 %12, v140\n\tv_mov_b32 %13, v141\n\tv_mov_b32 %14, v142\n\tv_mov_b32 %15, v143\n\t"
+                             "s_mov_b32 m0, 0"
+                             : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7]),
+                               "=&v"(t[8]), "=&v"(t[9]), "=&v"(t[10]), "=&v"(t[11]), "=&v"(t[12]), "=&v"(t[13]), "=&v"(t[14]), "=&v"(t[15])
+                             : "s"((32 * q + 16 * h) | 0x1000));
+#pragma unroll
+                for (int c = 0; c < 8; ++c) acc[(8 * h + c) * WIDE_LD + lane] = make_float2(t[2 * c], t[2 * c + 1]);
+                if (shared) {
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) any |= __float_as_uint(t[c]) << 1;       // (-0.0f counts as nothing)
+                }
+            }
+            if (shared && !__builtin_amdgcn_ballot_w64(any != 0)) continue;               // a piece that never touched this tile
+            tile_out(q, row00);
+        }
+        wide_img_zero<0, 16 * NT>();
+        ++cur;
+        cur_end = __builtin_amdgcn_readlane(my_end, cur & 63);
+    };
+    // quad k of the current trip (entries in lanes 4k .. 4k + 3, panel row in buffer k): request the row of the quad 11 ahead
+    // into the buffer the previous quad has just released, flush if a new brick starts here, accumulate.
+    auto body = [&](auto k, int32_t base) __attribute__((always_inline)) {
+        constexpr int KQ = decltype(k)::value;
+        request(std::integral_constant<int, (KQ + TQ - 1) % TQ>{}, k, tc.rowoff);
+        if (base >= nent) return;                                            // (trips are whole; the run is not)
+        if (base >= cur_end) flush();                                        // bricks are not empty: one flush
+        uint32_t mw[4]; float wr[4], wi[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            mw[i] = (uint32_t)__builtin_amdgcn_readlane((int)tc.m0w, 4 * KQ + i);
+            wr[i] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(tc.re), 4 * KQ + i));
+            wi[i] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(tc.im), 4 * KQ + i));
+        }
+        // image[cell] += conj(v) * x for the quad's four entries (one panel row)
+#define IG_WIDE_MAC(M, WR, WI) \
+                     "s_mov_b32 m0, " M "\n\ts_nop 0\n\t" \
+                     "v_fma_f32 v128, " WR ", v[%12], v128\n\t" \
+                     "v_fma_f32 v129, " WR ", v[%13], v129\n\t" \
+                     "v_fma_f32 v128, " WI ", v[%13], v128\n\t" \
+                     "v_fma_f32 v129, -" WI ", v[%12], v129\n\t"
+        asm volatile("s_waitcnt vmcnt(11)\n\t"                                // this quad's row has arrived
+                     IG_WIDE_MAC("%0", "%4", "%5") IG_WIDE_MAC("%1", "%6", "%7") IG_WIDE_MAC("%2", "%8", "%9") IG_WIDE_MAC("%3", "%10", "%11")
+                     "s_mov_b32 m0, 0"
+                     :: "s"(mw[0]), "s"(mw[1]), "s"(mw[2]), "s"(mw[3]),
+                        "s"(wr[0]), "s"(wi[0]), "s"(wr[1]), "s"(wi[1]), "s"(wr[2]), "s"(wi[2]), "s"(wr[3]), "s"(wi[3]),
+                        "i"(80 + 2 * KQ), "i"(81 + 2 * KQ) : "memory");
+#undef IG_WIDE_MAC
+    };
+    int32_t base = 0;
+    for (int t = 0; t * TRIP < nent; ++t, base += TRIP) {
+        body(std::integral_constant<int, 0>{}, base);      body(std::integral_constant<int, 1>{}, base + 4);
+        body(std::integral_constant<int, 2>{}, base + 8);  body(std::integral_constant<int, 3>{}, base + 12);
+        body(std::integral_constant<int, 4>{}, base + 16); body(std::integral_constant<int, 5>{}, base + 20);
+        body(std::integral_constant<int, 6>{}, base + 24); body(std::integral_constant<int, 7>{}, base + 28);
+        body(std::integral_constant<int, 8>{}, base + 32); body(std::integral_constant<int, 9>{}, base + 36);
+        body(std::integral_constant<int, 10>{}, base + 40); body(std::integral_constant<int, 11>{}, base + 44);
+        // (at most 11 loads are outstanding here, all of them panel rows requested after slot B's trip was)
+        asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+        tc = tn;
+        tn = cook_a();
+        asm volatile("v_mov_b32 v72, v76\n\tv_mov_b32 v73, v77\n\tv_mov_b32 v74, v78\n\tv_mov_b32 v75, v79" ::: "memory");
+        load_raw(std::integral_constant<int, 1>{}, t + 4);
+    }
+    flush();
+    asm volatile("s_set_gpr_idx_off");
+}
+
 // Zero the 16-row tiles of a column-major K x 64 result that no single task owns (bit clear in `owned`: tiles no nonzero
 // touches, which beta == 0 defines as zero, and the heavy tiles several tasks add into): the owning task of every other tile
 // stores all of its 16 x 64 values itself, so nothing is written twice.  A workgroup takes 4096 rows of every column.
@@ -2296,8 +2513,19 @@ int ig_ccsrmm_t_slots(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, float ar, fl
 int ig_ccsrmm_t_bricks_wide(ig_ctx* ctx, int64_t M, int64_t K, float ar, float ai,
                             const void* entries, const uint32_t* entry_rows, const void* X, int64_t ldx, void* Y, int64_t ldy,
                             const int32_t* tasks, int64_t ntasks, const int32_t* brick_table, const uint32_t* owned_tiles) {
+    return ig_ccsrmm_t_bricks_wide_grid(ctx, M, K, ar, ai, entries, entry_rows, X, ldx, Y, ldy, tasks, ntasks, brick_table, owned_tiles, 0, 0, 1, 1);
+}
+
+int ig_ccsrmm_t_bricks_wide_grid(ig_ctx* ctx, int64_t M, int64_t K, float ar, float ai,
+                                 const void* entries, const uint32_t* entry_rows, const void* X, int64_t ldx, void* Y, int64_t ldy,
+                                 const int32_t* tasks, int64_t ntasks, const int32_t* brick_table, const uint32_t* owned_tiles,
+                                 int64_t n0, int64_t nm, int bm, int bs) {
     IG_REQUIRE(ctx, ctx != nullptr, "ig_ccsrmm_t_bricks_wide: ctx is NULL");
     const int64_t N = 64;
+    const bool grid = bm * bs > 1;
+    IG_REQUIRE(ctx, !grid || (n0 > 0 && nm > 0 && K % (n0 * nm) == 0 && bricks_ok(n0, nm, K / (n0 * nm), bm, bs, 1) && bm * bs <= 4),
+               "ig_ccsrmm_t_bricks_wide_grid: rows (%lld) are not a grid of n0=%lld x nm=%lld x ... that divides into 16 x %d x %d bricks (bm * bs <= 4)",
+               (long long)K, (long long)n0, (long long)nm, bm, bs);
     IG_REQUIRE(ctx, M >= 0 && K >= 0 && K % 16 == 0 && K <= 0x7fffffffLL, "ig_ccsrmm_t_bricks_wide: K (%lld) must be a multiple of 16", (long long)K);
     IG_REQUIRE(ctx, (ntasks == 0 || (entries && entry_rows && tasks && brick_table)) && (M == 0 || X) && (K == 0 || Y) && ldx >= M && ldy >= K,
                "ig_ccsrmm_t_bricks_wide: NULL array or short leading dimension");
@@ -2333,6 +2561,18 @@ int ig_ccsrmm_t_bricks_wide(ig_ctx* ctx, int64_t M, int64_t K, float ar, float a
     }
     ig_prof_scope prof(ctx, "csrmm_bricks_wide_conj");
     const unsigned blocks = (unsigned)((ntasks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+    if (grid) {
+        int bm_log2 = 0, bs_log2 = 0;
+        while ((1 << bm_log2) < bm) ++bm_log2;
+        while ((1 << bs_log2) < bs) ++bs_log2;
+        const int nbx = (int)(n0 / 16), nbm = (int)(nm / bm);
+#define IG_WIDE_R(NT_) hipLaunchKernelGGL((k_bricks_wide64r<NT_>), dim3(blocks), dim3(BLK), 0, ctx->stream, (const BrickTask*)tasks, (int)ntasks, (const BrickRef*)brick_table, \
+                       (const BrickEntry*)entries, entry_rows, (const float2*)xp, (float2*)Y, ldy, make_float2(ar, ai), (int)n0, (int)nm, bm_log2, bs_log2, nbx, nbm)
+        if (bm * bs == 2) IG_WIDE_R(2); else IG_WIDE_R(4);
+#undef IG_WIDE_R
+        IG_LAUNCH_CHECK(ctx, "k_bricks_wide64r");
+        return IG_OK;
+    }
     hipLaunchKernelGGL(k_bricks_wide64, dim3(blocks), dim3(BLK), 0, ctx->stream, (const BrickTask*)tasks, (int)ntasks, (const BrickRef*)brick_table,
                        (const BrickEntry*)entries, entry_rows, (const float2*)xp, (float2*)Y, ldy, make_float2(ar, ai));
     IG_LAUNCH_CHECK(ctx, "k_bricks_wide64");

@@ -236,6 +236,9 @@ class SpMatrix(Operator):
                 self._matrix_d.set_grid_bricks(*self._grid_bricks)
             if getattr(self, '_grid_slots', None) is not None and hasattr(self._matrix_d, 'set_grid_slots'):
                 self._matrix_d.set_grid_slots(*self._grid_slots)
+            dims = getattr(self, '_grid_dims', None) or getattr(self._matrix, '_grid_dims', None)
+            if dims is not None and hasattr(self._matrix_d, 'set_grid_dims'):
+                self._matrix_d.set_grid_dims(*dims)          # (n0, nm, ns), n0 fastest: the grid the columns form
         return self._matrix_d
 
     def csrmm_bytes(self, x, y, beta, forward):

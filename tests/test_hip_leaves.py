@@ -264,6 +264,50 @@ def test_wide_panel_adjoint_by_bricks(hip, monkeypatch, K, alpha, ld_pad, dense_
     assert rel_err(y3.to_host(), exp + 0.5 * yfull[:K]) < RTOL
 
 
+@pytest.mark.parametrize("dims,shape,alpha,ld_pad,blob", [((32, 32, 32), (2, 2), 1, 0, False), ((48, 6, 8), (2, 2), 0.5 - 0.25j, 3, True),
+                                                         ((32, 8, 4), (2, 1), 2, 0, False), ((64, 4, 4), (1, 2), 1, 0, True)])
+def test_wide_panel_adjoint_by_grid_bricks(hip, monkeypatch, dims, shape, alpha, ld_pad, blob):
+    """ig_ccsrmm_t_bricks_wide_grid (k_bricks_wide64r: the brick image in registers, addressed through the VGPR index mode):
+    a gridding-like matrix (3 x 3 x 3 taps around a point of an n0 x nm x ns grid, wrapped) times a 64-column panel, bricks of
+    16 x bm x bs grid points -- against scipy in double precision; untouched rows zero over a sentinel; a hot spot makes
+    heavy bricks (shared pieces, atomics); the cube is guessed from the column count, other grids come through the hint"""
+    n0, nm, ns = dims
+    K = n0 * nm * ns
+    M = 6000
+    rng = np.random.default_rng(K + shape[0])
+    c = np.stack([rng.integers(0, n0, M), rng.integers(0, nm, M), rng.integers(0, ns, M)])
+    if blob:
+        hot = rng.random(M) < 0.6
+        c[:, hot] = np.stack([rng.integers(16, 20, hot.sum()), rng.integers(2, 4, hot.sum()), rng.integers(0, 2, hot.sum())])
+    c[:, ::11] = 0                                                        # a few samples at the corner: taps wrap around
+    d = np.stack(np.meshgrid(np.arange(-1, 2), np.arange(-1, 2), np.arange(-1, 2), indexing='ij')).reshape(3, 27)
+    p = (c[:, :, None] + d[:, None, :]) % np.array(dims)[:, None, None]
+    cols = (p[0] + n0 * (p[1] + nm * p[2])).reshape(-1)
+    rows = np.repeat(np.arange(M), 27)
+    A = spp.csr_matrix((rand64c(rows.size, seed=1), (rows, cols)), shape=(M, K))
+    A.sum_duplicates(); A.sort_indices()
+    monkeypatch.setitem(hip.tuning, "wide_brick_shape", shape)
+    A_d = hip.csr_matrix(hip, A)
+    if dims[0] != dims[1]:
+        A_d.set_grid_dims(*dims)
+    xfull = rand64c(M + ld_pad, 64, seed=2)
+    yfull = np.full((K + ld_pad, 64), 7 - 3j, dtype=C64, order='F')
+    x_d = hip.copy_array(xfull)[0:M, :]
+    y_d = hip.copy_array(yfull)[0:K, :]
+    A_d.adjoint(y_d, x_d, alpha=alpha)
+    assert A_d._wide is not None and A_d._wide['ntasks'] > 0 and A_d._wide['geom'] == (n0, nm) + shape
+    exp = alpha * (A.conj().T.astype(np.complex128) @ xfull[:M].astype(np.complex128))
+    got = y_d.to_host()
+    assert rel_err(got, exp) < RTOL
+    untouched = np.setdiff1d(np.arange(K), np.unique(A.indices))
+    assert np.all(got[untouched] == 0)
+    if blob:
+        assert np.any(np.asarray(A_d._wide['tasks'].to_host()).view(np.int32).reshape(-1, 4)[:, 3] >> 16)   # shared pieces ran
+    # a second product into the same result: every tile is written again, nothing accumulates
+    A_d.adjoint(y_d, x_d, alpha=alpha)
+    assert rel_err(y_d.to_host(), exp) < RTOL
+
+
 @pytest.mark.parametrize("n,frac,alpha,beta,ld_pad", [(64, 0.3, 1, 0, 0), (64, 0.05, 0.5 - 1j, 1.5, 7), (32, 0.5, 1, 1, 0), (16, 0.3, 2, 0, 3),
                                                      (17, 0.3, 1, 0.5j, 0), (48, 0.6, 1, 0, 0)])
 def test_wide_panel_forward_over_touched_rows(hip, monkeypatch, n, frac, alpha, beta, ld_pad):
