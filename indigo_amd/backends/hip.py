@@ -99,7 +99,7 @@ class HipBackend(Backend):
         #   slots         coil counts whose adjoint gridding is the slot-format scatter (ig_ccsrmm_t_slots): the ranks of a coil-sharded
         #                 run with one or two coils
         self.tuning = dict(bricks=(4, 8), slots=(1, 2), slot_shape=(4, 4, 256, 64), support_tile=8, brick_shape={8: (2, 2, 4096, 4096), 4: (2, 4, 4096, 4096)}, xrows=True, wide_bricks=True,
-                           wide_brick_shape=(2, 2), wide_task_shape=(4096, 1024))
+                           wide_brick_shape=(2, 2), wide_task_shape=(8192, 2048))
 
     def __del__(self):
         try:
@@ -860,7 +860,7 @@ class HipBackend(Backend):
             # (y, z)-blocked order of the grid, with chunks of 4..64 consecutive workgroups dealt to one XCD so that the bricks that
             # need the same rows of X meet behind one L2 -- 3.7..4.2 ms against 3.35 ms, and the same 9.7 GB of re-fetched rows by
             # the PMC counters: a brick takes a wave ~25 us, a line lives ~7 us in a 4 MB L2 that 0.5 TB/s stream through.
-            chunk, run = (max(4, int(v) // 4 * 4) for v in b.tuning.get('wide_task_shape', (4096, 1024)))
+            chunk, run = (max(4, int(v) // 4 * 4) for v in b.tuning.get('wide_task_shape', (8192, 2048)))
             tasks, table, shared = brick_tasks(counts, ptr, chunk, run, max_bricks=64, longest_first=True)
             # tiles (16 rows of the result) some task stores in full: those of the non-empty bricks that are not cut into shared pieces
             owned_b = np.zeros(counts.size, dtype=bool)
