@@ -366,7 +366,9 @@ class Backend(object):
         npts = int(np.prod(coord.shape[1:]))
         coord = coord.reshape((ndim, -1), order='F')
         from indigo_amd.interp import interp_mat
-        return self.SpMatrix(interp_mat(npts, N, width, table, coord).astype(dtype), **kwargs)
+        op = self.SpMatrix(interp_mat(npts, N, width, table, coord).astype(dtype), **kwargs)
+        op._grid_dims = tuple(int(v) for v in N)        # the columns are the points of this grid, first axis fastest (a hint: hip.py)
+        return op
 
     @staticmethod
     def nufft_params(width, oversamp):
