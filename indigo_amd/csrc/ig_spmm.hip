@@ -292,17 +292,35 @@ k_csrmm_gather_tile64(int64_t M, int64_t nnz, const int32_t* __restrict__ rowptr
     }
     const float4* __restrict__ X4 = reinterpret_cast<const float4*>(X) + c * 2;
     const int32_t last = (int32_t)(nnz - 1);
-    auto load_idx = [&](int32_t a, int32_t b, int32_t (&kk)[U], float2 (&vv)[U]) {
+    // The indices and values of a pass: ONE coalesced load each (lane l: nonzero a + l, l < 28), spread to the (column group,
+    // nonzero lane) roles through the LDS crossbar afterwards.  (Every lane loading its own copy -- 16 lanes the same address --
+    // cost 14 memory instructions per row beside the 14 of the panel rows, and the address unit takes its 16 clocks per wave
+    // instruction whatever the addresses are: it was busy 85 % of the kernel, TA_TA_BUSY.)
+    auto load_raw = [&](int32_t a, int32_t b, int32_t& rk, float2& rv) {
+        rk = 0; rv = make_float2(0.f, 0.f);
+        if (lane < 4 * U) {
+            const int32_t pu = a + lane;
+            const bool ok = pu < b;
+            int32_t q = ok ? pu : b - 1;                 // a slot past the row's end re-reads its last nonzero with value 0
+            q = q < 0 ? 0 : (q > last ? last : q);
+            rk = colind[q];
+            const float2 t = vals[q];
+            rv = ok ? t : make_float2(0.f, 0.f);
+        }
+    };
+    auto spread = [&](int32_t rk, float2 rv, int32_t (&kk)[U], float2 (&vv)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int32_t pu = a + i + 4 * u;
-            const bool ok = pu < b;
-            int32_t q = ok ? pu : b - 1;                 // a slot past the row's end re-reads its last nonzero (a cache hit) with value 0
-            q = q < 0 ? 0 : (q > last ? last : q);
-            kk[u] = colind[q];
-            const float2 t = vals[q];
-            vv[u] = ok ? t : make_float2(0.f, 0.f);
+            const int src = (i + 4 * u) * 4;             // lane (c, i) takes nonzero i + 4u of the pass
+            kk[u] = __builtin_amdgcn_ds_bpermute(src, rk);
+            vv[u].x = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(rv.x)));
+            vv[u].y = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(rv.y)));
         }
+    };
+    auto load_idx = [&](int32_t a, int32_t b, int32_t (&kk)[U], float2 (&vv)[U]) {
+        int32_t rk; float2 rv;
+        load_raw(a, b, rk, rv);
+        spread(rk, rv, kk, vv);
     };
     auto gather = [&](const int32_t (&kk)[U], const float2 (&vv)[U], float2 (&acc)[4]) {
         float4 x4[U][2];
@@ -339,8 +357,8 @@ k_csrmm_gather_tile64(int64_t M, int64_t nnz, const int32_t* __restrict__ rowptr
         float2 acc[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) acc[u] = make_float2(0.f, 0.f);
-        int32_t kn[U];
-        float2 vn[U];
+        int32_t rkn;
+        float2 rvn;
         if (!deferred) {
             // (program order = issue order: the panel rows of this row, then the indices of the wave's next row, and the
             // multiply-adds below only wait for the former -- loads return in order)
@@ -350,7 +368,7 @@ k_csrmm_gather_tile64(int64_t M, int64_t nnz, const int32_t* __restrict__ rowptr
                 x4[u][0] = X4[(int64_t)k[u] * 32];
                 x4[u][1] = X4[(int64_t)k[u] * 32 + 1];
             }
-            load_idx(q0, q1, kn, vn);
+            load_raw(q0, q1, rkn, rvn);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 acc_nz<CONJ>(acc[0], v[u], make_float2(x4[u][0].x, x4[u][0].y));
@@ -370,14 +388,13 @@ k_csrmm_gather_tile64(int64_t M, int64_t nnz, const int32_t* __restrict__ rowptr
                 acc[u].x += __shfl_xor(acc[u].x, 32, 64); acc[u].y += __shfl_xor(acc[u].y, 32, 64);
             }
         } else {
-            load_idx(q0, q1, kn, vn);
+            load_raw(q0, q1, rkn, rvn);
         }
         if (i == 0) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) tile[(wv + 4 * j) * TLD + 4 * c + u] = acc[u];
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) { k[u] = kn[u]; v[u] = vn[u]; }
+        spread(rkn, rvn, k, v);
         p0 = q0; p1 = q1;
     }
     // which of the tile's 64 rows are to be stored: wave w's bit j is row w + 4j
@@ -969,13 +986,27 @@ k_pack_panel_tiled(int64_t rows, int64_t N, const float2* __restrict__ X, int64_
                    const int32_t* __restrict__ xperm) {
     __shared__ float2 tile[NP][65];
     const int tid = threadIdx.x;
-    for (int64_t k0 = (int64_t)blockIdx.x * 64; k0 < rows; k0 += (int64_t)gridDim.x * 64) {
-        const int kk = tid & 63;
+    const int kk = tid & 63, c0 = tid >> 6;
+    constexpr int PER = NP / (BLK / 64);                 // columns per thread
+    // software-pipelined over the workgroup's tiles: the loads of the next tile are in flight while this one is written out
+    float2 v[PER];
+    auto load = [&](int64_t k0) {
         const int64_t k = k0 + kk;
         const int64_t src = k < rows ? (xperm ? (int64_t)xperm[k] : k) : 0;
-        for (int c = tid >> 6; c < NP; c += BLK / 64)
-            tile[c][kk] = (c < N && k < rows) ? X[c * ld + src] : make_float2(0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int c = c0 + u * (BLK / 64);
+            v[u] = (c < N && k < rows) ? X[c * ld + src] : make_float2(0.f, 0.f);
+        }
+    };
+    int64_t k0 = (int64_t)blockIdx.x * 64;
+    if (k0 < rows) load(k0);
+    for (; k0 < rows; k0 += (int64_t)gridDim.x * 64) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) tile[c0 + u * (BLK / 64)][kk] = v[u];
         __syncthreads();
+        const int64_t kn = k0 + (int64_t)gridDim.x * 64;
+        if (kn < rows) load(kn);
         for (int e = tid; e < 64 * NP; e += BLK) {
             const int r = e / NP, c = e % NP;
             if (k0 + r < rows) Xp[(k0 + r) * NP + c] = tile[c][r];
