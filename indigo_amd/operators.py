@@ -324,7 +324,11 @@ class ZpadFFT(MatrixFreeOperator):
         if box_lo is None:      # centred, as Backend.Zpad(mode='center')
             box_lo = tuple(m // 2 + int(np.ceil(-n / 2)) for m, n in zip(self._grid, self._box))
         self._lo = tuple(int(s) for s in box_lo)
-        w = np.asfortranarray(np.asarray(weights, dtype=_C64))
+        w = np.asarray(weights, dtype=_C64)
+        # layout 2 wants the coils of a voxel side by side: an array that already is (voxels in F order) x (coils, contiguous)
+        # -- SenseProblem.fused_weights(interleaved=True) -- is kept as it is instead of being turned coil-major and back
+        if not (self._layout == 2 and w.ndim == 4 and w.reshape((-1, w.shape[3]), order='F').flags['C_CONTIGUOUS']):
+            w = np.asfortranarray(w)
         assert w.shape[:3] == self._box, "weights must be box_shape + (ncoils,)"
         self._C = int(w.shape[3])
         self._w_h = w

@@ -144,13 +144,34 @@ class SenseProblem(object):
             data[:, j] = np.conj(base * self.coil_map(c).reshape(Nn, order='F'))
         return spp.csr_matrix((data.reshape(-1), indices.reshape(-1), indptr), shape=(Nn, Cn * P))
 
-    def fused_weights(self, coils=None):
-        """w[..., c] = mod(box) * apod * maps[..., c]: the per-voxel, per-coil factor of S' (F-ordered, box + (C,))."""
+    def fused_weights(self, coils=None, interleaved=False):
+        """w[..., c] = mod(box) * apod * maps[..., c]: the per-voxel, per-coil factor of S' (F-ordered, box + (C,)).
+        interleaved: the same values and shape with a voxel's coils side by side in memory (what the coil-interleaved grid
+        layout uploads: no transposition of a 2 GB array on the way)."""
         coils = list(range(self.C) if coils is None else coils)
         from indigo_amd.backends.backend import Backend
-        mod = fftc_mod_box(self.oN, self.N)
-        apod = rolloff3(self.oversamp, self.width, self.beta, self.N).astype(_C64)
-        base = (mod * apod).astype(_C64)
+        base = self._interp_cache.get('weights_base')       # the same for every coil chunk of a tree (config 5: four of them)
+        if base is None:
+            mod = fftc_mod_box(self.oN, self.N)
+            apod = rolloff3(self.oversamp, self.width, self.beta, self.N).astype(_C64)
+            base = self._interp_cache['weights_base'] = (mod * apod).astype(_C64)
+        if interleaved and len(coils) > 1:
+            w = np.empty(self.N[::-1] + (len(coils),), dtype=_C64).transpose(2, 1, 0, 3)
+            nz, nth = self.N[2], (8 if base.size >= 1 << 20 else 1)
+
+            def slab(k):                                 # threads own z slabs (coil-parallel writes would share cache lines)
+                z0, z1 = k * nz // nth, (k + 1) * nz // nth
+                for j in range(len(coils)):
+                    np.multiply(base[:, :, z0:z1], cmaps[j][:, :, z0:z1], out=w[:, :, z0:z1, j])
+            if nth > 1:
+                from concurrent.futures import ThreadPoolExecutor
+                with ThreadPoolExecutor(max_workers=nth) as ex:
+                    cmaps = list(ex.map(self.coil_map, coils))      # (lazy maps are generated here, coil-parallel)
+                    list(ex.map(slab, range(nth)))
+            else:
+                cmaps = [self.coil_map(c) for c in coils]
+                slab(0)
+            return w
         w = np.empty(self.N + (len(coils),), dtype=_C64, order='F')
 
         def one(jc):
@@ -257,7 +278,7 @@ class SenseProblem(object):
             table = self.grid_support(Gm)
         self.last_support_table = table
         order = self.locality_order(Gm) if reorder and Cn <= 8 else None
-        A = fused.assemble(backend, Gm, self.oN, self.N, lambda lo, hi: self.fused_weights(coils[lo:hi]), Cn,
+        A = fused.assemble(backend, Gm, self.oN, self.N, lambda lo, hi: self.fused_weights(coils[lo:hi], interleaved=(layout == 2)), Cn,
                            layout, chunks, table=table, row_order=order)
         self.last_support_fine = getattr(A, '_support_fine', None)       # (table, tile) when the tree took a finer table
         return A
