@@ -8,10 +8,11 @@ mkdir -p $OUT
 rocprofv3 --pmc $CNT --kernel-include-regex "$RE" -d $OUT -o p --output-format csv -- python3 bench.py --no-cpu-baseline --no-extras "$@" > /dev/null 2> $OUT/log.txt
 F=$(find $OUT -name 'p_counter_collection.csv' | head -1)
 python3 - "$F" <<'P'
-import csv, sys, collections
+import csv, sys, collections, re
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1])):
-    acc[r['Kernel_Name'].split('(')[0][-60:]][r['Counter_Name']].append(float(r['Counter_Value']))
+    m = re.search(r'k_\w+(<[^>]*>)?', r['Kernel_Name'])
+    acc[m.group(0) if m else r['Kernel_Name'][:60]][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, d in acc.items():
     print(k)
     for c, v in d.items():
