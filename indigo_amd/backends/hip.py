@@ -839,7 +839,9 @@ class HipBackend(Backend):
                 unit = 4 if bm * bs > 1 else 1
                 counts = np.zeros(nbx * nbm * (ns // bs), dtype=np.int32)
                 if b._L.ig_grid_bricks_count(m, indptr.ctypes.data, indices.ctypes.data, n0, nm, ns, bm, bs, unit, counts.ctypes.data) == 0:
-                    break
+                    # a matrix whose rows do not cluster on the (guessed) grid would be mostly padding in quads: keep 16-row bricks
+                    if unit == 1 or int(counts.sum(dtype=np.int64)) <= 1.6 * max(int(indptr[-1] - indptr[0]), 1):
+                        break
             else:
                 self._wide = None
                 return None

@@ -308,6 +308,23 @@ def test_wide_panel_adjoint_by_grid_bricks(hip, monkeypatch, dims, shape, alpha,
     assert rel_err(y_d.to_host(), exp) < RTOL
 
 
+def test_wide_panel_adjoint_cube_of_columns_that_is_no_grid(hip):
+    """32^3 columns look like a grid to the guess, but the rows of a random matrix do not cluster on it: quads would be three
+    quarters padding, so the format keeps 16-row bricks -- and the product is right either way"""
+    M, K = 3000, 32 ** 3
+    rng = np.random.default_rng(5)
+    rows = np.repeat(np.arange(M), 20)
+    cols = rng.integers(0, K, size=rows.size)
+    A = spp.csr_matrix((rand64c(rows.size, seed=1), (rows, cols)), shape=(M, K))
+    A.sum_duplicates(); A.sort_indices()
+    A_d = hip.csr_matrix(hip, A)
+    x = rand64c(M, 64, seed=2)
+    y_d = hip.copy_array(np.full((K, 64), 3 + 1j, dtype=C64, order='F'))
+    A_d.adjoint(y_d, hip.copy_array(x))
+    assert A_d._wide is not None and A_d._wide['geom'] == (K, 1, 1, 1)
+    assert rel_err(y_d.to_host(), A.conj().T.astype(np.complex128) @ x.astype(np.complex128)) < RTOL
+
+
 @pytest.mark.parametrize("n,frac,alpha,beta,ld_pad", [(64, 0.3, 1, 0, 0), (64, 0.05, 0.5 - 1j, 1.5, 7), (32, 0.5, 1, 1, 0), (16, 0.3, 2, 0, 3),
                                                      (17, 0.3, 1, 0.5j, 0), (48, 0.6, 1, 0, 0)])
 def test_wide_panel_forward_over_touched_rows(hip, monkeypatch, n, frac, alpha, beta, ld_pad):
