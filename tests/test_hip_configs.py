@@ -307,7 +307,20 @@ def test_config5_coil_chunks_vs_oracle(hip, oracle_backend):
     x = rand64c(A.shape[1], 1, seed=1)
     k = rand64c(A.shape[0], 1, seed=2)
     assert rel_err(A * x, A_o * x) < RTOL
-    assert rel_err(A.H * k, A_o.H * k) < RTOL
+    ref_h = A_o.H * k
+    got_h = A.H * k
+    if not rel_err(got_h, ref_h) < RTOL:                 # which chunk, and is a second evaluation the same?
+        T = p.T
+        again = A.H * k
+        msg = ["adjoint err %.3e, second evaluation err %.3e, first vs second %.3e" % (rel_err(got_h, ref_h), rel_err(again, ref_h), rel_err(again, got_h))]
+        lo = 0
+        for ci, ch in enumerate(A.children):
+            nc = ch.shape[0] // T
+            kk = k[lo:lo + ch.shape[0]]
+            Ao_c = p.build_zpadfft(oracle_backend, coils=list(range(lo // T, lo // T + nc)), layout=0, support=False)
+            msg.append("chunk %d (%d coils): err %.3e" % (ci, nc, rel_err(ch.H * kk, Ao_c.H * kk)))
+            lo += ch.shape[0]
+        raise AssertionError("; ".join(msg))
     AHA = normal_operator(A, lamda=0.3)
     y_d = hip.zero_array((A.shape[1], 1), C64)
     AHA.eval(y_d, hip.copy_array(x))
