@@ -605,6 +605,9 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
 #ifndef IG_F3B_NT_ST
 #define IG_F3B_NT_ST false
 #endif
+#ifndef IG_F3B_XCD
+#define IG_F3B_XCD 1
+#endif
 #ifndef IG_F3A_NT_LD
 #define IG_F3A_NT_LD true
 #endif
@@ -756,8 +759,17 @@ k_fft3d_b(const float2* __restrict__ in, float2* __restrict__ out, const float2*
     float2* __restrict__ tws = lds + 2 * F3_LDS_ELEMS;
     const int tid = threadIdx.x;
     for (int k = tid; k < 256; k += 512) tws[k] = tw[k];
+#if IG_F3B_XCD
+    // blocks are dealt round-robin to the 8 XCDs: give each XCD a contiguous range of (x tile, k1, volume) triples, so that the
+    // sixteen x tiles of a row group -- adjacent 128-byte pieces of the same 2 KB rows -- run behind one L2 at about the same time
+    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), tot = gridDim.x * gridDim.y * gridDim.z;
+    const unsigned logical = (lin & 7u) * (tot >> 3) + (lin >> 3);            // (tot is a multiple of 8: 16 * 64 * batch)
+    const int xs = (int)(logical & 15u) * 16, k1 = (int)((logical >> 4) & 63u);
+    const int64_t base = ((int64_t)(logical >> 10) << 24) + xs;
+#else
     const int xs = blockIdx.x * 16, k1 = blockIdx.y;
     const int64_t base = ((int64_t)blockIdx.z << 24) + xs;
+#endif
     // role 0: h = lane bit 0 picks the rows n2 = h, h + 2 (the other two live in the neighbouring lane); w = x; t = z mod 16
     const int h = tid & 1, w = (tid >> 1) & 15, t = tid >> 5;
     const bool inv = inverse != 0;
