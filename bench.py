@@ -819,6 +819,9 @@ def main():
     rank = RANK
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("INDIGO_BENCH_WATCHDOG"):          # debugging aid: dump every thread's stack and exit after that many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["INDIGO_BENCH_WATCHDOG"]), exit=True, file=sys.stderr)
     assert world == args.gpus, "--gpus %d but WORLD_SIZE is %d" % (args.gpus, world)
     if world > 1 and args.comm != "rccl":
         # The collective is the library's own RCCL binding (ig_comm_*).  Under `--comm auto` torch is imported FIRST --
