@@ -278,3 +278,17 @@ def test_support_tables_of_every_granularity_cover_the_touched_cells():
         ky, kz, tt = np.nonzero(seg)
         assert np.all(zr[ky * nt + tt, 0] <= kz) and np.all(kz < zr[ky * nt + tt, 1])  # z hull per (ky, tile)
         assert np.all(yr[tt, 0] <= ky) and np.all(ky < yr[tt, 1])                      # y hull per tile
+
+
+def test_fused_weights_interleaved_is_the_same_array_in_another_memory_order():
+    """SenseProblem.fused_weights(interleaved=True): same values and shape, a voxel's coils adjacent in memory -- what the
+    coil-interleaved leaf uploads without a transposition (lazy and stored maps, threaded and unthreaded sizes)"""
+    from indigo_amd.sense import SenseProblem
+    for N, C, lazy in (((24, 20, 16), 3, True), ((112, 96, 100), 4, False)):
+        p = SenseProblem.synthetic(N, C, nspokes=8, nreadout=16, lazy_maps=lazy)
+        a = p.fused_weights()
+        b = p.fused_weights(interleaved=True)
+        assert a.shape == b.shape == N + (C,) and np.array_equal(a, b)
+        assert a.flags['F_CONTIGUOUS'] and b.reshape((-1, C), order='F').flags['C_CONTIGUOUS']
+        one = p.fused_weights([1], interleaved=True)
+        assert np.array_equal(one[..., 0], a[..., 1])
