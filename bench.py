@@ -84,11 +84,12 @@ def kernel_symbols(layout, ncoils, half_box=True, n=512, support_tile=16):
                       "fft_crop_z": f % "32, false, 0, true, 2", "fft_crop_y": f % "32, false, 0, true, 2",
                       "fft_crop_x": f % ("16, false, %d, true, 4" % (3 + lg))})
         else:
-            # no compile-time half box (config 5: 320 of 512): run-time box predicates; the y passes (16 MB stride on the
-            # grid side) take 32-column tiles, the z passes 16-column ones
+            # no compile-time half box (config 5: 320 of 512): run-time box predicates; the y and z passes take 32-column tiles
+            # (the z passes where a support bitmap gates their loads / stores, i.e. in the fused tree)
+            zt = "32" if n == 512 else "16"
             m.update({"fft_pad_x": f % "16, false, 1, true, 0",
-                      "fft_pad_y": f % "32, false, 0, true, 0", "fft_pad_z": f % "16, false, 0, true, 0",
-                      "fft_crop_z": f % "16, false, 0, true, 0", "fft_crop_y": f % "32, false, 0, true, 0",
+                      "fft_pad_y": f % "32, false, 0, true, 0", "fft_pad_z": f % (zt + ", false, 0, true, 0"),
+                      "fft_crop_z": f % (zt + ", false, 0, true, 0"), "fft_crop_y": f % "32, false, 0, true, 0",
                       "fft_crop_x": f % ("16, false, %d, true, 0" % (3 + lg))})
         m.update({"csrmm_rowlane_conj": "k_csrmm_dense64<%d, true, true>" % ncoils, "csrmm_gather": gv, "csrmm_slots_conj": "k_grid_slots<%d>" % ncoils,
                   # (second argument: segments per 16 x 2 x 2 brick, unrolled for the 8-coil kernel)

@@ -1160,7 +1160,8 @@ int launch_2stage(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d_in, bool ax
     // 32-column tiles when one side runs at a huge stride: cropped y pass of config 5 0.85 -> 0.74 ms, padded y pass unchanged
     // ... and so do plain (unboxed) passes at a huge stride, through the same run-time-box variant: the z pass of a plain 512^3
     // transform steps 2 MB per element (3.82 -> 3.08 ms for 512^3 x 8)
-    const bool w32_generic = half == 0 && big_stride;
+    // ... and the z passes of such a box once the support bitmap gates their loads / stores (config 5: see DESIGN 3.1)
+    const bool w32_generic = half == 0 && (big_stride || d.tile_bits != nullptr);
     if (ax.n == 512 && !axis0 && wmode == 0 && !d.cw && d.ext0 % 32 == 0 &&
         (half == 1 || half == 3 || half == 2 || half == 4 || w32_generic) &&
         (!d.tile_range || d.tile_shift >= 1)) {
