@@ -270,24 +270,24 @@ k_csrmm_gather_v(int64_t M, const int32_t* __restrict__ rowptr, const int32_t* _
 // side by side).  Lane (c, i): panel columns 4c .. 4c+3 (two 16-byte loads), nonzero lane i of 4; a pass covers 28 nonzeros of
 // a row.  The 64 x 64 results go through an LDS tile and leave as full 128-byte lines of the column-major result (lanes = 16
 // rows x 4 columns).  Rows beyond thr_long nonzeros go to the workgroup-per-row list as everywhere else.
-template <bool CONJ, int BMODE>
-__global__ void __launch_bounds__(BLK)
+template <bool CONJ, int BMODE, int NW /* waves per workgroup: 4 or 16 */>
+__global__ void __launch_bounds__(64 * NW)
 k_csrmm_gather_tile64(int64_t M, int64_t nnz, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
                       const float2* __restrict__ vals, const float2* __restrict__ X /* [row][64] */,
                       float2* __restrict__ Y, int64_t ldy, float2 alpha, float2 beta, int xcd_remap,
                       WorkLists wl, int32_t thr_long) {
-    constexpr int TLD = 65, U = 7;          // 28 nonzeros per pass: a 27-tap gridding row in one, four idle slots fewer than at 8
+    constexpr int TLD = 65, U = 7, RPW = 64 / NW;     // rows per wave          // 28 nonzeros per pass: a 27-tap gridding row in one, four idle slots fewer than at 8
     __shared__ float2 tile[64 * TLD];
     const int lane = threadIdx.x & 63, c = lane & 15, i = lane >> 4;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t blk = xcd_remap ? xcd_block(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
     const int64_t row0 = blk * 64;
     if (row0 >= M) return;
-    // lanes 2j / 2j + 1 hold the row pointers p0 / p1 of this wave's j-th row, row0 + wv + 4j
+    // lanes 2j / 2j + 1 hold the row pointers p0 / p1 of this wave's j-th row, row0 + wv + NW j
     int32_t myp;
     {
-        int64_t r = row0 + wv + 4 * (lane >> 1) + (lane & 1);
-        if (lane >= 32 || r > M) r = M;
+        int64_t r = row0 + wv + NW * (lane >> 1) + (lane & 1);
+        if (lane >= 2 * RPW || r > M) r = M;
         myp = rowptr[r];
     }
     const float4* __restrict__ X4 = reinterpret_cast<const float4*>(X) + c * 2;
@@ -343,14 +343,14 @@ k_csrmm_gather_tile64(int64_t M, int64_t nnz, const int32_t* __restrict__ rowptr
     float2 v[U];
     load_idx(p0, p1, k, v);
 #pragma unroll 1
-    for (int j = 0; j < 16; ++j) {
-        const int jn = j + 1 < 16 ? j + 1 : 15;
+    for (int j = 0; j < RPW; ++j) {
+        const int jn = j + 1 < RPW ? j + 1 : RPW - 1;
         int32_t q0 = __builtin_amdgcn_readlane(myp, 2 * jn), q1 = __builtin_amdgcn_readlane(myp, 2 * jn + 1);
-        if (j == 15) q1 = q0;                            // nothing after the last row
-        const int64_t row = row0 + wv + 4 * j;
+        if (j == RPW - 1) q1 = q0;                       // nothing after the last row
+        const int64_t row = row0 + wv + NW * j;
         bool deferred = false;
         if (p1 - p0 > thr_long && row < M) {
-            const bool mine = wl_append(wl, 1, (int)((blk * 4 + wv) & (WL_SUB - 1)), lane == 0, (int32_t)row);
+            const bool mine = wl_append(wl, 1, (int)((blk * NW + wv) & (WL_SUB - 1)), lane == 0, (int32_t)row);
             deferred = __builtin_amdgcn_readfirstlane((int)mine) != 0;
         }
         if (deferred || row >= M) skip |= 1u << j;
@@ -392,22 +392,21 @@ k_csrmm_gather_tile64(int64_t M, int64_t nnz, const int32_t* __restrict__ rowptr
         }
         if (i == 0) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) tile[(wv + 4 * j) * TLD + 4 * c + u] = acc[u];
+            for (int u = 0; u < 4; ++u) tile[(wv + NW * j) * TLD + 4 * c + u] = acc[u];
         }
         spread(rkn, rvn, k, v);
         p0 = q0; p1 = q1;
     }
-    // which of the tile's 64 rows are to be stored: wave w's bit j is row w + 4j
-    __shared__ unsigned skip_all[4];
+    // which of the tile's 64 rows are to be stored: wave w's bit j is row w + NW j
+    __shared__ unsigned skip_all[NW];
     if (lane == 0) skip_all[wv] = skip;
     __syncthreads();
-    // the tile leaves as 128-byte lines: wave w stores rows 16w .. 16w + 15, lane = (row in that group, column group)
-    const int cell = lane & 15, cg = lane >> 4;
-    const int tr = 16 * wv + cell;                           // row of the tile; computed by wave tr & 3 as its (tr >> 2)-th row
-    const bool keep = !((skip_all[tr & 3] >> (tr >> 2)) & 1u);
+    // the tile leaves as full lines of the column-major result: lane = row of the tile (64 consecutive rows = 512 bytes of one
+    // column per wave store), wave w the columns w, w + NW, ...
+    const int tr = lane;                                     // computed by wave tr % NW as its (tr / NW)-th row
+    const bool keep = !((skip_all[tr % NW] >> (tr / NW)) & 1u);
 #pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-        const int col = cg + 4 * it;
+    for (int col = wv; col < 64; col += NW) {
         float2 out = cmul(alpha, tile[tr * TLD + col]);
         float2* dst = Y + (int64_t)col * ldy + row0 + tr;
         if (keep) {
@@ -1932,9 +1931,11 @@ int launch_gather(ig_ctx* ctx, int64_t rows, int64_t xrows, int64_t N, int64_t n
                     // 64 columns: tiles of 64 rows per workgroup, software-pipelined (k_csrmm_gather_tile64)
                     const int64_t tblocks = (rows + 63) / 64;
                     IG_REQUIRE(ctx, tblocks <= 0x7fffffffLL, "csrmm: matrix too large for one launch");
-                    if (b0) hipLaunchKernelGGL((k_csrmm_gather_tile64<CONJ, 0>), dim3((unsigned)tblocks), dim3(BLK), 0, ctx->stream,
+                    // (waves per 64-row tile, measured: 4 -> 1.77-1.85 ms, 8 -> 1.82, 16 -> 1.97: one big workgroup per CU loses the
+                    // overlap between workgroups and gains nothing from the smaller L2 footprint)
+                    if (b0) hipLaunchKernelGGL((k_csrmm_gather_tile64<CONJ, 0, 4>), dim3((unsigned)tblocks), dim3(256), 0, ctx->stream,
                                 rows, nnz, rowptr, colind, vals, X, Y, ldy, alpha, beta, xcd, wl, thr_long);
-                    else    hipLaunchKernelGGL((k_csrmm_gather_tile64<CONJ, 1>), dim3((unsigned)tblocks), dim3(BLK), 0, ctx->stream,
+                    else    hipLaunchKernelGGL((k_csrmm_gather_tile64<CONJ, 1, 4>), dim3((unsigned)tblocks), dim3(256), 0, ctx->stream,
                                 rows, nnz, rowptr, colind, vals, X, Y, ldy, alpha, beta, xcd, wl, thr_long);
                 }
                 else IG_GV(4, 16, 4);                                                                      // 64 columns: 16 nonzeros per trip
