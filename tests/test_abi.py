@@ -100,7 +100,7 @@ def test_host_grid_brick_binning_matches_definition():
     L = _lib.lib()
     rng = np.random.default_rng(11)
     n0, nm, ns = 32, 16, 32
-    for bm, bs, unit in ((4, 4, 8), (8, 8, 16), (2, 16, 8), (16, 4, 1)):
+    for bm, bs, unit in ((4, 4, 8), (8, 8, 16), (2, 16, 8), (16, 4, 1), (2, 2, 4)):       # (2, 2, 4): the quads of the wide adjoint
         M, P = 300, n0 * nm * ns
         A = spp.random(M, P, density=0.002, format='csr', random_state=rng).astype(np.complex64)
         A.data = (A.data.real + 1j * rng.random(A.nnz)).astype(np.complex64)
