@@ -802,8 +802,15 @@ def self_launch(args):
                         procs[q].terminate()
             time.sleep(0.2)
         if out0:
-            sys.stdout.write(out0.decode())
+            # rank 0's stdout is its ONE JSON line -- plus whatever a library chose to print there (gloo announces its
+            # connections on stdout): only the JSON goes on, the rest to stderr
+            for line in out0.decode().splitlines():
+                if line.lstrip().startswith("{"):
+                    sys.stdout.write(line + "\n")
+                else:
+                    print(line, file=sys.stderr)
             sys.stdout.flush()
+            sys.stderr.flush()
     finally:
         for p in procs:
             if p.poll() is None:
