@@ -608,6 +608,9 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
 #ifndef IG_F3B_XCD
 #define IG_F3B_XCD 1
 #endif
+#ifndef IG_F3A_XCD
+#define IG_F3A_XCD 1
+#endif
 #ifndef IG_F3A_NT_LD
 #define IG_F3A_NT_LD true
 #endif
@@ -628,8 +631,17 @@ k_fft3d_a(const float2* __restrict__ in, float2* __restrict__ out, const float2*
     float2* __restrict__ tws = lds + F3_LDS_ELEMS;
     const int tid = threadIdx.x;
     for (int k = tid; k < 256; k += 512) tws[k] = tw[k];
+#if IG_F3A_XCD
+    // each XCD walks a contiguous range of (n2, z, volume) triples: the four n2 workgroups of a plane -- interleaved 2 KB lines
+    // of the same 512 KB -- run behind one L2 at about the same time
+    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), tot = gridDim.x * gridDim.y * gridDim.z;
+    const unsigned logical = (lin & 7u) * (tot >> 3) + (lin >> 3);            // (tot is a multiple of 8: 256 * 4 * batch)
+    const int n2 = (int)(logical & 3u), z = (int)((logical >> 2) & 255u);
+    const int64_t base = ((int64_t)(logical >> 10) << 24) + ((int64_t)z << 16);
+#else
     const int z = blockIdx.x, n2 = blockIdx.y;
     const int64_t base = ((int64_t)blockIdx.z << 24) + ((int64_t)z << 16);
+#endif
     const int xl = tid & 63, a = tid >> 6;
     const bool inv = inverse != 0;
 
