@@ -27,7 +27,7 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
                      live with HIP events on the backend's stream; `traffic` = HBM bytes per launch from the
                      committed rocprofv3 PMC summary of this same command (profiles/)
   cpu_baseline     : the numpy oracle (restatement of the reference's numpy backend) timed on the host on ONE coil
-                     of the same problem (warm-up + min of 3), scaled to evals/s; single-threaded, baseline only
+                     of the same problem (warm-up + min of 5), scaled to evals/s; single-threaded, baseline only
   parity_rel_err   : the benchmarked operator with all coils but one switched off vs that oracle evaluation and vs a
                      double-precision evaluation of the same operator (the complex64 oracle is itself only good to
                      ~2.6e-5 on this DC-heavy input, oracle/precise.py)
@@ -182,6 +182,30 @@ def timed_steps(B, comm, fn, steps, warmup):
     return elapsed, prof
 
 
+def tree_support(A):
+    """(support table, kx points per entry) of the fused leaf the tree evaluates with -- read off the tree, so that trees built by
+    the reference's recipe + FuseZpadFFT are priced by the table THEY carry (None, 16 without one)"""
+    from indigo_amd.operators import ZpadFFT
+    stack = [A]
+    while stack:
+        node = stack.pop()
+        if isinstance(node, ZpadFFT):
+            if node._support_h is None:
+                return None, 16
+            return node._support_h, int(node._tile_kw.get('support_tile', 16))
+        stack.extend(getattr(node, '_children', None) or [])
+    return None, 16
+
+
+def check_fractions(obj, where="roofline"):
+    """a fraction of the HBM peak above 1 is a pricing bug (bytes the kernel never moved), never a result: refuse to print it"""
+    if isinstance(obj, dict):
+        for k, v in obj.items():
+            if isinstance(v, (int, float)) and not isinstance(v, bool) and (k == "frac" or k.endswith("_frac") or k.endswith("frac_of_peak")) and v > 1.0:
+                raise AssertionError("%s.%s = %.3f > 1.0: the byte model prices traffic the kernels do not move" % (where, k, v))
+            check_fractions(v, where + "." + str(k))
+
+
 def roofline_of(prof, symbols, cfg, pick=None):
     """merge call sites that launch the same device kernel, pick the dominant one, price it"""
     kernels = {}
@@ -245,6 +269,9 @@ def make_comm(args, B, world, rank, local_rank):
         return None
     from indigo_amd import dist as igdist
     if args.comm in ("auto", "rccl") and os.environ.get("INDIGO_BENCH_DIST_BACKEND", "nccl") == "nccl":
+        # (RcclComm raises on ALL ranks together or on none: what can fail on one rank alone -- loading RCCL -- is voted on in
+        # the id handshake before anyone enters ncclCommInitRank, and the handshake itself times out everywhere at once; so
+        # the fallback below is taken by every rank or by none)
         try:
             c = igdist.RcclComm(B, rank, world)
             log("communicator: ig_comm (RCCL through the C ABI), %d ranks" % world)
@@ -352,8 +379,8 @@ def run_sense(args, cfg, B, comm, world, rank, steps, warmup, want_cpu, quiet=Fa
     # ---- per call site: compulsory bytes (ours) and reference-model bytes (the leaf it replaces)
     cpr = len(coils) if nchunks == 1 else 8          # coils per chunk seen by one launch
     half_box = all(2 * b == n for b, n in zip(p.N, p.oN))
+    sup_tab, sup_tile = tree_support(A) if fused_fft else (None, 16)
     if fused_fft:
-        sup_tab, sup_tile = getattr(p, 'last_support_fine', None) or (getattr(p, 'last_support_table', None), 16)
         exact = p.zpadfft_pass_bytes(cpr, sup_tab, fused_sum=(layout == 2), tile=sup_tile)
         for name, nbytes in exact.items():
             if name in prof:
@@ -361,7 +388,6 @@ def run_sense(args, cfg, B, comm, world, rank, steps, warmup, want_cpu, quiet=Fa
                 # 4 * x.nbytes per 3-D transform, a third per pass; x = grid x coils
                 prof[name]['ref_bytes'] = 4.0 * np.prod(p.oN) * 8.0 * cpr / 3.0 * prof[name]['launches']
     csr = {(r['name'], r['forward']): r['nbytes'] for r in trace.records if r['event'] == 'csrmm' and not r.get('fused')}
-    sup_tab, sup_tile = getattr(p, 'last_support_fine', None) or (getattr(p, 'last_support_table', None), 16)
     grid_bytes = p.gridding_pass_bytes(cpr, sup_tab, tile=sup_tile) if fused_fft else {}
     for site, fwd in (("csrmm_gather", True), ("csrmm_rowlane_conj", False), ("csrmm_gather_conj", False), ("csrmm_bricks_conj", False),
                       ("csrmm_slots_conj", False)):
@@ -429,7 +455,7 @@ def run_sense(args, cfg, B, comm, world, rank, steps, warmup, want_cpu, quiet=Fa
 
 
 def cpu_baseline_and_parity(p, C, B, layout, y_dev):
-    """numpy oracle on ONE coil of the same problem: warm-up + min of 2 evaluations; evals/s = 1 / (C * t_one_coil).
+    """numpy oracle on ONE coil of the same problem: warm-up + min of 5 evaluations; evals/s = 1 / (C * t_one_coil).
     The same oracle result checks the benchmarked operator: coils 1..C-1 switched off, identical kernels."""
     import numpy as np
     from indigo_amd.sense import SenseProblem, normal_operator
@@ -443,7 +469,7 @@ def cpu_baseline_and_parity(p, C, B, layout, y_dev):
     x = O.copy_array(xh)
     y = O.zero_array((A1.shape[1], 1), np.dtype('complex64'))
     times = []
-    for i in range(4):                      # first = warm-up (scipy/pocketfft plan caches, page faults); ~25 s of CPU work in all
+    for i in range(6):                      # first = warm-up (scipy/pocketfft plan caches, page faults); ~40 s of CPU work in all
         t1 = time.perf_counter()
         AHA1.eval(y, x)
         times.append(time.perf_counter() - t1)
@@ -452,7 +478,7 @@ def cpu_baseline_and_parity(p, C, B, layout, y_dev):
     ref = y.to_host()
     cpu = dict(value=1.0 / (C * t), unit="evals/s", cores=1, kind="port", **host_info(),
                sample="numpy oracle (restatement of indigo/backends/np.py: np.fft.fftn + scipy csr @), 1 of %d coils of the same problem, "
-                      "1 warm-up + min of 3 evaluations (%.1f s each), scaled linearly in coils" % (C, t))
+                      "1 warm-up + min of 5 evaluations (%.1f s each), scaled linearly in coils" % (C, t))
     parity = None
     if layout is not None:
         zero = np.zeros(p.N, dtype=np.complex64, order='F')
@@ -526,6 +552,7 @@ def bench_sense(args, world, rank, local_rank):
         if extra5 is not None:
             out["config5"] = extra5
         out.update(leaves)
+        check_fractions({k: v for k, v in out.items() if k not in ("reference_model_equiv",)}, "line")
         print(json.dumps(out), flush=True)
     if comm is not None:
         comm.close()
@@ -565,12 +592,12 @@ def bench_fft(args, local_rank, B=None):
     if not args.no_cpu_baseline:
         v = x[:, :, :, 0:1].to_host()[..., 0]
         ts = []
-        for _ in range(3):
+        for _ in range(6):
             t1 = time.perf_counter()
             np.fft.fftn(v)
             ts.append(time.perf_counter() - t1)
         cpu = dict(value=1.0 / (batch * min(ts[1:])), unit="transforms/s", cores=1, kind="port", **host_info(),
-                   sample="np.fft.fftn (the reference numpy backend's fftn, np.py:102-115) on 1 of %d volumes, warm-up + min of 2 (%.2f s), scaled" % (batch, min(ts[1:])))
+                   sample="np.fft.fftn (the reference numpy backend's fftn, np.py:102-115) on 1 of %d volumes, warm-up + min of 5 (%.2f s), scaled" % (batch, min(ts[1:])))
     out = {"metric": "batched 3-D C2C FFT %d^3 x %d (complex64) transforms/sec" % (n, batch), "value": args.steps / elapsed,
            "unit": "transforms/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "complex64 (f32)", "data": "synthetic",
@@ -662,12 +689,12 @@ def bench_spmm(args, local_rank, B=None):
     if not args.no_cpu_baseline:
         xs = np.asfortranarray(X[:, 0:8].to_host())
         ts = []
-        for _ in range(3):
+        for _ in range(6):
             t1 = time.perf_counter()
             G @ xs
             ts.append(time.perf_counter() - t1)
         cpu = dict(value=1.0 / (min(ts[1:]) * ncol / 8.0), unit="products/s", cores=1, kind="port", **host_info(),
-                   sample="scipy csr @ dense (np.py:120-127) on 8 of the %d columns, warm-up + min of 2 (%.2f s), scaled" % (ncol, min(ts[1:])))
+                   sample="scipy csr @ dense (np.py:120-127) on 8 of the %d columns, warm-up + min of 5 (%.2f s), scaled" % (ncol, min(ts[1:])))
     out = {"metric": "gridding CSR (%d x %d^3, nnz %.2e) x %d-column SpMM products/sec" % (T, n, G.nnz, ncol), "value": args.steps / elapsed,
            "unit": "products/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "complex64 (f32)", "data": "synthetic",
@@ -771,6 +798,7 @@ def self_launch(args):
     rdv = tempfile.mkdtemp(prefix="indigo_bench_")
     procs = []
     rc = 0
+    kill_at = 0.0
     try:
         for r in range(n):
             env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
@@ -800,6 +828,11 @@ def self_launch(args):
                     print("[bench] launcher: rank %d exited with %d; stopping the others" % (r, code), file=sys.stderr, flush=True)
                     for q in pending:
                         procs[q].terminate()
+                    kill_at = time.time() + 10.0          # a rank inside ncclCommInitRank / a collective may ignore SIGTERM
+            if rc and pending and time.time() > kill_at:
+                for q in pending:
+                    if procs[q].poll() is None:
+                        procs[q].kill()
             time.sleep(0.2)
         if out0:
             # rank 0's stdout is its ONE JSON line -- plus whatever a library chose to print there (gloo announces its
@@ -827,10 +860,15 @@ def main():
     rank = RANK
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if os.environ.get("INDIGO_BENCH_WATCHDOG"):          # debugging aid: dump every thread's stack and exit after that many seconds
+    # Watchdog: after that many seconds every thread's stack is dumped and the rank exits non-zero (the launcher then stops the
+    # others).  ON by default for multi-rank runs (900 s; INDIGO_BENCH_WATCHDOG=0 disables): a bring-up or a collective that
+    # hangs on one rank must end with stacks and an exit status, not eat the caller's whole time limit in silence.
+    wd = int(os.environ.get("INDIGO_BENCH_WATCHDOG", "900" if world > 1 else "0") or 0)
+    if wd > 0:
         import faulthandler
-        faulthandler.dump_traceback_later(int(os.environ["INDIGO_BENCH_WATCHDOG"]), exit=True, file=sys.stderr)
-    assert world == args.gpus, "--gpus %d but WORLD_SIZE is %d" % (args.gpus, world)
+        faulthandler.dump_traceback_later(wd, exit=True, file=sys.stderr)
+    # (--shard R/W times one rank's share in this ONE process, whatever --gpus says the full run would use)
+    assert world == args.gpus or (args.shard and world == 1), "--gpus %d but WORLD_SIZE is %d" % (args.gpus, world)
     if world > 1 and args.comm != "rccl":
         # The collective is the library's own RCCL binding (ig_comm_*).  Under `--comm auto` torch is imported FIRST --
         # before libindigo_hip.so loads -- only so that the fallback to torch.distributed stays possible: torch ships its own
@@ -850,7 +888,9 @@ def main():
         bench_sense(args, world, rank, local_rank)
     else:
         assert world == 1, "configs 1-3 are single-GPU leaf benchmarks"
-        print(json.dumps({1: bench_spmm_example, 2: bench_fft, 3: bench_spmm}[args.config](args, local_rank)), flush=True)
+        out = {1: bench_spmm_example, 2: bench_fft, 3: bench_spmm}[args.config](args, local_rank)
+        check_fractions(out, "line")
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -134,6 +134,18 @@ int  ig_scalar_ratio_gated(ig_ctx* ctx, double* d_out, const double* d_num, cons
                            const double* d_gate_num, const double* d_gate_den, double gate_tol);
 int  ig_scalar_copy(ig_ctx* ctx, double* d_dst, const double* d_src, int64_t count);
 int  ig_scalar_read(ig_ctx* ctx, const double* d_src, int64_t count, double* host);
+/* One CG iteration's vector work in three passes (reference loop: indigo/backends/backend.py:666-686):
+ *   ig_cg_dot      Ap += lamda p (if lamda != 0) and the block partials of Re<p, Ap>
+ *   ig_cg_step_r   alpha = rr / <p, Ap> -- 0 once rr < tol2 * r0, or when <p, Ap> == 0 --, r -= alpha Ap, block partials of ||r||^2;
+ *                  *d_alpha = alpha
+ *   ig_cg_step_xp  beta = r2 / rr, x += alpha p, p = r + beta p; *d_rr_next = r2 = ||r||^2 (a slot other than d_rr),
+ *                  *d_hist = r2 / r0 (optional)
+ * issued in this order with the same n on one context (they hand the block partials to each other through the context's
+ * reduction scratch; every block of the consumer sums them itself: no separate reduction kernels, no host synchronisation). */
+int  ig_cg_dot(ig_ctx* ctx, int64_t n, const void* p, void* Ap, float lamda);
+int  ig_cg_step_r(ig_ctx* ctx, int64_t n, void* r, const void* Ap, const double* d_rr, const double* d_r0, double tol2, double* d_alpha);
+int  ig_cg_step_xp(ig_ctx* ctx, int64_t n, void* x, void* p, const void* r, const double* d_alpha, const double* d_rr, double* d_rr_next,
+                   const double* d_r0, double* d_hist);
 int  ig_caxpby_dev(ig_ctx* ctx, int64_t n, const double* d_beta, float beta_scale, void* y,
                    const double* d_alpha, float alpha_scale, const void* x);
 /* y(rows) = beta*y + alpha * sum_j X[:, j]  for a column-major rows x ncols panel: the coil
@@ -461,11 +473,15 @@ int  ig_fft_destroy(ig_fft* plan);
  * needs it.
  * ---------------------------------------------------------------------- */
 #define IG_COMM_ID_BYTES 128
+/* loads RCCL and resolves its entry points: everything of the bring-up that can fail on one rank ALONE.  The ranks agree on
+ * its outcome (out of band) before any of them enters ig_comm_init_rank, which returns only when all have entered it  */
+int  ig_comm_preflight(void);
 int  ig_comm_unique_id(void* id_out /* IG_COMM_ID_BYTES, host */);
 int  ig_comm_init_rank(ig_ctx* ctx, int nranks, int rank, const void* id, ig_comm** out);   /* collective */
 int  ig_comm_info(ig_comm* comm, int* rank, int* nranks, char* rccl_lib, size_t len);
-/* in-place sum over the ranks of nfloats float32 (an image of N complex64 is 2N floats), enqueued on the context's
- * stream like every other call -- no host synchronisation                                                     */
+/* in-place sum over the ranks of nfloats float32 (an image of N complex64 is 2N floats), in order with the context's
+ * stream like every other call -- no host synchronisation.  (All collectives of a communicator run on the communicator's
+ * own stream, bracketed by event dependencies: one communicator, one stream.)                                    */
 int  ig_allreduce_sum_f32(ig_comm* comm, void* buf, int64_t nfloats);
 /* the same on the communicator's own stream, ordered after everything enqueued so far on the context's stream;
  * ig_comm_join makes the context's stream wait for all such all-reduces (call it before anything reads the buffers) */

@@ -52,6 +52,9 @@ PROTOTYPES = {
     "ig_scalar_ratio_gated": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_double]),
     "ig_scalar_copy":     (c_int, [c_void_p, c_void_p, c_void_p, c_int64]),
     "ig_scalar_read":     (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "ig_cg_dot":          (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_float]),
+    "ig_cg_step_r":       (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_void_p]),
+    "ig_cg_step_xp":      (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ig_caxpby_dev":      (c_int, [c_void_p, c_int64, c_void_p, c_float, c_void_p, c_void_p, c_float, c_void_p]),
     "ig_csum_cols":       (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_void_p]),
     "ig_csum_il":         (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_float, c_float, c_float, c_float, c_void_p]),
@@ -117,6 +120,7 @@ PROTOTYPES = {
     "ig_fft_exec_cropped_sum": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ig_fft_exec_cropped_sum_slab": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64]),
     "ig_fft_exec_cropped_slab": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int64, c_int64]),
+    "ig_comm_preflight":  (c_int, []),
     "ig_comm_unique_id":  (c_int, [c_void_p]),
     "ig_comm_init_rank":  (c_int, [c_void_p, c_int, c_int, c_void_p, POINTER(c_void_p)]),
     "ig_comm_info":       (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), c_char_p, c_size_t]),

@@ -349,9 +349,10 @@ class HipBackend(Backend):
 
     def cg(self, A, b_h, x_h, lamda=0.0, tol=1e-10, maxiter=100, team=None, check_every=10):
         """Conjugate gradients with the iteration's scalars kept on the device (same update sequence and the same
-        numbers as Backend.cg / the reference's backend.py:651-689): alpha = rr/<p,Ap> and beta = r2/rr are computed
-        by one-thread kernels from the reductions' device results and read by the axpby kernels from device memory,
-        so an iteration enqueues without a host synchronisation.  The relative residuals are recorded on the device for
+        numbers as Backend.cg / the reference's backend.py:651-689), an iteration's vector work in three fused passes
+        (ig_cg_dot, ig_cg_step_r, ig_cg_step_xp: 7 reads + 3 writes of a vector instead of 9 + 3, three launches instead of
+        twelve): alpha = rr/<p,Ap> and beta = r2/rr are computed inside the update kernels from the block partials of the
+        reductions, so an iteration enqueues without a host synchronisation.  The relative residuals are recorded on the device for
         EVERY iteration and fetched every `check_every` iterations (the only syncs).  The reference leaves its loop the
         moment resid < tol (backend.py:683-685); here up to check_every-1 further iterations are already enqueued by
         then, so the step length is gated on the device: once rr/r0 < tol^2 (or <p,Ap> == 0: an exactly converged
@@ -362,7 +363,7 @@ class HipBackend(Backend):
             return super().cg(A, b_h, x_h, lamda=lamda, tol=tol, maxiter=maxiter, team=team)
         base, nslots = self._slots()
         S = lambda i: ctypes.c_void_p(base + 8 * i)          # slot i (a device double)
-        RR, R0, PAP, ALPHA, R2, BETA, HIST = 0, 1, 2, 4, 5, 6, 8
+        RRA, R0, RRB, ALPHA, HIST = 0, 1, 2, 4, 8            # rr lives in two slots used in turn (ig_cg_step_xp writes the other one)
         cap = nslots - HIST                                  # history slots: a ring, fetched before it wraps
         L, ctx = self._L, self._ctx
         P = lambda a: ctypes.c_void_p(a._arr)
@@ -377,28 +378,26 @@ class HipBackend(Backend):
         self.axpby(1, r, -1, Ap)
         self.axpby(1, r, -lamda, x)
         p = r.copy(name='p')
-        self._check(L.ig_scnrm2sq_dev(ctx, n, P(r), S(RR)), "ig_scnrm2sq_dev")
-        self._check(L.ig_scalar_copy(ctx, S(R0), S(RR), 1), "ig_scalar_copy")
+        self._check(L.ig_scnrm2sq_dev(ctx, n, P(r), S(RRA)), "ig_scnrm2sq_dev")
+        self._check(L.ig_scalar_copy(ctx, S(R0), S(RRA), 1), "ig_scalar_copy")
         history = []
         fetched = 0
         every = max(1, min(int(check_every), cap))
         host = (ctypes.c_double * every)()
         tol2 = float(tol) ** 2
+        lam = ctypes.c_float(float(np.real(lamda)))
+        assert np.imag(lamda) == 0, "cg: lamda is a real regularisation weight"
         it = 0
         done = False
         while it < maxiter and not done:
+            rr, rr_next = (RRA, RRB) if it % 2 == 0 else (RRB, RRA)
             A.eval(Ap, p)
-            self.axpby(1, Ap, lamda, p)
-            self._check(L.ig_cdotc_dev(ctx, n, P(p), P(Ap), S(PAP)), "ig_cdotc_dev")
-            # alpha = rr / Re<p, Ap>; zero once rr / r0 < tol^2 (the reference has left its loop by then)
-            self._check(L.ig_scalar_ratio_gated(ctx, S(ALPHA), S(RR), S(PAP), 1.0, S(RR), S(R0), tol2), "ig_scalar_ratio_gated")
-            self._check(L.ig_caxpby_dev(ctx, n, None, 1.0, P(x), S(ALPHA), 1.0, P(p)), "ig_caxpby_dev")    # x += alpha p
-            self._check(L.ig_caxpby_dev(ctx, n, None, 1.0, P(r), S(ALPHA), -1.0, P(Ap)), "ig_caxpby_dev")  # r -= alpha Ap
-            self._check(L.ig_scnrm2sq_dev(ctx, n, P(r), S(R2)), "ig_scnrm2sq_dev")
-            self._check(L.ig_scalar_ratio(ctx, S(BETA), S(R2), S(RR), 1.0), "ig_scalar_ratio")         # beta = r2 / rr
-            self._check(L.ig_caxpby_dev(ctx, n, S(BETA), 1.0, P(p), None, 1.0, P(r)), "ig_caxpby_dev")     # p = beta p + r
-            self._check(L.ig_scalar_copy(ctx, S(RR), S(R2), 1), "ig_scalar_copy")                      # rr = r2
-            self._check(L.ig_scalar_ratio(ctx, S(HIST + it % every), S(R2), S(R0), 1.0), "ig_scalar_ratio")   # (resid_it)^2
+            # three fused passes (ig_blas.hip): Ap += lamda p and <p, Ap>;  alpha = rr / <p, Ap> (zero once rr / r0 < tol^2: the
+            # reference has left its loop by then), r -= alpha Ap, ||r||^2;  beta = r2 / rr, x += alpha p, p = r + beta p,
+            # rr <- r2, history[it] = r2 / r0
+            self._check(L.ig_cg_dot(ctx, n, P(p), P(Ap), lam), "ig_cg_dot")
+            self._check(L.ig_cg_step_r(ctx, n, P(r), P(Ap), S(rr), S(R0), tol2, S(ALPHA)), "ig_cg_step_r")
+            self._check(L.ig_cg_step_xp(ctx, n, P(x), P(p), P(r), S(ALPHA), S(rr), S(rr_next), S(R0), S(HIST + it % every)), "ig_cg_step_xp")
             it += 1
             if it - fetched == every or it == maxiter:
                 self._check(L.ig_scalar_read(ctx, S(HIST), it - fetched, host), "ig_scalar_read")

@@ -221,6 +221,173 @@ k_reduce_final(int nblocks, const double* __restrict__ partials, double* __restr
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// ---- conjugate gradients: an iteration's vector work in THREE passes (reference loop: indigo/backends/backend.py:666-686) ----
+//   k_cg_dot    Ap += lamda p (if lamda != 0);  block partials of Re<p, Ap>                          2 reads (+1 write)
+//   k_cg_step_r alpha = rr / <p, Ap> (gated);   r -= alpha Ap;  block partials of ||r||^2             2 reads + 1 write
+//   k_cg_step_xp beta = r2 / rr;                x += alpha p;   p = r + beta p                        3 reads + 2 writes
+// instead of five vector passes and two two-kernel reductions with one-thread scalar kernels between them (12 launches, 9
+// reads + 3 writes).  There is no "final" reduction kernel and no atomic: EVERY block of the consuming kernel sums the
+// producer's block partials itself (<= 2048 doubles out of the L2, the same order in every block, hence the same bits) --
+// kernel boundaries are the only synchronisation.  Block 0 of the consumer records the scalars (alpha; rr for the next
+// iteration into the OTHER of two slots, since the blocks of this launch still read the current one; the history entry).
+__device__ __forceinline__ double block_sum_partials(const double* __restrict__ partials, int nparts) {
+    double v = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += BLK) v += partials[i];
+    v = wave_sum(v);
+    __shared__ double s_part[BLK / 64];
+    __shared__ double s_total;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) s_part[wid] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < BLK / 64; ++w) t += s_part[w];
+        s_total = t;
+    }
+    __syncthreads();
+    return s_total;
+}
+__device__ __forceinline__ void block_store_partial(double v, double* __restrict__ partials) {
+    v = wave_sum(v);
+    __shared__ double s_out[BLK / 64];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) s_out[wid] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < BLK / 64; ++w) t += s_out[w];
+        partials[blockIdx.x] = t;
+    }
+}
+
+// (VEC: both vectors 16-byte aligned -> two complex64 per lane and access; the odd last element goes to thread 0)
+template <bool VEC, bool LAMDA>
+__global__ void __launch_bounds__(BLK)
+k_cg_dot(int64_t n, const float2* __restrict__ p, float2* __restrict__ Ap, float lamda, double* __restrict__ partials) {
+    const int64_t tid = (int64_t)blockIdx.x * BLK + threadIdx.x, nth = (int64_t)gridDim.x * BLK;
+    double acc = 0.0;
+    auto one = [&](float2 pv, float2& av) -> float {
+        if (LAMDA) { av.x = fmaf(lamda, pv.x, av.x); av.y = fmaf(lamda, pv.y, av.y); }
+        return fmaf(pv.x, av.x, pv.y * av.y);                       // Re(conj(p) * Ap)
+    };
+    if (VEC) {
+        const float4* p4 = reinterpret_cast<const float4*>(p);
+        float4* a4 = reinterpret_cast<float4*>(Ap);
+        const int64_t n2 = n >> 1;
+        int64_t i = tid;
+        while (i < n2) {
+            float f = 0.f;
+#pragma unroll 4
+            for (int k = 0; k < 8 && i < n2; ++k, i += nth) {      // short float runs, flushed to double
+                const float4 pv = p4[i];
+                float4 av = a4[i];
+                float2 a0 = make_float2(av.x, av.y), a1 = make_float2(av.z, av.w);
+                f += one(make_float2(pv.x, pv.y), a0);
+                f += one(make_float2(pv.z, pv.w), a1);
+                if (LAMDA) a4[i] = make_float4(a0.x, a0.y, a1.x, a1.y);
+            }
+            acc += (double)f;
+        }
+        if ((n & 1) && tid == 0) { float2 av = Ap[n - 1]; acc += (double)one(p[n - 1], av); if (LAMDA) Ap[n - 1] = av; }
+    } else {
+        for (int64_t i = tid; i < n; i += nth) { float2 av = Ap[i]; acc += (double)one(p[i], av); if (LAMDA) Ap[i] = av; }
+    }
+    block_store_partial(acc, partials);
+}
+
+template <bool VEC>
+__global__ void __launch_bounds__(BLK)
+k_cg_step_r(int64_t n, float2* __restrict__ r, const float2* __restrict__ Ap, const double* __restrict__ pap_partials, int nparts,
+            const double* __restrict__ d_rr, const double* __restrict__ d_r0, double tol2, double* __restrict__ d_alpha,
+            double* __restrict__ rr_partials) {
+    const double pap = block_sum_partials(pap_partials, nparts);
+    const double rr = d_rr[0];
+    const bool stop = !(rr >= tol2 * d_r0[0]);                     // the reference has left its loop by now (backend.py:683-685)
+    const double alpha_d = (pap == 0.0 || stop) ? 0.0 : rr / pap; // 0/0 of an exactly converged system: a zero step, not NaN
+    if (blockIdx.x == 0 && threadIdx.x == 0) d_alpha[0] = alpha_d;
+    const float na = -(float)alpha_d;
+    const int64_t tid = (int64_t)blockIdx.x * BLK + threadIdx.x, nth = (int64_t)gridDim.x * BLK;
+    double acc = 0.0;
+    auto one = [&](float2& rv, float2 av) -> float {
+        rv.x = fmaf(na, av.x, rv.x); rv.y = fmaf(na, av.y, rv.y);
+        return fmaf(rv.x, rv.x, rv.y * rv.y);
+    };
+    if (VEC) {
+        float4* r4 = reinterpret_cast<float4*>(r);
+        const float4* a4 = reinterpret_cast<const float4*>(Ap);
+        const int64_t n2 = n >> 1;
+        int64_t i = tid;
+        while (i < n2) {
+            float f = 0.f;
+#pragma unroll 4
+            for (int k = 0; k < 8 && i < n2; ++k, i += nth) {
+                const float4 av = a4[i];
+                const float4 rv = r4[i];
+                float2 r0 = make_float2(rv.x, rv.y), r1 = make_float2(rv.z, rv.w);
+                f += one(r0, make_float2(av.x, av.y));
+                f += one(r1, make_float2(av.z, av.w));
+                r4[i] = make_float4(r0.x, r0.y, r1.x, r1.y);
+            }
+            acc += (double)f;
+        }
+        if ((n & 1) && tid == 0) { float2 rv = r[n - 1]; acc += (double)one(rv, Ap[n - 1]); r[n - 1] = rv; }
+    } else {
+        for (int64_t i = tid; i < n; i += nth) { float2 rv = r[i]; acc += (double)one(rv, Ap[i]); r[i] = rv; }
+    }
+    block_store_partial(acc, rr_partials);
+}
+
+template <bool VEC>
+__global__ void __launch_bounds__(BLK)
+k_cg_step_xp(int64_t n, float2* __restrict__ x, float2* __restrict__ p, const float2* __restrict__ r,
+             const double* __restrict__ rr_partials, int nparts, const double* __restrict__ d_alpha, const double* __restrict__ d_rr,
+             double* __restrict__ d_rr_next, const double* __restrict__ d_r0, double* __restrict__ d_hist) {
+    const double r2 = block_sum_partials(rr_partials, nparts);
+    const double rr = d_rr[0];
+    const float beta = (float)(rr == 0.0 ? 0.0 : r2 / rr);
+    const float alpha = (float)d_alpha[0];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        d_rr_next[0] = r2;
+        const double r0 = d_r0[0];
+        if (d_hist) d_hist[0] = r0 == 0.0 ? 0.0 : r2 / r0;        // (relative residual)^2 of this iteration
+    }
+    const int64_t tid = (int64_t)blockIdx.x * BLK + threadIdx.x, nth = (int64_t)gridDim.x * BLK;
+    if (VEC) {
+        float4* x4 = reinterpret_cast<float4*>(x);
+        float4* p4 = reinterpret_cast<float4*>(p);
+        const float4* r4 = reinterpret_cast<const float4*>(r);
+        const int64_t n2 = n >> 1;
+        for (int64_t i = tid; i < n2; i += nth) {
+            const float4 pv = p4[i], rv = r4[i];
+            float4 xv = x4[i];
+            xv.x = fmaf(alpha, pv.x, xv.x); xv.y = fmaf(alpha, pv.y, xv.y); xv.z = fmaf(alpha, pv.z, xv.z); xv.w = fmaf(alpha, pv.w, xv.w);
+            x4[i] = xv;
+            p4[i] = make_float4(fmaf(beta, pv.x, rv.x), fmaf(beta, pv.y, rv.y), fmaf(beta, pv.z, rv.z), fmaf(beta, pv.w, rv.w));
+        }
+        if ((n & 1) && tid == 0) {
+            const int64_t i = n - 1;
+            const float2 pv = p[i], rv = r[i];
+            float2 xv = x[i];
+            xv.x = fmaf(alpha, pv.x, xv.x); xv.y = fmaf(alpha, pv.y, xv.y);
+            x[i] = xv;
+            p[i] = make_float2(fmaf(beta, pv.x, rv.x), fmaf(beta, pv.y, rv.y));
+        }
+    } else {
+        for (int64_t i = tid; i < n; i += nth) {
+            const float2 pv = p[i], rv = r[i];
+            float2 xv = x[i];
+            xv.x = fmaf(alpha, pv.x, xv.x); xv.y = fmaf(alpha, pv.y, xv.y);
+            x[i] = xv;
+            p[i] = make_float2(fmaf(beta, pv.x, rv.x), fmaf(beta, pv.y, rv.y));
+        }
+    }
+}
+
+inline int cg_grid(const ig_ctx* ctx, int64_t n) {
+    int g = grid_for(ctx, (n + 1) / 2);
+    return g > IG_MAX_RED_BLOCKS ? IG_MAX_RED_BLOCKS : g;
+}
+
 // tiny scalar programs on device-resident doubles (one thread): the glue between a solver's reductions and its updates
 __global__ void k_scalar_ratio(double* __restrict__ out, const double* __restrict__ num, const double* __restrict__ den, double scale) {
     const double d = den[0];
@@ -317,6 +484,7 @@ int ig_scalars(ig_ctx* ctx, double** d_slots, int* nslots) {
     if (int rc = ig_set_device(ctx)) return rc;
     if (!ctx->d_scalars) {
         IG_HIP(ctx, hipMalloc((void**)&ctx->d_scalars, sizeof(double) * IG_NUM_SCALARS));
+        ctx->scalars_bytes = sizeof(double) * IG_NUM_SCALARS;
         IG_HIP(ctx, hipMemsetAsync(ctx->d_scalars, 0, sizeof(double) * IG_NUM_SCALARS, ctx->stream));
     }
     *d_slots = ctx->d_scalars;
@@ -378,6 +546,51 @@ int ig_scalar_copy(ig_ctx* ctx, double* d_dst, const double* d_src, int64_t coun
     if (int rc = ig_set_device(ctx)) return rc;
     hipLaunchKernelGGL(k_scalar_copy, dim3(1), dim3(64), 0, ctx->stream, d_dst, d_src, (int)count);
     IG_LAUNCH_CHECK(ctx, "k_scalar_copy");
+    return IG_OK;
+}
+
+// ---- the fused CG iteration (see k_cg_dot / k_cg_step_r / k_cg_step_xp).  The three calls of one iteration share the block
+// partials in the context's reduction scratch: dot partials in its first half, ||r||^2 partials in its second; they must be
+// issued in this order, with the same n, on this context.
+int ig_cg_dot(ig_ctx* ctx, int64_t n, const void* p, void* Ap, float lamda) {
+    IG_REQUIRE(ctx, ctx && n > 0 && p && Ap, "ig_cg_dot: bad arguments");
+    if (int rc = ig_set_device(ctx)) return rc;
+    const int g = cg_grid(ctx, n);
+    const bool vec = aligned16(p) && aligned16(Ap);
+    ig_prof_scope prof(ctx, "cg_dot", (double)n * 8.0 * (lamda != 0.f ? 3 : 2));
+    double* parts = ctx->d_partials;
+#define IG_CG_DOT(V_, L_) hipLaunchKernelGGL((k_cg_dot<V_, L_>), dim3(g), dim3(BLK), 0, ctx->stream, n, (const float2*)p, (float2*)Ap, lamda, parts)
+    if (vec) { if (lamda != 0.f) IG_CG_DOT(true, true); else IG_CG_DOT(true, false); }
+    else     { if (lamda != 0.f) IG_CG_DOT(false, true); else IG_CG_DOT(false, false); }
+#undef IG_CG_DOT
+    IG_LAUNCH_CHECK(ctx, "k_cg_dot");
+    return IG_OK;
+}
+
+int ig_cg_step_r(ig_ctx* ctx, int64_t n, void* r, const void* Ap, const double* d_rr, const double* d_r0, double tol2, double* d_alpha) {
+    IG_REQUIRE(ctx, ctx && n > 0 && r && Ap && d_rr && d_r0 && d_alpha, "ig_cg_step_r: bad arguments");
+    if (int rc = ig_set_device(ctx)) return rc;
+    const int g = cg_grid(ctx, n);
+    const bool vec = aligned16(r) && aligned16(Ap);
+    ig_prof_scope prof(ctx, "cg_step_r", (double)n * 8.0 * 3);
+    double* parts = ctx->d_partials;
+    if (vec) hipLaunchKernelGGL(k_cg_step_r<true>, dim3(g), dim3(BLK), 0, ctx->stream, n, (float2*)r, (const float2*)Ap, parts, g, d_rr, d_r0, tol2, d_alpha, parts + IG_MAX_RED_BLOCKS);
+    else     hipLaunchKernelGGL(k_cg_step_r<false>, dim3(g), dim3(BLK), 0, ctx->stream, n, (float2*)r, (const float2*)Ap, parts, g, d_rr, d_r0, tol2, d_alpha, parts + IG_MAX_RED_BLOCKS);
+    IG_LAUNCH_CHECK(ctx, "k_cg_step_r");
+    return IG_OK;
+}
+
+int ig_cg_step_xp(ig_ctx* ctx, int64_t n, void* x, void* p, const void* r, const double* d_alpha, const double* d_rr, double* d_rr_next,
+                  const double* d_r0, double* d_hist) {
+    IG_REQUIRE(ctx, ctx && n > 0 && x && p && r && d_alpha && d_rr && d_rr_next && d_r0 && d_rr != d_rr_next, "ig_cg_step_xp: bad arguments (rr and rr_next must be two slots)");
+    if (int rc = ig_set_device(ctx)) return rc;
+    const int g = cg_grid(ctx, n);
+    const bool vec = aligned16(x) && aligned16(p) && aligned16(r);
+    ig_prof_scope prof(ctx, "cg_step_xp", (double)n * 8.0 * 5);
+    const double* parts = ctx->d_partials + IG_MAX_RED_BLOCKS;
+    if (vec) hipLaunchKernelGGL(k_cg_step_xp<true>, dim3(g), dim3(BLK), 0, ctx->stream, n, (float2*)x, (float2*)p, (const float2*)r, parts, g, d_alpha, d_rr, d_rr_next, d_r0, d_hist);
+    else     hipLaunchKernelGGL(k_cg_step_xp<false>, dim3(g), dim3(BLK), 0, ctx->stream, n, (float2*)x, (float2*)p, (const float2*)r, parts, g, d_alpha, d_rr, d_rr_next, d_r0, d_hist);
+    IG_LAUNCH_CHECK(ctx, "k_cg_step_xp");
     return IG_OK;
 }
 

@@ -7,11 +7,14 @@
 // holds a copy (e.g. the one PyTorch ships) shares that copy instead of loading a second one.
 //
 // Two ways to issue the all-reduce:
-//   ig_allreduce_sum_f32        in order on the context's stream (what a caller without further knowledge wants)
-//   ig_allreduce_sum_f32_side   on the communicator's own stream, ordered after the work enqueued so far on the
-//                               context's stream; ig_comm_join makes the context's stream wait for it.  The cropped
-//                               transform produces the image slab by slab (ig_fft_exec_cropped_sum_slab), so the
-//                               all-reduce of slab s runs over xGMI while slab s+1 is still being transformed.
+//   ig_allreduce_sum_f32        in order with the context's stream (what a caller without further knowledge wants)
+//   ig_allreduce_sum_f32_side   ordered after the work enqueued so far on the context's stream, but NOT waited for by it;
+//                               ig_comm_join makes the context's stream wait.  The cropped transform produces the image
+//                               slab by slab (ig_fft_exec_cropped_sum_slab), so the all-reduce of slab s runs over xGMI
+//                               while slab s+1 is still being transformed.
+// EVERY collective of a communicator is enqueued on the communicator's own stream (`side`), in call order; the two forms
+// differ only in the event dependencies around it.  One communicator therefore only ever sees ONE stream: nothing here
+// relies on how RCCL orders launches that reach one communicator from two streams.
 #include "ig_common.h"
 #include <dlfcn.h>
 #include <rccl/rccl.h>
@@ -108,6 +111,11 @@ struct ig_comm {
 
 extern "C" {
 
+// Everything of the bring-up that can fail on ONE rank alone (no RCCL to load, entry points missing): to be called -- and
+// its result agreed on by all ranks (indigo_amd/dist.py: exchange_id) -- BEFORE anyone enters ncclCommInitRank, which
+// only returns when every rank has entered it.
+int ig_comm_preflight(void) { return load_rccl(nullptr); }
+
 int ig_comm_unique_id(void* id_out) {
     if (!id_out) return ig_fail(nullptr, IG_ERR_ARG, "ig_comm_unique_id: id_out is NULL");
     if (int rc = load_rccl(nullptr)) return rc;
@@ -161,7 +169,13 @@ int ig_allreduce_sum_f32(ig_comm* c, void* buf, int64_t nfloats) {
     if (nfloats == 0) return IG_OK;
     if (int rc = ig_set_device(ctx)) return rc;
     ig_prof_scope prof(ctx, "allreduce", (double)nfloats * 4.0);
-    IG_RCCL(ctx, g_rccl.all_reduce(buf, buf, (size_t)nfloats, RCCL_FLOAT32, RCCL_SUM, c->comm, ctx->stream));
+    // context's stream -> side stream -> collective -> context's stream: in order with both
+    IG_HIP(ctx, hipEventRecord(c->ev_work, ctx->stream));
+    IG_HIP(ctx, hipStreamWaitEvent(c->side, c->ev_work, 0));
+    IG_RCCL(ctx, g_rccl.all_reduce(buf, buf, (size_t)nfloats, RCCL_FLOAT32, RCCL_SUM, c->comm, c->side));
+    IG_HIP(ctx, hipEventRecord(c->ev_side, c->side));
+    IG_HIP(ctx, hipStreamWaitEvent(ctx->stream, c->ev_side, 0));
+    c->side_busy = false;                  // (the context's stream now waits for everything the side stream holds)
     return IG_OK;
 }
 
@@ -195,10 +209,15 @@ static int host_scalar(ig_comm* c, double* v, ncclRedOp_t op, const char* who) {
     if (!c || !v) return ig_fail(nullptr, IG_ERR_ARG, "%s: bad arguments", who);
     ig_ctx* ctx = c->ctx;
     if (int rc = ig_set_device(ctx)) return rc;
-    IG_HIP(ctx, hipMemcpyAsync(c->d_scalar, v, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    IG_RCCL(ctx, g_rccl.all_reduce(c->d_scalar, c->d_scalar, 1, RCCL_FLOAT64, op, c->comm, ctx->stream));
-    IG_HIP(ctx, hipMemcpyAsync(v, c->d_scalar, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    // on the communicator's stream like every collective, after whatever the context's stream holds; synchronous
+    IG_HIP(ctx, hipEventRecord(c->ev_work, ctx->stream));
+    IG_HIP(ctx, hipStreamWaitEvent(c->side, c->ev_work, 0));
+    IG_HIP(ctx, hipMemcpyAsync(c->d_scalar, v, sizeof(double), hipMemcpyHostToDevice, c->side));
+    IG_RCCL(ctx, g_rccl.all_reduce(c->d_scalar, c->d_scalar, 1, RCCL_FLOAT64, op, c->comm, c->side));
+    IG_HIP(ctx, hipMemcpyAsync(v, c->d_scalar, sizeof(double), hipMemcpyDeviceToHost, c->side));
+    IG_HIP(ctx, hipStreamSynchronize(c->side));
     IG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    c->side_busy = false;
     return IG_OK;
 }
 

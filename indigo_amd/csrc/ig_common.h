@@ -30,6 +30,7 @@ struct ig_ctx {
     void*        d_xpack     = nullptr;   // SpMM repacked-panel scratch (grown on demand)
     size_t       xpack_bytes = 0;
     int32_t*     d_worklist  = nullptr;   // SpMM deferred-row lists + counters (allocated on first use)
+    size_t       worklist_bytes = 0, partials_bytes = 0, scalars_bytes = 0;   // what was really allocated (ig_library_bytes)
     // plan options (ig_set_option): which transform kernels a NEW plan may use.  0 = all; 1 = no register-resident A x B passes
     // (their lengths fall back to the multi-stage LDS kernel); 2 = only the one-stage-per-launch generic kernel
     int          opt_fft_kernels = 0;

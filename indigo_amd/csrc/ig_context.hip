@@ -70,7 +70,8 @@ static int ig_init_common(int device_id, bool adopt, void* ext_stream, ig_ctx** 
             return bail("hipStreamCreateWithFlags", e);
         ctx->own_stream = true;
     }
-    if ((e = hipMalloc((void**)&ctx->d_partials, sizeof(double) * 2 * (IG_MAX_RED_BLOCKS + 1))) != hipSuccess)
+    ctx->partials_bytes = sizeof(double) * 2 * (IG_MAX_RED_BLOCKS + 1);
+    if ((e = hipMalloc((void**)&ctx->d_partials, ctx->partials_bytes)) != hipSuccess)
         return bail("hipMalloc(partials)", e);
     if ((e = hipHostMalloc((void**)&ctx->h_result, sizeof(double) * 2, hipHostMallocDefault)) != hipSuccess)
         return bail("hipHostMalloc(result)", e);
@@ -135,8 +136,9 @@ int ig_library_bytes(ig_ctx* ctx, size_t* bytes) {
     IG_REQUIRE(ctx, ctx && bytes, "ig_library_bytes: bad arguments");
     // device memory the library itself holds for this context: the repacked-panel buffer of the SpMM kernels (grown on
     // demand), the deferred-row lists, the reduction scratch and the solver scalars
-    *bytes = ctx->xpack_bytes + (ctx->d_worklist ? sizeof(int32_t) * 2 * (size_t)(1u << 20) + 2 * 32 * sizeof(uint32_t) : 0) +
-             (ctx->d_partials ? (size_t)(IG_MAX_RED_BLOCKS + 1) * 2 * sizeof(double) : 0) + (ctx->d_scalars ? sizeof(double) * IG_NUM_SCALARS : 0);
+    // (the byte counts are recorded where the buffers are allocated)
+    *bytes = ctx->xpack_bytes + (ctx->d_worklist ? ctx->worklist_bytes : 0) + (ctx->d_partials ? ctx->partials_bytes : 0) +
+             (ctx->d_scalars ? ctx->scalars_bytes : 0);
     return IG_OK;
 }
 

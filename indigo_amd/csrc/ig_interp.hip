@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cmath>
 #include <thread>
+#include <atomic>
 #include <vector>
 
 namespace {
@@ -104,7 +105,7 @@ static int interp3_fill(int64_t m, const int64_t* N, double width, const double*
     const int64_t n0 = N[0], n1 = N[1], n2 = N[2];
     if (n0 * n1 * n2 > 0x7fffffffLL) return ig_fail(nullptr, IG_ERR_ARG, "ig_interp3_fill: grid exceeds int32 column indices");
     const double* cx = coord; const double* cy = coord + m; const double* cz = coord + 2 * m;
-    int bad = 0;
+    std::atomic<int> bad{0};        // set from several host threads
     parallel_rows(m, [&](int64_t lo, int64_t hi) {
         std::vector<std::pair<int32_t, float>> row;
         std::vector<double> wxs;
@@ -201,7 +202,7 @@ int ig_grid_support(int64_t nnz, const int32_t* colind, int64_t n0, int64_t n1, 
     uint32_t* bits = reinterpret_cast<uint32_t*>(table + 2 * (ne + nt));
     std::fill(table, table + 2 * (ne + nt), (int16_t)0);
     std::fill(bits, bits + ne * 16, 0u);
-    int bad = 0;
+    std::atomic<int> bad{0};        // set from several host threads
     parallel_rows(nnz, [&](int64_t lo, int64_t hi) {
         int32_t last = -1;
         for (int64_t p = lo; p < hi; ++p) {

@@ -30,6 +30,7 @@
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 #include <vector>
 #include <thread>
+#include <atomic>
 #include <functional>
 #include <algorithm>
 #include <cstring>
@@ -1753,7 +1754,9 @@ constexpr uint32_t WL_CAP = 1u << 20;
 
 int ensure_worklists(ig_ctx* ctx) {
     if (ctx->d_worklist) return IG_OK;
-    IG_HIP(ctx, hipMalloc((void**)&ctx->d_worklist, sizeof(int32_t) * 2 * WL_CAP + 2 * WL_SUB * sizeof(uint32_t)));
+    const size_t bytes = sizeof(int32_t) * 2 * WL_CAP + 2 * WL_SUB * sizeof(uint32_t);
+    IG_HIP(ctx, hipMalloc((void**)&ctx->d_worklist, bytes));
+    ctx->worklist_bytes = bytes;
     return IG_OK;
 }
 
@@ -2261,7 +2264,7 @@ int ig_grid_bricks_count(int64_t M, const int32_t* rowptr, const int32_t* colind
         if (rc[t] == 1) return ig_fail(nullptr, IG_ERR_ARG, "ig_grid_bricks_count: column index outside the grid");
         if (rc[t] == 2) return ig_fail(nullptr, IG_ERR_UNSUPPORTED, "ig_grid_bricks_count: a row touches more than 64 bricks");
     }
-    int bad = 0;
+    std::atomic<int> bad{0};        // set from several host threads
     run_threads(nt, [&](int t) {                   // sum over the threads, brick ranges in parallel
         const int64_t pb = (g.nb + nt - 1) / nt, lo = std::min<int64_t>(g.nb, t * pb), hi = std::min<int64_t>(g.nb, lo + pb);
         for (int64_t b = lo; b < hi; ++b) {
@@ -2297,7 +2300,7 @@ int ig_grid_bricks_fill(int64_t M, const int32_t* rowptr, const int32_t* colind,
     });
     for (int t = 0; t < nt; ++t)
         if (rc[t] || ovf[t]) return ig_fail(nullptr, rc[t] == 2 ? IG_ERR_UNSUPPORTED : IG_ERR_ARG, "ig_grid_bricks_fill: the matrix does not fit the brick format (see ig_grid_bricks_count)");
-    int mismatch = 0;
+    std::atomic<int> mismatch{0};   // set from several host threads
     run_threads(nt, [&](int t) {                   // exclusive scan over the threads, brick ranges in parallel
         const int64_t pb = (g.nb + nt - 1) / nt, lo = std::min<int64_t>(g.nb, t * pb), hi = std::min<int64_t>(g.nb, lo + pb);
         for (int64_t b = lo; b < hi; ++b) {
@@ -2420,7 +2423,7 @@ int ig_grid_slots_build(int64_t nbricks, const int64_t* brick_ptr, const void* e
     SlotEntry* out = (SlotEntry*)entries16;
     const int nt = brick_threads(nbricks * 8);
     const int64_t per = (nbricks + nt - 1) / nt;
-    int bad = 0;
+    std::atomic<int> bad{0};        // set from several host threads
     // pass 1: slots per brick (the group sizes: how many cells are hit at least k + 1 times)
     run_threads(nt, [&](int th) {
         std::vector<int32_t> mult((size_t)ncell), gsize;

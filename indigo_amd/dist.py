@@ -96,17 +96,22 @@ def _remove_rendezvous_files(path, world):
             pass
 
 
-def exchange_id(rank, world, make_id, path, nbytes=128, timeout=60.0):
+def exchange_id(rank, world, make_id, path, nbytes=128, timeout=60.0, ready=True):
     """File rendezvous of one launch on one node: rank 0 publishes `make_id()` (nbytes), every other rank reads and
-    acknowledges it, rank 0 waits for all acknowledgements and publishes "go".  Returns the id on every rank.
+    acknowledges it, rank 0 waits for all acknowledgements and publishes the go-ahead.  Returns (id, all_ready) on every
+    rank: `all_ready` is the AND over the ranks' `ready` flags (can this rank load RCCL at all?  ig_comm_preflight) -- the
+    one decision the ranks must take TOGETHER before any of them enters ncclCommInitRank, which only returns when all have
+    entered it.  (make_id is not called on a rank 0 that is not ready: a zero id travels instead.)
 
     The handshake completes BEFORE anyone enters the collective bring-up, so that a rendezvous problem (ranks that are
     not siblings, an unwritable temp directory) makes EVERY rank raise within `timeout` -- and fall back together --
     instead of leaving some ranks inside ncclCommInitRank forever.
 
     Left-overs of an earlier launch under the same name cannot be mistaken for this one: rank 0 removes them before it
-    publishes, acknowledgements and the go-ahead carry a nonce derived from the id, and a reader that acknowledged a
-    stale id keeps re-reading until the go-ahead matches what it acknowledged.  A rank that fails removes its own files."""
+    publishes; an acknowledgement carries the nonce of the id it answers, the reader's readiness and a fresh random TOKEN
+    of that reader; the go-ahead echoes the nonce, the verdict and every token it was built from.  A reader only accepts a
+    go-ahead that holds ITS token -- which no file written before this call can -- and keeps re-reading (and
+    re-acknowledging a replaced id) until then.  A rank that fails removes its own files."""
     def wait_for(fn, what):
         t0 = time.time()
         while True:
@@ -118,22 +123,29 @@ def exchange_id(rank, world, make_id, path, nbytes=128, timeout=60.0):
             time.sleep(0.02)
 
     if rank == 0:
-        raw = make_id()
+        raw = make_id() if ready else bytes(nbytes)
         assert len(raw) == nbytes
+        all_ready = bool(ready)
         if world > 1:
             _remove_rendezvous_files(path, world)
             nonce = _nonce(raw)
             try:
                 _publish(path, raw)
+                tokens = []
                 for r in range(1, world):
-                    wait_for(lambda r=r: True if _read("%s.ack%d" % (path, r)) == nonce else None,
-                             "the acknowledgement of rank %d" % r)
-                _publish(path + ".go", nonce)
+                    def ack_of(r=r):
+                        parts = (_read("%s.ack%d" % (path, r)) or b"").split(b":")
+                        return parts if len(parts) == 3 and parts[0] == nonce and len(parts[1]) == 32 else None
+                    parts = wait_for(ack_of, "the acknowledgement of rank %d" % r)
+                    tokens.append(parts[1])
+                    all_ready = all_ready and parts[2] == b"1"
+                _publish(path + ".go", b":".join([nonce, b"1" if all_ready else b"0"] + tokens))
             except BaseException:
                 _remove_rendezvous_files(path, world)
                 raise
-        return raw
+        return raw, all_ready
     ack = "%s.ack%d" % (path, rank)
+    token = os.urandom(16).hex().encode()
     state = {}
 
     def step():
@@ -142,8 +154,11 @@ def exchange_id(rank, world, make_id, path, nbytes=128, timeout=60.0):
             return None
         if state.get("raw") != raw:                          # first sight of an id, or rank 0 replaced a stale one
             state["raw"] = raw
-            _publish(ack, _nonce(raw))
-        return raw if _read(path + ".go") == _nonce(raw) else None
+            _publish(ack, b":".join([_nonce(raw), token, b"1" if ready else b"0"]))
+        go = (_read(path + ".go") or b"").split(b":")
+        if len(go) >= 3 and go[0] == _nonce(raw) and token in go[2:]:
+            return raw, go[1] == b"1"
+        return None
     try:
         return wait_for(step, "rank 0's communicator id and go-ahead")
     except BaseException:
@@ -185,7 +200,18 @@ class RcclComm(object):
             buf = ctypes.create_string_buffer(nbytes)
             _lib.check(self._L.ig_comm_unique_id(buf), None, "ig_comm_unique_id")
             return buf.raw
-        idbuf = ctypes.create_string_buffer(exchange_id(self.rank, self.world, make_id, path, nbytes, timeout), nbytes)
+        # what can fail on this rank alone (no RCCL to load) is tried first and VOTED on in the handshake: either every rank
+        # enters ncclCommInitRank or none does (and all of them raise here -- `bench.py --comm auto` then falls back to
+        # torch.distributed on all ranks together)
+        ready = self._L.ig_comm_preflight() == 0
+        why = None if ready else _lib.last_error(None)
+        raw, all_ready = exchange_id(self.rank, self.world, make_id, path, nbytes, timeout, ready=ready)
+        if not all_ready:
+            if path:
+                cleanup_rendezvous(self.rank, self.world, path, timeout=2.0)
+            raise RuntimeError("ig_comm: %s; no rank enters the RCCL bring-up"
+                               % ("this rank cannot load RCCL (%s)" % why if not ready else "another rank cannot load RCCL"))
+        idbuf = ctypes.create_string_buffer(raw, nbytes)
         comm = ctypes.c_void_p()
         try:
             backend._check(self._L.ig_comm_init_rank(backend._ctx, self.world, self.rank, idbuf, ctypes.byref(comm)), "ig_comm_init_rank")
@@ -341,7 +367,16 @@ class ShardedNormalOperator(object):
         self.dtype = _C64
         self._ksp = None
         self._leaf = None
-        if getattr(comm, 'overlap', False) and comm.world > 1 and nslabs > 1:
+        self._nslabs = int(nslabs)
+        # How the image is all-reduced -- in `nslabs` slabs behind the transform, or whole -- is ONE decision of all ranks:
+        # their trees differ (8 coils on 3 ranks: 3 + 3 + 2 -- the 3-coil ranks have no coil-interleaved leaf, the 2-coil
+        # rank has), and ranks that issue different sequences of collectives hang or mix up their buffers.  'undecided':
+        # the first one-column evaluation reduces the whole image on every rank, records whether this rank's tree WOULD have
+        # covered the image slab by slab (the hook then only takes notes), and the ranks vote (one host max-reduction);
+        # 'slab' only if every rank can.  'full' without a vote where no rank can know otherwise (one rank, a communicator
+        # without its own stream, nslabs <= 1: the same on all ranks).
+        self._route = 'undecided' if (getattr(comm, 'overlap', False) and comm.world > 1 and self._nslabs > 1) else 'full'
+        if self._route == 'undecided':
             from indigo_amd import operators as op
             # the leaf that writes y LAST in the adjoint: the rightmost factor of the tree, or -- for a VStack of coil chunks,
             # whose adjoint accumulates its children's images in order (operators.VStack._eval) -- of its last child
@@ -352,7 +387,10 @@ class ShardedNormalOperator(object):
                 r = r.right
             if isinstance(r, op.ZpadFFT) and hasattr(self._backend, 'ifft_cropped_sum') and (r._layout == 2 or (r._layout == 1 and r._C == 1)):
                 self._leaf = r
-                self._nslabs = int(nslabs)
+
+    def _covers(self, done):
+        done = sorted(done)
+        return bool(done) and done[0][0] == 0 and done[-1][1] == self.shape[1] and all(a[1] == b[0] for a, b in zip(done[:-1], done[1:]))
 
     def eval(self, y, x, alpha=1, beta=0, forward=True, left=True):
         assert alpha == 1 and beta == 0, "ShardedNormalOperator computes y = AHA x only"
@@ -361,10 +399,23 @@ class ShardedNormalOperator(object):
         if self._ksp is None or self._ksp.shape != (self._A.shape[0], ncols):
             self._ksp = B.zero_array((self._A.shape[0], ncols), _C64, name='ksp(shard)')
         self._A.eval(self._ksp, x)
-        if self._leaf is not None and ncols == 1:
-            # The leaf all-reduces the image slab by slab (ZpadFFT._slab_hook).  Whether it really did is CHECKED: the hook
-            # records the voxel ranges it reduced, and unless they tile [0, N) exactly once the whole image is reduced here
-            # instead (a tree whose last writer took another branch would otherwise return the rank-local partial sum).
+        if self._route == 'undecided' and ncols == 1:
+            done = []
+            if self._leaf is not None:
+                self._leaf._slab_hook = (self._nslabs, lambda arr, lo, hi: done.append((lo, hi)))       # takes notes, sends nothing
+            try:
+                self._A.eval(y, self._ksp, forward=False)
+            finally:
+                if self._leaf is not None:
+                    self._leaf._slab_hook = None
+            self._comm.allreduce_(y)
+            cannot = 0.0 if self._covers(done) else 1.0
+            self._route = 'slab' if self._comm.max(cannot) == 0.0 else 'full'
+        elif self._route == 'slab' and ncols == 1:
+            # The leaf all-reduces the image slab by slab (ZpadFFT._slab_hook).  That it does was established -- on every rank --
+            # by the first evaluation; it is still CHECKED: a tree whose last writer suddenly takes another branch must not
+            # return a rank-local partial sum silently, and it cannot be repaired locally either (the other ranks have issued
+            # their slab collectives), so it raises.
             done = []
 
             def hook(arr, lo, hi):
@@ -376,13 +427,8 @@ class ShardedNormalOperator(object):
             finally:
                 self._leaf._slab_hook = None
             self._comm.join()
-            done.sort()
-            covered = bool(done) and done[0][0] == 0 and done[-1][1] == self.shape[1] and \
-                all(a[1] == b[0] for a, b in zip(done[:-1], done[1:]))
-            if not covered:
-                assert not done, "slab all-reduce covered only part of the image: %s" % (done,)
-                self._leaf = None                   # this tree does not take the slab route: plain all-reduce from now on
-                self._comm.allreduce_(y)
+            if not self._covers(done):
+                raise RuntimeError("slab all-reduce covered %s of [0, %d): the ranks' collectives no longer match" % (sorted(done), self.shape[1]))
         else:
             self._A.eval(y, self._ksp, forward=False)
             self._comm.allreduce_(y)

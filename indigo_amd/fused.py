@@ -137,7 +137,8 @@ def assemble(backend, Gm, oN, N, weights_of, Cn, layout, chunks, table=None, box
     and the adjoint accumulates the chunks' images (VStack, operators.py:440-447)."""
     tuning = getattr(backend, 'tuning', {})          # format choices of the backend (HipBackend.tuning)
 
-    def gridding(interleaved):
+    def gridding(interleaved, ncols=0):
+        # ncols: panel columns of the trees that use this matrix (per-coil layout: the chunk's coil count)
         G = backend.SpMatrix(Gm, name='interp*mod*scale')
         if interleaved:
             G._grid_interleaved = True
@@ -154,9 +155,11 @@ def assemble(backend, Gm, oN, N, weights_of, Cn, layout, chunks, table=None, box
             shape = tuning.get('brick_shape', {})
             shape = shape.get(bricks_cols, (2, 2, 4096, 4096)) if isinstance(shape, dict) else shape
             G._grid_bricks = (int(oN[0]), int(oN[2]), int(oN[1]), bricks_cols) + tuple(shape)
-        elif (bricks_cols if interleaved else 1) in tuning.get('slots', ()) and int(oN[2]) % 4 == 0 and int(oN[1]) % 4 == 0 and int(oN[0]) % 16 == 0:
-            # 1, 2 (or 4) columns: the same scatter with SLOTS in place of rounds (ig_ccsrmm_t_slots) -- no padding, no G'^T
-            G._grid_slots = (int(oN[0]), int(oN[2]), int(oN[1]), bricks_cols if interleaved else 1) + tuple(tuning.get('slot_shape', (4, 4, 256, 64)))
+        elif (bricks_cols if interleaved else ncols) in tuning.get('slots', ()) and int(oN[2]) % 4 == 0 and int(oN[1]) % 4 == 0 and int(oN[0]) % 16 == 0:
+            # 1, 2 (or 4) columns: the same scatter with SLOTS in place of rounds (ig_ccsrmm_t_slots) -- no padding, no G'^T.
+            # (per-coil layout: only for a chunk of exactly that many coils -- a 3-, 5-, 6- or 7-coil tree never takes the
+            # route, and the format is 16 bytes per nonzero of HBM plus its host passes)
+            G._grid_slots = (int(oN[0]), int(oN[2]), int(oN[1]), bricks_cols if interleaved else ncols) + tuple(tuning.get('slot_shape', (4, 4, 256, 64)))
         return G
 
     sizes = {hi - lo for lo, hi in chunks if hi - lo > 1}
@@ -179,7 +182,7 @@ def assemble(backend, Gm, oN, N, weights_of, Cn, layout, chunks, table=None, box
         if lay == 2:
             G = G_il
         else:
-            G_pc = G_pc or gridding(False)
+            G_pc = G_pc or gridding(False, hi - lo)
             G = G_pc
         if lay == 2 and fine is not None:
             Z = backend.ZpadFFT(oN, N, weights_of(lo, hi), box_lo=box_lo, layout=lay, support=fine[0], support_tile=fine[1],

@@ -1,0 +1,274 @@
+#!/usr/bin/env python3
+"""Stress harness for the adjoint of a coil-chunked SENSE tree (test infrastructure; GPU box only).
+
+    python tests/stress_adjoint.py --reps 500 [--procs 4] [--idle 5] [--rebuild 50] [--coils 7 --chunk 2]
+
+Why: round 3 saw `test_config5_coil_chunks_vs_oracle` (7 coils as 2 + 2 + 2 + 1 on a 256^3 grid: the slot scatter
+k_grid_slots<2> / <1> under a chunk VStack) return ONE adjoint 1.6e-2 off the oracle in about thirty suite runs.  This
+harness evaluates that adjoint over and over and checks every stage separately, so that a deviation names its kernel:
+
+  scatter    KronI(nc, G')^H of the chunk's k-space rows into a grid POISONED with NaN beforehand.  Compared with the first
+             evaluation BIT FOR BIT on every flagged segment of a brick no shared task touches (plain stores: any
+             difference is a bug, not summation order), to 2e-6 (relative to the grid's largest value) on bricks whose
+             pieces add with float atomics, and the unflagged segments must still be NaN (nobody may write them).  The
+             first evaluation itself is checked against scipy's G^H k in complex128.
+  transform  ZpadFFT^H of the reference grid with NaN in every unflagged segment (nobody may READ them) -- no atomics:
+             bit for bit against the first evaluation.
+  chain      the whole A^H k (scratch arena and dynamic scratch alternate), <= 1e-5 against the numpy oracle and 2e-6 against the
+             first evaluation.
+
+`--idle S` sleeps S seconds before every 10th evaluation (the one failure came after ~10 s of host-side oracle work: a GPU
+waking from idle clocks); `--rebuild N` rebuilds the tree and all formats every N evaluations; `--procs P` runs the whole
+thing in P fresh processes one after the other (first-touch / code-object-load effects).  Exit status 1 on any deviation;
+every deviation is printed with the bricks it touches (shared or not), the chunk and its coil count.
+Used by tests/test_hip_stress.py (a short version in the GPU suite)."""
+import argparse
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+C64 = np.dtype('complex64')
+
+
+def rel(a, b):
+    den = np.linalg.norm(np.asarray(b).ravel())
+    return float(np.linalg.norm((np.asarray(a) - np.asarray(b)).ravel()) / den) if den else 0.0
+
+
+class Harness(object):
+    def __init__(self, hip, image=160, coils=7, chunk=2, nspokes=300, nreadout=256, oversamp=1.6, seed=5, log=print):
+        from indigo_amd.sense import SenseProblem
+        from indigo_amd.util import rand64c
+        self.hip, self.log = hip, log
+        self.p = SenseProblem.synthetic((image,) * 3, coils, nspokes=nspokes, nreadout=nreadout, width=2, ntable=128,
+                                        oversamp=oversamp, seed=seed, lazy_maps=True)
+        self.chunk = chunk
+        self.k = rand64c(self.p.T * coils, 1, seed=2)
+        self.k_d = hip.copy_array(self.k)
+        self.ref = None              # per-chunk reference grids / images, the chain's reference image
+        self.build()
+
+    # -- the tree and what the checks need to know about its formats ---------------------------------------------------------
+    def build(self):
+        from indigo_amd import operators as op
+        hip, p = self.hip, self.p
+        hip._scratch = None
+        self.A = A = p.build_zpadfft(hip, chunk=self.chunk)
+        self.children = list(A.children) if isinstance(A, op.VStack) else [A]
+        self.table = p.last_support_table
+        n0, n1, n2 = p.oN
+        self.P = n0 * n1 * n2
+        # flagged segments of the (ky, kz, kx-tile) grid, from the support table the tree's kernels write and read by
+        # (16 kx points per entry, or the finer table of the coil-interleaved trees)
+        fine = getattr(p, 'last_support_fine', None)
+        self.tile = tile = int(fine[1]) if fine is not None else 16
+        _, _, bits = p.split_support(fine[0] if fine is not None else self.table, tile)
+        nt = n0 // tile
+        b = bits.reshape(n1, nt, 16)                                     # [ky, kxt, kz % 16] bit kz // 16
+        kz = np.arange(n2)
+        self.flag = ((b[:, :, kz % 16] >> (kz // 16).astype(np.uint32)) & 1).astype(bool).transpose(0, 2, 1)   # [ky, kz, kxt]
+        self.info = []
+        x_d = hip.zero_array((A.shape[1], 1), C64)
+        A.eval(x_d, self.k_d, forward=False)                             # formats are built on first use
+        hip.barrier()
+        for ch in self.children:
+            G = ch.left.right                                             # Product(KronI(nc, G'), ZpadFFT): KronI = Kron(Eye, G')
+            M = G._matrix_d
+            nc = ch.shape[0] // p.T
+            sl = getattr(M, '_slots', None)
+            br = getattr(M, '_bricks', None)
+            fmt = sl if (sl is not None and sl['ncols'] == nc) else br if (br is not None and br['ncols'] == nc) else None
+            shared = np.zeros((n1, n2, nt), dtype=bool)                  # segments of bricks whose pieces add with atomics
+            if fmt is not None and fmt['nshared']:
+                sb = fmt['shared'].to_host()[:fmt['nshared']].astype(np.int64)
+                bm, bs = fmt['bm'], fmt['bs']
+                nbx, nbm = n0 // 16, n2 // bm
+                bx, bmi, bsi = sb % nbx, (sb // nbx) % nbm, sb // (nbx * nbm)
+                for im in range(bm):
+                    for is_ in range(bs):
+                        for xs in range(16 // tile):
+                            shared[bsi * bs + is_, bmi * bm + im, bx * (16 // tile) + xs] = True
+            self.info.append(dict(nc=nc, fmt='slots' if fmt is sl and sl is not None else 'bricks' if fmt is not None else 'gather',
+                                  shared=shared, layout=ch.right._layout))
+
+    def chunk_rows(self, i):
+        lo = sum(c.shape[0] for c in self.children[:i])
+        return lo, lo + self.children[i].shape[0]
+
+    def grid_view(self, g, nc, layout):
+        """host grid panel (P*nc,) -> [ky, kz, kx tile, point in tile, nc] view"""
+        n0, n1, n2 = self.p.oN
+        t = self.tile
+        if layout == 2:
+            return g.reshape(n1, n2, n0 // t, t, nc)
+        return g.reshape(nc, n1, n2, n0 // t, t).transpose(1, 2, 3, 4, 0)
+
+    # -- stages ---------------------------------------------------------------------------------------------------------------
+    def scatter(self, i, poison_d):
+        hip = self.hip
+        ch, inf = self.children[i], self.info[i]
+        lo, hi = self.chunk_rows(i)
+        grid_d = hip.empty_array((self.P * inf['nc'], 1), C64)
+        grid_d._copy(poison_d[inf['nc']])
+        ch.left.eval(grid_d, self.k_d[lo:hi], forward=False)
+        return grid_d.to_host().reshape(-1)
+
+    def transform(self, i, grid_h):
+        hip = self.hip
+        ch = self.children[i]
+        img_d = hip.empty_array((ch.shape[1], 1), C64)
+        img_d._copy(self.nan_img_d)
+        g_d = hip.copy_array(grid_h.reshape(-1, 1))
+        ch.right.eval(img_d, g_d, forward=False)
+        return img_d.to_host().reshape(-1)
+
+    def chain(self, arena):
+        from indigo_amd.transforms import reserve_for
+        hip = self.hip
+        if arena:
+            reserve_for(self.A, 1)
+        else:
+            hip._scratch = None
+        y_d = hip.empty_array((self.A.shape[1], 1), C64)
+        y_d._copy(self.nan_img_d)
+        self.A.eval(y_d, self.k_d, forward=False)
+        out = y_d.to_host().reshape(-1)
+        hip._scratch = None
+        return out
+
+    # -- references ---------------------------------------------------------------------------------------------------------
+    def make_references(self, oracle_backend=None):
+        hip, p = self.hip, self.p
+        self.nan_img_d = hip.copy_array(np.full((self.A.shape[1], 1), np.nan + 1j * np.nan, dtype=C64))
+        self.poison = {}
+        for nc in sorted({inf['nc'] for inf in self.info}):
+            self.poison[nc] = hip.copy_array(np.full((self.P * nc, 1), np.nan + 1j * np.nan, dtype=C64))
+        Gm = p.fused_interp(1)
+        GH = Gm.conj().T.tocsr().astype(np.complex128)
+        self.ref = dict(grid=[], img=[], chain=None)
+        for i, inf in enumerate(self.info):
+            lo, hi = self.chunk_rows(i)
+            g = self.scatter(i, self.poison)
+            v = self.grid_view(g, inf['nc'], inf['layout'])
+            # nobody writes unflagged segments; flagged ones equal G^H k
+            assert np.isnan(v[~self.flag].real).all(), "chunk %d: the scatter wrote an unflagged segment" % i
+            exp = GH @ self.k[lo:hi].reshape(p.T, inf['nc'], order='F').astype(np.complex128)      # (P, nc), layout-1 rows
+            n0, n1, n2 = p.oN
+            e = exp.reshape(n1, n2, n0 // self.tile, self.tile, inf['nc'])
+            err = np.linalg.norm((v[self.flag] - e[self.flag]).ravel()) / np.linalg.norm(e[self.flag].ravel())
+            assert err < 1e-5, "chunk %d (%d coils, %s): first scatter %.3e off scipy's G^H k" % (i, inf['nc'], inf['fmt'], err)
+            assert np.count_nonzero(e[~self.flag]) == 0
+            self.ref['grid'].append(g)
+            self.ref['img'].append(self.transform(i, g))
+            self.log("chunk %d: %d coil(s), layout %d, %s, %d shared segments of %d flagged; scatter vs scipy %.2e"
+                     % (i, inf['nc'], inf['layout'], inf['fmt'], int((inf['shared'] & self.flag).sum()), int(self.flag.sum()), err))
+        self.ref['chain'] = self.chain(arena=False)
+        total = np.sum(self.ref['img'], axis=0)
+        self.log("chain vs sum of stage images: %.2e" % rel(self.ref['chain'], total))
+        assert rel(self.ref['chain'], total) < 2e-6
+        if oracle_backend is not None:
+            A_o = p.build_zpadfft(oracle_backend, layout=0, support=False)
+            exp = (A_o.H * self.k).reshape(-1)
+            e = rel(self.ref['chain'], exp)
+            self.log("chain vs numpy oracle: %.2e" % e)
+            assert e < 1e-5, e
+
+    # -- one round of checks; returns a list of findings ----------------------------------------------------------------------
+    def check(self, it):
+        bad = []
+        for i, inf in enumerate(self.info):
+            g = self.scatter(i, self.poison)
+            v, r = self.grid_view(g, inf['nc'], inf['layout']), self.grid_view(self.ref['grid'][i], inf['nc'], inf['layout'])
+            if not np.isnan(v[~self.flag].real).all():
+                bad.append("it %d chunk %d (%d coils, %s): %d values written into unflagged segments"
+                           % (it, i, inf['nc'], inf['fmt'], int((~np.isnan(v[~self.flag].real)).sum())))
+            own = self.flag & ~inf['shared']
+            same = (v.view(np.uint32) == r.view(np.uint32)).reshape(v.shape[:3] + (-1,)).all(axis=3)     # per segment
+            diff = own & ~same
+            if diff.any():
+                ky, kz, kxt = np.nonzero(diff)
+                dv = np.abs(np.nan_to_num(v[diff], nan=1e30) - r[diff]).max()
+                bad.append("it %d chunk %d (%d coils, %s): %d NON-SHARED segments differ bitwise (max |d| %.3e, grid max %.3e); first (ky,kz,kxt): %s; nan %d zero %d"
+                           % (it, i, inf['nc'], inf['fmt'], int(diff.sum()), dv, np.abs(r[self.flag]).max(),
+                              list(zip(ky[:6].tolist(), kz[:6].tolist(), kxt[:6].tolist())),
+                              int(np.isnan(v[diff].real).sum()), int((v[diff] == 0).sum())))
+            sh = self.flag & inf['shared']
+            if sh.any():
+                scale = np.abs(r[sh]).max()
+                d = np.abs(np.nan_to_num(v[sh], nan=1e30) - r[sh]).max() / scale
+                if d > 2e-6:
+                    seg = sh & ~same
+                    ky, kz, kxt = np.nonzero(seg)
+                    bad.append("it %d chunk %d (%d coils, %s): SHARED segments off by %.3e of the grid max; %d segments; first %s"
+                               % (it, i, inf['nc'], inf['fmt'], d, int(seg.sum()), list(zip(ky[:6].tolist(), kz[:6].tolist(), kxt[:6].tolist()))))
+            # the reader: reference grid with NaN in unflagged segments
+            img = self.transform(i, self.ref['grid'][i])
+            if not np.array_equal(img.view(np.uint32), self.ref['img'][i].view(np.uint32)):
+                bad.append("it %d chunk %d (%d coils): cropped transform differs bitwise from its first evaluation: rel %.3e, nan %d"
+                           % (it, i, inf['nc'], rel(np.nan_to_num(img), self.ref['img'][i]), int(np.isnan(img.real).sum())))
+        out = self.chain(arena=bool(it & 1))
+        e = rel(np.nan_to_num(out, nan=1e30), self.ref['chain'])
+        if not e < 2e-6:
+            bad.append("it %d chain (%s scratch): %.3e off the first evaluation; nan %d" % (it, "arena" if it & 1 else "dynamic", e, int(np.isnan(out.real).sum())))
+        return bad
+
+
+def run(reps, idle=0.0, rebuild=0, oracle=True, log=print, **kw):
+    from indigo_amd.backends import get_backend
+    hip = get_backend("hip")
+    ob = None
+    if oracle:
+        from oracle.np_backend import NumpyBackend
+        ob = NumpyBackend()
+    h = Harness(hip, log=log, **kw)
+    h.make_references(ob)
+    findings = []
+    t0 = time.time()
+    for it in range(reps):
+        if rebuild and it and it % rebuild == 0:
+            h.build()
+        if idle and it % 10 == 9:
+            time.sleep(idle)
+        bad = h.check(it)
+        for b in bad:
+            log("DEVIATION " + b)
+        findings += bad
+        if it % 50 == 49 or it == reps - 1:
+            log("  %d evaluations, %d deviations, %.0f s" % (it + 1, len(findings), time.time() - t0))
+    return findings
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=200)
+    ap.add_argument("--procs", type=int, default=1)
+    ap.add_argument("--idle", type=float, default=0.0)
+    ap.add_argument("--rebuild", type=int, default=0)
+    ap.add_argument("--image", type=int, default=160)
+    ap.add_argument("--coils", type=int, default=7)
+    ap.add_argument("--chunk", type=int, default=2)
+    ap.add_argument("--no-oracle", action="store_true")
+    a = ap.parse_args()
+    if a.procs > 1:                         # fresh processes, one after the other; this parent never touches the GPU
+        rc = 0
+        for pi in range(a.procs):
+            cmd = [sys.executable, os.path.abspath(__file__), "--reps", str(a.reps), "--idle", str(a.idle), "--rebuild", str(a.rebuild),
+                   "--image", str(a.image), "--coils", str(a.coils), "--chunk", str(a.chunk)] + (["--no-oracle"] if a.no_oracle or pi else [])
+            print("== process %d of %d" % (pi + 1, a.procs), flush=True)
+            rc |= subprocess.call(cmd)
+        sys.exit(rc)
+    f = run(a.reps, idle=a.idle, rebuild=a.rebuild, oracle=not a.no_oracle, image=a.image, coils=a.coils, chunk=a.chunk,
+            log=lambda s: print(s, flush=True))
+    print("stress_adjoint: %d deviations in %d evaluations" % (len(f), a.reps), flush=True)
+    sys.exit(1 if f else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -102,11 +102,13 @@ xs = B.copy_array(rand64c(A.shape[1], 1, seed=2))
 c64 = np.dtype("complex64")
 y1, y2 = B.zero_array((A.shape[1], 1), c64), B.zero_array((A.shape[1], 1), c64)
 op = ShardedNormalOperator(A, comm, lamda=0.1, nslabs=5)
-assert op._leaf is None               # one rank: nothing to overlap
+assert op._route == 'full'            # one rank: nothing to overlap, nothing to vote on
 comm.world = 2                        # pretend, to take the slab route (the RCCL communicator still has one rank)
 op = ShardedNormalOperator(A, comm, lamda=0.1, nslabs=5)
-assert op._leaf is not None
-op.eval(y1, xs)
+assert op._leaf is not None and op._route == 'undecided'
+op.eval(y1, xs)                       # first evaluation: whole-image all-reduce, the ranks vote on the route
+assert op._route == 'slab'
+op.eval(y1, xs)                       # the slab route for real
 comm.world = 1
 B._scratch = None
 normal_operator(A, lamda=0.1).eval(y2, xs)
@@ -123,6 +125,8 @@ comm.world = 2
 op = ShardedNormalOperator(A, comm, lamda=0.1, nslabs=3)
 assert op._leaf is A.children[-1].right
 op.eval(y1, xs)
+assert op._route == 'slab'
+op.eval(y1, xs)
 comm.world = 1
 B._scratch = None
 normal_operator(A, lamda=0.1).eval(y2, xs)
@@ -137,6 +141,8 @@ comm.world = 2
 op = ShardedNormalOperator(A, comm, lamda=0.1, nslabs=3)
 assert op._leaf is A.right
 op.eval(y1, xs)
+assert op._route == 'slab'
+op.eval(y1, xs)
 comm.world = 1
 B._scratch = None
 normal_operator(A, lamda=0.1).eval(y2, xs)
@@ -145,7 +151,8 @@ assert np.linalg.norm(a - b) <= 1e-6 * np.linalg.norm(b), np.linalg.norm(a - b) 
 del A, op
 B._scratch = None
 A = p.build_zpadfft(B, chunk=2)
-# a tree whose last writer does not take the slab branch: the coverage check falls back to ONE plain all-reduce
+# a tree whose last writer does not take the slab branch: the first evaluation notices (nothing was sent slab by slab yet),
+# the vote says 'full', and every evaluation is ONE plain all-reduce
 calls = []
 orig = comm.allreduce_
 comm.allreduce_ = lambda arr, force=False: (calls.append(arr.size), orig(arr, force=True))
@@ -154,8 +161,10 @@ op = ShardedNormalOperator(A, comm, nslabs=3)
 op._leaf = A.children[0].right           # (wrong on purpose: chunk 0's leaf runs with beta = 0 FIRST, then chunk 1 overwrites nothing it reduced)
 op._leaf = type("NoHook", (), {"_slab_hook": None})()    # a leaf that never calls the hook
 op.eval(y1, xs)
+assert calls == [y1.size] and op._route == 'full', (calls, op._route)
+op.eval(y1, xs)
 comm.world = 1
-assert calls == [y1.size] and op._leaf is None, calls
+assert calls == [y1.size] * 2, calls
 a = y1.to_host()
 B._scratch = None
 normal_operator(A).eval(y2, xs)
@@ -194,9 +203,13 @@ xs = B.copy_array(rand64c(int(np.prod(p.N)), 1, seed=2))
 A = p.build_zpadfft(B, coils=coil_range(8, rank, world))
 y = B.zero_array((A.shape[1], 1), c64)
 op = ShardedNormalOperator(A, comm, lamda=0.1, nslabs=4)
-assert op._leaf is not None                 # the slab route, for real this time
+assert op._leaf is not None
+op.eval(y, xs)                              # first evaluation: whole image, then the ranks vote
+assert op._route == 'slab', op._route       # the slab route, for real this time
+first = y.to_host()
 op.eval(y, xs)
 got = y.to_host()
+assert np.linalg.norm(got - first) <= 1e-6 * np.linalg.norm(first)
 B._scratch = None
 del A, op
 Afull = p.build_zpadfft(B)                  # the unsharded operator on this rank's GPU
