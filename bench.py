@@ -380,6 +380,7 @@ def run_sense(args, cfg, B, comm, world, rank, steps, warmup, want_cpu, quiet=Fa
     cpr = len(coils) if nchunks == 1 else 8          # coils per chunk seen by one launch
     half_box = all(2 * b == n for b, n in zip(p.N, p.oN))
     sup_tab, sup_tile = tree_support(A) if fused_fft else (None, 16)
+    p.last_support_zw = getattr(A, '_support_zw', None) or getattr(p, 'last_support_zw', (16, 16))     # (recipe trees carry their own)
     if fused_fft:
         exact = p.zpadfft_pass_bytes(cpr, sup_tab, fused_sum=(layout == 2), tile=sup_tile)
         for name, nbytes in exact.items():

@@ -258,7 +258,8 @@ int  ig_grid_bricks_fill(int64_t M, const int32_t* rowptr, const int32_t* colind
 int  ig_ccsrmm_t_bricks(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, float alpha_re, float alpha_im,
                         const void* entries, const uint32_t* round_rows, const void* X, int64_t ldx, void* Y_il,
                         const int16_t* support, int64_t n0, int64_t nm, int bm, int bs, const int32_t* tasks, int64_t ntasks,
-                        const int32_t* brick_table, const int32_t* shared_bricks, int64_t nshared, int support_tile);
+                        const int32_t* brick_table, const int32_t* shared_bricks, int64_t nshared, int support_tile, int support_zwords);
+/* (support_zwords: words per entry of the support table's bitmaps = zw_in of ig_grid_support; 16 for 256- / 512-point km axes) */
 
 /* The brick scatter for interleaved panels of 1, 2 or 4 columns (the ranks of a coil-sharded run that hold few coils): a
  * lane is an ENTRY and loops over the columns; race-freedom comes from the ORDER of the entries.  ig_grid_slots_build (host)
@@ -271,7 +272,7 @@ int  ig_grid_slots_build(int64_t nbricks, const int64_t* brick_ptr, const void* 
 int  ig_ccsrmm_t_slots(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, float alpha_re, float alpha_im,
                        const void* entries16, const int32_t* slot_ptr, const void* X, int64_t ldx, void* Y_il,
                        const int16_t* support, int64_t n0, int64_t nm, int bm, int bs, const int32_t* tasks, int64_t ntasks,
-                       const int32_t* brick_table, const int32_t* shared_bricks, int64_t nshared, int support_tile);
+                       const int32_t* brick_table, const int32_t* shared_bricks, int64_t nshared, int support_tile, int support_zwords);
 
 /* The same scatter for the reference's own panel layout, 64 columns: Y(K x 64, column-major, ldy) = alpha * A^H * X(M x 64,
  * column-major, ldx) for ANY CSR matrix with K a multiple of 16 (beta == 0: Y is zeroed first).  Bricks are 16 consecutive
@@ -377,9 +378,12 @@ int  ig_interp3_fill_modulated(int64_t m, const int64_t* N, double width, const 
                                const double* phase_x, const double* phase_y, const double* phase_z, double scale);
 /* k-space support table (host) of a gridding matrix whose columns number the grid as kx + n0*(kz + n2*ky): for every
  * (ky, kx tile of `tile` points) the kz hull and one bit per kz that holds a nonzero, and the ky hull of every kx tile --
- * the table ig_fft_exec_padded / _cropped and the gridding kernels take.  table: 2*(n1*nt + nt) int16 + n1*nt*16 uint32,
- * nt = n0 / tile.  n2 a multiple of 16, at most 512.                                                                   */
-int  ig_grid_support(int64_t nnz, const int32_t* colind, int64_t n0, int64_t n1, int64_t n2, int tile, int16_t* table);
+ * the table ig_fft_exec_padded / _cropped and the gridding kernels take.  The bitmaps come with zw_in words per (ky, kx tile)
+ * -- bit kz / zw_in of word kz % zw_in -- and, where zw_out differs, once more with zw_out words: the forms the z pass of the
+ * transform reads on its input and on its output side (ig_fft_support_words(n2): 16 / 16 for 256- and 512-point axes, B / A
+ * for an axis the A x B kernel transforms).  table: 2*(n1*nt + nt) int16 + n1*nt*(zw_in + (zw_out != zw_in ? zw_out : 0))
+ * uint32, nt = n0 / tile.  n2 <= 32 * zw_in, 32 * zw_out.                                                                */
+int  ig_grid_support(int64_t nnz, const int32_t* colind, int64_t n0, int64_t n1, int64_t n2, int tile, int zw_in, int zw_out, int16_t* table);
 
 /* ------------------------------------------------------------------------
  * Batched complex-to-complex FFT.  Replaces Backend.fftn/ifftn
@@ -429,7 +433,9 @@ int  ig_fft_plan_padded(ig_ctx* ctx, const int64_t* dims, const int64_t* box_lo,
  *   2. nt pairs     [y_lo, y_hi)  per kx tile: the ky range outside which every z hull is empty (y pass);
  *   3. n1*nt*16 uint32 words (4-byte aligned, every pair before it being 4 bytes):
  *      bit m of word 16*(ky*nt + kx/16) + t is set iff the 16-row segment (kx tile, ky, kz = t + 16*m)
- *      holds a nonzero of the gridding matrix.
+ *      holds a nonzero of the gridding matrix.  (A z axis that is not 256 or 512 points long -- an A x B axis -- has zw_in = B
+ *      words per entry, kz = t + B*m, followed by the same bits with zw_out = A words per entry: ig_fft_support_words tells
+ *      the two numbers for an axis length, ig_grid_support writes the table.)
  * The padded transform only guarantees the flagged segments of Y (the rest is undefined and must not be
  * read); the cropped transform reads only flagged segments (everything else counts as zero and may hold
  * anything).  A radial trajectory covers a ball (52 % of the cube) with gaps between its outer spokes:
@@ -438,6 +444,7 @@ int  ig_fft_plan_padded(ig_ctx* ctx, const int64_t* dims, const int64_t* box_lo,
  * (16 by default; 8, 4 or 2 as long as coils * tile >= 16).  The table then has n0/tile entries per (ky) row in each of its
  * three parts; a finer table flags fewer grid bytes (BASELINE config 4: 30.5 % of the grid at 16, 22.2 % at 8, 16.4 % at 4).   */
 int  ig_fft_set_support_tile(ig_fft* plan, int tile);
+int  ig_fft_support_words(int64_t n2, int* zw_in, int* zw_out);        /* host; IG_ERR_UNSUPPORTED: no zero-pad-aware z pass */
 int  ig_fft_exec_padded(ig_fft* plan, const void* x, int64_t x_bstride, const void* w, void* y, void* workspace,
                         const int16_t* support);
 int  ig_fft_exec_cropped(ig_fft* plan, const void* y, const void* w, void* x, int64_t x_bstride, void* workspace,

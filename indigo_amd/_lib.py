@@ -69,7 +69,7 @@ PROTOTYPES = {
     "ig_grid_bricks_fill": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ig_ccsrmm_t_bricks": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_float, c_float, c_void_p, c_void_p,
                                    c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_int64,
-                                   c_void_p, c_void_p, c_int64, c_int]),
+                                   c_void_p, c_void_p, c_int64, c_int, c_int]),
     "ig_ccsrmm":          (c_int, [c_void_p, c_int, c_int, c_int64, c_int64, c_int64, c_int64,
                                    c_float, c_float, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_int64, c_float, c_float, c_void_p, c_int64]),
@@ -82,7 +82,7 @@ PROTOTYPES = {
                                    c_void_p, c_int64, c_int64, c_void_p]),
     "ig_grid_slots_build": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, POINTER(c_int64)]),
     "ig_ccsrmm_t_slots":  (c_int, [c_void_p, c_int64, c_int64, c_int64, c_float, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
-                                   c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int]),
+                                   c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int]),
     "ig_ccsrmm_t_bricks_wide": (c_int, [c_void_p, c_int64, c_int64, c_float, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                         c_void_p, c_int64, c_void_p, c_void_p]),
     "ig_ccsrmm_t_bricks_wide_grid": (c_int, [c_void_p, c_int64, c_int64, c_float, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
@@ -105,7 +105,8 @@ PROTOTYPES = {
                                    c_void_p, c_int64, c_float, c_float, c_void_p, c_int64]),
     "ig_interp3_count":   (c_int, [c_int64, POINTER(c_int64), c_double, c_void_p, c_void_p]),
     "ig_interp3_fill":    (c_int, [c_int64, POINTER(c_int64), c_double, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int]),
-    "ig_grid_support":    (c_int, [c_int64, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
+    "ig_grid_support":    (c_int, [c_int64, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
+    "ig_fft_support_words": (c_int, [c_int64, POINTER(c_int), POINTER(c_int)]),
     "ig_interp3_fill_modulated": (c_int, [c_int64, POINTER(c_int64), c_double, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                           c_void_p, c_void_p, c_void_p, c_double]),
     "ig_fft_plan":        (c_int, [c_void_p, c_int, POINTER(c_int64), c_int64, POINTER(c_void_p), POINTER(c_size_t)]),

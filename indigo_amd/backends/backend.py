@@ -530,7 +530,7 @@ class Backend(object):
             same numbers in a different order."""
             self._grid_il = bool(flag)
 
-        def set_grid_support(self, table, n0, nm):
+        def set_grid_support(self, table, n0, nm, zw=16):
             """Hint: the columns of this matrix index a 3-D grid and only the tabulated support is ever
             non-zero / read in an adjoint product.  Backends may ignore it (the result inside the support
             is the same either way)."""

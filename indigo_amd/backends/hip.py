@@ -462,17 +462,26 @@ class HipBackend(Backend):
 
     # fused zero-pad / crop transforms (operators.ZpadFFT)
     PADDED_AXES_POW2 = (256, 512)
-    PADDED_AXES_AB = (160, 192, 240, 320, 384, 400, 432, 480, 640)       # k_fft_ab_desc instantiations (ig_fft.hip: IG_ABD_LIST)
+
+    def support_words(self, n):
+        """(zw_in, zw_out) of an axis the library has a zero-pad-aware z pass for (ig_fft_support_words: 256 and 512 through the
+        power-of-two kernel, every length 128 ... 640 with factors 2, 3, 5, 7 that splits as A x B, A, B <= 32, through the A x B
+        kernel), else None.  Doubles as the list of axis lengths `supports_padded_fft` accepts."""
+        zi, zo = ctypes.c_int(), ctypes.c_int()
+        if self._L.ig_fft_support_words(int(n), ctypes.byref(zi), ctypes.byref(zo)) != 0:
+            return None
+        return zi.value, zo.value
 
     def supports_padded_fft(self, grid, ncoils=None):
         """256- and 512-point axes in every grid layout; the reference driver's own oversampled grids (320 ... 640,
-        examples/pics.py:87-90, and smaller ones: 160 ... 640) in the coil-interleaved layout, i.e. for coil counts that split into chunks of 2, 4, 8 or 16"""
+        examples/pics.py:87-90) and every other smooth length from 128 to 640 in the coil-interleaved layout, i.e. for coil
+        counts that split into chunks of 2, 4, 8 or 16"""
         from indigo_amd import fused
         if len(grid) != 3:
             return False
         if all(int(n) in self.PADDED_AXES_POW2 for n in grid):
             return True
-        if not all(int(n) in self.PADDED_AXES_POW2 + self.PADDED_AXES_AB for n in grid):
+        if not all(self.support_words(n) is not None for n in grid):
             return False
         if ncoils is None:
             return True
@@ -693,9 +702,11 @@ class HipBackend(Backend):
                 self._host_csr = None
             return self._t
 
-        def set_grid_support(self, table, n0, nm):
+        def set_grid_support(self, table, n0, nm, zw=16):
+            """zw: words per entry of the table's bitmaps (the input-side form, ig_grid_support); 16 for 256- / 512-point nm"""
             self._support = (self._backend.copy_array(np.ascontiguousarray(table, dtype=np.int16).reshape(-1),
                                                       name=self._name + ".support"), int(n0), int(nm))
+            self._support_zw = int(zw)
 
         def set_grid_support_fine(self, table, tile):
             """a support table with `tile` (8 or 4) kx points per entry: what the brick scatter writes by (the gather routes keep
@@ -957,6 +968,9 @@ class HipBackend(Backend):
             sup = getattr(self, '_support', None)
             perm = getattr(self, '_perm', None)
             br = getattr(self, '_bricks', None)
+            # (the gather routes over the transposed matrix read 16-word bitmaps only: with another table they compute every
+            # row -- a superset of what any reader of the grid looks at)
+            sup_gather = sup if getattr(self, '_support_zw', 16) == 16 else None
             if (br is not None and perm is None and beta == 0 and y.contiguous and getattr(self, '_grid_il', False)
                     and x.shape[1] == br['ncols']):
                 fine = getattr(self, '_support_fine', None)
@@ -969,7 +983,8 @@ class HipBackend(Backend):
                                                  ctypes.c_void_p(br['entries']._arr), ctypes.c_void_p(br['rounds']._arr), ctypes.c_void_p(x._arr), x._leading_dim,
                                                  ctypes.c_void_p(y._arr), ctypes.c_void_p(tab._arr) if tab is not None else None,
                                                  br['n0'], br['nm'], br['bm'], br['bs'], ctypes.c_void_p(br['tasks']._arr), br['ntasks'],
-                                                 ctypes.c_void_p(br['table']._arr), ctypes.c_void_p(br['shared']._arr), br['nshared'], tile),
+                                                 ctypes.c_void_p(br['table']._arr), ctypes.c_void_p(br['shared']._arr), br['nshared'], tile,
+                                                 getattr(self, '_support_zw', 16)),
                          "ig_ccsrmm_t_bricks")
                 return
             sl = getattr(self, '_slots', None)
@@ -984,7 +999,8 @@ class HipBackend(Backend):
                                                 ctypes.c_void_p(x._arr), x._leading_dim, ctypes.c_void_p(y._arr),
                                                 ctypes.c_void_p(tab._arr) if tab is not None else None, sl['n0'], sl['nm'], sl['bm'], sl['bs'],
                                                 ctypes.c_void_p(sl['tasks']._arr), sl['ntasks'], ctypes.c_void_p(sl['table']._arr),
-                                                ctypes.c_void_p(sl['shared']._arr), sl['nshared'], tile), "ig_ccsrmm_t_slots")
+                                                ctypes.c_void_p(sl['shared']._arr), sl['nshared'], tile, getattr(self, '_support_zw', 16)),
+                         "ig_ccsrmm_t_slots")
                 return
             if (x.shape[1] == 64 and beta == 0 and perm is None and not getattr(self, '_grid_il', False) and self.shape[1] % 16 == 0
                     and self.shape[1] > 0 and self.shape[0] * 512 < 2 ** 31 and self.values.size >= self.shape[1] // 4
@@ -1004,7 +1020,7 @@ class HipBackend(Backend):
             if getattr(self, '_grid_il', False):
                 assert perm is None and beta == 0 and y.contiguous, "interleaved panels: no row order, beta = 0"
                 pt, it, dt = self._transposed()
-                tab, n0, nm = sup if sup is not None else (None, 0, 0)
+                tab, n0, nm = sup_gather if sup_gather is not None else (None, 0, 0)
                 ar, ai = _cplx(alpha)
                 m, k = self.shape
                 b._check(b._L.ig_ccsrmm_t_grid_il(b._ctx, m, k, x.shape[1], dt.size, ar, ai,
@@ -1016,9 +1032,9 @@ class HipBackend(Backend):
             if perm is not None:
                 assert not self._exwrite and b.adjoint_policy == 'transpose' and x.shape[1] <= 8, \
                     "row-ordered matrices use the packed transposed gather"
-            if (sup is not None or perm is not None) and not self._exwrite and b.adjoint_policy == 'transpose':
+            if (sup_gather is not None or perm is not None) and not self._exwrite and b.adjoint_policy == 'transpose':
                 pt, it, dt = self._transposed()
-                b.ccsrmm_t(y, self.shape, it, pt, dt, x, alpha=alpha, beta=beta, support=sup, xperm=perm)
+                b.ccsrmm_t(y, self.shape, it, pt, dt, x, alpha=alpha, beta=beta, support=sup_gather, xperm=perm)
                 return
             if self._exwrite or b.adjoint_policy != 'transpose':
                 b.ccsrmm(y, self.shape, self.colInds, self.rowPtrs, self.values,

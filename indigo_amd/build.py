@@ -18,7 +18,8 @@ LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "lib", "obj")
 LIBNAME = "libindigo_hip.so"
 
-SOURCES = ["ig_context.hip", "ig_blas.hip", "ig_spmm.hip", "ig_fft.hip", "ig_comm.hip", "ig_interp.hip", "ig_dense.hip"]
+SOURCES = ["ig_fft_abd0.hip", "ig_fft_abd1.hip", "ig_fft_abd2.hip", "ig_fft_abd3.hip", "ig_fft.hip", "ig_spmm.hip", "ig_context.hip", "ig_blas.hip",
+           "ig_comm.hip", "ig_interp.hip", "ig_dense.hip"]       # (the slow ones first: four compile side by side)
 ARCH = "gfx950"
 CXXFLAGS = [
     "--offload-arch=%s" % ARCH, "-O3", "-std=c++17", "-fPIC",
@@ -33,6 +34,8 @@ EXTRA_FLAGS = {
     # the SLP vectoriser pairs unrelated scalar butterfly operations into v_pk_* instructions and pays four v_mov per
     # pair to gather the operands (measured: 298 v_mov among 1942 instructions of the 512-point kernel)
     "ig_fft.hip": os.environ.get("INDIGO_FFT_FLAGS", "-fno-slp-vectorize").split(),
+    "ig_fft_abd0.hip": ["-fno-slp-vectorize"], "ig_fft_abd1.hip": ["-fno-slp-vectorize"],
+    "ig_fft_abd2.hip": ["-fno-slp-vectorize"], "ig_fft_abd3.hip": ["-fno-slp-vectorize"],
     # host-only double-precision arithmetic that must round like the reference's (numpy / numba): no fused multiply-add
     "ig_interp.hip": ["-ffp-contract=off"],
 }
@@ -44,7 +47,7 @@ def source_hash():
     import hashlib
     h = hashlib.sha256()
     for name in sorted(os.listdir(CSRC)):
-        if name.endswith((".hip", ".h")):
+        if name.endswith((".hip", ".h", ".inc")):
             with open(os.path.join(CSRC, name), "rb") as f:
                 h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]
@@ -71,7 +74,7 @@ def _hipcc():
 def build(force=False, verbose=False):
     """Compile every HIP translation unit and link the shared library.  Returns its path."""
     os.makedirs(OBJDIR, exist_ok=True)
-    headers = [os.path.join(INCLUDE, "indigo_hip.h")] + sorted(os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h"))
+    headers = [os.path.join(INCLUDE, "indigo_hip.h")] + sorted(os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith((".h", ".inc")))
     hipcc = _hipcc()
     jobs = []
     objs = []

@@ -35,6 +35,7 @@
 // The inverse transform is computed as conj(FFT(conj(x))).
 #include "ig_common.h"
 #include "ig_fft_ab.h"
+#include "ig_fft_ab_list.h"
 #include <vector>
 #include <cmath>
 #include <cstring>
@@ -42,26 +43,13 @@
 
 namespace {
 
-// Non-temporal loads/stores in the 2-stage axis passes (every byte is touched exactly once per pass).
-// A/B on the 256^3 x 8 SENSE eval: 8.95 ms (either one off) -> 8.58 ms (both on).
-#ifndef IG_FFT_MINWAVES
-#define IG_FFT_MINWAVES 1      // minimum waves per SIMD the 2-stage kernels are compiled for (register cap)
-#endif
-#ifndef IG_FFT_CAP4_HALFOUT
-#define IG_FFT_CAP4_HALFOUT 0     // 1: also cap the strided half-output variants (cropped z / y passes) at 128 VGPRs -- measured slower (spills)
-#endif
-#ifndef IG_FFT_NT_LOAD
-#define IG_FFT_NT_LOAD 1
-#endif
-#ifndef IG_FFT_NT_STORE
-#define IG_FFT_NT_STORE 1
-#endif
-#ifndef IG_FFT_GATE_STORES
-#define IG_FFT_GATE_STORES 1    // scalar-gated stores (one opaque asm block each) on unweighted passes with a run-time output box
-#endif
-#ifndef IG_FFT_GROUP_SKIP
-#define IG_FFT_GROUP_SKIP 1     // wave-uniform skipping of loads / stores no lane wants (support bitmap, boxes)
-#endif
+// Choices measured in rounds 1-3 and now fixed in the code (the rejected alternatives are recorded in DESIGN.md section 3.1; what
+// is left to switch lives in tools/kernel_lab.py, not here):
+//  * non-temporal (streaming) loads and stores in the 2-stage axis passes -- every byte of a pass is touched exactly once
+//    (256^3 x 8 SENSE evaluation: 8.95 ms with either one off, 8.58 ms with both on);
+//  * wave-uniform skipping of the load instructions no lane wants, and scalar-gated stores (one opaque asm block each) on
+//    unweighted passes with a run-time output box;
+//  * the strided half-OUTPUT variants are not capped at 128 VGPRs (the cap spilled and was slower).
 constexpr int MAX_STAGES = 16;
 constexpr int E = 8;                 // complex elements a thread holds per LDS stage
 constexpr int LDS_NMAX = 4096;
@@ -376,12 +364,11 @@ template <int N> struct PFFTHalfIn {
 // Half inputs prune the first butterfly layer; compile-time boxes need no predicates or bounds registers.
 // Loads and stores carry the non-temporal (streaming) hint: every byte of a pass is touched exactly once.
 template <int R1, int R2, int T, int W, bool AXIS0, int WMODE, bool BOXED, int HALF>
-__global__ void __launch_bounds__(W * T, (!AXIS0 && R1 == 32 && (W == 32 || HALF == 1 || HALF == 3 || (IG_FFT_CAP4_HALFOUT && WMODE == 0 && (HALF == 2 || HALF == 4)))) ? 4 : IG_FFT_MINWAVES)
+__global__ void __launch_bounds__(W * T, (!AXIS0 && R1 == 32 && (W == 32 || HALF == 1 || HALF == 3)) ? 4 : 1)
 k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
     constexpr int n = R1 * R2, B1 = R2 / T, B2 = R1 / T, NT = W * T;
-    constexpr bool NT_LD = IG_FFT_NT_LOAD != 0, NT_ST = IG_FFT_NT_STORE != 0;
+    constexpr bool NT_LD = true, NT_ST = true;      // streaming hints on both sides
     constexpr bool HALF_IN = HALF == 1 || HALF == 3, HALF_OUT = HALF == 2 || HALF == 4;
-    constexpr bool GROUP_SKIP = IG_FFT_GROUP_SKIP != 0;
     constexpr int SUMW = WMODE >= 3 ? (1 << (WMODE - 3)) : 0;       // WMODE 3 + log2(coils): 3 -> 1 (no sum), 4 -> 2, 5 -> 4, 6 -> 8, 7 -> 16
     // direction: the half-input variants only serve forward (zero-padded) passes and the half-output variants only
     // inverse (cropped) ones, so their conjugations are sign modifiers, not a select per element
@@ -483,13 +470,13 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
     // (padded y pass 1.08 -> 1.14 ms, config 5 41.9 -> 44.3 ms).  What works for the stores is the scalar branch INSIDE one
     // opaque block per store, buf_st_gated below: no control flow for the compiler, padded z pass 1.21 -> 1.14 ms.)
     uint32_t gin = 0xffffffffu;
-    if (BOXED && !AXIS0 && GROUP_SKIP && WMODE == 0 && !HALF_IN && HALF != 4) {
+    if (BOXED && !AXIS0 && WMODE == 0 && !HALF_IN && HALF != 4) {
         gin = 0;
 #pragma unroll
         for (int l = 0; l < 64; l += W) gin |= (uint32_t)__builtin_amdgcn_readlane((int)ibits, l);
     }
     // the same for the stores of unweighted passes with a run-time output box -- as ONE opaque block per store (buf_st_gated)
-    constexpr bool GATE_ST = IG_FFT_GATE_STORES && GROUP_SKIP && BOXED && !AXIS0 && WMODE == 0 && !HALF_OUT && HALF != 3;
+    constexpr bool GATE_ST = BOXED && !AXIS0 && WMODE == 0 && !HALF_OUT && HALF != 3;
     uint32_t gout = 0xffffffffu;
     if (GATE_ST) {
         gout = 0;
@@ -507,7 +494,7 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
             const bool stat = !BOXED || HALF_IN || HALF == 4;                 // box known at compile time
             // off = all ones (out of range) where the element is not wanted: one bit-field extract + one or
             const unsigned off = stat ? 0u : (unsigned)__builtin_amdgcn_sbfe((int)~ibits, k, 1);
-            if (!stat && !AXIS0 && GROUP_SKIP && WMODE == 0 && !((gin >> k) & 1u)) { v[k] = mk(0.f, 0.f); continue; }
+            if (!stat && !AXIS0 && WMODE == 0 && !((gin >> k) & 1u)) { v[k] = mk(0.f, 0.f); continue; }
             if (AXIS0) {
                 v[k] = from2(buf_ld<NT_LD>(r_in, l_in | off, (unsigned)(k * R2) * 8u));
                 if (WMODE == 1) wv[k] = from2(buf_ld<false>(r_w, l_w | off, (unsigned)(k * R2) * 8u));
@@ -599,24 +586,11 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
 // LDS in four 32 KB rounds (launch A: twice across waves and once inside each wave; launch B: once).  All LDS address
 // maps below are conflict-free (one lane per 8-byte slot modulo 64); tools/fft2pass_model.py is a thread-level numpy
 // model of exactly these maps, checked against numpy.fft.fftn.
-#ifndef IG_F3B_NT_LD
-#define IG_F3B_NT_LD false    // (launch B without the streaming hint on either side: 1.746 against 1.788 ms per 256^3 x 16 transform)
-#endif
-#ifndef IG_F3B_NT_ST
-#define IG_F3B_NT_ST false
-#endif
-#ifndef IG_F3B_XCD
-#define IG_F3B_XCD 1
-#endif
-#ifndef IG_F3A_XCD
-#define IG_F3A_XCD 1
-#endif
-#ifndef IG_F3A_NT_LD
-#define IG_F3A_NT_LD true
-#endif
-#ifndef IG_F3_NT_ST
-#define IG_F3_NT_ST false     // launch A stores 16-byte pieces (two instructions per 128-byte line): no streaming hint on partial lines
-#endif
+// Streaming hints of the two launches, as measured: launch A loads with the hint, stores WITHOUT it -- it stores 16-byte pieces,
+// two instructions per 128-byte line, and a streaming hint on partial-line stores is ruinous (1.48 against 0.78 ms) --, launch B
+// uses none (1.746 against 1.788 ms per 256^3 x 16 transform with them).  The blocks of both launches are renumbered so that every
+// XCD walks a contiguous range.
+constexpr bool F3A_NT_LD = true, F3A_NT_ST = false, F3B_NT_LD = false, F3B_NT_ST = false;
 constexpr int F3_LDS_ELEMS = 64 * 72;            // largest exchange image (launch A, second exchange)
 
 __device__ __forceinline__ void wave_sync() {
@@ -631,17 +605,12 @@ k_fft3d_a(const float2* __restrict__ in, float2* __restrict__ out, const float2*
     float2* __restrict__ tws = lds + F3_LDS_ELEMS;
     const int tid = threadIdx.x;
     for (int k = tid; k < 256; k += 512) tws[k] = tw[k];
-#if IG_F3A_XCD
     // each XCD walks a contiguous range of (n2, z, volume) triples: the four n2 workgroups of a plane -- interleaved 2 KB lines
     // of the same 512 KB -- run behind one L2 at about the same time
     const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), tot = gridDim.x * gridDim.y * gridDim.z;
     const unsigned logical = (lin & 7u) * (tot >> 3) + (lin >> 3);            // (tot is a multiple of 8: 256 * 4 * batch)
     const int n2 = (int)(logical & 3u), z = (int)((logical >> 2) & 255u);
     const int64_t base = ((int64_t)(logical >> 10) << 24) + ((int64_t)z << 16);
-#else
-    const int z = blockIdx.x, n2 = blockIdx.y;
-    const int64_t base = ((int64_t)blockIdx.z << 24) + ((int64_t)z << 16);
-#endif
     const int xl = tid & 63, a = tid >> 6;
     const bool inv = inverse != 0;
 
@@ -656,7 +625,7 @@ k_fft3d_a(const float2* __restrict__ in, float2* __restrict__ out, const float2*
         for (int b = 0; b < 8; ++b)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                v[j][b] = from2(buf_ld<IG_F3A_NT_LD>(r_in, (unsigned)xl * 8u, (unsigned)(64 * j + 8192 * b) * 8u));
+                v[j][b] = from2(buf_ld<F3A_NT_LD>(r_in, (unsigned)xl * 8u, (unsigned)(64 * j + 8192 * b) * 8u));
                 if (inv) v[j][b] = cconj(v[j][b]);
             }
     }
@@ -760,7 +729,7 @@ k_fft3d_a(const float2* __restrict__ in, float2* __restrict__ out, const float2*
             // the displacement goes into the instruction's immediate offset (lane offset + constant), NOT into the scalar
             // offset operand: a 16-byte buffer store with a scalar-register offset whose data registers are overwritten by the
             // next VALU instruction stored stale upper lanes on gfx950 (the compiler only pads that hazard for immediate offsets)
-            buf_st_f4<IG_F3_NT_ST>(r_out, l_out + (unsigned)(32 * kc + 2 * h) * 8u, make_float4(e0.v.x, e0.v.y, e1.v.x, e1.v.y));
+            buf_st_f4<F3A_NT_ST>(r_out, l_out + (unsigned)(32 * kc + 2 * h) * 8u, make_float4(e0.v.x, e0.v.y, e1.v.x, e1.v.y));
         }
     }
 }
@@ -771,17 +740,12 @@ k_fft3d_b(const float2* __restrict__ in, float2* __restrict__ out, const float2*
     float2* __restrict__ tws = lds + 2 * F3_LDS_ELEMS;
     const int tid = threadIdx.x;
     for (int k = tid; k < 256; k += 512) tws[k] = tw[k];
-#if IG_F3B_XCD
     // blocks are dealt round-robin to the 8 XCDs: give each XCD a contiguous range of (x tile, k1, volume) triples, so that the
     // sixteen x tiles of a row group -- adjacent 128-byte pieces of the same 2 KB rows -- run behind one L2 at about the same time
     const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), tot = gridDim.x * gridDim.y * gridDim.z;
     const unsigned logical = (lin & 7u) * (tot >> 3) + (lin >> 3);            // (tot is a multiple of 8: 16 * 64 * batch)
     const int xs = (int)(logical & 15u) * 16, k1 = (int)((logical >> 4) & 63u);
     const int64_t base = ((int64_t)(logical >> 10) << 24) + xs;
-#else
-    const int xs = blockIdx.x * 16, k1 = blockIdx.y;
-    const int64_t base = ((int64_t)blockIdx.z << 24) + xs;
-#endif
     // role 0: h = lane bit 0 picks the rows n2 = h, h + 2 (the other two live in the neighbouring lane); w = x; t = z mod 16
     const int h = tid & 1, w = (tid >> 1) & 15, t = tid >> 5;
     const bool inv = inverse != 0;
@@ -792,7 +756,7 @@ k_fft3d_b(const float2* __restrict__ in, float2* __restrict__ out, const float2*
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             // descriptor re-based per (k, m): a scalar add; the lane offset stays below 8.6 MB
-            v[m][k] = from2(buf_ld<IG_F3B_NT_LD>(make_rsrc(in + base + 256 * (k1 + 128 * m) + ((int64_t)(16 * k) << 16)), l_io, 0));
+            v[m][k] = from2(buf_ld<F3B_NT_LD>(make_rsrc(in + base + 256 * (k1 + 128 * m) + ((int64_t)(16 * k) << 16)), l_io, 0));
             if (inv) v[m][k] = cconj(v[m][k]);
         }
     __syncthreads();
@@ -841,7 +805,7 @@ k_fft3d_b(const float2* __restrict__ in, float2* __restrict__ out, const float2*
         for (int rr = 0; rr < 16; ++rr) {
             cx e = r[rr];
             if (inv) e = cconj(e);
-            buf_st<IG_F3B_NT_ST>(make_rsrc(ob + ((int64_t)(16 * rr) << 16)), l_st, 0, to2(e));
+            buf_st<F3B_NT_ST>(make_rsrc(ob + ((int64_t)(16 * rr) << 16)), l_st, 0, to2(e));
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -1003,7 +967,8 @@ struct ig_fft {
     bool two_launch = false;         // 256^3 volumes: k_fft3d_a + k_fft3d_b instead of three axis passes
     size_t inplace_workspace_bytes = 0;   // two-launch transform called in place: staging volumes in the CALLER's workspace (ig_fft_inplace_workspace)
     bool padded = false;
-    bool has_ab_axis = false;        // a zero-padded plan with an A x B axis (320 ... 640): no k-space support table
+    bool has_ab_axis = false;        // a zero-padded plan with an A x B axis (160 ... 640)
+    int zw_in = 16, zw_out = 16;     // words per entry of the k-space support table's bitmaps on the z axis (ig_fft_support_words)
     int layout = 0;                  // memory order of the grid: 0 = (x, y, z), 1 = (x, z, y)
     int support_tile = 16;           // kx points per entry of the k-space support table (layout 2: ig_fft_set_support_tile)
     int64_t box_lo[3] = {0, 0, 0}, box_dims[3] = {1, 1, 1};
@@ -1011,9 +976,15 @@ struct ig_fft {
 
 namespace {
 
-// ---- two-stage A x B passes (ig_fft_ab.h): the instantiated splits ------------------------------------------------
-#define IG_AB_LIST(X) X(10, 16, 1) X(12, 16, 1) X(14, 16, 1) X(15, 16, 1) X(15, 18, 1) X(16, 18, 1) X(16, 20, 1) X(18, 20, 2) X(16, 24, 2) X(14, 28, 2) X(20, 20, 2) \
-                      X(18, 24, 2) X(20, 24, 2) X(24, 24, 2) X(24, 25, 2) X(20, 32, 2) X(16, 32, 2) X(16, 16, 1)
+// ---- two-stage A x B passes (ig_fft_ab.h): the instantiated splits (ig_fft_ab_list.h, generated by tools/gen_ab_list.py; the
+// kernels themselves are compiled in four side translation units, ig_fft_abd0..3.hip) -------------------------------------------
+}  // namespace
+#define IG_ABD_DECL(K_)                                                                                                              \
+    int ig_ab_launch_part##K_(hipStream_t, int64_t, bool, dim3, dim3, size_t, const float2*, float2*, const float2*, int64_t, int64_t, int); \
+    int ig_abd_launch_part##K_(hipStream_t, int64_t, int, dim3, dim3, const PassDesc&, const float2*);
+IG_ABD_DECL(0) IG_ABD_DECL(1) IG_ABD_DECL(2) IG_ABD_DECL(3)
+#undef IG_ABD_DECL
+namespace {
 bool ab_split(int64_t n, int& A, int& B) {
 #define IG_AB_CASE(A_, B_, R_) if (n == (A_) * (B_)) { A = A_; B = B_; return true; }
     IG_AB_LIST(IG_AB_CASE)
@@ -1031,13 +1002,12 @@ int launch_ab(ig_ctx* ctx, const AxisPlan& ax, const float2* in, float2* out, in
     const int64_t blocks = (ncols + anyfft::AB_W - 1) / anyfft::AB_W;
     IG_REQUIRE(ctx, blocks <= 0x7fffffffLL, "ig_fft_exec: too many tiles");
     const dim3 grid((unsigned)blocks), block((unsigned)(anyfft::AB_W * ax.ab_B));
-#define IG_AB_CASE(A_, B_, R_)                                                                                              \
-    if (ax.n == (A_) * (B_)) {                                                                                              \
-        if (ax.inner == 1) hipLaunchKernelGGL((anyfft::k_fft_ab<A_, B_, R_, true>), grid, block, ax.lds_bytes, ctx->stream, in, out, ax.d_tw, ax.inner, ncols, inverse); \
-        else hipLaunchKernelGGL((anyfft::k_fft_ab<A_, B_, R_, false>), grid, block, ax.lds_bytes, ctx->stream, in, out, ax.d_tw, ax.inner, ncols, inverse);             \
-    } else
-    IG_AB_LIST(IG_AB_CASE) { return ig_fail(ctx, IG_ERR_UNSUPPORTED, "ig_fft_exec: no A x B kernel for n = %lld", (long long)ax.n); }
-#undef IG_AB_CASE
+    const bool ax0 = ax.inner == 1;
+    if (!(ig_ab_launch_part0(ctx->stream, ax.n, ax0, grid, block, ax.lds_bytes, in, out, ax.d_tw, ax.inner, ncols, inverse) ||
+          ig_ab_launch_part1(ctx->stream, ax.n, ax0, grid, block, ax.lds_bytes, in, out, ax.d_tw, ax.inner, ncols, inverse) ||
+          ig_ab_launch_part2(ctx->stream, ax.n, ax0, grid, block, ax.lds_bytes, in, out, ax.d_tw, ax.inner, ncols, inverse) ||
+          ig_ab_launch_part3(ctx->stream, ax.n, ax0, grid, block, ax.lds_bytes, in, out, ax.d_tw, ax.inner, ncols, inverse)))
+        return ig_fail(ctx, IG_ERR_UNSUPPORTED, "ig_fft_exec: no A x B kernel for n = %lld", (long long)ax.n);
     IG_LAUNCH_CHECK(ctx, "k_fft_ab");
     return IG_OK;
 }
@@ -1121,6 +1091,7 @@ int plan_axis(ig_ctx* ctx, ig_fft* p, int a) {
 int launch_2stage(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d_in, bool axis0, int wmode) {
     PassDesc d = d_in;
     if (d.ncols == 0) return IG_OK;
+    IG_REQUIRE(ctx, !d.tile_bits || d.tile_words == 16 || d.tile_words == 0, "ig_fft: the two-stage kernel reads support bitmaps of 16 words per entry (got %d)", d.tile_words);
     const int64_t cpt = (!axis0 && d.cw) ? ax.W / d.cw : ax.W;           // columns (k0 values) per tile
     IG_REQUIRE(ctx, !d.cw || (!axis0 && d.cw <= ax.W && ax.W % d.cw == 0), "ig_fft: bad lane split");
     const int64_t tpr = (d.ext0 + cpt - 1) / cpt;
@@ -1215,7 +1186,6 @@ int launch_2stage(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d_in, bool ax
 }
 
 // ---- zero-pad-aware passes on A x B axes (k_fft_ab_desc): the lengths with a descriptor-driven instantiation -------------
-#define IG_ABD_LIST(X) X(10, 16, 1) X(12, 16, 1) X(15, 16, 1) X(16, 20, 1) X(16, 24, 2) X(20, 20, 2) X(18, 24, 2) X(20, 24, 2) X(20, 32, 2)   /* 160 192 240 320 384 400 432 480 640 */
 bool abd_supported(int64_t n) {
 #define IG_ABD_CASE(A_, B_, R_) if (n == (A_) * (B_)) return true;
     IG_ABD_LIST(IG_ABD_CASE)
@@ -1225,8 +1195,9 @@ bool abd_supported(int64_t n) {
 int launch_ab_desc(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d_in, int wmode) {
     PassDesc d = d_in;
     if (d.ncols == 0) return IG_OK;
-    IG_REQUIRE(ctx, !d.tile_range && !d.tile_bits && !d.k1_range, "ig_fft: the k-space support table needs 256- or 512-point axes");
     IG_REQUIRE(ctx, !d.cw || (d.cw <= anyfft::AB_W && anyfft::AB_W % d.cw == 0), "ig_fft: bad lane split");
+    IG_REQUIRE(ctx, !d.tile_bits || d.tile_words == (d.tile_range_mode == 1 ? ax.ab_A : ax.ab_B), "ig_fft: the support bitmap has %d words per entry, this pass needs %d",
+               d.tile_words, d.tile_range_mode == 1 ? ax.ab_A : ax.ab_B);
     const int64_t cpt = d.cw ? anyfft::AB_W / d.cw : anyfft::AB_W;
     const int64_t tpr = (d.ext0 + cpt - 1) / cpt;
     const int64_t blocks = tpr * (d.ncols / d.ext0);
@@ -1245,16 +1216,9 @@ int launch_ab_desc(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d_in, int wm
         wm = d.cw == 2 ? 4 : d.cw == 4 ? 5 : d.cw == 8 ? 6 : 7;
     }
     const dim3 grid((unsigned)blocks), block((unsigned)(anyfft::AB_W * ax.ab_B));
-#define IG_ABD_WM(A_, B_, R_, WM_) hipLaunchKernelGGL((anyfft::k_fft_ab_desc<A_, B_, R_, WM_>), grid, block, (anyfft::ab_lds_bytes<A_, B_, R_, false>()), ctx->stream, d, ax.d_tw)
-#define IG_ABD_CASE(A_, B_, R_)                                                                             \
-    if (ax.n == (A_) * (B_)) {                                                                              \
-        switch (wm) { case 0: IG_ABD_WM(A_, B_, R_, 0); break; case 1: IG_ABD_WM(A_, B_, R_, 1); break; case 2: IG_ABD_WM(A_, B_, R_, 2); break; \
-                      case 4: IG_ABD_WM(A_, B_, R_, 4); break; case 5: IG_ABD_WM(A_, B_, R_, 5); break; case 6: IG_ABD_WM(A_, B_, R_, 6); break; \
-                      default: IG_ABD_WM(A_, B_, R_, 7); break; }                                           \
-    } else
-    IG_ABD_LIST(IG_ABD_CASE) { return ig_fail(ctx, IG_ERR_UNSUPPORTED, "ig_fft: no zero-pad-aware kernel for n = %lld", (long long)ax.n); }
-#undef IG_ABD_CASE
-#undef IG_ABD_WM
+    if (!(ig_abd_launch_part0(ctx->stream, ax.n, wm, grid, block, d, ax.d_tw) || ig_abd_launch_part1(ctx->stream, ax.n, wm, grid, block, d, ax.d_tw) ||
+          ig_abd_launch_part2(ctx->stream, ax.n, wm, grid, block, d, ax.d_tw) || ig_abd_launch_part3(ctx->stream, ax.n, wm, grid, block, d, ax.d_tw)))
+        return ig_fail(ctx, IG_ERR_UNSUPPORTED, "ig_fft: no zero-pad-aware kernel for n = %lld", (long long)ax.n);
     IG_LAUNCH_CHECK(ctx, "k_fft_ab_desc");
     return IG_OK;
 }
@@ -1463,9 +1427,11 @@ int ig_fft_plan_padded(ig_ctx* ctx, const int64_t* dims, const int64_t* box_lo, 
             *plan = nullptr;
             return ig_fail(ctx, IG_ERR_UNSUPPORTED,
                            "ig_fft_plan_padded: grid axis %d has length %lld; the padded path needs 256 or 512 -- or, with 2, 4, 8 or 16 "
-                           "coil-interleaved batch members (grid_layout 2), 160, 192, 240, 320, 384, 400, 432, 480 or 640", a, (long long)dims[a]);
+                           "coil-interleaved batch members (grid_layout 2), any length from 128 to 640 with factors 2, 3, 5, 7 only that "
+                           "splits as A x B with A, B <= 32", a, (long long)dims[a]);
         }
         if (ab_ok) p->has_ab_axis = true;
+        if (a == 2) { p->zw_in = ab_ok ? p->axis[a].ab_B : 16; p->zw_out = ab_ok ? p->axis[a].ab_A : 16; }
         p->box_lo[a] = box_lo[a];
         p->box_dims[a] = box_dims[a];
     }
@@ -1523,7 +1489,7 @@ static int exec_padded_layout1(ig_fft* p, const float2* x, int64_t x_bstride, co
         d.ext0 = n0; d.ext1 = n1; d.ncols = n0 * n1 * C;
         d.in_lo = (int)l2; d.in_hi = (int)(l2 + b2); d.out_lo = 0; d.out_hi = (int)n2; d.inverse = 0;
         d.tile_range = support; d.tile_range_mode = 1; d.tile_range_k1 = n0 / 16;   // only the support is ever gridded from
-        if (support) d.tile_bits = reinterpret_cast<const uint32_t*>(support + n1 * (n0 / 16) + n0 / 16);
+        if (support) { d.tile_bits = reinterpret_cast<const uint32_t*>(support + n1 * (n0 / 16) + n0 / 16); d.tile_words = 16; }
         if (int rc = launch_2stage(ctx, p->axis[2], d, false, 0)) return rc;
     }
     return IG_OK;
@@ -1549,7 +1515,7 @@ static int exec_cropped_layout1(ig_fft* p, const float2* y, const float2* w, flo
         d.ext0 = n0; d.ext1 = n1; d.ncols = n0 * n1 * C;
         d.in_lo = 0; d.in_hi = (int)n2; d.out_lo = (int)l2; d.out_hi = (int)(l2 + b2); d.inverse = 1;
         d.tile_range = support; d.tile_range_mode = 2; d.tile_range_k1 = n0 / 16;   // the adjoint gridding only wrote the support
-        if (support) d.tile_bits = reinterpret_cast<const uint32_t*>(support + n1 * (n0 / 16) + n0 / 16);
+        if (support) { d.tile_bits = reinterpret_cast<const uint32_t*>(support + n1 * (n0 / 16) + n0 / 16); d.tile_words = 16; }
         if (support) d.k1_range = support + n1 * (n0 / 16);                         // ky the y pass will never read
         if (int rc = launch_2stage(ctx, p->axis[2], d, false, 0)) return rc;
     }
@@ -1628,7 +1594,10 @@ static int exec_padded_layout2(ig_fft* p, const float2* x, int64_t x_bstride, co
         d.ext0 = C * n0; d.ext1 = n1; d.ncols = C * n0 * n1;
         d.in_lo = (int)l2; d.in_hi = (int)(l2 + b2); d.out_lo = 0; d.out_hi = (int)n2; d.inverse = 0;
         d.tile_range = support; d.tile_range_mode = 1; d.tile_range_k1 = snt; d.tile_shift = sshift;
-        if (support) d.tile_bits = reinterpret_cast<const uint32_t*>(support + n1 * snt + snt);
+        if (support) {      // the output-side form of the bitmaps (it follows the input-side form where the two differ)
+            d.tile_bits = reinterpret_cast<const uint32_t*>(support + n1 * snt + snt) + (p->zw_out != p->zw_in ? n1 * snt * p->zw_in : 0);
+            d.tile_words = p->zw_out;
+        }
         if (int rc = launch_pass(ctx, p->axis[2], d, false, 0)) return rc;
     }
     return IG_OK;
@@ -1656,7 +1625,7 @@ static int exec_cropped_layout2(ig_fft* p, const float2* y, const float2* w, flo
         d.ext0 = C * n0; d.ext1 = n1; d.ncols = C * n0 * n1;
         d.in_lo = 0; d.in_hi = (int)n2; d.out_lo = (int)l2; d.out_hi = (int)(l2 + b2); d.inverse = 1;
         d.tile_range = support; d.tile_range_mode = 2; d.tile_range_k1 = snt; d.tile_shift = sshift;
-        if (support) d.tile_bits = reinterpret_cast<const uint32_t*>(support + n1 * snt + snt);
+        if (support) { d.tile_bits = reinterpret_cast<const uint32_t*>(support + n1 * snt + snt); d.tile_words = p->zw_in; }
         if (support) d.k1_range = support + n1 * snt;                         // ky the y pass will never read
         if (int rc = launch_pass(ctx, p->axis[2], d, false, 0)) return rc;
     }
@@ -1696,10 +1665,18 @@ static int exec_cropped_layout2(ig_fft* p, const float2* y, const float2* w, flo
     return IG_OK;
 }
 
+int ig_fft_support_words(int64_t n, int* zw_in, int* zw_out) {
+    if (!zw_in || !zw_out) return ig_fail(nullptr, IG_ERR_ARG, "ig_fft_support_words: bad arguments");
+    int A = 0, B = 0;
+    if (n == 256 || n == 512) { *zw_in = *zw_out = 16; return IG_OK; }
+    if (abd_supported(n) && ab_split(n, A, B)) { *zw_in = B; *zw_out = A; return IG_OK; }
+    return ig_fail(nullptr, IG_ERR_UNSUPPORTED, "ig_fft_support_words: no zero-pad-aware z pass for an axis of %lld points", (long long)n);
+}
+
 int ig_fft_set_support_tile(ig_fft* p, int tile) {
     if (!p) return ig_fail(nullptr, IG_ERR_ARG, "ig_fft_set_support_tile: plan is NULL");
     ig_ctx* ctx = p->ctx;
-    IG_REQUIRE(ctx, p->padded && p->layout == 2 && !p->has_ab_axis, "ig_fft_set_support_tile: a zero-padded plan of the coil-interleaved layout with 256- or 512-point axes");
+    IG_REQUIRE(ctx, p->padded && p->layout == 2, "ig_fft_set_support_tile: a zero-padded plan of the coil-interleaved layout");
     IG_REQUIRE(ctx, (tile == 2 || tile == 4 || tile == 8 || tile == 16) && p->batch * tile >= 16 && p->dims[0] % tile == 0,
                "ig_fft_set_support_tile: tile %d (2, 4, 8 or 16 kx points; coils * tile >= 16)", tile);
     p->support_tile = tile;
@@ -1713,7 +1690,6 @@ int ig_fft_exec_padded(ig_fft* p, const void* xv, int64_t x_bstride, const void*
     IG_REQUIRE(ctx, p->padded, "ig_fft_exec_padded: plan was not made by ig_fft_plan_padded");
     IG_REQUIRE(ctx, xv && yv, "ig_fft_exec_padded: NULL array");
     IG_REQUIRE(ctx, p->layout == 0 || workspace, "ig_fft_exec_padded: grid layouts 1 and 2 need the workspace");
-    IG_REQUIRE(ctx, !support || !p->has_ab_axis, "ig_fft_exec_padded: the k-space support table needs 256- or 512-point grid axes");
     if (int rc = ig_set_device(ctx)) return rc;
     IG_REQUIRE(ctx, !support || p->layout >= 1, "ig_fft_exec_padded: a support table needs grid layout 1 or 2");
     if (p->layout == 2)
@@ -1766,7 +1742,6 @@ int ig_fft_exec_cropped(ig_fft* p, const void* yv, const void* wv, void* xv, int
     ig_ctx* ctx = p->ctx;
     IG_REQUIRE(ctx, p->padded, "ig_fft_exec_cropped: plan was not made by ig_fft_plan_padded");
     IG_REQUIRE(ctx, xv && yv && workspace, "ig_fft_exec_cropped: NULL array");
-    IG_REQUIRE(ctx, !support || !p->has_ab_axis, "ig_fft_exec_cropped: the k-space support table needs 256- or 512-point grid axes");
     if (int rc = ig_set_device(ctx)) return rc;
     IG_REQUIRE(ctx, !support || p->layout >= 1, "ig_fft_exec_cropped: a support table needs grid layout 1 or 2");
     if (p->layout == 2)
@@ -1833,7 +1808,6 @@ int ig_fft_exec_cropped_sum(ig_fft* p, const void* yv, const void* wv, void* xv,
     ig_ctx* ctx = p->ctx;
     IG_REQUIRE(ctx, p->padded && p->layout == 2, "ig_fft_exec_cropped_sum: needs a plan of ig_fft_plan_padded with grid_layout 2");
     IG_REQUIRE(ctx, xv && yv && wv && workspace, "ig_fft_exec_cropped_sum: NULL array");
-    IG_REQUIRE(ctx, !support || !p->has_ab_axis, "ig_fft_exec_cropped_sum: the k-space support table needs 256- or 512-point grid axes");
     if (int rc = ig_set_device(ctx)) return rc;
     return exec_cropped_layout2(p, (const float2*)yv, (const float2*)wv, (float2*)xv, (float2*)workspace,
                                 (const short2*)support, true);
@@ -1848,7 +1822,6 @@ int ig_fft_exec_cropped_sum_slab(ig_fft* p, const void* yv, const void* wv, void
     IG_REQUIRE(ctx, phase == 0 || phase == 1, "ig_fft_exec_cropped_sum_slab: phase must be 0 (z pass) or 1 (y and x passes of a slab)");
     IG_REQUIRE(ctx, phase == 0 || (0 <= z0 && z0 <= z1 && z1 <= p->box_dims[2]),
                "ig_fft_exec_cropped_sum_slab: slab [%lld, %lld) outside the image's %lld planes", (long long)z0, (long long)z1, (long long)p->box_dims[2]);
-    IG_REQUIRE(ctx, !support || !p->has_ab_axis, "ig_fft_exec_cropped_sum_slab: the k-space support table needs 256- or 512-point grid axes");
     if (int rc = ig_set_device(ctx)) return rc;
     return exec_cropped_layout2(p, (const float2*)yv, (const float2*)wv, (float2*)xv, (float2*)workspace,
                                 (const short2*)support, true, phase == 0 ? 1 : 2, z0, z1);

@@ -45,9 +45,12 @@ struct PassDesc {
     const short2* tile_range;
     int tile_range_mode;
     int64_t tile_range_k1;      // table row stride per k1 (tiles per row), or 0 if the ranges do not depend on k1
-    // optional refinement of tile_range (same mode, same indexing, 16 words per tile): bit m of word t is set iff
-    // element j = t + 16*m of the tile's columns is needed (mode 1) / was ever written (mode 2)
+    // optional refinement of tile_range (same mode, same indexing, tile_words words per tile; 0 means 16): bit m of word t is
+    // set iff element j = t + tile_words*m of the tile's columns is needed (mode 1) / was ever written (mode 2).  The
+    // power-of-two kernel holds the elements t + 16 m on both sides; the A x B kernel b + B a on its input side and
+    // k1 + A k2 on its output side (tile_words = B in mode 2, A in mode 1: ig_grid_support writes both forms)
     const uint32_t* tile_bits;
+    int tile_words;
     // optional: tiles whose k1 lies outside k1_range[tile >> tile_shift] = [lo, hi) are skipped altogether (the
     // cropped z pass: the y pass that follows never reads ky outside the kx tile's ky hull)
     const short2* k1_range;
@@ -278,7 +281,9 @@ k_fft_ab(const float2* __restrict__ x, float2* __restrict__ y, const float2* __r
 // load instructions no lane of the wave wants are skipped by a scalar branch), WMODE 1 multiplies the inputs by the weights,
 // 2 the outputs by their conjugates, 3 + log2(cw) also sums the cw sub-columns (coils) of a column with DPP adds; `cw` splits
 // a tile's 16 lanes into 16 / cw columns x cw sub-columns (the x passes of the coil-interleaved layout).  Strided passes only
-// (every pass of that layout is one); no k-space support table (its 16 x 32-bit words index 512 rows).
+// (every pass of that layout is one).  The k-space support table narrows the boxes per tile exactly as in k_fft_2stage
+// (tile_range / k1_range: tiles outside the hulls leave at once; tile_bits: one word per thread and-ed into its element mask),
+// and unweighted passes skip the store instructions no lane of a wave wants by a scalar branch (buf_st_gated).
 template <int CTRL>
 __device__ __forceinline__ float ab_dpp(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
@@ -327,13 +332,41 @@ k_fft_ab_desc(PassDesc d, const float2* __restrict__ tw) {
     if (!valid) l_in = l_out = l_w = IG_OOB;
     if (!WMODE) l_w = IG_OOB;
     if (SUMW && (w % SUMW) != 0) l_out = IG_OOB;            // only a column's first sub-column stores the coil sum
+    // the tile's support records (three independent loads, all addressed by the tile index: requested together, tested afterwards)
+    int in_lo = d.in_lo, in_hi = d.in_hi, out_lo = d.out_lo, out_hi = d.out_hi;
+    uint32_t zb = 0xffffffffu;
+    {
+        short2 k1r = make_short2(0, 0x7fff), trg = make_short2(0, 0x7fff);
+        const int64_t tidx = (int64_t)k1i * d.tile_range_k1 + (tr >> d.tile_shift);
+        if (d.k1_range) k1r = d.k1_range[tr >> d.tile_shift];
+        if (d.tile_range) trg = d.tile_range[tidx];
+        if (d.tile_bits) { const int tw_ = d.tile_words ? d.tile_words : 16; zb = b < tw_ ? d.tile_bits[tidx * tw_ + b] : 0u; }
+        if (d.k1_range && ((int)k1i < k1r.x || (int)k1i >= k1r.y)) return;          // (wave- and workgroup-uniform: before any barrier)
+        if (d.tile_range) {
+            if (d.tile_range_mode == 1) {
+                out_lo = out_lo > trg.x ? out_lo : trg.x;
+                out_hi = out_hi < trg.y ? out_hi : trg.y;
+                if (out_hi <= out_lo) return;                                           // nothing of this tile is ever read
+            } else {
+                in_lo = in_lo > trg.x ? in_lo : trg.x;
+                in_hi = in_hi < trg.y ? in_hi : trg.y;
+            }
+        }
+    }
     // element j = b + B a <-> bit a of ibits (stage 1 loads); output k = b + A k2 <-> bit k2 of obits (stage 2 stores, b < A)
     auto below = [](int h) -> uint32_t { return h >= 32 ? 0xffffffffu : ((1u << h) - 1u); };
-    const uint32_t ibits = below(ab_ceil_div_clamp(d.in_hi - b, B, A)) & ~below(ab_ceil_div_clamp(d.in_lo - b, B, A));
-    const uint32_t obits = below(ab_ceil_div_clamp(d.out_hi - b, A, B)) & ~below(ab_ceil_div_clamp(d.out_lo - b, A, B));
+    uint32_t ibits = below(ab_ceil_div_clamp(in_hi - b, B, A)) & ~below(ab_ceil_div_clamp(in_lo - b, B, A));
+    uint32_t obits = below(ab_ceil_div_clamp(out_hi - b, A, B)) & ~below(ab_ceil_div_clamp(out_lo - b, A, B));
+    if (d.tile_bits) { if (d.tile_range_mode == 1) obits &= zb; else ibits &= zb; }
     uint32_t gin = 0;                                          // wave-uniform: elements SOME lane of this wave wants
 #pragma unroll
     for (int l = 0; l < 64; l += AB_W) gin |= (uint32_t)__builtin_amdgcn_readlane((int)ibits, l);
+    uint32_t gout = 0xffffffffu;                               // the same for the outputs (unweighted passes gate their stores with it)
+    if (WMODE == 0) {
+        gout = 0;
+#pragma unroll
+        for (int l = 0; l < 64; l += AB_W) gout |= (uint32_t)__builtin_amdgcn_readlane((int)obits, l);
+    }
 
     float2 v[A];
     {
@@ -389,7 +422,8 @@ k_fft_ab_desc(PassDesc d, const float2* __restrict__ tw) {
                 if (SUMW >= 8)  { e.x += ab_dpp<0x104>(e.x); e.y += ab_dpp<0x104>(e.y); }     // row_shl:4
                 if (SUMW >= 16) { e.x += ab_dpp<0x108>(e.x); e.y += ab_dpp<0x108>(e.y); }     // row_shl:8
                 const unsigned off = (unsigned)__builtin_amdgcn_sbfe((int)~obits, k2, 1);
-                buf_st<true>(make_rsrc(b_out + (int64_t)(A * k2) * d.out_sj), l_out | off, 0, e);
+                if (WMODE == 0) buf_st_gated<true>(make_rsrc_words(b_out + (int64_t)(A * k2) * d.out_sj), l_out | off, e, (gout >> k2) & 1u);
+                else buf_st<true>(make_rsrc(b_out + (int64_t)(A * k2) * d.out_sj), l_out | off, 0, e);
             }
         }
     }

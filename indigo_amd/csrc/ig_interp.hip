@@ -191,17 +191,23 @@ int ig_interp3_fill_modulated(int64_t m, const int64_t* N, double width, const d
 
 // k-space support table of a gridding matrix whose columns number an n0 x n2 x n1 grid as kx + n0*(kz + n2*ky) (grid layouts
 // 1 and 2 of the fused transform): one pass over the column indices sets the segment bits, the hulls follow from the bits.
-// Layout of `table` (int16): [z_lo, z_hi) per (ky, kx tile), [y_lo, y_hi) per kx tile, then 16 uint32 words per (ky, kx tile)
-// -- bit m of word t is set iff segment (kx tile, ky, kz = t + 16 m) holds a nonzero.  (indigo_amd/fused.py:grid_support.)
-int ig_grid_support(int64_t nnz, const int32_t* colind, int64_t n0, int64_t n1, int64_t n2, int tile, int16_t* table) {
-    if (nnz < 0 || (nnz > 0 && !colind) || !table || n0 < 1 || n1 < 1 || n2 < 1 || n2 > 512 || n2 % 16 || tile < 1 || n0 % tile)
-        return ig_fail(nullptr, IG_ERR_ARG, "ig_grid_support: bad arguments (n2 a multiple of 16, at most 512; tile divides n0)");
+// Layout of `table` (int16): [z_lo, z_hi) per (ky, kx tile), [y_lo, y_hi) per kx tile, then the segment bitmaps: zw_in uint32
+// words per (ky, kx tile) -- bit kz / zw_in of word kz % zw_in is set iff segment (kx tile, ky, kz) holds a nonzero -- and, if
+// zw_out differs, the same bits once more with zw_out words per entry.  The two forms are what the z pass of the transform
+// wants on its input side (cropped transform: thread b of zw_in holds rows b + zw_in a) and on its output side (padded
+// transform: thread k1 of zw_out stores rows k1 + zw_out k2): ig_fft_support_words gives both for a grid axis; 16 / 16 for the
+// 256- and 512-point axes, where the table is round 1's.  (indigo_amd/fused.py:grid_support.)
+int ig_grid_support(int64_t nnz, const int32_t* colind, int64_t n0, int64_t n1, int64_t n2, int tile, int zw_in, int zw_out, int16_t* table) {
+    if (nnz < 0 || (nnz > 0 && !colind) || !table || n0 < 1 || n1 < 1 || n2 < 1 || tile < 1 || n0 % tile || zw_in < 1 || zw_out < 1 ||
+        zw_in > 64 || zw_out > 64 || n2 > 32 * (int64_t)zw_in || n2 > 32 * (int64_t)zw_out || n2 > 32767 || n1 > 32767)
+        return ig_fail(nullptr, IG_ERR_ARG, "ig_grid_support: bad arguments (tile divides n0; n2 <= 32 * words per entry)");
     const int64_t nt = n0 / tile, ne = n1 * nt;
     int16_t* zr = table;
     int16_t* yr = table + 2 * ne;
     uint32_t* bits = reinterpret_cast<uint32_t*>(table + 2 * (ne + nt));
+    uint32_t* bits_out = zw_out != zw_in ? bits + ne * zw_in : nullptr;
     std::fill(table, table + 2 * (ne + nt), (int16_t)0);
-    std::fill(bits, bits + ne * 16, 0u);
+    std::fill(bits, bits + ne * zw_in + (bits_out ? ne * zw_out : 0), 0u);
     std::atomic<int> bad{0};        // set from several host threads
     parallel_rows(nnz, [&](int64_t lo, int64_t hi) {
         int32_t last = -1;
@@ -211,21 +217,24 @@ int ig_grid_support(int64_t nnz, const int32_t* colind, int64_t n0, int64_t n1, 
             last = col;
             const int64_t kx = col % n0, kz = (col / n0) % n2, ky = col / (n0 * n2);
             if (col < 0 || ky >= n1) { bad = 1; continue; }
-            uint32_t* w = bits + (ky * nt + kx / tile) * 16 + (kz & 15);
-            const uint32_t m = 1u << (kz >> 4);
-            if (!(__atomic_load_n(w, __ATOMIC_RELAXED) & m)) __atomic_fetch_or(w, m, __ATOMIC_RELAXED);
+            uint32_t* w = bits + (ky * nt + kx / tile) * zw_in + (kz % zw_in);
+            const uint32_t m = 1u << (kz / zw_in);
+            if (!(__atomic_load_n(w, __ATOMIC_RELAXED) & m)) {
+                __atomic_fetch_or(w, m, __ATOMIC_RELAXED);
+                if (bits_out) __atomic_fetch_or(bits_out + (ky * nt + kx / tile) * zw_out + (kz % zw_out), 1u << (kz / zw_out), __ATOMIC_RELAXED);
+            }
         }
     });
     if (bad) return ig_fail(nullptr, IG_ERR_ARG, "ig_grid_support: column index outside the grid");
     parallel_rows(ne, [&](int64_t lo, int64_t hi) {
         for (int64_t e = lo; e < hi; ++e) {
             int zlo = 1 << 30, zhi = -1;
-            for (int t = 0; t < 16; ++t) {
-                const uint32_t w = bits[e * 16 + t];
+            for (int t = 0; t < zw_in; ++t) {
+                const uint32_t w = bits[e * zw_in + t];
                 if (!w) continue;
                 const int first = __builtin_ctz(w), lastb = 31 - __builtin_clz(w);
-                zlo = std::min(zlo, t + 16 * first);
-                zhi = std::max(zhi, t + 16 * lastb);
+                zlo = std::min(zlo, t + zw_in * first);
+                zhi = std::max(zhi, t + zw_in * lastb);
             }
             if (zhi >= 0) { zr[2 * e] = (int16_t)zlo; zr[2 * e + 1] = (int16_t)(zhi + 1); }
         }

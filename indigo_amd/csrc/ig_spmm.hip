@@ -40,9 +40,6 @@ namespace {
 
 constexpr int BLK = 256;
 constexpr int WAVES_PER_BLOCK = BLK / 64;
-#ifndef IG_DENSE_MINWAVES
-#define IG_DENSE_MINWAVES 1
-#endif
 
 // Blocks are dealt round-robin to the 8 XCDs (each with a private L2).  Give
 // each XCD a contiguous range of row blocks so neighbouring rows -- which in
@@ -548,7 +545,7 @@ k_csrmm_rowlane(int64_t M, int64_t N,
 // row's lane sums its own run of products (LDS reads, no atomics) and stores as before, 512 contiguous bytes per
 // panel column.  Rows beyond thr_mid go to the deferred-row lists and are skipped here.
 template <int NC, bool CONJ, bool YIL>
-__global__ void __launch_bounds__(BLK, IG_DENSE_MINWAVES)     // (74 VGPRs, 6 waves/SIMD.  Measured: a 72-VGPR cap for 7 waves is 4 % SLOWER
+__global__ void __launch_bounds__(BLK, 1)     // (74 VGPRs, 6 waves/SIMD.  Measured: a 72-VGPR cap for 7 waves is 4 % SLOWER
                                                               // (1.68 vs 1.61 ms), a 64-VGPR cap for 8 waves spills and takes 2.69 ms: not occupancy bound)
 k_csrmm_dense64(int64_t M, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
                 const float2* __restrict__ vals, const float2* __restrict__ Xp,
@@ -1058,7 +1055,7 @@ k_grid_bricks(const BrickTask* __restrict__ tasks, int ntasks, const BrickRef* _
               const BrickEntry* __restrict__ entries, const uint32_t* __restrict__ round_rows,
               const float2* __restrict__ Xp /* packed rows: [t][NC] */,
               float2* __restrict__ Y, float2 alpha, const uint32_t* __restrict__ bits,
-              int n0, int nm, int bm_log2, int bs_log2, int nbx, int nbm, int st_log2 /* log2(cells per segment) */) {
+              int n0, int nm, int bm_log2, int bs_log2, int nbx, int nbm, int st_log2 /* log2(cells per segment) */, int zw /* words per entry of the support bitmaps */) {
     extern __shared__ float2 acc_all[];                  // per wave: [cells][NC]
     constexpr int TPR = 64 / NC;                         // entries per round (one wave instruction of the accumulation)
     constexpr int RS = 64 / TPR;                         // rounds per super-trip
@@ -1127,7 +1124,8 @@ k_grid_bricks(const BrickTask* __restrict__ tasks, int ntasks, const BrickRef* _
             const int jbx = __shfl(my_bx, j & 63), jm0 = __shfl(my_m0, j & 63), js0 = __shfl(my_s0, j & 63);
             const int xs = seg & ((1 << xs_log2) - 1), im = (seg >> xs_log2) & (BM - 1), is = seg >> (xs_log2 + bm_log2);
             const int km = jm0 + im, ks = js0 + is;
-            w[p] = (uint32_t)buf_ld_i32(r_bits, j < nb ? (unsigned)((ks * nt + (jbx << xs_log2) + xs) * 16 + (km & 15)) * 4u : IG_OOB) >> (km >> 4);
+            const int kmq = km / zw, kmr = km - kmq * zw;            // bit km / zw of word km % zw
+            w[p] = (uint32_t)buf_ld_i32(r_bits, j < nb ? (unsigned)((ks * nt + (jbx << xs_log2) + xs) * zw + kmr) * 4u : IG_OOB) >> kmq;
         }
         my_mask = 0u;
 #pragma unroll
@@ -1233,7 +1231,7 @@ __global__ void __launch_bounds__(BLK)
 k_grid_slots(const BrickTask* __restrict__ tasks, int ntasks, const BrickRef* __restrict__ btab,
              const int32_t* __restrict__ slot_ptr, const SlotEntry* __restrict__ entries,
              const float2* __restrict__ Xp /* packed rows: [t][NC] */, float2* __restrict__ Y, float2 alpha,
-             const uint32_t* __restrict__ bits, int n0, int nm, int bm_log2, int bs_log2, int nbx, int nbm, int st_log2) {
+             const uint32_t* __restrict__ bits, int n0, int nm, int bm_log2, int bs_log2, int nbx, int nbm, int st_log2, int zw /* words per entry of the support bitmaps */) {
     extern __shared__ float2 acc_all[];                  // per wave: [cells][NC]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1268,7 +1266,8 @@ k_grid_slots(const BrickTask* __restrict__ tasks, int ntasks, const BrickRef* __
             const int jbx = __shfl(my_bx, j & 63), jm0 = __shfl(my_m0, j & 63), js0 = __shfl(my_s0, j & 63);
             const int xs = seg & ((1 << xs_log2) - 1), im = (seg >> xs_log2) & (BM - 1), is = seg >> (xs_log2 + bm_log2);
             const int km = jm0 + im, ks = js0 + is;
-            w[p] = (uint32_t)buf_ld_i32(r_bits, j < nb ? (unsigned)((ks * nt + (jbx << xs_log2) + xs) * 16 + (km & 15)) * 4u : IG_OOB) >> (km >> 4);
+            const int kmq = km / zw, kmr = km - kmq * zw;            // bit km / zw of word km % zw
+            w[p] = (uint32_t)buf_ld_i32(r_bits, j < nb ? (unsigned)((ks * nt + (jbx << xs_log2) + xs) * zw + kmr) * 4u : IG_OOB) >> kmq;
         }
         my_mask = 0u;
 #pragma unroll
@@ -1713,7 +1712,7 @@ k_wide_zero_unowned(const uint32_t* __restrict__ owned, float2* __restrict__ Y, 
 template <int NC>
 __global__ void __launch_bounds__(BLK)
 k_grid_bricks_zero(const int32_t* __restrict__ shared_bricks, float2* __restrict__ Y, const uint32_t* __restrict__ bits,
-                   int n0, int nm, int bm_log2, int bs_log2, int nbx, int nbm, int st_log2) {
+                   int n0, int nm, int bm_log2, int bs_log2, int nbx, int nbm, int st_log2, int zw) {
     const int brick = shared_bricks[blockIdx.x];
     const int xs_log2 = 4 - st_log2;
     const int BM = 1 << bm_log2, nseg = 1 << (xs_log2 + bm_log2 + bs_log2);
@@ -1723,7 +1722,7 @@ k_grid_bricks_zero(const int32_t* __restrict__ shared_bricks, float2* __restrict
     for (int seg = wv; seg < nseg; seg += WAVES_PER_BLOCK) {
         const int xs = seg & ((1 << xs_log2) - 1), im = (seg >> xs_log2) & (BM - 1), is = seg >> (xs_log2 + bm_log2);
         const int km = m0 + im, ks = s0 + is;
-        if (bits && !((bits[((size_t)ks * nt + (bx << xs_log2) + xs) * 16 + (km & 15)] >> (km >> 4)) & 1u)) continue;
+        if (bits && !((bits[((size_t)ks * nt + (bx << xs_log2) + xs) * zw + (km % zw)] >> (km / zw)) & 1u)) continue;
         float2* dst = Y + ((int64_t)x0 + (xs << st_log2) + (int64_t)n0 * (km + (int64_t)nm * ks)) * NC;
         for (int e = lane; e < (NC << st_log2); e += 64) dst[e] = make_float2(0.f, 0.f);
     }
@@ -2349,15 +2348,16 @@ int ig_grid_bricks_fill(int64_t M, const int32_t* rowptr, const int32_t* colind,
 int ig_ccsrmm_t_bricks(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, float ar, float ai,
                        const void* entries, const uint32_t* round_rows, const void* X, int64_t ldx, void* Y_il, const int16_t* support, int64_t n0, int64_t nm,
                        int bm, int bs, const int32_t* tasks, int64_t ntasks, const int32_t* brick_table,
-                       const int32_t* shared_bricks, int64_t nshared, int support_tile) {
+                       const int32_t* shared_bricks, int64_t nshared, int support_tile, int support_zwords) {
     IG_REQUIRE(ctx, ctx != nullptr, "ig_ccsrmm_t_bricks: ctx is NULL");
+    const int zw = support_zwords > 0 ? support_zwords : 16;
     IG_REQUIRE(ctx, M >= 0 && K >= 0 && M <= 0x7fffffffLL, "ig_ccsrmm_t_bricks: bad dimensions");
     IG_REQUIRE(ctx, N == 4 || N == 8, "ig_ccsrmm_t_bricks: 4 or 8 columns (got %lld); entries must be padded to 64/N per row and brick", (long long)N);
     IG_REQUIRE(ctx, (ntasks == 0 || (entries && round_rows)) && (M == 0 || X) && (K == 0 || Y_il) && ldx >= M, "ig_ccsrmm_t_bricks: NULL array or short leading dimension");
     IG_REQUIRE(ctx, n0 > 0 && nm > 0 && K % (n0 * nm) == 0 && K < 0x7fffffffLL && bricks_ok(n0, nm, K / (n0 * nm), bm, bs, 8) && bm * bs <= 32,
                "ig_ccsrmm_t_bricks: rows (%lld) are not a grid of n0=%lld x nm=%lld x ... that divides into 16 x %d x %d bricks", (long long)K, (long long)n0, (long long)nm, bm, bs);
     const int64_t ns = K / (n0 * nm);
-    IG_REQUIRE(ctx, !support || (nm % 16 == 0 && nm <= 512), "ig_ccsrmm_t_bricks: the support table needs nm %% 16 == 0 and nm <= 512");
+    IG_REQUIRE(ctx, !support || (zw <= 64 && nm <= 32 * (int64_t)zw), "ig_ccsrmm_t_bricks: the support bitmaps hold 32 bits in each of %d words: nm <= %d", zw, 32 * zw);
     IG_REQUIRE(ctx, support_tile == 16 || support_tile == 8 || support_tile == 4, "ig_ccsrmm_t_bricks: support_tile %d (kx points per entry of the support table: 16, 8 or 4)", support_tile);
     IG_REQUIRE(ctx, (16 / support_tile) * bm * bs <= 32, "ig_ccsrmm_t_bricks: at most 32 segments per brick (%d x %d x %d)", 16 / support_tile, bm, bs);
     const int st_log2 = support_tile == 16 ? 4 : support_tile == 8 ? 3 : 2;
@@ -2396,10 +2396,10 @@ int ig_ccsrmm_t_bricks(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, float ar, f
 #define IG_BRICKS(NC_, NSEG_) do {                                                                                            \
         if (nshared) {                                                                                                          \
             ig_prof_scope prof(ctx, "grid_bricks_zero");                                                                        \
-            hipLaunchKernelGGL((k_grid_bricks_zero<NC_>), dim3((unsigned)nshared), dim3(BLK), 0, ctx->stream, shared_bricks, (float2*)Y_il, bits, (int)n0, (int)nm, bm_log2, bs_log2, nbx, nbm, st_log2); } \
+            hipLaunchKernelGGL((k_grid_bricks_zero<NC_>), dim3((unsigned)nshared), dim3(BLK), 0, ctx->stream, shared_bricks, (float2*)Y_il, bits, (int)n0, (int)nm, bm_log2, bs_log2, nbx, nbm, st_log2, zw); } \
         ig_prof_scope prof(ctx, "csrmm_bricks_conj");                                                                           \
         hipLaunchKernelGGL((k_grid_bricks<NC_, NSEG_>), dim3(blocks), dim3(BLK), lds, ctx->stream, (const BrickTask*)tasks, (int)ntasks, (const BrickRef*)brick_table, (const BrickEntry*)entries, round_rows, \
-                           (const float2*)xp, (float2*)Y_il, alpha, bits, (int)n0, (int)nm, bm_log2, bs_log2, nbx, nbm, st_log2); } while (0)
+                           (const float2*)xp, (float2*)Y_il, alpha, bits, (int)n0, (int)nm, bm_log2, bs_log2, nbx, nbm, st_log2, zw); } while (0)
     const int nseg_total = (16 / support_tile) * bm * bs;
     if (N == 8 && nseg_total == 4) IG_BRICKS(8, 4);
     else if (N == 8 && nseg_total == 8) IG_BRICKS(8, 8);
@@ -2488,15 +2488,16 @@ int ig_grid_slots_build(int64_t nbricks, const int64_t* brick_ptr, const void* e
 int ig_ccsrmm_t_slots(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, float ar, float ai,
                       const void* entries16, const int32_t* slot_ptr, const void* X, int64_t ldx, void* Y_il, const int16_t* support,
                       int64_t n0, int64_t nm, int bm, int bs, const int32_t* tasks, int64_t ntasks, const int32_t* brick_table,
-                      const int32_t* shared_bricks, int64_t nshared, int support_tile) {
+                      const int32_t* shared_bricks, int64_t nshared, int support_tile, int support_zwords) {
     IG_REQUIRE(ctx, ctx != nullptr, "ig_ccsrmm_t_slots: ctx is NULL");
+    const int zw = support_zwords > 0 ? support_zwords : 16;
     IG_REQUIRE(ctx, M >= 0 && K >= 0 && M <= 0x7fffffffLL, "ig_ccsrmm_t_slots: bad dimensions");
     IG_REQUIRE(ctx, N == 1 || N == 2 || N == 4, "ig_ccsrmm_t_slots: 1, 2 or 4 columns (got %lld; at 8 the round format of ig_ccsrmm_t_bricks is faster: 0.77 against 1.28 ms)", (long long)N);
     IG_REQUIRE(ctx, (ntasks == 0 || (entries16 && slot_ptr)) && (M == 0 || X) && (K == 0 || Y_il) && ldx >= M, "ig_ccsrmm_t_slots: NULL array or short leading dimension");
     IG_REQUIRE(ctx, n0 > 0 && nm > 0 && K % (n0 * nm) == 0 && K < 0x7fffffffLL && bricks_ok(n0, nm, K / (n0 * nm), bm, bs, 1) && bm * bs <= 32,
                "ig_ccsrmm_t_slots: rows (%lld) are not a grid of n0=%lld x nm=%lld x ... that divides into 16 x %d x %d bricks", (long long)K, (long long)n0, (long long)nm, bm, bs);
     const int64_t ns = K / (n0 * nm);
-    IG_REQUIRE(ctx, !support || (nm % 16 == 0 && nm <= 512), "ig_ccsrmm_t_slots: the support table needs nm %% 16 == 0 and nm <= 512");
+    IG_REQUIRE(ctx, !support || (zw <= 64 && nm <= 32 * (int64_t)zw), "ig_ccsrmm_t_slots: the support bitmaps hold 32 bits in each of %d words: nm <= %d", zw, 32 * zw);
     IG_REQUIRE(ctx, support_tile == 16 || support_tile == 8 || support_tile == 4, "ig_ccsrmm_t_slots: support_tile %d", support_tile);
     IG_REQUIRE(ctx, (16 / support_tile) * bm * bs <= 32, "ig_ccsrmm_t_slots: at most 32 segments per brick");
     const int st_log2 = support_tile == 16 ? 4 : support_tile == 8 ? 3 : 2;
@@ -2535,10 +2536,10 @@ int ig_ccsrmm_t_slots(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, float ar, fl
 #define IG_SLOTS(NC_) do {                                                                                                      \
         if (nshared) {                                                                                                          \
             ig_prof_scope prof(ctx, "grid_bricks_zero");                                                                        \
-            hipLaunchKernelGGL((k_grid_bricks_zero<NC_>), dim3((unsigned)nshared), dim3(BLK), 0, ctx->stream, shared_bricks, (float2*)Y_il, bits, (int)n0, (int)nm, bm_log2, bs_log2, nbx, nbm, st_log2); } \
+            hipLaunchKernelGGL((k_grid_bricks_zero<NC_>), dim3((unsigned)nshared), dim3(BLK), 0, ctx->stream, shared_bricks, (float2*)Y_il, bits, (int)n0, (int)nm, bm_log2, bs_log2, nbx, nbm, st_log2, zw); } \
         ig_prof_scope prof(ctx, "csrmm_slots_conj");                                                                            \
         hipLaunchKernelGGL((k_grid_slots<NC_>), dim3(blocks), dim3(BLK), lds, ctx->stream, (const BrickTask*)tasks, (int)ntasks, (const BrickRef*)brick_table, slot_ptr, (const SlotEntry*)entries16, \
-                           xp, (float2*)Y_il, alpha, bits, (int)n0, (int)nm, bm_log2, bs_log2, nbx, nbm, st_log2); } while (0)
+                           xp, (float2*)Y_il, alpha, bits, (int)n0, (int)nm, bm_log2, bs_log2, nbx, nbm, st_log2, zw); } while (0)
     if (N == 1) IG_SLOTS(1); else if (N == 2) IG_SLOTS(2); else IG_SLOTS(4);
 #undef IG_SLOTS
     IG_LAUNCH_CHECK(ctx, "k_grid_slots");

@@ -44,20 +44,23 @@ def touched_columns(G):
     return c
 
 
-def grid_support(G, oN, tile=16):
+def grid_support(G, oN, tile=16, zw=(16, 16)):
     """k-space support table of a layout-1 gridding matrix (see grid_support_numpy for the format): the library's native
-    host routine, one threaded pass over the column indices (ig_grid_support)"""
+    host routine, one threaded pass over the column indices (ig_grid_support).  zw = (words per entry of the bitmaps as the
+    z pass reads them on its input side, ... on its output side): (16, 16) for 256- and 512-point z axes, (B, A) for an axis the
+    A x B kernel transforms (backend.support_words(n2))."""
     from indigo_amd import _lib
     n0, n1, n2 = (int(n) for n in oN)
-    assert n0 % 16 == 0 and n2 % 16 == 0 and n2 <= 512 and tile in (2, 4, 8, 16)
+    zi, zo = (int(v) for v in zw)
+    assert n0 % tile == 0 and n2 <= 32 * min(zi, zo) and tile in (2, 4, 8, 16)
     nt = n0 // tile
     idx = np.ascontiguousarray(G.indices, dtype=np.int32)
-    table = np.empty(2 * (n1 * nt + nt) + 2 * n1 * nt * 16, dtype=np.int16)
-    _lib.check(_lib.lib().ig_grid_support(idx.size, idx.ctypes.data, n0, n1, n2, int(tile), table.ctypes.data), None, "ig_grid_support")
+    table = np.empty(2 * (n1 * nt + nt) + 2 * n1 * nt * (zi + (zo if zo != zi else 0)), dtype=np.int16)
+    _lib.check(_lib.lib().ig_grid_support(idx.size, idx.ctypes.data, n0, n1, n2, int(tile), zi, zo, table.ctypes.data), None, "ig_grid_support")
     return table
 
 
-def grid_support_numpy(G, oN, tile=16):
+def grid_support_numpy(G, oN, tile=16, zw=(16, 16)):
     """k-space support of a layout-1 gridding matrix G (T x P) as the flat int16 table ig_fft_exec_padded,
     ig_fft_exec_cropped and ig_ccsrmm_t_grid take.  Three parts:
       1. [z_lo, z_hi) per (ky, 16-wide kx tile): the kz range outside which no sample touches the grid;
@@ -68,15 +71,20 @@ def grid_support_numpy(G, oN, tile=16):
     A radial trajectory fills a ball (half of the grid cube lies outside) and, away from the centre, leaves
     gaps between spokes: 30 % of the 16-row segments of the 512^3 grid of the headline problem are flagged."""
     n0, n1, n2 = (int(n) for n in oN)
-    assert n0 % 16 == 0 and n2 % 16 == 0 and n2 <= 512 and tile in (2, 4, 8, 16)
+    zi, zo = (int(v) for v in zw)          # words per entry: bit kz // z of word kz % z (input-side form, then the output-side form)
+    assert n0 % tile == 0 and n2 <= 32 * min(zi, zo) and tile in (2, 4, 8, 16)
     nt = n0 // tile               # `tile` kx points per entry (16 unless the caller asked for a finer table, see ig_fft_set_support_tile)
     cols = touched_columns(G)
     kx = cols % n0
     kz = (cols // n0) % n2
     ky = cols // (n0 * n2)
     key = ky * nt + kx // tile
-    bits = np.zeros((n1 * nt, 16), dtype=np.uint32)
-    np.bitwise_or.at(bits, (key, kz % 16), np.uint32(1) << (kz // 16).astype(np.uint32))
+    bits = np.zeros((n1 * nt, zi), dtype=np.uint32)
+    np.bitwise_or.at(bits, (key, kz % zi), np.uint32(1) << (kz // zi).astype(np.uint32))
+    bits_out = None
+    if zo != zi:
+        bits_out = np.zeros((n1 * nt, zo), dtype=np.uint32)
+        np.bitwise_or.at(bits_out, (key, kz % zo), np.uint32(1) << (kz // zo).astype(np.uint32))
     order = np.argsort(key, kind='stable')
     key, kz = key[order], kz[order]
     ranges = np.zeros((n1 * nt + nt, 2), dtype=np.int16)
@@ -89,22 +97,29 @@ def grid_support_numpy(G, oN, tile=16):
         ys = np.flatnonzero(nonempty[:, t])
         if ys.size:
             ranges[n1 * nt + t] = (ys[0], ys[-1] + 1)
-    return np.concatenate([ranges.reshape(-1), bits.reshape(-1).view(np.int16)])
+    parts = [ranges.reshape(-1), bits.reshape(-1).view(np.int16)]
+    if bits_out is not None:
+        parts.append(bits_out.reshape(-1).view(np.int16))
+    return np.concatenate(parts)
 
 
-def support_table_ok(oN):
-    """the k-space support table (16 words of up to 32 bits per tile: one bit per row of a 256- or 512-point axis) exists for
-    these grids only; others run without one (every grid row is written and read)"""
-    return all(int(n) in (256, 512) for n in oN)
+def support_words(backend, oN):
+    """(zw_in, zw_out) of the k-space support table for this grid on this backend -- the words per entry of its bitmaps, which
+    follow from the kernel that transforms the z axis (oN[2]) --, or None where the backend takes no table for the grid
+    (the grid then runs without one: every grid row is written and read)"""
+    f = getattr(backend, 'support_words', None)
+    if f is None or int(oN[0]) % 16:
+        return None
+    return f(int(oN[2]))
 
 
-def split_support(table, oN, tile=16):
-    """(z ranges (n1*nt, 2), y ranges (nt, 2), segment bits (n1*nt, 16) uint32) views of a support table"""
+def split_support(table, oN, tile=16, zw_in=16):
+    """(z ranges (n1*nt, 2), y ranges (nt, 2), segment bits (n1*nt, zw_in) uint32: the input-side form) views of a support table"""
     n0, n1, n2 = (int(n) for n in oN)
     nt = n0 // tile
     table = np.ascontiguousarray(table, dtype=np.int16).reshape(-1)
     a, b = 2 * n1 * nt, 2 * (n1 * nt + nt)
-    return table[:a].reshape(-1, 2), table[a:b].reshape(-1, 2), table[b:].view(np.uint32).reshape(n1 * nt, 16)
+    return table[:a].reshape(-1, 2), table[a:b].reshape(-1, 2), table[b:b + 2 * n1 * nt * zw_in].view(np.uint32).reshape(n1 * nt, zw_in)
 
 
 def coil_chunks(Cn, chunk=8):
@@ -126,7 +141,7 @@ def choose_layout(Cn, chunk=8, layout=None):
 
 
 def assemble(backend, Gm, oN, N, weights_of, Cn, layout, chunks, table=None, box_lo=None, row_order=None,
-             name='SENSE-fusedFFT'):
+             name='SENSE-fusedFFT', zw=(16, 16)):
     """A = KronI(C, G') * ZpadFFT, or a VStack of such trees over coil chunks sharing ONE device copy of G'.
 
     Gm          gridding matrix (T x P, complex64 CSR) with its columns in the order of `layout` (see
@@ -143,7 +158,7 @@ def assemble(backend, Gm, oN, N, weights_of, Cn, layout, chunks, table=None, box
         if interleaved:
             G._grid_interleaved = True
         if table is not None:
-            G._grid_support = (table, int(oN[0]), int(oN[2]))
+            G._grid_support = (table, int(oN[0]), int(oN[2]), int(zw[0]))
         if interleaved and fine is not None:
             G._grid_support_fine = fine
         if row_order is not None:
@@ -173,7 +188,7 @@ def assemble(backend, Gm, oN, N, weights_of, Cn, layout, chunks, table=None, box
     fine = None
     if (table is not None and layout == 2 and tile in (4, 8) and bricks_cols * tile >= 32 and len(sizes) == 0
             and getattr(backend, 'supports_support_tile', False)):
-        fine = (grid_support(Gm, oN, tile), tile)
+        fine = (grid_support(Gm, oN, tile, zw), tile)
     G_il = gridding(True) if layout == 2 else None
     G_pc = None
     trees = []
@@ -193,6 +208,7 @@ def assemble(backend, Gm, oN, N, weights_of, Cn, layout, chunks, table=None, box
     A = trees[0] if len(trees) == 1 else backend.VStack(trees, name='coil-chunks')
     A._name = name
     A._support_fine = fine
+    A._support_zw = tuple(int(v) for v in zw)
     return A
 
 

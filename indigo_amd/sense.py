@@ -185,12 +185,12 @@ class SenseProblem(object):
                 one(jc)
         return w
 
-    def grid_support(self, G, tile=16):
+    def grid_support(self, G, tile=16, zw=(16, 16)):
         """k-space support table of a layout-1 gridding matrix (see indigo_amd.fused.grid_support)"""
-        return fused.grid_support(G, self.oN, tile)
+        return fused.grid_support(G, self.oN, tile, zw)
 
-    def split_support(self, table, tile=16):
-        return fused.split_support(table, self.oN, tile)
+    def split_support(self, table, tile=16, zw_in=None):
+        return fused.split_support(table, self.oN, tile, int(zw_in or getattr(self, 'last_support_zw', (16, 16))[0]))
 
     def zpadfft_pass_bytes(self, ncoils, table=None, fused_sum=False, tile=16):
         """Compulsory HBM bytes of each axis pass of the fused transform (layout 1): what the pass must read
@@ -273,13 +273,16 @@ class SenseProblem(object):
         layout, chunks = fused.choose_layout(Cn, chunk, layout)
         Gm = self.fused_interp(1 if layout == 2 else layout)      # layout 2 = layout 1 with the coils interleaved below
         table = None
-        if (support is None or support) and layout >= 1 and self.oN[0] % 16 == 0 and (support or fused.support_table_ok(self.oN)):
+        zw = fused.support_words(backend, self.oN)      # words per entry of the table's bitmaps: follows from the z pass's kernel
+        if (support is None or support) and layout >= 1 and zw is not None and (layout == 2 or zw == (16, 16)):
             # restrict the transform's z pass and the adjoint gridding to the k-space support of G'
-            table = self.grid_support(Gm)
+            table = self.grid_support(Gm, 16, zw)
+        zw = zw or (16, 16)
         self.last_support_table = table
+        self.last_support_zw = zw
         order = self.locality_order(Gm) if reorder and Cn <= 8 else None
         A = fused.assemble(backend, Gm, self.oN, self.N, lambda lo, hi: self.fused_weights(coils[lo:hi], interleaved=(layout == 2)), Cn,
-                           layout, chunks, table=table, row_order=order)
+                           layout, chunks, table=table, row_order=order, zw=zw)
         self.last_support_fine = getattr(A, '_support_fine', None)       # (table, tile) when the tree took a finer table
         return A
 

@@ -392,7 +392,10 @@ def test_config5_as_benchmarked_on_one_gpu(hip, oracle_backend):
 # passes on the A x B two-stage kernel (k_fft_ab_desc), coil-interleaved layout
 # ---------------------------------------------------------------------------------------
 @pytest.mark.parametrize("grid,box,C", [((320, 320, 320), (256, 256, 256), 8), ((480, 384, 640), (360, 300, 500), 2),
-                                        ((400, 432, 512), (300, 310, 256), 4)])
+                                        ((400, 432, 512), (300, 310, 256), 4),
+                                        # lengths of the generated list (tools/gen_ab_list.py): odd ones, splits with A != B, 3 / 5 / 7 in both factors
+                                        ((288, 270, 392), (208, 208, 308), 4), ((600, 135, 175), (480, 100, 140), 2),
+                                        ((144, 625, 128), (100, 500, 96), 16), ((360, 250, 567), (256, 200, 400), 2)])
 def test_padded_transforms_on_non_power_of_two_grids_vs_numpy(hip, grid, box, C):
     """fft_padded / ifft_cropped / ifft_cropped_sum (layout 2) on grids whose axes are 320 ... 640 points long (and mixed
     with 512): one coil of the forward grid against numpy, the cropped inverse and the coil combination against their
@@ -437,16 +440,20 @@ def test_padded_transforms_on_non_power_of_two_grids_vs_numpy(hip, grid, box, C)
     hip._scratch = None
 
 
-def test_sense_on_the_reference_drivers_grid_vs_oracle(hip, oracle_backend):
+@pytest.mark.parametrize("C", [4, 8])
+def test_sense_on_the_reference_drivers_grid_vs_oracle(hip, oracle_backend, C):
     """image 256^3 on a 320^3 grid (oversampling 1.25, the reference driver's choice of grid, examples/pics.py:87-90): the fused
-    leaf on the A x B passes, 4 coils, forward / adjoint / normal operator against the numpy oracle"""
-    p = SenseProblem.synthetic((256, 256, 256), 4, nspokes=400, nreadout=320, width=2, ntable=128, oversamp=1.25, seed=6)
+    leaf on the A x B passes WITH the k-space support table (bitmaps of 20 and 16 words per entry for the 16 x 20 split of the z
+    axis; the 8-point table; the 8- and the 4-coil brick scatter), forward / adjoint / normal
+    operator against the numpy oracle, which knows no table"""
+    p = SenseProblem.synthetic((256, 256, 256), C, nspokes=400, nreadout=320, width=2, ntable=128, oversamp=1.25, seed=6)
     assert p.oN == (320, 320, 320)
     hip._scratch = None
     oracle_backend._scratch = None
     A = p.build_zpadfft(hip)
     from indigo_amd import operators as op
-    assert A.has(op.ZpadFFT) and A.right._layout == 2 and A.right._support_h is None
+    assert A.has(op.ZpadFFT) and A.right._layout == 2 and A.right._support_h is not None and p.last_support_zw == (20, 16)
+    assert p.last_support_fine is not None and p.last_support_fine[1] == 8          # (coils * tile >= 32: the 8-point table for both)
     x = rand64c(A.shape[1], 1, seed=1)
     k = rand64c(A.shape[0], 1, seed=2)
     A_o = p.build_zpadfft(oracle_backend, layout=0, support=False)

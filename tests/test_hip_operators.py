@@ -363,8 +363,9 @@ def test_zpadfft_operator_matches_reference_composition(hip, oracle_backend):
     hip._scratch = None
 
 
-def support_table_from_segments(seg):
-    """flat int16 support table (see SenseProblem.grid_support) from a boolean array seg[ky, kz, kx tile]"""
+def support_table_from_segments(seg, zw=(16, 16)):
+    """flat int16 support table (see SenseProblem.grid_support) from a boolean array seg[ky, kz, kx tile]; zw = words per entry
+    of the bitmaps in their input-side and output-side form (ig_grid_support)"""
     n1, n2, nt = seg.shape
     kz = np.arange(n2)[None, :, None]
     lo = np.where(seg, kz, n2).min(axis=1)
@@ -376,10 +377,13 @@ def support_table_from_segments(seg):
         ys = np.flatnonzero(hi[:, t] > lo[:, t])
         if ys.size:
             ranges[n1 * nt + t] = (ys[0], ys[-1] + 1)
-    bits = np.zeros((n1, nt, 16), dtype=np.uint32)
     ky, kzz, tt = np.nonzero(seg)
-    np.bitwise_or.at(bits, (ky, tt, kzz % 16), np.uint32(1) << (kzz // 16).astype(np.uint32))
-    return np.concatenate([ranges.reshape(-1), bits.reshape(-1).view(np.int16)]), ranges[:n1 * nt]
+    parts = [ranges.reshape(-1)]
+    for z in ((zw[0],) if zw[0] == zw[1] else zw):
+        bits = np.zeros((n1, nt, z), dtype=np.uint32)
+        np.bitwise_or.at(bits, (ky, tt, kzz % z), np.uint32(1) << (kzz // z).astype(np.uint32))
+        parts.append(bits.reshape(-1).view(np.int16))
+    return np.concatenate(parts), ranges[:n1 * nt]
 
 
 def test_single_coil_sense_rank(hip, oracle_backend):
@@ -455,25 +459,31 @@ def test_padded_fft_with_support_table(hip):
     np.testing.assert_array_equal(out[~inside], sentinel[~inside])
 
 
-@pytest.mark.parametrize("C,tile", [(4, 8), (8, 8), (8, 4), (8, 2), (2, 8), (4, 16)])
-def test_padded_fft_with_a_finer_support_table_layout2(hip, C, tile):
+@pytest.mark.parametrize("C,tile,grid,box", [(4, 8, (256,) * 3, (128,) * 3), (8, 8, (256,) * 3, (128,) * 3), (8, 4, (256,) * 3, (128,) * 3),
+                                             (8, 2, (256,) * 3, (128,) * 3), (2, 8, (256,) * 3, (128,) * 3), (4, 16, (256,) * 3, (128,) * 3),
+                                             (8, 8, (160, 192, 320), (128, 150, 256)), (4, 16, (320, 144, 200), (256, 100, 160)),
+                                             (8, 8, (256, 240, 270), (128, 200, 208)), (2, 8, (160, 256, 640), (100, 128, 480))])
+def test_padded_fft_with_a_finer_support_table_layout2(hip, C, tile, grid, box):
     """ig_fft_set_support_tile: the coil-interleaved transform with a support table of `tile` kx points per entry (coils * tile
     >= 16): the padded transform defines exactly the flagged segments (everything else keeps the sentinel outside the image
     planes), the cropped ones (per-coil and coil-summing) read everything else as zero -- against the same transforms
-    without a table"""
-    grid, box, layout = (256, 256, 256), (128, 128, 128), 2
+    without a table.  Grids whose z axis the A x B kernel transforms carry the bitmaps in two forms, B and A words per entry
+    (ig_fft_support_words): 320 = 16 x 20, 200 = 10 x 20, 270 = 15 x 18, 640 = 20 x 32."""
+    layout = 2
     lo = tuple(m // 2 + int(np.ceil(-n / 2)) for m, n in zip(grid, box))
     n0, n1, n2 = grid
     P, N = int(np.prod(grid)), int(np.prod(box))
-    rng = np.random.default_rng(100 * C + tile)
+    rng = np.random.default_rng(100 * C + tile + n2)
     nt = n0 // tile
-    zlo = rng.integers(0, 200, (n1, 1, nt))
-    zhi = zlo + rng.integers(0, 57, (n1, 1, nt))
+    zw = hip.support_words(n2)
+    assert zw is not None and (zw == (16, 16)) == (n2 in (256, 512))
+    zlo = rng.integers(0, int(n2 * 0.8), (n1, 1, nt))
+    zhi = zlo + rng.integers(0, max(2, n2 // 4), (n1, 1, nt))
     kzv = np.arange(n2)[None, :, None]
     seg = (kzv >= zlo) & (kzv < zhi) & (rng.random((n1, n2, nt)) < 0.6)
-    seg[:30, :, ::2] = False
-    seg[220:, :, ::3] = False
-    flat_table, table = support_table_from_segments(seg)
+    seg[:n1 // 8, :, ::2] = False
+    seg[n1 - n1 // 8:, :, ::3] = False
+    flat_table, table = support_table_from_segments(seg, zw)
     sup = hip.copy_array(flat_table)
     inside = np.repeat(seg, tile, axis=2).reshape(-1)                         # rows kx + n0*(kz + n2*ky)
     x, w = rand64c(N, 1, seed=1), rand64c(N, C, seed=2)

@@ -292,3 +292,36 @@ def test_fused_weights_interleaved_is_the_same_array_in_another_memory_order():
         assert a.flags['F_CONTIGUOUS'] and b.reshape((-1, C), order='F').flags['C_CONTIGUOUS']
         one = p.fused_weights([1], interleaved=True)
         assert np.array_equal(one[..., 0], a[..., 1])
+
+
+@pytest.mark.parametrize("oN,tile,zw", [((32, 24, 48), 16, (16, 16)), ((32, 30, 40), 8, (8, 5)), ((64, 20, 100), 16, (10, 10)), ((48, 18, 70), 4, (10, 7))])
+def test_support_table_builder_native_vs_numpy(oN, tile, zw):
+    """ig_grid_support (threaded host routine) against the numpy formulation, for bitmaps of 16 words per entry (256- and
+    512-point z axes) and of B / A words per entry (an axis the A x B kernel transforms): same table bit for bit, and the
+    bitmaps' two forms flag the same (ky, kz, kx tile) segments"""
+    import scipy.sparse as spp
+    from indigo_amd import fused
+    n0, n1, n2 = oN
+    rng = np.random.default_rng(n2)
+    P = n0 * n1 * n2
+    cols = np.unique(rng.integers(0, P, size=P // 7))
+    cols = cols[((cols // n0) % n2 > n2 // 5) | (cols % 3 == 0)]
+    G = spp.csr_matrix((np.ones(cols.size, np.complex64), cols, np.array([0, cols.size])), shape=(1, P))
+    a = fused.grid_support(G, oN, tile, zw)
+    b = fused.grid_support_numpy(G, oN, tile, zw)
+    np.testing.assert_array_equal(a, b)
+    nt = n0 // tile
+    zr, yr, bits_in = fused.split_support(a, oN, tile, zw[0])
+    kz = np.arange(n2)
+    seg_in = (bits_in.reshape(n1, nt, zw[0])[:, :, kz % zw[0]] >> (kz // zw[0]).astype(np.uint32)) & 1
+    if zw[0] != zw[1]:
+        off = 2 * (n1 * nt + nt) + 2 * n1 * nt * zw[0]
+        bits_out = np.ascontiguousarray(a[off:]).view(np.uint32).reshape(n1, nt, zw[1])
+        seg_out = (bits_out[:, :, kz % zw[1]] >> (kz // zw[1]).astype(np.uint32)) & 1
+        np.testing.assert_array_equal(seg_in, seg_out)
+    # every touched column lies in a flagged segment and inside the hulls
+    kx, kzc, kyc = cols % n0, (cols // n0) % n2, cols // (n0 * n2)
+    assert seg_in[kyc, kx // tile, kzc].all()
+    z = zr.reshape(n1, nt, 2)
+    assert (z[kyc, kx // tile, 0] <= kzc).all() and (kzc < z[kyc, kx // tile, 1]).all()
+    assert (yr[kx // tile, 0] <= kyc).all() and (kyc < yr[kx // tile, 1]).all()
