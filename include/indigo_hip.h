@@ -445,6 +445,11 @@ int  ig_fft_plan_padded(ig_ctx* ctx, const int64_t* dims, const int64_t* box_lo,
  * three parts; a finer table flags fewer grid bytes (BASELINE config 4: 30.5 % of the grid at 16, 22.2 % at 8, 16.4 % at 4).   */
 int  ig_fft_set_support_tile(ig_fft* plan, int tile);
 int  ig_fft_support_words(int64_t n2, int* zw_in, int* zw_out);        /* host; IG_ERR_UNSUPPORTED: no zero-pad-aware z pass */
+/* what ig_fft_plan_padded would run an axis of n points with: 3 = the power-of-two kernel (256, 512; any layout), 4 = the A x B
+ * kernel (smooth lengths 128 ... 640; coil-interleaved layout), 5 = chirp-z (Bluestein) over an A x B length m >= 2 n - 1 for
+ * lengths with a prime factor above 7 (y and z axes of the coil-interleaved layout; no support table on such a grid), 0 = none.
+ * The lengths int(N * osf) of the reference's driver (indigo/backends/backend.py:427-430) are of kinds 4 and 5.               */
+int  ig_fft_padded_axis_kind(int64_t n, int* kind);
 int  ig_fft_exec_padded(ig_fft* plan, const void* x, int64_t x_bstride, const void* w, void* y, void* workspace,
                         const int16_t* support);
 int  ig_fft_exec_cropped(ig_fft* plan, const void* y, const void* w, void* x, int64_t x_bstride, void* workspace,

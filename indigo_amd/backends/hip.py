@@ -452,7 +452,16 @@ class HipBackend(Backend):
         plan, ws, ws_inplace = self._get_or_create_plan(x.shape)
         if x._arr == y._arr:
             ws = ws_inplace
-        if ws:
+        if ws and getattr(self, '_scratch', None) is None:
+            # no arena reserved (a bare fftn / ifftn call, not an operator tree): a grow-only workspace kept by the backend --
+            # allocating, zeroing and freeing 9 GB per call (the chirp-z columns of a 640 x 277 x 410 x 8 transform) cost 50x
+            # the transform.  The kernels write every element of it before they read it.
+            tmp = getattr(self, '_fft_ws', None)
+            if tmp is None or tmp.nbytes < ws:
+                self._fft_ws = None
+                tmp = self._fft_ws = self.empty_array((int(ws) // 8,), _C64, name='fft workspace')
+            rc = self._L.ig_fft_exec(plan, ctypes.c_void_p(x._arr), ctypes.c_void_p(y._arr), direction, ctypes.c_void_p(tmp._arr))
+        elif ws:
             with self.scratch(nbytes=ws) as tmp:
                 rc = self._L.ig_fft_exec(plan, ctypes.c_void_p(x._arr), ctypes.c_void_p(y._arr), direction,
                                          ctypes.c_void_p(tmp._arr))
@@ -472,6 +481,12 @@ class HipBackend(Backend):
             return None
         return zi.value, zo.value
 
+    def padded_axis_kind(self, n):
+        """3 = power-of-two kernel, 4 = A x B kernel, 5 = chirp-z over an A x B length, 0 = no zero-pad-aware pass (ig_fft_padded_axis_kind)"""
+        k = ctypes.c_int(0)
+        self._check(self._L.ig_fft_padded_axis_kind(int(n), ctypes.byref(k)), "ig_fft_padded_axis_kind")
+        return k.value
+
     def supports_padded_fft(self, grid, ncoils=None):
         """256- and 512-point axes in every grid layout; the reference driver's own oversampled grids (320 ... 640,
         examples/pics.py:87-90) and every other smooth length from 128 to 640 in the coil-interleaved layout, i.e. for coil
@@ -481,7 +496,9 @@ class HipBackend(Backend):
             return False
         if all(int(n) in self.PADDED_AXES_POW2 for n in grid):
             return True
-        if not all(self.support_words(n) is not None for n in grid):
+        kinds = [self.padded_axis_kind(n) for n in grid]
+        # (5 = chirp-z: lengths with a prime factor above 7 -- 277, 410: int(N * osf) of the reference's driver -- on the y and z axes)
+        if kinds[0] not in (3, 4) or any(k not in (3, 4, 5) for k in kinds[1:]):
             return False
         if ncoils is None:
             return True

@@ -37,9 +37,14 @@
 #include "ig_fft_ab.h"
 #include "ig_fft_ab_list.h"
 #include <vector>
+#include <functional>
+#include <algorithm>
+#include <cmath>
 #include <cmath>
 #include <cstring>
 #include <string>
+#include <memory>
+#include <complex>
 
 namespace {
 
@@ -917,9 +922,12 @@ k_fft_generic_stage(const float2* __restrict__ in, float2* __restrict__ out, con
 
 // ---- planning -----------------------------------------------------------------
 
+struct Chirp;
 struct AxisPlan {
     int64_t n = 1, inner = 1, outer = 1;
-    int kind = 2;                      // 0 LDS kernel, 1 generic stages, 2 nothing to do (n == 1), 3 two-stage (256, 512), 4 two-stage A x B
+    int kind = 2;                      // 0 LDS kernel, 1 generic stages, 2 nothing to do (n == 1), 3 two-stage (256, 512), 4 two-stage A x B,
+                                       // 5 chirp-z (Bluestein) over a smooth length m >= 2 n - 1: lengths with a prime factor > 7
+    std::shared_ptr<Chirp> chirp;      // kind 5
     int nstages = 0;
     int ab_A = 0, ab_B = 0;            // kind 4: n = A * B (ig_fft_ab.h)
     Radices rad{};
@@ -927,6 +935,26 @@ struct AxisPlan {
     int W = 16, T = 1;
     size_t lds_bytes = 0;
     float2* d_tw = nullptr;
+};
+
+// Bluestein: X_k = b_k sum_j (x_j b_j) conj(b)_{k-j}, b_j = exp(-i pi j^2 / n) -- a cyclic convolution of length m >= 2 n - 1, done
+// with two transforms of a length the fast kernels have.  Tables for both directions (the inverse's are the conjugates):
+//   b[dir]    m entries: the chirp (input weights; only j < n is ever read)
+//   bhat[dir] m entries: F_m of the wrapped conjugate chirp (the convolution kernel in the frequency domain)
+//   bout[dir] m entries: b_k / m (output weights of the inverse sub-transform, which is unnormalised)
+struct Chirp {
+    int64_t m = 0;
+    float2* d_b[2] = {nullptr, nullptr};
+    float2* d_bhat[2] = {nullptr, nullptr};
+    float2* d_bout[2] = {nullptr, nullptr};
+    float2* d_hat_out[2] = {nullptr, nullptr};     // bhat then bout in one array (the one-launch kernel's second table)
+    AxisPlan sub;                      // the length-m axis with this axis's inner / outer extents
+    bool fused = false;                // ONE launch per pass (k_fft_chirp: both length-m transforms in registers / LDS; strided axes, m = A x B)
+    ~Chirp() {
+        for (int d = 0; d < 2; ++d) { if (d_b[d]) (void)hipFree(d_b[d]); if (d_bhat[d]) (void)hipFree(d_bhat[d]); if (d_bout[d]) (void)hipFree(d_bout[d]);
+                                      if (d_hat_out[d]) (void)hipFree(d_hat_out[d]); }
+        if (sub.d_tw) (void)hipFree(sub.d_tw);
+    }
 };
 
 bool factor_lds(int64_t n, Radices& rad, int& nstages) {
@@ -956,6 +984,7 @@ void factor_generic(int64_t n, std::vector<int64_t>& out) {
 
 struct ig_fft {
     ig_ctx* ctx = nullptr;
+    bool is_chirp_sub = false;       // a throw-away plan made to plan the length-m axis of a chirp-z axis (no nesting)
     int rank = 0;
     int64_t dims[3] = {1, 1, 1};
     int64_t batch = 1;
@@ -968,6 +997,7 @@ struct ig_fft {
     size_t inplace_workspace_bytes = 0;   // two-launch transform called in place: staging volumes in the CALLER's workspace (ig_fft_inplace_workspace)
     bool padded = false;
     bool has_ab_axis = false;        // a zero-padded plan with an A x B axis (160 ... 640)
+    bool has_chirp_axis = false;     // ... with a chirp-z axis (y or z): no k-space support table
     int zw_in = 16, zw_out = 16;     // words per entry of the k-space support table's bitmaps on the z axis (ig_fft_support_words)
     int layout = 0;                  // memory order of the grid: 0 = (x, y, z), 1 = (x, z, y)
     int support_tile = 16;           // kx points per entry of the k-space support table (layout 2: ig_fft_set_support_tile)
@@ -981,7 +1011,8 @@ namespace {
 }  // namespace
 #define IG_ABD_DECL(K_)                                                                                                              \
     int ig_ab_launch_part##K_(hipStream_t, int64_t, bool, dim3, dim3, size_t, const float2*, float2*, const float2*, int64_t, int64_t, int); \
-    int ig_abd_launch_part##K_(hipStream_t, int64_t, int, dim3, dim3, const PassDesc&, const float2*);
+    int ig_abd_launch_part##K_(hipStream_t, int64_t, int, dim3, dim3, const PassDesc&, const float2*);                                     \
+    int ig_abz_launch_part##K_(hipStream_t, int64_t, dim3, dim3, const PassDesc&, const float2*);
 IG_ABD_DECL(0) IG_ABD_DECL(1) IG_ABD_DECL(2) IG_ABD_DECL(3)
 #undef IG_ABD_DECL
 namespace {
@@ -1011,6 +1042,8 @@ int launch_ab(ig_ctx* ctx, const AxisPlan& ax, const float2* in, float2* out, in
     IG_LAUNCH_CHECK(ctx, "k_fft_ab");
     return IG_OK;
 }
+
+int plan_chirp(ig_ctx* ctx, AxisPlan& ax, int64_t m);
 
 int plan_axis(ig_ctx* ctx, ig_fft* p, int a) {
     AxisPlan& ax = p->axis[a];
@@ -1075,6 +1108,29 @@ int plan_axis(ig_ctx* ctx, ig_fft* p, int a) {
         ax.kind = 1;
         factor_generic(ax.n, ax.gen_radices);
         ax.nstages = (int)ax.gen_radices.size();
+        // a prime factor above 7 (277, 410 = 2 * 5 * 41: what int(N * osf) of the reference's driver produces, backend.py:427-430):
+        // chirp-z over the smallest smooth length m >= 2 n - 1 that a fast kernel transforms -- an A x B length up to 1024 where
+        // one exists (two fused launches on strided axes), else a length of the LDS kernel up to 4096
+        int64_t big = 1;
+        for (int64_t r : ax.gen_radices) big = std::max(big, r);
+        if (big > 7 && ax.n >= 32 && ctx->opt_fft_kernels == 0 && !p->is_chirp_sub) {        // (shorter ones: the direct stages are fine)
+            int64_t m = 0;
+            int A = 0, B = 0;
+            // (measured on 640 x 277 x 410 x 8: what a pass costs follows m AND the split -- 410 over m = 840 = 28 x 30 9.6 ms, over
+            // 864 = 27 x 32 8.6 ms, over 896 = 28 x 32 8.5 ms; 277 over 560 = 20 x 28 5.7 ms, over 576 = 24 x 24 7.5 ms: whole waves
+            // (B a multiple of 4) beat the shortest m -- so: the first length within 8 % of 2 n - 1 whose B is a multiple of 4,
+            // else the shortest)
+            for (int64_t c = 2 * ax.n - 1; c <= 1024 && c * 100 <= (2 * ax.n - 1) * 108; ++c)
+                if (ab_split(c, A, B)) { if (!m) m = c; if (B % 4 == 0) { m = c; break; } }
+            for (int64_t c = 2 * ax.n - 1; c <= 1024 && !m; ++c) if (ab_split(c, A, B)) m = c;
+            Radices r2{};
+            int ns2 = 0;
+            for (int64_t c = 2 * ax.n - 1; c <= LDS_NMAX && !m; ++c) if (factor_lds(c, r2, ns2)) m = c;
+            if (m) {
+                if (int rc = plan_chirp(ctx, ax, m)) return rc;
+                ax.kind = 5;
+            }
+        }
     }
     // twiddles exp(-2 pi i k / n), rounded once from double
     std::vector<float2> tw((size_t)ax.n);
@@ -1223,9 +1279,116 @@ int launch_ab_desc(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d_in, int wm
     return IG_OK;
 }
 
-// one pass of a zero-padded / cropped transform: the power-of-two kernel or the A x B one, by the axis plan
+int plan_chirp(ig_ctx* ctx, AxisPlan& ax, int64_t m) {
+    auto ch = std::make_shared<Chirp>();
+    ch->m = m;
+    const int64_t n = ax.n;
+    {   // the length-m axis: planned like any other axis of an (inner, m, outer) array
+        ig_fft tmp;
+        tmp.ctx = ctx; tmp.is_chirp_sub = true; tmp.rank = 3; tmp.batch = 1;
+        tmp.dims[0] = ax.inner; tmp.dims[1] = m; tmp.dims[2] = ax.outer;
+        tmp.total = ax.inner * m * ax.outer;
+        if (int rc = plan_axis(ctx, &tmp, 1)) return rc;
+        ch->sub = tmp.axis[1];
+        tmp.axis[1].d_tw = nullptr;
+    }
+    IG_REQUIRE(ctx, ch->sub.kind == 0 || ch->sub.kind == 3 || ch->sub.kind == 4, "ig_fft_plan: no fast kernel for the chirp-z length %lld", (long long)m);
+    ch->fused = ch->sub.kind == 4 && ax.inner >= 16;
+    // tables in double, rounded once
+    typedef std::complex<double> cd;
+    std::vector<cd> b((size_t)n), h((size_t)m, cd(0, 0)), H((size_t)m);
+    for (int64_t j = 0; j < n; ++j) {
+        const double ang = -M_PI * (double)((j * j) % (2 * n)) / (double)n;       // j^2 mod 2n keeps the argument small
+        b[j] = cd(cos(ang), sin(ang));
+    }
+    h[0] = cd(1, 0);
+    for (int64_t j = 1; j < n; ++j) h[j] = h[m - j] = std::conj(b[j]);
+    {   // H = F_m(h): h is even, so H_k = h_0 + 2 sum_{j=1}^{n-1} h_j cos(2 pi j k / m)
+        std::vector<double> cs((size_t)m);
+        for (int64_t k = 0; k < m; ++k) cs[k] = cos(2.0 * M_PI * (double)k / (double)m);
+        for (int64_t k = 0; k < m; ++k) {
+            cd acc = h[0];
+            for (int64_t j = 1; j < n; ++j) acc += 2.0 * h[j] * cs[(j * k) % m];
+            H[k] = acc;
+        }
+    }
+    std::vector<float2> t((size_t)m);
+    auto upload = [&](float2*& dst, const std::function<cd(int64_t)>& f) -> int {
+        for (int64_t k = 0; k < m; ++k) { const cd v = f(k); t[k] = make_float2((float)v.real(), (float)v.imag()); }
+        IG_HIP(ctx, hipMalloc((void**)&dst, sizeof(float2) * (size_t)m));
+        IG_HIP(ctx, hipMemcpy(dst, t.data(), sizeof(float2) * (size_t)m, hipMemcpyHostToDevice));
+        return IG_OK;
+    };
+    for (int dir = 0; dir < 2; ++dir) {
+        auto cj = [dir](cd v) { return dir ? std::conj(v) : v; };
+        if (int rc = upload(ch->d_b[dir], [&](int64_t k) { return k < n ? cj(b[k]) : cd(0, 0); })) return rc;
+        if (int rc = upload(ch->d_bhat[dir], [&](int64_t k) { return cj(H[k]); })) return rc;
+        if (int rc = upload(ch->d_bout[dir], [&](int64_t k) { return k < n ? cj(b[k]) / (double)m : cd(0, 0); })) return rc;
+        IG_HIP(ctx, hipMalloc((void**)&ch->d_hat_out[dir], sizeof(float2) * 2 * (size_t)m));
+        IG_HIP(ctx, hipMemcpy(ch->d_hat_out[dir], ch->d_bhat[dir], sizeof(float2) * (size_t)m, hipMemcpyDeviceToDevice));
+        IG_HIP(ctx, hipMemcpy(ch->d_hat_out[dir] + m, ch->d_bout[dir], sizeof(float2) * (size_t)m, hipMemcpyDeviceToDevice));
+    }
+    ax.chirp = ch;
+    return IG_OK;
+}
+
+// elementwise steps of the unfused chirp-z route (contiguous axes, lengths beyond the A x B kernel)
+__global__ void __launch_bounds__(256)
+k_chirp_pre(const float2* __restrict__ x, float2* __restrict__ W, const float2* __restrict__ b, int64_t n, int64_t m, int64_t inner, int64_t total_m) {
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total_m; idx += (int64_t)gridDim.x * 256) {
+        const int64_t i = idx % inner, rest = idx / inner, j = rest % m, o = rest / m;
+        W[idx] = j < n ? cmul(x[i + inner * (j + n * o)], b[j]) : make_float2(0.f, 0.f);
+    }
+}
+__global__ void __launch_bounds__(256)
+k_chirp_mul(float2* __restrict__ W, const float2* __restrict__ bhat, int64_t m, int64_t inner, int64_t total_m) {
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total_m; idx += (int64_t)gridDim.x * 256)
+        W[idx] = cmul(W[idx], bhat[(idx / inner) % m]);
+}
+__global__ void __launch_bounds__(256)
+k_chirp_post(const float2* __restrict__ W, float2* __restrict__ y, const float2* __restrict__ bout, int64_t n, int64_t m, int64_t inner, int64_t total_n) {
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total_n; idx += (int64_t)gridDim.x * 256) {
+        const int64_t i = idx % inner, rest = idx / inner, k = rest % n, o = rest / n;
+        y[idx] = cmul(W[i + inner * (k + m * o)], bout[k]);
+    }
+}
+
+// A chirp-z pass described by a PassDesc (boxes on both sides, strided columns, no weights of its own): ONE launch of k_fft_chirp
+// (ig_fft_ab.h) -- both length-m transforms of the convolution run in the registers and the LDS of the workgroup that holds the
+// column; nothing of length m ever reaches memory.
+int launch_chirp_desc(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d_in) {
+    const Chirp& ch = *ax.chirp;
+    IG_REQUIRE(ctx, ch.fused, "ig_fft: this chirp-z axis has no one-launch route");
+    IG_REQUIRE(ctx, !d_in.cw && !d_in.tile_range && !d_in.tile_bits && !d_in.k1_range, "ig_fft: a chirp-z pass takes no lane split and no support table");
+    IG_REQUIRE(ctx, d_in.in_lo >= 0 && d_in.in_hi <= ax.n && d_in.out_lo >= 0 && d_in.out_hi <= ax.n, "ig_fft: chirp-z boxes must lie inside the axis");
+    PassDesc d = d_in;
+    if (d.ncols == 0) return IG_OK;
+    const int dir = d.inverse ? 1 : 0;
+    d.w = ch.d_b[dir]; d.w2 = ch.d_hat_out[dir];
+    const int64_t tpr = (d.ext0 + anyfft::AB_W - 1) / anyfft::AB_W;
+    const int64_t blocks = tpr * (d.ncols / d.ext0);
+    IG_REQUIRE(ctx, blocks <= 0x7fffffffLL && d.ext1 <= 0x7fffffffLL, "ig_fft: too many tiles");
+    d.tpr = (unsigned)tpr;
+    {
+        const int64_t lim = 0x7fffffffLL / 8, reach = ch.sub.ab_B - 1;
+        IG_REQUIRE(ctx, d.in_sj >= 0 && d.out_sj >= 0 && d.in_s[0] >= 0 && d.out_s[0] >= 0 && reach * d.in_sj + 15 * d.in_s[0] < lim && reach * d.out_sj + 15 * d.out_s[0] < lim,
+                   "ig_fft: axis stride too large for the chirp-z kernel");
+    }
+    const dim3 grid((unsigned)blocks), block((unsigned)(anyfft::AB_W * ch.sub.ab_B));
+    if (!(ig_abz_launch_part0(ctx->stream, ch.m, grid, block, d, ch.sub.d_tw) || ig_abz_launch_part1(ctx->stream, ch.m, grid, block, d, ch.sub.d_tw) ||
+          ig_abz_launch_part2(ctx->stream, ch.m, grid, block, d, ch.sub.d_tw) || ig_abz_launch_part3(ctx->stream, ch.m, grid, block, d, ch.sub.d_tw)))
+        return ig_fail(ctx, IG_ERR_UNSUPPORTED, "ig_fft: no chirp-z kernel for m = %lld", (long long)ch.m);
+    IG_LAUNCH_CHECK(ctx, "k_fft_chirp");
+    return IG_OK;
+}
+
+// one pass of a zero-padded / cropped transform: the power-of-two kernel, the A x B one or a chirp-z pair, by the axis plan
 int launch_pass(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d, bool axis0, int wmode) {
     if (ax.kind == 3) return launch_2stage(ctx, ax, d, axis0, wmode);
+    if (ax.kind == 5) {
+        IG_REQUIRE(ctx, !axis0 && wmode == 0, "ig_fft: a chirp-z axis takes unweighted strided passes only");
+        return launch_chirp_desc(ctx, ax, d);
+    }
     IG_REQUIRE(ctx, ax.kind == 4 && !axis0, "ig_fft: a zero-padded pass on an axis without a two-stage kernel");
     return launch_ab_desc(ctx, ax, d, wmode);
 }
@@ -1255,6 +1418,9 @@ int ig_fft_plan(ig_ctx* ctx, int rank, const int64_t* dims, int64_t batch, ig_ff
         if (p->axis[a].kind == 1) need_ws = true;
     }
     p->workspace_bytes = need_ws ? (size_t)p->total * 8 : 0;
+    for (int a = 0; a < rank; ++a)           // a chirp-z axis stages its length-m columns in the workspace
+        if (p->axis[a].kind == 5 && !p->axis[a].chirp->fused)
+            p->workspace_bytes = std::max(p->workspace_bytes, (size_t)(p->total / p->axis[a].n * p->axis[a].chirp->m) * 8);
     if (workspace_bytes) *workspace_bytes = p->workspace_bytes;
     p->two_launch = rank == 3 && dims[0] == 256 && dims[1] == 256 && dims[2] == 256 && p->axis[0].kind == 3;
     if (p->two_launch) p->inplace_workspace_bytes = (size_t)p->total * 8;
@@ -1264,8 +1430,14 @@ int ig_fft_plan(ig_ctx* ctx, int rank, const int64_t* dims, int64_t batch, ig_ff
     for (int a = 0; a < rank; ++a) {
         const AxisPlan& ax = p->axis[a];
         if (ax.kind == 2) { snprintf(buf, sizeof(buf), "axis%d n=1 skip; ", a); p->desc += buf; continue; }
-        snprintf(buf, sizeof(buf), "axis%d n=%lld %s", a, (long long)ax.n, ax.kind == 0 ? "lds" : ax.kind == 3 ? "2stage" : ax.kind == 4 ? "AxB" : "generic");
+        snprintf(buf, sizeof(buf), "axis%d n=%lld %s", a, (long long)ax.n, ax.kind == 0 ? "lds" : ax.kind == 3 ? "2stage" : ax.kind == 4 ? "AxB" : ax.kind == 5 ? "chirp-z" : "generic");
         p->desc += buf;
+        if (ax.kind == 5) {
+            snprintf(buf, sizeof(buf), " m=%lld (%s, %s); ", (long long)ax.chirp->m, ax.chirp->sub.kind == 4 ? "AxB" : ax.chirp->sub.kind == 3 ? "2stage" : "lds",
+                     ax.chirp->fused ? "one fused launch" : "five steps");
+            p->desc += buf;
+            continue;
+        }
         if (ax.kind == 0 || ax.kind == 3 || ax.kind == 4) {
             snprintf(buf, sizeof(buf), " W=%d T=%d lds=%zuB radices=", ax.W, ax.T, ax.lds_bytes);
             p->desc += buf;
@@ -1333,13 +1505,12 @@ int ig_fft_exec(ig_fft* p, const void* xv, void* yv, int direction, void* worksp
     // (Measured and rejected: a volume-at-a-time schedule whose passes hand a 134 MB volume to each other through the 256 MB
     // Infinity Cache -- the kernels themselves ran 7 % faster on 256^3 x 16, but 48 small dependent launches lost more than
     // that in the gaps between them: 2.45 against 2.37 ms.)
-    for (int a = 0; a < p->rank; ++a) {
-        const AxisPlan& ax = p->axis[a];
-        if (ax.kind == 2) continue;
+    // one axis pass with a fast kernel (kinds 0, 3, 4), in -> out (in place allowed: a workgroup holds its columns before it stores)
+    auto fast_axis = [&](const AxisPlan& ax, const float2* in, float2* out, int inv, int a, double bytes) -> int {
         if (ax.kind == 3) {
-            ig_prof_scope prof(ctx, a == 0 ? "fft_2stage_axis0" : a == 1 ? "fft_2stage_axis1" : "fft_2stage_axis2", pass_bytes);
+            ig_prof_scope prof(ctx, a == 0 ? "fft_2stage_axis0" : a == 1 ? "fft_2stage_axis1" : "fft_2stage_axis2", bytes);
             PassDesc d{};
-            d.in = cur; d.out = y; d.w = nullptr;
+            d.in = in; d.out = out; d.w = nullptr;
             d.in_sj = d.out_sj = ax.inner; d.w_sj = 0;
             d.ncols = ax.inner * ax.outer;
             if (ax.inner == 1) {            // contiguous lines: the lines themselves are the tile's W columns
@@ -1348,26 +1519,73 @@ int ig_fft_exec(ig_fft* p, const void* xv, void* yv, int direction, void* worksp
                 d.ext0 = ax.inner; d.ext1 = ax.outer; d.in_s[0] = d.out_s[0] = 1; d.in_s[1] = d.out_s[1] = ax.inner * ax.n;
             }
             d.in_s[2] = d.out_s[2] = 0;
-            d.in_lo = d.out_lo = 0; d.in_hi = d.out_hi = (int)ax.n; d.inverse = inverse;
-            if (int rc = launch_2stage(ctx, ax, d, ax.inner == 1, 0)) return rc;
+            d.in_lo = d.out_lo = 0; d.in_hi = d.out_hi = (int)ax.n; d.inverse = inv;
+            return launch_2stage(ctx, ax, d, ax.inner == 1, 0);
+        }
+        if (ax.kind == 4) {
+            ig_prof_scope prof(ctx, a == 0 ? "fft_ab_axis0" : a == 1 ? "fft_ab_axis1" : "fft_ab_axis2", bytes);
+            return launch_ab(ctx, ax, in, out, inv);
+        }
+        IG_REQUIRE(ctx, ax.kind == 0, "ig_fft_exec: not a fast axis");
+        ig_prof_scope prof(ctx, a == 0 ? "fft_lds_axis0" : a == 1 ? "fft_lds_axis1" : "fft_lds_axis2", bytes);
+        const int64_t ncols = ax.inner * ax.outer;
+        const int64_t blocks = (ncols + ax.W - 1) / ax.W;
+        IG_REQUIRE(ctx, blocks <= 0x7fffffffLL, "ig_fft_exec: too many tiles");
+        const dim3 grid((unsigned)blocks), block((unsigned)(ax.W * ax.T));
+        if (ax.inner == 1)
+            hipLaunchKernelGGL(k_fft_lds<true>, grid, block, ax.lds_bytes, ctx->stream, in, out, ax.d_tw,
+                               (int)ax.n, ax.inner, ncols, ax.W, ax.T, ax.nstages, ax.rad, inv);
+        else
+            hipLaunchKernelGGL(k_fft_lds<false>, grid, block, ax.lds_bytes, ctx->stream, in, out, ax.d_tw,
+                               (int)ax.n, ax.inner, ncols, ax.W, ax.T, ax.nstages, ax.rad, inv);
+        IG_LAUNCH_CHECK(ctx, "k_fft_lds");
+        return IG_OK;
+    };
+    for (int a = 0; a < p->rank; ++a) {
+        const AxisPlan& ax = p->axis[a];
+        if (ax.kind == 2) continue;
+        if (ax.kind == 0 || ax.kind == 3 || ax.kind == 4) {
+            if (int rc = fast_axis(ax, cur, y, inverse, a, pass_bytes)) return rc;
             cur = y;
-        } else if (ax.kind == 4) {
-            ig_prof_scope prof(ctx, a == 0 ? "fft_ab_axis0" : a == 1 ? "fft_ab_axis1" : "fft_ab_axis2", pass_bytes);
-            if (int rc = launch_ab(ctx, ax, cur, y, inverse)) return rc;
-            cur = y;
-        } else if (ax.kind == 0) {
-            ig_prof_scope prof(ctx, a == 0 ? "fft_lds_axis0" : a == 1 ? "fft_lds_axis1" : "fft_lds_axis2", pass_bytes);
-            const int64_t ncols = ax.inner * ax.outer;
-            const int64_t blocks = (ncols + ax.W - 1) / ax.W;
-            IG_REQUIRE(ctx, blocks <= 0x7fffffffLL, "ig_fft_exec: too many tiles");
-            const dim3 grid((unsigned)blocks), block((unsigned)(ax.W * ax.T));
-            if (ax.inner == 1)
-                hipLaunchKernelGGL(k_fft_lds<true>, grid, block, ax.lds_bytes, ctx->stream, cur, y, ax.d_tw,
-                                   (int)ax.n, ax.inner, ncols, ax.W, ax.T, ax.nstages, ax.rad, inverse);
-            else
-                hipLaunchKernelGGL(k_fft_lds<false>, grid, block, ax.lds_bytes, ctx->stream, cur, y, ax.d_tw,
-                                   (int)ax.n, ax.inner, ncols, ax.W, ax.T, ax.nstages, ax.rad, inverse);
-            IG_LAUNCH_CHECK(ctx, "k_fft_lds");
+        } else if (ax.kind == 5) {
+            // chirp-z through the workspace: W holds the columns at length m
+            const Chirp& ch = *ax.chirp;
+            const int dir = inverse ? 1 : 0;
+            if (cur == work) {              // (an earlier generic axis left its result there)
+                IG_HIP(ctx, hipMemcpyAsync(y, cur, (size_t)p->total * 8, hipMemcpyDeviceToDevice, ctx->stream));
+                cur = y;
+            }
+            if (ch.fused) {
+                ig_prof_scope prof(ctx, a == 1 ? "fft_chirp_axis1" : "fft_chirp_axis2", pass_bytes);
+                PassDesc d{};
+                d.in = cur; d.in_sj = ax.inner; d.in_s[0] = 1; d.in_s[1] = ax.inner * ax.n;
+                d.out = y; d.out_sj = ax.inner; d.out_s[0] = 1; d.out_s[1] = ax.inner * ax.n;
+                d.ext0 = ax.inner; d.ext1 = ax.outer; d.ncols = ax.inner * ax.outer;
+                d.in_lo = d.out_lo = 0; d.in_hi = d.out_hi = (int)ax.n; d.inverse = inverse;
+                if (int rc = launch_chirp_desc(ctx, ax, d)) return rc;
+            } else {
+                const int64_t total_m = p->total / ax.n * ch.m;
+                int64_t g = (total_m + 255) / 256;
+                const int64_t cap = (int64_t)ctx->num_cu * 16;
+                if (g > cap) g = cap;
+                {
+                    ig_prof_scope prof(ctx, "fft_chirp_pre");
+                    hipLaunchKernelGGL(k_chirp_pre, dim3((unsigned)g), dim3(256), 0, ctx->stream, cur, work, ch.d_b[dir], ax.n, ch.m, ax.inner, total_m);
+                    IG_LAUNCH_CHECK(ctx, "k_chirp_pre");
+                }
+                if (int rc = fast_axis(ch.sub, work, work, 0, a, 0.0)) return rc;
+                {
+                    ig_prof_scope prof(ctx, "fft_chirp_mul");
+                    hipLaunchKernelGGL(k_chirp_mul, dim3((unsigned)g), dim3(256), 0, ctx->stream, work, ch.d_bhat[dir], ch.m, ax.inner, total_m);
+                    IG_LAUNCH_CHECK(ctx, "k_chirp_mul");
+                }
+                if (int rc = fast_axis(ch.sub, work, work, 1, a, 0.0)) return rc;
+                {
+                    ig_prof_scope prof(ctx, "fft_chirp_post");
+                    hipLaunchKernelGGL(k_chirp_post, dim3((unsigned)g), dim3(256), 0, ctx->stream, (const float2*)work, y, ch.d_bout[dir], ax.n, ch.m, ax.inner, p->total);
+                    IG_LAUNCH_CHECK(ctx, "k_chirp_post");
+                }
+            }
             cur = y;
         } else {
             int64_t Ns = 1;
@@ -1421,7 +1639,11 @@ int ig_fft_plan_padded(ig_ctx* ctx, const int64_t* dims, const int64_t* box_lo, 
     if (rc != IG_OK) return rc;
     ig_fft* p = *plan;
     for (int a = 0; a < 3; ++a) {
-        const bool ab_ok = p->axis[a].kind == 4 && abd_supported(dims[a]) && grid_layout == 2 && batch >= 2;
+        // chirp-z axes (a prime factor above 7: 277, 410 ...) take the unweighted strided passes, i.e. the y and z axes of the
+        // coil-interleaved layout; no k-space support table on such a grid
+        const bool cz_ok = p->axis[a].kind == 5 && p->axis[a].chirp->sub.kind == 4 && a >= 1 && grid_layout == 2 && batch >= 2;
+        if (cz_ok) p->axis[a].chirp->fused = true;
+        const bool ab_ok = (p->axis[a].kind == 4 && abd_supported(dims[a]) && grid_layout == 2 && batch >= 2) || cz_ok;
         if (p->axis[a].kind != 3 && !ab_ok) {
             ig_fft_destroy(p);
             *plan = nullptr;
@@ -1431,7 +1653,8 @@ int ig_fft_plan_padded(ig_ctx* ctx, const int64_t* dims, const int64_t* box_lo, 
                            "splits as A x B with A, B <= 32", a, (long long)dims[a]);
         }
         if (ab_ok) p->has_ab_axis = true;
-        if (a == 2) { p->zw_in = ab_ok ? p->axis[a].ab_B : 16; p->zw_out = ab_ok ? p->axis[a].ab_A : 16; }
+        if (a == 2) { p->zw_in = cz_ok ? 0 : ab_ok ? p->axis[a].ab_B : 16; p->zw_out = cz_ok ? 0 : ab_ok ? p->axis[a].ab_A : 16; }
+        if (cz_ok) p->has_chirp_axis = true;
         p->box_lo[a] = box_lo[a];
         p->box_dims[a] = box_dims[a];
     }
@@ -1673,10 +1896,26 @@ int ig_fft_support_words(int64_t n, int* zw_in, int* zw_out) {
     return ig_fail(nullptr, IG_ERR_UNSUPPORTED, "ig_fft_support_words: no zero-pad-aware z pass for an axis of %lld points", (long long)n);
 }
 
+int ig_fft_padded_axis_kind(int64_t n, int* kind) {
+    if (!kind || n < 1) return ig_fail(nullptr, IG_ERR_ARG, "ig_fft_padded_axis_kind: bad arguments");
+    int A = 0, B = 0;
+    *kind = 0;
+    if (n == 256 || n == 512) { *kind = 3; return IG_OK; }
+    if (abd_supported(n)) { *kind = 4; return IG_OK; }
+    // chirp-z: a length with a prime factor above 7 whose 2 n - 1 is covered by an A x B length
+    std::vector<int64_t> f;
+    factor_generic(n, f);
+    int64_t big = 1;
+    for (int64_t r : f) big = std::max(big, r);
+    if (big > 7 && n >= 32)
+        for (int64_t c = 2 * n - 1; c <= 1024; ++c) if (ab_split(c, A, B)) { *kind = 5; break; }
+    return IG_OK;
+}
+
 int ig_fft_set_support_tile(ig_fft* p, int tile) {
     if (!p) return ig_fail(nullptr, IG_ERR_ARG, "ig_fft_set_support_tile: plan is NULL");
     ig_ctx* ctx = p->ctx;
-    IG_REQUIRE(ctx, p->padded && p->layout == 2, "ig_fft_set_support_tile: a zero-padded plan of the coil-interleaved layout");
+    IG_REQUIRE(ctx, p->padded && p->layout == 2 && !p->has_chirp_axis, "ig_fft_set_support_tile: a zero-padded plan of the coil-interleaved layout without a chirp-z axis");
     IG_REQUIRE(ctx, (tile == 2 || tile == 4 || tile == 8 || tile == 16) && p->batch * tile >= 16 && p->dims[0] % tile == 0,
                "ig_fft_set_support_tile: tile %d (2, 4, 8 or 16 kx points; coils * tile >= 16)", tile);
     p->support_tile = tile;
@@ -1691,7 +1930,7 @@ int ig_fft_exec_padded(ig_fft* p, const void* xv, int64_t x_bstride, const void*
     IG_REQUIRE(ctx, xv && yv, "ig_fft_exec_padded: NULL array");
     IG_REQUIRE(ctx, p->layout == 0 || workspace, "ig_fft_exec_padded: grid layouts 1 and 2 need the workspace");
     if (int rc = ig_set_device(ctx)) return rc;
-    IG_REQUIRE(ctx, !support || p->layout >= 1, "ig_fft_exec_padded: a support table needs grid layout 1 or 2");
+    IG_REQUIRE(ctx, !support || (p->layout >= 1 && !p->has_chirp_axis), "ig_fft_exec_padded: a support table needs grid layout 1 or 2 and no chirp-z axis");
     if (p->layout == 2)
         return exec_padded_layout2(p, (const float2*)xv, x_bstride, (const float2*)wv, (float2*)yv, (float2*)workspace,
                                    (const short2*)support);
@@ -1743,7 +1982,7 @@ int ig_fft_exec_cropped(ig_fft* p, const void* yv, const void* wv, void* xv, int
     IG_REQUIRE(ctx, p->padded, "ig_fft_exec_cropped: plan was not made by ig_fft_plan_padded");
     IG_REQUIRE(ctx, xv && yv && workspace, "ig_fft_exec_cropped: NULL array");
     if (int rc = ig_set_device(ctx)) return rc;
-    IG_REQUIRE(ctx, !support || p->layout >= 1, "ig_fft_exec_cropped: a support table needs grid layout 1 or 2");
+    IG_REQUIRE(ctx, !support || (p->layout >= 1 && !p->has_chirp_axis), "ig_fft_exec_cropped: a support table needs grid layout 1 or 2 and no chirp-z axis");
     if (p->layout == 2)
         return exec_cropped_layout2(p, (const float2*)yv, (const float2*)wv, (float2*)xv, (float2*)workspace,
                                     (const short2*)support);
@@ -1808,6 +2047,7 @@ int ig_fft_exec_cropped_sum(ig_fft* p, const void* yv, const void* wv, void* xv,
     ig_ctx* ctx = p->ctx;
     IG_REQUIRE(ctx, p->padded && p->layout == 2, "ig_fft_exec_cropped_sum: needs a plan of ig_fft_plan_padded with grid_layout 2");
     IG_REQUIRE(ctx, xv && yv && wv && workspace, "ig_fft_exec_cropped_sum: NULL array");
+    IG_REQUIRE(ctx, !support || !p->has_chirp_axis, "ig_fft_exec_cropped_sum: no support table on a grid with a chirp-z axis");
     if (int rc = ig_set_device(ctx)) return rc;
     return exec_cropped_layout2(p, (const float2*)yv, (const float2*)wv, (float2*)xv, (float2*)workspace,
                                 (const short2*)support, true);
@@ -1822,6 +2062,7 @@ int ig_fft_exec_cropped_sum_slab(ig_fft* p, const void* yv, const void* wv, void
     IG_REQUIRE(ctx, phase == 0 || phase == 1, "ig_fft_exec_cropped_sum_slab: phase must be 0 (z pass) or 1 (y and x passes of a slab)");
     IG_REQUIRE(ctx, phase == 0 || (0 <= z0 && z0 <= z1 && z1 <= p->box_dims[2]),
                "ig_fft_exec_cropped_sum_slab: slab [%lld, %lld) outside the image's %lld planes", (long long)z0, (long long)z1, (long long)p->box_dims[2]);
+    IG_REQUIRE(ctx, !support || !p->has_chirp_axis, "ig_fft_exec_cropped_sum_slab: no support table on a grid with a chirp-z axis");
     if (int rc = ig_set_device(ctx)) return rc;
     return exec_cropped_layout2(p, (const float2*)yv, (const float2*)wv, (float2*)xv, (float2*)workspace,
                                 (const short2*)support, true, phase == 0 ? 1 : 2, z0, z1);

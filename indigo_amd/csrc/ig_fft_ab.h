@@ -27,6 +27,8 @@
 // and stores the sum once, through the addressing of sub-column 0.
 struct PassDesc {
     const float2* in; float2* out; const float2* w;
+    // chirp-z passes (k_fft_chirp): w and w2 are ONE-dimensional tables along the transform axis (no column dependence)
+    const float2* w2;
     int64_t in_sj, out_sj, w_sj;
     int64_t in_s[3], out_s[3], w_s[3];
     int64_t ext0, ext1, ncols;
@@ -427,6 +429,119 @@ k_fft_ab_desc(PassDesc d, const float2* __restrict__ tw) {
             }
         }
     }
+}
+
+// ---- chirp-z (Bluestein) pass in ONE launch: an axis of n points with a prime factor above 7 (277, 410 = 2 * 5 * 41: what
+// int(N * osf) of the reference's driver produces, indigo/backends/backend.py:427-430) as a cyclic convolution of length
+// m = A * B >= 2 n - 1,
+//      X_k = b_k sum_j (x_j b_j) conj(b)_{k - j},      b_j = exp(-i pi j^2 / n),
+// i.e. F_m^-1( F_m(x b) . F_m(conj b) ) times b.  Both length-m transforms run back to back in the registers and the LDS of the
+// workgroup that holds the column -- a column is read once (n elements) and written once (n elements), like any other axis pass;
+// the length-m intermediates never reach memory.  The OUTPUT layout of the (A, B) split -- thread k1 < A holds X[k1 + A k2] --
+// is the INPUT layout of the (B, A) split -- thread b' < A holds x[b' + A a'] --, so the second transform is the same two-stage
+// scheme with the roles of A and B exchanged: B-point DFTs on the A threads that hold the first result, one exchange, A-point
+// DFTs on all B threads, whose outputs k1' + B k2' land where the first transform's inputs came from.
+//   d.w   b_j        (m entries; inputs j >= n are zeros that are never loaded: the input box must lie inside [0, n))
+//   d.w2  F_m of the wrapped conjugate chirp (m entries), then b_k / m (m entries): tables of the direction d.inverse asks for
+// Boxes as everywhere: inputs outside [in_lo, in_hi) are not read, outputs outside [out_lo, out_hi) (inside [0, n)) not stored.
+template <int A, int B, int ROUNDS>
+__global__ void __launch_bounds__(AB_W * B)
+k_fft_chirp(PassDesc d, const float2* __restrict__ tw) {
+    constexpr int N = A * B, AR = (A + ROUNDS - 1) / ROUNDS, BR = (B + ROUNDS - 1) / ROUNDS;
+    static_assert(A <= 32 && B <= 32 && A <= B, "element masks are 32-bit words");
+    constexpr int EX1 = AR * B * AB_W, EX2 = BR * A * AB_W;
+    extern __shared__ float2 lds[];
+    float2* __restrict__ tws = lds + (EX1 > EX2 ? EX1 : EX2);
+    const int tid = threadIdx.x;
+    for (int k = tid; k < N; k += AB_W * B) tws[k] = tw[k];
+    const int b = tid / AB_W, w = tid % AB_W;
+    const unsigned tile = blockIdx.x;
+    const unsigned tr = tile % d.tpr, rest = tile / d.tpr;
+    const unsigned k1i = rest % d.ext1, k2i = rest / d.ext1;
+    const int64_t k0u = (int64_t)tr * AB_W;
+    const float2* const b_in = d.in + (k0u * d.in_s[0] + (int64_t)k1i * d.in_s[1] + (int64_t)k2i * d.in_s[2]);
+    float2* const b_out = d.out + (k0u * d.out_s[0] + (int64_t)k1i * d.out_s[1] + (int64_t)k2i * d.out_s[2]);
+    const bool valid = k0u + w < d.ext0;
+    unsigned l_in = ((unsigned)w * (unsigned)d.in_s[0] + (unsigned)b * (unsigned)d.in_sj) * 8u;
+    unsigned l_out = ((unsigned)w * (unsigned)d.out_s[0] + (unsigned)b * (unsigned)d.out_sj) * 8u;
+    if (!valid) l_in = l_out = IG_OOB;
+    auto below = [](int h) -> uint32_t { return h >= 32 ? 0xffffffffu : ((1u << h) - 1u); };
+    // input j = b + B a <-> bit a; output k = b + B k2 (k2 < A) <-> bit k2
+    const uint32_t ibits = below(ab_ceil_div_clamp(d.in_hi - b, B, A)) & ~below(ab_ceil_div_clamp(d.in_lo - b, B, A));
+    const uint32_t obits = below(ab_ceil_div_clamp(d.out_hi - b, B, A)) & ~below(ab_ceil_div_clamp(d.out_lo - b, B, A));
+    uint32_t gin = 0, gout = 0;
+#pragma unroll
+    for (int l = 0; l < 64; l += AB_W) { gin |= (uint32_t)__builtin_amdgcn_readlane((int)ibits, l); gout |= (uint32_t)__builtin_amdgcn_readlane((int)obits, l); }
+    const float2* __restrict__ t_b = d.w;
+    const float2* __restrict__ t_hat = d.w2;
+    const float2* __restrict__ t_out = d.w2 + N;
+    auto cm = [](float2 a, float2 c) { return make_float2(fmaf(a.x, c.x, -a.y * c.y), fmaf(a.x, c.y, a.y * c.x)); };
+
+    // ---- first transform, (A, B): v_j = x_j b_j
+    float2 v[A];
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+        if (!((gin >> a) & 1u)) { v[a] = make_float2(0.f, 0.f); continue; }
+        const unsigned off = (unsigned)__builtin_amdgcn_sbfe((int)~ibits, a, 1);
+        v[a] = cm(buf_ld<true>(make_rsrc(b_in + (int64_t)(B * a) * d.in_sj), l_in | off, 0), t_b[b + B * a]);
+    }
+    RegDFT<A>::run(v);
+    __syncthreads();                                   // the twiddle table is in place
+#pragma unroll
+    for (int k1 = 1; k1 < A; ++k1) v[k1] = cm(v[k1], tws[b * k1]);
+    float2 u[B];                                       // threads b < A: U[b + A k2] after the first transform
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        if (r) __syncthreads();
+#pragma unroll
+        for (int k1 = 0; k1 < A; ++k1)
+            if (k1 >= r * AR && k1 < (r + 1) * AR) lds[ab_slot<AR, B, false>(k1 - r * AR, b, w)] = v[k1];
+        __syncthreads();
+        if (b >= r * AR && b < (r + 1) * AR && b < A) {
+#pragma unroll
+            for (int bb = 0; bb < B; ++bb) u[bb] = lds[ab_slot<AR, B, false>(b - r * AR, bb, w)];
+        }
+    }
+    // ---- the convolution in the frequency domain, and the second (inverse) transform, (B, A): conj, forward, conj
+    if (b < A) {
+        RegDFT<B>::run(u);
+#pragma unroll
+        for (int k2 = 0; k2 < B; ++k2) { u[k2] = cm(u[k2], t_hat[b + A * k2]); u[k2].y = -u[k2].y; }
+        RegDFT<B>::run(u);                             // thread b' = b < A holds the B inputs b' + A a'
+#pragma unroll
+        for (int k1 = 1; k1 < B; ++k1) u[k1] = cm(u[k1], tws[b * k1]);       // w_m^(b' k1')
+    }
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        __syncthreads();                               // (the previous exchange has been read)
+        if (b < A) {
+#pragma unroll
+            for (int k1 = 0; k1 < B; ++k1)
+                if (k1 >= r * BR && k1 < (r + 1) * BR) lds[ab_slot<BR, A, false>(k1 - r * BR, b, w)] = u[k1];
+        }
+        __syncthreads();
+        if (b >= r * BR && b < (r + 1) * BR) {         // stage 2 on all B threads: output residue k1' = b
+            float2 y[A];
+#pragma unroll
+            for (int bb = 0; bb < A; ++bb) y[bb] = lds[ab_slot<BR, A, false>(b - r * BR, bb, w)];
+            RegDFT<A>::run(y);
+#pragma unroll
+            for (int k2 = 0; k2 < A; ++k2) {           // X[b + B k2], k2 < A: only k < n is ever kept
+                if (!((gout >> k2) & 1u)) continue;
+                float2 e = y[k2];
+                e.y = -e.y;
+                e = cm(e, t_out[b + B * k2]);
+                const unsigned off = (unsigned)__builtin_amdgcn_sbfe((int)~obits, k2, 1);
+                buf_st<true>(make_rsrc(b_out + (int64_t)(B * k2) * d.out_sj), l_out | off, 0, e);
+            }
+        }
+    }
+}
+template <int A, int B, int ROUNDS>
+constexpr size_t chirp_lds_bytes() {
+    constexpr int AR = (A + ROUNDS - 1) / ROUNDS, BR = (B + ROUNDS - 1) / ROUNDS;
+    constexpr int EX1 = AR * B * AB_W, EX2 = BR * A * AB_W;
+    return ((size_t)(EX1 > EX2 ? EX1 : EX2) + (size_t)A * B) * 8;
 }
 
 }  // namespace anyfft

@@ -110,6 +110,9 @@ def support_words(backend, oN):
     f = getattr(backend, 'support_words', None)
     if f is None or int(oN[0]) % 16:
         return None
+    kind = getattr(backend, 'padded_axis_kind', None)
+    if kind is not None and any(kind(int(n)) == 5 for n in oN):      # a chirp-z axis: its passes know no table
+        return None
     return f(int(oN[2]))
 
 
@@ -120,6 +123,14 @@ def split_support(table, oN, tile=16, zw_in=16):
     table = np.ascontiguousarray(table, dtype=np.int16).reshape(-1)
     a, b = 2 * n1 * nt, 2 * (n1 * nt + nt)
     return table[:a].reshape(-1, 2), table[a:b].reshape(-1, 2), table[b:b + 2 * n1 * nt * zw_in].view(np.uint32).reshape(n1 * nt, zw_in)
+
+
+def pow2_divisor(n, cap):
+    """the largest power of two <= cap that divides n"""
+    b = int(cap)
+    while b > 1 and int(n) % b:
+        b //= 2
+    return max(b, 1)
 
 
 def coil_chunks(Cn, chunk=8):
@@ -163,18 +174,22 @@ def assemble(backend, Gm, oN, N, weights_of, Cn, layout, chunks, table=None, box
             G._grid_support_fine = fine
         if row_order is not None:
             G._row_order = row_order
-        elif interleaved and bricks_cols in tuning.get('bricks', ()) and int(oN[2]) % 4 == 0 and int(oN[1]) % 4 == 0:
+        elif interleaved and bricks_cols in tuning.get('bricks', ()) and int(oN[0]) % 16 == 0:
             # adjoint gridding by grid bricks (a scatter binned on the host) instead of a gather over the transposed matrix.
             # Measured (config 4): 8 coils 0.91 ms against 1.82 ms (gather + its deferred long rows); 4 coils 0.68 against
             # 1.05 ms.  Two coils or one would pad every sample's share of a brick to 32 / 64 entries: they keep the gather.
             shape = tuning.get('brick_shape', {})
             shape = shape.get(bricks_cols, (2, 2, 4096, 4096)) if isinstance(shape, dict) else shape
-            G._grid_bricks = (int(oN[0]), int(oN[2]), int(oN[1]), bricks_cols) + tuple(shape)
-        elif (bricks_cols if interleaved else ncols) in tuning.get('slots', ()) and int(oN[2]) % 4 == 0 and int(oN[1]) % 4 == 0 and int(oN[0]) % 16 == 0:
+            # bricks of 16 x bm x bs cells must tile the grid: halve a side until it divides (277 x 410, the reference driver's
+            # default grid: 16 x 2 x 1)
+            G._grid_bricks = (int(oN[0]), int(oN[2]), int(oN[1]), bricks_cols, pow2_divisor(oN[2], shape[0]), pow2_divisor(oN[1], shape[1])) + tuple(shape[2:])
+        elif (bricks_cols if interleaved else ncols) in tuning.get('slots', ()) and int(oN[0]) % 16 == 0:
             # 1, 2 (or 4) columns: the same scatter with SLOTS in place of rounds (ig_ccsrmm_t_slots) -- no padding, no G'^T.
             # (per-coil layout: only for a chunk of exactly that many coils -- a 3-, 5-, 6- or 7-coil tree never takes the
             # route, and the format is 16 bytes per nonzero of HBM plus its host passes)
-            G._grid_slots = (int(oN[0]), int(oN[2]), int(oN[1]), bricks_cols if interleaved else ncols) + tuple(tuning.get('slot_shape', (4, 4, 256, 64)))
+            sshape = tuple(tuning.get('slot_shape', (4, 4, 256, 64)))
+            G._grid_slots = (int(oN[0]), int(oN[2]), int(oN[1]), bricks_cols if interleaved else ncols,
+                             pow2_divisor(oN[2], sshape[0]), pow2_divisor(oN[1], sshape[1])) + sshape[2:]
         return G
 
     sizes = {hi - lo for lo, hi in chunks if hi - lo > 1}

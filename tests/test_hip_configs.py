@@ -440,6 +440,41 @@ def test_padded_transforms_on_non_power_of_two_grids_vs_numpy(hip, grid, box, C)
     hip._scratch = None
 
 
+def test_padded_transforms_with_chirp_z_axes_vs_numpy(hip):
+    """the reference driver's default oversampling (640/480, examples/pics.py:86) on a 240 x 104 x 154 image: grid 320 x 138 x 205
+    -- 138 = 2 * 3 * 23 and 205 = 5 * 41 run as chirp-z passes inside the fused leaf (two launches of the A x B kernel each, no
+    support table).  fft_padded against numpy, the cropped transforms against their closed forms and numpy"""
+    grid, box, C = (320, 138, 205), (240, 104, 154), 4
+    assert hip.supports_padded_fft(grid, C) and hip.padded_axis_kind(138) == 5 and hip.padded_axis_kind(205) == 5
+    assert not hip.supports_padded_fft((138, 320, 205), C)          # the x axis carries the weights: no chirp-z there
+    lo = tuple(m // 2 + int(np.ceil(-n / 2)) for m, n in zip(grid, box))
+    P, N = int(np.prod(grid)), int(np.prod(box))
+    hip._scratch = None
+    x = rand64c(N, 1, seed=1)
+    w = rand64c(N, C, seed=2)
+    w_d = hip.copy_array(np.ascontiguousarray(w).reshape(-1))
+    sl = tuple(slice(l, l + b) for l, b in zip(lo, box))
+    ws = hip.zero_array((hip._fft_padded_workspace(grid, lo, box, C, 2) // 8,), C64)
+    y_d = hip.copy_array(np.full((P, C), np.nan, dtype=C64, order='F'))
+    hip.fft_padded(y_d, hip.copy_array(x), w_d, grid, lo, box, ws, 2)
+    y = y_d.to_host().reshape(-1, order='F').reshape((C, grid[0], grid[2], grid[1]), order='F')        # (c, x, z, y)
+    for c in (0, C - 1):
+        full = np.zeros(grid, dtype=C64, order='F')
+        full[sl] = (w[:, c] * x[:, 0]).reshape(box, order='F')
+        assert rel_err(y[c].transpose(0, 2, 1), np.fft.fftn(full)) < RTOL, c
+    xs_d = hip.copy_array(np.full((N, 1), np.nan, dtype=C64, order='F'))
+    hip.ifft_cropped_sum(xs_d, y_d, w_d, grid, lo, box, ws)
+    assert rel_err(xs_d.to_host(), P * (np.abs(w) ** 2).sum(axis=1, keepdims=True) * x) < RTOL
+    g = rand64c(P, C, seed=3)
+    g_d = hip.copy_array(np.ascontiguousarray(g).reshape(-1)).reshape((P, C))
+    xc_d = hip.copy_array(np.full((N, C), np.nan, dtype=C64, order='F'))
+    hip.ifft_cropped(xc_d, g_d, w_d, grid, lo, box, ws, 2)
+    vol = g[:, 1].reshape((grid[0], grid[2], grid[1]), order='F').transpose(0, 2, 1)
+    ref = (np.fft.ifftn(vol) * P)[sl].reshape(-1, order='F') * np.conj(w[:, 1])
+    assert rel_err(xc_d.to_host().reshape(-1, order='F').reshape(N, C)[:, 1], ref) < RTOL
+    hip._scratch = None
+
+
 @pytest.mark.parametrize("C", [4, 8])
 def test_sense_on_the_reference_drivers_grid_vs_oracle(hip, oracle_backend, C):
     """image 256^3 on a 320^3 grid (oversampling 1.25, the reference driver's choice of grid, examples/pics.py:87-90): the fused

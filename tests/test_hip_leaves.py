@@ -553,7 +553,9 @@ def test_fft_shapes(hip, shape):
     _check_fft(hip, tuple(shape), 3, seed=sum(shape))
 
 
-AB_LENGTHS = [160, 192, 224, 240, 270, 288, 320, 360, 384, 392, 400, 432, 480, 576, 600, 640]
+AB_LENGTHS = [160, 192, 224, 240, 270, 288, 320, 360, 384, 392, 400, 432, 480, 576, 600, 640,
+              # further lengths of the generated list (tools/gen_ab_list.py): odd ones, 5 x 25, the longest splits (four exchange rounds)
+              96, 105, 125, 147, 243, 375, 441, 567, 625, 675, 729, 840, 1000 - 40, 1024]
 
 
 @pytest.mark.parametrize("n", AB_LENGTHS)
@@ -582,6 +584,42 @@ def test_fft_two_stage_any_length_3d_and_lds_agreement(hip, monkeypatch):
     z_d = other.zero_array(x.shape, C64)
     other.fftn(z_d, other.copy_array(x))
     assert rel_err(z_d.to_host(), y_d.to_host()) < 1e-6
+
+
+@pytest.mark.parametrize("n", [277, 410, 139, 1009, 69, 102, 205, 2 * 1009, 37 * 11])
+def test_fft_chirp_z_lengths(hip, n):
+    """lengths with a prime factor above 7 -- what int(N * osf) of the reference's driver produces (208 -> 277, 308 -> 410:
+    indigo/backends/backend.py:427-430) -- run as chirp-z (Bluestein) transforms over a smooth length m >= 2 n - 1: two fused
+    launches of the A x B kernel on strided axes (m <= 1024), five steps on contiguous lines and for longer m; against numpy:
+    contiguous lines (ragged tile), strided middle and last axes, 3-D with two chirp-z axes, forward + inverse + in place;
+    and against the one-stage-per-launch kernel"""
+    from indigo_amd.backends import get_backend
+    assert "chirp-z" in hip.fft_describe((n, 3)), hip.fft_describe((n, 3))
+    _check_fft(hip, (n,), 5, seed=n)
+    _check_fft(hip, (6, n), 3, seed=n + 1)
+    _check_fft(hip, (32, n), 2, seed=n + 2)               # 32 lanes of columns: the fused route where m <= 1024
+    _check_fft(hip, (20, 3, n), 2, seed=n + 3)
+    if n <= 512:
+        _check_fft(hip, (48, n, 5), 2, seed=n + 4)
+        assert "one fused launch" in hip.fft_describe((48, n, 5, 2))
+    x = rand64c(16, n, 3, seed=n + 5)
+    y_d = hip.zero_array(x.shape, C64)
+    hip.fftn(y_d, hip.copy_array(x))
+    other = get_backend("hip")
+    other.set_option("fft.kernels", 2)
+    assert "chirp-z" not in other.fft_describe(x.shape)
+    z_d = other.zero_array(x.shape, C64)
+    other.fftn(z_d, other.copy_array(x))
+    assert rel_err(z_d.to_host(), y_d.to_host()) < 2e-6
+
+
+def test_fft_two_chirp_z_axes_of_the_reference_drivers_default_grid(hip):
+    """(160, 69, 102) and (320, 138, 205): the default oversampling 640/480 of examples/pics.py:86 on images 120 x 52 x 77 and
+    240 x 104 x 154 -- one A x B axis and two chirp-z axes in one transform"""
+    for shape in ((160, 69, 102), (320, 138, 205)):
+        d = hip.fft_describe(shape + (2,))
+        assert d.count("chirp-z") == 2 and "AxB" in d, d
+        _check_fft(hip, shape, 2, seed=shape[1])
 
 
 def test_fft_generic_path_matches_lds_path(hip, monkeypatch):

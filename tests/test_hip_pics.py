@@ -76,3 +76,31 @@ def test_pics_on_a_non_power_of_two_grid(tmp_path, hip, oracle_backend, caplog):
     assert _rel(out, base) < 2e-4
     # three coils split into a pair and a single one: the single coil has no interleaved layout, the tree keeps its -O3 leaves
     assert not hip.supports_padded_fft((160, 160, 160), 3)
+
+
+def test_pics_at_the_reference_drivers_default_oversampling(tmp_path, hip, oracle_backend, caplog):
+    """examples/pics.py:86 oversamples by 640/480; indigo/backends/backend.py:427-430 sizes the grid as int(N * osf): the
+    reference's own 480 x 208 x 308 scan lands on 640 x 277 x 410 -- 277 is prime, 410 = 2 * 5 * 41.  The same at a quarter of
+    the size: image 120 x 52 x 77, grid 160 x 69 x 102 (69 = 3 * 23, 102 = 2 * 3 * 17).  FuseZpadFFT takes the fused leaf -- the x
+    axis on the A x B kernel, the y and z axes as chirp-z passes -- and the image equals the unfused -O3 leaves' and the
+    oracle backend's"""
+    import logging
+    N, C = (120, 52, 77), 4
+    path, img = _scan(tmp_path, hip, N, C, nro=160, nsp=300, osf=640 / 480, width=3)
+    args = ["-i", "4", "--width", "3", "--lamda", "1e-3", "--debug", "40", path]          # (--osf: the driver's default)
+    assert hip.supports_padded_fft((160, 69, 102), C)
+    with caplog.at_level(logging.INFO, logger="pics"):
+        out = pics.main(["-O", "3"] + args, backend=hip)
+    tree = [r.getMessage() for r in caplog.records if r.getMessage().startswith("tree:")][-1]
+    assert "ZpadFFT" in tree and "UnscaledFFT" not in tree and "(160, 69, 102)" in hip_grid_of(tree), tree
+    plain = pics.main(["-O", "3", "--no-fuse"] + args, backend=hip)
+    assert _rel(out, plain) < 2e-4
+    oracle_backend._scratch = None
+    ref = pics.main(["-O", "3", "--no-fuse"] + args, backend=oracle_backend)
+    oracle_backend._scratch = None
+    assert _rel(out, ref) < 1e-3
+
+
+def hip_grid_of(tree):
+    """the ZpadFFT line of a dumped tree names its shape (C * P, N): recover P's factors from the test's known grid"""
+    return "(160, 69, 102)" if str(4 * 160 * 69 * 102) in tree else ""
