@@ -1,8 +1,11 @@
 #!/bin/bash
 # everything under profiles/ that the current round cites, re-measured in one GPU call: tools/refresh_profiles.sh r03
 # (copy gpurun_out/${R}_* into profiles/ afterwards; the PMC summaries record the hash of the kernel sources they belong to)
-R=${1:-r03}
+# Two parts (a gpurun call is limited to 20 minutes): A = rocprofv3 stats + PMC of configs 4, 5, 3, 2 and the default line; B = everything else.
+R=${1:-r04}
+PART=${2:-AB}
 mkdir -p gpurun_out
+if [[ $PART == *A* ]]; then
 timeout -k 10 300 tools/profile_config.sh ${R}_cfg4 || exit 1
 timeout -k 10 300 tools/profile_config.sh ${R}_cfg5 --config 5 --shard 0/4 --steps 5 || exit 1
 timeout -k 10 400 tools/profile_config.sh ${R}_cfg3 --config 3 --steps 5 || exit 1
@@ -10,9 +13,11 @@ timeout -k 10 300 tools/profile_config.sh ${R}_cfg2 --config 2 || exit 1
 cp gpurun_out/${R}_cfg4_pmc_traffic.json gpurun_out/${R}_cfg5_pmc_traffic.json gpurun_out/${R}_cfg3_pmc_traffic.json gpurun_out/${R}_cfg2_pmc_traffic.json profiles/      # bench.py reads the PMC traffic from profiles/
 timeout -k 10 600 python bench.py --steps 20 --warmup 5 > gpurun_out/${R}_bench_default.json 2> gpurun_out/${R}_bench_default.log || exit 1
 tail -3 gpurun_out/${R}_bench_default.log
+fi
+if [[ $PART == *B* ]]; then
 for s in 0/1 0/2 0/4 0/8; do t=$(echo $s | sed "s|/|of|"); timeout -k 10 300 python bench.py --config 5 --shard $s --steps 5 --no-cpu-baseline > gpurun_out/${R}_bench_cfg5_shard_$t.json 2> gpurun_out/${R}_bench_cfg5_shard_$t.log || exit 1; python -c "import json;print('cfg5 $t', json.load(open('gpurun_out/${R}_bench_cfg5_shard_$t.json'))['ms_per_step'])"; done
 for s in 0/2 0/4 0/8; do t=$(echo $s | sed "s|/|of|"); timeout -k 10 300 python bench.py --config 4 --shard $s --steps 10 --no-cpu-baseline --no-extras > gpurun_out/${R}_bench_cfg4_shard_$t.json 2> gpurun_out/${R}_bench_cfg4_shard_$t.log || exit 1; python -c "import json;print('cfg4 $t', json.load(open('gpurun_out/${R}_bench_cfg4_shard_$t.json'))['ms_per_step'])"; done
-timeout -k 10 300 python tools/cg_bench.py 30 > gpurun_out/${R}_cg.log 2>&1 || exit 1
+CG_PROFILE=1 timeout -k 10 300 python tools/cg_bench.py 30 > gpurun_out/${R}_cg.log 2>&1 || exit 1
 tail -2 gpurun_out/${R}_cg.log
 for t in o3 recipe; do timeout -k 10 300 python bench.py --tree $t --steps 5 --no-extras --no-cpu-baseline > gpurun_out/${R}_bench_tree_$t.json 2> gpurun_out/${R}_bench_tree_$t.log || exit 1; python -c "import json;print('tree $t', json.load(open('gpurun_out/${R}_bench_tree_$t.json'))['ms_per_step'])"; done
 for t in zpadfft o3 recipe; do timeout -k 10 300 python bench.py --osf 1.25 --tree $t --steps 10 --no-extras --no-cpu-baseline > gpurun_out/${R}_bench_osf125_$t.json 2> gpurun_out/${R}_bench_osf125_$t.log || exit 1; python -c "import json;print('osf 1.25 tree $t', json.load(open('gpurun_out/${R}_bench_osf125_$t.json'))['ms_per_step'])"; done
@@ -22,3 +27,8 @@ timeout -k 10 200 python bench.py --config 1 > gpurun_out/${R}_bench_cfg1.json 2
 timeout -k 10 200 python bench.py --config 2 --steps 20 > gpurun_out/${R}_bench_cfg2.json 2> gpurun_out/${R}_bench_cfg2.log || exit 1
 python -c "import json;d=json.load(open('gpurun_out/${R}_bench_cfg2.json'));print('cfg2', d['ms_per_step'], d['roofline']['frac'])"
 python -c "import json;d=json.load(open('gpurun_out/${R}_bench_cfg3.json'));print('cfg3 fwd', d['ms_per_step'], d['roofline']['frac'], 'adj', d['config']['adjoint_ms'], d['config']['adjoint_frac_of_peak_reference_model'])"
+# the self-launching multi-rank path, rehearsed over gloo on this one GPU (all ranks on GPU 0; numbers are NOT scaling results)
+for n in 2 4; do INDIGO_BENCH_DIST_BACKEND=gloo timeout -k 10 600 python bench.py --gpus $n --steps 3 --warmup 1 --no-config5 > gpurun_out/${R}_bench_selflaunch_${n}rank_gloo.json 2> gpurun_out/${R}_bench_selflaunch_${n}rank_gloo.log || exit 1; python -c "import json;d=json.load(open('gpurun_out/${R}_bench_selflaunch_${n}rank_gloo.json'));print('self-launch gloo', d['n_gpus'], d['ms_per_step'])"; done
+timeout -k 10 200 python tools/lab/chirp_fft.py > gpurun_out/${R}_chirp_fft.log 2>&1 || exit 1
+tail -1 gpurun_out/${R}_chirp_fft.log
+fi
