@@ -322,6 +322,21 @@ int  ig_ccsrmm_xrows(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, int64_t nnz,
                      void* Y, int64_t ldy,
                      const int32_t* xrows, int64_t nxrows);
 
+/* The same product for 64 panel columns through the RUN format of A' (rows of A' in runs of 16, the nonzeros of a run grouped by
+ * column: a run of 16 consecutive gridding samples touches ~100 distinct panel rows with its 432 nonzeros, and each is then
+ * loaded once; the run's 16 result rows stay in registers).  ig_csr_runs_build (host): first call with dcols == NULL fills
+ * run_dptr[ceil(M/16) + 1] (prefix sums of the runs' distinct columns), second call fills dcols (run_dptr[last] words: column |
+ * (entries - 1) << 27) and entries (nnz x {row in run, re, im}, 12 bytes, a run's entries where its nonzeros sit in the CSR).
+ * IG_ERR_UNSUPPORTED when a row holds a column twice or K > 2^27 (callers then keep ig_ccsrmm_xrows).  nxrows * 512 < 2^32.
+ * Reference contract: indigo/backends/backend.py:514-519.                                                                  */
+int  ig_csr_runs_build(int64_t M, int64_t K, const int32_t* rowptr, const int32_t* colind, const void* vals,
+                       int32_t* run_dptr, uint32_t* dcols, void* entries, int* all_real);
+int  ig_ccsrmm_xrows_runs(ig_ctx* ctx, int64_t M, int64_t K, int64_t nnz, float alpha_re, float alpha_im, const int32_t* rowptr,
+                          const int32_t* run_dptr, const uint32_t* dcols, const void* entries, int all_real,
+                          const int32_t* run_order /* optional: a permutation of the runs, e.g. by the grid brick they start in */,
+                          const void* X, int64_t ldx, float beta_re, float beta_im, void* Y, int64_t ldy,
+                          const int32_t* xrows, int64_t nxrows);
+
 /* Host-side structure analysis.  Replaces `inspect`
  * (indigo/backends/_customcpu.c:179-215): number of non-empty rows / columns
  * and exwrite = "every column has <= 1 nonzero".  Pointers are HOST memory. */

@@ -98,7 +98,7 @@ class HipBackend(Backend):
         #   wide_bricks   64-column column-major panels: brick scatter through LDS (adjoint)
         #   slots         coil counts whose adjoint gridding is the slot-format scatter (ig_ccsrmm_t_slots): the ranks of a coil-sharded
         #                 run with one or two coils
-        self.tuning = dict(bricks=(4, 8), slots=(1, 2), slot_shape=(4, 4, 256, 64), support_tile=8, brick_shape={8: (2, 2, 4096, 4096), 4: (2, 4, 4096, 4096)}, xrows=True, wide_bricks=True,
+        self.tuning = dict(bricks=(4, 8), slots=(1, 2), slot_shape=(4, 4, 256, 64), support_tile=8, brick_shape={8: (2, 2, 4096, 4096), 4: (2, 4, 4096, 4096)}, xrows=True, runs=True, wide_bricks=True,
                            wide_brick_shape=(2, 2), wide_task_shape=(8192, 2048))
 
     def __del__(self):
@@ -910,6 +910,47 @@ class HipBackend(Backend):
                               rows=b.copy_array(rows, name=self._name + ".wideEntryRows"))
             return self._wide
 
+        def _runs(self, sub):
+            """The run format of the matrix over its touched columns (ig_csr_runs_build; `sub` = the cached (touched columns,
+            compact column indices) pair of the xrows route): built on first use, None when the matrix does not qualify."""
+            r = getattr(self, '_runs_fmt', False)
+            if r is not False:
+                return r
+            b = self._backend
+            m = self.shape[0]
+            indptr = np.ascontiguousarray(self._host_csr.indptr if self._host_csr is not None else self.rowPtrs.to_host(), dtype=np.int32)
+            compact = np.ascontiguousarray(sub[1].to_host(), dtype=np.int32)
+            data = np.ascontiguousarray(self._host_csr.data if self._host_csr is not None else self.values.to_host(), dtype=_C64)
+            nruns = (m + 15) // 16
+            dptr = np.zeros(nruns + 1, dtype=np.int32)
+            K = int(sub[0].size)
+            if indptr[0] != 0 or b._L.ig_csr_runs_build(m, K, indptr.ctypes.data, compact.ctypes.data, data.ctypes.data, dptr.ctypes.data, None, None, None) != 0:
+                log.info("%s: no run format (%s); the forward product keeps the per-nonzero gather", self._name, _lib.last_error(None))
+                self._runs_fmt = None
+                return None
+            dcols = np.empty(max(int(dptr[-1]), 1), dtype=np.uint32)
+            entries = np.empty((max(int(indptr[-1]), 1), 3), dtype=np.uint32)
+            real = ctypes.c_int(0)
+            _lib.check(b._L.ig_csr_runs_build(m, K, indptr.ctypes.data, compact.ctypes.data, data.ctypes.data, dptr.ctypes.data,
+                                              dcols.ctypes.data, entries.ctypes.data, ctypes.byref(real)), None, "ig_csr_runs_build")
+            # order of the runs: by the 16 x 16 x 16 brick of the grid (set_grid_dims, or a cube guessed from the column count) their
+            # first nonzero falls into -- runs that are neighbours in space share panel rows and then meet behind one L2.  Only a
+            # grouping: any order gives the same product.
+            order = None
+            dims = getattr(self, '_grid_dims', None) or self._guess_grid_dims()
+            if dims is not None and b.tuning.get('runs_order', True) and nruns > 1:
+                touched = sub[0].to_host().astype(np.int64)
+                first = np.minimum(indptr[np.minimum(np.arange(nruns, dtype=np.int64) * 16, m - 1)], max(int(indptr[-1]) - 1, 0))
+                col = touched[compact[first]] if indptr[-1] > 0 else np.zeros(nruns, np.int64)
+                n0, nm, ns = dims
+                bx, bm_, bs_ = (col % n0) // 16, ((col // n0) % nm) // 16, (col // (n0 * nm)) // 16
+                key = bx + ((n0 + 15) // 16) * (bm_ + ((nm + 15) // 16) * bs_)
+                order = b.copy_array(np.argsort(key, kind='stable').astype(np.int32), name=self._name + ".runOrder")
+            self._runs_fmt = dict(dptr=b.copy_array(dptr, name=self._name + ".runPtr"), dcols=b.copy_array(dcols, name=self._name + ".runCols"),
+                                  entries=b.copy_array(entries.reshape(-1), name=self._name + ".runEntries"), all_real=int(real.value),
+                                  ndistinct=int(dptr[-1]), order=order)
+            return self._runs_fmt
+
         def set_row_order(self, perm):
             """Store the matrix with its rows in the order `perm` (stored row r = row perm[r] of A), e.g. gridding
             samples sorted by the grid cell they touch: neighbouring rows then gather neighbouring panel rows.
@@ -959,6 +1000,16 @@ class HipBackend(Backend):
                 ar, ai = _cplx(alpha)
                 br, bi = _cplx(beta)
                 m, k = self.shape
+                runs = self._runs(sub) if (x.shape[1] == 64 and b.tuning.get('runs', True) and sub[0].size * 512 < 2 ** 32) else None
+                if runs is not None:
+                    # 64 columns: the run format -- every panel row a run of 16 matrix rows touches is loaded once (ig_ccsrmm_xrows_runs)
+                    b._check(b._L.ig_ccsrmm_xrows_runs(b._ctx, m, k, self.values.size, ar, ai, ctypes.c_void_p(self.rowPtrs._arr),
+                                                       ctypes.c_void_p(runs['dptr']._arr), ctypes.c_void_p(runs['dcols']._arr),
+                                                       ctypes.c_void_p(runs['entries']._arr), runs['all_real'],
+                                                       ctypes.c_void_p(runs['order']._arr) if runs['order'] is not None else None,
+                                                       ctypes.c_void_p(x._arr), x._leading_dim, br, bi, ctypes.c_void_p(y._arr), y._leading_dim,
+                                                       ctypes.c_void_p(sub[0]._arr), sub[0].size), "ig_ccsrmm_xrows_runs")
+                    return
                 b._check(b._L.ig_ccsrmm_xrows(b._ctx, m, k, x.shape[1], self.values.size, ar, ai,
                                               ctypes.c_void_p(self.values._arr), ctypes.c_void_p(sub[1]._arr),
                                               ctypes.c_void_p(self.rowPtrs._arr), ctypes.c_void_p(x._arr), x._leading_dim,

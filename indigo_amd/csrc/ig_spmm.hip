@@ -414,6 +414,220 @@ k_csrmm_gather_tile64(int64_t M, int64_t nnz, const int32_t* __restrict__ rowptr
     }
 }
 
+// ---- forward product over a 64-column row-major panel, the panel rows of a RUN of 16 matrix rows loaded ONCE, results in REGISTERS ----
+// k_csrmm_gather_tile64 loads the panel row of every nonzero: 5e7 x 512 bytes through the vector memory path for a gridding matrix
+// whose 16 consecutive samples (half a grid cell apart along a spoke) touch ~100 DISTINCT panel rows with their 432 nonzeros, and
+// that path -- ~25-30 bytes per clock and CU for 16-byte-per-lane gathers -- is what bounds it (profiles/r04_cfg3_forward_notes.txt:
+// neither whole-line loads, nor software pipelining, nor folding the panel into the L1 moved it).  Here the host groups the
+// nonzeros of a run of 16 rows by panel row (ig_csr_runs_build): a wave walks the run's distinct panel rows -- lane = panel column,
+// ONE 512-byte load per panel row, eight rows in flight in a ring of registers -- and adds w * row into the result rows of the
+// samples that use it.  A first version kept those 16 result rows in LDS (read-add-write per entry): 7.5-10 instructions per entry,
+// issue-bound at the old kernel's time.  The results now sit in REGISTERS (lane = column: 16 rows x (re, im) = v[128..159]) addressed
+// through the VGPR index mode -- an entry's row is wave-uniform, so its multiply-adds name v128 / v129 with M0 = {destination and
+// third source relative, 2 row}: 2 v_readlane + s_mov m0 + 2 v_fma per real-weight entry, no LDS traffic, no read-modify-write
+// chain through memory (the technique of k_bricks_wide64r).  The compiler never sees those registers: it is capped at 96 VGPRs
+// (amdgpu_num_vgpr), the kernel claims 160, and every access to v96..v159 is an assembly block with literal register numbers.
+//   dcols[j]   : panel row (compact column of the matrix) | (number of its entries - 1) << 27, the run's distinct rows in turn
+//   entries[e] : {row of the run 0..15, re, im}, grouped by distinct panel row in the order of dcols; a run's entries sit at
+//                rowptr[16 run] .. rowptr[16 (run + 1)) like its nonzeros in the CSR
+constexpr int RUN_ROWS = 16;
+struct RunEntry { uint32_t row; float re, im; };
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for_runs(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for_runs<I + 1, N>(f);
+    }
+}
+template <int K, int END>
+__device__ __forceinline__ void runs_acc_zero() {
+    if constexpr (K < END) {
+        asm volatile("v_mov_b64 v[%0:%1], 0" :: "i"(96 + 2 * K), "i"(97 + 2 * K));
+        runs_acc_zero<K + 1, END>();
+    }
+}
+template <int K, int END>
+__device__ __forceinline__ void runs_acc_store(float2* __restrict__ dst /* + K * TLD */, int tld) {
+    if constexpr (K < END) {
+        float re, im;
+        asm volatile("v_mov_b32 %0, v[%2]\n\tv_mov_b32 %1, v[%3]" : "=v"(re), "=v"(im) : "i"(96 + 2 * K), "i"(97 + 2 * K));
+        dst[K * tld] = make_float2(re, im);
+        runs_acc_store<K + 1, END>(dst, tld);
+    }
+}
+
+template <int BMODE, bool REALW>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(56)))
+k_csrmm_runs64r(int64_t M, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ run_dptr, const uint32_t* __restrict__ dcols,
+                const RunEntry* __restrict__ entries, const int32_t* __restrict__ run_order /* optional: the runs in the order to process them */,
+                const float2* __restrict__ X /* [row][64] */, float2* __restrict__ Y, int64_t ldy, float2 alpha, float2 beta) {
+    constexpr int TLD = 65;
+    __shared__ float2 tile[64 * TLD];
+    asm volatile("" ::: "v127");                          // the kernel owns 128 VGPRs: v0..v55 the compiler's, v56..v59 the prefetched
+                                                          // windows, v64..v95 a ring of 16 panel rows, v96..v127 the run's 16 result rows
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // What bounds the kernel is the bytes its panel rows cost in HBM (the loads alone take 1.40 of its 1.58 ms), and a panel row is
+    // wanted by ~2.3 runs: runs that are neighbours in SPACE should run close in time behind one L2.  The host may hand over an
+    // order of the runs (by the grid brick they start in); every XCD walks a contiguous range of it (blocks are dealt round-robin
+    // to the XCDs otherwise).  A run's 16 result rows are whole 128-byte lines of the column-major result, so any order stores
+    // full lines.
+    const int64_t blk = xcd_block(blockIdx.x, gridDim.x);
+    const int64_t nruns = (M + RUN_ROWS - 1) / RUN_ROWS;
+    const int64_t slot = blk * 4 + wv;
+    const int64_t run = slot < nruns ? (run_order ? (int64_t)run_order[slot] : slot) : nruns;
+    asm volatile("s_set_gpr_idx_on %0, 0x0" :: "s"(0));   // index mode on for the whole kernel; M0 = 0: nothing relative
+    runs_acc_zero<0, RUN_ROWS>();
+    if (run < nruns) {
+        const int32_t d0 = run_dptr[run], nd = run_dptr[run + 1] - d0;
+        const int64_t rlo = run * RUN_ROWS, rhi = rlo + RUN_ROWS < M ? rlo + RUN_ROWS : M;
+        const int32_t e0 = rowptr[rlo], ne = rowptr[rhi] - e0;
+        const rsrc_t r_d = make_rsrc(dcols + d0), r_e = make_rsrc(entries + e0);
+        // the repacked panel may exceed 2 GB (config 3: 2.57 GB): a descriptor over the whole 4 GB offset range.  Rows past the run's
+        // end are requested all the same (row 0: the load counts, so the waits below stay static)
+        const rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(X), 0, -1, 0x00020000);
+        const unsigned x_voff = (unsigned)lane * 8u;
+        // Windows of 64 distinct rows / 64 entries, one per lane, handed out with v_readlane (wave-uniform control).  Inside the loop
+        // EVERY load is an assembly block: one load the compiler knows about makes its wait-count pass drain the whole ring in front
+        // of each use of the window registers (s_waitcnt vmcnt(0) at the head of every row: 3.5 ms).  The next windows are
+        // prefetched into v112..v114 (entries) and v115 (distinct rows) and moved over when the current ones are used up.
+        int32_t dbase = 0, ebase = 0;
+        uint32_t dv = (uint32_t)buf_ld_i32(r_d, lane < nd ? (unsigned)lane * 4u : IG_OOB);
+        struct Win { uint32_t m0w; float re, im; };
+        auto cook = [&](u3 raw) { Win wn; wn.m0w = ((raw.x & 15u) * 2u) | 0xC000u; wn.re = __uint_as_float(raw.y); wn.im = __uint_as_float(raw.z); return wn; };
+        Win ev = cook(buf_ld_u3(r_e, lane < ne ? (unsigned)lane * 12u : IG_OOB));
+        auto prefetch_entries = [&](int32_t base) __attribute__((always_inline)) {     // entries base .. base + 63 -> v112..v114
+            const unsigned o = base + lane < ne ? (unsigned)(base + lane) * 12u : IG_OOB;
+            const rsrc_t re_ = r_e;
+            asm volatile("buffer_load_dwordx3 v[56:58], %0, %1, 0 offen" :: "v"(o), "s"(re_) : "memory");
+        };
+        auto prefetch_rows = [&](int32_t base) __attribute__((always_inline)) {        // distinct rows base .. base + 63 -> v115
+            const unsigned o = base + lane < nd ? (unsigned)(base + lane) * 4u : IG_OOB;
+            const rsrc_t rd_ = r_d;
+            asm volatile("buffer_load_dword v59, %0, %1, 0 offen" :: "v"(o), "s"(rd_) : "memory");
+        };
+        auto take_entries = [&]() __attribute__((always_inline)) -> Win {
+            u3 raw;
+            asm volatile("v_mov_b32 %0, v56\n\tv_mov_b32 %1, v57\n\tv_mov_b32 %2, v58" : "=v"(raw.x), "=v"(raw.y), "=v"(raw.z));
+            return cook(raw);
+        };
+        prefetch_entries(64);
+        prefetch_rows(64);
+        int32_t ei = 0;                                   // next entry inside the window `ev`
+        int32_t since = 0;                                // panel rows requested since the entry window in flight was asked for
+        // panel row j of the run -> ring slot KF (v[64 + 2 KF], v[65 + 2 KF]); returns the row's word (column | (entries - 1) << 27)
+        auto request = [&](auto kf, int32_t j) __attribute__((always_inline)) -> uint32_t {
+            constexpr int KF = decltype(kf)::value;
+            const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)dv, (j - dbase) & 63);
+            const uint32_t o = j < nd ? (w & 0x7ffffffu) * 512u : 0u;       // (past the run's end: panel row 0 once more -- a hit in the L1)
+            const rsrc_t rx = r_x;
+            const unsigned vo = x_voff;
+            asm volatile("s_nop 4\n\tbuffer_load_dwordx2 v[%0:%1], %2, %3, %4 offen" :: "i"(64 + 2 * KF), "i"(65 + 2 * KF), "v"(vo), "s"(rx), "s"(o) : "memory");
+            ++since;
+            return w;
+        };
+        // acc[row] += w * x for ONE entry: M0 = {third source and destination relative, 2 row}
+#define IG_RUNS_MAC_R(M, WR)      "s_mov_b32 m0, " M "\n\ts_nop 0\n\tv_fma_f32 v96, " WR ", v[%[xr]], v96\n\tv_fma_f32 v97, " WR ", v[%[xi]], v97\n\t"
+#define IG_RUNS_MAC_C(M, WR, WI)  IG_RUNS_MAC_R(M, WR) "v_fma_f32 v96, -" WI ", v[%[xi]], v96\n\tv_fma_f32 v97, " WI ", v[%[xr]], v97\n\t"
+        auto consume = [&](auto kf, uint32_t w, int32_t j) __attribute__((always_inline)) {
+            constexpr int KF = decltype(kf)::value;
+            if (j >= nd) return;
+            int cnt = (int)(w >> 27) + 1;
+            // this row has arrived: fifteen younger panel-row loads may still be out (anything else in flight is younger than they are
+            // or older than this row; loads return in order)
+            asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+            while (cnt > 0) {
+                if (ei >= 64) {                           // the window of entries is used up: the prefetched one takes over
+                    // it was asked for a window ago: once sixteen panel rows have been requested since, the vmcnt(15) above has
+                    // covered it (in-order return); a run of very dense rows gets there sooner and waits for everything
+                    if (since < 16) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    ev = take_entries(); ebase += 64; ei = 0;
+                    prefetch_entries(ebase + 64);
+                    since = 0;
+                    // (that load is younger than every panel row in flight: the static waits stay valid, only stricter)
+                }
+                const int avail = 64 - ei;
+                if (cnt >= 4 && avail >= 4) {
+                    uint32_t m[4]; float a[4], bi[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        m[q] = (uint32_t)__builtin_amdgcn_readlane((int)ev.m0w, ei + q);
+                        a[q] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(ev.re), ei + q));
+                        if (!REALW) bi[q] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(ev.im), ei + q));
+                    }
+                    if (REALW)
+                        asm volatile(IG_RUNS_MAC_R("%0", "%4") IG_RUNS_MAC_R("%1", "%5") IG_RUNS_MAC_R("%2", "%6") IG_RUNS_MAC_R("%3", "%7") "s_mov_b32 m0, 0"
+                                     :: "s"(m[0]), "s"(m[1]), "s"(m[2]), "s"(m[3]), "s"(a[0]), "s"(a[1]), "s"(a[2]), "s"(a[3]),
+                                        [xr] "i"(64 + 2 * KF), [xi] "i"(65 + 2 * KF) : "memory");
+                    else
+                        asm volatile(IG_RUNS_MAC_C("%0", "%4", "%8") IG_RUNS_MAC_C("%1", "%5", "%9") IG_RUNS_MAC_C("%2", "%6", "%10") IG_RUNS_MAC_C("%3", "%7", "%11") "s_mov_b32 m0, 0"
+                                     :: "s"(m[0]), "s"(m[1]), "s"(m[2]), "s"(m[3]), "s"(a[0]), "s"(a[1]), "s"(a[2]), "s"(a[3]),
+                                        "s"(bi[0]), "s"(bi[1]), "s"(bi[2]), "s"(bi[3]), [xr] "i"(64 + 2 * KF), [xi] "i"(65 + 2 * KF) : "memory");
+                    ei += 4; cnt -= 4;
+                } else {
+                    const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)ev.m0w, ei);
+                    const float a = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(ev.re), ei));
+                    if (REALW) {
+                        asm volatile(IG_RUNS_MAC_R("%0", "%1") "s_mov_b32 m0, 0" :: "s"(m), "s"(a), [xr] "i"(64 + 2 * KF), [xi] "i"(65 + 2 * KF) : "memory");
+                    } else {
+                        const float bi = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(ev.im), ei));
+                        asm volatile(IG_RUNS_MAC_C("%0", "%1", "%2") "s_mov_b32 m0, 0" :: "s"(m), "s"(a), "s"(bi), [xr] "i"(64 + 2 * KF), [xi] "i"(65 + 2 * KF) : "memory");
+                    }
+                    ei += 1; cnt -= 1;
+                }
+            }
+        };
+#undef IG_RUNS_MAC_C
+#undef IG_RUNS_MAC_R
+        // ring of sixteen: rows d .. d + 15 in flight while row d is consumed; slot KF is refilled (row d + 16) right after its row is
+        // used up.  (What bounds the kernel is bytes in flight: with eight rows per wave and three waves per SIMD -- 48 KB per CU --
+        // it fetched its 5.9 GB at 3.2 TB/s, 1.87 ms, the per-nonzero gather's time.)
+        uint32_t wr_[16];
+        auto fill = [&](auto k) __attribute__((always_inline)) { wr_[decltype(k)::value] = request(k, decltype(k)::value); };
+        static_for_runs<0, 16>(fill);
+        for (int32_t d = 0; d < nd; d += 16) {
+            const int32_t dn = d + 16;
+            const bool move = dn < nd && ((dn - dbase) & 63) == 0;
+            auto step = [&](auto k) __attribute__((always_inline)) {
+                constexpr int KF = decltype(k)::value;
+                consume(k, wr_[KF], d + KF);
+                if (KF == 0 && move) {                    // (the next window was asked for 64 rows ago: the vmcnt(15) above covers it)
+                    asm volatile("v_mov_b32 %0, v59" : "=v"(dv));
+                    dbase = dn;
+                    prefetch_rows(dn + 64);
+                }
+                wr_[KF] = request(k, dn + KF);
+            };
+            static_for_runs<0, 16>(step);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the out-of-range tail requests write the ring registers too)
+    }
+    asm volatile("s_set_gpr_idx_off");
+    if (run >= nruns) return;
+    // the run's results: registers -> the wave's quarter of the tile -> full 128-byte lines of the column-major result (lanes = 16
+    // rows x 4 columns).  Only this wave touches its quarter: LDS operations of a wave execute in order, the fence pins that for
+    // the compiler.
+    float2* __restrict__ mine = tile + (wv * RUN_ROWS) * TLD;
+    runs_acc_store<0, RUN_ROWS>(mine + lane, TLD);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int r16 = lane & 15, cg = lane >> 4;
+    const int64_t orow = run * RUN_ROWS + r16;
+    const bool keep = orow < M;
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const int col = cg + 4 * i;
+        float2 out = cmul(alpha, mine[r16 * TLD + col]);
+        float2* dst = Y + (int64_t)col * ldy + orow;
+        if (keep) {
+            if (BMODE == 1) cfma(out, beta, *dst);
+            *dst = out;
+        }
+    }
+}
+
 // Row-per-lane variant for matrices whose rows are mostly empty or very short (mean <= 1 nonzero per
 // row, e.g. the transposed gridding matrix: 89 % empty rows).  A lane owns a row and keeps NC panel
 // columns in registers, so a wave covers 64 rows, every store instruction writes 512 contiguous bytes
@@ -1283,6 +1497,12 @@ k_grid_slots(const BrickTask* __restrict__ tasks, int ntasks, const BrickRef* __
     int cur = 0;
     int32_t cur_end = __builtin_amdgcn_readlane(my_end, 0);
     auto flush = [&]() {
+        // The lanes that read a cell below are not the lanes that accumulated into it.  A wave's LDS operations execute in
+        // program order, so the hardware needs nothing here; the fence pair pins that order for the COMPILER too (it may not
+        // move the reads of the image above the read-add-writes of the slot before, whatever it learns about the pointers).
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const int pt = __builtin_amdgcn_readlane(my_pt, cur);
         const uint32_t mask = (uint32_t)__builtin_amdgcn_readlane((int)my_mask, cur);
         for (int seg = 0; seg < nseg; ++seg) {
@@ -2612,6 +2832,103 @@ int ig_ccsrmm_t_bricks_wide_grid(ig_ctx* ctx, int64_t M, int64_t K, float ar, fl
     hipLaunchKernelGGL(k_bricks_wide64, dim3(blocks), dim3(BLK), 0, ctx->stream, (const BrickTask*)tasks, (int)ntasks, (const BrickRef*)brick_table,
                        (const BrickEntry*)entries, entry_rows, (const float2*)xp, (float2*)Y, ldy, make_float2(ar, ai));
     IG_LAUNCH_CHECK(ctx, "k_bricks_wide64");
+    return IG_OK;
+}
+
+// The run format of k_csrmm_runs64r from a CSR with sorted rows: the nonzeros of every run of 16 consecutive rows grouped by
+// column.  Two calls: dcols == NULL counts (run_dptr[nruns + 1] = prefix sums of the runs' distinct columns), the second fills
+// dcols (run_dptr[nruns] words) and entries (nnz x 12 bytes).  *all_real = every value has a zero imaginary part.
+// IG_ERR_UNSUPPORTED when a row holds a column twice or a column index needs more than 27 bits.
+int ig_csr_runs_build(int64_t M, int64_t K, const int32_t* rowptr, const int32_t* colind, const void* vals,
+                      int32_t* run_dptr, uint32_t* dcols, void* entries, int* all_real) {
+    if (M < 0 || !rowptr || !run_dptr || (rowptr[M] > rowptr[0] && (!colind || !vals)) || (dcols && !entries))
+        return ig_fail(nullptr, IG_ERR_ARG, "ig_csr_runs_build: bad arguments");
+    if (K > (1LL << 27)) return ig_fail(nullptr, IG_ERR_UNSUPPORTED, "ig_csr_runs_build: column indices need more than 27 bits");
+    const int64_t nruns = (M + RUN_ROWS - 1) / RUN_ROWS;
+    const float2* v = (const float2*)vals;
+    RunEntry* out = (RunEntry*)entries;
+    const int nt = brick_threads(M);
+    const int64_t per = (nruns + nt - 1) / nt;
+    std::atomic<int> bad{0}, cplx{0};
+    if (!dcols) run_dptr[0] = 0;
+    run_threads(nt, [&](int th) {
+        struct Nz { int32_t col; uint32_t row; float2 val; };
+        std::vector<Nz> buf;
+        const int64_t lo = std::min<int64_t>(nruns, th * per), hi = std::min<int64_t>(nruns, lo + per);
+        for (int64_t r = lo; r < hi; ++r) {
+            const int64_t rlo = r * RUN_ROWS, rhi = std::min<int64_t>(M, rlo + RUN_ROWS);
+            buf.clear();
+            for (int64_t t = rlo; t < rhi; ++t)
+                for (int32_t p = rowptr[t]; p < rowptr[t + 1]; ++p) {
+                    if (colind[p] < 0 || colind[p] >= K) { bad = 1; continue; }
+                    buf.push_back(Nz{colind[p], (uint32_t)(t - rlo), v[p]});
+                }
+            std::stable_sort(buf.begin(), buf.end(), [](const Nz& a, const Nz& b) { return a.col < b.col; });
+            int32_t nd = 0;
+            for (size_t i = 0; i < buf.size(); ++i) {
+                if (i == 0 || buf[i].col != buf[i - 1].col) ++nd;
+                else if (buf[i].row == buf[i - 1].row) bad = 1;                       // a row holds a column twice
+            }
+            if (!dcols) { run_dptr[r + 1] = nd; continue; }                           // counting pass: sizes, prefix-summed below
+            uint32_t* dc = dcols + run_dptr[r];
+            RunEntry* e = out + (rowptr[rlo] - rowptr[0]);
+            int32_t j = -1;
+            for (size_t i = 0; i < buf.size(); ++i) {
+                if (i == 0 || buf[i].col != buf[i - 1].col) { ++j; dc[j] = (uint32_t)buf[i].col; }
+                else dc[j] += 1u << 27;
+                e[i] = RunEntry{buf[i].row, buf[i].val.x, buf[i].val.y};
+                if (buf[i].val.y != 0.f) cplx = 1;
+            }
+        }
+    });
+    if (bad) return ig_fail(nullptr, IG_ERR_UNSUPPORTED, "ig_csr_runs_build: a column index outside the matrix, or a row that holds a column twice");
+    if (!dcols) {
+        for (int64_t r = 0; r < nruns; ++r) {
+            const int64_t sum = (int64_t)run_dptr[r] + run_dptr[r + 1];
+            if (sum > 0x7fffffffLL) return ig_fail(nullptr, IG_ERR_UNSUPPORTED, "ig_csr_runs_build: more than 2^31 distinct columns");
+            run_dptr[r + 1] = (int32_t)sum;
+        }
+    } else if (all_real) *all_real = cplx ? 0 : 1;
+    return IG_OK;
+}
+
+// Y = beta*Y + alpha * A' * X[xrows, :] like ig_ccsrmm_xrows, for 64 columns, through the run format of A' (ig_csr_runs_build on the
+// compact column indices): the panel's touched rows are repacked row-major, then k_csrmm_runs64r.
+int ig_ccsrmm_xrows_runs(ig_ctx* ctx, int64_t M, int64_t K, int64_t nnz, float ar, float ai, const int32_t* rowptr,
+                         const int32_t* run_dptr, const uint32_t* dcols, const void* entries, int all_real, const int32_t* run_order,
+                         const void* X, int64_t ldx, float br, float bi, void* Y, int64_t ldy, const int32_t* xrows, int64_t nxrows) {
+    IG_REQUIRE(ctx, ctx != nullptr, "ig_ccsrmm_xrows_runs: ctx is NULL");
+    IG_REQUIRE(ctx, M >= 0 && K >= 0 && nnz >= 0 && nnz <= 0x7fffffffLL && M <= 0x7fffffffLL, "ig_ccsrmm_xrows_runs: bad dimensions");
+    IG_REQUIRE(ctx, rowptr && run_dptr && (nnz == 0 || (dcols && entries)) && (M == 0 || Y) && ldy >= M && ldx >= K, "ig_ccsrmm_xrows_runs: NULL array or short leading dimension");
+    IG_REQUIRE(ctx, nxrows >= 1 && nxrows <= K && xrows && X && nxrows * 512 < 0xffffffffLL, "ig_ccsrmm_xrows_runs: bad row list (1 .. 2^23 - 1 rows: the repacked panel is addressed with 32 bits)");
+    IG_REQUIRE(ctx, nnz * 12 < 0x7fffffffLL, "ig_ccsrmm_xrows_runs: the entries exceed the 2 GB window of a buffer descriptor");
+    if (M == 0) return IG_OK;
+    if (int rc = ig_set_device(ctx)) return rc;
+    const size_t need = (size_t)nxrows * 512;
+    if (ctx->xpack_bytes < need) {
+        if (ctx->d_xpack) { IG_HIP(ctx, hipStreamSynchronize(ctx->stream)); IG_HIP(ctx, hipFree(ctx->d_xpack)); ctx->d_xpack = nullptr; ctx->xpack_bytes = 0; }
+        IG_HIP(ctx, hipMalloc((void**)&ctx->d_xpack, need));
+        ctx->xpack_bytes = need;
+    }
+    float2* xp = (float2*)ctx->d_xpack;
+    {
+        ig_prof_scope prof(ctx, "pack_panel", (double)nxrows * 512.0 * 2.0);
+        int64_t gt = (nxrows + 63) / 64;
+        const int64_t cap = (int64_t)ctx->num_cu * 16;
+        if (gt > cap) gt = cap;
+        hipLaunchKernelGGL(k_pack_panel_tiled<64>, dim3((unsigned)gt), dim3(BLK), 0, ctx->stream, nxrows, (int64_t)64, (const float2*)X, ldx, xp, xrows);
+        IG_LAUNCH_CHECK(ctx, "k_pack_panel_tiled");
+    }
+    const float2 alpha = make_float2(ar, ai), beta = make_float2(br, bi);
+    const bool b0 = br == 0.f && bi == 0.f;
+    const unsigned blocks = (unsigned)((M + 63) / 64);
+    ig_prof_scope prof(ctx, "csrmm_runs");
+#define IG_RUNS(BM_, RW_) hipLaunchKernelGGL((k_csrmm_runs64r<BM_, RW_>), dim3(blocks), dim3(256), 0, ctx->stream, M, rowptr, run_dptr, dcols, \
+                                             (const RunEntry*)entries, run_order, (const float2*)xp, (float2*)Y, ldy, alpha, beta)
+    if (b0) { if (all_real) IG_RUNS(0, true); else IG_RUNS(0, false); }
+    else    { if (all_real) IG_RUNS(1, true); else IG_RUNS(1, false); }
+#undef IG_RUNS
+    IG_LAUNCH_CHECK(ctx, "k_csrmm_runs64r");
     return IG_OK;
 }
 

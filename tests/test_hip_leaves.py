@@ -877,3 +877,48 @@ def test_wide_panel_forward_ragged_rows(hip, alpha, beta, ld_pad):
     assert rel_err(y_d.to_host(), exp) < RTOL
     if ld_pad:
         np.testing.assert_array_equal(hip.copy_array(yfull)[M:, :].to_host(), yfull[M:])      # (rows past M of the parent are not ours)
+
+
+@pytest.mark.parametrize("real_weights,alpha,beta,ld_pad", [(False, 1, 0, 0), (True, 1, 0, 0), (False, 0.5 - 1j, 1.5, 5), (True, 2, 1j, 3)])
+def test_wide_panel_forward_by_runs(hip, monkeypatch, real_weights, alpha, beta, ld_pad):
+    """the run format (ig_csr_runs_build + k_csrmm_runs64r: 64 columns, the panel rows of a run of 16 matrix rows loaded once, the
+    run's results in registers through the VGPR index mode): rows of every length -- empty rows, whole empty runs, runs with
+    more than 64 distinct columns and more than 64 entries (several windows), clustered columns (many entries per panel row: the
+    quad and single paths) -- a row count that is not a multiple of 16, real and complex values, alpha / beta and padded
+    leading dimensions; against scipy in complex128 and against the per-nonzero gather"""
+    M, K = 1003, 12000
+    rng = np.random.default_rng(12)
+    lens = rng.integers(0, 40, size=M)
+    lens[[5, 300, 1002]] = [700, 300, 257]
+    lens[[0, 17, 18, 19, 640]] = 0
+    lens[160:192] = 0                                           # two empty runs
+    rows = np.repeat(np.arange(M), lens)
+    # columns cluster around a centre per run of 16 rows, inside a pool of 30 % of the columns (col_frac <= 0.6: the xrows route)
+    pool = np.sort(rng.choice(K, size=int(K * 0.3), replace=False))
+    centre = rng.integers(0, pool.size, size=(M + 15) // 16)[rows // 16]
+    spread = np.where(lens[rows] > 200, 400, 20)
+    cols = pool[(centre + rng.integers(-spread, spread + 1)) % pool.size]
+    vals = rand64c(rows.size, seed=1)
+    if real_weights:
+        vals = vals.real.astype(C64)
+    A = spp.csr_matrix((vals, (rows, cols)), shape=(M, K))
+    A.sum_duplicates(); A.sort_indices()
+    A_d = hip.csr_matrix(hip, A)
+    assert A_d._col_frac <= 0.6 and A.nnz >= K, (A_d._col_frac, A.nnz)
+    xfull = rand64c(K + ld_pad, 64, seed=2)
+    yfull = rand64c(M + ld_pad, 64, seed=3)
+    x_d = hip.copy_array(xfull)[0:K, :]
+    y_d = hip.copy_array(yfull)[0:M, :]
+    A_d.forward(y_d, x_d, alpha=alpha, beta=beta)
+    fmt = getattr(A_d, '_runs_fmt', None)
+    assert fmt is not None and fmt['all_real'] == int(real_weights) and fmt['ndistinct'] < A.nnz
+    exp = alpha * (A.astype(np.complex128) @ xfull[:K].astype(np.complex128)) + beta * yfull[:M]
+    assert rel_err(y_d.to_host(), exp) < RTOL
+    if ld_pad:
+        np.testing.assert_array_equal(hip.copy_array(yfull)[M:, :].to_host(), yfull[M:])
+    monkeypatch.setitem(hip.tuning, "runs", False)
+    B_d = hip.csr_matrix(hip, A)
+    y2 = hip.copy_array(yfull)[0:M, :]
+    B_d.forward(y2, x_d, alpha=alpha, beta=beta)
+    assert getattr(B_d, '_runs_fmt', None) is None
+    assert rel_err(y2.to_host(), y_d.to_host()) < 2e-6
