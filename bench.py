@@ -56,6 +56,14 @@ PMC_NOTE = " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_
 # profile-scope name (call site) -> device kernel symbol as rocprofv3 prints it.  The template arguments of the FFT
 # kernel are <R1, R2, T, W, AXIS0, WMODE, BOXED, HALF> (indigo_amd/csrc/ig_fft.hip); which instantiation a pass runs
 # depends on the grid layout, the axis length and whether the image box is the middle half of the axis.
+def bricks_symbol(ncoils, support_tile):
+    """k_grid_bricks<NC, NSEG, PAIR>: segments per 16 x 2 x 2 brick unrolled for the 8-coil kernel (4 at 16 kx points per table entry, 8
+    at 8; the 4-point table's 16 segments are flushed in 8 pairs)"""
+    if ncoils != 8:
+        return "k_grid_bricks<%d, 0, false>" % ncoils
+    return {16: "k_grid_bricks<8, 4, false>", 8: "k_grid_bricks<8, 8, false>", 4: "k_grid_bricks<8, 8, true>"}.get(support_tile, "k_grid_bricks<8, 0, false>")
+
+
 def kernel_symbols(layout, ncoils, half_box=True, n=512, support_tile=16):
     r1 = 32 if n == 512 else 16
     f = "k_fft_2stage<%d, 16, 16, %%s>" % r1
@@ -74,7 +82,7 @@ def kernel_symbols(layout, ncoils, half_box=True, n=512, support_tile=16):
         gv = {8: "k_csrmm_gather_v<4, 2, 8, false, 0>", 4: "k_csrmm_gather_v<2, 2, 8, false, 0>",
               2: "k_csrmm_gather_v<2, 1, 8, false, 0>"}.get(ncoils, "k_csrmm_gather")
         m.update({"csrmm_rowlane_conj": "k_csrmm_dense64<%d, true, true>" % ncoils, "csrmm_gather": gv,
-                  "csrmm_bricks_conj": "k_grid_bricks<%d, %d>" % (ncoils, 4 if ncoils == 8 else 0)})
+                  "csrmm_bricks_conj": bricks_symbol(ncoils, support_tile)})
     elif layout == 2:
         gv = {8: "k_csrmm_gather_v<4, 2, 8, false, 0>", 4: "k_csrmm_gather_v<2, 2, 8, false, 0>",
               2: "k_csrmm_gather_v<2, 1, 8, false, 0>"}.get(ncoils, "k_csrmm_gather")
@@ -92,8 +100,7 @@ def kernel_symbols(layout, ncoils, half_box=True, n=512, support_tile=16):
                       "fft_crop_z": f % (zt + ", false, 0, true, 0"), "fft_crop_y": f % "32, false, 0, true, 0",
                       "fft_crop_x": f % ("16, false, %d, true, 0" % (3 + lg))})
         m.update({"csrmm_rowlane_conj": "k_csrmm_dense64<%d, true, true>" % ncoils, "csrmm_gather": gv, "csrmm_slots_conj": "k_grid_slots<%d>" % ncoils,
-                  # (second argument: segments per 16 x 2 x 2 brick, unrolled for the 8-coil kernel)
-                  "csrmm_bricks_conj": "k_grid_bricks<%d, %d>" % (ncoils, (16 // support_tile) * 4 if ncoils == 8 else 0)})
+                  "csrmm_bricks_conj": bricks_symbol(ncoils, support_tile)})
     elif layout == 1:
         h = (3, 1, 1, 2, 2, 4) if half_box else (0,) * 6
         w = 32 if (half_box and n == 512) else 16         # compile-time half box: 32-column tiles (launch_2stage, ig_fft.hip)

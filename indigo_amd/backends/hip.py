@@ -90,7 +90,7 @@ class HipBackend(Backend):
         # Format choices of this backend's matrices and fused trees (defaults = the measured best; tests switch routes off to
         # reach the fallback kernels):
         #   bricks        coil counts whose interleaved adjoint gridding is the brick-binned scatter (others: gather over G'^T)
-        #   support_tile  kx points per entry of the fine k-space support table of coil-interleaved trees (16: one table only)
+        #   support_tile  kx points per entry of the fine k-space support table of coil-interleaved trees, by coil count (16: one table only)
         #   brick_shape   per coil count: (grid lines, slabs, heavy-brick piece, entries per run) of the binned format.  Four coils
         #                 pad a sample's share of a brick to 16 entries: bricks of 16 x 2 x 4 cells waste less than 16 x 2 x 2 (0.61
         #                 against 0.68 ms; profiles/r03_brick_shape_sweep.txt)
@@ -98,7 +98,7 @@ class HipBackend(Backend):
         #   wide_bricks   64-column column-major panels: brick scatter through LDS (adjoint)
         #   slots         coil counts whose adjoint gridding is the slot-format scatter (ig_ccsrmm_t_slots): the ranks of a coil-sharded
         #                 run with one or two coils
-        self.tuning = dict(bricks=(4, 8), slots=(1, 2), slot_shape=(4, 4, 256, 64), support_tile=8, brick_shape={8: (2, 2, 4096, 4096), 4: (2, 4, 4096, 4096)}, xrows=True, runs=True, wide_bricks=True,
+        self.tuning = dict(bricks=(4, 8), slots=(1, 2), slot_shape=(4, 4, 256, 64), support_tile={8: 4, 4: 8}, brick_shape={8: (2, 2, 4096, 4096), 4: (2, 4, 4096, 4096)}, xrows=True, runs=True, wide_bricks=True,
                            wide_brick_shape=(2, 2), wide_task_shape=(8192, 2048))
 
     def __del__(self):

@@ -1263,7 +1263,11 @@ struct BrickEntry { uint32_t cell; float re, im; };       // 12 bytes; cell == 0
 // At a brick boundary (wave-uniform test, once per round -- a brick holds at least one round) the image is stored and
 // cleared; with NSEG > 0 the segment loop is unrolled.  Brick ends, grid offsets and segment flags of the run sit one
 // brick per lane (v_readlane).
-template <int NC, int NSEG /* bm * bs, or 0: any */>
+// PAIR: the support table has 4 kx points per entry (16 / 4 x bm x bs = 2 NSEG segments per brick), and the flush handles them two
+// at a time -- segments 2 p and 2 p + 1 are the two halves of the same 8 cells x NC values a wave stores with one instruction, so the
+// loop keeps the shape of the 8-point table's (NSEG unrolled stores) and a half-wave is predicated by its own flag.  (Unrolled 16
+// times the flush spilled; the generic loop cost 0.86 against 0.76 ms and ate what the finer table saves the z passes.)
+template <int NC, int NSEG /* bm * bs, or 0: any */, bool PAIR = false>
 __global__ void __launch_bounds__(BLK)
 k_grid_bricks(const BrickTask* __restrict__ tasks, int ntasks, const BrickRef* __restrict__ btab,
               const BrickEntry* __restrict__ entries, const uint32_t* __restrict__ round_rows,
@@ -1284,7 +1288,7 @@ k_grid_bricks(const BrickTask* __restrict__ tasks, int ntasks, const BrickRef* _
     // a segment = 2^st_log2 consecutive cells of one grid row (the support table's granularity: 16, 8 or 4 kx points);
     // segment index inside a brick: s = xs + XS*(im + BM*is) with XS = 16 >> st_log2 segments per brick row
     const int xs_log2 = 4 - st_log2, seg_log2 = xs_log2 + bm_log2 + bs_log2;
-    const int BM = 1 << bm_log2, nseg = NSEG ? NSEG : 1 << seg_log2, ncell = 16 << (bm_log2 + bs_log2);
+    const int BM = 1 << bm_log2, nseg = NSEG ? (PAIR ? 2 * NSEG : NSEG) : 1 << seg_log2, ncell = 16 << (bm_log2 + bs_log2);
     float2* __restrict__ acc = acc_all + (size_t)wv * ncell * NC;
     const int coil = lane % NC, tsub = lane / NC, xround = (lane / NC) % RS;
     const rsrc_t r_en = make_rsrc(entries + tk.lo), r_rr = make_rsrc(round_rows + tk.lo / TPR), r_x = make_rsrc(Xp);
@@ -1356,12 +1360,17 @@ k_grid_bricks(const BrickTask* __restrict__ tasks, int ntasks, const BrickRef* _
     int32_t cur_end = __builtin_amdgcn_readlane(my_end, 0);
     // store the image of brick `cur` (flagged segments: 16 cells x NC coils = NC*128 bytes each) and clear it
     auto flush_segment = [&](int pt, uint32_t mask, int seg) {
-        if (!((mask >> seg) & 1u)) return;
-        const int xs = seg & ((1 << xs_log2) - 1), im = (seg >> xs_log2) & (BM - 1), is = seg >> (xs_log2 + bm_log2);
-        const int cell0 = (xs << st_log2) + 16 * (im + BM * is);          // first cell of the segment in the image
+        // PAIR: `seg` numbers PAIRS of 4-cell segments = the 8-cell pieces of the 8-point table's geometry; lane half h keeps its
+        // values iff segment 2 seg + h is flagged
+        const uint32_t flags = PAIR ? (mask >> (2 * seg)) & 3u : (mask >> seg) & 1u;
+        if (!flags) return;
+        const bool mine = PAIR ? ((flags >> (lane >> 5)) & 1u) != 0 : true;
+        const int f_log2 = PAIR ? 3 : st_log2, fx_log2 = 4 - f_log2;
+        const int xs = seg & ((1 << fx_log2) - 1), im = (seg >> fx_log2) & (BM - 1), is = seg >> (fx_log2 + bm_log2);
+        const int cell0 = (xs << f_log2) + 16 * (im + BM * is);           // first cell of the segment in the image
         float2* src = acc + (size_t)cell0 * NC;
-        float2* dst = Y + ((int64_t)pt + (xs << st_log2) + (int64_t)n0 * (im + (int64_t)nm * is)) * NC;
-        const int nel = NC << st_log2;                                    // float2 values of the segment (128 for 16 cells x 8 coils)
+        float2* dst = Y + ((int64_t)pt + (xs << f_log2) + (int64_t)n0 * (im + (int64_t)nm * is)) * NC;
+        const int nel = NC << f_log2;                                     // float2 values of the segment (128 for 16 cells x 8 coils)
         for (int e = lane; e < nel; e += 64) {
             const float2 o = cmul(alpha, src[e]);
             // Stores and atomics as asm statements: the compiler's wait-count bookkeeping does not see them.  With ordinary
@@ -1369,7 +1378,7 @@ k_grid_bricks(const BrickTask* __restrict__ tasks, int ntasks, const BrickRef* _
             // it cannot bound the number of stores between a load and its use), which undoes the prefetching; not
             // counting them only makes its counted waits for loads somewhat earlier than necessary.  An 8-byte store
             // reads its data registers at issue (no write-after-read hazard), and nothing here reads Y back.
-            {
+            if (mine) {
                 if (shared) {
                     asm volatile("global_atomic_add_f32 %0, %1, off\n\tglobal_atomic_add_f32 %0, %2, off offset:4"
                                  :: "v"(dst + e), "v"(o.x), "v"(o.y) : "memory");
@@ -2613,19 +2622,22 @@ int ig_ccsrmm_t_bricks(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, float ar, f
     const size_t lds = (size_t)WAVES_PER_BLOCK * 16 * bm * bs * N * 8;          // one brick image per wave
     IG_REQUIRE(ctx, lds <= 64 * 1024, "ig_ccsrmm_t_bricks: bricks of 16 x %d x %d points x %lld columns need %zu bytes of LDS per workgroup (limit 64 KB)", bm, bs, (long long)N, lds);
     const unsigned blocks = (unsigned)((ntasks + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
-#define IG_BRICKS(NC_, NSEG_) do {                                                                                            \
+#define IG_BRICKS(NC_, NSEG_) IG_BRICKS_P(NC_, NSEG_, false)
+#define IG_BRICKS_P(NC_, NSEG_, PAIR_) do {                                                                                            \
         if (nshared) {                                                                                                          \
             ig_prof_scope prof(ctx, "grid_bricks_zero");                                                                        \
             hipLaunchKernelGGL((k_grid_bricks_zero<NC_>), dim3((unsigned)nshared), dim3(BLK), 0, ctx->stream, shared_bricks, (float2*)Y_il, bits, (int)n0, (int)nm, bm_log2, bs_log2, nbx, nbm, st_log2, zw); } \
         ig_prof_scope prof(ctx, "csrmm_bricks_conj");                                                                           \
-        hipLaunchKernelGGL((k_grid_bricks<NC_, NSEG_>), dim3(blocks), dim3(BLK), lds, ctx->stream, (const BrickTask*)tasks, (int)ntasks, (const BrickRef*)brick_table, (const BrickEntry*)entries, round_rows, \
+        hipLaunchKernelGGL((k_grid_bricks<NC_, NSEG_, PAIR_>), dim3(blocks), dim3(BLK), lds, ctx->stream, (const BrickTask*)tasks, (int)ntasks, (const BrickRef*)brick_table, (const BrickEntry*)entries, round_rows, \
                            (const float2*)xp, (float2*)Y_il, alpha, bits, (int)n0, (int)nm, bm_log2, bs_log2, nbx, nbm, st_log2, zw); } while (0)
     const int nseg_total = (16 / support_tile) * bm * bs;
     if (N == 8 && nseg_total == 4) IG_BRICKS(8, 4);
     else if (N == 8 && nseg_total == 8) IG_BRICKS(8, 8);
+    else if (N == 8 && nseg_total == 16 && support_tile == 4) IG_BRICKS_P(8, 8, true);      // the 4-point table: pairs of segments
     else if (N == 8) IG_BRICKS(8, 0);
     else IG_BRICKS(4, 0);
 #undef IG_BRICKS
+#undef IG_BRICKS_P
     IG_LAUNCH_CHECK(ctx, "k_grid_bricks");
     return IG_OK;
 }

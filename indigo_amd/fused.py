@@ -199,7 +199,10 @@ def assemble(backend, Gm, oN, N, weights_of, Cn, layout, chunks, table=None, box
     # 16-point table: whatever they write is a superset of what a reader with the finer table reads.
     # (measured on the headline problem: 7.80 ms at 16, 7.52 ms at 8; at 4 the scatter's 16 segments per brick spill.  coils * tile
     # >= 32 keeps the transform's 32-column tiles, which need two tiles per table entry.)
-    tile = int(tuning.get('support_tile', 8))
+    # (round 4: 4 kx points per entry for 8-coil trees -- 16.4 % of the headline grid flagged instead of 22.2 %; the scatter flushes
+    # the 4-point segments in pairs, one wave store as before: 6.92 -> 6.77 ms.  4-coil trees keep 8 points: coils * tile >= 32.)
+    tile = tuning.get('support_tile', 8)
+    tile = int(tile.get(bricks_cols, 8) if isinstance(tile, dict) else tile)
     fine = None
     if (table is not None and layout == 2 and tile in (4, 8) and bricks_cols * tile >= 32 and len(sizes) == 0
             and getattr(backend, 'supports_support_tile', False)):

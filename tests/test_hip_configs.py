@@ -479,7 +479,7 @@ def test_padded_transforms_with_chirp_z_axes_vs_numpy(hip):
 def test_sense_on_the_reference_drivers_grid_vs_oracle(hip, oracle_backend, C):
     """image 256^3 on a 320^3 grid (oversampling 1.25, the reference driver's choice of grid, examples/pics.py:87-90): the fused
     leaf on the A x B passes WITH the k-space support table (bitmaps of 20 and 16 words per entry for the 16 x 20 split of the z
-    axis; the 8-point table; the 8- and the 4-coil brick scatter), forward / adjoint / normal
+    axis; the 4-point table with 8 coils, the 8-point one with 4; the 8- and the 4-coil brick scatter), forward / adjoint / normal
     operator against the numpy oracle, which knows no table"""
     p = SenseProblem.synthetic((256, 256, 256), C, nspokes=400, nreadout=320, width=2, ntable=128, oversamp=1.25, seed=6)
     assert p.oN == (320, 320, 320)
@@ -488,7 +488,7 @@ def test_sense_on_the_reference_drivers_grid_vs_oracle(hip, oracle_backend, C):
     A = p.build_zpadfft(hip)
     from indigo_amd import operators as op
     assert A.has(op.ZpadFFT) and A.right._layout == 2 and A.right._support_h is not None and p.last_support_zw == (20, 16)
-    assert p.last_support_fine is not None and p.last_support_fine[1] == 8          # (coils * tile >= 32: the 8-point table for both)
+    assert p.last_support_fine is not None and p.last_support_fine[1] == (4 if C == 8 else 8)       # (coils * tile >= 32)
     x = rand64c(A.shape[1], 1, seed=1)
     k = rand64c(A.shape[0], 1, seed=2)
     A_o = p.build_zpadfft(oracle_backend, layout=0, support=False)
