@@ -213,8 +213,10 @@ def check_fractions(obj, where="roofline"):
             check_fractions(v, where + "." + str(k))
 
 
-def roofline_of(prof, symbols, cfg, pick=None):
-    """merge call sites that launch the same device kernel, pick the dominant one, price it"""
+def roofline_of(prof, symbols, cfg, pick=None, traffic_ok=True):
+    """merge call sites that launch the same device kernel, pick the dominant one, price it.  traffic_ok: the committed PMC summary
+    of this config was collected on launches of THIS shape (8 coils per launch, the standard image and grid); otherwise `traffic`
+    stays null -- a per-launch byte count of another shape is not this kernel's traffic"""
     kernels = {}
     for name, d in prof.items():
         sym = symbols.get(name, name)
@@ -231,7 +233,7 @@ def roofline_of(prof, symbols, cfg, pick=None):
     avg_ms = d['total_ms'] / d['launches']
     per_launch = d['bytes'] / d['launches'] if d['bytes'] else None
     achieved = per_launch / (avg_ms * 1e-3) / 1e9 if per_launch else None
-    pmc, src = load_pmc(cfg)
+    pmc, src = load_pmc(cfg) if traffic_ok else (None, None)
     traffic = pmc.get(dom, {}).get("hbm_bytes_per_launch") if pmc else None
     out = dict(bound="hbm", kernel=dom, call_sites=d['sites'], achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                frac=(achieved / HBM_PEAK_GBS) if achieved else None, traffic=traffic,
@@ -407,7 +409,8 @@ def run_sense(args, cfg, B, comm, world, rank, steps, warmup, want_cpu, quiet=Fa
     if "pack_panel" in prof and "pack_panel" in grid_bytes:
         prof["pack_panel"]['bytes'] = float(grid_bytes["pack_panel"]) * prof["pack_panel"]['launches']
     symbols = kernel_symbols(layout if fused_fft else 0, cpr, half_box, p.oN[0], sup_tile if fused_fft else 16)
-    roofline, kernels = roofline_of(prof, symbols, cfg)
+    standard = not args.image and not args.coils and not (args.osf if cfg == 4 else 0) and tree == "zpadfft"
+    roofline, kernels = roofline_of(prof, symbols, cfg, traffic_ok=(standard and cpr == 8))
     if not quiet:
         for k in sorted(prof, key=lambda k: -prof[k]['total_ms']):
             log("  %-24s %4d launches  avg %8.3f ms  total %9.2f ms  %s" % (
@@ -419,7 +422,7 @@ def run_sense(args, cfg, B, comm, world, rank, steps, warmup, want_cpu, quiet=Fa
     comp_bytes = sum(v['bytes'] / steps for v in prof.values())
     pmc, pmc_src = load_pmc(cfg)
     traffic_bytes, traffic_src = None, None
-    if pmc and world == 1 and not shard and not args.image and not args.coils and not args.osf and tree == "zpadfft":
+    if pmc and world == 1 and not shard and standard:
         tot = 0.0
         for sym, k in kernels.items():
             if sym in pmc:

@@ -361,6 +361,7 @@ class HipBackend(Backend):
         base implementation."""
         if team is not None or not (hasattr(A, 'eval')):
             return super().cg(A, b_h, x_h, lamda=lamda, tol=tol, maxiter=maxiter, team=team)
+        A, lamda = self._split_identity(A, lamda)
         base, nslots = self._slots()
         S = lambda i: ctypes.c_void_p(base + 8 * i)          # slot i (a device double)
         RRA, R0, RRB, ALPHA, HIST = 0, 1, 2, 4, 8            # rr lives in two slots used in turn (ig_cg_step_xp writes the other one)
@@ -414,6 +415,19 @@ class HipBackend(Backend):
         if not x_dev:
             x.copy_to(x_h)
         return history
+
+    @staticmethod
+    def _split_identity(A, lamda):
+        """(A', lamda') with A + lamda I = A' + lamda' I: examples/pics.py:195 puts the Tikhonov term INTO the operator
+        ((A.H * A) + lamda * Eye), which costs an axpby per evaluation; a real multiple of Eye at the root of the tree is
+        moved into cg's own lamda instead, where ig_cg_dot adds it on the pass that reads p and Ap anyway."""
+        from indigo_amd.operators import Sum, Scale, Eye
+        if isinstance(A, Sum):
+            for k in (0, 1):
+                c = A._children[k]
+                if isinstance(c, Scale) and isinstance(c.child, Eye) and np.imag(c._val) == 0:
+                    return A._children[1 - k], lamda + float(np.real(c._val))
+        return A, lamda
 
     def max(self, val, arr):
         """elementwise max on the real and imaginary parts independently"""
