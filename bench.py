@@ -673,14 +673,19 @@ def bench_spmm(args, local_rank, B=None):
     a_elapsed, a_prof = timed_steps(B, None, lambda: S.eval(Z, Y, forward=False), args.steps, args.warmup)
     a_ms = a_elapsed / args.steps * 1e3
     pmc, src = load_pmc(3) if n == 256 and ncol == 64 else (None, None)
-    traffic = None
-    if pmc:
-        traffic = sum(pmc[k]["hbm_bytes_per_launch"] for k in pmc if k.startswith("k_csrmm_gather") or k.startswith("k_pack"))
+    traffic = traffic_note = None
     a_traffic = None
     ktab_f, ktab_a = kernel_table(prof, args.steps), kernel_table(a_prof, args.steps)
     if pmc:
-        # (the repacking kernel serves both directions under one name and the zero-fill is a runtime kernel: no per-site PMC figure)
-        sym = {"csrmm_gather": "k_csrmm_gather", "csrmm_bricks_wide_conj": "k_bricks_wide64", "bricks_wide_zero": "k_wide_zero_unowned"}
+        # The repacking kernel serves both directions under ONE symbol: its PMC figure is the mean over a forward and an adjoint
+        # launch.  The adjoint's repack is dense (every byte of the panel read once and written once: its compulsory bytes ARE its
+        # traffic), so the forward's share is 2 x mean - that.
+        sym = {"csrmm_gather": "k_csrmm_gather", "csrmm_runs": "k_csrmm_runs64r", "csrmm_bricks_wide_conj": "k_bricks_wide64", "bricks_wide_zero": "k_wide_zero_unowned"}
+        packs = [k for k in pmc if k.startswith("k_pack_panel_tiled")]
+        a_pack = ktab_a.get("pack_panel", {}).get("bytes_per_launch")
+        if packs and a_pack and "pack_panel" in ktab_f:
+            ktab_f["pack_panel"]["pmc_bytes_per_launch"] = 2.0 * pmc[packs[0]]["hbm_bytes_per_launch"] - a_pack
+            traffic_note = "PMC of the product kernel + (2 x the repack kernel's mean over a forward and an adjoint launch - the adjoint repack's dense bytes)"
         for tab in (ktab_f, ktab_a):
             for site, ent in tab.items():
                 ks = [k for k in pmc if isinstance(pmc[k], dict) and sym.get(site) and k.startswith(sym[site])]
@@ -688,6 +693,8 @@ def bench_spmm(args, local_rank, B=None):
                     ent["pmc_bytes_per_launch"] = pmc[ks[0]]["hbm_bytes_per_launch"]
                     ent["pmc_GBps"] = round(pmc[ks[0]]["hbm_bytes_per_launch"] / (ent["avg_ms"] * 1e-3) / 1e9, 1)
         a_traffic = sum(e.get("pmc_bytes_per_launch", e.get("bytes_per_launch") or 0.0) * e["launches_per_step"] for e in ktab_a.values()) or None
+        if all("pmc_bytes_per_launch" in e for e in ktab_f.values()):
+            traffic = sum(e["pmc_bytes_per_launch"] * e["launches_per_step"] for e in ktab_f.values())
     # parity: column 5 against scipy, forward and adjoint
     x5 = X[:, 5:6].to_host()
     y5 = Y[:, 5:6].to_host()
@@ -720,7 +727,8 @@ def bench_spmm(args, local_rank, B=None):
                             peak=HBM_PEAK_GBS, unit="GB/s", frac=fb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             algorithmic_bytes_per_launch=fb,
                             bytes_model="SURVEY 8(d) / operators.py:246-256: nnz*12 + (M+1)*4 + K*n*8*col_frac + M*n*8",
-                            traffic=traffic, traffic_source=src if traffic else None, traffic_stale=pmc_stale(pmc),
+                            traffic=traffic, traffic_source=src if traffic else None, traffic_note=traffic_note if traffic else None,
+                            traffic_stale=pmc_stale(pmc),
                             traffic_frac_of_peak=(traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None),
            "cpu_baseline": cpu, "parity_rel_err": perr,
            "kernels": {"forward": ktab_f, "adjoint": ktab_a}}

@@ -46,6 +46,13 @@ def test_pics_on_the_gpu_matches_the_oracle_backend(tmp_path, hip, oracle_backen
     oracle_backend._scratch = None
     assert _rel(fused, ref) < 1e-3
     assert _rel(plain, ref) < 1e-3
+    # parity proper: ONE iteration (x = alpha r: a forward, two adjoints, two reductions; nothing amplified yet) is held to north_star's
+    # 1e-5 against the oracle backend running the same driver
+    one = ["-i", "1"] + args[2:]
+    fused1 = pics.main(["-O", "3"] + one, backend=hip)
+    ref1 = pics.main(["-O", "3", "--no-fuse"] + one, backend=oracle_backend)
+    oracle_backend._scratch = None
+    assert _rel(fused1, ref1) < 1e-5, _rel(fused1, ref1)
     # more iterations on the GPU alone: CG recovers the phantom up to the driver's normalisation of the right-hand side
     full = pics.main(["-O", "3", "-i", "30", "--osf", "2.0", "--width", "2", "--lamda", "1e-4", "--debug", "40", path], backend=hip)
     x, t = full.reshape(-1, order='F'), img.reshape(-1, order='F')
