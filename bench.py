@@ -524,8 +524,43 @@ def bench_sense(args, world, rank, local_rank):
     cfg = args.config
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and not args.shard and cfg == 4
     res = run_sense(args, cfg, B, comm, world, rank, args.steps, args.warmup, want_cpu)
+
+    def emit(extra5, leaves):
+        name = ("SENSE AHA evals/sec (256^3 x 8-coil non-Cartesian)" if cfg == 4 and not args.image and not args.coils and not args.osf
+                else "SENSE AHA evals/sec (%s)" % res["config"]["workload"].split(",", 1)[1].split(";")[0].strip())
+        out = {"metric": name, "value": res["value"], "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "dtype": "complex64 (f32)", "data": "synthetic"}
+        out.update({k: v for k, v in res.items() if k not in ("value", "ms_per_step")})
+        out.setdefault("cpu_baseline", None)
+        if extra5 is not None:
+            out["config5"] = extra5
+        out.update(leaves)
+        check_fractions({k: v for k, v in out.items() if k not in ("reference_model_equiv",)}, "line")
+        print(json.dumps(out), flush=True)
+
     extra5 = None
     if cfg == 4 and not args.no_config5 and not args.shard and not args.image and not args.coils and not args.osf and args.tree == "zpadfft":
+        # Multi-rank runs: the extra is a second distributed job.  If ONE rank fails in it alone, the others wait for it inside a
+        # collective -- the headline, already measured, must not go down with that: after a limit every rank gives up, rank 0
+        # prints the line with the extra marked as failed, and the processes leave without the clean-up a hung collective would block.
+        import threading
+        finished = threading.Event()
+        limit = int(os.environ.get("INDIGO_BENCH_EXTRA_LIMIT", "300") or 0)
+
+        def give_up():
+            if finished.is_set():
+                return
+            print("[bench] rank %d: the config-5 extra did not finish within %d s" % (rank, limit), file=sys.stderr, flush=True)
+            if rank == 0:
+                emit({"error": "the config-5 extra did not finish within %d s on every rank" % limit}, {})
+            sys.stderr.flush()
+            os._exit(0)
+        timer = None
+        if world > 1 and limit > 0:
+            timer = threading.Timer(limit, give_up)
+            timer.daemon = True
+            timer.start()
         try:
             r5 = run_sense(args, 5, B, comm, world, rank, max(2, min(args.steps, 5)), min(args.warmup, 2), False, quiet=True)
             extra5 = {"evals_per_s": r5["value"], "ms_per_step": r5["ms_per_step"], "setup_s": r5["setup_s"], "n_gpus": world, "config": r5["config"],
@@ -534,6 +569,10 @@ def bench_sense(args, world, rank, local_rank):
         except Exception as e:             # noqa: BLE001 -- the extra measurement must not cost the headline its line
             extra5 = {"error": "%s: %s" % (type(e).__name__, e)}
             print("[bench] config-5 extra failed on rank %d: %s" % (rank, extra5["error"]), file=sys.stderr, flush=True)
+        finally:
+            finished.set()
+            if timer is not None:
+                timer.cancel()
     leaves = {}
     if rank == 0 and world == 1 and cfg == 4 and not args.no_leaf_configs and not args.shard and not args.image and not args.coils and not args.osf \
             and args.tree == "zpadfft":
@@ -553,18 +592,7 @@ def bench_sense(args, world, rank, local_rank):
                 leaves["config%d" % c] = {"error": "%s: %s" % (type(e).__name__, e)}
                 print("[bench] config-%d extra failed: %s" % (c, leaves["config%d" % c]["error"]), file=sys.stderr, flush=True)
     if rank == 0:
-        name = ("SENSE AHA evals/sec (256^3 x 8-coil non-Cartesian)" if cfg == 4 and not args.image and not args.coils and not args.osf
-                else "SENSE AHA evals/sec (%s)" % res["config"]["workload"].split(",", 1)[1].split(";")[0].strip())
-        out = {"metric": name, "value": res.pop("value"), "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": res.pop("ms_per_step"), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-               "dtype": "complex64 (f32)", "data": "synthetic"}
-        out.update(res)
-        out.setdefault("cpu_baseline", None)
-        if extra5 is not None:
-            out["config5"] = extra5
-        out.update(leaves)
-        check_fractions({k: v for k, v in out.items() if k not in ("reference_model_equiv",)}, "line")
-        print(json.dumps(out), flush=True)
+        emit(extra5, leaves)
     if comm is not None:
         comm.close()
 
