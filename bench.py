@@ -56,15 +56,31 @@ PMC_NOTE = " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_
 # profile-scope name (call site) -> device kernel symbol as rocprofv3 prints it.  The template arguments of the FFT
 # kernel are <R1, R2, T, W, AXIS0, WMODE, BOXED, HALF> (indigo_amd/csrc/ig_fft.hip); which instantiation a pass runs
 # depends on the grid layout, the axis length and whether the image box is the middle half of the axis.
-def bricks_symbol(ncoils, support_tile):
-    """k_grid_bricks<NC, NSEG, PAIR>: segments per 16 x 2 x 2 brick unrolled for the 8-coil kernel (4 at 16 kx points per table entry, 8
-    at 8; the 4-point table's 16 segments are flushed in 8 pairs)"""
+def bricks_symbol(ncoils, support_tile, real_entries=False):
+    """k_grid_bricks<NC, NSEG, PAIR, REALW>: segments per 16 x 2 x 2 brick unrolled for the 8-coil kernel (4 at 16 kx points per table
+    entry, 8 at 8; the 4-point table's 16 segments are flushed in 8 pairs); REALW: 8-byte entries of a matrix with real weights"""
+    rw = "true" if real_entries else "false"
     if ncoils != 8:
-        return "k_grid_bricks<%d, 0, false>" % ncoils
-    return {16: "k_grid_bricks<8, 4, false>", 8: "k_grid_bricks<8, 8, false>", 4: "k_grid_bricks<8, 8, true>"}.get(support_tile, "k_grid_bricks<8, 0, false>")
+        return "k_grid_bricks<%d, 0, false, %s>" % (ncoils, rw)
+    return {16: "k_grid_bricks<8, 4, false, %s>", 8: "k_grid_bricks<8, 8, false, %s>", 4: "k_grid_bricks<8, 8, true, %s>"}.get(support_tile, "k_grid_bricks<8, 0, false, %s>") % rw
 
 
-def kernel_symbols(layout, ncoils, half_box=True, n=512, support_tile=16):
+def tree_real_entries(A):
+    """does the tree's gridding matrix carry the 8-byte brick entries of a real-weight matrix?"""
+    stack = [A]
+    while stack:
+        node = stack.pop()
+        md = getattr(node, '_matrix_d', None)
+        br, sl = getattr(md, '_bricks', None), getattr(md, '_slots', None)
+        if br is not None:
+            return br.get('words', 3) == 2
+        if sl is not None:
+            return sl.get('words', 4) == 3
+        stack.extend(getattr(node, '_children', None) or [])
+    return False
+
+
+def kernel_symbols(layout, ncoils, half_box=True, n=512, support_tile=16, real_entries=False):
     r1 = 32 if n == 512 else 16
     f = "k_fft_2stage<%d, 16, 16, %%s>" % r1
     m = {
@@ -74,18 +90,20 @@ def kernel_symbols(layout, ncoils, half_box=True, n=512, support_tile=16):
         "csrmm_gather": "k_csrmm_gather<8, 8, false, 0>",
     }
     lg = ncoils.bit_length() - 1
-    ab = {160: "10, 16, 1", 192: "12, 16, 1", 240: "15, 16, 1", 320: "16, 20, 1", 384: "16, 24, 2", 400: "20, 20, 2", 432: "18, 24, 2", 480: "20, 24, 2", 640: "20, 32, 2"}
+    ab = {160: "10, 16, 1", 192: "12, 16, 1", 240: "15, 16, 1", 320: "16, 20, 1", 384: "16, 24, 1", 400: "20, 20, 1", 432: "18, 24, 1", 480: "20, 24, 1", 640: "20, 32, 1"}
     if layout == 2 and n in ab:
         # the reference driver's own grids: zero-pad-aware passes on the A x B kernel <A, B, ROUNDS, WMODE> (ig_fft_ab.h)
         g = "anyfft::k_fft_ab_desc<%s, %%d>" % ab[n]
         m.update({"fft_pad_x": g % 1, "fft_pad_y": g % 0, "fft_pad_z": g % 0, "fft_crop_z": g % 0, "fft_crop_y": g % 0, "fft_crop_x": g % (3 + lg)})
-        gv = {8: "k_csrmm_gather_v<4, 2, 8, false, 0>", 4: "k_csrmm_gather_v<2, 2, 8, false, 0>",
-              2: "k_csrmm_gather_v<2, 1, 8, false, 0>"}.get(ncoils, "k_csrmm_gather")
+        rw = "true" if real_entries else "false"
+        gv = {8: "k_csrmm_gather_v<4, 2, 8, false, 0, %s>" % rw, 4: "k_csrmm_gather_v<2, 2, 8, false, 0, %s>" % rw,
+              2: "k_csrmm_gather_v<2, 1, 8, false, 0, %s>" % rw}.get(ncoils, "k_csrmm_gather")
         m.update({"csrmm_rowlane_conj": "k_csrmm_dense64<%d, true, true>" % ncoils, "csrmm_gather": gv,
-                  "csrmm_bricks_conj": bricks_symbol(ncoils, support_tile)})
+                  "csrmm_bricks_conj": bricks_symbol(ncoils, support_tile, real_entries)})
     elif layout == 2:
-        gv = {8: "k_csrmm_gather_v<4, 2, 8, false, 0>", 4: "k_csrmm_gather_v<2, 2, 8, false, 0>",
-              2: "k_csrmm_gather_v<2, 1, 8, false, 0>"}.get(ncoils, "k_csrmm_gather")
+        rw = "true" if real_entries else "false"
+        gv = {8: "k_csrmm_gather_v<4, 2, 8, false, 0, %s>" % rw, 4: "k_csrmm_gather_v<2, 2, 8, false, 0, %s>" % rw,
+              2: "k_csrmm_gather_v<2, 1, 8, false, 0, %s>" % rw}.get(ncoils, "k_csrmm_gather")
         if half_box and n == 512:
             m.update({"fft_pad_x": f % "16, false, 1, true, 3",
                       "fft_pad_y": f % "32, false, 0, true, 1", "fft_pad_z": f % "32, false, 0, true, 1",
@@ -99,15 +117,15 @@ def kernel_symbols(layout, ncoils, half_box=True, n=512, support_tile=16):
                       "fft_pad_y": f % "32, false, 0, true, 0", "fft_pad_z": f % (zt + ", false, 0, true, 0"),
                       "fft_crop_z": f % (zt + ", false, 0, true, 0"), "fft_crop_y": f % "32, false, 0, true, 0",
                       "fft_crop_x": f % ("16, false, %d, true, 0" % (3 + lg))})
-        m.update({"csrmm_rowlane_conj": "k_csrmm_dense64<%d, true, true>" % ncoils, "csrmm_gather": gv, "csrmm_slots_conj": "k_grid_slots<%d>" % ncoils,
-                  "csrmm_bricks_conj": bricks_symbol(ncoils, support_tile)})
+        m.update({"csrmm_rowlane_conj": "k_csrmm_dense64<%d, true, true>" % ncoils, "csrmm_gather": gv, "csrmm_slots_conj": "k_grid_slots<%d, %s>" % (ncoils, "true" if real_entries else "false"),
+                  "csrmm_bricks_conj": bricks_symbol(ncoils, support_tile, real_entries)})
     elif layout == 1:
         h = (3, 1, 1, 2, 2, 4) if half_box else (0,) * 6
         w = 32 if (half_box and n == 512) else 16         # compile-time half box: 32-column tiles (launch_2stage, ig_fft.hip)
         m.update({"fft_pad_x": f % ("16, true, 1, true, %d" % h[0]), "fft_pad_y": f % ("%d, false, 0, true, %d" % (w, h[1])),
                   "fft_pad_z": f % ("%d, false, 0, true, %d" % (w, h[2])), "fft_crop_z": f % ("%d, false, 0, true, %d" % (w, h[3])),
                   "fft_crop_y": f % ("%d, false, 0, true, %d" % (w, h[4])), "fft_crop_x": f % ("16, true, 2, true, %d" % h[5]),
-                  "csrmm_rowlane_conj": "k_csrmm_dense64<%d, true, false>" % ncoils, "csrmm_slots_conj": "k_grid_slots<%d>" % ncoils})
+                  "csrmm_rowlane_conj": "k_csrmm_dense64<%d, true, false>" % ncoils, "csrmm_slots_conj": "k_grid_slots<%d, %s>" % (ncoils, "true" if real_entries else "false")})
     return m
 
 
@@ -398,7 +416,7 @@ def run_sense(args, cfg, B, comm, world, rank, steps, warmup, want_cpu, quiet=Fa
                 # 4 * x.nbytes per 3-D transform, a third per pass; x = grid x coils
                 prof[name]['ref_bytes'] = 4.0 * np.prod(p.oN) * 8.0 * cpr / 3.0 * prof[name]['launches']
     csr = {(r['name'], r['forward']): r['nbytes'] for r in trace.records if r['event'] == 'csrmm' and not r.get('fused')}
-    grid_bytes = p.gridding_pass_bytes(cpr, sup_tab, tile=sup_tile) if fused_fft else {}
+    grid_bytes = p.gridding_pass_bytes(cpr, sup_tab, tile=sup_tile, real_entries=tree_real_entries(A)) if fused_fft else {}
     for site, fwd in (("csrmm_gather", True), ("csrmm_rowlane_conj", False), ("csrmm_gather_conj", False), ("csrmm_bricks_conj", False),
                       ("csrmm_slots_conj", False)):
         nb = csr.get(('interp*mod*scale', fwd))
@@ -408,7 +426,7 @@ def run_sense(args, cfg, B, comm, world, rank, steps, warmup, want_cpu, quiet=Fa
             prof[site]['bytes'] = float(grid_bytes.get(site, nb)) * prof[site]['launches']
     if "pack_panel" in prof and "pack_panel" in grid_bytes:
         prof["pack_panel"]['bytes'] = float(grid_bytes["pack_panel"]) * prof["pack_panel"]['launches']
-    symbols = kernel_symbols(layout if fused_fft else 0, cpr, half_box, p.oN[0], sup_tile if fused_fft else 16)
+    symbols = kernel_symbols(layout if fused_fft else 0, cpr, half_box, p.oN[0], sup_tile if fused_fft else 16, tree_real_entries(A))
     standard = not args.image and not args.coils and not (args.osf if cfg == 4 else 0) and tree == "zpadfft"
     roofline, kernels = roofline_of(prof, symbols, cfg, traffic_ok=(standard and cpr == 8))
     if not quiet:

@@ -61,6 +61,9 @@ PROTOTYPES = {
     "ig_ccsrmm_il":       (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64,
                                    c_float, c_float, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_float, c_float, c_void_p, c_int64]),
+    "ig_ccsrmm_il_rw":    (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64,
+                                   c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_float, c_float, c_void_p, c_int64]),
     "ig_ccsrmm_t_grid_il": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int64,
                                     c_float, c_float, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_int64, c_void_p,
@@ -69,7 +72,7 @@ PROTOTYPES = {
     "ig_grid_bricks_fill": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ig_ccsrmm_t_bricks": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_float, c_float, c_void_p, c_void_p,
                                    c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_int64,
-                                   c_void_p, c_void_p, c_int64, c_int, c_int]),
+                                   c_void_p, c_void_p, c_int64, c_int, c_int, c_int]),
     "ig_ccsrmm":          (c_int, [c_void_p, c_int, c_int, c_int64, c_int64, c_int64, c_int64,
                                    c_float, c_float, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_int64, c_float, c_float, c_void_p, c_int64]),
@@ -82,11 +85,11 @@ PROTOTYPES = {
                                    c_void_p, c_int64, c_int64, c_void_p]),
     "ig_grid_slots_build": (c_int, [c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, POINTER(c_int64)]),
     "ig_ccsrmm_t_slots":  (c_int, [c_void_p, c_int64, c_int64, c_int64, c_float, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
-                                   c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int]),
+                                   c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int]),
     "ig_ccsrmm_t_bricks_wide": (c_int, [c_void_p, c_int64, c_int64, c_float, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                         c_void_p, c_int64, c_void_p, c_void_p]),
     "ig_ccsrmm_t_bricks_wide_grid": (c_int, [c_void_p, c_int64, c_int64, c_float, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
-                                             c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int]),
+                                             c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int]),
     "ig_fft_set_support_tile": (c_int, [c_void_p, c_int]),
     "ig_csr_runs_build":  (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_int)]),
     "ig_ccsrmm_xrows_runs": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,

@@ -23,6 +23,15 @@ log = logging.getLogger(__name__)
 _C64 = np.dtype('complex64')
 
 
+def weights_are_real(data):
+    """True when the imaginary parts of a complex64 array are nothing but rounding residue: at most 2^-40 of the largest magnitude
+    (dropping them changes a float32 product by less than 1e-12 of a unit in the last place)"""
+    if data.size == 0:
+        return False
+    im = float(np.abs(data.imag).max())
+    return im == 0.0 or im <= float(np.abs(data.real).max()) * 2.0 ** -40
+
+
 def brick_tasks(counts, ptr, chunk, run, max_bricks=64, longest_first=True):
     """Task list and brick table of ig_ccsrmm_t_bricks (include/indigo_hip.h) from the entries per brick `counts` and their
     prefix sums `ptr`: table = (brick, end of its entries) per non-empty brick; a brick with more than `chunk` entries is
@@ -783,7 +792,13 @@ class HipBackend(Backend):
             fine = getattr(self, '_support_fine', None)
             nseg = (16 // (fine[1] if fine is not None else 16)) * bm * bs          # segments per brick (the kernel looks up 512 per run)
             tasks, table, shared = brick_tasks(counts, ptr, chunk, run, max_bricks=min(64, 512 // nseg))
-            self._bricks = dict(n0=int(n0), nm=int(nm), bm=int(bm), bs=int(bs), ncols=int(ncols), ntasks=int(tasks.shape[0]),
+            # Real weights (a gridding matrix times the +-1 modulation of a centred transform on an even grid, whose imaginary parts
+            # are the 1e-16 rounding residue of exp(i pi k)): 8-byte entries {cell, re}
+            words = 3
+            if b.tuning.get('real_entries', True) and weights_are_real(data):
+                entries = np.ascontiguousarray(entries[:, :2])
+                words = 2
+            self._bricks = dict(n0=int(n0), nm=int(nm), bm=int(bm), bs=int(bs), ncols=int(ncols), ntasks=int(tasks.shape[0]), words=words,
                                 nshared=int(shared.size), nentries=int(ptr[-1]),
                                 tasks=b.copy_array(tasks.reshape(-1) if tasks.size else np.zeros(4, np.int32), name=self._name + ".brickTasks"),
                                 table=b.copy_array(table.reshape(-1) if table.size else np.zeros(2, np.int32), name=self._name + ".brickTable"),
@@ -828,7 +843,11 @@ class HipBackend(Backend):
             fine = getattr(self, '_support_fine', None)
             nseg = (16 // (fine[1] if fine is not None else 16)) * bm * bs      # segments per brick (the kernel looks up 512 per run)
             tasks, table, shared = brick_tasks(brick_slots, sptr, chunk, run, max_bricks=min(64, 512 // nseg))
-            self._slots = dict(n0=int(n0), nm=int(nm), bm=int(bm), bs=int(bs), ncols=int(ncols), ntasks=int(tasks.shape[0]),
+            words = 4
+            if b.tuning.get('real_entries', True) and weights_are_real(data):
+                e16 = np.ascontiguousarray(e16.reshape(-1, 4)[:, [0, 1, 3]])     # {cell, re, row}: 12 bytes per nonzero
+                words = 3
+            self._slots = dict(n0=int(n0), nm=int(nm), bm=int(bm), bs=int(bs), ncols=int(ncols), ntasks=int(tasks.shape[0]), words=words,
                                nshared=int(shared.size), nslots=int(nslots.value), nentries=nent,
                                tasks=b.copy_array(tasks.reshape(-1) if tasks.size else np.zeros(4, np.int32), name=self._name + ".slotTasks"),
                                table=b.copy_array(table.reshape(-1) if table.size else np.zeros(2, np.int32), name=self._name + ".slotTable"),
@@ -916,7 +935,11 @@ class HipBackend(Backend):
                 for is_ in range(bs):
                     owned[bx + nbx * ((bmi * bm + im) + nm * (bsi * bs + is_))] = True
             bits = np.packbits(np.concatenate([owned, np.zeros((-owned.size) % 32, dtype=bool)]), bitorder='little').view(np.uint32)
-            self._wide = dict(ntasks=int(tasks.shape[0]), geom=(n0, nm, bm, bs),
+            words = 3
+            if bm * bs > 1 and b.tuning.get('real_entries', True) and weights_are_real(data):
+                e12 = np.ascontiguousarray(e12[:, :2])            # {cell, re}: the register-image kernel's real-weight form
+                words = 2
+            self._wide = dict(ntasks=int(tasks.shape[0]), geom=(n0, nm, bm, bs), words=words,
                               owned=b.copy_array(bits, name=self._name + ".wideOwnedTiles"),
                               tasks=b.copy_array(tasks.reshape(-1) if tasks.size else np.zeros(4, np.int32), name=self._name + ".wideTasks"),
                               table=b.copy_array(table.reshape(-1) if table.size else np.zeros(2, np.int32), name=self._name + ".wideTable"),
@@ -982,6 +1005,18 @@ class HipBackend(Backend):
             self._t = None
             self._perm = b.copy_array(perm, name=self._name + ".rowOrder")
 
+        def _real_values(self):
+            """the weights' real parts as a float32 device array when the matrix is real up to rounding residue (built on first
+            use; None otherwise, or when the backend's tuning asks for complex entries)"""
+            r = getattr(self, '_values_re', False)
+            if r is False:
+                r = None
+                data = self._host_csr.data if self._host_csr is not None else self.values.to_host()
+                if self._backend.tuning.get('real_entries', True) and weights_are_real(data):
+                    r = self._backend.copy_array(np.ascontiguousarray(data.real, dtype=np.float32), name=self._name + ".dataRe")
+                self._values_re = r
+            return r
+
         def forward(self, y, x, alpha=1, beta=0):
             perm = getattr(self, '_perm', None)
             if getattr(self, '_grid_il', False):
@@ -991,6 +1026,14 @@ class HipBackend(Backend):
                 ar, ai = _cplx(alpha)
                 br, bi = _cplx(beta)
                 m, k = self.shape
+                vre = self._real_values() if x.shape[1] in (2, 4, 8) else None
+                if vre is not None:
+                    # every weight real (see weights_are_real): the gather reads 4-byte values
+                    b._check(b._L.ig_ccsrmm_il_rw(b._ctx, m, k, x.shape[1], self.values.size, ar, ai,
+                                                  ctypes.c_void_p(self.values._arr), ctypes.c_void_p(vre._arr), ctypes.c_void_p(self.colInds._arr),
+                                                  ctypes.c_void_p(self.rowPtrs._arr), ctypes.c_void_p(x._arr), br, bi,
+                                                  ctypes.c_void_p(y._arr), y._leading_dim), "ig_ccsrmm_il_rw")
+                    return
                 b._check(b._L.ig_ccsrmm_il(b._ctx, m, k, x.shape[1], self.values.size, ar, ai,
                                            ctypes.c_void_p(self.values._arr), ctypes.c_void_p(self.colInds._arr),
                                            ctypes.c_void_p(self.rowPtrs._arr), ctypes.c_void_p(x._arr), br, bi,
@@ -1066,7 +1109,7 @@ class HipBackend(Backend):
                                                  ctypes.c_void_p(y._arr), ctypes.c_void_p(tab._arr) if tab is not None else None,
                                                  br['n0'], br['nm'], br['bm'], br['bs'], ctypes.c_void_p(br['tasks']._arr), br['ntasks'],
                                                  ctypes.c_void_p(br['table']._arr), ctypes.c_void_p(br['shared']._arr), br['nshared'], tile,
-                                                 getattr(self, '_support_zw', 16)),
+                                                 getattr(self, '_support_zw', 16), br['words']),
                          "ig_ccsrmm_t_bricks")
                 return
             sl = getattr(self, '_slots', None)
@@ -1081,7 +1124,7 @@ class HipBackend(Backend):
                                                 ctypes.c_void_p(x._arr), x._leading_dim, ctypes.c_void_p(y._arr),
                                                 ctypes.c_void_p(tab._arr) if tab is not None else None, sl['n0'], sl['nm'], sl['bm'], sl['bs'],
                                                 ctypes.c_void_p(sl['tasks']._arr), sl['ntasks'], ctypes.c_void_p(sl['table']._arr),
-                                                ctypes.c_void_p(sl['shared']._arr), sl['nshared'], tile, getattr(self, '_support_zw', 16)),
+                                                ctypes.c_void_p(sl['shared']._arr), sl['nshared'], tile, getattr(self, '_support_zw', 16), sl['words']),
                          "ig_ccsrmm_t_slots")
                 return
             if (x.shape[1] == 64 and beta == 0 and perm is None and not getattr(self, '_grid_il', False) and self.shape[1] % 16 == 0
@@ -1096,7 +1139,7 @@ class HipBackend(Backend):
                     b._check(b._L.ig_ccsrmm_t_bricks_wide_grid(b._ctx, m, k, ar, ai, ctypes.c_void_p(wb['entries']._arr), ctypes.c_void_p(wb['rows']._arr),
                                                                ctypes.c_void_p(x._arr), x._leading_dim, ctypes.c_void_p(y._arr), y._leading_dim,
                                                                ctypes.c_void_p(wb['tasks']._arr), wb['ntasks'], ctypes.c_void_p(wb['table']._arr),
-                                                               ctypes.c_void_p(wb['owned']._arr), n0, nm, bm, bs),
+                                                               ctypes.c_void_p(wb['owned']._arr), n0, nm, bm, bs, wb['words']),
                              "ig_ccsrmm_t_bricks_wide_grid")
                     return
             if getattr(self, '_grid_il', False):

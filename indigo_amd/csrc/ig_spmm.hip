@@ -184,7 +184,8 @@ k_csrmm_gather(int64_t M, int64_t N,
 // owns VW consecutive columns and fetches them with 16-byte loads, so a row needs only (N/VW) x NL lanes and a wave
 // covers 64 / ((N/VW)*NL) rows with the same dependent chain as one row per wave: the kernel is latency bound, more
 // rows per wave is more rows per unit time.
-template <int VW, int CLV, int NL, bool CONJ, int BMODE>
+// REALW: `vals` points to FLOATS, the real parts of a matrix whose weights are all real (4 bytes per nonzero instead of 8).
+template <int VW, int CLV, int NL, bool CONJ, int BMODE, bool REALW = false>
 __global__ void __launch_bounds__(BLK)
 k_csrmm_gather_v(int64_t M, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colind,
                  const float2* __restrict__ vals, const float2* __restrict__ X, int64_t sxr,
@@ -224,7 +225,7 @@ k_csrmm_gather_v(int64_t M, const int32_t* __restrict__ rowptr, const int32_t* _
             const bool ok = pu < p1;
             const int32_t q = ok ? pu : p1 - 1;
             k4[u] = colind[q];
-            const float2 vv = vals[q];
+            const float2 vv = REALW ? make_float2(reinterpret_cast<const float*>(vals)[q], 0.f) : vals[q];
             v4[u] = ok ? vv : make_float2(0.f, 0.f);
         }
 #pragma unroll
@@ -235,8 +236,13 @@ k_csrmm_gather_v(int64_t M, const int32_t* __restrict__ rowptr, const int32_t* _
         for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int h = 0; h < NV; ++h) {
-                acc_nz<CONJ>(acc[2 * h], v4[u], make_float2(x4[u][h].x, x4[u][h].y));
-                acc_nz<CONJ>(acc[2 * h + 1], v4[u], make_float2(x4[u][h].z, x4[u][h].w));
+                if (REALW) {            // (conj of a real weight is itself)
+                    acc[2 * h].x = fmaf(v4[u].x, x4[u][h].x, acc[2 * h].x);         acc[2 * h].y = fmaf(v4[u].x, x4[u][h].y, acc[2 * h].y);
+                    acc[2 * h + 1].x = fmaf(v4[u].x, x4[u][h].z, acc[2 * h + 1].x); acc[2 * h + 1].y = fmaf(v4[u].x, x4[u][h].w, acc[2 * h + 1].y);
+                } else {
+                    acc_nz<CONJ>(acc[2 * h], v4[u], make_float2(x4[u][h].x, x4[u][h].y));
+                    acc_nz<CONJ>(acc[2 * h + 1], v4[u], make_float2(x4[u][h].z, x4[u][h].w));
+                }
             }
     }
 #pragma unroll
@@ -1267,10 +1273,12 @@ struct BrickEntry { uint32_t cell; float re, im; };       // 12 bytes; cell == 0
 // at a time -- segments 2 p and 2 p + 1 are the two halves of the same 8 cells x NC values a wave stores with one instruction, so the
 // loop keeps the shape of the 8-point table's (NSEG unrolled stores) and a half-wave is predicated by its own flag.  (Unrolled 16
 // times the flush spilled; the generic loop cost 0.86 against 0.76 ms and ate what the finer table saves the z passes.)
-template <int NC, int NSEG /* bm * bs, or 0: any */, bool PAIR = false>
+// REALW: the entries are 8 bytes {cell, re} -- every weight real (a gridding matrix times the +-1 modulation of a centred transform on
+// an even grid): a third less of the format to read, four ds_bpermute per round instead of five, two multiply-adds instead of four.
+template <int NC, int NSEG /* bm * bs, or 0: any */, bool PAIR = false, bool REALW = false>
 __global__ void __launch_bounds__(BLK)
 k_grid_bricks(const BrickTask* __restrict__ tasks, int ntasks, const BrickRef* __restrict__ btab,
-              const BrickEntry* __restrict__ entries, const uint32_t* __restrict__ round_rows,
+              const BrickEntry* __restrict__ entries /* REALW: {cell, re} pairs */, const uint32_t* __restrict__ round_rows,
               const float2* __restrict__ Xp /* packed rows: [t][NC] */,
               float2* __restrict__ Y, float2 alpha, const uint32_t* __restrict__ bits,
               int n0, int nm, int bm_log2, int bs_log2, int nbx, int nbm, int st_log2 /* log2(cells per segment) */, int zw /* words per entry of the support bitmaps */) {
@@ -1291,7 +1299,8 @@ k_grid_bricks(const BrickTask* __restrict__ tasks, int ntasks, const BrickRef* _
     const int BM = 1 << bm_log2, nseg = NSEG ? (PAIR ? 2 * NSEG : NSEG) : 1 << seg_log2, ncell = 16 << (bm_log2 + bs_log2);
     float2* __restrict__ acc = acc_all + (size_t)wv * ncell * NC;
     const int coil = lane % NC, tsub = lane / NC, xround = (lane / NC) % RS;
-    const rsrc_t r_en = make_rsrc(entries + tk.lo), r_rr = make_rsrc(round_rows + tk.lo / TPR), r_x = make_rsrc(Xp);
+    const rsrc_t r_en = REALW ? make_rsrc(reinterpret_cast<const float2*>(entries) + tk.lo) : make_rsrc(entries + tk.lo);
+    const rsrc_t r_rr = make_rsrc(round_rows + tk.lo / TPR), r_x = make_rsrc(Xp);
 
     struct Set { u3 en; uint32_t rid; float2 x; };
     Set s0, s1, s2, s3;
@@ -1303,7 +1312,12 @@ k_grid_bricks(const BrickTask* __restrict__ tasks, int ntasks, const BrickRef* _
     };
     auto request_entries = [&](Set& s, int st) {         // (past the end of the task: nothing is fetched)
         const int32_t idx = st * 64 + lane;
-        s.en = buf_ld_u3(r_en, idx < nent ? (unsigned)idx * 12u : IG_OOB);
+        if (REALW) {
+            const float2 t = buf_ld<false>(r_en, idx < nent ? (unsigned)idx * 8u : IG_OOB, 0);
+            s.en.x = __float_as_uint(t.x); s.en.y = __float_as_uint(t.y); s.en.z = 0u;
+        } else {
+            s.en = buf_ld_u3(r_en, idx < nent ? (unsigned)idx * 12u : IG_OOB);
+        }
     };
     auto request_rows = [&](Set& s, int st) {            // panel rows of super-trip st (its samples have arrived)
         const int32_t q = st * RS + xround;
@@ -1415,14 +1429,19 @@ k_grid_bricks(const BrickTask* __restrict__ tasks, int ntasks, const BrickRef* _
             const int from_e = (r * TPR + tsub) * 4, from_x = (r * NC + coil) * 4;
             const uint32_t cell = (uint32_t)__builtin_amdgcn_ds_bpermute(from_e, (int)e_cell);
             const float vr = __int_as_float(__builtin_amdgcn_ds_bpermute(from_e, (int)e_re));
-            const float vi = __int_as_float(__builtin_amdgcn_ds_bpermute(from_e, (int)e_im));
+            const float vi = REALW ? 0.f : __int_as_float(__builtin_amdgcn_ds_bpermute(from_e, (int)e_im));
             const float xr = __int_as_float(__builtin_amdgcn_ds_bpermute(from_x, __float_as_int(x_re)));
             const float xi = __int_as_float(__builtin_amdgcn_ds_bpermute(from_x, __float_as_int(x_im)));
             if (cell != 0xffffffffu) {
                 float2* a = acc + (int)cell * NC + coil;
                 float2 v = *a;                                            // plain read-add-write: the entries of a round belong to
-                v.x += fmaf(vr, xr, vi * xi);                             // one sample (distinct cells), the image is this wave's,
-                v.y += fmaf(vr, xi, -vi * xr);                            // and a wave's LDS operations execute in order.  conj(v) * x
+                if (REALW) {                                              // one sample (distinct cells), the image is this wave's,
+                    v.x = fmaf(vr, xr, v.x);                              // and a wave's LDS operations execute in order.  conj(v) * x
+                    v.y = fmaf(vr, xi, v.y);
+                } else {
+                    v.x += fmaf(vr, xr, vi * xi);
+                    v.y += fmaf(vr, xi, -vi * xr);
+                }
                 *a = v;
             }
         }
@@ -1449,7 +1468,8 @@ k_grid_bricks(const BrickTask* __restrict__ tasks, int ntasks, const BrickRef* _
 // instructions and there are few of them.  Entries are requested two slots ahead, the panel rows of their samples one.
 struct SlotEntry { uint32_t cell; float re, im; uint32_t row; };
 
-template <int NC>
+// REALW: 12-byte entries {cell, re, sample} of a matrix whose weights are all real.
+template <int NC, bool REALW = false>
 __global__ void __launch_bounds__(BLK)
 k_grid_slots(const BrickTask* __restrict__ tasks, int ntasks, const BrickRef* __restrict__ btab,
              const int32_t* __restrict__ slot_ptr, const SlotEntry* __restrict__ entries,
@@ -1540,9 +1560,14 @@ k_grid_slots(const BrickTask* __restrict__ tasks, int ntasks, const BrickRef* __
     const rsrc_t r_sp = make_rsrc(slot_ptr + tk.lo), r_en = make_rsrc(entries), r_x = make_rsrc(Xp);
     struct XV { float2 v[NC]; };
     auto load_entry = [&](int32_t off, int32_t n) -> SlotEntry {
-        const float4 q = buf_ld_f4(r_en, lane < n ? (unsigned)(off + lane) * 16u : IG_OOB);
         SlotEntry e;
-        e.cell = lane < n ? __float_as_uint(q.x) : 0xffffffffu; e.re = q.y; e.im = q.z; e.row = __float_as_uint(q.w);
+        if (REALW) {
+            const u3 q = buf_ld_u3(r_en, lane < n ? (unsigned)(off + lane) * 12u : IG_OOB);
+            e.cell = lane < n ? q.x : 0xffffffffu; e.re = __uint_as_float(q.y); e.im = 0.f; e.row = q.z;
+        } else {
+            const float4 q = buf_ld_f4(r_en, lane < n ? (unsigned)(off + lane) * 16u : IG_OOB);
+            e.cell = lane < n ? __float_as_uint(q.x) : 0xffffffffu; e.re = q.y; e.im = q.z; e.row = __float_as_uint(q.w);
+        }
         return e;
     };
     auto load_x = [&](const SlotEntry& e) -> XV {
@@ -1576,8 +1601,13 @@ k_grid_slots(const BrickTask* __restrict__ tasks, int ntasks, const BrickRef* __
                 for (int c = 0; c < NC; ++c) {
                     float2* a = acc + (int)e0.cell * NC + c;
                     float2 t = *a;                                               // the cells of a slot are distinct
-                    t.x += fmaf(e0.re, x0.v[c].x, e0.im * x0.v[c].y);            // conj(v) * x
-                    t.y += fmaf(e0.re, x0.v[c].y, -e0.im * x0.v[c].x);
+                    if (REALW) {
+                        t.x = fmaf(e0.re, x0.v[c].x, t.x);
+                        t.y = fmaf(e0.re, x0.v[c].y, t.y);
+                    } else {
+                        t.x += fmaf(e0.re, x0.v[c].x, e0.im * x0.v[c].y);        // conj(v) * x
+                        t.y += fmaf(e0.re, x0.v[c].y, -e0.im * x0.v[c].x);
+                    }
                     *a = t;
                 }
             }
@@ -1731,7 +1761,9 @@ __device__ __forceinline__ void wide_img_zero() {
     }
 }
 
-template <int NT /* 16-row tiles per brick: bm * bs = 2, 4 */>
+// REALW: 8-byte entries {cell, re} of a matrix whose weights are all real (a plain gridding matrix): a third less of the format to read,
+// two v_readlane and two multiply-adds less per entry.
+template <int NT /* 16-row tiles per brick: bm * bs = 2, 4 */, bool REALW = false>
 __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_num_vgpr(72)))
 k_bricks_wide64r(const BrickTask* __restrict__ tasks, int ntasks, const BrickRef* __restrict__ btab,
                  const BrickEntry* __restrict__ entries, const uint32_t* __restrict__ quad_rows,
@@ -1751,7 +1783,7 @@ k_bricks_wide64r(const BrickTask* __restrict__ tasks, int ntasks, const BrickRef
     const int32_t nquad = nent >> 2;
     float2* __restrict__ acc = acc_all + wv * 16 * WIDE_LD;
     asm volatile("s_set_gpr_idx_on %0, 0x0" :: "s"(0));
-    rsrc_t r_en = make_rsrc(entries + tk.lo);            // (not const: operands of assembly blocks inside generic lambdas)
+    rsrc_t r_en = REALW ? make_rsrc(reinterpret_cast<const float2*>(entries) + tk.lo) : make_rsrc(entries + tk.lo);   // (not const: operands of assembly blocks inside generic lambdas)
     rsrc_t r_qr = make_rsrc(quad_rows + (tk.lo >> 2));
     rsrc_t r_x = make_rsrc(Xp);
 
@@ -1762,12 +1794,17 @@ k_bricks_wide64r(const BrickTask* __restrict__ tasks, int ntasks, const BrickRef
     auto load_raw = [&](auto slot, int ti) __attribute__((always_inline)) {
         constexpr int R = 72 + 4 * decltype(slot)::value;
         const int32_t e = ti * TRIP + lane, q = ti * TQ + lane + AHEAD;
-        const unsigned oe = (lane < TRIP && e < nent) ? (unsigned)e * 12u : IG_OOB;
+        const unsigned oe = (lane < TRIP && e < nent) ? (unsigned)e * (REALW ? 8u : 12u) : IG_OOB;
         const unsigned oq = (lane < TQ && q < nquad) ? (unsigned)q * 4u : IG_OOB;           // (past the end: row 0, never used)
         const rsrc_t ren = r_en, rqr = r_qr;             // (copies: a generic lambda does not capture a variable only an asm operand names)
-        asm volatile("buffer_load_dwordx3 v[%0:%1], %3, %4, 0 offen\n\t"
-                     "buffer_load_dword v[%2], %5, %6, 0 offen"
-                     :: "i"(R), "i"(R + 2), "i"(R + 3), "v"(oe), "s"(ren), "v"(oq), "s"(rqr) : "memory");
+        if (REALW)
+            asm volatile("buffer_load_dwordx2 v[%0:%1], %3, %4, 0 offen\n\t"
+                         "buffer_load_dword v[%2], %5, %6, 0 offen"
+                         :: "i"(R), "i"(R + 1), "i"(R + 3), "v"(oe), "s"(ren), "v"(oq), "s"(rqr) : "memory");
+        else
+            asm volatile("buffer_load_dwordx3 v[%0:%1], %3, %4, 0 offen\n\t"
+                         "buffer_load_dword v[%2], %5, %6, 0 offen"
+                         :: "i"(R), "i"(R + 2), "i"(R + 3), "v"(oe), "s"(ren), "v"(oq), "s"(rqr) : "memory");
     };
     auto cook_a = [&]() __attribute__((always_inline)) {                        // slot A -> the words the loop reads with v_readlane
         uint32_t c, re, im, row;
@@ -1878,7 +1915,21 @@ k_bricks_wide64r(const BrickTask* __restrict__ tasks, int ntasks, const BrickRef
         for (int i = 0; i < 4; ++i) {
             mw[i] = (uint32_t)__builtin_amdgcn_readlane((int)tc.m0w, 4 * KQ + i);
             wr[i] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(tc.re), 4 * KQ + i));
-            wi[i] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(tc.im), 4 * KQ + i));
+            if (!REALW) wi[i] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(tc.im), 4 * KQ + i));
+        }
+        if (REALW) {
+            // image[cell] += w * x, w real
+#define IG_WIDE_MAC_R(M, WR) \
+                     "s_mov_b32 m0, " M "\n\ts_nop 0\n\t" \
+                     "v_fma_f32 v128, " WR ", v[%8], v128\n\t" \
+                     "v_fma_f32 v129, " WR ", v[%9], v129\n\t"
+            asm volatile("s_waitcnt vmcnt(11)\n\t"                            // this quad's row has arrived
+                         IG_WIDE_MAC_R("%0", "%4") IG_WIDE_MAC_R("%1", "%5") IG_WIDE_MAC_R("%2", "%6") IG_WIDE_MAC_R("%3", "%7")
+                         "s_mov_b32 m0, 0"
+                         :: "s"(mw[0]), "s"(mw[1]), "s"(mw[2]), "s"(mw[3]), "s"(wr[0]), "s"(wr[1]), "s"(wr[2]), "s"(wr[3]),
+                            "i"(80 + 2 * KQ), "i"(81 + 2 * KQ) : "memory");
+#undef IG_WIDE_MAC_R
+            return;
         }
         // image[cell] += conj(v) * x for the quad's four entries (one panel row)
 #define IG_WIDE_MAC(M, WR, WI) \
@@ -1993,7 +2044,9 @@ int launch_gather(ig_ctx* ctx, int64_t rows, int64_t xrows, int64_t N, int64_t n
                   const int32_t* rowptr, const int32_t* colind, const float2* vals,
                   const float2* X, int64_t ldx, float2* Y, int64_t ldy, float2 alpha, float2 beta,
                   GridMask mask = GridMask{nullptr, 0, 0}, const int32_t* yperm = nullptr,
-                  const int32_t* xperm = nullptr, bool x_il = false, bool y_il = false) {
+                  const int32_t* xperm = nullptr, bool x_il = false, bool y_il = false, const float* rvals = nullptr) {
+    // rvals: the real parts of `vals` as floats, for a matrix whose weights are all real; the several-rows-per-wave gather over an
+    // interleaved panel of 2, 4 or 8 columns reads them instead (rows it defers to the long-row kernels still take `vals`)
     // x_il / y_il: the panel is stored row-major (its N values of a row contiguous, row stride N) instead of
     // column-major with a leading dimension -- the coil-interleaved grid of the fused transform's layout 2
     const Shape s = pick_shape(rows, N, nnz);
@@ -2152,6 +2205,17 @@ int launch_gather(ig_ctx* ctx, int64_t rows, int64_t xrows, int64_t N, int64_t n
                         rows, rowptr, colind, vals, X, sxr, Y, ldy, alpha, beta, xcd, wl, thr_mid, thr_long);   \
             else    hipLaunchKernelGGL((k_csrmm_gather_v<VW_, CLV_, NL_, CONJ, 1>), dim3((unsigned)vblocks), dim3(BLK), 0, ctx->stream, \
                         rows, rowptr, colind, vals, X, sxr, Y, ldy, alpha, beta, xcd, wl, thr_mid, thr_long); } while (0)
+#define IG_GVR(VW_, CLV_, NL_) do {                                                                        \
+            const int rpw_v = 64 / (CLV_ * NL_);                                                           \
+            const int64_t vblocks = ((rows + rpw_v - 1) / rpw_v + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;  \
+            if (b0) hipLaunchKernelGGL((k_csrmm_gather_v<VW_, CLV_, NL_, CONJ, 0, true>), dim3((unsigned)vblocks), dim3(BLK), 0, ctx->stream, \
+                        rows, rowptr, colind, reinterpret_cast<const float2*>(rvals), X, sxr, Y, ldy, alpha, beta, xcd, wl, thr_mid, thr_long);   \
+            else    hipLaunchKernelGGL((k_csrmm_gather_v<VW_, CLV_, NL_, CONJ, 1, true>), dim3((unsigned)vblocks), dim3(BLK), 0, ctx->stream, \
+                        rows, rowptr, colind, reinterpret_cast<const float2*>(rvals), X, sxr, Y, ldy, alpha, beta, xcd, wl, thr_mid, thr_long); } while (0)
+            if (rvals && N == 8 && vw >= 4 && vw < 8) IG_GVR(4, 2, 8);
+            else if (rvals && N == 4) IG_GVR(2, 2, 8);
+            else if (rvals && N == 2) IG_GVR(2, 1, 8);
+            else
             if (N == 8) { if (vw >= 8) IG_GV(8, 1, 8); else if (vw >= 4) IG_GV(4, 2, 8); else IG_GV(2, 4, 8); }   // 8 / 4 / 2 rows per wave
             else if (N == 4) IG_GV(2, 2, 8);                                                               // 4 rows per wave
             else if (N == 2) IG_GV(2, 1, 8);                                                               // 8 rows per wave
@@ -2176,6 +2240,7 @@ int launch_gather(ig_ctx* ctx, int64_t rows, int64_t xrows, int64_t N, int64_t n
                 else IG_GV(4, 16, 1);                                                                      // 4 rows per wave
             }
 #undef IG_GV
+#undef IG_GVR
             IG_LAUNCH_CHECK(ctx, "k_csrmm_gather_v");
         } else {
 #define IG_GATHER(CL_, NL_)                                                                        \
@@ -2397,6 +2462,22 @@ int ig_ccsrmm_il(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, int64_t nnz,
                                 GridMask{nullptr, 0, 0}, nullptr, nullptr, true, false);
 }
 
+// The same product for a matrix whose weights are all real: `vals_re` = their real parts as floats (nnz x 4 bytes) beside the complex
+// values (which the rows deferred to the long-row kernels, and every panel width other than 2, 4 or 8, still read).
+int ig_ccsrmm_il_rw(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, int64_t nnz,
+                    float ar, float ai, const void* vals, const float* vals_re, const int32_t* colind, const int32_t* rowptr,
+                    const void* X_il, float br, float bi, void* Y, int64_t ldy) {
+    IG_REQUIRE(ctx, ctx != nullptr, "ig_ccsrmm_il_rw: ctx is NULL");
+    if (int rc = check_panel_args(ctx, "ig_ccsrmm_il_rw", K, M, N, nnz, vals, colind, rowptr, X_il, K, Y, ldy)) return rc;
+    IG_REQUIRE(ctx, N >= 1 && (N & (N - 1)) == 0 && N <= 64, "ig_ccsrmm_il_rw: an interleaved panel needs a power-of-two column count <= 64 (got %lld)", (long long)N);
+    IG_REQUIRE(ctx, nnz == 0 || vals_re, "ig_ccsrmm_il_rw: vals_re is NULL");
+    if (M == 0) return IG_OK;
+    if (int rc = ig_set_device(ctx)) return rc;
+    return launch_gather<false>(ctx, M, K, N, nnz, rowptr, colind, (const float2*)vals,
+                                (const float2*)X_il, K, (float2*)Y, ldy, make_float2(ar, ai), make_float2(br, bi),
+                                GridMask{nullptr, 0, 0}, nullptr, nullptr, true, false, vals_re);
+}
+
 int ig_ccsrmm_t_grid_il(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, int64_t nnz,
                         float ar, float ai, const void* vals_t, const int32_t* colind_t, const int32_t* rowptr_t,
                         const void* X, int64_t ldx, void* Y_il,
@@ -2577,8 +2658,10 @@ int ig_grid_bricks_fill(int64_t M, const int32_t* rowptr, const int32_t* colind,
 int ig_ccsrmm_t_bricks(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, float ar, float ai,
                        const void* entries, const uint32_t* round_rows, const void* X, int64_t ldx, void* Y_il, const int16_t* support, int64_t n0, int64_t nm,
                        int bm, int bs, const int32_t* tasks, int64_t ntasks, const int32_t* brick_table,
-                       const int32_t* shared_bricks, int64_t nshared, int support_tile, int support_zwords) {
+                       const int32_t* shared_bricks, int64_t nshared, int support_tile, int support_zwords, int entry_words) {
     IG_REQUIRE(ctx, ctx != nullptr, "ig_ccsrmm_t_bricks: ctx is NULL");
+    IG_REQUIRE(ctx, entry_words == 3 || entry_words == 2, "ig_ccsrmm_t_bricks: entries of 3 words {cell, re, im} or 2 {cell, re} (got %d)", entry_words);
+    const bool realw = entry_words == 2;
     const int zw = support_zwords > 0 ? support_zwords : 16;
     IG_REQUIRE(ctx, M >= 0 && K >= 0 && M <= 0x7fffffffLL, "ig_ccsrmm_t_bricks: bad dimensions");
     IG_REQUIRE(ctx, N == 4 || N == 8, "ig_ccsrmm_t_bricks: 4 or 8 columns (got %lld); entries must be padded to 64/N per row and brick", (long long)N);
@@ -2628,7 +2711,9 @@ int ig_ccsrmm_t_bricks(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, float ar, f
             ig_prof_scope prof(ctx, "grid_bricks_zero");                                                                        \
             hipLaunchKernelGGL((k_grid_bricks_zero<NC_>), dim3((unsigned)nshared), dim3(BLK), 0, ctx->stream, shared_bricks, (float2*)Y_il, bits, (int)n0, (int)nm, bm_log2, bs_log2, nbx, nbm, st_log2, zw); } \
         ig_prof_scope prof(ctx, "csrmm_bricks_conj");                                                                           \
-        hipLaunchKernelGGL((k_grid_bricks<NC_, NSEG_, PAIR_>), dim3(blocks), dim3(BLK), lds, ctx->stream, (const BrickTask*)tasks, (int)ntasks, (const BrickRef*)brick_table, (const BrickEntry*)entries, round_rows, \
+        if (realw) hipLaunchKernelGGL((k_grid_bricks<NC_, NSEG_, PAIR_, true>), dim3(blocks), dim3(BLK), lds, ctx->stream, (const BrickTask*)tasks, (int)ntasks, (const BrickRef*)brick_table, (const BrickEntry*)entries, round_rows, \
+                           (const float2*)xp, (float2*)Y_il, alpha, bits, (int)n0, (int)nm, bm_log2, bs_log2, nbx, nbm, st_log2, zw); \
+        else hipLaunchKernelGGL((k_grid_bricks<NC_, NSEG_, PAIR_, false>), dim3(blocks), dim3(BLK), lds, ctx->stream, (const BrickTask*)tasks, (int)ntasks, (const BrickRef*)brick_table, (const BrickEntry*)entries, round_rows, \
                            (const float2*)xp, (float2*)Y_il, alpha, bits, (int)n0, (int)nm, bm_log2, bs_log2, nbx, nbm, st_log2, zw); } while (0)
     const int nseg_total = (16 / support_tile) * bm * bs;
     if (N == 8 && nseg_total == 4) IG_BRICKS(8, 4);
@@ -2720,8 +2805,10 @@ int ig_grid_slots_build(int64_t nbricks, const int64_t* brick_ptr, const void* e
 int ig_ccsrmm_t_slots(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, float ar, float ai,
                       const void* entries16, const int32_t* slot_ptr, const void* X, int64_t ldx, void* Y_il, const int16_t* support,
                       int64_t n0, int64_t nm, int bm, int bs, const int32_t* tasks, int64_t ntasks, const int32_t* brick_table,
-                      const int32_t* shared_bricks, int64_t nshared, int support_tile, int support_zwords) {
+                      const int32_t* shared_bricks, int64_t nshared, int support_tile, int support_zwords, int entry_words) {
     IG_REQUIRE(ctx, ctx != nullptr, "ig_ccsrmm_t_slots: ctx is NULL");
+    IG_REQUIRE(ctx, entry_words == 4 || entry_words == 3, "ig_ccsrmm_t_slots: entries of 4 words {cell, re, im, row} or 3 {cell, re, row} (got %d)", entry_words);
+    const bool realw = entry_words == 3;
     const int zw = support_zwords > 0 ? support_zwords : 16;
     IG_REQUIRE(ctx, M >= 0 && K >= 0 && M <= 0x7fffffffLL, "ig_ccsrmm_t_slots: bad dimensions");
     IG_REQUIRE(ctx, N == 1 || N == 2 || N == 4, "ig_ccsrmm_t_slots: 1, 2 or 4 columns (got %lld; at 8 the round format of ig_ccsrmm_t_bricks is faster: 0.77 against 1.28 ms)", (long long)N);
@@ -2770,7 +2857,9 @@ int ig_ccsrmm_t_slots(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, float ar, fl
             ig_prof_scope prof(ctx, "grid_bricks_zero");                                                                        \
             hipLaunchKernelGGL((k_grid_bricks_zero<NC_>), dim3((unsigned)nshared), dim3(BLK), 0, ctx->stream, shared_bricks, (float2*)Y_il, bits, (int)n0, (int)nm, bm_log2, bs_log2, nbx, nbm, st_log2, zw); } \
         ig_prof_scope prof(ctx, "csrmm_slots_conj");                                                                            \
-        hipLaunchKernelGGL((k_grid_slots<NC_>), dim3(blocks), dim3(BLK), lds, ctx->stream, (const BrickTask*)tasks, (int)ntasks, (const BrickRef*)brick_table, slot_ptr, (const SlotEntry*)entries16, \
+        if (realw) hipLaunchKernelGGL((k_grid_slots<NC_, true>), dim3(blocks), dim3(BLK), lds, ctx->stream, (const BrickTask*)tasks, (int)ntasks, (const BrickRef*)brick_table, slot_ptr, (const SlotEntry*)entries16, \
+                           xp, (float2*)Y_il, alpha, bits, (int)n0, (int)nm, bm_log2, bs_log2, nbx, nbm, st_log2, zw); \
+        else hipLaunchKernelGGL((k_grid_slots<NC_, false>), dim3(blocks), dim3(BLK), lds, ctx->stream, (const BrickTask*)tasks, (int)ntasks, (const BrickRef*)brick_table, slot_ptr, (const SlotEntry*)entries16, \
                            xp, (float2*)Y_il, alpha, bits, (int)n0, (int)nm, bm_log2, bs_log2, nbx, nbm, st_log2, zw); } while (0)
     if (N == 1) IG_SLOTS(1); else if (N == 2) IG_SLOTS(2); else IG_SLOTS(4);
 #undef IG_SLOTS
@@ -2781,16 +2870,17 @@ int ig_ccsrmm_t_slots(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, float ar, fl
 int ig_ccsrmm_t_bricks_wide(ig_ctx* ctx, int64_t M, int64_t K, float ar, float ai,
                             const void* entries, const uint32_t* entry_rows, const void* X, int64_t ldx, void* Y, int64_t ldy,
                             const int32_t* tasks, int64_t ntasks, const int32_t* brick_table, const uint32_t* owned_tiles) {
-    return ig_ccsrmm_t_bricks_wide_grid(ctx, M, K, ar, ai, entries, entry_rows, X, ldx, Y, ldy, tasks, ntasks, brick_table, owned_tiles, 0, 0, 1, 1);
+    return ig_ccsrmm_t_bricks_wide_grid(ctx, M, K, ar, ai, entries, entry_rows, X, ldx, Y, ldy, tasks, ntasks, brick_table, owned_tiles, 0, 0, 1, 1, 3);
 }
 
 int ig_ccsrmm_t_bricks_wide_grid(ig_ctx* ctx, int64_t M, int64_t K, float ar, float ai,
                                  const void* entries, const uint32_t* entry_rows, const void* X, int64_t ldx, void* Y, int64_t ldy,
                                  const int32_t* tasks, int64_t ntasks, const int32_t* brick_table, const uint32_t* owned_tiles,
-                                 int64_t n0, int64_t nm, int bm, int bs) {
+                                 int64_t n0, int64_t nm, int bm, int bs, int entry_words) {
     IG_REQUIRE(ctx, ctx != nullptr, "ig_ccsrmm_t_bricks_wide: ctx is NULL");
     const int64_t N = 64;
     const bool grid = bm * bs > 1;
+    IG_REQUIRE(ctx, entry_words == 3 || (entry_words == 2 && grid), "ig_ccsrmm_t_bricks_wide_grid: entries of 3 words {cell, re, im}, or 2 {cell, re} (grid bricks only); got %d", entry_words);
     IG_REQUIRE(ctx, !grid || (n0 > 0 && nm > 0 && K % (n0 * nm) == 0 && bricks_ok(n0, nm, K / (n0 * nm), bm, bs, 1) && bm * bs <= 4),
                "ig_ccsrmm_t_bricks_wide_grid: rows (%lld) are not a grid of n0=%lld x nm=%lld x ... that divides into 16 x %d x %d bricks (bm * bs <= 4)",
                (long long)K, (long long)n0, (long long)nm, bm, bs);
@@ -2834,8 +2924,10 @@ int ig_ccsrmm_t_bricks_wide_grid(ig_ctx* ctx, int64_t M, int64_t K, float ar, fl
         while ((1 << bm_log2) < bm) ++bm_log2;
         while ((1 << bs_log2) < bs) ++bs_log2;
         const int nbx = (int)(n0 / 16), nbm = (int)(nm / bm);
-#define IG_WIDE_R(NT_) hipLaunchKernelGGL((k_bricks_wide64r<NT_>), dim3(blocks), dim3(BLK), 0, ctx->stream, (const BrickTask*)tasks, (int)ntasks, (const BrickRef*)brick_table, \
-                       (const BrickEntry*)entries, entry_rows, (const float2*)xp, (float2*)Y, ldy, make_float2(ar, ai), (int)n0, (int)nm, bm_log2, bs_log2, nbx, nbm)
+#define IG_WIDE_R(NT_) do { if (entry_words == 2) hipLaunchKernelGGL((k_bricks_wide64r<NT_, true>), dim3(blocks), dim3(BLK), 0, ctx->stream, (const BrickTask*)tasks, (int)ntasks, (const BrickRef*)brick_table, \
+                       (const BrickEntry*)entries, entry_rows, (const float2*)xp, (float2*)Y, ldy, make_float2(ar, ai), (int)n0, (int)nm, bm_log2, bs_log2, nbx, nbm); \
+                       else hipLaunchKernelGGL((k_bricks_wide64r<NT_, false>), dim3(blocks), dim3(BLK), 0, ctx->stream, (const BrickTask*)tasks, (int)ntasks, (const BrickRef*)brick_table, \
+                       (const BrickEntry*)entries, entry_rows, (const float2*)xp, (float2*)Y, ldy, make_float2(ar, ai), (int)n0, (int)nm, bm_log2, bs_log2, nbx, nbm); } while (0)
         if (bm * bs == 2) IG_WIDE_R(2); else IG_WIDE_R(4);
 #undef IG_WIDE_R
         IG_LAUNCH_CHECK(ctx, "k_bricks_wide64r");

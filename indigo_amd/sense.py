@@ -221,12 +221,13 @@ class SenseProblem(object):
             "fft_crop_x": cvol * e + bvol * e + (bvol * 8 if fused_sum else bvol * e),
         }
 
-    def gridding_pass_bytes(self, ncoils, table=None, tile=16):
+    def gridding_pass_bytes(self, ncoils, table=None, tile=16, real_entries=False):
         """Compulsory HBM bytes of the two gridding products of the fused tree for `ncoils` coils: the matrix once, the
         panel rows that are really touched once, the result once.  The adjoint (a gather over G'^T restricted to the
         flagged 16-row segments of the support table) reads the transposed matrix's row pointers only inside flagged
         segments and writes only those segments.  (The reference's model, operators.py:246-256, prices the adjoint
-        with a full read-modify-write of the 8.6 GB grid panel; both figures are reported by bench.py.)"""
+        with a full read-modify-write of the 8.6 GB grid panel; both figures are reported by bench.py.)
+        real_entries: the formats store real weights (4 bytes per value instead of 8, see HipBackend weights_are_real)."""
         Gm = self.fused_interp(1)
         T, P = Gm.shape
         nnz = Gm.nnz
@@ -238,13 +239,13 @@ class SenseProblem(object):
         else:
             sup = P
         return {
-            "csrmm_gather": nnz * 12 + (T + 1) * 4 + touched * e + T * e,
+            "csrmm_gather": nnz * (8 if real_entries else 12) + (T + 1) * 4 + touched * e + T * e,
             "csrmm_rowlane_conj": nnz * 12 + (sup + 1) * 4 + T * e + sup * e,
-            # brick-binned scatter: 12 bytes per nonzero (cell + value; the padding and the row list of the binned format
-            # are overhead, not compulsory), the panel, the flagged rows
-            "csrmm_bricks_conj": nnz * 12 + T * e + sup * e,
+            # brick-binned scatter: 12 bytes per nonzero (cell + value; 8 when the weights are real and stored so; the padding and the
+            # row list of the binned format are overhead, not compulsory), the panel, the flagged rows
+            "csrmm_bricks_conj": nnz * (8 if real_entries else 12) + T * e + sup * e,
             # slot-format scatter (1- and 2-coil ranks): 16 bytes per nonzero (cell, value, sample), the panel, the flagged rows
-            "csrmm_slots_conj": nnz * 16 + T * e + sup * e,
+            "csrmm_slots_conj": nnz * (12 if real_entries else 16) + T * e + sup * e,
             "pack_panel": 2 * T * e,
         }
 

@@ -853,6 +853,102 @@ def test_slot_format_adjoint_gridding(hip, N, bm, bs, chunk, run, with_support):
         assert rel_err(got, exp) < RTOL
 
 
+@pytest.mark.parametrize("N,residue", [(8, 0.0), (8, 3e-17), (4, 3e-17), (2, 0.0), (1, 3e-17)])
+def test_real_weight_formats_of_a_gridding_matrix(hip, monkeypatch, N, residue):
+    """A gridding matrix times the +-1 modulation of a centred transform on an even grid is REAL up to the 1e-16 rounding residue of
+    exp(i pi k) (weights_are_real).  Its formats then store 4-byte weights -- 8-byte brick entries (ig_ccsrmm_t_bricks, entry_words 2),
+    12-byte slot entries (ig_ccsrmm_t_slots, entry_words 3), float values for the forward gather over an interleaved panel
+    (ig_ccsrmm_il_rw): against scipy in complex128 and against the complex formats of the same matrix; a matrix with genuinely
+    complex weights keeps the complex formats."""
+    from indigo_amd.backends.hip import weights_are_real
+    rng = np.random.default_rng(7 + N)
+    n0, nm, ns = 64, 32, 32
+    P, T = n0 * nm * ns, 2500
+    centre = rng.integers(0, P, size=30)
+    rows, cols = [], []
+    for t in range(T):
+        base = centre[t % 30] if t % 3 else rng.integers(0, P)
+        off = rng.integers(-2, 3, size=(40 if t % 89 == 0 else 27, 3))
+        kx, km, ks = base % n0, (base // n0) % nm, base // (n0 * nm)
+        c = np.unique(((kx + off[:, 0]) % n0) + n0 * (((km + off[:, 1]) % nm) + nm * ((ks + off[:, 2]) % ns)))
+        rows.append(np.full(c.size, t)); cols.append(c)
+    rows, cols = np.concatenate(rows), np.concatenate(cols)
+    w = rng.standard_normal(rows.size).astype(np.float32) * np.where(rng.random(rows.size) < 0.5, -1, 1)
+    vals = (w + 1j * (residue * rng.standard_normal(rows.size))).astype(C64)
+    assert weights_are_real(vals) and not weights_are_real(rand64c(16, seed=1)) and not weights_are_real(np.zeros(0, C64))
+    A = spp.csr_matrix((vals, (rows, cols)), shape=(T, P))
+    A.sort_indices()
+    X = rand64c(T, N, seed=5)
+    G = rand64c(P, N, seed=6)
+
+    def products(real_entries):
+        monkeypatch.setitem(hip.tuning, "real_entries", real_entries)
+        A_d = hip.csr_matrix(hip, A)
+        if N > 1:
+            A_d.set_grid_interleaved(True)
+        if N in (4, 8):
+            A_d.set_grid_bricks(n0, nm, ns, ncols=N, bm=2, bs=2, chunk=64, run=512)
+            assert A_d._bricks['words'] == (2 if real_entries else 3) and A_d._bricks['nshared'] > 0
+        else:
+            A_d.set_grid_slots(n0, nm, ns, ncols=N, bm=4, bs=4, chunk=8, run=64)
+            assert A_d._slots['words'] == (3 if real_entries else 4)
+        y_d = hip.zero_array((P, N), C64)
+        A_d.adjoint(y_d, hip.copy_array(X), alpha=0.5 - 0.25j)
+        adj = y_d.to_host().reshape(-1, order='F').reshape(P, N)
+        fwd = None
+        if N > 1:       # forward over the interleaved grid panel (row-major memory)
+            g_d = hip.copy_array(np.asfortranarray(G.reshape(-1).reshape(P, N, order='F')))
+            k_d = hip.zero_array((T, N), C64)
+            A_d.forward(k_d, g_d, alpha=1.5)
+            assert (A_d._real_values() is not None) == real_entries
+            fwd = k_d.to_host()
+        return adj, fwd
+    adj_r, fwd_r = products(True)
+    adj_c, fwd_c = products(False)
+    exp = (0.5 - 0.25j) * (A.conj().T.astype(np.complex128) @ X.astype(np.complex128))
+    assert rel_err(adj_r, exp) < RTOL and rel_err(adj_c, exp) < RTOL and rel_err(adj_r, adj_c) < 2e-6
+    if N > 1:
+        expf = 1.5 * (A.astype(np.complex128) @ G.astype(np.complex128))
+        assert rel_err(fwd_r, expf) < RTOL and rel_err(fwd_c, expf) < RTOL and rel_err(fwd_r, fwd_c) < 2e-6
+    # genuinely complex weights: no real formats, whatever the tuning says
+    monkeypatch.setitem(hip.tuning, "real_entries", True)
+    B_d = hip.csr_matrix(hip, spp.csr_matrix((rand64c(rows.size, seed=3), (rows, cols)), shape=(T, P)))
+    assert B_d._real_values() is None
+
+
+def test_real_weight_wide_adjoint(hip, monkeypatch):
+    """the 64-column adjoint by grid bricks with the image in registers (k_bricks_wide64r) on 8-byte entries {cell, re}: a plain
+    gridding matrix has real weights (ig_ccsrmm_t_bricks_wide_grid, entry_words 2); against scipy and against the 12-byte form"""
+    rng = np.random.default_rng(21)
+    n0, nm, ns = 32, 32, 32
+    P, T = n0 * nm * ns, 4000
+    centre = rng.integers(0, P, size=25)
+    rows, cols = [], []
+    for t in range(T):
+        base = centre[t % 25] if t % 4 else rng.integers(0, P)
+        off = rng.integers(-1, 2, size=(27, 3))
+        kx, km, ks = base % n0, (base // n0) % nm, base // (n0 * nm)
+        c = np.unique(((kx + off[:, 0]) % n0) + n0 * (((km + off[:, 1]) % nm) + nm * ((ks + off[:, 2]) % ns)))
+        rows.append(np.full(c.size, t)); cols.append(c)
+    rows, cols = np.concatenate(rows), np.concatenate(cols)
+    A = spp.csr_matrix((rng.standard_normal(rows.size).astype(np.float32).astype(C64), (rows, cols)), shape=(T, P))
+    A.sort_indices()
+    X = rand64c(T, 64, seed=8)
+    exp = (0.5 + 2j) * (A.conj().T.astype(np.complex128) @ X.astype(np.complex128))
+    outs = []
+    for real_entries in (True, False):
+        monkeypatch.setitem(hip.tuning, "real_entries", real_entries)
+        monkeypatch.setitem(hip.tuning, "wide_task_shape", (512, 256))      # heavy bricks in shared pieces as well
+        A_d = hip.csr_matrix(hip, A)
+        A_d.set_grid_dims(n0, nm, ns)
+        y_d = hip.copy_array(np.full((P, 64), 7 - 3j, dtype=C64, order='F'))
+        A_d.adjoint(y_d, hip.copy_array(X), alpha=0.5 + 2j)
+        assert A_d._wide is not None and A_d._wide['geom'][2:] == (2, 2) and A_d._wide['words'] == (2 if real_entries else 3)
+        outs.append(y_d.to_host())
+        assert rel_err(outs[-1], exp) < RTOL
+    assert rel_err(outs[0], outs[1]) < 2e-6
+
+
 @pytest.mark.parametrize("alpha,beta,ld_pad", [(1, 0, 0), (0.5 - 1j, 1.5, 5)])
 def test_wide_panel_forward_ragged_rows(hip, alpha, beta, ld_pad):
     """the 16-row-tile gather (k_csrmm_gather_tile64: 64 columns, software-pipelined over the rows of a tile): rows of every
