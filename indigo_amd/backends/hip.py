@@ -1004,6 +1004,7 @@ class HipBackend(Backend):
             self.values = b.copy_array(Ap.data.astype(_C64), name=self._name + ".data")
             self._host_csr = Ap
             self._t = None
+            self._values_re = False          # (built on first use from the reordered values)
             self._perm = b.copy_array(perm, name=self._name + ".rowOrder")
 
         def _real_values(self):
