@@ -325,3 +325,35 @@ def test_support_table_builder_native_vs_numpy(oN, tile, zw):
     z = zr.reshape(n1, nt, 2)
     assert (z[kyc, kx // tile, 0] <= kzc).all() and (kzc < z[kyc, kx // tile, 1]).all()
     assert (yr[kx // tile, 0] <= kyc).all() and (kyc < yr[kx // tile, 1]).all()
+
+
+def test_modulated_gridding_matrix_of_an_even_grid_is_real_up_to_rounding_residue():
+    """what HipBackend's real-weight formats rest on (indigo_amd/backends/hip.py:weights_are_real): on an even grid the centred
+    transform's modulation is exp(i pi k) = +-1, so G' = G * mod * scale has real weights and its imaginary parts are the rounding
+    residue of sin(pi k) -- orders of magnitude below the threshold; on an odd grid (the reference driver's 277-point axis) the
+    weights are genuinely complex"""
+    from indigo_amd.backends.hip import weights_are_real
+    from indigo_amd.sense import SenseProblem
+    even = SenseProblem.synthetic((32, 32, 32), 2, nspokes=60, nreadout=64, width=2, oversamp=2.0, seed=4).fused_interp(2)
+    assert weights_are_real(even.data)
+    assert np.abs(even.data.imag).max() < 1e-9 * np.abs(even.data.real).max()
+    odd = SenseProblem.synthetic((30, 26, 22), 2, nspokes=60, nreadout=60, width=2, oversamp=1.25, seed=4)
+    assert any(n % 2 for n in odd.oN)
+    assert not weights_are_real(odd.fused_interp(2).data)
+    assert weights_are_real(np.array([2.0, -1.0], dtype=np.complex64)) and not weights_are_real(np.zeros(0, np.complex64))
+    assert not weights_are_real(np.array([1 + 1e-6j], dtype=np.complex64))
+
+
+def test_cg_splits_a_tikhonov_term_off_the_operator(oracle_backend):
+    """HipBackend.cg moves a real multiple of Eye at the root of the tree (examples/pics.py:195 writes the regularisation into the
+    operator) into its own lamda; anything else is left alone"""
+    import scipy.sparse as spp
+    from indigo_amd.backends.hip import HipBackend
+    B = oracle_backend
+    M = B.SpMatrix(spp.identity(6, dtype=np.complex64, format='csr'))
+    for tree in (M + 0.25 * B.Eye(6), 0.25 * B.Eye(6) + M):
+        rest, lam = HipBackend._split_identity(tree, 0.5)
+        assert rest is M and abs(lam - 0.75) < 1e-12
+    for tree in (M, M + (0.25 + 1j) * B.Eye(6), M + M):
+        rest, lam = HipBackend._split_identity(tree, 0.5)
+        assert rest is tree and lam == 0.5
