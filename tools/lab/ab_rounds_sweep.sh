@@ -1,3 +1,5 @@
+# Exchange rounds of the A x B kernels: lib80.so / lib160.so = the library built after `IG_AB_LDS_BUDGET=81920|163840 python tools/gen_ab_list.py`
+# (copied to indigo_amd/lib/lab/ for the run; output: profiles/r04_ab_rounds_sweep.txt).  The shipped list is the 160 KB one.
 for v in lib80 lib160; do
   echo "== $v"
   export INDIGO_HIP_LIB=$PWD/indigo_amd/lib/lab/$v.so
