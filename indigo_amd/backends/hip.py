@@ -796,7 +796,7 @@ class HipBackend(Backend):
             # Real weights (a gridding matrix times the +-1 modulation of a centred transform on an even grid, whose imaginary parts
             # are the 1e-16 rounding residue of exp(i pi k)): 8-byte entries {cell, re}
             words = 3
-            if b.tuning.get('real_entries', True) and weights_are_real(data):
+            if self._real_weights(data):
                 entries = np.ascontiguousarray(entries[:, :2])
                 words = 2
             self._bricks = dict(n0=int(n0), nm=int(nm), bm=int(bm), bs=int(bs), ncols=int(ncols), ntasks=int(tasks.shape[0]), words=words,
@@ -845,7 +845,7 @@ class HipBackend(Backend):
             nseg = (16 // (fine[1] if fine is not None else 16)) * bm * bs      # segments per brick (the kernel looks up 512 per run)
             tasks, table, shared = brick_tasks(brick_slots, sptr, chunk, run, max_bricks=min(64, 512 // nseg))
             words = 4
-            if b.tuning.get('real_entries', True) and weights_are_real(data):
+            if self._real_weights(data):
                 e16 = np.ascontiguousarray(e16.reshape(-1, 4)[:, [0, 1, 3]])     # {cell, re, row}: 12 bytes per nonzero
                 words = 3
             self._slots = dict(n0=int(n0), nm=int(nm), bm=int(bm), bs=int(bs), ncols=int(ncols), ntasks=int(tasks.shape[0]), words=words,
@@ -937,7 +937,7 @@ class HipBackend(Backend):
                     owned[bx + nbx * ((bmi * bm + im) + nm * (bsi * bs + is_))] = True
             bits = np.packbits(np.concatenate([owned, np.zeros((-owned.size) % 32, dtype=bool)]), bitorder='little').view(np.uint32)
             words = 3
-            if bm * bs > 1 and b.tuning.get('real_entries', True) and weights_are_real(data):
+            if bm * bs > 1 and self._real_weights(data):
                 e12 = np.ascontiguousarray(e12[:, :2])            # {cell, re}: the register-image kernel's real-weight form
                 words = 2
             self._wide = dict(ntasks=int(tasks.shape[0]), geom=(n0, nm, bm, bs), words=words,
@@ -1005,7 +1005,18 @@ class HipBackend(Backend):
             self._host_csr = Ap
             self._t = None
             self._values_re = False          # (built on first use from the reordered values)
+            self._weights_real = None
             self._perm = b.copy_array(perm, name=self._name + ".rowOrder")
+
+        def _real_weights(self, data):
+            """are the matrix's weights real up to rounding residue (weights_are_real; one pass over the values, remembered) -- and
+            does the backend's tuning allow the 4-byte forms?"""
+            if not self._backend.tuning.get('real_entries', True):
+                return False
+            r = getattr(self, '_weights_real', None)
+            if r is None:
+                r = self._weights_real = weights_are_real(data)
+            return r
 
         def _real_values(self):
             """the weights' real parts as a float32 device array when the matrix is real up to rounding residue (built on first
@@ -1014,7 +1025,7 @@ class HipBackend(Backend):
             if r is False:
                 r = None
                 data = self._host_csr.data if self._host_csr is not None else self.values.to_host()
-                if self._backend.tuning.get('real_entries', True) and weights_are_real(data):
+                if self._real_weights(data):
                     r = self._backend.copy_array(np.ascontiguousarray(data.real, dtype=np.float32), name=self._name + ".dataRe")
                 self._values_re = r
             return r

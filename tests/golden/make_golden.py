@@ -365,6 +365,65 @@ def gold_sense(B):
     save("sense", **out)
 
 
+def gold_sense_even(B):
+    """A second SENSE fixture on an EVEN grid at a size the GPU's fused leaf takes: image 64^3, 8 coils, oversampling 2 (grid 128^3), a
+    radial trajectory, width 2 -- BASELINE config 4 in small.  On an even grid the centred transform's modulation is +-1, so the -O3
+    tree's G' is real up to rounding residue; the residue of the REFERENCE's own matrix is recorded.  Inputs come from seeds
+    (indigo_amd.util.rand64c, indigo_amd.sense.radial_trajectory) and are not stored; A x is stored whole, the image-sized results
+    (A^H k, A^H A x: 2 MB each) as 16384 seeded samples plus their norms."""
+    from indigo_amd.sense import radial_trajectory
+    N, C, width, ntab, osf = (64, 64, 64), 8, 2, 128, 2.0
+    nsp, ro = 48, 128
+    T = ro * nsp
+    coord = radial_trajectory(nsp, ro, seed=5)
+    maps = rand64c(*N, C, seed=1301)
+    dtype = np.dtype('complex64')
+
+    def build():
+        F1, parts = ref_nufft(B, (1, ro, nsp), N, coord, width, ntab, osf, dtype)
+        F = B.KronI(C, F1)
+        S = B.VStack([B.Diag(maps[:, :, :, c:c + 1]) for c in range(C)], name='maps')
+        return F * S, parts
+    A, parts = build()
+    x = rand64c(A.shape[1], 1, seed=1304)
+    k = rand64c(A.shape[0], 1, seed=1305)
+    Ax = A * x
+    AHk = A.H * k
+    AHA = A.H * A
+    y_d = B.zero_array((A.shape[1], 1), dtype)
+    AHA.eval(y_d, B.copy_array(x))
+    AHAx = y_d.to_host()
+    pick = np.sort(np.random.default_rng(1306).choice(A.shape[1], size=16384, replace=False))
+    out = dict(params=np.array([C, width, ntab, osf, ro, nsp], dtype=np.float64), N=np.array(N), oN=np.array(parts['oN']),
+               seeds=np.array([5, 1301, 1304, 1305, 1306]), sense_Ax=Ax, pick=pick,
+               sense_AHk_pick=AHk[pick], sense_AHk_norm=np.array(np.linalg.norm(AHk.astype(np.complex128))),
+               sense_AHAx_pick=AHAx[pick], sense_AHAx_norm=np.array(np.linalg.norm(AHAx.astype(np.complex128))))
+    # the -O3 tree of the reference's own recipe: its G' (interp * modulation * scale) is real up to rounding residue
+    src = open(os.path.join(REF, "examples", "pics.py")).read().split("\n")
+    ns = {}
+    exec("\n".join(src[96:177]), ns)       # pics.py:97-177: imports + Transform classes
+    A3, _ = build()
+    for Step in (ns['MakeRightLeaning'], ns['AssocSpMatrices'], ns['DistKroniOverFFT'], ns['MakeRightLeaning'], ns['MriRealize'], ns['MriGoodAdjoints']):
+        A3 = Step().visit(A3)
+    from indigo.operators import SpMatrix as RefSp
+
+    def collect(node, acc):
+        if isinstance(node, RefSp):
+            acc.append(node)
+        for c in getattr(node, '_children', []):
+            collect(c, acc)
+    leaves = []
+    collect(A3, leaves)
+    Gp = [leaf._matrix for leaf in leaves if leaf._matrix.shape[0] == T][0].tocsr()
+    d = Gp.data.astype(np.complex64)
+    out.update(gprime_nnz=np.array(Gp.nnz), gprime_max_abs_imag=np.array(np.abs(d.imag).max()), gprime_max_abs_real=np.array(np.abs(d.real).max()),
+               gprime_sum=np.array(d.astype(np.complex128).sum()))
+    if hasattr(B, '_scratch'):
+        del B._scratch
+    out['sense_O3_Ax'] = A3 * x
+    save("sense_even", **out)
+
+
 def gold_misc(B):
     """the leaves outside the SENSE tree: onemm, cdiamm (DIA), cgemm / csymm, and two apgd iterates
     (reference: np.py:76-97,129-136; backend.py:599-635,691-732; operators One / DenseMatrix / SpMatrix._use_dia)"""
@@ -458,11 +517,15 @@ def gold_misc(B):
 def main():
     B = import_reference()
     print("reference backend:", type(B).__module__, type(B).__name__)
+    if len(sys.argv) > 1 and sys.argv[1] == "sense_even":      # (added in round 4: the other fixtures stay as they were generated)
+        gold_sense_even(B)
+        return
     gold_blas(B)
     gold_csrmm(B)
     gold_fft(B)
     gold_composites(B)
     gold_sense(B)
+    gold_sense_even(B)
     gold_misc(B)
 
 

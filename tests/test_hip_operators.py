@@ -156,6 +156,30 @@ def test_sense_golden(hip, level):
     hip._scratch = None
 
 
+def test_sense_even_grid_golden(hip):
+    """tests/golden/sense_even.npz: the REFERENCE's products for image 64^3, 8 coils, grid 128^3 (even: the -O3 tree's G' is real up
+    to rounding residue), a radial trajectory -- BASELINE config 4 in small -- against the fused HIP tree, which on this grid takes the
+    zero-pad-aware A x B passes, the 8-byte brick entries and the 4-byte gather values (real-weight formats)"""
+    from test_sense_cpu import even_grid_problem, check_even_grid_products
+    p, g, x, k = even_grid_problem()
+    hip._scratch = None
+    assert hip.supports_padded_fft(p.oN, p.C)
+    A = p.build_zpadfft(hip)
+    check_even_grid_products(A, g, x, k, tol=RTOL)
+    mats = []
+    stack = [A]
+    while stack:
+        node = stack.pop()
+        if getattr(node, '_matrix_d', None) is not None:
+            mats.append(node._matrix_d)
+        stack.extend(getattr(node, '_children', None) or [])
+    assert mats and all((getattr(m, '_bricks', None) or {}).get('words') == 2 and m._real_values() is not None for m in mats), \
+        "the fused tree's gridding matrix should carry the real-weight formats on an even grid"
+    hip._scratch = None
+    check_even_grid_products(p.build_tree(hip, level=3), g, x, k, tol=RTOL)       # the reference's own -O3 leaves
+    hip._scratch = None
+
+
 def test_sense_medium_vs_oracle_and_properties(hip, oracle_backend):
     """64^3 image, 4 coils, grid 128^3 (pow-2 LDS FFT path), ~1e5 samples: oracle parity + adjointness + linearity"""
     p = SenseProblem.synthetic((64, 64, 64), 4, nspokes=400, nreadout=128, width=2, oversamp=2.0, seed=4)

@@ -357,3 +357,54 @@ def test_cg_splits_a_tikhonov_term_off_the_operator(oracle_backend):
     for tree in (M, M + (0.25 + 1j) * B.Eye(6), M + M):
         rest, lam = HipBackend._split_identity(tree, 0.5)
         assert rest is tree and lam == 0.5
+
+
+def even_grid_problem():
+    """the problem of tests/golden/sense_even.npz, rebuilt from its seeds (image 64^3, 8 coils, grid 128^3, radial, width 2)"""
+    from indigo_amd.sense import radial_trajectory
+    from indigo_amd.util import rand64c
+    g = golden("sense_even")
+    C, width, ntab, osf, ro, nsp = g["params"]
+    s_coord, s_maps, s_x, s_k, _ = (int(v) for v in g["seeds"])
+    N = tuple(int(n) for n in g["N"])
+    p = SenseProblem(N, radial_trajectory(int(nsp), int(ro), seed=s_coord), np.asfortranarray(rand64c(*N, int(C), seed=s_maps)),
+                     width=int(width), ntable=int(ntab), oversamp=float(osf))
+    assert p.oN == tuple(int(n) for n in g["oN"]) and p.T == int(ro * nsp)
+    x = rand64c(int(np.prod(N)), 1, seed=s_x)
+    k = rand64c(p.T * int(C), 1, seed=s_k)
+    return p, g, x, k
+
+
+def check_even_grid_products(A, g, x, k, tol=1e-5):
+    """A x whole, A^H k and A^H A x on the fixture's sample of voxels -- errors relative to the norm of the reference's vector"""
+    pick = g["pick"]
+    Ax = A * x
+    assert rel_err(Ax, g["sense_Ax"]) < tol
+    assert rel_err(Ax, g["sense_O3_Ax"]) < tol
+    scale = np.sqrt(pick.size / float(A.shape[1]))          # a sample of n of P entries carries ~sqrt(n / P) of the norm
+    AHk = (A.H * k)[pick]
+    assert np.linalg.norm(AHk - g["sense_AHk_pick"]) < tol * scale * float(g["sense_AHk_norm"])
+    AHAx = (A.H * (A * x))[pick]
+    assert np.linalg.norm(AHAx - g["sense_AHAx_pick"]) < tol * scale * float(g["sense_AHAx_norm"])
+    assert abs(np.linalg.norm(g["sense_AHAx_pick"]) / (scale * float(g["sense_AHAx_norm"])) - 1) < 0.05     # (the sample is representative)
+
+
+def test_even_grid_fixture_construction_and_gprime(oracle_backend):
+    """OUR construction against the reference at a second size, on an even grid (64^3 x 8 coils, grid 128^3): the products of the
+    -O3 tree and of the directly fused tree on the oracle backend, and the reference's own G' -- same nonzeros, same sum, and an
+    imaginary part that is rounding residue (7e-14 of the real part in the reference's matrix): what the GPU's real-weight formats
+    rest on"""
+    from indigo_amd.backends.hip import weights_are_real
+    p, g, x, k = even_grid_problem()
+    Gp = p.fused_interp(2)
+    # (a sample exactly on a grid point -- the centre of every spoke -- has four taps per axis of which the outermost weighs zero:
+    # the reference's sparse products drop those 37 explicit zeros per spoke, our builder stores them)
+    assert np.count_nonzero(Gp.data) == int(g["gprime_nnz"]) and Gp.nnz - int(g["gprime_nnz"]) == 37 * 48
+    assert abs(Gp.data.astype(np.complex128).sum() - complex(g["gprime_sum"])) < 1e-5 * abs(complex(g["gprime_sum"]))
+    assert float(g["gprime_max_abs_imag"]) < 1e-12 * float(g["gprime_max_abs_real"])
+    assert abs(np.abs(Gp.data.real).max() / float(g["gprime_max_abs_real"]) - 1) < 1e-6 and weights_are_real(Gp.data)
+    oracle_backend._scratch = None
+    check_even_grid_products(p.build_tree(oracle_backend, level=3), g, x, k)
+    oracle_backend._scratch = None
+    check_even_grid_products(p.build_fused(oracle_backend), g, x, k)
+    oracle_backend._scratch = None
