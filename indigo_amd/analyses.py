@@ -45,7 +45,7 @@ class Memusage(Visitor):
     def visit(self, node):
         # pre-order bookkeeping with scoped pushes, so do not use Visitor's post-order dispatch
         self._peak = max(self._peak, sum(self._live))
-        if isinstance(node, (op.Product, op.UnscaledFFT, op.ZpadFFT)):
+        if isinstance(node, (op.Product, op.UnscaledFFT, op.ZpadFFT, op.HeadRows)):
             with self._push(self._live, self._round(node._mem_usage(self._ncols()))):
                 self._peak = max(self._peak, sum(self._live))
                 self.generic_visit(node)

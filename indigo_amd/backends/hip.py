@@ -513,21 +513,21 @@ class HipBackend(Backend):
 
     def supports_padded_fft(self, grid, ncoils=None):
         """256- and 512-point axes in every grid layout; the reference driver's own oversampled grids (320 ... 640,
-        examples/pics.py:87-90) and every other smooth length from 128 to 640 in the coil-interleaved layout, i.e. for coil
-        counts that split into chunks of 2, 4, 8 or 16"""
-        from indigo_amd import fused
+        examples/pics.py:87-90), every other smooth length from 128 to 640 and chirp-z y / z axes in the coil-interleaved layout --
+        for ANY coil count: indigo_amd.fused.plan_chunks cuts it into interleaved chunks of 8, 4 and 2 coils, the last one
+        padded with zero-weight coils where the count does not divide"""
         if len(grid) != 3:
             return False
         if all(int(n) in self.PADDED_AXES_POW2 for n in grid):
             return True
         kinds = [self.padded_axis_kind(n) for n in grid]
         # (5 = chirp-z: lengths with a prime factor above 7 -- 277, 410: int(N * osf) of the reference's driver -- on the y and z axes)
-        if kinds[0] not in (3, 4) or any(k not in (3, 4, 5) for k in kinds[1:]):
-            return False
-        if ncoils is None:
-            return True
-        layout, chunks = fused.choose_layout(int(ncoils), 8, None)
-        return layout == 2 and all(hi - lo >= 2 for lo, hi in chunks)
+        return kinds[0] in (3, 4) and all(k in (3, 4, 5) for k in kinds[1:])
+
+    def supports_single_coil_layout(self, grid):
+        """the per-coil grid layouts (one coil per panel column: a left-over single coil runs without a padding coil) exist for
+        power-of-two grids only"""
+        return len(grid) == 3 and all(int(n) in self.PADDED_AXES_POW2 for n in grid)
 
     supports_support_tile = True          # ZpadFFT / the brick scatter take support tables of 8 or 4 kx points per entry
 
@@ -749,14 +749,28 @@ class HipBackend(Backend):
                                                       name=self._name + ".support"), int(n0), int(nm))
             self._support_zw = int(zw)
 
-        def set_grid_support_fine(self, table, tile):
+        def set_grid_support_fine(self, table, tile, ncols=None):
             """a support table with `tile` (8 or 4) kx points per entry: what the brick scatter writes by (the gather routes keep
-            the 16-point table of set_grid_support; a reader with the finer table reads a subset of what they write)"""
-            assert getattr(self, '_bricks', None) is None, \
+            the 16-point table of set_grid_support; a reader with the finer table reads a subset of what they write).
+            ncols: the panel width whose adjoint writes by this table (a matrix shared by coil chunks of several widths carries
+            one table per width); None = every width without a table of its own."""
+            built = getattr(self, '_bricks_by', {})
+            assert not (any(v is not None for v in built.values()) if ncols is None else built.get(int(ncols)) is not None), \
                 "set_grid_support_fine must come before set_grid_bricks: the runs of bricks are sized for the table's segments"
             assert int(tile) in (4, 8, 16)
             self._support_fine = (self._backend.copy_array(np.ascontiguousarray(table, dtype=np.int16).reshape(-1),
                                                            name=self._name + ".supportFine"), int(tile))
+            self.__dict__.setdefault('_support_fine_by', {})[None if ncols is None else int(ncols)] = self._support_fine
+
+        def _format(self, which, ncols, exact=False):
+            """the binned format ('_bricks' / '_slots') or fine table ('_support_fine') registered for panels of `ncols` columns"""
+            by = getattr(self, which + '_by', None)
+            if by is None:
+                return None
+            key = None if ncols is None else int(ncols)
+            if key in by or exact:
+                return by.get(key)
+            return by.get(None)
 
         def set_grid_bricks(self, n0, nm, ns, ncols=8, bm=2, bs=2, chunk=4096, run=4096):
             """Sort the nonzeros by the 16 x bm x bs brick of the n0 x nm x ns grid their column falls into (native host
@@ -781,6 +795,7 @@ class HipBackend(Backend):
                 log.info("%s: no brick-binned format (%s); the adjoint keeps the gather route", self._name,
                          _lib.last_error(None) if hasattr(_lib, 'last_error') else "ig_grid_bricks_count failed")
                 self._bricks = None
+                self.__dict__.setdefault('_bricks_by', {})[int(ncols)] = None
                 return
             ptr = np.zeros(nb + 1, dtype=np.int64)
             np.cumsum(counts, out=ptr[1:])
@@ -790,7 +805,7 @@ class HipBackend(Backend):
             _lib.check(b._L.ig_grid_bricks_fill(A.shape[0], indptr.ctypes.data, indices.ctypes.data, data.ctypes.data, n0, nm, ns,
                                                 bm, bs, unit, ptr.ctypes.data, entries.ctypes.data, round_rows.ctypes.data),
                        None, "ig_grid_bricks_fill")
-            fine = getattr(self, '_support_fine', None)
+            fine = self._format('_support_fine', ncols)
             nseg = (16 // (fine[1] if fine is not None else 16)) * bm * bs          # segments per brick (the kernel looks up 512 per run)
             tasks, table, shared = brick_tasks(counts, ptr, chunk, run, max_bricks=min(64, 512 // nseg))
             # Real weights (a gridding matrix times the +-1 modulation of a centred transform on an even grid, whose imaginary parts
@@ -806,6 +821,7 @@ class HipBackend(Backend):
                                 entries=b.copy_array(entries.reshape(-1), name=self._name + ".brickEntries"),
                                 rounds=b.copy_array(round_rows, name=self._name + ".brickRoundRows"),
                                 shared=b.copy_array(shared if shared.size else np.zeros(1, np.int32), name=self._name + ".sharedBricks"))
+            self.__dict__.setdefault('_bricks_by', {})[int(ncols)] = self._bricks
 
         def set_grid_slots(self, n0, nm, ns, ncols=1, bm=2, bs=2, chunk=256, run=128):
             """The slot format of ig_ccsrmm_t_slots for an `ncols`-column panel (1, 2 or 4): the nonzeros binned by 16 x bm x bs
@@ -824,6 +840,7 @@ class HipBackend(Backend):
                     or int(counts.sum(dtype=np.int64)) * 16 >= 2 ** 31:
                 log.info("%s: no slot format; the adjoint keeps the gather route", self._name)
                 self._slots = None
+                self.__dict__.setdefault('_slots_by', {})[int(ncols)] = None
                 return
             ptr = np.zeros(nb + 1, dtype=np.int64)
             np.cumsum(counts, out=ptr[1:])
@@ -841,7 +858,7 @@ class HipBackend(Backend):
             del e12, rows
             sptr = np.zeros(nb + 1, dtype=np.int64)
             np.cumsum(brick_slots, out=sptr[1:])
-            fine = getattr(self, '_support_fine', None)
+            fine = self._format('_support_fine', ncols)
             nseg = (16 // (fine[1] if fine is not None else 16)) * bm * bs      # segments per brick (the kernel looks up 512 per run)
             tasks, table, shared = brick_tasks(brick_slots, sptr, chunk, run, max_bricks=min(64, 512 // nseg))
             words = 4
@@ -855,6 +872,7 @@ class HipBackend(Backend):
                                entries=b.copy_array(e16.reshape(-1), name=self._name + ".slotEntries"),
                                slot_ptr=b.copy_array(slot_ptr[:int(nslots.value) + 1].copy(), name=self._name + ".slotPtr"),
                                shared=b.copy_array(shared if shared.size else np.zeros(1, np.int32), name=self._name + ".slotSharedBricks"))
+            self.__dict__.setdefault('_slots_by', {})[int(ncols)] = self._slots
 
         def set_grid_dims(self, n0, nm, ns):
             """Hint: the columns of the matrix are the points of an n0 x nm x ns grid, n0 running fastest (a gridding matrix).
@@ -1105,13 +1123,13 @@ class HipBackend(Backend):
             b = self._backend
             sup = getattr(self, '_support', None)
             perm = getattr(self, '_perm', None)
-            br = getattr(self, '_bricks', None)
+            br = self._format('_bricks', x.shape[1], exact=True)
             # (the gather routes over the transposed matrix read 16-word bitmaps only: with another table they compute every
             # row -- a superset of what any reader of the grid looks at)
             sup_gather = sup if getattr(self, '_support_zw', 16) == 16 else None
             if (br is not None and perm is None and beta == 0 and y.contiguous and getattr(self, '_grid_il', False)
                     and x.shape[1] == br['ncols']):
-                fine = getattr(self, '_support_fine', None)
+                fine = self._format('_support_fine', x.shape[1])
                 tab, tile = (fine[0], fine[1]) if fine is not None else (sup[0] if sup is not None else None, 16)
                 if tab is None:
                     y._zero()           # without a support table every row is defined: bricks no sample touches stay zero
@@ -1125,9 +1143,9 @@ class HipBackend(Backend):
                                                  getattr(self, '_support_zw', 16), br['words']),
                          "ig_ccsrmm_t_bricks")
                 return
-            sl = getattr(self, '_slots', None)
+            sl = self._format('_slots', x.shape[1], exact=True)
             if sl is not None and perm is None and beta == 0 and y.contiguous and x.shape[1] == sl['ncols'] and sl['ntasks'] > 0:
-                fine = getattr(self, '_support_fine', None)
+                fine = self._format('_support_fine', x.shape[1])
                 tab, tile = (fine[0], fine[1]) if fine is not None else (sup[0] if sup is not None else None, 16)
                 if tab is None:
                     y._zero()

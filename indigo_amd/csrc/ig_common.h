@@ -146,14 +146,15 @@ __device__ __forceinline__ v4i_t make_rsrc_words(const void* p) {
     return v4i_t{(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xffffu), (int)IG_OOB, 0x00020000};
 }
 template <bool NT>
-__device__ __forceinline__ void buf_st_gated(v4i_t r, unsigned voff, float2 a, unsigned wanted /* wave-uniform: 0 = skip */) {
+__device__ __forceinline__ void buf_st_gated(v4i_t r, unsigned voff, unsigned soff /* wave-uniform byte offset */, float2 a,
+                                             unsigned wanted /* wave-uniform: 0 = skip */) {
     v2u_t v; v.x = __float_as_uint(a.x); v.y = __float_as_uint(a.y);
     if (NT)
-        asm volatile("s_cmp_eq_u32 %3, 0\n\ts_cbranch_scc1 .Lig_st_skip%=\n\tbuffer_store_dwordx2 %0, %1, %2, 0 offen nt\n.Lig_st_skip%=:"
-                     :: "v"(v), "v"(voff), "s"(r), "s"(wanted) : "scc", "memory");
+        asm volatile("s_cmp_eq_u32 %3, 0\n\ts_cbranch_scc1 .Lig_st_skip%=\n\tbuffer_store_dwordx2 %0, %1, %2, %4 offen nt\n.Lig_st_skip%=:"
+                     :: "v"(v), "v"(voff), "s"(r), "s"(wanted), "s"(soff) : "scc", "memory");
     else
-        asm volatile("s_cmp_eq_u32 %3, 0\n\ts_cbranch_scc1 .Lig_st_skip%=\n\tbuffer_store_dwordx2 %0, %1, %2, 0 offen\n.Lig_st_skip%=:"
-                     :: "v"(v), "v"(voff), "s"(r), "s"(wanted) : "scc", "memory");
+        asm volatile("s_cmp_eq_u32 %3, 0\n\ts_cbranch_scc1 .Lig_st_skip%=\n\tbuffer_store_dwordx2 %0, %1, %2, %4 offen\n.Lig_st_skip%=:"
+                     :: "v"(v), "v"(voff), "s"(r), "s"(wanted), "s"(soff) : "scc", "memory");
 }
 
 typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));

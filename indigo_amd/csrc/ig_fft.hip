@@ -266,65 +266,111 @@ __device__ __forceinline__ cx operator+(cx a, cx b) { cx r; r.v = a.v + b.v; ret
 __device__ __forceinline__ cx operator-(cx a, cx b) { cx r; r.v = a.v - b.v; return r; }
 __device__ __forceinline__ cx cneg(cx a) { cx r; r.v = -a.v; return r; }
 __device__ __forceinline__ cx cconj(cx a) { cx r; r.v = v2f{a.v.x, -a.v.y}; return r; }
-__device__ __forceinline__ cx cmul_mi(cx a) { cx r; r.v = v2f{a.v.y, -a.v.x}; return r; }          // a * (-i)
-__device__ __forceinline__ cx cmul_pi(cx a) { cx r; r.v = v2f{-a.v.y, a.v.x}; return r; }          // a * (+i)
-// a * w = a.xx * (w.x, w.y) + a.yy * (-w.y, w.x)
+// Multiplications by -+i and the twiddle products with a RUN-TIME root are single packed instructions with operand swizzles
+// (op_sel) and sign modifiers -- written as assembly, because from vector shuffles the compiler builds the rotated operand
+// (-w.y, w.x) with a v_xor and a v_mov first: two extra vector instructions per twiddle and per -i, 130 of the 800 of a 512-point
+// pass.  (Pure register operations: the compiler schedules them like any other instruction.)
+__device__ __forceinline__ cx cmul_mi(cx a) {          // a * (-i) = (a.y, -a.x)
+    cx r; asm("v_pk_add_f32 %0, %1, 0 op_sel:[1,0] op_sel_hi:[0,1] neg_hi:[1,0]" : "=v"(r.v) : "v"(a.v)); return r;
+}
+__device__ __forceinline__ cx cmul_pi(cx a) {          // a * (+i) = (-a.y, a.x)
+    cx r; asm("v_pk_add_f32 %0, %1, 0 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[1,0]" : "=v"(r.v) : "v"(a.v)); return r;
+}
+__device__ __forceinline__ cx cmul_mi_c(cx a) { cx r; r.v = v2f{a.v.y, -a.v.x}; return r; }          // (compiler-lowered forms: k_fft3d_b)
+__device__ __forceinline__ cx cmul_pi_c(cx a) { cx r; r.v = v2f{-a.v.y, a.v.x}; return r; }
+__device__ __forceinline__ cx padd_mi(cx a, cx b) {    // a + (-i) b = (a.x + b.y, a.y - b.x)
+    cx r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r.v) : "v"(a.v), "v"(b.v)); return r;
+}
+__device__ __forceinline__ cx padd_pi(cx a, cx b) {    // a + (+i) b = (a.x - b.y, a.y + b.x)
+    cx r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r.v) : "v"(a.v), "v"(b.v)); return r;
+}
+// a * w = a.xx * (w.x, w.y) + a.yy * (-w.y, w.x)   (w a literal: the compiler folds the rotation into the constants)
 __device__ __forceinline__ cx cxmul(cx a, cx w) {
     cx r;
     r.v = __builtin_shufflevector(a.v, a.v, 0, 0) * w.v + __builtin_shufflevector(a.v, a.v, 1, 1) * v2f{-w.v.y, w.v.x};
     return r;
 }
-// conj(w) * a = a.xx * (w.x, -w.y) + a.yy * (w.y, w.x)
+// the same with w in registers (twiddles out of LDS, weights out of memory): two instructions, no rotated copy of w
+__device__ __forceinline__ cx cxmul_r(cx a, cx w) {
+    cx t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t.v) : "v"(a.v), "v"(w.v));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r.v) : "v"(a.v), "v"(w.v), "v"(t.v));
+    return r;
+}
+// conj(w) * a = a.xx * (w.x, -w.y) + a.yy * (w.y, w.x), w in registers
 __device__ __forceinline__ cx cxmulc(cx w, cx a) {
-    cx r;
-    r.v = __builtin_shufflevector(a.v, a.v, 0, 0) * v2f{w.v.x, -w.v.y} + __builtin_shufflevector(a.v, a.v, 1, 1) * v2f{w.v.y, w.v.x};
+    cx t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(t.v) : "v"(a.v), "v"(w.v));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(r.v) : "v"(a.v), "v"(w.v), "v"(t.v));
     return r;
 }
 __device__ __forceinline__ void pbfly2(cx& a, cx& b) { const cx t = a - b; a = a + b; b = t; }
+// Direction as arithmetic: INV = true is the same butterfly network with every constant conjugated (the unnormalised inverse
+// DFT), so an inverse pass needs no conjugation of its inputs and outputs -- that cost the cropped passes two VALU
+// instructions per element on each side (a packed negate and a move), a tenth of their vector instructions.
+// (ASM = false keeps the compiler's own lowering of the -+i products: the second launch of the two-launch 256^3 transform is
+// scheduled around it -- with the assembly forms it went from 94 to 128 registers and spilled.)
+template <bool INV = false, bool ASM = true>
 __device__ __forceinline__ void pbfly4(cx& a0, cx& a1, cx& a2, cx& a3) {
-    const cx t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = cmul_mi(a1 - a3);
-    a0 = t0 + t2; a2 = t0 - t2; a1 = t1 + t3; a3 = t1 - t3;
+    const cx t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, dd = a1 - a3;
+    a0 = t0 + t2; a2 = t0 - t2;
+    if (ASM) {
+        a1 = INV ? padd_pi(t1, dd) : padd_mi(t1, dd);          // t1 -+ i dd
+        a3 = INV ? padd_mi(t1, dd) : padd_pi(t1, dd);
+    } else {
+        const cx t3 = INV ? cmul_pi_c(dd) : cmul_mi_c(dd);
+        a1 = t1 + t3; a3 = t1 - t3;
+    }
 }
-// a * exp(-2 pi i j / 32) with a literal root (j constant after unrolling), trivial rotations without multiplies
+// a * exp(-+2 pi i j / 32) with a literal root (j constant after unrolling), trivial rotations without multiplies
+template <bool INV = false, bool ASM = true>
 __device__ __forceinline__ cx pmul_w32(cx a, int j) {
     j &= 31;
+    if (INV) j = (32 - j) & 31;
     if (j == 0) return a;
-    if (j == 8) return cmul_mi(a);
+    if (j == 8) return ASM ? cmul_mi(a) : cmul_mi_c(a);
     if (j == 16) return cneg(a);
-    if (j == 24) return cmul_pi(a);
+    if (j == 24) return ASM ? cmul_pi(a) : cmul_pi_c(a);
     const float c = cos32(j), s = -cos32(j + 24);      // w = c + i s
     return cxmul(a, mk(c, s));
 }
-template <int N> struct PFFT;          // in-place forward DFT of N packed register values, natural order out
-template <> struct PFFT<4> {
-    __device__ static __forceinline__ void run(cx (&x)[4]) { pbfly4(x[0], x[1], x[2], x[3]); }
+template <int N, bool INV = false, bool ASM = true> struct PFFT;          // in-place DFT of N packed register values, natural order out
+template <bool INV, bool ASM> struct PFFT<4, INV, ASM> {
+    __device__ static __forceinline__ void run(cx (&x)[4]) { pbfly4<INV, ASM>(x[0], x[1], x[2], x[3]); }
 };
-template <> struct PFFT<8> {
+template <bool INV, bool ASM> struct PFFT<8, INV, ASM> {
     __device__ static __forceinline__ void run(cx (&v)[8]) {
-        pbfly4(v[0], v[2], v[4], v[6]);
-        pbfly4(v[1], v[3], v[5], v[7]);
+        pbfly4<INV, ASM>(v[0], v[2], v[4], v[6]);
+        pbfly4<INV, ASM>(v[1], v[3], v[5], v[7]);
         const float h = 0.70710678118654752440f;
-        v[3] = cxmul(v[3], mk(h, -h));
-        v[5] = cmul_mi(v[5]);
-        v[7] = cxmul(v[7], mk(-h, -h));
-        pbfly2(v[0], v[1]); pbfly2(v[2], v[3]); pbfly2(v[4], v[5]); pbfly2(v[6], v[7]);
+        v[3] = cxmul(v[3], mk(h, INV ? h : -h));
+        v[7] = cxmul(v[7], mk(-h, INV ? h : -h));
+        pbfly2(v[0], v[1]); pbfly2(v[2], v[3]); pbfly2(v[6], v[7]);
+        if (ASM) {   // v[4] +- (-+i) v[5]
+            const cx e = v[4], o = v[5];
+            v[4] = INV ? padd_pi(e, o) : padd_mi(e, o);
+            v[5] = INV ? padd_mi(e, o) : padd_pi(e, o);
+        } else {
+            v[5] = INV ? cmul_pi_c(v[5]) : cmul_mi_c(v[5]);
+            pbfly2(v[4], v[5]);
+        }
         const cx x4 = v[1], x1 = v[2], x5 = v[3], x2 = v[4], x6 = v[5], x3 = v[6];
         v[1] = x1; v[2] = x2; v[3] = x3; v[4] = x4; v[5] = x5; v[6] = x6;
     }
 };
-template <int N> struct PFFT {         // N = 16, 32: radix-4 decimation in frequency over N/4-point DFTs
+template <int N, bool INV, bool ASM> struct PFFT {         // N = 16, 32: radix-4 decimation in frequency over N/4-point DFTs
     __device__ static __forceinline__ void run(cx (&x)[N]) {
         constexpr int M = N / 4;
         cx z[4][M];
 #pragma unroll
         for (int r = 0; r < M; ++r) {
-            pbfly4(x[r], x[r + M], x[r + 2 * M], x[r + 3 * M]);
+            pbfly4<INV, ASM>(x[r], x[r + M], x[r + 2 * M], x[r + 3 * M]);
             z[0][r] = x[r];
 #pragma unroll
-            for (int q = 1; q < 4; ++q) z[q][r] = pmul_w32(x[r + q * M], r * q * (32 / N));
+            for (int q = 1; q < 4; ++q) z[q][r] = pmul_w32<INV, ASM>(x[r + q * M], r * q * (32 / N));
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) PFFT<M>::run(z[q]);
+        for (int q = 0; q < 4; ++q) PFFT<M, INV, ASM>::run(z[q]);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -339,11 +385,10 @@ template <int N> struct PFFTHalfIn {
 #pragma unroll
         for (int r = 0; r < M; ++r) {
             const cx a1 = x[r + M], a2 = x[r + 2 * M];
-            const cx t3 = cmul_mi(a1);
             z[0][r] = a2 + a1;
-            z[1][r] = pmul_w32(t3 - a2, r * (32 / N));
+            z[1][r] = pmul_w32(cneg(padd_pi(a2, a1)), r * (32 / N));          // (-i) a1 - a2
             z[2][r] = pmul_w32(a2 - a1, r * 2 * (32 / N));
-            z[3][r] = pmul_w32(cneg(a2 + t3), r * 3 * (32 / N));
+            z[3][r] = pmul_w32(cneg(padd_mi(a2, a1)), r * 3 * (32 / N));      // -(a2 + (-i) a1)
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) PFFT<M>::run(z[q]);
@@ -377,12 +422,17 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
     constexpr int SUMW = WMODE >= 3 ? (1 << (WMODE - 3)) : 0;       // WMODE 3 + log2(coils): 3 -> 1 (no sum), 4 -> 2, 5 -> 4, 6 -> 8, 7 -> 16
     // direction: the half-input variants only serve forward (zero-padded) passes and the half-output variants only
     // inverse (cropped) ones, so their conjugations are sign modifiers, not a select per element
-    const bool inv = HALF_OUT ? true : HALF_IN ? false : (d.inverse != 0);
+    // (SINV: the inverse transform by conjugated constants, PFFT<N, true>; the run-time direction of the general variants by
+    // conjugating inputs and outputs around the forward network)
+    constexpr bool SINV = HALF_OUT;
+    const bool inv = (HALF_OUT || HALF_IN) ? false : (d.inverse != 0);
     static_assert(R2 % T == 0 && R1 % T == 0 && T == 16 && B1 == 1, "lane groups of 16, one stage-1 butterfly per thread");
     extern __shared__ float2 lds[];
     float2* __restrict__ tws = lds + (AXIS0 ? 16 * 17 * W : 16 * T * W);
     const int tid = threadIdx.x;
-    for (int k = tid; k < n; k += NT) tws[k] = tw[k];
+    // inter-stage twiddles in the order the threads read them: entry t * R1 + k = w_n^(t k) (the second half of the plan's table),
+    // so a thread's R1 - 1 reads are one base address plus compile-time offsets, two values per LDS instruction
+    for (int k = tid; k < n; k += NT) tws[k] = tw[n + k];
 
     const int t = AXIS0 ? (tid % T) : (tid / W);
     const int w = AXIS0 ? (tid / T) : (tid % W);
@@ -490,36 +540,55 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
     }
 
     // ---- stage 1: radix R1 on inputs j = t + k*R2, results (times w_n^{t k}) to the exchange
+    // Strided passes re-base their descriptors once per GRP elements -- one 64-bit scalar add, hidden from the compiler, which
+    // otherwise recomputes base + k * step with two 32-bit multiplies, a high multiply and their adds for every element -- and
+    // reach the elements in between through the instruction's scalar offset (1, 2, 3 steps: three registers per stream, computed
+    // once).  Per-element re-basing was a third of the scalar instructions of these kernels, and a wave issues one instruction
+    // of any kind per turn.  (GRP * 16 - 1 element steps plus the tile's lanes must fit the 2 GB window: launch_2stage checks.)
+    constexpr int GRP = 4;
+    auto opaque = [](const float2*& q) { asm("" : "+s"(q)); };
     cx v[R1];
     {
         cx wv[R1];
+        constexpr int K0 = HALF_IN ? R1 / 4 : 0, K1 = HALF_IN ? 3 * R1 / 4 : R1;
+        const int64_t st_in = (int64_t)R2 * d.in_sj, st_w = WMODE == 1 ? (int64_t)R2 * d.w_sj : 0;
+        const unsigned so_in = (unsigned)st_in * 8u, so_w = (unsigned)st_w * 8u;
+        const float2* p_in = AXIS0 ? b_in : b_in + K0 * st_in;
+        const float2* p_w = (AXIS0 || WMODE != 1) ? b_w : b_w + K0 * st_w;
+        rsrc_t g_in = make_rsrc(p_in), g_w = make_rsrc(p_w);
 #pragma unroll
-        for (int k = 0; k < R1; ++k) {
-            if (HALF_IN && (k < R1 / 4 || k >= 3 * R1 / 4)) continue;        // never read
+        for (int k = K0; k < K1; ++k) {
+            const int g = (k - K0) % GRP;
+            if (!AXIS0 && g == 0 && k > K0) {
+                p_in += GRP * st_in; opaque(p_in); g_in = make_rsrc(p_in);
+                if (WMODE == 1) { p_w += GRP * st_w; opaque(p_w); g_w = make_rsrc(p_w); }
+            }
             const bool stat = !BOXED || HALF_IN || HALF == 4;                 // box known at compile time
             // off = all ones (out of range) where the element is not wanted: one bit-field extract + one or
             const unsigned off = stat ? 0u : (unsigned)__builtin_amdgcn_sbfe((int)~ibits, k, 1);
-            if (!stat && !AXIS0 && WMODE == 0 && !((gin >> k) & 1u)) { v[k] = mk(0.f, 0.f); continue; }
-            if (AXIS0) {
+            if (!stat && !AXIS0 && WMODE == 0 && !((gin >> k) & 1u)) v[k] = mk(0.f, 0.f);
+            else if (AXIS0) {
                 v[k] = from2(buf_ld<NT_LD>(r_in, l_in | off, (unsigned)(k * R2) * 8u));
                 if (WMODE == 1) wv[k] = from2(buf_ld<false>(r_w, l_w | off, (unsigned)(k * R2) * 8u));
             } else {
-                v[k] = from2(buf_ld<NT_LD>(make_rsrc(b_in + (int64_t)(k * R2) * d.in_sj), l_in | off, 0));
-                if (WMODE == 1) wv[k] = from2(buf_ld<false>(make_rsrc(b_w + (int64_t)(k * R2) * d.w_sj), l_w | off, 0));
+                v[k] = from2(buf_ld<NT_LD>(g_in, l_in | off, (unsigned)g * so_in));
+                if (WMODE == 1) wv[k] = from2(buf_ld<false>(g_w, l_w | off, (unsigned)g * so_w));
             }
         }
 #pragma unroll
-        for (int k = 0; k < R1; ++k) {
-            if (HALF_IN && (k < R1 / 4 || k >= 3 * R1 / 4)) continue;
-            if (WMODE == 1) v[k] = cxmul(v[k], wv[k]);
+        for (int k = K0; k < K1; ++k) {
+            if (WMODE == 1) v[k] = cxmul_r(v[k], wv[k]);
             if (inv) v[k] = cconj(v[k]);
         }
     }
     __syncthreads();            // twiddle table visible (the global loads above are already in flight)
     if (HALF_IN) PFFTHalfIn<R1>::run(v);
-    else PFFT<R1>::run(v);
+    else PFFT<R1, SINV>::run(v);
+    {
+        const float2* __restrict__ twt = tws + t * R1;
 #pragma unroll
-    for (int k = 1; k < R1; ++k) v[k] = cxmul(v[k], from2(tws[t * k]));
+        for (int k = 1; k < R1; ++k) v[k] = SINV ? cxmulc(from2(twt[k]), v[k]) : cxmul_r(v[k], from2(twt[k]));
+    }
 
     // ---- exchange + stage 2 in B2 = R1/16 rounds.  Stage-2 butterfly b2 = t + 16*q needs, from every
     // stage-1 thread b, exactly its output k = b2: round q therefore moves only the outputs
@@ -527,6 +596,9 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
     // Exchange element (b, kk) lives at row b, slot kk.  Strided axes: [b][kk][w] (lanes along w).  Axis 0: column
     // group w owns 16 rows of 17 slots -- the odd row stride makes both the row-wise writes and the column-wise
     // reads conflict-free, and every address is one per-thread base plus a compile-time offset.
+    // (Round 5, not adopted: handing a round over in two halves of 8 slots makes the 32-column tiles' image 32 KB -- three workgroups
+    // per CU by LDS -- but a thread then holds its 24 outputs still to hand over beside the 16 inputs of its second transform:
+    // at the 80 registers six waves per SIMD allow the kernels spill 18 ... 24 registers.  Not measured.)
     float2* __restrict__ lw = AXIS0 ? lds + w * (16 * 17) + t * 17 : lds + (t * 16) * W + w;     // + kk * (AXIS0 ? 1 : W)
     float2* __restrict__ lr = AXIS0 ? lds + w * (16 * 17) + t      : lds + t * W + w;            // + k2 * (AXIS0 ? 17 : 16 * W)
 #pragma unroll
@@ -538,21 +610,34 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
         cx u[R2];
 #pragma unroll
         for (int r = 0; r < R2; ++r) u[r] = from2(lr[r * (AXIS0 ? 17 : 16 * W)]);
-        PFFT<R2>::run(u);
+        PFFT<R2, SINV>::run(u);
+        constexpr int Q0 = HALF_OUT ? R2 / 4 : 0, Q1 = HALF_OUT ? 3 * R2 / 4 : R2;          // outputs outside are never stored
+        const int64_t st_out = (int64_t)R1 * d.out_sj, st_w = WMODE >= 2 ? (int64_t)R1 * d.w_sj : 0;
+        const unsigned so_out = (unsigned)st_out * 8u, so_w = (unsigned)st_w * 8u;
+        const float2* p_out = AXIS0 ? b_out : b_out + (q * T) * d.out_sj + Q0 * st_out;
+        const float2* p_w = (AXIS0 || WMODE < 2) ? b_w : b_w + (q * T) * d.w_sj + Q0 * st_w;
         cx wv[R2];          // kept outputs j = t + 16*(q + r*B2): bit q + r*B2 of obits
         if (WMODE >= 2) {
+            rsrc_t g_w = make_rsrc(p_w);
 #pragma unroll
-            for (int r = 0; r < R2; ++r) {
-                if (HALF_OUT && (r < R2 / 4 || r >= 3 * R2 / 4)) continue;
+            for (int r = Q0; r < Q1; ++r) {
+                const int g = (r - Q0) % GRP;
+                if (!AXIS0 && g == 0 && r > Q0) { p_w += GRP * st_w; opaque(p_w); g_w = make_rsrc(p_w); }
                 const bool stat = !BOXED || HALF_OUT || HALF == 3;
                 const unsigned off = stat ? 0u : (unsigned)__builtin_amdgcn_sbfe((int)~obits, q + r * B2, 1);
                 if (AXIS0) wv[r] = from2(buf_ld<false>(r_w, l_w | off, (unsigned)(q * T + r * R1) * 8u));
-                else wv[r] = from2(buf_ld<false>(make_rsrc(b_w + (int64_t)(q * T + r * R1) * d.w_sj), l_w | off, 0));
+                else wv[r] = from2(buf_ld<false>(g_w, l_w | off, (unsigned)g * so_w));
             }
         }
+        rsrc_t g_out = make_rsrc(p_out);
+        v4i_t gw_out = make_rsrc_words(p_out);
 #pragma unroll
-        for (int r = 0; r < R2; ++r) {
-            if (HALF_OUT && (r < R2 / 4 || r >= 3 * R2 / 4)) continue;          // never stored
+        for (int r = Q0; r < Q1; ++r) {
+            const int g = (r - Q0) % GRP;
+            if (!AXIS0 && g == 0 && r > Q0) {
+                p_out += GRP * st_out; opaque(p_out);
+                if (GATE_ST) gw_out = make_rsrc_words(p_out); else g_out = make_rsrc(p_out);
+            }
             const bool stat = !BOXED || HALF_OUT || HALF == 3;
             cx ac = u[r];
             if (inv) ac = cconj(ac);
@@ -569,8 +654,8 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
                 if (SUMW >= 16) { a.x += dpp_f<0x108>(a.x); a.y += dpp_f<0x108>(a.y); }     // row_shl:8
             }
             if (AXIS0) buf_st<NT_ST>(r_out, l_out | off, (unsigned)(q * T + r * R1) * 8u, a);
-            else if (GATE_ST) buf_st_gated<NT_ST>(make_rsrc_words(b_out + (int64_t)(q * T + r * R1) * d.out_sj), l_out | off, a, (gout >> (q + r * B2)) & 1u);
-            else buf_st<NT_ST>(make_rsrc(b_out + (int64_t)(q * T + r * R1) * d.out_sj), l_out | off, 0, a);
+            else if (GATE_ST) buf_st_gated<NT_ST>(gw_out, l_out | off, (unsigned)g * so_out, a, (gout >> (q + r * B2)) & 1u);
+            else buf_st<NT_ST>(g_out, l_out | off, (unsigned)g * so_out, a);
         }
     }
 }
@@ -640,7 +725,7 @@ k_fft3d_a(const float2* __restrict__ in, float2* __restrict__ out, const float2*
     for (int j = 0; j < 4; ++j) {
         PFFT<8>::run(v[j]);
 #pragma unroll
-        for (int kb = 1; kb < 8; ++kb) v[j][kb] = cxmul(v[j][kb], from2(tws[(4 * a * kb) & 255]));
+        for (int kb = 1; kb < 8; ++kb) v[j][kb] = cxmul_r(v[j][kb], from2(tws[(4 * a * kb) & 255]));
     }
     // exchange 1 (a <-> kb between waves, lane kept): image [a][kb][xl], two images (two j) per round
     cx r[4][8];
@@ -670,11 +755,11 @@ k_fft3d_a(const float2* __restrict__ in, float2* __restrict__ out, const float2*
         const cx wy = from2(tws[(n2 * (kb + 8 * ka)) & 255]);
         cx t4[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) t4[j] = cxmul(r[j][ka], wy);
+        for (int j = 0; j < 4; ++j) t4[j] = cxmul_r(r[j][ka], wy);
         PFFT<4>::run(t4);
         p[ka][0] = t4[0];
 #pragma unroll
-        for (int kj = 1; kj < 4; ++kj) p[ka][kj] = cxmul(t4[kj], from2(tws[(xl * kj) & 255]));
+        for (int kj = 1; kj < 4; ++kj) p[ka][kj] = cxmul_r(t4[kj], from2(tws[(xl * kj) & 255]));
     }
     // exchange 2: image [line][72] (x within a line); role 2 = (c = x mod 8, line): lane = c + 8*(line mod 8), wave = line / 8
     const int c = tid & 7, l = (tid >> 3) & 7, line = (tid >> 3);
@@ -699,7 +784,7 @@ k_fft3d_a(const float2* __restrict__ in, float2* __restrict__ out, const float2*
     for (int kj = 0; kj < 4; ++kj) {
         PFFT<8>::run(q[kj]);
 #pragma unroll
-        for (int kd = 1; kd < 8; ++kd) q[kj][kd] = cxmul(q[kj][kd], from2(tws[(4 * c * kd) & 255]));
+        for (int kd = 1; kd < 8; ++kd) q[kj][kd] = cxmul_r(q[kj][kd], from2(tws[(4 * c * kd) & 255]));
     }
     // exchange 3 (c <-> kd among the 8 lanes of a line: inside the wave): image [line][64], swizzled both ways
     __syncthreads();                                   // the last round of exchange 2 has been read everywhere
@@ -772,7 +857,7 @@ k_fft3d_b(const float2* __restrict__ in, float2* __restrict__ out, const float2*
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         cx a0 = v[0][k] + v[1][k], a1 = v[0][k] - v[1][k];
-        if (h) a1 = cmul_mi(a1);
+        if (h) a1 = cmul_mi_c(a1);
         cx p0, p1;
         p0.v = v2f{dpp_f<0xB1>(a0.v.x), dpp_f<0xB1>(a0.v.y)};      // quad_perm [1,0,3,2]: the lane with the other h
         p1.v = v2f{dpp_f<0xB1>(a1.v.x), dpp_f<0xB1>(a1.v.y)};
@@ -787,7 +872,7 @@ k_fft3d_b(const float2* __restrict__ in, float2* __restrict__ out, const float2*
     const unsigned l_st = ((unsigned)w + ((unsigned)kk1 << 16) + (unsigned)k2_base * (256u * 64u)) * 8u;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-        PFFT<16>::run(y[q]);
+        PFFT<16, false, false>::run(y[q]);
         if (q) __syncthreads();
         // twiddle and hand over four values at a time; the compiler-level fences keep the scheduler from hoisting all
         // fifteen twiddle loads (30 registers) above the transform, which spilled y[1] at the 128-register cap
@@ -804,7 +889,7 @@ k_fft3d_b(const float2* __restrict__ in, float2* __restrict__ out, const float2*
         cx r[16];
 #pragma unroll
         for (int tt = 0; tt < 16; ++tt) r[tt] = from2(lds[tt * 544 + kk1 * 32 + h * 16 + w]);
-        PFFT<16>::run(r);
+        PFFT<16, false, false>::run(r);
         const float2* const ob = out + base + 256 * (k1 + 64 * q);
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) {
@@ -1133,13 +1218,21 @@ int plan_axis(ig_ctx* ctx, ig_fft* p, int a) {
         }
     }
     // twiddles exp(-2 pi i k / n), rounded once from double
-    std::vector<float2> tw((size_t)ax.n);
+    // (two-stage axes: a second table behind the first, the inter-stage twiddles in the order k_fft_2stage's threads read them --
+    // entry n + t * R1 + k = w_n^(t k) for thread t < 16 and stage-1 output k < R1 = n / 16)
+    const size_t ntw = (size_t)ax.n * (ax.kind == 3 ? 2 : 1);
+    std::vector<float2> tw(ntw);
     for (int64_t k = 0; k < ax.n; ++k) {
         const double ang = -2.0 * M_PI * (double)k / (double)ax.n;
         tw[k] = make_float2((float)cos(ang), (float)sin(ang));
     }
-    IG_HIP(ctx, hipMalloc((void**)&ax.d_tw, sizeof(float2) * (size_t)ax.n));
-    IG_HIP(ctx, hipMemcpy(ax.d_tw, tw.data(), sizeof(float2) * (size_t)ax.n, hipMemcpyHostToDevice));
+    if (ax.kind == 3) {
+        const int64_t R1 = ax.n / 16;
+        for (int64_t t = 0; t < 16; ++t)
+            for (int64_t k = 0; k < R1; ++k) tw[ax.n + t * R1 + k] = tw[(t * k) % ax.n];
+    }
+    IG_HIP(ctx, hipMalloc((void**)&ax.d_tw, sizeof(float2) * ntw));
+    IG_HIP(ctx, hipMemcpy(ax.d_tw, tw.data(), sizeof(float2) * ntw, hipMemcpyHostToDevice));
     return IG_OK;
 }
 
@@ -1156,8 +1249,9 @@ int launch_2stage(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d_in, bool ax
     d.tpr = (unsigned)tpr;
     {   // every in-tile byte offset must stay inside the 2 GB descriptor window
         const int64_t lim = 0x7fffffffLL / 8;
-        // (strided passes re-base per 16 elements: only 31 element steps plus the tile's lanes must fit)
-        const int64_t reach = axis0 ? ax.n + 15 : 31;
+        // (strided passes re-base once per 4 groups of 16 elements and reach the three groups in between through the scalar
+        // offset -- at 32 elements per step on the output side of a 512-point axis: 3 * 32 + 15 element steps plus the tile's lanes must fit)
+        const int64_t reach = axis0 ? ax.n + 15 : 3 * (ax.n / 16) + 15;
         const int64_t span_in = reach * d.in_sj + 15 * d.in_s[0] + 15 * d.in_sa, span_out = reach * d.out_sj + 15 * d.out_s[0] + 15 * d.out_sa;
         const int64_t span_w = wmode ? reach * d.w_sj + 15 * d.w_s[0] + 15 * d.w_sa : 0;
         IG_REQUIRE(ctx, d.in_sj >= 0 && d.out_sj >= 0 && d.in_s[0] >= 0 && d.out_s[0] >= 0 && span_in < lim && span_out < lim && span_w < lim,

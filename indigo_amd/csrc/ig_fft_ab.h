@@ -424,7 +424,7 @@ k_fft_ab_desc(PassDesc d, const float2* __restrict__ tw) {
                 if (SUMW >= 8)  { e.x += ab_dpp<0x104>(e.x); e.y += ab_dpp<0x104>(e.y); }     // row_shl:4
                 if (SUMW >= 16) { e.x += ab_dpp<0x108>(e.x); e.y += ab_dpp<0x108>(e.y); }     // row_shl:8
                 const unsigned off = (unsigned)__builtin_amdgcn_sbfe((int)~obits, k2, 1);
-                if (WMODE == 0) buf_st_gated<true>(make_rsrc_words(b_out + (int64_t)(A * k2) * d.out_sj), l_out | off, e, (gout >> k2) & 1u);
+                if (WMODE == 0) buf_st_gated<true>(make_rsrc_words(b_out + (int64_t)(A * k2) * d.out_sj), l_out | off, 0u, e, (gout >> k2) & 1u);
                 else buf_st<true>(make_rsrc(b_out + (int64_t)(A * k2) * d.out_sj), l_out | off, 0, e);
             }
         }

@@ -383,6 +383,8 @@ class ShardedNormalOperator(object):
             r = A_local
             if isinstance(r, op.VStack):
                 r = r.children[-1]
+            if isinstance(r, op.HeadRows):          # a chunk padded with zero-weight coils: alpha and beta pass through to its tree
+                r = r.child
             while isinstance(r, op.Product):
                 r = r.right
             if isinstance(r, op.ZpadFFT) and hasattr(self._backend, 'ifft_cropped_sum') and (r._layout == 2 or (r._layout == 1 and r._C == 1)):

@@ -133,22 +133,55 @@ def pow2_divisor(n, cap):
     return max(b, 1)
 
 
-def coil_chunks(Cn, chunk=8):
-    """Split Cn coils into runs the coil-interleaved kernels take (8, then 4, 2; a last odd coil alone)."""
+# What one chunk of w interleaved coils costs per evaluation of the headline problem (ms, MI355X, DESIGN.md section 5: the per-rank
+# timings of a coil-sharded run; w = 1 is the per-coil grid layout).  Only the ratios matter: they decide how a coil count
+# that is no power of two is cut up -- 7 coils are cheaper as ONE 8-wide chunk with a zero-weight coil (6.6) than as 4 + 2 + 1
+# (8.1), 12 coils as 8 + 4, 3 coils as a 4-wide chunk (3.9) rather than 2 + 1 (4.2).
+CHUNK_COST = {16: 13.0, 8: 6.6, 4: 3.9, 2: 2.45, 1: 1.7}
+
+
+def plan_chunks(Cn, chunk=8, single_ok=True):
+    """Cut Cn coils into chunks the coil-interleaved kernels take: [(lo, hi, width)], width in {16, 8, 4, 2} (<= chunk) coils
+    interleaved below the grid -- of which hi - lo are real and the rest, if any, zero-weight padding -- or width 1: one coil
+    in the per-coil layout (only where the backend has those kernels for the grid: `single_ok`).  The cheapest cover by
+    CHUNK_COST; every chunk of every coil count reaches the binned adjoint gridding and the fused transform leaf."""
+    widths = [w for w in (16, 8, 4, 2) if w <= max(int(chunk), 2)] + ([1] if single_ok else [])
+    best = [(0.0, [])]
+    for c in range(1, int(Cn) + 1):
+        cand = [(best[max(c - w, 0)][0] + CHUNK_COST[w], best[max(c - w, 0)][1] + [w]) for w in widths]
+        best.append(min(cand, key=lambda t: (round(t[0], 6), len(t[1]))))
     out, lo = [], 0
-    for size in (c for c in (16, 8, 4, 2, 1) if c <= chunk):
-        while Cn - lo >= size:
-            out.append((lo, lo + size))
-            lo += size
+    for w in sorted(best[int(Cn)][1], reverse=True):
+        hi = min(lo + w, int(Cn))
+        out.append((lo, hi, w))
+        lo = hi
     return out
 
 
-def choose_layout(Cn, chunk=8, layout=None):
-    """(layout, chunks) for Cn coils on one rank"""
-    chunks = coil_chunks(Cn, chunk) if Cn > chunk and layout in (None, 2) else [(0, Cn)]
-    if layout is None:      # coils interleaved below the grid where the kernels support it (2, 4 or 8 per rank)
-        layout = 2 if (len(chunks) > 1 or Cn in (2, 4, 8)) else 1
-    return layout, chunks
+def coil_chunks(Cn, chunk=8):
+    """(lo, hi) of the chunks of plan_chunks"""
+    return [(lo, hi) for lo, hi, _ in plan_chunks(Cn, chunk)]
+
+
+def choose_layout(Cn, chunk=8, layout=None, single_ok=True):
+    """(layout, chunks) for Cn coils on one rank: chunks = [(lo, hi, width)] (plan_chunks); layout 2 when any chunk is
+    coil-interleaved.  An explicit per-coil layout (0 or 1) keeps all coils in one chunk."""
+    if layout in (0, 1):
+        return layout, [(0, int(Cn), 0)]                  # width 0: per-coil layout, any coil count
+    chunks = plan_chunks(Cn, chunk, single_ok)
+    return (2 if any(w > 1 for _, _, w in chunks) else 1), chunks
+
+
+def pad_coils(w, width, interleaved=True):
+    """weights box + (c,) -> box + (width,) with zero weights for the padding coils, in the memory form ZpadFFT keeps as it is
+    (layout 2: a voxel's coils side by side)"""
+    w = np.asarray(w)
+    box, c = w.shape[:3], w.shape[3]
+    if c == width:
+        return w
+    out = np.zeros(box[::-1] + (width,), dtype=_C64).transpose(2, 1, 0, 3) if interleaved else np.zeros(box + (width,), dtype=_C64, order='F')
+    out[..., :c] = w
+    return out
 
 
 def assemble(backend, Gm, oN, N, weights_of, Cn, layout, chunks, table=None, box_lo=None, row_order=None,
@@ -158,10 +191,35 @@ def assemble(backend, Gm, oN, N, weights_of, Cn, layout, chunks, table=None, box
     Gm          gridding matrix (T x P, complex64 CSR) with its columns in the order of `layout` (see
                 permute_grid_columns; layout 2 uses layout 1's numbering)
     weights_of  (lo, hi) -> weights array box + (hi - lo,) for that run of coils (maps * roll-off * modulation)
+    chunks      [(lo, hi, width)] from choose_layout: width coils interleaved, hi - lo of them real
     More coils than a chunk holds (the reference's `batch` hint, indigo/operators.py:15-17,341: evaluate a wide
     KronI a few columns at a time) become a VStack: the k-space rows come out coil-major exactly as from KronI(C, G'),
-    and the adjoint accumulates the chunks' images (VStack, operators.py:440-447)."""
+    and the adjoint accumulates the chunks' images (VStack, operators.py:440-447).  Chunks of different widths share the
+    matrix too: it carries one binned adjoint format and one fine support table PER WIDTH present (8 and 4: brick rounds;
+    2: slots), so 12 coils (8 + 4) or 6 (4 + 2) run the same kernels as 8, 4 and 2 coils do alone."""
+    from indigo_amd import operators as op
     tuning = getattr(backend, 'tuning', {})          # format choices of the backend (HipBackend.tuning)
+    chunks = [(c[0], c[1], (c[2] if len(c) > 2 else (c[1] - c[0] if layout == 2 else 0))) for c in chunks]
+    il_widths = sorted({w for _, _, w in chunks if w > 1}, reverse=True)
+    x16 = int(oN[0]) % 16 == 0
+
+    # A finer k-space support table for the coil-interleaved trees (backends that take one): `tile` kx points per entry instead
+    # of 16 -- 22 % instead of 30 % of the headline problem's grid is flagged at 8, 16 % at 4.  The gather routes keep the
+    # 16-point table: whatever they write is a superset of what a reader with the finer table reads.
+    # (measured on the headline problem: 7.80 ms at 16, 7.52 ms at 8; coils * tile >= 32 keeps the transform's 32-column tiles,
+    # which need two tiles per table entry.  Round 4: 4 kx points per entry for 8-coil trees -- 16.4 % of the headline grid flagged
+    # instead of 22.2 %; the scatter flushes the 4-point segments in pairs, one wave store as before: 6.92 -> 6.77 ms.)
+    # One table per width present: a chunk's scatter writes by the table its own transform reads by.
+    tile_of = tuning.get('support_tile', 8)
+    fine = {}
+    by_tile = {}
+    for w in il_widths:
+        tile = int(tile_of.get(w, 8) if isinstance(tile_of, dict) else tile_of)
+        if (table is not None and tile in (4, 8) and w * tile >= 32 and getattr(backend, 'supports_support_tile', False)
+                and w in tuning.get('bricks', ())):
+            if tile not in by_tile:
+                by_tile[tile] = grid_support(Gm, oN, tile, zw)
+            fine[w] = (by_tile[tile], tile)
 
     def gridding(interleaved, ncols=0):
         # ncols: panel columns of the trees that use this matrix (per-coil layout: the chunk's coil count)
@@ -170,63 +228,61 @@ def assemble(backend, Gm, oN, N, weights_of, Cn, layout, chunks, table=None, box
             G._grid_interleaved = True
         if table is not None:
             G._grid_support = (table, int(oN[0]), int(oN[2]), int(zw[0]))
-        if interleaved and fine is not None:
-            G._grid_support_fine = fine
         if row_order is not None:
             G._row_order = row_order
-        elif interleaved and bricks_cols in tuning.get('bricks', ()) and int(oN[0]) % 16 == 0:
-            # adjoint gridding by grid bricks (a scatter binned on the host) instead of a gather over the transposed matrix.
-            # Measured (config 4): 8 coils 0.91 ms against 1.82 ms (gather + its deferred long rows); 4 coils 0.68 against
-            # 1.05 ms.  Two coils or one would pad every sample's share of a brick to 32 / 64 entries: they keep the gather.
-            shape = tuning.get('brick_shape', {})
-            shape = shape.get(bricks_cols, (2, 2, 4096, 4096)) if isinstance(shape, dict) else shape
-            # bricks of 16 x bm x bs cells must tile the grid: halve a side until it divides (277 x 410, the reference driver's
-            # default grid: 16 x 2 x 1)
-            G._grid_bricks = (int(oN[0]), int(oN[2]), int(oN[1]), bricks_cols, pow2_divisor(oN[2], shape[0]), pow2_divisor(oN[1], shape[1])) + tuple(shape[2:])
-        elif (bricks_cols if interleaved else ncols) in tuning.get('slots', ()) and int(oN[0]) % 16 == 0:
-            # 1, 2 (or 4) columns: the same scatter with SLOTS in place of rounds (ig_ccsrmm_t_slots) -- no padding, no G'^T.
-            # (per-coil layout: only for a chunk of exactly that many coils -- a 3-, 5-, 6- or 7-coil tree never takes the
-            # route, and the format is 16 bytes per nonzero of HBM plus its host passes)
-            sshape = tuple(tuning.get('slot_shape', (4, 4, 256, 64)))
-            G._grid_slots = (int(oN[0]), int(oN[2]), int(oN[1]), bricks_cols if interleaved else ncols,
-                             pow2_divisor(oN[2], sshape[0]), pow2_divisor(oN[1], sshape[1])) + sshape[2:]
+            return G
+        bricks, slots, fines = {}, {}, {}
+        for w in (il_widths if interleaved else [ncols]):
+            if interleaved and w in tuning.get('bricks', ()) and x16:
+                # adjoint gridding by grid bricks (a scatter binned on the host) instead of a gather over the transposed matrix.
+                # Measured (config 4): 8 coils 0.91 ms against 1.82 ms (gather + its deferred long rows); 4 coils 0.68 against
+                # 1.05 ms.  Two coils or one would pad every sample's share of a brick to 32 / 64 entries: they take the slots.
+                shape = tuning.get('brick_shape', {})
+                shape = shape.get(w, (2, 2, 4096, 4096)) if isinstance(shape, dict) else shape
+                # bricks of 16 x bm x bs cells must tile the grid: halve a side until it divides (277 x 410, the reference driver's
+                # default grid: 16 x 2 x 1)
+                bricks[w] = (int(oN[0]), int(oN[2]), int(oN[1]), w, pow2_divisor(oN[2], shape[0]), pow2_divisor(oN[1], shape[1])) + tuple(shape[2:])
+                if w in fine:
+                    fines[w] = fine[w]
+            elif w in tuning.get('slots', ()) and x16:
+                # 1, 2 (or 4) columns: the same scatter with SLOTS in place of rounds (ig_ccsrmm_t_slots) -- no padding, no G'^T.
+                sshape = tuple(tuning.get('slot_shape', (4, 4, 256, 64)))
+                slots[w] = (int(oN[0]), int(oN[2]), int(oN[1]), w, pow2_divisor(oN[2], sshape[0]), pow2_divisor(oN[1], sshape[1])) + sshape[2:]
+        if fines:
+            G._grid_support_fine = fines
+        if bricks:
+            G._grid_bricks = bricks
+        if slots:
+            G._grid_slots = slots
         return G
 
-    sizes = {hi - lo for lo, hi in chunks if hi - lo > 1}
-    bricks_cols = sizes.pop() if len(sizes) == 1 else 0          # one interleaved width per tree: the binned format is padded for it
-    # A finer k-space support table for the coil-interleaved trees (backends that take one): `tile` kx points per entry instead
-    # of 16 -- 22 % instead of 30 % of the headline problem's grid is flagged at 8, 16 % at 4.  The gather routes keep the
-    # 16-point table: whatever they write is a superset of what a reader with the finer table reads.
-    # (measured on the headline problem: 7.80 ms at 16, 7.52 ms at 8; at 4 the scatter's 16 segments per brick spill.  coils * tile
-    # >= 32 keeps the transform's 32-column tiles, which need two tiles per table entry.)
-    # (round 4: 4 kx points per entry for 8-coil trees -- 16.4 % of the headline grid flagged instead of 22.2 %; the scatter flushes
-    # the 4-point segments in pairs, one wave store as before: 6.92 -> 6.77 ms.  4-coil trees keep 8 points: coils * tile >= 32.)
-    tile = tuning.get('support_tile', 8)
-    tile = int(tile.get(bricks_cols, 8) if isinstance(tile, dict) else tile)
-    fine = None
-    if (table is not None and layout == 2 and tile in (4, 8) and bricks_cols * tile >= 32 and len(sizes) == 0
-            and getattr(backend, 'supports_support_tile', False)):
-        fine = (grid_support(Gm, oN, tile, zw), tile)
-    G_il = gridding(True) if layout == 2 else None
+    G_il = gridding(True) if il_widths else None
     G_pc = None
     trees = []
-    for lo, hi in chunks:
-        lay = layout if (layout != 2 or hi - lo > 1 or len(chunks) == 1) else 1     # a left-over single coil: per-coil kernels
-        if lay == 2:
-            G = G_il
+    for lo, hi, w in chunks:
+        real = hi - lo
+        if w > 1:
+            wts = pad_coils(weights_of(lo, hi), w)
+            if w in fine:
+                Z = backend.ZpadFFT(oN, N, wts, box_lo=box_lo, layout=2, support=fine[w][0], support_tile=fine[w][1], name='fft*zpad*apod*maps')
+            else:
+                Z = backend.ZpadFFT(oN, N, wts, box_lo=box_lo, layout=2, support=table, name='fft*zpad*apod*maps')
+            tree = backend.KronI(w, G_il) * Z
+            if real < w:
+                # zero-weight padding coils: their k-space rows come last, are exact zeros on the way out and read as zeros on the way in
+                tree = op.HeadRows(backend, tree, real * Gm.shape[0], name='coils %d..%d of a %d-wide chunk' % (lo, hi, w))
         else:
-            G_pc = G_pc or gridding(False, hi - lo)
-            G = G_pc
-        if lay == 2 and fine is not None:
-            Z = backend.ZpadFFT(oN, N, weights_of(lo, hi), box_lo=box_lo, layout=lay, support=fine[0], support_tile=fine[1],
-                                name='fft*zpad*apod*maps')
-        else:
-            Z = backend.ZpadFFT(oN, N, weights_of(lo, hi), box_lo=box_lo, layout=lay, support=table, name='fft*zpad*apod*maps')
-        trees.append(backend.KronI(hi - lo, G) * Z)
+            lay = layout if layout in (0, 1) else 1          # one coil (or an explicit per-coil layout): the per-coil kernels
+            G_pc = G_pc or gridding(False, real)
+            Z = backend.ZpadFFT(oN, N, weights_of(lo, hi), box_lo=box_lo, layout=lay, support=table if lay == 1 else None, name='fft*zpad*apod*maps')
+            tree = backend.KronI(real, G_pc) * Z
+        trees.append(tree)
     A = trees[0] if len(trees) == 1 else backend.VStack(trees, name='coil-chunks')
     A._name = name
-    A._support_fine = fine
+    A._support_fine = fine.get(il_widths[0]) if il_widths else None          # (the widest chunks' table: what most of the tree runs by)
+    A._support_fine_by_width = fine
     A._support_zw = tuple(int(v) for v in zw)
+    A._coil_chunks = chunks
     return A
 
 

@@ -226,16 +226,24 @@ class SpMatrix(Operator):
                 self._matrix_d._exwrite = False
             if getattr(self, '_grid_support', None) is not None:
                 self._matrix_d.set_grid_support(*self._grid_support)
-            if getattr(self, '_grid_support_fine', None) is not None and hasattr(self._matrix_d, 'set_grid_support_fine'):
-                self._matrix_d.set_grid_support_fine(*self._grid_support_fine)
+            # (the binned adjoint formats and the fine support tables come per panel width: a dict {columns: arguments} when the
+            # matrix serves coil chunks of several widths, indigo_amd.fused.assemble)
+            fine = getattr(self, '_grid_support_fine', None)
+            if fine is not None and hasattr(self._matrix_d, 'set_grid_support_fine'):
+                if isinstance(fine, dict):
+                    for w in sorted(fine):
+                        self._matrix_d.set_grid_support_fine(fine[w][0], fine[w][1], ncols=w)
+                else:
+                    self._matrix_d.set_grid_support_fine(*fine)
             if getattr(self, '_row_order', None) is not None:
                 self._matrix_d.set_row_order(self._row_order)
             if getattr(self, '_grid_interleaved', False):
                 self._matrix_d.set_grid_interleaved(True)
-            if getattr(self, '_grid_bricks', None) is not None:
-                self._matrix_d.set_grid_bricks(*self._grid_bricks)
-            if getattr(self, '_grid_slots', None) is not None and hasattr(self._matrix_d, 'set_grid_slots'):
-                self._matrix_d.set_grid_slots(*self._grid_slots)
+            for attr, setter in (('_grid_bricks', 'set_grid_bricks'), ('_grid_slots', 'set_grid_slots')):
+                args = getattr(self, attr, None)
+                if args is not None and hasattr(self._matrix_d, setter):
+                    for a in ([args[w] for w in sorted(args)] if isinstance(args, dict) else [args]):
+                        getattr(self._matrix_d, setter)(*a)
             dims = getattr(self, '_grid_dims', None) or getattr(self._matrix, '_grid_dims', None)
             if dims is not None and hasattr(self._matrix_d, 'set_grid_dims'):
                 self._matrix_d.set_grid_dims(*dims)          # (n0, nm, ns), n0 fastest: the grid the columns form
@@ -651,6 +659,42 @@ class VStack(CompositeOperator):
                 h = C.shape[0]
                 C.eval(y, _slice_rows(x, off, off + h), alpha=alpha, beta=beta if i == 0 else 1, forward=False, left=left)
                 off += h
+
+
+class HeadRows(CompositeOperator):
+    """The first `keep` rows of a child operator:  y = alpha * A[:keep, :] x + beta * y;  adjoint  y = alpha * A[:keep, :]^H x + beta * y.
+
+    What a chunk of coils padded with zero-weight coils evaluates through (indigo_amd.fused.assemble): the coil-interleaved
+    kernels take 2, 4 or 8 coils, a 3-coil chunk is a 4-coil one whose last map is zero -- its k-space rows come last
+    (KronI stacks the coils, reference operators.py:374-375), are exactly zero in the forward product and must read as zero
+    in the adjoint one.  One panel of the child's height from the scratch arena, one copy in each direction."""
+
+    def __init__(self, backend, child, keep, **kwargs):
+        super().__init__(backend, child, **kwargs)
+        self._keep = int(keep)
+        assert 0 < self._keep <= child.shape[0]
+
+    @property
+    def shape(self):
+        return self._keep, self.child.shape[1]
+
+    def _mem_usage(self, ncols):
+        return self.child.shape[0] * ncols * 8
+
+    def _eval(self, y, x, alpha=1, beta=0, forward=True, left=True):
+        B, A = self._backend, self.child
+        ncols = x.shape[1]
+        with B.scratch(shape=(A.shape[0], ncols)) as tmp:
+            if forward:
+                A.eval(tmp, x, alpha=alpha, beta=0, forward=True, left=left)
+                for j in range(ncols):
+                    B.axpby(beta, y[:, j:j + 1] if ncols > 1 else y, 1, tmp[:self._keep, j:j + 1] if ncols > 1 else tmp[:self._keep])
+            else:
+                for j in range(ncols):
+                    tj = tmp[:, j:j + 1] if ncols > 1 else tmp
+                    tj[self._keep:]._zero()
+                    B.axpby(0, tj[:self._keep], 1, x[:, j:j + 1] if ncols > 1 else x)
+                A.eval(y, tmp, alpha=alpha, beta=beta, forward=False, left=left)
 
 
 class HStack(CompositeOperator):

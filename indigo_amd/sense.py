@@ -271,7 +271,8 @@ class SenseProblem(object):
         and stays the size the kernels were tuned on (indigo_amd.fused.assemble)."""
         coils = list(range(self.C) if coils is None else coils)
         Cn = len(coils)
-        layout, chunks = fused.choose_layout(Cn, chunk, layout)
+        single_ok = getattr(backend, 'supports_single_coil_layout', lambda g: True)(self.oN)
+        layout, chunks = fused.choose_layout(Cn, chunk, layout, single_ok)
         Gm = self.fused_interp(1 if layout == 2 else layout)      # layout 2 = layout 1 with the coils interleaved below
         table = None
         zw = fused.support_words(backend, self.oN)      # words per entry of the table's bitmaps: follows from the z pass's kernel
@@ -282,7 +283,8 @@ class SenseProblem(object):
         self.last_support_table = table
         self.last_support_zw = zw
         order = self.locality_order(Gm) if reorder and Cn <= 8 else None
-        A = fused.assemble(backend, Gm, self.oN, self.N, lambda lo, hi: self.fused_weights(coils[lo:hi], interleaved=(layout == 2)), Cn,
+        widths = {lo: w for lo, _, w in chunks}
+        A = fused.assemble(backend, Gm, self.oN, self.N, lambda lo, hi: self.fused_weights(coils[lo:hi], interleaved=(widths.get(lo, 0) > 1)), Cn,
                            layout, chunks, table=table, row_order=order, zw=zw)
         self.last_support_fine = getattr(A, '_support_fine', None)       # (table, tile) when the tree took a finer table
         return A

@@ -16,7 +16,7 @@ import logging
 import numpy as np
 import scipy.sparse as spp
 
-from indigo_amd.operators import (Adjoint, BlockDiag, CompositeOperator, Eye, HStack, Kron, One,
+from indigo_amd.operators import (Adjoint, BlockDiag, CompositeOperator, Eye, HeadRows, HStack, Kron, One,  # noqa: F401
                                   Product, Scale, SpMatrix, UnscaledFFT, VStack)
 
 log = logging.getLogger(__name__)
@@ -275,7 +275,7 @@ class FuseZpadFFT(Transform):
             log.warning("FuseZpadFFT: %s is not a zero-pad * diagonal factor; the tree keeps the unfused -O3 leaves (S' csrmm + dense FFT)", X._name)
             return node
         lo, box, w = dec
-        layout, chunks = fused.choose_layout(C, self.chunk)
+        layout, chunks = fused.choose_layout(C, self.chunk, None, getattr(b, 'supports_single_coil_layout', lambda g: True)(grid))
         Gm = L.right._matrix.astype(np.complex64).tocsr()
         if layout >= 1:
             Gm = fused.permute_grid_columns(Gm, grid)

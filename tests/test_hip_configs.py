@@ -501,3 +501,59 @@ def test_sense_on_the_reference_drivers_grid_vs_oracle(hip, oracle_backend, C):
     hip._scratch = None
     oracle_backend._scratch = None
     p.drop_cache()
+
+
+def _chunk_trees(A):
+    from indigo_amd import operators as op
+    out = []
+    for ch in (A.children if isinstance(A, op.VStack) else [A]):
+        out.append(ch.child if isinstance(ch, op.HeadRows) else ch)
+    return out
+
+
+@pytest.mark.parametrize("C", [3, 6, 9, 12])
+@pytest.mark.parametrize("image,osf", [((128, 128, 128), 2.0), ((256, 256, 256), 1.25)])
+def test_every_coil_count_takes_the_fast_routes(hip, oracle_backend, C, image, osf):
+    """A KronI takes any coil count (reference backend.py:311-314, operators.py:374-375; examples/pics.py:93).  The coil-interleaved
+    kernels take 2, 4 or 8: other counts are cut into chunks of those widths that share ONE device gridding matrix carrying a binned
+    adjoint format and a fine support table per width present, the last chunk padded with zero-weight coils where needed
+    (indigo_amd.fused.plan_chunks: 3 -> 4 wide; 6 -> 4 + 2; 9 -> 8 + 1 on a power-of-two grid, 8 + 2 wide elsewhere; 12 -> 8 + 4).
+    Forward / adjoint (/ normal operator on the small grid) against the per-coil numpy oracle on a 256^3 grid (power-of-two
+    passes) and on a 320^3 grid (A x B passes), and: every chunk runs the fused leaf, a scatter format of its own width and --
+    8 and 4 wide -- its fine table."""
+    from indigo_amd import operators as op
+    p = SenseProblem.synthetic(image, C, nspokes=300, nreadout=2 * image[0] if osf == 2.0 else 320, width=2, ntable=128, oversamp=osf, seed=7)
+    pow2 = p.oN == (256, 256, 256)
+    assert pow2 or p.oN == (320, 320, 320)
+    hip._scratch = None
+    oracle_backend._scratch = None
+    A = p.build_zpadfft(hip)
+    widths = [w for _, _, w in A._coil_chunks]
+    assert widths == {3: [4], 6: [4, 2], 9: [8, 1] if pow2 else [8, 2], 12: [8, 4]}[C]
+    assert A.shape == (C * p.T, int(np.prod(image)))
+    G_il = None
+    for tree, w in zip(_chunk_trees(A), widths):
+        Z, G = tree.right, tree.left.right
+        assert isinstance(Z, op.ZpadFFT) and Z._C == w and Z._layout == (2 if w > 1 else 1)
+        M = G._get_or_create_device_matrix()
+        if w > 1:
+            assert G_il is None or G is G_il, "the interleaved chunks share one gridding matrix"
+            G_il = G
+            assert M._format('_bricks' if w in (4, 8) else '_slots', w, exact=True) is not None
+            if w in (4, 8):
+                assert M._format('_support_fine', w)[1] == (4 if w == 8 else 8) and Z._tile_kw == {'support_tile': 4 if w == 8 else 8}
+        else:
+            assert M._format('_slots', 1, exact=True) is not None
+    x = rand64c(A.shape[1], 1, seed=1)
+    k = rand64c(A.shape[0], 1, seed=2)
+    A_o = p.build_zpadfft(oracle_backend, layout=0, support=False)
+    assert rel_err(A * x, A_o * x) < RTOL
+    assert rel_err(A.H * k, A_o.H * k) < RTOL
+    if pow2:
+        y_d = hip.zero_array((A.shape[1], 1), C64)
+        normal_operator(A, lamda=0.2).eval(y_d, hip.copy_array(x))
+        exp = A_o.H * (A_o * x) + np.float32(0.2) * x
+        assert rel_err(y_d.to_host(), exp) < RTOL
+    hip._scratch = None
+    oracle_backend._scratch = None
+    p.drop_cache()

@@ -195,7 +195,11 @@ def test_fuse_zpadfft_transform_on_the_reference_recipe(prob, oracle_backend):
     B._scratch = None
     # the same leaves as the direct builder
     Ad = p.build_zpadfft(B)
-    assert type(Ad.right).__name__ == type(A.right).__name__ == "ZpadFFT"
+    # (three coils: one 4-wide interleaved chunk whose last coil has zero weights, its k-space rows cut off by HeadRows)
+    assert isinstance(A, op.HeadRows) and isinstance(Ad, op.HeadRows) and A.shape == Ad.shape == (3 * p.T, int(np.prod(p.N)))
+    A, Ad = A.child, Ad.child
+    assert type(Ad.right).__name__ == type(A.right).__name__ == "ZpadFFT" and A.right._C == 4
+    assert not np.any(A.right._weights().to_host().reshape(-1, 4)[:, 3])
     assert Ad.right._lo == A.right._lo and Ad.right._box == A.right._box and Ad.right._layout == A.right._layout
     np.testing.assert_allclose(A.right._weights().to_host(), Ad.right._weights().to_host(), rtol=2e-6, atol=1e-9)
     Ga, Gd = A.left.right._matrix.tocsr(), Ad.left.right._matrix.tocsr()
@@ -229,7 +233,8 @@ def test_fuse_zpadfft_with_masked_maps(prob, oracle_backend):
     assert St.nnz < int(np.prod(p.N)) * C              # entries really are missing
     Af = FuseZpadFFT().visit(q.build_tree(B, level=3))
     assert Af.has(op.ZpadFFT) and not Af.has(op.UnscaledFFT)
-    assert Af.right._box == p.N
+    core = Af.child if isinstance(Af, op.HeadRows) else Af      # (C = 3: a 4-wide chunk with a zero-weight coil)
+    assert core.right._box == p.N
     x, k = g["sense_x"], g["sense_k"]
     assert rel_err(Af * x, A3 * x) < 2e-6
     assert rel_err(Af.H * k, A3.H * k) < 2e-6
