@@ -152,7 +152,11 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=4, choices=[1, 2, 3, 4, 5])
-    ap.add_argument("--image", type=int, default=0, help="image edge (debug: smaller problems; default 256 / 320 for config 4 / 5)")
+    ap.add_argument("--image", default="", help="image edge, or X,Y,Z for a non-cubic image (config 4: e.g. 480,208,308 --osf 1.3333 is the "
+                    "reference driver's own scan on the 640 x 277 x 410 grid its sizing rule gives, backend.py:427-430); default 256 / 320 for config 4 / 5")
+    ap.add_argument("--spokes-scale", type=float, default=1.0, help="config 4: multiply the number of radial spokes (8: a densely sampled "
+                    "scan -- the k-space support table then flags most of the ball)")
+    ap.add_argument("--no-dense", action="store_true", help="default run at N = 1: skip the extra dense-trajectory measurement")
     ap.add_argument("--coils", type=int, default=0, help="coils (default 8 / 32 for config 4 / 5)")
     ap.add_argument("--osf", type=float, default=0.0, help="config 4: oversampling factor of the gridding (default 2.0; 1.25 puts the 256^3 "
                     "image on the 320^3 grid the reference's own driver would pick, examples/pics.py:87-90)")
@@ -172,11 +176,29 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="only the selected config: --no-config5 --no-leaf-configs (profiling runs)")
     args = ap.parse_args()
     if args.no_extras:
-        args.no_config5 = args.no_leaf_configs = True
+        args.no_config5 = args.no_leaf_configs = args.no_dense = True
+    dims = [int(v) for v in str(args.image).split(",") if v.strip()] if args.image else []
+    assert len(dims) in (0, 1, 3), "--image N or --image X,Y,Z"
+    args.image_dims = tuple(dims) if len(dims) == 3 else None          # non-cubic image (config 4 only)
+    args.image = dims[0] if len(dims) == 1 else 0
+    # the standard problem of the selected config: what the committed PMC summaries and the headline's name describe
+    args.standard = not (args.image or args.image_dims or args.coils or args.osf or args.spokes_scale != 1.0) and args.tree == "zpadfft"
     return args
 
 
 RANK = int(os.environ.get("RANK", "0"))
+# fd 1 carries rank 0's ONE JSON line and nothing else -- under torchrun too, where all ranks share the launcher's stdout and
+# libraries print there (gloo announces its connections on stdout): everything else this process or its libraries write to
+# stdout goes to stderr (claim_stdout, called by main before any library is loaded)
+REAL_STDOUT = sys.stdout
+
+
+def claim_stdout():
+    global REAL_STDOUT
+    sys.stdout.flush()
+    REAL_STDOUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    sys.stdout = sys.stderr
 
 
 def log(*a):
@@ -222,13 +244,35 @@ def tree_support(A):
     return None, 16
 
 
-def check_fractions(obj, where="roofline"):
-    """a fraction of the HBM peak above 1 is a pricing bug (bytes the kernel never moved), never a result: refuse to print it"""
+def fused_leaves(A):
+    """the ZpadFFT leaves of a fused tree in evaluation order (one per coil chunk): [dict(width, layout, table, tile)] -- read off the
+    tree, so that trees built by the reference's recipe + FuseZpadFFT are priced by the tables THEY carry"""
+    from indigo_amd.operators import ZpadFFT
+    out = []
+
+    def walk(node):
+        if isinstance(node, ZpadFFT):
+            out.append(dict(width=node._C, layout=node._layout, table=node._support_h,
+                            tile=int(node._tile_kw.get('support_tile', 16)) if node._support_h is not None else 16))
+        for c in (getattr(node, '_children', None) or []):
+            walk(c)
+    walk(A)
+    return out
+
+
+def check_fractions(obj, where="line", errors=None):
+    """A fraction of the HBM peak above 1 is a pricing bug (bytes the kernel never moved) or a problem served from the caches, never
+    a roofline result: the field is set to null and named in the returned list -- the rest of the line, the measured headline
+    included, is still printed (the caller adds the list as `pricing_error` and exits non-zero after printing)."""
+    errors = [] if errors is None else errors
     if isinstance(obj, dict):
-        for k, v in obj.items():
+        for k, v in list(obj.items()):
             if isinstance(v, (int, float)) and not isinstance(v, bool) and (k == "frac" or k.endswith("_frac") or k.endswith("frac_of_peak")) and v > 1.0:
-                raise AssertionError("%s.%s = %.3f > 1.0: the byte model prices traffic the kernels do not move" % (where, k, v))
-            check_fractions(v, where + "." + str(k))
+                errors.append("%s.%s = %.3f > 1.0: the byte model prices traffic the kernels do not move (or the problem fits the caches)" % (where, k, v))
+                obj[k] = None
+            else:
+                check_fractions(v, where + "." + str(k), errors)
+    return errors
 
 
 def roofline_of(prof, symbols, cfg, pick=None, traffic_ok=True):
@@ -324,13 +368,15 @@ def make_comm(args, B, world, rank, local_rank):
 # ---------------------------------------------------------------------------------------------------------
 # configs 4 and 5: SENSE A^H A
 # ---------------------------------------------------------------------------------------------------------
-def sense_problem(cfg, img, C, osf=0.0):
+def sense_problem(cfg, img, C, osf=0.0, dims=None, spokes_scale=1.0):
     from indigo_amd.sense import SenseProblem
     if cfg == 4:
         osf = osf or 2.0
-        nreadout = int(img * osf)                            # samples per spoke = oversampled grid edge
-        nspokes = int(round(3617 * (img / 256.0) ** 2))      # 3617 spokes at 256^3 -> T = 1,851,904 at oversampling 2
-        return SenseProblem.synthetic((img,) * 3, C, nspokes=nspokes, nreadout=nreadout, width=2, ntable=128,
+        N = tuple(dims) if dims else (img,) * 3
+        nreadout = int(N[0] * osf)                           # samples per spoke = oversampled grid edge along the readout
+        # 3617 spokes at 256^3 -> T = 1,851,904 at oversampling 2; scaled with the area of the (y, z) face for other images
+        nspokes = int(round(3617 * (N[1] * N[2]) / 256.0 ** 2 * spokes_scale))
+        return SenseProblem.synthetic(N, C, nspokes=nspokes, nreadout=nreadout, width=2, ntable=128,
                                       oversamp=osf, seed=4)
     # config 5: 320^3 in 512^3 (oversampling 1.6), maps generated per coil so that a rank only materialises its own
     grid = int(img * 1.6)
@@ -339,7 +385,7 @@ def sense_problem(cfg, img, C, osf=0.0):
                                   oversamp=1.6, seed=5, lazy_maps=True)
 
 
-def run_sense(args, cfg, B, comm, world, rank, steps, warmup, want_cpu, quiet=False):
+def run_sense(args, cfg, B, comm, world, rank, steps, warmup, want_cpu, quiet=False, want_parity=False):
     import numpy as np
     from indigo_amd.dist import ShardedNormalOperator, coil_range
     from indigo_amd.sense import normal_operator
@@ -349,7 +395,9 @@ def run_sense(args, cfg, B, comm, world, rank, steps, warmup, want_cpu, quiet=Fa
     t_setup = time.time()
     img = args.image or (256 if cfg == 4 else 320)
     C = args.coils or (8 if cfg == 4 else 32)
-    p = sense_problem(cfg, img, C, args.osf if cfg == 4 else 0.0)
+    dims = getattr(args, 'image_dims', None) if cfg == 4 else None
+    scale = float(getattr(args, 'spokes_scale', 1.0)) if cfg == 4 else 1.0
+    p = sense_problem(cfg, img, C, args.osf if cfg == 4 else 0.0, dims, scale)
     shard = None
     if args.shard:
         r, w = (int(v) for v in args.shard.split("/"))
@@ -357,11 +405,11 @@ def run_sense(args, cfg, B, comm, world, rank, steps, warmup, want_cpu, quiet=Fa
         coils = list(coil_range(C, r, w))
     else:
         coils = list(coil_range(C, rank, world))
-    log("config %d: image %d^3, %d coils (%d here%s), grid %s, T=%d (%.1fs)" % (
-        cfg, img, C, len(coils), " = shard %d/%d" % shard if shard else "", p.oN, p.T, time.time() - t_setup))
+    log("config %d: image %s, %d coils (%d here%s), grid %s, T=%d (%.1fs)" % (
+        cfg, "x".join(str(n) for n in p.N), C, len(coils), " = shard %d/%d" % shard if shard else "", p.oN, p.T, time.time() - t_setup))
     tree = args.tree if cfg == 4 else "zpadfft"
     fused_fft = tree in ("zpadfft", "recipe") and B.supports_padded_fft(p.oN, len(coils))
-    layout = args.layout if args.layout >= 0 else (2 if (len(coils) in (2, 4, 8) or len(coils) > 8) else 1)
+    layout = args.layout if args.layout >= 0 else None          # None: indigo_amd.fused.choose_layout cuts the coils into interleaved chunks
     if tree == "recipe":
         from indigo_amd.transforms import FuseZpadFFT, sense_recipe
         A = p.build_tree(B, level=0, coils=coils)
@@ -370,6 +418,7 @@ def run_sense(args, cfg, B, comm, world, rank, steps, warmup, want_cpu, quiet=Fa
         layout = FuseZpadFFT.layout_of(A)
     elif fused_fft:
         A = p.build_zpadfft(B, coils=coils, layout=layout)
+        layout = max([lf['layout'] for lf in fused_leaves(A)] or [0])
     else:
         A = p.build_fused(B, coils=coils)
         layout = 0
@@ -403,32 +452,54 @@ def run_sense(args, cfg, B, comm, world, rank, steps, warmup, want_cpu, quiet=Fa
     ms_per_step = elapsed / steps * 1e3
     value = steps / elapsed
 
-    # ---- per call site: compulsory bytes (ours) and reference-model bytes (the leaf it replaces)
-    cpr = len(coils) if nchunks == 1 else 8          # coils per chunk seen by one launch
+    # ---- per call site: compulsory bytes (ours) and reference-model bytes (the leaf it replaces).  A tree of several coil chunks
+    # launches every call site once per chunk; chunks may differ in width (12 coils: 8 + 4) and then in support table too, so the
+    # bytes are summed chunk by chunk, each priced by the table and tile ITS leaf carries.
     half_box = all(2 * b == n for b, n in zip(p.N, p.oN))
-    sup_tab, sup_tile = tree_support(A) if fused_fft else (None, 16)
+    leaves_z = fused_leaves(A) if fused_fft else []
+    cpr = max([lf['width'] for lf in leaves_z] or [len(coils)])          # widest chunk: names the kernel symbols
+    sup_tab, sup_tile = (leaves_z[0]['table'], leaves_z[0]['tile']) if leaves_z else (None, 16)
     p.last_support_zw = getattr(A, '_support_zw', None) or getattr(p, 'last_support_zw', (16, 16))     # (recipe trees carry their own)
+    real_entries = tree_real_entries(A)
+    recs = {True: [r['nbytes'] for r in trace.records if r['event'] == 'csrmm' and not r.get('fused') and r['name'] == 'interp*mod*scale' and r['forward']],
+            False: [r['nbytes'] for r in trace.records if r['event'] == 'csrmm' and not r.get('fused') and r['name'] == 'interp*mod*scale' and not r['forward']]}
+    acc = {}
+
+    def add(site, nbytes, ref):
+        if site in prof:
+            a = acc.setdefault(site, [0.0, 0.0])
+            a[0] += float(nbytes)
+            a[1] += float(ref)
     if fused_fft:
-        exact = p.zpadfft_pass_bytes(cpr, sup_tab, fused_sum=(layout == 2), tile=sup_tile)
-        for name, nbytes in exact.items():
-            if name in prof:
-                prof[name]['bytes'] = float(nbytes) * prof[name]['launches']
+        for ci, lf in enumerate(leaves_z):
+            w = lf['width']
+            for name, nbytes in p.zpadfft_pass_bytes(w, lf['table'], fused_sum=(lf['layout'] == 2), tile=lf['tile']).items():
                 # 4 * x.nbytes per 3-D transform, a third per pass; x = grid x coils
-                prof[name]['ref_bytes'] = 4.0 * np.prod(p.oN) * 8.0 * cpr / 3.0 * prof[name]['launches']
-    csr = {(r['name'], r['forward']): r['nbytes'] for r in trace.records if r['event'] == 'csrmm' and not r.get('fused')}
-    grid_bytes = p.gridding_pass_bytes(cpr, sup_tab, tile=sup_tile, real_entries=tree_real_entries(A)) if fused_fft else {}
-    for site, fwd in (("csrmm_gather", True), ("csrmm_rowlane_conj", False), ("csrmm_gather_conj", False), ("csrmm_bricks_conj", False),
-                      ("csrmm_slots_conj", False)):
-        nb = csr.get(('interp*mod*scale', fwd))
-        if site in prof and nb:
+                add(name, nbytes, 4.0 * np.prod(p.oN) * 8.0 * w / 3.0)
+            gb = p.gridding_pass_bytes(w, lf['table'], tile=lf['tile'], real_entries=real_entries)
             # SpMM GB/s two ways: the reference's model (operators.py:246-256) and the bytes this kernel must move
-            prof[site]['ref_bytes'] = float(nb) * prof[site]['launches']          # one launch per coil chunk, nb is per chunk
-            prof[site]['bytes'] = float(grid_bytes.get(site, nb)) * prof[site]['launches']
-    if "pack_panel" in prof and "pack_panel" in grid_bytes:
-        prof["pack_panel"]['bytes'] = float(grid_bytes["pack_panel"]) * prof["pack_panel"]['launches']
-    symbols = kernel_symbols(layout if fused_fft else 0, cpr, half_box, p.oN[0], sup_tile if fused_fft else 16, tree_real_entries(A))
-    standard = not args.image and not args.coils and not (args.osf if cfg == 4 else 0) and tree == "zpadfft"
-    roofline, kernels = roofline_of(prof, symbols, cfg, traffic_ok=(standard and cpr == 8))
+            add("csrmm_gather", gb["csrmm_gather"], recs[True][ci] if ci < len(recs[True]) else 0.0)
+            adj_ref = recs[False][ci] if ci < len(recs[False]) else 0.0
+            for site in (("csrmm_bricks_conj",) if w >= 4 else ("csrmm_slots_conj",)) + ("csrmm_rowlane_conj", "csrmm_gather_conj"):
+                if site in prof:
+                    add(site, gb.get(site, gb["csrmm_rowlane_conj"]), adj_ref)
+                    break
+            add("pack_panel", gb["pack_panel"], 0.0)
+    else:
+        for fwd, sites in ((True, ("csrmm_gather",)), (False, ("csrmm_rowlane_conj", "csrmm_gather_conj", "csrmm_bricks_conj", "csrmm_slots_conj"))):
+            for nb in recs[fwd]:
+                for site in sites:
+                    if site in prof:
+                        add(site, nb, nb)
+                        break
+    for site, (nb, ref) in acc.items():          # (sums over the chunks of ONE evaluation; the profile covers `steps` of them)
+        prof[site]['bytes'] = nb * steps
+        if ref:
+            prof[site]['ref_bytes'] = ref * steps
+    symbols = kernel_symbols(layout if fused_fft else 0, cpr, half_box, p.oN[0], sup_tile if fused_fft else 16, real_entries)
+    standard = args.standard or (cfg == 5 and not args.image and not args.coils)
+    uniform8 = bool(leaves_z) and all(lf['width'] == 8 for lf in leaves_z)
+    roofline, kernels = roofline_of(prof, symbols, cfg, traffic_ok=(standard and uniform8))
     if not quiet:
         for k in sorted(prof, key=lambda k: -prof[k]['total_ms']):
             log("  %-24s %4d launches  avg %8.3f ms  total %9.2f ms  %s" % (
@@ -452,12 +523,15 @@ def run_sense(args, cfg, B, comm, world, rank, steps, warmup, want_cpu, quiet=Fa
 
     out = {
         "ms_per_step": ms_per_step, "value": value, "setup_s": round(setup_s, 2),
-        "config": {"workload": "non-Cartesian SENSE A^H A, image %d^3, %d coils, grid %d^3 (osf %.2g), radial T=%d, KB width 4; "
-                               "-O3 tree S'->FFT->G'->G'^H->IFFT->S'^H%s" % (img, C, p.oN[0], p.oversamp, p.T,
-                                                                             " (BASELINE config %d)" % cfg),
+        "config": {"workload": "non-Cartesian SENSE A^H A, image %s, %d coils, grid %s (osf %.4g), radial T=%d, KB width 4; "
+                               "-O3 tree S'->FFT->G'->G'^H->IFFT->S'^H%s" % (
+                                   ("%d^3" % p.N[0]) if len(set(p.N)) == 1 else "x".join(str(n) for n in p.N), C,
+                                   ("%d^3" % p.oN[0]) if len(set(p.oN)) == 1 else "x".join(str(n) for n in p.oN), p.oversamp, p.T,
+                                   " (BASELINE config %d)" % cfg),
                    "parallelism": ("coil-sharded x%d (%d coils per rank), one all-reduce of the image per eval" % (world, len(coils))
                                    if world > 1 else ("rank %d of %d alone (no communication)" % shard if shard else "single GPU")),
                    "grid_layout": layout, "tree": tree, "coil_chunks_per_rank": nchunks,
+                   "coil_chunk_widths": [lf['width'] for lf in leaves_z] or None, "spokes_scale": scale,
                    "support_table_kx_points_per_entry": (sup_tile if sup_tab is not None else None)},
         "roofline": roofline,
         "eval_traffic_GB": traffic_bytes / 1e9,
@@ -477,6 +551,13 @@ def run_sense(args, cfg, B, comm, world, rank, steps, warmup, want_cpu, quiet=Fa
         cpu, parity = cpu_baseline_and_parity(p, C, B, layout if fused_fft else None, y)
         out["cpu_baseline"] = cpu
         out["parity_rel_err"] = parity
+    elif want_parity and fused_fft:
+        out["parity_rel_err"] = parity_vs_float64(p, C, B, layout, y, rand64c(Nvox, 1, seed=1))
+    if fused_fft and leaves_z and leaves_z[0]['table'] is not None:
+        # what the k-space support tables flag: the fraction of the grid's rows every z pass and both gridding products touch
+        lf = leaves_z[0]
+        _, _, bits = p.split_support(lf['table'], lf['tile'])
+        out["config"]["support_flagged_frac"] = float(np.unpackbits(bits.view(np.uint8)).sum()) * lf['tile'] / float(np.prod(p.oN))
     del AHA, A, x, y
     B._scratch = None
     p.drop_cache()
@@ -508,30 +589,39 @@ def cpu_baseline_and_parity(p, C, B, layout, y_dev):
     cpu = dict(value=1.0 / (C * t), unit="evals/s", cores=1, kind="port", **host_info(),
                sample="numpy oracle (restatement of indigo/backends/np.py: np.fft.fftn + scipy csr @), 1 of %d coils of the same problem, "
                       "1 warm-up + min of 5 evaluations (%.1f s each), scaled linearly in coils" % (C, t))
-    parity = None
-    if layout is not None:
-        zero = np.zeros(p.N, dtype=np.complex64, order='F')
-        q = SenseProblem(p.N, p.coord, lambda c: p.coil_map(c) if c == 0 else zero, width=p.width, ntable=p.ntable,
-                         oversamp=p.oversamp, ncoils=min(C, 8))
-        q._interp_cache = p._interp_cache
-        B._scratch = None
-        A0 = q.build_zpadfft(B, layout=layout)
-        AHA0 = normal_operator(A0)
-        AHA0.eval(y_dev, B.copy_array(xh))
-        got = y_dev.to_host()
-        # the complex64 oracle's own error on this DC-heavy input is ~2.6e-5 (oracle/precise.py): the double-precision
-        # evaluation of the same operator is the arbiter, the distance to the complex64 oracle is reported beside it
-        from oracle.precise import CoilOperatorF64
-        exact = CoilOperatorF64(p, 0).normal(xh).reshape(-1, 1)
-        nrm = np.linalg.norm(exact)
-        parity = dict(vs_float64_evaluation=float(np.linalg.norm(got - exact) / nrm),
-                      vs_complex64_oracle=float(np.linalg.norm(got - ref) / np.linalg.norm(ref)),
-                      complex64_oracle_own_error=float(np.linalg.norm(ref - exact) / nrm), tolerance=1e-5)
-        log("parity: benchmarked operator (coils 1.. switched off) vs float64 evaluation %.3e; vs the complex64 oracle %.3e "
-            "(the oracle's own error: %.3e)" % (parity["vs_float64_evaluation"], parity["vs_complex64_oracle"], parity["complex64_oracle_own_error"]))
-        del A0, AHA0
-        B._scratch = None
+    parity = parity_vs_float64(p, C, B, layout, y_dev, xh, ref) if layout is not None else None
     return cpu, parity
+
+
+def parity_vs_float64(p, C, B, layout, y_dev, xh, ref_c64=None):
+    """the benchmarked operator (same tree, same kernels) with every coil but the first switched off, against the
+    double-precision evaluation of that one-coil operator (oracle/precise.py) -- and, where given, the complex64 oracle's result"""
+    import numpy as np
+    from indigo_amd.sense import SenseProblem, normal_operator
+    zero = np.zeros(p.N, dtype=np.complex64, order='F')
+    q = SenseProblem(p.N, p.coord, lambda c: p.coil_map(c) if c == 0 else zero, width=p.width, ntable=p.ntable,
+                     oversamp=p.oversamp, ncoils=min(C, 8))
+    q._interp_cache = p._interp_cache
+    B._scratch = None
+    A0 = q.build_zpadfft(B, layout=layout)
+    AHA0 = normal_operator(A0)
+    AHA0.eval(y_dev, B.copy_array(xh))
+    got = y_dev.to_host()
+    # the complex64 oracle's own error on this DC-heavy input is ~2.6e-5 (oracle/precise.py): the double-precision
+    # evaluation of the same operator is the arbiter, the distance to the complex64 oracle is reported beside it
+    from oracle.precise import CoilOperatorF64
+    exact = CoilOperatorF64(p, 0).normal(xh).reshape(-1, 1)
+    nrm = np.linalg.norm(exact)
+    parity = dict(vs_float64_evaluation=float(np.linalg.norm(got - exact) / nrm), tolerance=1e-5)
+    if ref_c64 is not None:
+        parity.update(vs_complex64_oracle=float(np.linalg.norm(got - ref_c64) / np.linalg.norm(ref_c64)),
+                      complex64_oracle_own_error=float(np.linalg.norm(ref_c64 - exact) / nrm))
+    log("parity: benchmarked operator (coils 1.. switched off) vs float64 evaluation %.3e%s" % (
+        parity["vs_float64_evaluation"], ("; vs the complex64 oracle %.3e (the oracle's own error: %.3e)" % (
+            parity["vs_complex64_oracle"], parity["complex64_oracle_own_error"])) if ref_c64 is not None else ""))
+    del A0, AHA0
+    B._scratch = None
+    return parity
 
 
 def bench_sense(args, world, rank, local_rank):
@@ -543,37 +633,52 @@ def bench_sense(args, world, rank, local_rank):
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and not args.shard and cfg == 4
     res = run_sense(args, cfg, B, comm, world, rank, args.steps, args.warmup, want_cpu)
 
+    import threading
+    emit_lock = threading.Lock()
+    emitted = []
+
     def emit(extra5, leaves):
-        name = ("SENSE AHA evals/sec (256^3 x 8-coil non-Cartesian)" if cfg == 4 and not args.image and not args.coils and not args.osf
-                else "SENSE AHA evals/sec (%s)" % res["config"]["workload"].split(",", 1)[1].split(";")[0].strip())
-        out = {"metric": name, "value": res["value"], "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-               "dtype": "complex64 (f32)", "data": "synthetic"}
-        out.update({k: v for k, v in res.items() if k not in ("value", "ms_per_step")})
-        out.setdefault("cpu_baseline", None)
-        if extra5 is not None:
-            out["config5"] = extra5
-        out.update(leaves)
-        check_fractions({k: v for k, v in out.items() if k not in ("reference_model_equiv",)}, "line")
-        print(json.dumps(out), flush=True)
+        """prints the ONE line (at most once: the main thread and the give-up timer may both get here); returns the pricing errors"""
+        with emit_lock:
+            if emitted:
+                return []
+            emitted.append(True)
+            name = ("SENSE AHA evals/sec (256^3 x 8-coil non-Cartesian)" if cfg == 4 and args.standard
+                    else "SENSE AHA evals/sec (%s)" % res["config"]["workload"].split(",", 1)[1].split(";")[0].strip())
+            out = {"metric": name, "value": res["value"], "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                   "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                   "dtype": "complex64 (f32)", "data": "synthetic"}
+            out.update({k: v for k, v in res.items() if k not in ("value", "ms_per_step")})
+            out.setdefault("cpu_baseline", None)
+            if extra5 is not None:
+                out["config5"] = extra5
+            out.update(leaves)
+            errs = check_fractions({k: v for k, v in out.items() if k not in ("reference_model_equiv",)}, "line")
+            if errs:
+                out["pricing_error"] = errs
+            print(json.dumps(out), file=REAL_STDOUT, flush=True)
+            return errs
 
     extra5 = None
-    if cfg == 4 and not args.no_config5 and not args.shard and not args.image and not args.coils and not args.osf and args.tree == "zpadfft":
+    if cfg == 4 and not args.no_config5 and not args.shard and args.standard:
         # Multi-rank runs: the extra is a second distributed job.  If ONE rank fails in it alone, the others wait for it inside a
         # collective -- the headline, already measured, must not go down with that: after a limit every rank gives up, rank 0
         # prints the line with the extra marked as failed, and the processes leave without the clean-up a hung collective would block.
-        import threading
         finished = threading.Event()
         limit = int(os.environ.get("INDIGO_BENCH_EXTRA_LIMIT", "300") or 0)
 
         def give_up():
             if finished.is_set():
                 return
-            print("[bench] rank %d: the config-5 extra did not finish within %d s" % (rank, limit), file=sys.stderr, flush=True)
-            if rank == 0:
-                emit({"error": "the config-5 extra did not finish within %d s on every rank" % limit}, {})
-            sys.stderr.flush()
-            os._exit(0)
+            try:
+                print("[bench] rank %d: the config-5 extra did not finish within %d s" % (rank, limit), file=sys.stderr, flush=True)
+                if rank == 0:
+                    emit({"error": "the config-5 extra did not finish within %d s on every rank" % limit}, {})
+                sys.stderr.flush()
+            finally:
+                # the headline line is out (rank 0); the run as a whole FAILED -- some rank hung in the extra's collective: every
+                # rank leaves non-zero, the launcher keeps rank 0's line (self_launch relays it whatever the exit status)
+                os._exit(3)
         timer = None
         if world > 1 and limit > 0:
             timer = threading.Timer(limit, give_up)
@@ -592,8 +697,7 @@ def bench_sense(args, world, rank, local_rank):
             if timer is not None:
                 timer.cancel()
     leaves = {}
-    if rank == 0 and world == 1 and cfg == 4 and not args.no_leaf_configs and not args.shard and not args.image and not args.coils and not args.osf \
-            and args.tree == "zpadfft":
+    if rank == 0 and world == 1 and cfg == 4 and not args.no_leaf_configs and not args.shard and args.standard:
         # the other half of BASELINE.json's metric ("SpMM HBM GB/s vs peak") and the plain FFT contract, in the same driver-run
         # line: BASELINE configs 2 and 3 with their own roofline / cpu_baseline / parity objects (`--config 2|3` alone prints
         # the same objects as full lines)
@@ -609,10 +713,31 @@ def bench_sense(args, world, rank, local_rank):
             except Exception as e:             # noqa: BLE001 -- an extra must not cost the headline its line
                 leaves["config%d" % c] = {"error": "%s: %s" % (type(e).__name__, e)}
                 print("[bench] config-%d extra failed: %s" % (c, leaves["config%d" % c]["error"]), file=sys.stderr, flush=True)
-    if rank == 0:
-        emit(extra5, leaves)
+    if rank == 0 and world == 1 and cfg == 4 and not args.no_dense and not args.shard and args.standard:
+        # What a densely sampled scan costs: the same image, coils and grid with 8 x the spokes.  The headline's radial trajectory
+        # touches 11 % of the grid's points and its support table flags 16 % of the rows -- every z pass and both gridding products
+        # profit; here the table flags most of the k-space ball.  Same kernels, same pricing, parity against the float64 evaluation.
+        import copy
+        a2 = copy.copy(args)
+        a2.spokes_scale, a2.standard = 8.0, False
+        try:
+            B._scratch = None
+            r = run_sense(a2, 4, B, None, 1, 0, max(3, min(args.steps, 5)), min(args.warmup, 2), False, quiet=True, want_parity=True)
+            leaves["dense_trajectory"] = {"evals_per_s": r["value"], "ms_per_step": r["ms_per_step"], "setup_s": r["setup_s"], "config": r["config"],
+                                          "roofline": r["roofline"], "eval_compulsory_GB": r["eval_compulsory_GB"],
+                                          "eval_compulsory_frac": r["eval_compulsory_GB"] / (r["ms_per_step"] * 1e-3) / HBM_PEAK_GBS,
+                                          "parity_rel_err": r.get("parity_rel_err"), "kernels": r["kernels"],
+                                          "note": "the headline problem with 8 x the radial spokes (python bench.py --spokes-scale 8): bounds what a well-sampled scan costs"}
+        except Exception as e:             # noqa: BLE001 -- an extra must not cost the headline its line
+            leaves["dense_trajectory"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            print("[bench] dense-trajectory extra failed: %s" % leaves["dense_trajectory"]["error"], file=sys.stderr, flush=True)
+    errs = emit(extra5, leaves) if rank == 0 else []
     if comm is not None:
         comm.close()
+    if errs:
+        for e in errs:
+            print("[bench] pricing error:", e, file=sys.stderr, flush=True)
+        sys.exit(4)
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -922,6 +1047,7 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1 and not args.shard:
         assert args.config in (4, 5), "configs 1-3 are single-GPU leaf benchmarks"
         self_launch(args)
+    claim_stdout()
     rank = RANK
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -954,8 +1080,12 @@ def main():
     else:
         assert world == 1, "configs 1-3 are single-GPU leaf benchmarks"
         out = {1: bench_spmm_example, 2: bench_fft, 3: bench_spmm}[args.config](args, local_rank)
-        check_fractions(out, "line")
-        print(json.dumps(out), flush=True)
+        errs = check_fractions(out, "line")
+        if errs:
+            out["pricing_error"] = errs
+        print(json.dumps(out), file=REAL_STDOUT, flush=True)
+        if errs:
+            sys.exit(4)
 
 
 if __name__ == "__main__":

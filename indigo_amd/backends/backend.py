@@ -267,8 +267,8 @@ class Backend(object):
     # ---------------------------------------------------------------------------
     # operator factories
     # ---------------------------------------------------------------------------
-    def SpMatrix(self, M, **kwargs):
-        assert spp.issparse(M)
+    def SpMatrix(self, M=None, **kwargs):
+        assert (M is not None and spp.issparse(M)) or kwargs.get('struct') is not None
         return op.SpMatrix(self, M, **kwargs)
 
     def DenseMatrix(self, M, **kwargs):
@@ -281,6 +281,10 @@ class Backend(object):
         if v.ndim > 1:
             v = v.flatten(order='A')
         dtype = kwargs.pop('dtype', _C64)
+        if np.dtype(dtype) == _C64:
+            # (described as the diagonal it is: the scipy matrix is made when somebody asks for it, indigo_amd.structured)
+            from indigo_amd.structured import DiagS
+            return self.SpMatrix(struct=DiagS(v.size, [('vec', v.astype(_C64))]), **kwargs)
         return self.SpMatrix(spp.diags(v, offsets=0).astype(dtype), **kwargs)
 
     def Adjoint(self, A, **kwargs):
@@ -318,22 +322,34 @@ class Backend(object):
     def FFT(self, shape, dtype=_C64, **kwargs):
         """unitary FFT = diag(1/sqrt(n)) * UnscaledFFT"""
         n = int(np.prod(shape))
+        if np.dtype(dtype) == _C64:
+            from indigo_amd.structured import DiagS
+            c = (np.ones(1, dtype=dtype) / np.sqrt(n))[0]          # the value the reference's ones(n) / sqrt(n) holds n times
+            return self.SpMatrix(struct=DiagS(n, [('const', c)]), name='scale') * self.UnscaledFFT(shape, dtype, **kwargs)
         s = np.ones(n, order='F', dtype=dtype) / np.sqrt(n)
         return self.Diag(s, name='scale') * self.UnscaledFFT(shape, dtype, **kwargs)
 
     @staticmethod
+    def fftc_mod_phases(ft_shape):
+        """per-axis terms (idx_d - c_d/2) c_d / n_d of the modulation's phase (in turns)"""
+        return [(np.arange(n) - (n // 2) / 2.0) * ((n // 2) / n) for n in ft_shape]
+
+    @staticmethod
     def fftc_mod(ft_shape, dtype=_C64):
-        """Modulation vector of the centred FFT: exp(2 pi i sum_d (idx_d - c_d/2) c_d / n_d), c_d = n_d // 2."""
-        idx = np.mgrid[tuple(slice(d) for d in ft_shape)]
+        """Modulation vector of the centred FFT: exp(2 pi i sum_d (idx_d - c_d/2) c_d / n_d), c_d = n_d // 2.  (The phase as a
+        broadcast sum of per-axis terms, added in the reference's order: the same numbers without the index grids.)"""
         phase = 0
-        for i, n in enumerate(ft_shape):
-            c = n // 2
-            phase = phase + (idx[i] - c / 2.0) * (c / n)
+        for i, ph in enumerate(Backend.fftc_mod_phases(ft_shape)):
+            phase = phase + ph.reshape([-1 if j == i else 1 for j in range(len(ft_shape))])
         return np.exp(1j * 2.0 * np.pi * phase).astype(dtype)
 
     def FFTc(self, ft_shape, dtype=_C64, normalize=True, **kwargs):
         """centred (fftshift-ed) FFT as mod * F * mod"""
-        M = self.Diag(self.fftc_mod(ft_shape, dtype), name='mod')
+        if np.dtype(dtype) == _C64:
+            from indigo_amd.structured import DiagS, SepPhase
+            M = self.SpMatrix(struct=DiagS(int(np.prod(ft_shape)), [('sep', SepPhase(ft_shape, self.fftc_mod_phases(ft_shape)))]), name='mod')
+        else:
+            M = self.Diag(self.fftc_mod(ft_shape, dtype), name='mod')
         F = self.FFT(ft_shape, dtype=dtype, **kwargs) if normalize else self.UnscaledFFT(ft_shape, dtype=dtype, **kwargs)
         return M * F * M
 
@@ -353,6 +369,9 @@ class Backend(object):
         """zero-pad an N-volume into an M-volume; a 0/1 matrix of shape (prod M, prod N)"""
         rows = self.zpad_rows(M, N, mode)
         cols = np.arange(rows.size)
+        if np.dtype(dtype) == _C64:
+            from indigo_amd.structured import SelectS
+            return self.SpMatrix(struct=SelectS((int(np.prod(M)), int(np.prod(N))), rows, cols, np.ones(rows.size, dtype=_C64)), **kwargs)
         mat = spp.coo_matrix((np.ones(rows.size), (rows, cols)), shape=(int(np.prod(M)), int(np.prod(N))), dtype=dtype)
         return self.SpMatrix(mat, **kwargs)
 
@@ -365,10 +384,21 @@ class Backend(object):
         ndim = coord.shape[0]
         npts = int(np.prod(coord.shape[1:]))
         coord = coord.reshape((ndim, -1), order='F')
-        from indigo_amd.interp import interp_mat
-        op = self.SpMatrix(interp_mat(npts, N, width, table, coord).astype(dtype), **kwargs)
+        from indigo_amd.structured import InterpS
+        op = self.SpMatrix(struct=InterpS(N, coord, width, table, npts, make_plain=lambda: self._interp_matrix(npts, N, width, table, coord, dtype)), **kwargs)
         op._grid_dims = tuple(int(v) for v in N)        # the columns are the points of this grid, first axis fastest (a hint: hip.py)
         return op
+
+    def _interp_matrix(self, npts, N, width, table, coord, dtype):
+        """the gridding matrix itself (scipy): the vectorised numpy formulation of the reference's loop; backends with a native
+        builder override this"""
+        from indigo_amd.interp import interp_mat
+        return interp_mat(npts, N, width, table, coord).astype(dtype)
+
+    def gridding_from_struct(self, s, grid_order=0):
+        """CSR (complex64, sorted columns) of an InterpS description with its columns numbered in `grid_order` (0: (x, y, z),
+        1: (x, z, y)), built directly -- or None: the caller materialises the scipy matrix and permutes it"""
+        return None
 
     @staticmethod
     def nufft_params(width, oversamp):

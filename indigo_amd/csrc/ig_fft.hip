@@ -723,9 +723,9 @@ k_fft3d_a(const float2* __restrict__ in, float2* __restrict__ out, const float2*
     // y stage 1a: 8-point DFT over b, twiddle w64^(a kb)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        PFFT<8>::run(v[j]);
+        PFFT<8, false, false>::run(v[j]);
 #pragma unroll
-        for (int kb = 1; kb < 8; ++kb) v[j][kb] = cxmul_r(v[j][kb], from2(tws[(4 * a * kb) & 255]));
+        for (int kb = 1; kb < 8; ++kb) v[j][kb] = cxmul(v[j][kb], from2(tws[(4 * a * kb) & 255]));
     }
     // exchange 1 (a <-> kb between waves, lane kept): image [a][kb][xl], two images (two j) per round
     cx r[4][8];
@@ -749,17 +749,17 @@ k_fft3d_a(const float2* __restrict__ in, float2* __restrict__ out, const float2*
     // y stage 1b: 8-point DFT over a -> line k1 = kb + 8 ka; inter-launch twiddle w256^(n2 k1); x stage 1: 4-point DFT over j
     cx p[8][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) PFFT<8>::run(r[j]);
+    for (int j = 0; j < 4; ++j) PFFT<8, false, false>::run(r[j]);
 #pragma unroll
     for (int ka = 0; ka < 8; ++ka) {
         const cx wy = from2(tws[(n2 * (kb + 8 * ka)) & 255]);
         cx t4[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) t4[j] = cxmul_r(r[j][ka], wy);
-        PFFT<4>::run(t4);
+        for (int j = 0; j < 4; ++j) t4[j] = cxmul(r[j][ka], wy);
+        PFFT<4, false, false>::run(t4);
         p[ka][0] = t4[0];
 #pragma unroll
-        for (int kj = 1; kj < 4; ++kj) p[ka][kj] = cxmul_r(t4[kj], from2(tws[(xl * kj) & 255]));
+        for (int kj = 1; kj < 4; ++kj) p[ka][kj] = cxmul(t4[kj], from2(tws[(xl * kj) & 255]));
     }
     // exchange 2: image [line][72] (x within a line); role 2 = (c = x mod 8, line): lane = c + 8*(line mod 8), wave = line / 8
     const int c = tid & 7, l = (tid >> 3) & 7, line = (tid >> 3);
@@ -782,9 +782,9 @@ k_fft3d_a(const float2* __restrict__ in, float2* __restrict__ out, const float2*
     // x stage 2: 8-point DFT over d, twiddle w64^(c kd)
 #pragma unroll
     for (int kj = 0; kj < 4; ++kj) {
-        PFFT<8>::run(q[kj]);
+        PFFT<8, false, false>::run(q[kj]);
 #pragma unroll
-        for (int kd = 1; kd < 8; ++kd) q[kj][kd] = cxmul_r(q[kj][kd], from2(tws[(4 * c * kd) & 255]));
+        for (int kd = 1; kd < 8; ++kd) q[kj][kd] = cxmul(q[kj][kd], from2(tws[(4 * c * kd) & 255]));
     }
     // exchange 3 (c <-> kd among the 8 lanes of a line: inside the wave): image [line][64], swizzled both ways
     __syncthreads();                                   // the last round of exchange 2 has been read everywhere
@@ -807,7 +807,7 @@ k_fft3d_a(const float2* __restrict__ in, float2* __restrict__ out, const float2*
     }
     // x stage 3: 8-point DFT over c -> kx = kj + 4 kd + 32 kc; four adjacent kx per thread and kc: two 16-byte stores
 #pragma unroll
-    for (int kj = 0; kj < 4; ++kj) PFFT<8>::run(t3[kj]);
+    for (int kj = 0; kj < 4; ++kj) PFFT<8, false, false>::run(t3[kj]);
     const rsrc_t r_out = make_rsrc(out + base + 256 * 64 * n2);
     const unsigned l_out = (unsigned)(256 * line + 4 * kd3) * 8u;
 #pragma unroll

@@ -296,26 +296,32 @@ def decode_zpad_maps(St, C, P, oN):
     is then recovered from the rows that are present: i = ix + d0*(iy + d1*iz) with (kx, ky, kz) = lo + (ix, iy, iz).
     Returns None if the matrix does not have that structure."""
     St = St.tocsr()
-    St.sort_indices()
-    Nn = St.shape[0]
     if St.shape[1] != C * P or St.nnz == 0:
         return None
-    rows = np.repeat(np.arange(Nn, dtype=np.int64), np.diff(St.indptr))
-    cols = St.indices.astype(np.int64)
+    rows = np.repeat(np.arange(St.shape[0], dtype=np.int64), np.diff(St.indptr))
+    return decode_zpad_entries(rows, St.indices.astype(np.int64), St.data, St.shape[0], C, P, oN)
+
+
+def decode_zpad_entries(rows, cols, data, Nn, C, P, oN):
+    """decode_zpad_maps on the entries themselves, St[rows[j], cols[j]] = data[j] in any order (what the structured realisation of
+    the recipe hands over, indigo_amd.structured.SelectS)"""
+    rows, cols = np.asarray(rows, dtype=np.int64), np.asarray(cols, dtype=np.int64)
+    Nn = int(Nn)
+    if rows.size == 0 or cols.min() < 0 or cols.max() >= C * P or rows.min() < 0 or rows.max() >= Nn:
+        return None
     coil, pos = cols // P, cols % P
     # one grid position per row (all its coils at the same point), at most one entry per (row, coil)
-    first = St.indptr[:-1][np.diff(St.indptr) > 0]
-    present = np.flatnonzero(np.diff(St.indptr) > 0)
     zrow = np.full(Nn, -1, dtype=np.int64)
-    zrow[present] = pos[first]
+    zrow[rows] = pos
     if not np.array_equal(pos, zrow[rows]):
         return None
-    if rows.size > 1 and np.any((rows[1:] == rows[:-1]) & (coil[1:] <= coil[:-1])):
+    if np.bincount(rows * C + coil, minlength=Nn * C).max() > 1:
         return None
+    present = np.flatnonzero(zrow >= 0)
     n0, n1, n2 = (int(n) for n in oN)
     z = zrow[present]
     kx, ky, kz = z % n0, (z // n0) % n1, z // (n0 * n1)
-    if St.nnz == Nn * C:
+    if rows.size == Nn * C:
         dims = (int(kx.max() - kx.min()) + 1, int(ky.max() - ky.min()) + 1, int(kz.max() - kz.min()) + 1)
     else:
         # present rows only: solve i = kx + d0*ky + d0*d1*kz + const for the box's pitches
@@ -336,5 +342,5 @@ def decode_zpad_maps(St, C, P, oN):
     if min(lo) < 0 or lo[0] + dims[0] > n0 or lo[1] + dims[1] > n1 or lo[2] + dims[2] > n2:
         return None
     w = np.zeros((Nn, C), dtype=_C64)
-    w[rows, coil] = np.conj(St.data)
+    w[rows, coil] = np.conj(data)
     return lo, dims, np.asfortranarray(w).reshape(dims + (C,), order='F')

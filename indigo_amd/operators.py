@@ -188,30 +188,45 @@ class MatrixFreeOperator(CompositeOperator):
 # ------------------------------------------------------------------------------
 
 class SpMatrix(Operator):
-    """Leaf holding a scipy sparse matrix; device CSR is built lazily on first use."""
+    """Leaf holding a scipy sparse matrix; device CSR is built lazily on first use.
 
-    def __init__(self, backend, M, **kwargs):
+    `struct` (optional): what the matrix IS -- a diagonal, a selection with weights, a gridding matrix (indigo_amd.structured) --
+    as the factories of the backend know it.  With a description the scipy matrix itself is only made when somebody reads
+    `_matrix`; the recipe's realisation passes compose descriptions instead of multiplying 1e8-row matrices."""
+
+    def __init__(self, backend, M=None, struct=None, **kwargs):
         super().__init__(backend, **kwargs)
-        assert spp.issparse(M)
-        self._matrix = M
+        assert (M is not None and spp.issparse(M)) or struct is not None
+        self._m = M
+        self._struct = struct
         self._matrix_d = None
         self._allow_exwrite = True
         self._use_dia = False
 
     @property
+    def _matrix(self):
+        if self._m is None:
+            self._m = self._struct.to_scipy()
+        return self._m
+
+    @_matrix.setter
+    def _matrix(self, M):
+        self._m = M
+
+    @property
     def shape(self):
-        return tuple(int(s) for s in self._matrix.shape)
+        return tuple(int(s) for s in (self._m.shape if self._m is not None else self._struct.shape))
 
     @property
     def dtype(self):
-        return self._matrix.dtype
+        return self._m.dtype if self._m is not None else _C64
 
     @property
     def nnz(self):
-        return self._matrix.nnz
+        return self._m.nnz if self._m is not None else self._struct.nnz
 
     def _mem_usage(self, ncols=1):
-        return self._matrix.data.nbytes
+        return self._m.data.nbytes if self._m is not None else self._struct.nnz * 8
 
     def _get_or_create_device_matrix(self):
         if self._matrix_d is None:

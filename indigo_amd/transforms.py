@@ -78,14 +78,29 @@ def reserve_for(node, ncols=1, slack_products=2):
     return elems + extra
 
 
+def _struct(node):
+    return getattr(node, '_struct', None) if isinstance(node, SpMatrix) else None
+
+
 class RealizeMatrices(Transform):
-    """Fold subtrees made only of sparse matrices into a single SpMatrix (scipy on the host)."""
+    """Fold subtrees made only of sparse matrices into a single SpMatrix (indigo/transforms.py:81-175).  Factors that carry a
+    description of what they are (indigo_amd.structured: diagonals, selections, gridding matrices -- everything the SENSE
+    factories make) are composed as index arithmetic; anything else is multiplied by scipy on the host, as in the reference."""
 
     def visit_Product(self, node):
         node = self.generic_visit(node)
         L, R = node._children
         if isinstance(L, SpMatrix) and isinstance(R, SpMatrix):
-            return SpMatrix(node._backend, L._matrix @ R._matrix, name="{}*{}".format(L._name, R._name))
+            from indigo_amd.structured import compose_product
+            name = "{}*{}".format(L._name, R._name)
+            s = compose_product(_struct(L), _struct(R))
+            if s is not None:
+                out = SpMatrix(node._backend, None, struct=s, name=name)
+                for attr in ('_grid_dims',):
+                    if getattr(L, attr, None) is not None:
+                        setattr(out, attr, getattr(L, attr))
+                return out
+            return SpMatrix(node._backend, L._matrix @ R._matrix, name=name)
         return node
 
     def _stack(self, node, stacker):
@@ -97,6 +112,11 @@ class RealizeMatrices(Transform):
         return node
 
     def visit_VStack(self, node):
+        from indigo_amd.structured import DiagS, vstack_diags
+        node = self.generic_visit(node)
+        kids = node._children
+        if kids and all(isinstance(_struct(c), DiagS) for c in kids):
+            return SpMatrix(node._backend, None, struct=vstack_diags([c._struct for c in kids]), name="{}+".format(kids[0]._name))
         return self._stack(node, spp.vstack)
 
     def visit_HStack(self, node):
@@ -106,6 +126,15 @@ class RealizeMatrices(Transform):
         return self._stack(node, spp.block_diag)
 
     def visit_Kron(self, node):
+        from indigo_amd.structured import DiagS, SelectS
+        L, R = node._children
+        if isinstance(L, Eye):
+            R = self.visit(R)
+            if isinstance(_struct(R), (DiagS, SelectS)):          # I_c (x) a selection: kept as the pair (c, selection)
+                from indigo_amd.structured import KronS
+                s = R._struct if isinstance(R._struct, SelectS) else SelectS.from_diag(R._struct)
+                return SpMatrix(node._backend, None, struct=KronS(L.shape[0], s), name="({}(x){})".format(L._name, R._name))
+            node._adopt([L, R])
         node = self.generic_visit(node)
         L, R = node._children
         if isinstance(L, Eye):
@@ -118,6 +147,10 @@ class RealizeMatrices(Transform):
         node = self.generic_visit(node)
         child = node.child
         if isinstance(child, SpMatrix):
+            s = _struct(child)
+            sa = s.adjoint() if hasattr(s, 'adjoint') else None          # (a diagonal or a selection: its triples swapped and conjugated)
+            if sa is not None:
+                return SpMatrix(node._backend, None, struct=sa, name="{}.H".format(child._name))
             return SpMatrix(node._backend, child._matrix.conjugate().transpose(), name="{}.H".format(child._name))
         return node
 
@@ -127,6 +160,9 @@ class RealizeMatrices(Transform):
     def visit_Scale(self, node):
         node = self.generic_visit(node)
         if isinstance(node.child, SpMatrix):
+            s = _struct(node.child)
+            if hasattr(s, 'scaled'):
+                return SpMatrix(node._backend, None, struct=s.scaled(node._val), name=node._name)
             return SpMatrix(node._backend, node.child._matrix * node._val, name=node._name)
         return node
 
@@ -263,22 +299,48 @@ class FuseZpadFFT(Transform):
         grid = F.right._ft_shape
         if L.left.shape[0] != C or len(grid) != 3 or not b.supports_padded_fft(grid, C):
             return node
+        from indigo_amd.structured import InterpS, SelectS
+        P = int(np.prod(grid))
         if isinstance(X, Adjoint) and isinstance(X.child, SpMatrix):
-            St = X.child._matrix
+            Sx, St = X.child, None
         elif isinstance(X, SpMatrix):
-            St = X._matrix.conjugate().transpose()
+            Sx, St = None, X
         else:
             return node
-        P = int(np.prod(grid))
-        dec = fused.decode_zpad_maps(St.astype(np.complex64), C, P, grid)
+        from indigo_amd.structured import AdjointS, StackS
+        sel = _struct(Sx if Sx is not None else St)
+        stack = sel.inner if (Sx is not None and isinstance(sel, AdjointS)) else sel if (St is not None and isinstance(sel, StackS)) else None
+        if isinstance(stack, StackS) and len(stack.blocks) == C and stack.blocks[0].shape[0] == P and stack.shared_pattern() \
+                and stack.blocks[0].rows_unique and stack.blocks[0].cols_unique:
+            # S' as the realisation passes composed it: C blocks (mod * zpad * apod) * diag(map_c) over ONE pattern (grid position
+            # of every voxel) -- no (C P)-row CSR was ever made
+            b0 = stack.blocks[0]
+            Nn = b0.shape[1]
+            dec = fused.decode_zpad_entries(b0.cols, b0.rows, np.ones(b0.nnz, dtype=np.complex64), Nn, 1, P, grid)
+            if dec is not None:
+                w = np.zeros((Nn, C), dtype=np.complex64)
+                for c, blk in enumerate(stack.blocks):
+                    w[blk.cols, c] = blk.vals
+                dec = (dec[0], dec[1], np.asfortranarray(w).reshape(tuple(dec[1]) + (C,), order='F'))
+        elif isinstance(sel, SelectS):
+            sel = sel if Sx is not None else sel.adjoint()
+            dec = fused.decode_zpad_entries(sel.rows, sel.cols, sel.vals, sel.shape[0], C, P, grid)
+        else:
+            Sm = Sx._matrix if Sx is not None else St._matrix.conjugate().transpose()
+            dec = fused.decode_zpad_maps(Sm.astype(np.complex64), C, P, grid)
         if dec is None:
             log.warning("FuseZpadFFT: %s is not a zero-pad * diagonal factor; the tree keeps the unfused -O3 leaves (S' csrmm + dense FFT)", X._name)
             return node
         lo, box, w = dec
         layout, chunks = fused.choose_layout(C, self.chunk, None, getattr(b, 'supports_single_coil_layout', lambda g: True)(grid))
-        Gm = L.right._matrix.astype(np.complex64).tocsr()
-        if layout >= 1:
-            Gm = fused.permute_grid_columns(Gm, grid)
+        # G' = interp * mod * scale: where the factories' description survived the recipe and the backend has a native builder, the
+        # matrix is built directly in the leaf's grid order (ig_interp3_fill_modulated); else from the scipy product, renumbered
+        gs = _struct(L.right)
+        Gm = b.gridding_from_struct(gs, 1 if layout >= 1 else 0) if (isinstance(gs, InterpS) and hasattr(b, 'gridding_from_struct')) else None
+        if Gm is None:
+            Gm = L.right._matrix.astype(np.complex64).tocsr()
+            if layout >= 1:
+                Gm = fused.permute_grid_columns(Gm, grid)
         zw = fused.support_words(b, grid)
         table = fused.grid_support(Gm, grid, 16, zw) if (layout >= 1 and zw is not None and (layout == 2 or zw == (16, 16))) else None
         A = fused.assemble(b, Gm, grid, box, lambda c0, c1: w[..., c0:c1], C, layout, chunks, table=table, box_lo=lo,

@@ -21,8 +21,10 @@ class CoilOperatorF64(object):
     def __init__(self, problem, coil):
         p = problem
         self.N, self.oN = p.N, p.oN
-        self.G = p.fused_interp(0).astype(np.complex128)
-        self.GH = None
+        # the gridding matrix in whichever grid order the problem already holds (0: (x, y, z) columns; 1: (x, z, y)) -- a second
+        # copy of a 4e8-nonzero matrix is not worth ten seconds and five gigabytes
+        self.layout = 1 if (1 in p._interp_cache and 0 not in p._interp_cache) else 0
+        self.G = p.fused_interp(self.layout).astype(np.complex128)
         self.w = p.fused_weights([coil])[..., 0].astype(np.complex128)
         lo = tuple(m // 2 + int(np.ceil(-n / 2)) for m, n in zip(self.oN, self.N))
         self.sl = tuple(slice(l, l + b) for l, b in zip(lo, self.N))
@@ -31,13 +33,19 @@ class CoilOperatorF64(object):
         full = np.zeros(self.oN, dtype=np.complex128, order='F')
         full[self.sl] = self.w * np.asarray(x, dtype=np.complex128).reshape(self.N, order='F')
         F = np.fft.fftn(full)
+        if self.layout == 1:
+            F = F.transpose(0, 2, 1)
         return self.G @ F.reshape(-1, order='F')
 
     def adjoint(self, k):
-        if self.GH is None:
-            self.GH = self.G.conj().T.tocsr()
-        g = self.GH @ np.asarray(k, dtype=np.complex128).reshape(-1)
-        inv = np.fft.ifftn(g.reshape(self.oN, order='F')) * np.prod(self.oN)
+        # G^H k = conj(G^T conj(k)): the transpose of a CSR matrix is a CSC VIEW, its product a scatter over the same arrays -- no
+        # transposed copy of the matrix is ever built
+        g = np.conj(self.G.T @ np.conj(np.asarray(k, dtype=np.complex128).reshape(-1)))
+        if self.layout == 1:
+            vol = g.reshape((self.oN[0], self.oN[2], self.oN[1]), order='F').transpose(0, 2, 1)
+        else:
+            vol = g.reshape(self.oN, order='F')
+        inv = np.fft.ifftn(vol) * np.prod(self.oN)
         return (np.conj(self.w) * inv[self.sl]).reshape(-1, order='F')
 
     def normal(self, x):

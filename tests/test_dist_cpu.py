@@ -245,3 +245,77 @@ def test_three_ranks_agree_on_one_allreduce_route(tmp_path):
         assert str(r["route"][0]) == "full"
         assert list(r["log"]) == ["full", "max", "full"], list(r["log"])
         assert rel_err(r["y"], g["sense_AHAx"]) < 1e-5
+
+
+SPLIT_WORKER = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["REPO_ROOT"])
+import torch.distributed as dist
+from oracle.np_backend import NumpyBackend
+from indigo_amd import operators as op
+from indigo_amd.dist import ShardedNormalOperator, TorchComm, coil_range
+from indigo_amd.sense import SenseProblem
+from indigo_amd.util import rand64c
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+p = SenseProblem.synthetic((12, 10, 8), 8, nspokes=9, nreadout=24, oversamp=1.5, seed=21)
+B = NumpyBackend()
+coils = list(coil_range(p.C, rank, world))          # 8 coils on 3 ranks: 3 + 3 + 2
+A = p.build_zpadfft(B, coils=coils)
+leaves = []
+def walk(n):
+    if isinstance(n, op.ZpadFFT):
+        leaves.append((n._C, n._layout))
+    for c in getattr(n, "_children", None) or []:
+        walk(c)
+walk(A)
+AHA = ShardedNormalOperator(A, TorchComm(B), lamda=0.25)
+x = B.copy_array(rand64c(A.shape[1], 1, seed=3))
+y = B.zero_array((A.shape[1], 1), np.dtype("complex64"))
+AHA.eval(y, x)
+np.savez(os.environ["OUT"] + ".%d.npz" % rank, y=y.to_host(), ncoils=len(coils), leaves=np.array(leaves), rows=A.shape[0])
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_eight_coils_on_three_ranks_take_interleaved_leaves(tmp_path, oracle_backend):
+    """8 coils on 3 ranks are 3 + 3 + 2 (coil_range): a 3-coil rank evaluates ONE 4-wide coil-interleaved chunk whose fourth coil
+    has zero weights -- the fused leaf with the binned adjoint and the fine table on the GPU -- instead of falling back to the
+    per-coil layout; the 2-coil rank a 2-wide chunk.  The all-reduced normal operator equals the unsharded -O3 tree's."""
+    from indigo_amd.sense import SenseProblem, normal_operator
+    from indigo_amd.util import rand64c
+    port = _free_port()
+    out = str(tmp_path / "split")
+    procs = []
+    for rank in range(3):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="3", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   REPO_ROOT=ROOT, OUT=out, OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, "-c", SPLIT_WORKER], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("distributed workers timed out")
+        logs.append(o)
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)
+    res = [np.load(out + ".%d.npz" % r) for r in range(3)]
+    assert [int(r["ncoils"]) for r in res] == [3, 3, 2]
+    assert [r["leaves"].tolist() for r in res] == [[[4, 2]], [[4, 2]], [[2, 2]]]          # (interleave width, grid layout) per chunk
+    q = SenseProblem.synthetic((12, 10, 8), 8, nspokes=9, nreadout=24, oversamp=1.5, seed=21)
+    assert [int(r["rows"]) for r in res] == [3 * q.T, 3 * q.T, 2 * q.T]                   # padding coils add no k-space rows
+    B = oracle_backend
+    B._scratch = None
+    A = q.build_fused(B)
+    x = rand64c(A.shape[1], 1, seed=3)
+    y = B.zero_array((A.shape[1], 1), np.dtype("complex64"))
+    normal_operator(A, lamda=0.25).eval(y, B.copy_array(x))
+    for r in res:
+        assert rel_err(r["y"], y.to_host()) < 1e-5
+    B._scratch = None

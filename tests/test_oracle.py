@@ -175,6 +175,13 @@ def test_double_precision_arbiter_against_reference_goldens():
     assert rel_err(AHk, g["sense_AHk"][:, 0]) < TOL
     AHAx = sum(o.normal(x) for o in ops) + float(g["lamda"]) * x
     assert rel_err(AHAx, g["sense_AHAx"][:, 0]) < TOL
+    # ... and the same through the (x, z, y)-ordered gridding matrix a problem already holds (what bench.py's dense-trajectory
+    # leg evaluates with: no second copy of a 4e8-nonzero matrix)
+    p2 = SenseProblem(N, g["coord"], np.asfortranarray(g["maps"]), width=int(width), ntable=int(ntab), oversamp=float(osf))
+    p2.fused_interp(1)
+    ops2 = [CoilOperatorF64(p2, c) for c in range(C)]
+    assert all(o.layout == 1 for o in ops2) and all(o.layout == 0 for o in ops)
+    assert rel_err(sum(o.normal(x) for o in ops2) + float(g["lamda"]) * x, g["sense_AHAx"][:, 0]) < TOL
     # the NUFFT leaf: unit maps
     q = SenseProblem(N, g["coord"], np.ones(N + (1,), dtype=C64, order='F'), width=int(width), ntable=int(ntab), oversamp=float(osf))
     F = CoilOperatorF64(q, 0)

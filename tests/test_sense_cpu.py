@@ -228,10 +228,21 @@ def test_fuse_zpadfft_with_masked_maps(prob, oracle_backend):
     maps[~ball] = 0                                   # outside the body: every coil; boundary planes vanish entirely
     maps[:, : n1 // 2, :, 1] = 0                      # coil 1 sees half of it
     q = SenseProblem(p.N, p.coord, maps, width=p.width, ntable=p.ntable, oversamp=p.oversamp)
-    A3 = q.build_tree(B, level=3)
+    def scipy_route():          # the recipe on plain scipy matrices, as the reference runs it (no factor knows what it is)
+        from indigo_amd.transforms import sense_recipe
+        A = q.build_tree(B, level=0)
+        _strip_descriptions(A)
+        for Step in sense_recipe(3):
+            A = Step().visit(A)
+        return A
+    A3 = scipy_route()
     St = [n for n in _leaves(A3) if isinstance(n, op.SpMatrix)][-1]._matrix
     assert St.nnz < int(np.prod(p.N)) * C              # entries really are missing
-    Af = FuseZpadFFT().visit(q.build_tree(B, level=3))
+    Af = FuseZpadFFT().visit(scipy_route())
+    # ... and the realisation that composes the factors' descriptions keeps the zeros as zero weights: the same leaf
+    Ag = FuseZpadFFT().visit(q.build_tree(B, level=3))
+    xx, kk = g["sense_x"], g["sense_k"]
+    assert Ag.has(op.ZpadFFT) and rel_err(Ag * xx, Af * xx) < 2e-6 and rel_err(Ag.H * kk, Af.H * kk) < 2e-6
     assert Af.has(op.ZpadFFT) and not Af.has(op.UnscaledFFT)
     core = Af.child if isinstance(Af, op.HeadRows) else Af      # (C = 3: a 4-wide chunk with a zero-weight coil)
     assert core.right._box == p.N
@@ -413,3 +424,61 @@ def test_even_grid_fixture_construction_and_gprime(oracle_backend):
     oracle_backend._scratch = None
     check_even_grid_products(p.build_fused(oracle_backend), g, x, k)
     oracle_backend._scratch = None
+
+
+def _strip_descriptions(node):
+    """materialise every sparse leaf and forget what it is: the realisation passes then multiply with scipy, as the reference does"""
+    if isinstance(node, op.SpMatrix):
+        node._matrix
+        node._struct = None
+    for c in getattr(node, '_children', None) or []:
+        _strip_descriptions(c)
+
+
+@pytest.mark.parametrize("masked", [False, True])
+def test_structured_realisation_equals_the_scipy_products(oracle_backend, masked):
+    """`pics.py -O3` on the factories' tree (examples/pics.py:104-193) two ways: the realisation passes composing the factors'
+    descriptions (indigo_amd.structured: no sparse-sparse product at all) and the same passes on plain scipy matrices, as the
+    reference runs them.  G' = interp * mod * scale and S' = (I (x) mod * zpad * apod) * maps come out with the same pattern and
+    the same values to float32 rounding; the trees evaluate alike; and the HIP backend's native G' (one pass over the
+    trajectory, ig_interp3_fill_modulated, in the fused leaf's column order) equals the scipy product renumbered."""
+    from indigo_amd import fused
+    from indigo_amd.structured import AdjointS, InterpS, StackS
+    from indigo_amd.transforms import sense_recipe
+    B = oracle_backend
+    B._scratch = None
+    p = SenseProblem.synthetic((12, 10, 8), 3, nspokes=11, nreadout=24, oversamp=1.5, seed=17)
+    if masked:
+        p.maps[:, :5, :, 1] = 0
+        p.maps[:3] = 0
+    trees = []
+    for strip in (False, True):
+        A = p.build_tree(B, level=0)
+        if strip:
+            _strip_descriptions(A)
+        for Step in sense_recipe(3):
+            A = Step().visit(A)
+        trees.append(A)
+    At, As = trees
+    Lt = [n for n in _leaves(At) if isinstance(n, op.SpMatrix)]
+    Ls = [n for n in _leaves(As) if isinstance(n, op.SpMatrix)]
+    assert len(Lt) == len(Ls) == 2
+    assert isinstance(Lt[0]._struct, InterpS) and Ls[0]._struct is None and Ls[1]._struct is None
+    # S' (stored transposed by MriGoodAdjoints): the blocks (mod * zpad * apod) * diag(map_c) over one shared pattern
+    assert isinstance(Lt[1]._struct, AdjointS) and isinstance(Lt[1]._struct.inner, StackS) and Lt[1]._struct.inner.shared_pattern()
+    for a, b in zip(Lt, Ls):
+        Ma, Mb = a._matrix.tocsr().astype(C64), b._matrix.tocsr().astype(C64)
+        Ma.sort_indices(), Mb.sort_indices()
+        # (scipy's products drop exact zeros -- taps at the very edge of the kernel, masked maps --, the descriptions keep them as
+        # zero weights: the matrices are compared as matrices, not pattern by pattern)
+        assert Ma.shape == Mb.shape and Ma.nnz >= Mb.nnz and abs(Ma - Mb).max() <= 3e-7 * abs(Mb).max()
+    from indigo_amd.util import rand64c
+    x, k = rand64c(At.shape[1], 1, seed=1), rand64c(At.shape[0], 1, seed=2)
+    assert rel_err(At * x, As * x) < 2e-6 and rel_err(At.H * k, As.H * k) < 2e-6
+    # the native builder of the HIP backend's host library against the scipy product, in the fused leaf's (x, z, y) column order
+    import types
+    from indigo_amd.backends.hip import HipBackend
+    Gn = HipBackend.gridding_from_struct(types.SimpleNamespace(), Lt[0]._struct, 1)
+    Gs = fused.permute_grid_columns(Ls[0]._matrix.tocsr().astype(C64), p.oN)
+    assert Gn.shape == Gs.shape and Gn.has_sorted_indices and abs(Gn - Gs).max() <= 3e-7 * abs(Gs).max()
+    B._scratch = None
