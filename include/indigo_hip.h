@@ -45,6 +45,7 @@ typedef struct ig_ctx   ig_ctx;    /* one device + one stream                */
 typedef struct ig_fft   ig_fft;    /* batched C2C FFT plan                   */
 typedef struct ig_event ig_event;  /* timing event on the context's stream   */
 typedef struct ig_comm  ig_comm;   /* RCCL communicator of one rank (one GPU) */
+typedef struct ig_graph ig_graph;  /* a recorded sequence of launches on the context's stream (hipGraph) */
 
 /* ------------------------------------------------------------------------
  * Context.  Replaces the handle/bring-up code of CudaBackend.__init__
@@ -91,6 +92,20 @@ int  ig_event_create(ig_ctx* ctx, ig_event** out);
 int  ig_event_record(ig_event* ev);
 int  ig_event_elapsed_ms(ig_event* start, ig_event* stop, float* ms);   /* synchronous on `stop` */
 int  ig_event_destroy(ig_event* ev);
+
+/* Recorded launch sequences (HIP graphs).  The reference's solver loop (Backend.cg, indigo/backends/backend.py:666-686) issues
+ * the same ~25 dependent launches every iteration -- one operator evaluation and the vector updates --, each paying the host's
+ * launch path; recorded once and replayed as ONE graph launch the gaps between them shrink to the device's own.
+ *   ig_graph_begin : every launch made through this context from now on is RECORDED on its stream, not executed.  Calls that
+ *                    synchronise or allocate (ig_sync, ig_malloc, host reads, a first-use format build) are errors while recording:
+ *                    run the sequence once unrecorded first.  Profile mode must be off.
+ *   ig_graph_end   : stops recording and instantiates the graph; ig_graph_abort : stops recording and drops what was recorded
+ *   ig_graph_launch: enqueues the whole sequence on the context's stream (same buffers, same scalars as when it was recorded)  */
+int  ig_graph_begin(ig_ctx* ctx);
+int  ig_graph_end(ig_ctx* ctx, ig_graph** out);
+int  ig_graph_abort(ig_ctx* ctx);
+int  ig_graph_launch(ig_graph* graph);
+int  ig_graph_destroy(ig_graph* graph);
 
 /* Profile mode: while enabled, every kernel launch made through this context
  * is bracketed by two events on the stream (no host sync).  ig_prof_report

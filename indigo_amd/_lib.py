@@ -38,6 +38,11 @@ PROTOTYPES = {
     "ig_event_record":    (c_int, [c_void_p]),
     "ig_event_elapsed_ms": (c_int, [c_void_p, c_void_p, POINTER(c_float)]),
     "ig_event_destroy":   (c_int, [c_void_p]),
+    "ig_graph_begin":     (c_int, [c_void_p]),
+    "ig_graph_end":       (c_int, [c_void_p, POINTER(c_void_p)]),
+    "ig_graph_abort":     (c_int, [c_void_p]),
+    "ig_graph_launch":    (c_int, [c_void_p]),
+    "ig_graph_destroy":   (c_int, [c_void_p]),
     "ig_prof_enable":     (c_int, [c_void_p, c_int]),
     "ig_prof_report":     (c_int, [c_void_p, c_char_p, c_size_t]),
     "ig_caxpby":          (c_int, [c_void_p, c_int64, c_float, c_float, c_void_p, c_float, c_float, c_void_p]),

@@ -108,7 +108,9 @@ class HipBackend(Backend):
         #   wide_bricks   64-column column-major panels: brick scatter through LDS (adjoint)
         #   slots         coil counts whose adjoint gridding is the slot-format scatter (ig_ccsrmm_t_slots): the ranks of a coil-sharded
         #                 run with one or two coils
-        self.tuning = dict(bricks=(4, 8), slots=(1, 2), slot_shape=(4, 4, 256, 64), support_tile={8: 4, 4: 8}, brick_shape={8: (2, 2, 4096, 4096), 4: (2, 4, 4096, 4096)}, xrows=True, runs=True, wide_bricks=True,
+        #   cg_graph      HipBackend.cg replays a block of iterations as one HIP graph launch (ig_graph_*).  Off: measured on the headline
+        #                 problem the replay saves 0.03 ms of a 6.89 ms iteration and recording costs 5 ms per solve (profiles/r05_cg_graph_ab.log)
+        self.tuning = dict(cg_graph=False, bricks=(4, 8), slots=(1, 2), slot_shape=(4, 4, 256, 64), support_tile={8: 4, 4: 8}, brick_shape={8: (2, 2, 4096, 4096), 4: (2, 4, 4096, 4096)}, xrows=True, runs=True, wide_bricks=True,
                            wide_brick_shape=(2, 2), wide_task_shape=(8192, 2048))
 
     def __del__(self):
@@ -179,6 +181,7 @@ class HipBackend(Backend):
     def profile(self, on=True):
         """bracket every kernel launch with stream events (no host sync) until switched off"""
         self._check(self._L.ig_prof_enable(self._ctx, 1 if on else 0), "ig_prof_enable")
+        self._prof_on = bool(on)
 
     def profile_report(self):
         """{kernel: dict(launches, total_ms, avg_ms, bytes)} since the last report; synchronises"""
@@ -371,7 +374,12 @@ class HipBackend(Backend):
         base implementation."""
         if team is not None or not (hasattr(A, 'eval')):
             return super().cg(A, b_h, x_h, lamda=lamda, tol=tol, maxiter=maxiter, team=team)
+        A_in, lamda_in = A, lamda
         A, lamda = self._split_identity(A, lamda)
+        if np.imag(lamda) != 0:
+            # the fused passes carry a REAL regularisation weight; a complex one (which the reference's loop accepts,
+            # backend.py:651-689) takes the base implementation with the caller's own operator -- decided before anything is allocated
+            return super().cg(A_in, b_h, x_h, lamda=lamda_in, tol=tol, maxiter=maxiter, team=team)
         base, nslots = self._slots()
         S = lambda i: ctypes.c_void_p(base + 8 * i)          # slot i (a device double)
         RRA, R0, RRB, ALPHA, HIST = 0, 1, 2, 4, 8            # rr lives in two slots used in turn (ig_cg_step_xp writes the other one)
@@ -397,21 +405,50 @@ class HipBackend(Backend):
         host = (ctypes.c_double * every)()
         tol2 = float(tol) ** 2
         lam = ctypes.c_float(float(np.real(lamda)))
-        assert np.imag(lamda) == 0, "cg: lamda is a real regularisation weight"
         it = 0
         done = False
-        while it < maxiter and not done:
-            rr, rr_next = (RRA, RRB) if it % 2 == 0 else (RRB, RRA)
+
+        def iteration(i):
+            rr, rr_next = (RRA, RRB) if i % 2 == 0 else (RRB, RRA)
             A.eval(Ap, p)
             # three fused passes (ig_blas.hip): Ap += lamda p and <p, Ap>;  alpha = rr / <p, Ap> (zero once rr / r0 < tol^2: the
             # reference has left its loop by then), r -= alpha Ap, ||r||^2;  beta = r2 / rr, x += alpha p, p = r + beta p,
-            # rr <- r2, history[it] = r2 / r0
+            # rr <- r2, history[i] = r2 / r0
             self._check(L.ig_cg_dot(ctx, n, P(p), P(Ap), lam), "ig_cg_dot")
             self._check(L.ig_cg_step_r(ctx, n, P(r), P(Ap), S(rr), S(R0), tol2, S(ALPHA)), "ig_cg_step_r")
-            self._check(L.ig_cg_step_xp(ctx, n, P(x), P(p), P(r), S(ALPHA), S(rr), S(rr_next), S(R0), S(HIST + it % every)), "ig_cg_step_xp")
-            it += 1
-            if it - fetched == every or it == maxiter:
-                self._check(L.ig_scalar_read(ctx, S(HIST), it - fetched, host), "ig_scalar_read")
+            self._check(L.ig_cg_step_xp(ctx, n, P(x), P(p), P(r), S(ALPHA), S(rr), S(rr_next), S(R0), S(HIST + i % every)), "ig_cg_step_xp")
+
+        # A block of `every` iterations issues the same launches on the same buffers every time (an even `every` keeps the two
+        # rr slots in step): the SECOND block is recorded as a HIP graph (the first ran plain: formats built, attributes set,
+        # the library's buffers sized) and every later full block is one graph launch -- the gaps between ~25 dependent launches
+        # per iteration shrink from the host's launch path to the device's own.  Needs the scratch arena (the evaluation's
+        # temporaries must sit where they sat when recorded); anything that cannot be recorded falls back to plain launches.
+        graph = None
+        use_graph = (self.tuning.get('cg_graph', True) and getattr(self, '_scratch', None) is not None and every % 2 == 0
+                     and maxiter >= 3 * every and getattr(self, 'trace', None) is None and not getattr(self, '_prof_on', False))
+        try:
+            while it < maxiter and not done:
+                nblk = min(every, maxiter - it)
+                if use_graph and nblk == every and it % every == 0 and it >= every:
+                    if graph is None:
+                        try:
+                            self._check(L.ig_graph_begin(ctx), "ig_graph_begin")
+                            for j in range(every):
+                                iteration(it + j)
+                            g = ctypes.c_void_p()
+                            self._check(L.ig_graph_end(ctx, ctypes.byref(g)), "ig_graph_end")
+                            graph = g
+                        except Exception as e:          # noqa: BLE001 -- e.g. a leaf that synchronises: this solve runs on plain launches
+                            L.ig_graph_abort(ctx)
+                            log.info("cg: the iteration cannot be recorded as a graph (%s); plain launches", e)
+                            use_graph = False
+                            continue
+                    self._check(L.ig_graph_launch(graph), "ig_graph_launch")
+                else:
+                    for j in range(nblk):
+                        iteration(it + j)
+                it += nblk
+                self._check(L.ig_scalar_read(ctx, S(HIST), it - fetched, host), "ig_scalar_read")       # (the block's only synchronisation)
                 for j in range(it - fetched):
                     history.append(float(np.sqrt(host[j])))
                     log.info("iter %d, residual %g", fetched + j, history[-1])
@@ -420,6 +457,10 @@ class HipBackend(Backend):
                         done = True
                         break
                 fetched = it
+        finally:
+            if graph is not None:
+                self.barrier()
+                L.ig_graph_destroy(graph)
         if not done:
             log.info("cg reached maxiter")
         if not x_dev:
@@ -530,6 +571,7 @@ class HipBackend(Backend):
         return len(grid) == 3 and all(int(n) in self.PADDED_AXES_POW2 for n in grid)
 
     supports_support_tile = True          # ZpadFFT / the brick scatter take support tables of 8 or 4 kx points per entry
+    supports_support_hulls = True         # ... and the chirp-z passes the hulls of a 16-point table (fused.support_mode 'hulls')
 
     def _padded_plan(self, grid, box_lo, box_dims, batch, layout=0, support_tile=16):
         key = ('padded', tuple(grid), tuple(box_lo), tuple(box_dims), int(batch), int(layout), int(support_tile))

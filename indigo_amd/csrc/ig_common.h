@@ -39,6 +39,7 @@ struct ig_ctx {
     bool         fft_w32_attr = false;    // the 32-column FFT kernels' dynamic-LDS opt-in was applied on this device
     // profile mode (ig_prof_enable): every kernel launch is bracketed by two events
     bool                     prof_on = false;
+    bool                     capturing = false;    // ig_graph_begin ... ig_graph_end / _abort: launches are recorded, not executed
     std::vector<ig_prof_rec> prof;
     std::vector<hipEvent_t>  prof_pool;    // recycled events
 };
@@ -59,6 +60,12 @@ struct ig_prof_scope {
         ctx->prof.push_back(r);
     }
     ~ig_prof_scope() { if (on) (void)hipEventRecord(ctx->prof[idx].e1, ctx->stream); }
+};
+
+struct ig_graph {
+    ig_ctx*        ctx  = nullptr;
+    hipGraph_t     graph = nullptr;
+    hipGraphExec_t exec = nullptr;
 };
 
 struct ig_event {

@@ -114,6 +114,72 @@ int ig_sync(ig_ctx* ctx) {
 
 void* ig_stream(ig_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
+// ---- recorded launch sequences (HIP graphs) --------------------------------------------------------------------------
+int ig_graph_begin(ig_ctx* ctx) {
+    IG_REQUIRE(ctx, ctx != nullptr, "ig_graph_begin: ctx is NULL");
+    IG_REQUIRE(ctx, !ctx->capturing, "ig_graph_begin: already recording");
+    IG_REQUIRE(ctx, !ctx->prof_on, "ig_graph_begin: profile mode brackets launches with events of its own; switch it off");
+    if (int rc = ig_set_device(ctx)) return rc;
+    // thread-local mode: only this thread's unsafe calls (allocations, synchronisations) invalidate the recording
+    IG_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    ctx->capturing = true;
+    return IG_OK;
+}
+
+int ig_graph_end(ig_ctx* ctx, ig_graph** out) {
+    IG_REQUIRE(ctx, ctx && out, "ig_graph_end: bad arguments");
+    IG_REQUIRE(ctx, ctx->capturing, "ig_graph_end: not recording");
+    *out = nullptr;
+    ctx->capturing = false;
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(ctx->stream, &g);
+    if (e != hipSuccess || !g) {
+        (void)hipGetLastError();
+        if (g) (void)hipGraphDestroy(g);
+        return ig_fail(ctx, IG_ERR_HIP, "ig_graph_end: the recording is invalid (%s): a call inside it synchronised or allocated",
+                       hipGetErrorString(e));
+    }
+    hipGraphExec_t x = nullptr;
+    e = hipGraphInstantiate(&x, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipGraphDestroy(g);
+        return ig_fail(ctx, IG_ERR_HIP, "ig_graph_end: hipGraphInstantiate failed: %s", hipGetErrorString(e));
+    }
+    ig_graph* r = new ig_graph();
+    r->ctx = ctx; r->graph = g; r->exec = x;
+    *out = r;
+    return IG_OK;
+}
+
+int ig_graph_abort(ig_ctx* ctx) {
+    IG_REQUIRE(ctx, ctx != nullptr, "ig_graph_abort: ctx is NULL");
+    if (!ctx->capturing) return IG_OK;
+    ctx->capturing = false;
+    hipGraph_t g = nullptr;
+    (void)hipStreamEndCapture(ctx->stream, &g);
+    (void)hipGetLastError();
+    if (g) (void)hipGraphDestroy(g);
+    return IG_OK;
+}
+
+int ig_graph_launch(ig_graph* graph) {
+    IG_REQUIRE(nullptr, graph && graph->ctx && graph->exec, "ig_graph_launch: bad graph");
+    ig_ctx* ctx = graph->ctx;
+    IG_REQUIRE(ctx, !ctx->capturing, "ig_graph_launch: the context is recording");
+    if (int rc = ig_set_device(ctx)) return rc;
+    IG_HIP(ctx, hipGraphLaunch(graph->exec, ctx->stream));
+    return IG_OK;
+}
+
+int ig_graph_destroy(ig_graph* graph) {
+    if (!graph) return IG_OK;
+    if (graph->exec) (void)hipGraphExecDestroy(graph->exec);
+    if (graph->graph) (void)hipGraphDestroy(graph->graph);
+    delete graph;
+    return IG_OK;
+}
+
 int ig_device_name(ig_ctx* ctx, char* buf, size_t len) {
     IG_REQUIRE(ctx, ctx && buf && len > 0, "ig_device_name: bad arguments");
     hipDeviceProp_t prop;

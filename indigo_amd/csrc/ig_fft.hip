@@ -660,6 +660,11 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
     }
 }
 
+// (Round 5, measured and removed: two neighbouring tiles per workgroup, software-pipelined -- the second tile's loads issued as soon
+// as the first tile's stage-1 outputs sat in the exchange image, 110 registers, no spills, bit-identical results.  Same box,
+// alternating runs: 6.652 / 6.657 ms per evaluation against 6.664 / 6.678 ms; two of the four passes 2-5 % faster, two 1-3 % slower.
+// profiles/r05_fft_pass_experiments.txt.)
+
 // ---- 256^3 in TWO launches ------------------------------------------------------------------------------------
 // The plain 3-D transform above is three passes = 6 x the volume in HBM traffic; the reference's own accounting
 // (benchmark.py:55) prices a 3-D transform at 4 x.  For 256^3 volumes (BASELINE config 2) two launches suffice if a
@@ -1119,11 +1124,12 @@ int launch_ab(ig_ctx* ctx, const AxisPlan& ax, const float2* in, float2* out, in
     IG_REQUIRE(ctx, blocks <= 0x7fffffffLL, "ig_fft_exec: too many tiles");
     const dim3 grid((unsigned)blocks), block((unsigned)(anyfft::AB_W * ax.ab_B));
     const bool ax0 = ax.inner == 1;
-    if (!(ig_ab_launch_part0(ctx->stream, ax.n, ax0, grid, block, ax.lds_bytes, in, out, ax.d_tw, ax.inner, ncols, inverse) ||
-          ig_ab_launch_part1(ctx->stream, ax.n, ax0, grid, block, ax.lds_bytes, in, out, ax.d_tw, ax.inner, ncols, inverse) ||
-          ig_ab_launch_part2(ctx->stream, ax.n, ax0, grid, block, ax.lds_bytes, in, out, ax.d_tw, ax.inner, ncols, inverse) ||
-          ig_ab_launch_part3(ctx->stream, ax.n, ax0, grid, block, ax.lds_bytes, in, out, ax.d_tw, ax.inner, ncols, inverse)))
-        return ig_fail(ctx, IG_ERR_UNSUPPORTED, "ig_fft_exec: no A x B kernel for n = %lld", (long long)ax.n);
+    int r = ig_ab_launch_part0(ctx->stream, ax.n, ax0, grid, block, ax.lds_bytes, in, out, ax.d_tw, ax.inner, ncols, inverse);
+    if (!r) r = ig_ab_launch_part1(ctx->stream, ax.n, ax0, grid, block, ax.lds_bytes, in, out, ax.d_tw, ax.inner, ncols, inverse);
+    if (!r) r = ig_ab_launch_part2(ctx->stream, ax.n, ax0, grid, block, ax.lds_bytes, in, out, ax.d_tw, ax.inner, ncols, inverse);
+    if (!r) r = ig_ab_launch_part3(ctx->stream, ax.n, ax0, grid, block, ax.lds_bytes, in, out, ax.d_tw, ax.inner, ncols, inverse);
+    if (r == 2) return ig_fail(ctx, IG_ERR_UNSUPPORTED, "ig_fft_exec: device %d refused %zu bytes of LDS for the %lld-point kernel", ctx->device, ax.lds_bytes, (long long)ax.n);
+    if (!r) return ig_fail(ctx, IG_ERR_UNSUPPORTED, "ig_fft_exec: no A x B kernel for n = %lld", (long long)ax.n);
     IG_LAUNCH_CHECK(ctx, "k_fft_ab");
     return IG_OK;
 }
@@ -1366,8 +1372,12 @@ int launch_ab_desc(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d_in, int wm
         wm = d.cw == 2 ? 4 : d.cw == 4 ? 5 : d.cw == 8 ? 6 : 7;
     }
     const dim3 grid((unsigned)blocks), block((unsigned)(anyfft::AB_W * ax.ab_B));
-    if (!(ig_abd_launch_part0(ctx->stream, ax.n, wm, grid, block, d, ax.d_tw) || ig_abd_launch_part1(ctx->stream, ax.n, wm, grid, block, d, ax.d_tw) ||
-          ig_abd_launch_part2(ctx->stream, ax.n, wm, grid, block, d, ax.d_tw) || ig_abd_launch_part3(ctx->stream, ax.n, wm, grid, block, d, ax.d_tw)))
+    int r = ig_abd_launch_part0(ctx->stream, ax.n, wm, grid, block, d, ax.d_tw);
+    if (!r) r = ig_abd_launch_part1(ctx->stream, ax.n, wm, grid, block, d, ax.d_tw);
+    if (!r) r = ig_abd_launch_part2(ctx->stream, ax.n, wm, grid, block, d, ax.d_tw);
+    if (!r) r = ig_abd_launch_part3(ctx->stream, ax.n, wm, grid, block, d, ax.d_tw);
+    if (r == 2) return ig_fail(ctx, IG_ERR_UNSUPPORTED, "ig_fft: device %d refused the LDS the %lld-point zero-pad-aware kernel needs", ctx->device, (long long)ax.n);
+    if (!r)
         return ig_fail(ctx, IG_ERR_UNSUPPORTED, "ig_fft: no zero-pad-aware kernel for n = %lld", (long long)ax.n);
     IG_LAUNCH_CHECK(ctx, "k_fft_ab_desc");
     return IG_OK;
@@ -1453,7 +1463,7 @@ k_chirp_post(const float2* __restrict__ W, float2* __restrict__ y, const float2*
 int launch_chirp_desc(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d_in) {
     const Chirp& ch = *ax.chirp;
     IG_REQUIRE(ctx, ch.fused, "ig_fft: this chirp-z axis has no one-launch route");
-    IG_REQUIRE(ctx, !d_in.cw && !d_in.tile_range && !d_in.tile_bits && !d_in.k1_range, "ig_fft: a chirp-z pass takes no lane split and no support table");
+    IG_REQUIRE(ctx, !d_in.cw && !d_in.tile_bits, "ig_fft: a chirp-z pass takes no lane split and no support bitmaps (the table's hulls only)");
     IG_REQUIRE(ctx, d_in.in_lo >= 0 && d_in.in_hi <= ax.n && d_in.out_lo >= 0 && d_in.out_hi <= ax.n, "ig_fft: chirp-z boxes must lie inside the axis");
     PassDesc d = d_in;
     if (d.ncols == 0) return IG_OK;
@@ -1469,8 +1479,12 @@ int launch_chirp_desc(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d_in) {
                    "ig_fft: axis stride too large for the chirp-z kernel");
     }
     const dim3 grid((unsigned)blocks), block((unsigned)(anyfft::AB_W * ch.sub.ab_B));
-    if (!(ig_abz_launch_part0(ctx->stream, ch.m, grid, block, d, ch.sub.d_tw) || ig_abz_launch_part1(ctx->stream, ch.m, grid, block, d, ch.sub.d_tw) ||
-          ig_abz_launch_part2(ctx->stream, ch.m, grid, block, d, ch.sub.d_tw) || ig_abz_launch_part3(ctx->stream, ch.m, grid, block, d, ch.sub.d_tw)))
+    int r = ig_abz_launch_part0(ctx->stream, ch.m, grid, block, d, ch.sub.d_tw);
+    if (!r) r = ig_abz_launch_part1(ctx->stream, ch.m, grid, block, d, ch.sub.d_tw);
+    if (!r) r = ig_abz_launch_part2(ctx->stream, ch.m, grid, block, d, ch.sub.d_tw);
+    if (!r) r = ig_abz_launch_part3(ctx->stream, ch.m, grid, block, d, ch.sub.d_tw);
+    if (r == 2) return ig_fail(ctx, IG_ERR_UNSUPPORTED, "ig_fft: device %d refused the LDS the chirp-z kernel over %lld points needs", ctx->device, (long long)ch.m);
+    if (!r)
         return ig_fail(ctx, IG_ERR_UNSUPPORTED, "ig_fft: no chirp-z kernel for m = %lld", (long long)ch.m);
     IG_LAUNCH_CHECK(ctx, "k_fft_chirp");
     return IG_OK;
@@ -1911,7 +1925,8 @@ static int exec_padded_layout2(ig_fft* p, const float2* x, int64_t x_bstride, co
         d.ext0 = C * n0; d.ext1 = n1; d.ncols = C * n0 * n1;
         d.in_lo = (int)l2; d.in_hi = (int)(l2 + b2); d.out_lo = 0; d.out_hi = (int)n2; d.inverse = 0;
         d.tile_range = support; d.tile_range_mode = 1; d.tile_range_k1 = snt; d.tile_shift = sshift;
-        if (support) {      // the output-side form of the bitmaps (it follows the input-side form where the two differ)
+        if (support && p->axis[2].kind != 5) {      // the output-side form of the bitmaps (it follows the input-side form where the two differ);
+                                                     // a chirp-z axis reads the hulls only
             d.tile_bits = reinterpret_cast<const uint32_t*>(support + n1 * snt + snt) + (p->zw_out != p->zw_in ? n1 * snt * p->zw_in : 0);
             d.tile_words = p->zw_out;
         }
@@ -1942,7 +1957,7 @@ static int exec_cropped_layout2(ig_fft* p, const float2* y, const float2* w, flo
         d.ext0 = C * n0; d.ext1 = n1; d.ncols = C * n0 * n1;
         d.in_lo = 0; d.in_hi = (int)n2; d.out_lo = (int)l2; d.out_hi = (int)(l2 + b2); d.inverse = 1;
         d.tile_range = support; d.tile_range_mode = 2; d.tile_range_k1 = snt; d.tile_shift = sshift;
-        if (support) { d.tile_bits = reinterpret_cast<const uint32_t*>(support + n1 * snt + snt); d.tile_words = p->zw_in; }
+        if (support && p->axis[2].kind != 5) { d.tile_bits = reinterpret_cast<const uint32_t*>(support + n1 * snt + snt); d.tile_words = p->zw_in; }
         if (support) d.k1_range = support + n1 * snt;                         // ky the y pass will never read
         if (int rc = launch_pass(ctx, p->axis[2], d, false, 0)) return rc;
     }
@@ -2024,7 +2039,7 @@ int ig_fft_exec_padded(ig_fft* p, const void* xv, int64_t x_bstride, const void*
     IG_REQUIRE(ctx, xv && yv, "ig_fft_exec_padded: NULL array");
     IG_REQUIRE(ctx, p->layout == 0 || workspace, "ig_fft_exec_padded: grid layouts 1 and 2 need the workspace");
     if (int rc = ig_set_device(ctx)) return rc;
-    IG_REQUIRE(ctx, !support || (p->layout >= 1 && !p->has_chirp_axis), "ig_fft_exec_padded: a support table needs grid layout 1 or 2 and no chirp-z axis");
+    IG_REQUIRE(ctx, !support || (p->layout >= 1 && (!p->has_chirp_axis || p->layout == 2)), "ig_fft_exec_padded: a support table needs grid layout 1 or 2 (chirp-z axes: layout 2, hulls only)");
     if (p->layout == 2)
         return exec_padded_layout2(p, (const float2*)xv, x_bstride, (const float2*)wv, (float2*)yv, (float2*)workspace,
                                    (const short2*)support);
@@ -2076,7 +2091,7 @@ int ig_fft_exec_cropped(ig_fft* p, const void* yv, const void* wv, void* xv, int
     IG_REQUIRE(ctx, p->padded, "ig_fft_exec_cropped: plan was not made by ig_fft_plan_padded");
     IG_REQUIRE(ctx, xv && yv && workspace, "ig_fft_exec_cropped: NULL array");
     if (int rc = ig_set_device(ctx)) return rc;
-    IG_REQUIRE(ctx, !support || (p->layout >= 1 && !p->has_chirp_axis), "ig_fft_exec_cropped: a support table needs grid layout 1 or 2 and no chirp-z axis");
+    IG_REQUIRE(ctx, !support || (p->layout >= 1 && (!p->has_chirp_axis || p->layout == 2)), "ig_fft_exec_cropped: a support table needs grid layout 1 or 2 (chirp-z axes: layout 2, hulls only)");
     if (p->layout == 2)
         return exec_cropped_layout2(p, (const float2*)yv, (const float2*)wv, (float2*)xv, (float2*)workspace,
                                     (const short2*)support);
@@ -2141,7 +2156,7 @@ int ig_fft_exec_cropped_sum(ig_fft* p, const void* yv, const void* wv, void* xv,
     ig_ctx* ctx = p->ctx;
     IG_REQUIRE(ctx, p->padded && p->layout == 2, "ig_fft_exec_cropped_sum: needs a plan of ig_fft_plan_padded with grid_layout 2");
     IG_REQUIRE(ctx, xv && yv && wv && workspace, "ig_fft_exec_cropped_sum: NULL array");
-    IG_REQUIRE(ctx, !support || !p->has_chirp_axis, "ig_fft_exec_cropped_sum: no support table on a grid with a chirp-z axis");
+    // (a grid with a chirp-z axis takes the table's hulls; its bitmaps are not read)
     if (int rc = ig_set_device(ctx)) return rc;
     return exec_cropped_layout2(p, (const float2*)yv, (const float2*)wv, (float2*)xv, (float2*)workspace,
                                 (const short2*)support, true);
@@ -2156,7 +2171,7 @@ int ig_fft_exec_cropped_sum_slab(ig_fft* p, const void* yv, const void* wv, void
     IG_REQUIRE(ctx, phase == 0 || phase == 1, "ig_fft_exec_cropped_sum_slab: phase must be 0 (z pass) or 1 (y and x passes of a slab)");
     IG_REQUIRE(ctx, phase == 0 || (0 <= z0 && z0 <= z1 && z1 <= p->box_dims[2]),
                "ig_fft_exec_cropped_sum_slab: slab [%lld, %lld) outside the image's %lld planes", (long long)z0, (long long)z1, (long long)p->box_dims[2]);
-    IG_REQUIRE(ctx, !support || !p->has_chirp_axis, "ig_fft_exec_cropped_sum_slab: no support table on a grid with a chirp-z axis");
+
     if (int rc = ig_set_device(ctx)) return rc;
     return exec_cropped_layout2(p, (const float2*)yv, (const float2*)wv, (float2*)xv, (float2*)workspace,
                                 (const short2*)support, true, phase == 0 ? 1 : 2, z0, z1);

@@ -62,29 +62,30 @@ class Harness(object):
         hip._scratch = None
         self.A = A = p.build_zpadfft(hip, chunk=self.chunk)
         self.children = list(A.children) if isinstance(A, op.VStack) else [A]
-        self.table = p.last_support_table
         n0, n1, n2 = p.oN
         self.P = n0 * n1 * n2
-        # flagged segments of the (ky, kz, kx-tile) grid, from the support table the tree's kernels write and read by
-        # (16 kx points per entry, or the finer table of the coil-interleaved trees)
-        fine = getattr(p, 'last_support_fine', None)
-        self.tile = tile = int(fine[1]) if fine is not None else 16
-        _, _, bits = p.split_support(fine[0] if fine is not None else self.table, tile)
-        nt = n0 // tile
-        b = bits.reshape(n1, nt, 16)                                     # [ky, kxt, kz % 16] bit kz // 16
-        kz = np.arange(n2)
-        self.flag = ((b[:, :, kz % 16] >> (kz // 16).astype(np.uint32)) & 1).astype(bool).transpose(0, 2, 1)   # [ky, kz, kxt]
         self.info = []
         x_d = hip.zero_array((A.shape[1], 1), C64)
         A.eval(x_d, self.k_d, forward=False)                             # formats are built on first use
         hip.barrier()
+        kz = np.arange(n2)
         for ch in self.children:
-            G = ch.left.right                                             # Product(KronI(nc, G'), ZpadFFT): KronI = Kron(Eye, G')
+            # a chunk padded with zero-weight coils (operators.HeadRows): the tree underneath evaluates `width` coils, its k-space
+            # rows beyond the real coils are zeros
+            tree = ch.child if isinstance(ch, op.HeadRows) else ch
+            G, Z = tree.left.right, tree.right                            # Product(KronI(nc, G'), ZpadFFT): KronI = Kron(Eye, G')
             M = G._matrix_d
-            nc = ch.shape[0] // p.T
-            sl = getattr(M, '_slots', None)
-            br = getattr(M, '_bricks', None)
-            fmt = sl if (sl is not None and sl['ncols'] == nc) else br if (br is not None and br['ncols'] == nc) else None
+            nc = tree.shape[0] // p.T                                     # panel width (with padding coils)
+            # flagged segments of the (ky, kz, kx-tile) grid, from the support table THIS chunk's kernels write and read by (16 kx
+            # points per entry, or the finer table of the 8- and 4-wide chunks): a tree of several widths carries several
+            tile = int(Z._tile_kw.get('support_tile', 16))
+            _, _, bits = p.split_support(Z._support_h, tile)
+            nt = n0 // tile
+            b = bits.reshape(n1, nt, 16)                                 # [ky, kxt, kz % 16] bit kz // 16
+            flag = ((b[:, :, kz % 16] >> (kz // 16).astype(np.uint32)) & 1).astype(bool).transpose(0, 2, 1)   # [ky, kz, kxt]
+            sl = M._format('_slots', nc, exact=True)
+            br = M._format('_bricks', nc, exact=True)
+            fmt = sl if sl is not None else br
             shared = np.zeros((n1, n2, nt), dtype=bool)                  # segments of bricks whose pieces add with atomics
             if fmt is not None and fmt['nshared']:
                 sb = fmt['shared'].to_host()[:fmt['nshared']].astype(np.int64)
@@ -95,17 +96,17 @@ class Harness(object):
                     for is_ in range(bs):
                         for xs in range(16 // tile):
                             shared[bsi * bs + is_, bmi * bm + im, bx * (16 // tile) + xs] = True
-            self.info.append(dict(nc=nc, fmt='slots' if fmt is sl and sl is not None else 'bricks' if fmt is not None else 'gather',
-                                  shared=shared, layout=ch.right._layout))
+            self.info.append(dict(nc=nc, real=ch.shape[0] // p.T, tree=tree, tile=tile, flag=flag,
+                                  fmt='slots' if (fmt is sl and sl is not None) else 'bricks' if fmt is not None else 'gather',
+                                  shared=shared, layout=Z._layout))
 
     def chunk_rows(self, i):
         lo = sum(c.shape[0] for c in self.children[:i])
         return lo, lo + self.children[i].shape[0]
 
-    def grid_view(self, g, nc, layout):
-        """host grid panel (P*nc,) -> [ky, kz, kx tile, point in tile, nc] view"""
+    def grid_view(self, g, nc, layout, t):
+        """host grid panel (P*nc,) -> [ky, kz, kx tile, point in tile, nc] view; t = kx points per support-table entry of the chunk"""
         n0, n1, n2 = self.p.oN
-        t = self.tile
         if layout == 2:
             return g.reshape(n1, n2, n0 // t, t, nc)
         return g.reshape(nc, n1, n2, n0 // t, t).transpose(1, 2, 3, 4, 0)
@@ -113,20 +114,29 @@ class Harness(object):
     # -- stages ---------------------------------------------------------------------------------------------------------------
     def scatter(self, i, poison_d):
         hip = self.hip
-        ch, inf = self.children[i], self.info[i]
-        lo, hi = self.chunk_rows(i)
+        inf = self.info[i]
         grid_d = hip.empty_array((self.P * inf['nc'], 1), C64)
         grid_d._copy(poison_d[inf['nc']])
-        ch.left.eval(grid_d, self.k_d[lo:hi], forward=False)
+        inf['tree'].left.eval(grid_d, self.chunk_k(i), forward=False)
         return grid_d.to_host().reshape(-1)
+
+    def chunk_k(self, i):
+        """the chunk's k-space rows on the device, zero rows appended for its padding coils"""
+        inf = self.info[i]
+        lo, hi = self.chunk_rows(i)
+        if inf['real'] == inf['nc']:
+            return self.k_d[lo:hi]
+        kp = np.zeros((self.p.T * inf['nc'], 1), dtype=C64)
+        kp[:hi - lo] = self.k[lo:hi]
+        return self.hip.copy_array(kp)
 
     def transform(self, i, grid_h):
         hip = self.hip
-        ch = self.children[i]
-        img_d = hip.empty_array((ch.shape[1], 1), C64)
+        tree = self.info[i]['tree']
+        img_d = hip.empty_array((tree.shape[1], 1), C64)
         img_d._copy(self.nan_img_d)
         g_d = hip.copy_array(grid_h.reshape(-1, 1))
-        ch.right.eval(img_d, g_d, forward=False)
+        tree.right.eval(img_d, g_d, forward=False)
         return img_d.to_host().reshape(-1)
 
     def chain(self, arena):
@@ -155,20 +165,23 @@ class Harness(object):
         self.ref = dict(grid=[], img=[], chain=None)
         for i, inf in enumerate(self.info):
             lo, hi = self.chunk_rows(i)
+            flag, tile = inf['flag'], inf['tile']
             g = self.scatter(i, self.poison)
-            v = self.grid_view(g, inf['nc'], inf['layout'])
+            v = self.grid_view(g, inf['nc'], inf['layout'], tile)
             # nobody writes unflagged segments; flagged ones equal G^H k
-            assert np.isnan(v[~self.flag].real).all(), "chunk %d: the scatter wrote an unflagged segment" % i
-            exp = GH @ self.k[lo:hi].reshape(p.T, inf['nc'], order='F').astype(np.complex128)      # (P, nc), layout-1 rows
+            assert np.isnan(v[~flag].real).all(), "chunk %d: the scatter wrote an unflagged segment" % i
+            kc = np.zeros((p.T, inf['nc']), dtype=np.complex128)
+            kc[:, :inf['real']] = self.k[lo:hi].reshape(p.T, inf['real'], order='F')               # (padding coils: zero rows)
+            exp = GH @ kc                                                                           # (P, nc), layout-1 rows
             n0, n1, n2 = p.oN
-            e = exp.reshape(n1, n2, n0 // self.tile, self.tile, inf['nc'])
-            err = np.linalg.norm((v[self.flag] - e[self.flag]).ravel()) / np.linalg.norm(e[self.flag].ravel())
+            e = exp.reshape(n1, n2, n0 // tile, tile, inf['nc'])
+            err = np.linalg.norm((v[flag] - e[flag]).ravel()) / np.linalg.norm(e[flag].ravel())
             assert err < 1e-5, "chunk %d (%d coils, %s): first scatter %.3e off scipy's G^H k" % (i, inf['nc'], inf['fmt'], err)
-            assert np.count_nonzero(e[~self.flag]) == 0
+            assert np.count_nonzero(e[~flag]) == 0
             self.ref['grid'].append(g)
             self.ref['img'].append(self.transform(i, g))
             self.log("chunk %d: %d coil(s), layout %d, %s, %d shared segments of %d flagged; scatter vs scipy %.2e"
-                     % (i, inf['nc'], inf['layout'], inf['fmt'], int((inf['shared'] & self.flag).sum()), int(self.flag.sum()), err))
+                     % (i, inf['nc'], inf['layout'], inf['fmt'], int((inf['shared'] & flag).sum()), int(flag.sum()), err))
         self.ref['chain'] = self.chain(arena=False)
         total = np.sum(self.ref['img'], axis=0)
         self.log("chain vs sum of stage images: %.2e" % rel(self.ref['chain'], total))
@@ -185,21 +198,22 @@ class Harness(object):
         bad = []
         for i, inf in enumerate(self.info):
             g = self.scatter(i, self.poison)
-            v, r = self.grid_view(g, inf['nc'], inf['layout']), self.grid_view(self.ref['grid'][i], inf['nc'], inf['layout'])
-            if not np.isnan(v[~self.flag].real).all():
+            flag = inf['flag']
+            v, r = self.grid_view(g, inf['nc'], inf['layout'], inf['tile']), self.grid_view(self.ref['grid'][i], inf['nc'], inf['layout'], inf['tile'])
+            if not np.isnan(v[~flag].real).all():
                 bad.append("it %d chunk %d (%d coils, %s): %d values written into unflagged segments"
-                           % (it, i, inf['nc'], inf['fmt'], int((~np.isnan(v[~self.flag].real)).sum())))
-            own = self.flag & ~inf['shared']
+                           % (it, i, inf['nc'], inf['fmt'], int((~np.isnan(v[~flag].real)).sum())))
+            own = flag & ~inf['shared']
             same = (v.view(np.uint32) == r.view(np.uint32)).reshape(v.shape[:3] + (-1,)).all(axis=3)     # per segment
             diff = own & ~same
             if diff.any():
                 ky, kz, kxt = np.nonzero(diff)
                 dv = np.abs(np.nan_to_num(v[diff], nan=1e30) - r[diff]).max()
                 bad.append("it %d chunk %d (%d coils, %s): %d NON-SHARED segments differ bitwise (max |d| %.3e, grid max %.3e); first (ky,kz,kxt): %s; nan %d zero %d"
-                           % (it, i, inf['nc'], inf['fmt'], int(diff.sum()), dv, np.abs(r[self.flag]).max(),
+                           % (it, i, inf['nc'], inf['fmt'], int(diff.sum()), dv, np.abs(r[flag]).max(),
                               list(zip(ky[:6].tolist(), kz[:6].tolist(), kxt[:6].tolist())),
                               int(np.isnan(v[diff].real).sum()), int((v[diff] == 0).sum())))
-            sh = self.flag & inf['shared']
+            sh = flag & inf['shared']
             if sh.any():
                 scale = np.abs(r[sh]).max()
                 d = np.abs(np.nan_to_num(v[sh], nan=1e30) - r[sh]).max() / scale

@@ -81,8 +81,18 @@ def test_pics_on_a_non_power_of_two_grid(tmp_path, hip, oracle_backend, caplog):
     assert _rel(out, ref) < 1e-3
     base = pics.main(["-O", "0"] + args, backend=hip)
     assert _rel(out, base) < 2e-4
-    # three coils split into a pair and a single one: the single coil has no interleaved layout, the tree keeps its -O3 leaves
-    assert not hip.supports_padded_fft((160, 160, 160), 3)
+    # three coils (the reference takes any count, examples/pics.py:93): ONE 4-wide interleaved chunk whose fourth coil has zero
+    # weights -- the fused leaf on this grid too, the same image as the unfused leaves
+    assert hip.supports_padded_fft((160, 160, 160), 3)
+    (tmp_path / "c3").mkdir()
+    path3, _ = _scan(tmp_path / "c3", hip, N, 3, nro=160, nsp=300, osf=1.25, width=3)
+    args3 = ["-i", "3", "--osf", "1.25", "--width", "3", "--lamda", "1e-3", "--debug", "40", path3]
+    caplog.clear()
+    with caplog.at_level(logging.INFO, logger="pics"):
+        out3 = pics.main(["-O", "3"] + args3, backend=hip)
+    tree3 = [r.getMessage() for r in caplog.records if r.getMessage().startswith("tree:")][-1]
+    assert "ZpadFFT" in tree3 and "HeadRows" in tree3 and "UnscaledFFT" not in tree3, tree3
+    assert _rel(out3, pics.main(["-O", "3", "--no-fuse"] + args3, backend=hip)) < 2e-4
 
 
 def test_pics_at_the_reference_drivers_default_oversampling(tmp_path, hip, oracle_backend, caplog):

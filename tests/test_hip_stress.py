@@ -25,12 +25,33 @@ def test_adjoint_of_coil_chunks_is_bitwise_repeatable(hip, oracle_backend):
 
 
 def test_adjoint_of_eight_coil_bricks_is_bitwise_repeatable(hip):
-    """the same for the round format (k_grid_bricks<8,8>, 8-point support table) of the headline tree, at reduced size"""
+    """the same for the round format of the headline tree at reduced size: k_grid_bricks<8, 8, PAIR> writing by the 4-point support
+    table (pairs of 4-cell segments per wave store), 8-byte real-weight entries"""
     import stress_adjoint
     h = stress_adjoint.Harness(hip, coils=8, chunk=8, log=lambda s: None)
     h.make_references(None)
     findings = []
     for it in range(10):
+        findings += h.check(it)
+    hip._scratch = None
+    assert not findings, "\n".join(findings)
+
+
+@pytest.mark.parametrize("coils,chunk,widths", [(6, 4, [4, 2]), (7, 4, [4, 4])])
+def test_adjoint_of_chunks_of_different_widths_is_bitwise_repeatable(hip, oracle_backend, coils, chunk, widths):
+    """Chunks of DIFFERENT widths under one VStack -- 6 coils as 4 + 2: the brick rounds of the 4-wide chunk write by the 8-point
+    table, the slots of the 2-wide one by the 16-point table, both formats and both tables on ONE device matrix, the repacked-panel
+    buffer of the library resized between them, the scratch arena reused chunk after chunk -- and a chunk padded with a zero-weight
+    coil (7 coils as 4 + 4, operators.HeadRows).  Every stage of every chunk bit for bit against its first evaluation over
+    NaN-poisoned memory, the chain against the oracle; a deviation names stage, chunk, bricks and whether they are shared."""
+    import stress_adjoint
+    h = stress_adjoint.Harness(hip, coils=coils, chunk=chunk, log=lambda s: None)
+    assert [inf['nc'] for inf in h.info] == widths
+    h.make_references(oracle_backend)
+    findings = []
+    for it in range(12):
+        if it == 6:
+            h.build()
         findings += h.check(it)
     hip._scratch = None
     assert not findings, "\n".join(findings)

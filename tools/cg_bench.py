@@ -26,6 +26,19 @@ t0 = time.perf_counter()
 hist = B.cg(AHA, b_d, x_d, maxiter=iters)
 B.barrier()
 t = time.perf_counter() - t0
+# the same solve on plain launches (no HIP graph), and the steady state of the graph route: a long solve minus a short one
+def solve(n, graph):
+    B.tuning['cg_graph'] = graph
+    xx = B.zero_array(b.shape, b.dtype)
+    B.barrier()
+    t1 = time.perf_counter()
+    B.cg(AHA, b_d, xx, maxiter=n, tol=0.0)
+    B.barrier()
+    return time.perf_counter() - t1
+for graph in (False, True):
+    ta, tb = solve(30, graph), solve(130, graph)
+    print("cg_graph=%s: 30 iterations %.1f ms, 130 iterations %.1f ms -> steady state %.3f ms/iteration" % (graph, ta * 1e3, tb * 1e3, (tb - ta) * 1e3 / 100))
+B.tuning['cg_graph'] = True
 print("history:", " ".join("%.3f" % h for h in hist)); print("CG: %d iterations in %.1f ms -> %.2f ms/iteration (%.1f it/s); relative residual %.3e -> %.3e" % (
     len(hist), t * 1e3, t * 1e3 / max(len(hist), 1), len(hist) / t, hist[0], hist[-1]))
 

@@ -3,8 +3,12 @@
 # and the default line with its dense-trajectory extra
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 1000 python -m pytest tests -m gpu -x -q > gpurun_out/r05b_gputest.log 2>&1 || { tail -40 gpurun_out/r05b_gputest.log; exit 1; }
+timeout -k 10 1000 python -m pytest ${R05_TESTS:-tests} -m gpu -x -q > gpurun_out/r05b_gputest.log 2>&1 || { tail -40 gpurun_out/r05b_gputest.log; exit 1; }
 tail -2 gpurun_out/r05b_gputest.log
+timeout -k 10 300 python bench.py --tree recipe --steps 5 --no-extras --no-cpu-baseline > gpurun_out/r05b_bench_tree_recipe.json 2> gpurun_out/r05b_bench_tree_recipe.log || { tail -20 gpurun_out/r05b_bench_tree_recipe.log; exit 1; }
+python -c "import json;d=json.load(open('gpurun_out/r05b_bench_tree_recipe.json'));print('tree recipe', round(d['ms_per_step'],3), 'setup_s', d['setup_s'], d['roofline']['frac'])"
+(time timeout -k 10 300 python tools/lab/pics_default_grid.py) > gpurun_out/r05b_pics_default_grid.log 2>&1 || { tail -20 gpurun_out/r05b_pics_default_grid.log; exit 1; }
+tail -6 gpurun_out/r05b_pics_default_grid.log
 for c in 12 6 3 5 7 9; do
   timeout -k 10 300 python bench.py --coils $c --steps 10 --no-extras --no-cpu-baseline > gpurun_out/r05b_bench_coils$c.json 2> gpurun_out/r05b_bench_coils$c.log || { tail -20 gpurun_out/r05b_bench_coils$c.log; exit 1; }
   python -c "import json;d=json.load(open('gpurun_out/r05b_bench_coils$c.json'));print('coils $c', round(d['ms_per_step'],3), d['config']['coil_chunk_widths'], 'setup', d['setup_s'])"

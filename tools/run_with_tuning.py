@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Kernel-lab helper: run bench.py with entries of HipBackend.tuning overridden (the product reads no environment switches):
-    python tools/run_with_tuning.py tiles64=64 xrows=False -- --config 3 --steps 5"""
+    python tools/run_with_tuning.py tiles64=64 xrows=False -- --config 3 --steps 5
+    python tools/run_with_tuning.py opt:fft.kernels=1 -- --steps 20 --no-extras          (a plan option of the library)"""
 import ast
 import os
 import runpy
@@ -19,7 +20,10 @@ _init = H.HipBackend.__init__
 
 def patched(self, *a, **k):
     _init(self, *a, **k)
-    self.tuning.update(over)
+    self.tuning.update({k: v for k, v in over.items() if not k.startswith("opt:")})
+    for k, v in over.items():          # opt:<name>=<value>: a plan option of the library (ig_set_option), e.g. opt:fft.kernels=1
+        if k.startswith("opt:"):
+            self.set_option(k[4:], v)
 
 
 H.HipBackend.__init__ = patched
