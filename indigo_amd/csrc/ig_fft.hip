@@ -34,6 +34,7 @@
 //
 // The inverse transform is computed as conj(FFT(conj(x))).
 #include "ig_common.h"
+#include "ig_packed.h"
 #include "ig_fft_ab.h"
 #include "ig_fft_ab_list.h"
 #include <vector>
@@ -252,58 +253,7 @@ template <int N> struct RegFFTHalfIn {
     }
 };
 
-// ---- packed complex arithmetic for the two-stage kernel ---------------------------------------------------------
-// A complex number is ONE 64-bit register pair (native 2-vector): complex add/sub is a single v_pk_add_f32, a complex
-// multiply is v_pk_mul_f32 + v_pk_fma_f32 with operand swizzles, multiplication by -i is a swizzle with a sign
-// modifier.  Written on float2 structs the same butterflies compile to scalar v_add/v_mul/v_fmac, twice the VALU
-// instructions -- and these kernels are bound by instruction issue as much as by HBM (SIMDs ~85 % busy).
-typedef float v2f __attribute__((ext_vector_type(2)));
-struct cx { v2f v; };
-__device__ __forceinline__ cx mk(float re, float im) { cx r; r.v = v2f{re, im}; return r; }
-__device__ __forceinline__ cx from2(float2 a) { return mk(a.x, a.y); }
-__device__ __forceinline__ float2 to2(cx a) { return make_float2(a.v.x, a.v.y); }
-__device__ __forceinline__ cx operator+(cx a, cx b) { cx r; r.v = a.v + b.v; return r; }
-__device__ __forceinline__ cx operator-(cx a, cx b) { cx r; r.v = a.v - b.v; return r; }
-__device__ __forceinline__ cx cneg(cx a) { cx r; r.v = -a.v; return r; }
-__device__ __forceinline__ cx cconj(cx a) { cx r; r.v = v2f{a.v.x, -a.v.y}; return r; }
-// Multiplications by -+i and the twiddle products with a RUN-TIME root are single packed instructions with operand swizzles
-// (op_sel) and sign modifiers -- written as assembly, because from vector shuffles the compiler builds the rotated operand
-// (-w.y, w.x) with a v_xor and a v_mov first: two extra vector instructions per twiddle and per -i, 130 of the 800 of a 512-point
-// pass.  (Pure register operations: the compiler schedules them like any other instruction.)
-__device__ __forceinline__ cx cmul_mi(cx a) {          // a * (-i) = (a.y, -a.x)
-    cx r; asm("v_pk_add_f32 %0, %1, 0 op_sel:[1,0] op_sel_hi:[0,1] neg_hi:[1,0]" : "=v"(r.v) : "v"(a.v)); return r;
-}
-__device__ __forceinline__ cx cmul_pi(cx a) {          // a * (+i) = (-a.y, a.x)
-    cx r; asm("v_pk_add_f32 %0, %1, 0 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[1,0]" : "=v"(r.v) : "v"(a.v)); return r;
-}
-__device__ __forceinline__ cx cmul_mi_c(cx a) { cx r; r.v = v2f{a.v.y, -a.v.x}; return r; }          // (compiler-lowered forms: k_fft3d_b)
-__device__ __forceinline__ cx cmul_pi_c(cx a) { cx r; r.v = v2f{-a.v.y, a.v.x}; return r; }
-__device__ __forceinline__ cx padd_mi(cx a, cx b) {    // a + (-i) b = (a.x + b.y, a.y - b.x)
-    cx r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r.v) : "v"(a.v), "v"(b.v)); return r;
-}
-__device__ __forceinline__ cx padd_pi(cx a, cx b) {    // a + (+i) b = (a.x - b.y, a.y + b.x)
-    cx r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r.v) : "v"(a.v), "v"(b.v)); return r;
-}
-// a * w = a.xx * (w.x, w.y) + a.yy * (-w.y, w.x)   (w a literal: the compiler folds the rotation into the constants)
-__device__ __forceinline__ cx cxmul(cx a, cx w) {
-    cx r;
-    r.v = __builtin_shufflevector(a.v, a.v, 0, 0) * w.v + __builtin_shufflevector(a.v, a.v, 1, 1) * v2f{-w.v.y, w.v.x};
-    return r;
-}
-// the same with w in registers (twiddles out of LDS, weights out of memory): two instructions, no rotated copy of w
-__device__ __forceinline__ cx cxmul_r(cx a, cx w) {
-    cx t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t.v) : "v"(a.v), "v"(w.v));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r.v) : "v"(a.v), "v"(w.v), "v"(t.v));
-    return r;
-}
-// conj(w) * a = a.xx * (w.x, -w.y) + a.yy * (w.y, w.x), w in registers
-__device__ __forceinline__ cx cxmulc(cx w, cx a) {
-    cx t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(t.v) : "v"(a.v), "v"(w.v));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(r.v) : "v"(a.v), "v"(w.v), "v"(t.v));
-    return r;
-}
+// (packed complex arithmetic -- one 64-bit register pair per complex number, v_pk_* instructions: ig_packed.h)
 __device__ __forceinline__ void pbfly2(cx& a, cx& b) { const cx t = a - b; a = a + b; b = t; }
 // Direction as arithmetic: INV = true is the same butterfly network with every constant conjugated (the unnormalised inverse
 // DFT), so an inverse pass needs no conjugation of its inputs and outputs -- that cost the cropped passes two VALU
@@ -1371,6 +1321,10 @@ int launch_ab_desc(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d_in, int wm
         IG_REQUIRE(ctx, d.cw == 2 || d.cw == 4 || d.cw == 8 || d.cw == 16, "ig_fft: the coil-summing A x B pass takes 2, 4, 8 or 16 interleaved coils");
         wm = d.cw == 2 ? 4 : d.cw == 4 ? 5 : d.cw == 8 ? 6 : 7;
     }
+    // (Round 5, measured and removed: 32-column tiles on these passes, as on the power-of-two kernel.  Image 256^3 x 8 coils on the
+    // 320^3 grid, same box, alternating runs: 4.03 / 4.08 ms per evaluation against 3.84 / 3.86 ms on 16-column tiles -- padded z
+    // 0.56 against 0.47 ms, padded y 0.61-0.63 against 0.57: 20 threads per column make a 32-column workgroup 10 waves with an 80 KB
+    // exchange image.  profiles/r05_lab_osf125_ab_w32_{1,0}.json)
     const dim3 grid((unsigned)blocks), block((unsigned)(anyfft::AB_W * ax.ab_B));
     int r = ig_abd_launch_part0(ctx->stream, ax.n, wm, grid, block, d, ax.d_tw);
     if (!r) r = ig_abd_launch_part1(ctx->stream, ax.n, wm, grid, block, d, ax.d_tw);

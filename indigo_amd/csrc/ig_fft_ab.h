@@ -59,6 +59,8 @@ struct PassDesc {
 };
 
 
+#include "ig_packed.h"
+
 namespace anyfft {
 
 constexpr double kPi = 3.14159265358979323846264338327950288;
@@ -104,6 +106,21 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
+// ---- the element type of the generated DFTs: float2 (scalar arithmetic: the bandwidth-bound A x B passes) or cx (ig_packed.h:
+// one v_pk_* instruction per complex add, two per complex product: the compute-bound chirp-z passes) ----------------------------
+__device__ __forceinline__ float2 d_add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 d_sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 d_addmi(float2 a, float2 b) { return make_float2(a.x + b.y, a.y - b.x); }      // a + (-i) b
+__device__ __forceinline__ float2 d_addpi(float2 a, float2 b) { return make_float2(a.x - b.y, a.y + b.x); }      // a + (+i) b
+__device__ __forceinline__ float2 d_fma_r(float c, float2 t, float2 acc) { return make_float2(fmaf(c, t.x, acc.x), fmaf(c, t.y, acc.y)); }
+__device__ __forceinline__ float2 d_mul_r(float c, float2 t) { return make_float2(c * t.x, c * t.y); }
+__device__ __forceinline__ cx d_add(cx a, cx b) { return a + b; }
+__device__ __forceinline__ cx d_sub(cx a, cx b) { return a - b; }
+__device__ __forceinline__ cx d_addmi(cx a, cx b) { return padd_mi(a, b); }
+__device__ __forceinline__ cx d_addpi(cx a, cx b) { return padd_pi(a, b); }
+__device__ __forceinline__ cx d_fma_r(float c, cx t, cx acc) { return cfma_r(c, t, acc); }
+__device__ __forceinline__ cx d_mul_r(float c, cx t) { cx r; r.v = t.v * v2f{c, c}; return r; }
+
 // a * exp(-2 pi i M / N) with M, N compile-time: rotations by multiples of a quarter turn cost no multiply
 template <int M, int N>
 __device__ __forceinline__ float2 rot(float2 a) {
@@ -117,79 +134,88 @@ __device__ __forceinline__ float2 rot(float2 a) {
         return make_float2(fmaf(a.x, c, -a.y * s), fmaf(a.x, s, a.y * c));
     }
 }
+template <int M, int N>
+__device__ __forceinline__ cx rot(cx a) {
+    constexpr int r = c_mod(M, N);
+    if constexpr (r == 0) return a;
+    else if constexpr (4 * r == N) return cmul_mi(a);
+    else if constexpr (2 * r == N) return cneg(a);
+    else if constexpr (4 * r == 3 * N) return cmul_pi(a);
+    else {
+        constexpr float c = cos2pi(r, N), s = -sin2pi(r, N);          // w = c + i s
+        return cxmul(a, mk(c, s));
+    }
+}
 
 constexpr int pick_radix(int n) { return n % 4 == 0 ? 4 : n % 2 == 0 ? 2 : n % 3 == 0 ? 3 : n % 5 == 0 ? 5 : n % 7 == 0 ? 7 : n; }
 
-// forward DFT of N register values, in place, natural order
-template <int N, bool BASE = (pick_radix(N) == N)>
+// forward DFT of N register values of type T (float2 or cx), in place, natural order
+template <int N, typename T = float2, bool BASE = (pick_radix(N) == N)>
 struct RegDFT;
 
-template <> struct RegDFT<1, true> { __device__ static __forceinline__ void run(float2 (&)[1]) {} };
-template <> struct RegDFT<2, true> {
-    __device__ static __forceinline__ void run(float2 (&x)[2]) {
-        const float2 a = x[0], b = x[1];
-        x[0] = make_float2(a.x + b.x, a.y + b.y); x[1] = make_float2(a.x - b.x, a.y - b.y);
+template <typename T> struct RegDFT<1, T, true> { __device__ static __forceinline__ void run(T (&)[1]) {} };
+template <typename T> struct RegDFT<2, T, true> {
+    __device__ static __forceinline__ void run(T (&x)[2]) {
+        const T a = x[0], b = x[1];
+        x[0] = d_add(a, b); x[1] = d_sub(a, b);
     }
 };
-template <> struct RegDFT<4, true> {
-    __device__ static __forceinline__ void run(float2 (&x)[4]) {
-        const float2 t0 = make_float2(x[0].x + x[2].x, x[0].y + x[2].y), t1 = make_float2(x[0].x - x[2].x, x[0].y - x[2].y);
-        const float2 t2 = make_float2(x[1].x + x[3].x, x[1].y + x[3].y);
-        const float2 d = make_float2(x[1].x - x[3].x, x[1].y - x[3].y), t3 = make_float2(d.y, -d.x);      // -i (x1 - x3)
-        x[0] = make_float2(t0.x + t2.x, t0.y + t2.y); x[2] = make_float2(t0.x - t2.x, t0.y - t2.y);
-        x[1] = make_float2(t1.x + t3.x, t1.y + t3.y); x[3] = make_float2(t1.x - t3.x, t1.y - t3.y);
+template <typename T> struct RegDFT<4, T, true> {
+    __device__ static __forceinline__ void run(T (&x)[4]) {
+        const T t0 = d_add(x[0], x[2]), t1 = d_sub(x[0], x[2]), t2 = d_add(x[1], x[3]), d = d_sub(x[1], x[3]);
+        x[0] = d_add(t0, t2); x[2] = d_sub(t0, t2);
+        x[1] = d_addmi(t1, d); x[3] = d_addpi(t1, d);              // t1 -+ i (x1 - x3)
     }
 };
 // odd primes (3, 5, 7): X_k, X_{P-k} = a_k -/+ i b_k with a_k = x0 + sum_q cos(2 pi q k / P) (x_q + x_{P-q}),
 // b_k = sum_q sin(2 pi q k / P) (x_q - x_{P-q})
-template <int P>
-struct RegDFT<P, true> {
+template <int P, typename T>
+struct RegDFT<P, T, true> {
     static_assert(P == 3 || P == 5 || P == 7, "RegDFT: lengths with factors 2, 3, 5, 7 only");
-    __device__ static __forceinline__ void run(float2 (&x)[P]) {
+    __device__ static __forceinline__ void run(T (&x)[P]) {
         constexpr int H = (P - 1) / 2;
-        float2 t[H], d[H];
+        T t[H], d[H];
         static_for<0, H>([&](auto q_) {
             constexpr int q = decltype(q_)::value + 1;
-            t[q - 1] = make_float2(x[q].x + x[P - q].x, x[q].y + x[P - q].y);
-            d[q - 1] = make_float2(x[q].x - x[P - q].x, x[q].y - x[P - q].y);
+            t[q - 1] = d_add(x[q], x[P - q]);
+            d[q - 1] = d_sub(x[q], x[P - q]);
         });
-        const float2 x0 = x[0];
-        float2 s0 = x0;
-        static_for<0, H>([&](auto q_) { s0.x += t[decltype(q_)::value].x; s0.y += t[decltype(q_)::value].y; });
+        const T x0 = x[0];
+        T s0 = x0;
+        static_for<0, H>([&](auto q_) { s0 = d_add(s0, t[decltype(q_)::value]); });
         x[0] = s0;
         static_for<0, H>([&](auto k_) {
             constexpr int k = decltype(k_)::value + 1;
-            float2 a = x0, b = make_float2(0.f, 0.f);
+            T a = x0, b = d_mul_r(sin2pi(k, P), d[0]);
             static_for<0, H>([&](auto q_) {
                 constexpr int q = decltype(q_)::value + 1;
                 constexpr float c = cos2pi(q * k, P), s = sin2pi(q * k, P);
-                a.x = fmaf(c, t[q - 1].x, a.x); a.y = fmaf(c, t[q - 1].y, a.y);
-                b.x = fmaf(s, d[q - 1].x, b.x); b.y = fmaf(s, d[q - 1].y, b.y);
+                a = d_fma_r(c, t[q - 1], a);
+                if constexpr (q > 1) b = d_fma_r(s, d[q - 1], b);
             });
-            // -i b = (b.y, -b.x)
-            x[k] = make_float2(a.x + b.y, a.y - b.x);
-            x[P - k] = make_float2(a.x - b.y, a.y + b.x);
+            x[k] = d_addmi(a, b);               // a - i b
+            x[P - k] = d_addpi(a, b);
         });
     }
 };
 // composite N = P Q:  n = Q n1 + n2,  k = k1 + P k2
-template <int N>
-struct RegDFT<N, false> {
-    __device__ static __forceinline__ void run(float2 (&x)[N]) {
+template <int N, typename T>
+struct RegDFT<N, T, false> {
+    __device__ static __forceinline__ void run(T (&x)[N]) {
         constexpr int P = pick_radix(N), Q = N / P;
-        float2 y[Q][P];
+        T y[Q][P];
         static_for<0, Q>([&](auto n2_) {
             constexpr int n2 = decltype(n2_)::value;
-            float2 a[P];
+            T a[P];
             static_for<0, P>([&](auto n1_) { constexpr int n1 = decltype(n1_)::value; a[n1] = x[Q * n1 + n2]; });
-            RegDFT<P>::run(a);
+            RegDFT<P, T>::run(a);
             static_for<0, P>([&](auto k1_) { constexpr int k1 = decltype(k1_)::value; y[n2][k1] = rot<n2 * k1, N>(a[k1]); });
         });
         static_for<0, P>([&](auto k1_) {
             constexpr int k1 = decltype(k1_)::value;
-            float2 b[Q];
+            T b[Q];
             static_for<0, Q>([&](auto n2_) { constexpr int n2 = decltype(n2_)::value; b[n2] = y[n2][k1]; });
-            RegDFT<Q>::run(b);
+            RegDFT<Q, T>::run(b);
             static_for<0, Q>([&](auto k2_) { constexpr int k2 = decltype(k2_)::value; x[k1 + P * k2] = b[k2]; });
         });
     }
@@ -296,23 +322,26 @@ __device__ __forceinline__ int ab_ceil_div_clamp(int num, int den, int hi) {    
     return q > hi ? hi : q;
 }
 
-template <int A, int B, int ROUNDS, int WMODE>
-__global__ void __launch_bounds__(AB_W * B)
+template <int AR, int B, int W>
+__device__ __forceinline__ int abd_slot(int k1, int b, int w) { return (k1 * B + b) * W + w; }
+
+template <int A, int B, int ROUNDS, int WMODE, int W = AB_W>          // W columns per workgroup (16: 32 were measured in round 5 and lost)
+__global__ void __launch_bounds__(W * B)
 k_fft_ab_desc(PassDesc d, const float2* __restrict__ tw) {
     constexpr int N = A * B, AR = (A + ROUNDS - 1) / ROUNDS;
     constexpr int SUMW = WMODE >= 3 ? (1 << (WMODE - 3)) : 0;
     static_assert(A <= 32 && B <= 32, "element masks are 32-bit words");
     extern __shared__ float2 lds[];
-    float2* __restrict__ tws = lds + AR * B * AB_W;
+    float2* __restrict__ tws = lds + AR * B * W;
     const int tid = threadIdx.x;
-    for (int k = tid; k < N; k += AB_W * B) tws[k] = tw[k];
-    const int b = tid / AB_W, w = tid % AB_W;
+    for (int k = tid; k < N; k += W * B) tws[k] = tw[k];
+    const int b = tid / W, w = tid % W;
     const bool inv = d.inverse != 0;
     // the workgroup's tile: 16 consecutive k0 (or 16 / cw columns x cw sub-columns) of one (k1, k2) row
     const unsigned tile = blockIdx.x;
     const unsigned tr = tile % d.tpr, rest = tile / d.tpr;
     const unsigned k1i = rest % d.ext1, k2i = rest / d.ext1;
-    const int64_t k0u = (int64_t)tr * (d.cw ? AB_W / d.cw : AB_W);
+    const int64_t k0u = (int64_t)tr * (d.cw ? W / d.cw : W);
     const float2* const b_in = d.in + (k0u * d.in_s[0] + (int64_t)k1i * d.in_s[1] + (int64_t)k2i * d.in_s[2]);
     float2* const b_out = d.out + (k0u * d.out_s[0] + (int64_t)k1i * d.out_s[1] + (int64_t)k2i * d.out_s[2]);
     const float2* const b_w = WMODE ? d.w + (k0u * d.w_s[0] + (int64_t)k1i * d.w_s[1] + (int64_t)k2i * d.w_s[2]) : nullptr;
@@ -362,12 +391,12 @@ k_fft_ab_desc(PassDesc d, const float2* __restrict__ tw) {
     if (d.tile_bits) { if (d.tile_range_mode == 1) obits &= zb; else ibits &= zb; }
     uint32_t gin = 0;                                          // wave-uniform: elements SOME lane of this wave wants
 #pragma unroll
-    for (int l = 0; l < 64; l += AB_W) gin |= (uint32_t)__builtin_amdgcn_readlane((int)ibits, l);
+    for (int l = 0; l < 64; l += W) gin |= (uint32_t)__builtin_amdgcn_readlane((int)ibits, l);
     uint32_t gout = 0xffffffffu;                               // the same for the outputs (unweighted passes gate their stores with it)
     if (WMODE == 0) {
         gout = 0;
 #pragma unroll
-        for (int l = 0; l < 64; l += AB_W) gout |= (uint32_t)__builtin_amdgcn_readlane((int)obits, l);
+        for (int l = 0; l < 64; l += W) gout |= (uint32_t)__builtin_amdgcn_readlane((int)obits, l);
     }
 
     float2 v[A];
@@ -398,13 +427,13 @@ k_fft_ab_desc(PassDesc d, const float2* __restrict__ tw) {
         if (r) __syncthreads();
 #pragma unroll
         for (int k1 = 0; k1 < A; ++k1)
-            if (k1 >= r * AR && k1 < (r + 1) * AR) lds[ab_slot<AR, B, false>(k1 - r * AR, b, w)] = v[k1];
+            if (k1 >= r * AR && k1 < (r + 1) * AR) lds[abd_slot<AR, B, W>(k1 - r * AR, b, w)] = v[k1];
         __syncthreads();
         const int k1 = b;                              // stage 2: this thread's output residue
         if (k1 >= r * AR && k1 < (r + 1) * AR && k1 < A) {
             float2 u[B];
 #pragma unroll
-            for (int bb = 0; bb < B; ++bb) u[bb] = lds[ab_slot<AR, B, false>(k1 - r * AR, bb, w)];
+            for (int bb = 0; bb < B; ++bb) u[bb] = lds[abd_slot<AR, B, W>(k1 - r * AR, bb, w)];
             RegDFT<B>::run(u);
             float2 wv[B];
             if (WMODE >= 2) {
@@ -452,8 +481,14 @@ k_fft_chirp(PassDesc d, const float2* __restrict__ tw) {
     constexpr int EX1 = AR * B * AB_W, EX2 = BR * A * AB_W;
     extern __shared__ float2 lds[];
     float2* __restrict__ tws = lds + (EX1 > EX2 ? EX1 : EX2);
+    // The chirp, its transform and the output weights in LDS beside the twiddles (round 5): a thread reads 2 A + B of them, the same
+    // for all 16 columns of its row -- as global loads they were three times the tile's own loads and stores in vector-memory
+    // instructions, every one a 16-lane broadcast through the address unit.
+    float2* __restrict__ t_b = tws + N;
+    float2* __restrict__ t_hat = t_b + N;
+    float2* __restrict__ t_out = t_hat + N;
     const int tid = threadIdx.x;
-    for (int k = tid; k < N; k += AB_W * B) tws[k] = tw[k];
+    for (int k = tid; k < N; k += AB_W * B) { tws[k] = tw[k]; t_b[k] = d.w[k]; t_hat[k] = d.w2[k]; t_out[k] = d.w2[N + k]; }
     const int b = tid / AB_W, w = tid % AB_W;
     const unsigned tile = blockIdx.x;
     const unsigned tr = tile % d.tpr, rest = tile / d.tpr;
@@ -495,44 +530,45 @@ k_fft_chirp(PassDesc d, const float2* __restrict__ tw) {
     uint32_t gin = 0, gout = 0;
 #pragma unroll
     for (int l = 0; l < 64; l += AB_W) { gin |= (uint32_t)__builtin_amdgcn_readlane((int)ibits, l); gout |= (uint32_t)__builtin_amdgcn_readlane((int)obits, l); }
-    const float2* __restrict__ t_b = d.w;
-    const float2* __restrict__ t_hat = d.w2;
-    const float2* __restrict__ t_out = d.w2 + N;
-    auto cm = [](float2 a, float2 c) { return make_float2(fmaf(a.x, c.x, -a.y * c.y), fmaf(a.x, c.y, a.y * c.x)); };
+    // Packed arithmetic throughout (cx, ig_packed.h): these passes are bound by their two length-m transforms per column, not by
+    // memory -- one v_pk_* instruction per complex add, two per product, the conjugations folded into the products.
 
     // ---- first transform, (A, B): v_j = x_j b_j
-    float2 v[A];
+    cx v[A];
 #pragma unroll
     for (int a = 0; a < A; ++a) {
-        if (!((gin >> a) & 1u)) { v[a] = make_float2(0.f, 0.f); continue; }
+        if (!((gin >> a) & 1u)) { v[a] = mk(0.f, 0.f); continue; }
         const unsigned off = (unsigned)__builtin_amdgcn_sbfe((int)~ibits, a, 1);
-        v[a] = cm(buf_ld<true>(make_rsrc(b_in + (int64_t)(B * a) * d.in_sj), l_in | off, 0), t_b[b + B * a]);
+        v[a] = from2(buf_ld<true>(make_rsrc(b_in + (int64_t)(B * a) * d.in_sj), l_in | off, 0));
     }
-    RegDFT<A>::run(v);
-    __syncthreads();                                   // the twiddle table is in place
+    __syncthreads();                                   // the tables are in place (the loads above are in flight)
 #pragma unroll
-    for (int k1 = 1; k1 < A; ++k1) v[k1] = cm(v[k1], tws[b * k1]);
-    float2 u[B];                                       // threads b < A: U[b + A k2] after the first transform
+    for (int a = 0; a < A; ++a)
+        if ((gin >> a) & 1u) v[a] = cxmul_r(v[a], from2(t_b[b + B * a]));
+    RegDFT<A, cx>::run(v);
+#pragma unroll
+    for (int k1 = 1; k1 < A; ++k1) v[k1] = cxmul_r(v[k1], from2(tws[b * k1]));
+    cx u[B];                                           // threads b < A: U[b + A k2] after the first transform
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
         if (r) __syncthreads();
 #pragma unroll
         for (int k1 = 0; k1 < A; ++k1)
-            if (k1 >= r * AR && k1 < (r + 1) * AR) lds[ab_slot<AR, B, false>(k1 - r * AR, b, w)] = v[k1];
+            if (k1 >= r * AR && k1 < (r + 1) * AR) lds[ab_slot<AR, B, false>(k1 - r * AR, b, w)] = to2(v[k1]);
         __syncthreads();
         if (b >= r * AR && b < (r + 1) * AR && b < A) {
 #pragma unroll
-            for (int bb = 0; bb < B; ++bb) u[bb] = lds[ab_slot<AR, B, false>(b - r * AR, bb, w)];
+            for (int bb = 0; bb < B; ++bb) u[bb] = from2(lds[ab_slot<AR, B, false>(b - r * AR, bb, w)]);
         }
     }
     // ---- the convolution in the frequency domain, and the second (inverse) transform, (B, A): conj, forward, conj
     if (b < A) {
-        RegDFT<B>::run(u);
+        RegDFT<B, cx>::run(u);
 #pragma unroll
-        for (int k2 = 0; k2 < B; ++k2) { u[k2] = cm(u[k2], t_hat[b + A * k2]); u[k2].y = -u[k2].y; }
-        RegDFT<B>::run(u);                             // thread b' = b < A holds the B inputs b' + A a'
+        for (int k2 = 0; k2 < B; ++k2) u[k2] = cxmul_cc(u[k2], from2(t_hat[b + A * k2]));      // conj(U . hat)
+        RegDFT<B, cx>::run(u);                         // thread b' = b < A holds the B inputs b' + A a'
 #pragma unroll
-        for (int k1 = 1; k1 < B; ++k1) u[k1] = cm(u[k1], tws[b * k1]);       // w_m^(b' k1')
+        for (int k1 = 1; k1 < B; ++k1) u[k1] = cxmul_r(u[k1], from2(tws[b * k1]));       // w_m^(b' k1')
     }
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
@@ -540,22 +576,20 @@ k_fft_chirp(PassDesc d, const float2* __restrict__ tw) {
         if (b < A) {
 #pragma unroll
             for (int k1 = 0; k1 < B; ++k1)
-                if (k1 >= r * BR && k1 < (r + 1) * BR) lds[ab_slot<BR, A, false>(k1 - r * BR, b, w)] = u[k1];
+                if (k1 >= r * BR && k1 < (r + 1) * BR) lds[ab_slot<BR, A, false>(k1 - r * BR, b, w)] = to2(u[k1]);
         }
         __syncthreads();
         if (b >= r * BR && b < (r + 1) * BR) {         // stage 2 on all B threads: output residue k1' = b
-            float2 y[A];
+            cx y[A];
 #pragma unroll
-            for (int bb = 0; bb < A; ++bb) y[bb] = lds[ab_slot<BR, A, false>(b - r * BR, bb, w)];
-            RegDFT<A>::run(y);
+            for (int bb = 0; bb < A; ++bb) y[bb] = from2(lds[ab_slot<BR, A, false>(b - r * BR, bb, w)]);
+            RegDFT<A, cx>::run(y);
 #pragma unroll
             for (int k2 = 0; k2 < A; ++k2) {           // X[b + B k2], k2 < A: only k < n is ever kept
                 if (!((gout >> k2) & 1u)) continue;
-                float2 e = y[k2];
-                e.y = -e.y;
-                e = cm(e, t_out[b + B * k2]);
+                const cx e = cxmulc(y[k2], from2(t_out[b + B * k2]));            // conj(y) . out
                 const unsigned off = (unsigned)__builtin_amdgcn_sbfe((int)~obits, k2, 1);
-                buf_st<true>(make_rsrc(b_out + (int64_t)(B * k2) * d.out_sj), l_out | off, 0, e);
+                buf_st<true>(make_rsrc(b_out + (int64_t)(B * k2) * d.out_sj), l_out | off, 0, to2(e));
             }
         }
     }
@@ -564,7 +598,10 @@ template <int A, int B, int ROUNDS>
 constexpr size_t chirp_lds_bytes() {
     constexpr int AR = (A + ROUNDS - 1) / ROUNDS, BR = (B + ROUNDS - 1) / ROUNDS;
     constexpr int EX1 = AR * B * AB_W, EX2 = BR * A * AB_W;
-    return ((size_t)(EX1 > EX2 ? EX1 : EX2) + (size_t)A * B) * 8;
+    return ((size_t)(EX1 > EX2 ? EX1 : EX2) + (size_t)4 * A * B) * 8;          // exchange image + twiddles + the three chirp tables
 }
+// exchange rounds of the chirp-z kernel: two where that lets a second workgroup onto the CU (80 KB each), else one
+template <int A, int B>
+constexpr int chirp_rounds() { return (chirp_lds_bytes<A, B, 1>() > 80 * 1024 && chirp_lds_bytes<A, B, 2>() <= 80 * 1024) ? 2 : 1; }
 
 }  // namespace anyfft

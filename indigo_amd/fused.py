@@ -124,7 +124,7 @@ def support_mode(backend, oN):
         return None, None
     kind = getattr(backend, 'padded_axis_kind', None)
     if kind is not None and kind(int(oN[2])) == 5:
-        if not getattr(backend, 'supports_support_hulls', False):
+        if not getattr(backend, 'supports_support_hulls', False) or not getattr(backend, 'tuning', {}).get('support_hulls', True):
             return None, None
         w = max(1, -(-int(oN[2]) // 32))
         return 'hulls', (w, w)

@@ -1,8 +1,9 @@
 #!/bin/bash
-# everything under profiles/ that the current round cites, re-measured in one GPU call: tools/refresh_profiles.sh r03
+# everything under profiles/ that the current round cites, re-measured in two GPU calls: tools/refresh_profiles.sh r05 A|B
 # (copy gpurun_out/${R}_* into profiles/ afterwards; the PMC summaries record the hash of the kernel sources they belong to)
-# Two parts (a gpurun call is limited to 20 minutes): A = rocprofv3 stats + PMC of configs 4, 5, 3, 2 and the default line; B = everything else.
-R=${1:-r04}
+# Three parts (a gpurun call is limited to 20 minutes): A = rocprofv3 stats + PMC of configs 4, 5, 3, 2; D = the default line (after A's
+# summaries are in profiles/); B = everything else.
+R=${1:-r05}
 PART=${2:-AB}
 mkdir -p gpurun_out
 if [[ $PART == *A* ]]; then
@@ -11,8 +12,15 @@ timeout -k 10 300 tools/profile_config.sh ${R}_cfg5 --config 5 --shard 0/4 --ste
 timeout -k 10 400 tools/profile_config.sh ${R}_cfg3 --config 3 --steps 5 || exit 1
 timeout -k 10 300 tools/profile_config.sh ${R}_cfg2 --config 2 || exit 1
 cp gpurun_out/${R}_cfg4_pmc_traffic.json gpurun_out/${R}_cfg5_pmc_traffic.json gpurun_out/${R}_cfg3_pmc_traffic.json gpurun_out/${R}_cfg2_pmc_traffic.json profiles/      # bench.py reads the PMC traffic from profiles/
-timeout -k 10 600 python bench.py --steps 20 --warmup 5 > gpurun_out/${R}_bench_default.json 2> gpurun_out/${R}_bench_default.log || exit 1
+fi
+if [[ $PART == *D* ]]; then
+# the default line as the driver runs it (headline + config 5 + configs 2 and 3 + the dense-trajectory extra), after part A's PMC
+# summaries have been copied into profiles/
+timeout -k 10 900 python bench.py --steps 20 --warmup 5 > gpurun_out/${R}_bench_default.json 2> gpurun_out/${R}_bench_default.log || exit 1
 tail -3 gpurun_out/${R}_bench_default.log
+python -c "import json;d=json.load(open('gpurun_out/${R}_bench_default.json'));print('default', d['ms_per_step'], d['roofline']['frac'], d['roofline']['traffic_stale'], 'dense', d['dense_trajectory'].get('ms_per_step'), 'cfg5', d['config5'].get('ms_per_step'), 'cfg3', d['config3'].get('ms_per_step'), 'cfg2', d['config2'].get('ms_per_step'))"
+timeout -k 10 600 python bench.py --steps 20 --warmup 5 --no-dense > gpurun_out/${R}_bench_default_run2.json 2> gpurun_out/${R}_bench_default_run2.log || exit 1
+python -c "import json;d=json.load(open('gpurun_out/${R}_bench_default_run2.json'));print('default run 2', d['ms_per_step'], d['roofline']['frac'])"
 fi
 if [[ $PART == *B* ]]; then
 for s in 0/1 0/2 0/4 0/8; do t=$(echo $s | sed "s|/|of|"); timeout -k 10 300 python bench.py --config 5 --shard $s --steps 5 --no-cpu-baseline > gpurun_out/${R}_bench_cfg5_shard_$t.json 2> gpurun_out/${R}_bench_cfg5_shard_$t.log || exit 1; python -c "import json;print('cfg5 $t', json.load(open('gpurun_out/${R}_bench_cfg5_shard_$t.json'))['ms_per_step'])"; done
@@ -21,6 +29,9 @@ CG_PROFILE=1 timeout -k 10 300 python tools/cg_bench.py 30 > gpurun_out/${R}_cg.
 tail -2 gpurun_out/${R}_cg.log
 for t in o3 recipe; do timeout -k 10 300 python bench.py --tree $t --steps 5 --no-extras --no-cpu-baseline > gpurun_out/${R}_bench_tree_$t.json 2> gpurun_out/${R}_bench_tree_$t.log || exit 1; python -c "import json;print('tree $t', json.load(open('gpurun_out/${R}_bench_tree_$t.json'))['ms_per_step'])"; done
 for t in zpadfft o3 recipe; do timeout -k 10 300 python bench.py --osf 1.25 --tree $t --steps 10 --no-extras --no-cpu-baseline > gpurun_out/${R}_bench_osf125_$t.json 2> gpurun_out/${R}_bench_osf125_$t.log || exit 1; python -c "import json;print('osf 1.25 tree $t', json.load(open('gpurun_out/${R}_bench_osf125_$t.json'))['ms_per_step'])"; done
+for c in 12 6 3 7; do timeout -k 10 300 python bench.py --coils $c --steps 10 --no-extras --no-cpu-baseline > gpurun_out/${R}_bench_coils$c.json 2> gpurun_out/${R}_bench_coils$c.log || exit 1; python -c "import json;d=json.load(open('gpurun_out/${R}_bench_coils$c.json'));print('coils $c', d['ms_per_step'], d['config']['coil_chunk_widths'])"; done
+timeout -k 10 400 python bench.py --image 480,208,308 --osf 640/480 --steps 10 --no-extras > gpurun_out/${R}_bench_default_grid_640x277x410.json 2> gpurun_out/${R}_bench_default_grid_640x277x410.log || exit 1
+python -c "import json;d=json.load(open('gpurun_out/${R}_bench_default_grid_640x277x410.json'));print('640x277x410', d['ms_per_step'], d['parity_rel_err'])"
 for cfg in "320 8" "480 2" "640 1" "432 2" "512 8"; do set -- $cfg; timeout -k 10 200 python bench.py --config 2 --image $1 --batch $2 --steps 10 > gpurun_out/${R}_bench_fft$1.json 2>gpurun_out/${R}_bench_fft$1.log || exit 1; python -c "import json;d=json.load(open('gpurun_out/${R}_bench_fft$1.json'));print('fft $1', d['ms_per_step'], d['roofline']['frac'])"; done
 timeout -k 10 400 python bench.py --config 3 --steps 5 > gpurun_out/${R}_bench_cfg3.json 2> gpurun_out/${R}_bench_cfg3.log || exit 1
 timeout -k 10 200 python bench.py --config 1 > gpurun_out/${R}_bench_cfg1.json 2> gpurun_out/${R}_bench_cfg1.log || exit 1
