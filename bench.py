@@ -460,7 +460,6 @@ def run_sense(args, cfg, B, comm, world, rank, steps, warmup, want_cpu, quiet=Fa
     cpr = max([lf['width'] for lf in leaves_z] or [len(coils)])          # widest chunk: names the kernel symbols
     sup_tab, sup_tile = (leaves_z[0]['table'], leaves_z[0]['tile']) if leaves_z else (None, 16)
     p.last_support_zw = getattr(A, '_support_zw', None) or getattr(p, 'last_support_zw', (16, 16))     # (recipe trees carry their own)
-    p.last_support_hulls_only = bool(getattr(A, '_support_hulls_only', False))
     real_entries = tree_real_entries(A)
     recs = {True: [r['nbytes'] for r in trace.records if r['event'] == 'csrmm' and not r.get('fused') and r['name'] == 'interp*mod*scale' and r['forward']],
             False: [r['nbytes'] for r in trace.records if r['event'] == 'csrmm' and not r.get('fused') and r['name'] == 'interp*mod*scale' and not r['forward']]}
@@ -557,12 +556,8 @@ def run_sense(args, cfg, B, comm, world, rank, steps, warmup, want_cpu, quiet=Fa
     if fused_fft and leaves_z and leaves_z[0]['table'] is not None:
         # what the k-space support tables flag: the fraction of the grid's rows every z pass and both gridding products touch
         lf = leaves_z[0]
-        zr, _, bits = p.split_support(lf['table'], lf['tile'])
-        if p.last_support_hulls_only:          # (a chirp-z z axis: the passes go by the hulls, every row inside them counts)
-            out["config"]["support_flagged_frac"] = float((zr[:, 1].astype(np.int64) - zr[:, 0]).clip(0).sum()) * lf['tile'] / float(np.prod(p.oN))
-            out["config"]["support_table"] = "hulls only (chirp-z z axis)"
-        else:
-            out["config"]["support_flagged_frac"] = float(np.unpackbits(bits.view(np.uint8)).sum()) * lf['tile'] / float(np.prod(p.oN))
+        _, _, bits = p.split_support(lf['table'], lf['tile'])
+        out["config"]["support_flagged_frac"] = float(np.unpackbits(bits.view(np.uint8)).sum()) * lf['tile'] / float(np.prod(p.oN))
     del AHA, A, x, y
     B._scratch = None
     p.drop_cache()

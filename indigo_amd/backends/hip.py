@@ -540,7 +540,9 @@ class HipBackend(Backend):
     def support_words(self, n):
         """(zw_in, zw_out) of an axis the library has a zero-pad-aware z pass for (ig_fft_support_words: 256 and 512 through the
         power-of-two kernel, every length 128 ... 640 with factors 2, 3, 5, 7 that splits as A x B, A, B <= 32, through the A x B
-        kernel), else None.  Doubles as the list of axis lengths `supports_padded_fft` accepts."""
+        kernel, lengths with a larger prime factor through the chirp-z kernel over an A x B length), else None."""
+        if not self.tuning.get('support_chirp', True) and self.padded_axis_kind(n) == 5:
+            return None          # (lab switch: a chirp-z grid without its table, as in round 4)
         zi, zo = ctypes.c_int(), ctypes.c_int()
         if self._L.ig_fft_support_words(int(n), ctypes.byref(zi), ctypes.byref(zo)) != 0:
             return None
@@ -571,7 +573,6 @@ class HipBackend(Backend):
         return len(grid) == 3 and all(int(n) in self.PADDED_AXES_POW2 for n in grid)
 
     supports_support_tile = True          # ZpadFFT / the brick scatter take support tables of 8 or 4 kx points per entry
-    supports_support_hulls = True         # ... and the chirp-z passes the hulls of a 16-point table (fused.support_mode 'hulls')
 
     def _padded_plan(self, grid, box_lo, box_dims, batch, layout=0, support_tile=16):
         key = ('padded', tuple(grid), tuple(box_lo), tuple(box_dims), int(batch), int(layout), int(support_tile))

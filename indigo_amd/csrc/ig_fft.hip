@@ -1086,6 +1086,19 @@ int launch_ab(ig_ctx* ctx, const AxisPlan& ax, const float2* in, float2* out, in
 
 int plan_chirp(ig_ctx* ctx, AxisPlan& ax, int64_t m);
 
+// The A x B length m >= 2 n - 1 a chirp-z axis of n points runs over (0: none up to 1024), and its split.
+// (measured on 640 x 277 x 410 x 8: what a pass costs follows m AND the split -- 410 over m = 840 = 28 x 30 9.6 ms, over
+// 864 = 27 x 32 8.6 ms, over 896 = 28 x 32 8.5 ms; 277 over 560 = 20 x 28 5.7 ms, over 576 = 24 x 24 7.5 ms: whole waves
+// (B a multiple of 4) beat the shortest m -- so: the first length within 8 % of 2 n - 1 whose B is a multiple of 4, else the shortest)
+int64_t chirp_ab_length(int64_t n, int& A, int& B) {
+    int64_t m = 0;
+    for (int64_t c = 2 * n - 1; c <= 1024 && c * 100 <= (2 * n - 1) * 108; ++c)
+        if (ab_split(c, A, B)) { if (!m) m = c; if (B % 4 == 0) { m = c; break; } }
+    for (int64_t c = 2 * n - 1; c <= 1024 && !m; ++c) if (ab_split(c, A, B)) m = c;
+    if (m) ab_split(m, A, B);
+    return m;
+}
+
 int plan_axis(ig_ctx* ctx, ig_fft* p, int a) {
     AxisPlan& ax = p->axis[a];
     ax.n = p->dims[a];
@@ -1155,15 +1168,8 @@ int plan_axis(ig_ctx* ctx, ig_fft* p, int a) {
         int64_t big = 1;
         for (int64_t r : ax.gen_radices) big = std::max(big, r);
         if (big > 7 && ax.n >= 32 && ctx->opt_fft_kernels == 0 && !p->is_chirp_sub) {        // (shorter ones: the direct stages are fine)
-            int64_t m = 0;
             int A = 0, B = 0;
-            // (measured on 640 x 277 x 410 x 8: what a pass costs follows m AND the split -- 410 over m = 840 = 28 x 30 9.6 ms, over
-            // 864 = 27 x 32 8.6 ms, over 896 = 28 x 32 8.5 ms; 277 over 560 = 20 x 28 5.7 ms, over 576 = 24 x 24 7.5 ms: whole waves
-            // (B a multiple of 4) beat the shortest m -- so: the first length within 8 % of 2 n - 1 whose B is a multiple of 4,
-            // else the shortest)
-            for (int64_t c = 2 * ax.n - 1; c <= 1024 && c * 100 <= (2 * ax.n - 1) * 108; ++c)
-                if (ab_split(c, A, B)) { if (!m) m = c; if (B % 4 == 0) { m = c; break; } }
-            for (int64_t c = 2 * ax.n - 1; c <= 1024 && !m; ++c) if (ab_split(c, A, B)) m = c;
+            int64_t m = chirp_ab_length(ax.n, A, B);
             Radices r2{};
             int ns2 = 0;
             for (int64_t c = 2 * ax.n - 1; c <= LDS_NMAX && !m; ++c) if (factor_lds(c, r2, ns2)) m = c;
@@ -1417,7 +1423,7 @@ k_chirp_post(const float2* __restrict__ W, float2* __restrict__ y, const float2*
 int launch_chirp_desc(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d_in) {
     const Chirp& ch = *ax.chirp;
     IG_REQUIRE(ctx, ch.fused, "ig_fft: this chirp-z axis has no one-launch route");
-    IG_REQUIRE(ctx, !d_in.cw && !d_in.tile_bits, "ig_fft: a chirp-z pass takes no lane split and no support bitmaps (the table's hulls only)");
+    IG_REQUIRE(ctx, !d_in.cw && (!d_in.tile_bits || d_in.tile_words == ch.sub.ab_B), "ig_fft: a chirp-z pass takes no lane split, and support bitmaps of B = %d words per entry", ch.sub.ab_B);
     IG_REQUIRE(ctx, d_in.in_lo >= 0 && d_in.in_hi <= ax.n && d_in.out_lo >= 0 && d_in.out_hi <= ax.n, "ig_fft: chirp-z boxes must lie inside the axis");
     PassDesc d = d_in;
     if (d.ncols == 0) return IG_OK;
@@ -1715,7 +1721,8 @@ int ig_fft_plan_padded(ig_ctx* ctx, const int64_t* dims, const int64_t* box_lo, 
                            "splits as A x B with A, B <= 32", a, (long long)dims[a]);
         }
         if (ab_ok) p->has_ab_axis = true;
-        if (a == 2) { p->zw_in = cz_ok ? 0 : ab_ok ? p->axis[a].ab_B : 16; p->zw_out = cz_ok ? 0 : ab_ok ? p->axis[a].ab_A : 16; }
+        // (a chirp-z z axis: its threads hold rows b + B a of the length-m transform on both sides -- B words per entry either way)
+        if (a == 2) { p->zw_in = cz_ok ? p->axis[a].chirp->sub.ab_B : ab_ok ? p->axis[a].ab_B : 16; p->zw_out = cz_ok ? p->axis[a].chirp->sub.ab_B : ab_ok ? p->axis[a].ab_A : 16; }
         if (cz_ok) p->has_chirp_axis = true;
         p->box_lo[a] = box_lo[a];
         p->box_dims[a] = box_dims[a];
@@ -1879,8 +1886,7 @@ static int exec_padded_layout2(ig_fft* p, const float2* x, int64_t x_bstride, co
         d.ext0 = C * n0; d.ext1 = n1; d.ncols = C * n0 * n1;
         d.in_lo = (int)l2; d.in_hi = (int)(l2 + b2); d.out_lo = 0; d.out_hi = (int)n2; d.inverse = 0;
         d.tile_range = support; d.tile_range_mode = 1; d.tile_range_k1 = snt; d.tile_shift = sshift;
-        if (support && p->axis[2].kind != 5) {      // the output-side form of the bitmaps (it follows the input-side form where the two differ);
-                                                     // a chirp-z axis reads the hulls only
+        if (support) {      // the output-side form of the bitmaps (it follows the input-side form where the two differ)
             d.tile_bits = reinterpret_cast<const uint32_t*>(support + n1 * snt + snt) + (p->zw_out != p->zw_in ? n1 * snt * p->zw_in : 0);
             d.tile_words = p->zw_out;
         }
@@ -1911,7 +1917,7 @@ static int exec_cropped_layout2(ig_fft* p, const float2* y, const float2* w, flo
         d.ext0 = C * n0; d.ext1 = n1; d.ncols = C * n0 * n1;
         d.in_lo = 0; d.in_hi = (int)n2; d.out_lo = (int)l2; d.out_hi = (int)(l2 + b2); d.inverse = 1;
         d.tile_range = support; d.tile_range_mode = 2; d.tile_range_k1 = snt; d.tile_shift = sshift;
-        if (support && p->axis[2].kind != 5) { d.tile_bits = reinterpret_cast<const uint32_t*>(support + n1 * snt + snt); d.tile_words = p->zw_in; }
+        if (support) { d.tile_bits = reinterpret_cast<const uint32_t*>(support + n1 * snt + snt); d.tile_words = p->zw_in; }
         if (support) d.k1_range = support + n1 * snt;                         // ky the y pass will never read
         if (int rc = launch_pass(ctx, p->axis[2], d, false, 0)) return rc;
     }
@@ -1956,6 +1962,13 @@ int ig_fft_support_words(int64_t n, int* zw_in, int* zw_out) {
     int A = 0, B = 0;
     if (n == 256 || n == 512) { *zw_in = *zw_out = 16; return IG_OK; }
     if (abd_supported(n) && ab_split(n, A, B)) { *zw_in = B; *zw_out = A; return IG_OK; }
+    {   // a chirp-z axis (a prime factor above 7) over an A x B length: B words on both sides
+        std::vector<int64_t> f;
+        factor_generic(n, f);
+        int64_t big = 1;
+        for (int64_t r : f) big = std::max(big, r);
+        if (big > 7 && n >= 32 && chirp_ab_length(n, A, B) && n <= 32 * (int64_t)B) { *zw_in = *zw_out = B; return IG_OK; }
+    }
     return ig_fail(nullptr, IG_ERR_UNSUPPORTED, "ig_fft_support_words: no zero-pad-aware z pass for an axis of %lld points", (long long)n);
 }
 
@@ -1978,7 +1991,7 @@ int ig_fft_padded_axis_kind(int64_t n, int* kind) {
 int ig_fft_set_support_tile(ig_fft* p, int tile) {
     if (!p) return ig_fail(nullptr, IG_ERR_ARG, "ig_fft_set_support_tile: plan is NULL");
     ig_ctx* ctx = p->ctx;
-    IG_REQUIRE(ctx, p->padded && p->layout == 2 && !p->has_chirp_axis, "ig_fft_set_support_tile: a zero-padded plan of the coil-interleaved layout without a chirp-z axis");
+    IG_REQUIRE(ctx, p->padded && p->layout == 2, "ig_fft_set_support_tile: a zero-padded plan of the coil-interleaved layout");
     IG_REQUIRE(ctx, (tile == 2 || tile == 4 || tile == 8 || tile == 16) && p->batch * tile >= 16 && p->dims[0] % tile == 0,
                "ig_fft_set_support_tile: tile %d (2, 4, 8 or 16 kx points; coils * tile >= 16)", tile);
     p->support_tile = tile;

@@ -500,17 +500,19 @@ k_fft_chirp(PassDesc d, const float2* __restrict__ tw) {
     unsigned l_in = ((unsigned)w * (unsigned)d.in_s[0] + (unsigned)b * (unsigned)d.in_sj) * 8u;
     unsigned l_out = ((unsigned)w * (unsigned)d.out_s[0] + (unsigned)b * (unsigned)d.out_sj) * 8u;
     if (!valid) l_in = l_out = IG_OOB;
-    // the k-space support table's HULLS (round 5): tiles outside the ky hull of their kx tile, or with an empty z range, leave at
-    // once; inside, the range narrows the output box (zero-padded forward pass) or the input box (cropped inverse pass).  The table's
-    // bitmaps are not read here -- their words follow the element order of the A x B kernels, a chirp-z thread holds b + B a of a
-    // LONGER transform -- so whoever writes the grid behind such an axis defines every row inside the hulls (the adjoint gridding
-    // zero-fills first).  All of it wave- and workgroup-uniform, before any barrier.
+    // the k-space support table (round 5): tiles outside the ky hull of their kx tile, or with an empty z range, leave at once;
+    // inside, the range narrows the output box (zero-padded forward pass) or the input box (cropped inverse pass), and the segment
+    // bitmap masks single rows.  A thread holds the rows b + B a on its input side and b + B k2 on its output side -- of a
+    // transform of m = A B >= 2 n - 1 points, of which only rows below n exist --, so the bitmaps of a chirp-z axis are B words per
+    // entry on both sides: bit kz / B of word kz % B (ig_fft_support_words).  All of it wave- and workgroup-uniform, before any barrier.
     int in_lo = d.in_lo, in_hi = d.in_hi, out_lo = d.out_lo, out_hi = d.out_hi;
+    uint32_t zb = 0xffffffffu;
     {
         short2 k1r = make_short2(0, 0x7fff), trg = make_short2(0, 0x7fff);
         const int64_t tidx = (int64_t)k1i * d.tile_range_k1 + (tr >> d.tile_shift);
         if (d.k1_range) k1r = d.k1_range[tr >> d.tile_shift];
         if (d.tile_range) trg = d.tile_range[tidx];
+        if (d.tile_bits) zb = d.tile_bits[tidx * B + b];
         if (d.k1_range && ((int)k1i < k1r.x || (int)k1i >= k1r.y)) return;
         if (d.tile_range) {
             if (d.tile_range_mode == 1) {
@@ -525,8 +527,9 @@ k_fft_chirp(PassDesc d, const float2* __restrict__ tw) {
     }
     auto below = [](int h) -> uint32_t { return h >= 32 ? 0xffffffffu : ((1u << h) - 1u); };
     // input j = b + B a <-> bit a; output k = b + B k2 (k2 < A) <-> bit k2
-    const uint32_t ibits = below(ab_ceil_div_clamp(in_hi - b, B, A)) & ~below(ab_ceil_div_clamp(in_lo - b, B, A));
-    const uint32_t obits = below(ab_ceil_div_clamp(out_hi - b, B, A)) & ~below(ab_ceil_div_clamp(out_lo - b, B, A));
+    uint32_t ibits = below(ab_ceil_div_clamp(in_hi - b, B, A)) & ~below(ab_ceil_div_clamp(in_lo - b, B, A));
+    uint32_t obits = below(ab_ceil_div_clamp(out_hi - b, B, A)) & ~below(ab_ceil_div_clamp(out_lo - b, B, A));
+    if (d.tile_bits) { if (d.tile_range_mode == 1) obits &= zb; else ibits &= zb; }
     uint32_t gin = 0, gout = 0;
 #pragma unroll
     for (int l = 0; l < 64; l += AB_W) { gin |= (uint32_t)__builtin_amdgcn_readlane((int)ibits, l); gout |= (uint32_t)__builtin_amdgcn_readlane((int)obits, l); }

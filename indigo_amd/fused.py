@@ -105,31 +105,13 @@ def grid_support_numpy(G, oN, tile=16, zw=(16, 16)):
 
 def support_words(backend, oN):
     """(zw_in, zw_out) of the k-space support table for this grid on this backend -- the words per entry of its bitmaps, which
-    follow from the kernel that transforms the z axis (oN[2]) --, or None where the backend reads no bitmaps for the grid (a
-    chirp-z z axis: see support_mode)"""
-    mode, zw = support_mode(backend, oN)
-    return zw if mode == 'full' else None
-
-
-def support_mode(backend, oN):
-    """How much of a k-space support table the backend's kernels take on this grid:
-      ('full', (zw_in, zw_out))   hulls and segment bitmaps: transform passes, adjoint gridding and zero-fill all go by it
-      ('hulls', (w, w))           a chirp-z z axis (a prime factor above 7: 410 = 2 * 5 * 41 of the reference driver's default grid):
-                                  the transform passes skip tiles outside the ky / kz hulls and narrow their boxes to them; the
-                                  bitmaps (w = ceil(n2 / 32) words per entry, the builder's generic form) are not read, so the
-                                  gridding matrix carries NO table -- its adjoint zero-fills the grid and writes every row
-      (None, None)                no table"""
+    follow from the kernel that transforms the z axis (oN[2]): 16 / 16 (256, 512), B / A (an A x B length), B / B (a chirp-z axis
+    over an A x B length: 410 = 2 * 5 * 41 of the reference driver's default grid runs over 864 = 27 x 32) --, or None where the
+    backend takes no table for the grid (the grid then runs without one: every grid row is written and read)"""
     f = getattr(backend, 'support_words', None)
     if f is None or int(oN[0]) % 16:
-        return None, None
-    kind = getattr(backend, 'padded_axis_kind', None)
-    if kind is not None and kind(int(oN[2])) == 5:
-        if not getattr(backend, 'supports_support_hulls', False) or not getattr(backend, 'tuning', {}).get('support_hulls', True):
-            return None, None
-        w = max(1, -(-int(oN[2]) // 32))
-        return 'hulls', (w, w)
-    zw = f(int(oN[2]))
-    return ('full', zw) if zw is not None else (None, None)
+        return None
+    return f(int(oN[2]))
 
 
 def split_support(table, oN, tile=16, zw_in=16):
@@ -201,7 +183,7 @@ def pad_coils(w, width, interleaved=True):
 
 
 def assemble(backend, Gm, oN, N, weights_of, Cn, layout, chunks, table=None, box_lo=None, row_order=None,
-             name='SENSE-fusedFFT', zw=(16, 16), hulls_only=False):
+             name='SENSE-fusedFFT', zw=(16, 16)):
     """A = KronI(C, G') * ZpadFFT, or a VStack of such trees over coil chunks sharing ONE device copy of G'.
 
     Gm          gridding matrix (T x P, complex64 CSR) with its columns in the order of `layout` (see
@@ -212,8 +194,7 @@ def assemble(backend, Gm, oN, N, weights_of, Cn, layout, chunks, table=None, box
     KronI a few columns at a time) become a VStack: the k-space rows come out coil-major exactly as from KronI(C, G'),
     and the adjoint accumulates the chunks' images (VStack, operators.py:440-447).  Chunks of different widths share the
     matrix too: it carries one binned adjoint format and one fine support table PER WIDTH present (8 and 4: brick rounds;
-    2: slots), so 12 coils (8 + 4) or 6 (4 + 2) run the same kernels as 8, 4 and 2 coils do alone.
-    hulls_only  the table serves the transform leaf's hulls only (support_mode 'hulls'): the matrix carries none, no finer table"""
+    2: slots), so 12 coils (8 + 4) or 6 (4 + 2) run the same kernels as 8, 4 and 2 coils do alone."""
     from indigo_amd import operators as op
     tuning = getattr(backend, 'tuning', {})          # format choices of the backend (HipBackend.tuning)
     chunks = [(c[0], c[1], (c[2] if len(c) > 2 else (c[1] - c[0] if layout == 2 else 0))) for c in chunks]
@@ -232,7 +213,7 @@ def assemble(backend, Gm, oN, N, weights_of, Cn, layout, chunks, table=None, box
     by_tile = {}
     for w in il_widths:
         tile = int(tile_of.get(w, 8) if isinstance(tile_of, dict) else tile_of)
-        if (table is not None and not hulls_only and tile in (4, 8) and w * tile >= 32 and getattr(backend, 'supports_support_tile', False)
+        if (table is not None and tile in (4, 8) and w * tile >= 32 and getattr(backend, 'supports_support_tile', False)
                 and w in tuning.get('bricks', ())):
             if tile not in by_tile:
                 by_tile[tile] = grid_support(Gm, oN, tile, zw)
@@ -243,7 +224,7 @@ def assemble(backend, Gm, oN, N, weights_of, Cn, layout, chunks, table=None, box
         G = backend.SpMatrix(Gm, name='interp*mod*scale')
         if interleaved:
             G._grid_interleaved = True
-        if table is not None and not hulls_only:
+        if table is not None:
             G._grid_support = (table, int(oN[0]), int(oN[2]), int(zw[0]))
         if row_order is not None:
             G._row_order = row_order
@@ -299,7 +280,6 @@ def assemble(backend, Gm, oN, N, weights_of, Cn, layout, chunks, table=None, box
     A._support_fine = fine.get(il_widths[0]) if il_widths else None          # (the widest chunks' table: what most of the tree runs by)
     A._support_fine_by_width = fine
     A._support_zw = tuple(int(v) for v in zw)
-    A._support_hulls_only = bool(hulls_only)
     A._coil_chunks = chunks
     return A
 

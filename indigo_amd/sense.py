@@ -206,11 +206,7 @@ class SenseProblem(object):
             ylen = np.full(nt, n1, dtype=np.int64)
         else:
             zr, yr, bits = self.split_support(table, tile)
-            if getattr(self, 'last_support_hulls_only', False):
-                # a chirp-z z axis reads the hulls only: every row inside a (ky, kx tile)'s z range is written / read
-                z_sup = int((zr[:, 1].astype(np.int64) - zr[:, 0]).clip(0).sum()) * tile
-            else:
-                z_sup = int(np.unpackbits(bits.view(np.uint8)).sum()) * tile   # grid points in flagged segments, per coil
+            z_sup = int(np.unpackbits(bits.view(np.uint8)).sum()) * tile   # grid points in flagged segments, per coil
             z_tiles = int(np.count_nonzero(zr[:, 1] > zr[:, 0]))           # (kx tile, ky) columns with any support
             ylen = (yr[:, 1].astype(np.int64) - yr[:, 0]).clip(0)
         y_sup = int(ylen.sum()) * tile * b2          # points the y pass produces / consumes on its grid side
@@ -237,11 +233,11 @@ class SenseProblem(object):
         nnz = Gm.nnz
         touched = int(fused.touched_columns(Gm).size)
         e = 8 * ncoils
-        if table is not None and not getattr(self, 'last_support_hulls_only', False):
+        if table is not None:
             _, _, bits = self.split_support(table, tile)
             sup = int(np.unpackbits(bits.view(np.uint8)).sum()) * tile
         else:
-            sup = P          # (no table on the matrix: the adjoint zero-fills the grid and writes every row)
+            sup = P
         return {
             "csrmm_gather": nnz * (8 if real_entries else 12) + (T + 1) * 4 + touched * e + T * e,
             "csrmm_rowlane_conj": nnz * 12 + (sup + 1) * 4 + T * e + sup * e,
@@ -279,20 +275,17 @@ class SenseProblem(object):
         layout, chunks = fused.choose_layout(Cn, chunk, layout, single_ok)
         Gm = self.fused_interp(1 if layout == 2 else layout)      # layout 2 = layout 1 with the coils interleaved below
         table = None
-        mode, zw = fused.support_mode(backend, self.oN)      # words per entry of the table's bitmaps: follows from the z pass's kernel
-        if (support is None or support) and layout >= 1 and zw is not None and (layout == 2 or (zw == (16, 16) and mode == 'full')):
-            # restrict the transform's z pass and the adjoint gridding to the k-space support of G' (mode 'hulls': the transform's
-            # passes only, by the table's hulls -- a chirp-z z axis)
+        zw = fused.support_words(backend, self.oN)      # words per entry of the table's bitmaps: follows from the z pass's kernel
+        if (support is None or support) and layout >= 1 and zw is not None and (layout == 2 or zw == (16, 16)):
+            # restrict the transform's z pass and the adjoint gridding to the k-space support of G'
             table = self.grid_support(Gm, 16, zw)
-        hulls_only = table is not None and mode == 'hulls'
         zw = zw or (16, 16)
         self.last_support_table = table
         self.last_support_zw = zw
-        self.last_support_hulls_only = hulls_only
         order = self.locality_order(Gm) if reorder and Cn <= 8 else None
         widths = {lo: w for lo, _, w in chunks}
         A = fused.assemble(backend, Gm, self.oN, self.N, lambda lo, hi: self.fused_weights(coils[lo:hi], interleaved=(widths.get(lo, 0) > 1)), Cn,
-                           layout, chunks, table=table, row_order=order, zw=zw, hulls_only=hulls_only)
+                           layout, chunks, table=table, row_order=order, zw=zw)
         self.last_support_fine = getattr(A, '_support_fine', None)       # (table, tile) when the tree took a finer table
         return A
 

@@ -341,10 +341,10 @@ class FuseZpadFFT(Transform):
             Gm = L.right._matrix.astype(np.complex64).tocsr()
             if layout >= 1:
                 Gm = fused.permute_grid_columns(Gm, grid)
-        mode, zw = fused.support_mode(b, grid)
-        table = fused.grid_support(Gm, grid, 16, zw) if (layout >= 1 and zw is not None and (layout == 2 or (zw == (16, 16) and mode == 'full'))) else None
+        zw = fused.support_words(b, grid)
+        table = fused.grid_support(Gm, grid, 16, zw) if (layout >= 1 and zw is not None and (layout == 2 or zw == (16, 16))) else None
         A = fused.assemble(b, Gm, grid, box, lambda c0, c1: w[..., c0:c1], C, layout, chunks, table=table, box_lo=lo,
-                           name=node._name, zw=zw or (16, 16), hulls_only=(table is not None and mode == 'hulls'))
+                           name=node._name, zw=zw or (16, 16))
         A._fused_layout = layout
         return A
 

@@ -559,23 +559,29 @@ def test_every_coil_count_takes_the_fast_routes(hip, oracle_backend, C, image, o
     p.drop_cache()
 
 
-@pytest.mark.parametrize("C", [4, 3])
-def test_sense_on_a_chirp_z_grid_goes_by_the_support_hulls(hip, oracle_backend, C):
+@pytest.mark.parametrize("C", [4, 3, 8])
+def test_sense_on_a_chirp_z_grid_with_its_support_table(hip, oracle_backend, C):
     """The reference driver's default oversampling (640/480, examples/pics.py:86) with its sizing rule int(N * osf)
     (indigo/backends/backend.py:427-430) at a quarter of its scan: image 120 x 52 x 77 on 160 x 69 x 102 -- 69 = 3 * 23 and
-    102 = 2 * 3 * 17 are chirp-z axes.  The fused leaf takes the k-space support table's HULLS there (tiles outside the ky / kz
-    hulls are skipped, boxes narrowed), its bitmaps are not read and the gridding matrix carries no table (its adjoint zero-fills the
-    grid and writes every row).  Forward / adjoint / normal operator against the per-coil numpy oracle, which knows no table."""
+    102 = 2 * 3 * 17 are chirp-z axes.  The fused leaf takes the k-space support table there too: a chirp-z thread holds the rows
+    b + B a of its length-m transform on both sides, so the bitmaps of such a z axis are B words per entry
+    (ig_fft_support_words); the brick scatter writes by them (no zero-fill of the grid), the chirp-z passes skip the tiles outside
+    the hulls and mask their loads and stores with the bitmaps, 8- and 4-wide chunks take the fine table.
+    Forward / adjoint / normal operator against the per-coil numpy oracle, which knows no table."""
     from indigo_amd import operators as op
     p = SenseProblem.synthetic((120, 52, 77), C, nspokes=200, nreadout=160, width=3, ntable=128, oversamp=640 / 480, seed=8)
     assert p.oN == (160, 69, 102)
     hip._scratch = None
     oracle_backend._scratch = None
     A = p.build_zpadfft(hip)
-    assert p.last_support_hulls_only and p.last_support_table is not None and p.last_support_fine is None
+    assert p.last_support_table is not None
+    zw = p.last_support_zw
+    assert zw[0] == zw[1] and zw[0] * 32 >= 102 and zw == hip.support_words(102)
     for tree in _chunk_trees(A):
         Z, G = tree.right, tree.left.right
-        assert isinstance(Z, op.ZpadFFT) and Z._layout == 2 and Z._support_h is not None and getattr(G, '_grid_support', None) is None
+        assert isinstance(Z, op.ZpadFFT) and Z._layout == 2 and Z._support_h is not None and getattr(G, '_grid_support', None) is not None
+    if C in (4, 8):
+        assert p.last_support_fine is not None and p.last_support_fine[1] == (8 if C == 4 else 4)
     # the hulls really cut something: a radial trajectory leaves the corners of the (ky, kx tile) plane empty
     zr, yr, _ = p.split_support(p.last_support_table, 16)
     assert np.count_nonzero(zr[:, 1] > zr[:, 0]) < zr.shape[0]
