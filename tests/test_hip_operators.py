@@ -672,3 +672,30 @@ def test_cg_with_device_scalars_matches_host_scalar_cg(hip):
     h9 = Backend.cg(hip, A.H * A, b.copy(order='F'), x9, lamda=0.05 + 0.01j, maxiter=3)
     assert len(h8) == len(h9) == 3 and rel_err(x8, x9) < 1e-6
     hip._scratch = None
+
+
+def test_head_rows_operator_on_the_gpu(hip):
+    """operators.HeadRows (the first rows of a tree: a coil chunk padded with zero-weight coils) with alpha / beta and a two-column
+    panel, on device arrays: views into the scratch panel, the zeroed tail, NaN-poisoned outputs with beta = 0"""
+    import scipy.sparse as spp
+    from indigo_amd import operators as op
+    hip._scratch = None
+    rng = np.random.default_rng(5)
+    M = (spp.random(900, 64, density=0.2, random_state=rng) + 1j * spp.random(900, 64, density=0.2, random_state=rng)).astype(C64).tocsr()
+    H = op.HeadRows(hip, hip.SpMatrix(M), 517)
+    Md = M.toarray()[:517]
+    for ncol in (1, 2):
+        x = rand64c(64, ncol, seed=1)
+        y0 = rand64c(517, ncol, seed=2)
+        y = hip.copy_array(y0)
+        H.eval(y, hip.copy_array(x), alpha=0.5 - 1j, beta=2.0)
+        assert rel_err(y.to_host(), (0.5 - 1j) * (Md @ x) + 2.0 * y0) < RTOL
+        k = rand64c(517, ncol, seed=3)
+        z0 = rand64c(64, ncol, seed=4)
+        z = hip.copy_array(z0)
+        H.H.eval(z, hip.copy_array(k), alpha=1j, beta=-0.5)
+        assert rel_err(z.to_host(), 1j * (Md.conj().T @ k) - 0.5 * z0) < RTOL
+        yn = hip.copy_array(np.full((517, ncol), np.nan + 1j * np.nan, dtype=C64, order='F'))
+        H.eval(yn, hip.copy_array(x))
+        assert rel_err(yn.to_host(), Md @ x) < RTOL
+    hip._scratch = None

@@ -482,3 +482,32 @@ def test_structured_realisation_equals_the_scipy_products(oracle_backend, masked
     Gs = fused.permute_grid_columns(Ls[0]._matrix.tocsr().astype(C64), p.oN)
     assert Gn.shape == Gs.shape and Gn.has_sorted_indices and abs(Gn - Gs).max() <= 3e-7 * abs(Gs).max()
     B._scratch = None
+
+
+def test_head_rows_operator_alpha_beta_and_panels(oracle_backend):
+    """operators.HeadRows (a coil chunk padded with zero-weight coils: the first rows of its tree): forward and adjoint with
+    alpha / beta and a two-column panel against the explicit matrix rows"""
+    import scipy.sparse as spp
+    B = oracle_backend
+    B._scratch = None
+    rng = np.random.default_rng(5)
+    M = (spp.random(9, 6, density=0.6, random_state=rng) + 1j * spp.random(9, 6, density=0.6, random_state=rng)).astype(C64).tocsr()
+    H = op.HeadRows(B, B.SpMatrix(M), 5)
+    assert H.shape == (5, 6)
+    Md = M.toarray()[:5]
+    for ncol in (1, 2):
+        x = (rng.random((6, ncol)) + 1j * rng.random((6, ncol))).astype(C64)
+        y0 = (rng.random((5, ncol)) + 1j * rng.random((5, ncol))).astype(C64)
+        y = B.copy_array(np.asfortranarray(y0))
+        H.eval(y, B.copy_array(np.asfortranarray(x)), alpha=0.5 - 1j, beta=2.0)
+        np.testing.assert_allclose(y.to_host(), (0.5 - 1j) * (Md @ x) + 2.0 * y0, rtol=2e-6, atol=1e-6)
+        k = (rng.random((5, ncol)) + 1j * rng.random((5, ncol))).astype(C64)
+        z0 = (rng.random((6, ncol)) + 1j * rng.random((6, ncol))).astype(C64)
+        z = B.copy_array(np.asfortranarray(z0))
+        H.H.eval(z, B.copy_array(np.asfortranarray(k)), alpha=1j, beta=-0.5)
+        np.testing.assert_allclose(z.to_host(), 1j * (Md.conj().T @ k) - 0.5 * z0, rtol=2e-6, atol=1e-6)
+        # beta = 0 never reads the output
+        yn = B.copy_array(np.full((5, ncol), np.nan + 1j * np.nan, dtype=C64, order='F'))
+        H.eval(yn, B.copy_array(np.asfortranarray(x)))
+        np.testing.assert_allclose(yn.to_host(), Md @ x, rtol=2e-6, atol=1e-6)
+    B._scratch = None

@@ -2,7 +2,8 @@
 # everything under profiles/ that the current round cites, re-measured in two GPU calls: tools/refresh_profiles.sh r05 A|B
 # (copy gpurun_out/${R}_* into profiles/ afterwards; the PMC summaries record the hash of the kernel sources they belong to)
 # Three parts (a gpurun call is limited to 20 minutes): A = rocprofv3 stats + PMC of configs 4, 5, 3, 2; D = the default line (after A's
-# summaries are in profiles/); B = everything else.
+# summaries are in profiles/); B = per-rank shares, CG, the recipe's trees, osf 1.25; C = coil counts, the reference driver's default grid,
+# plain transforms, configs 1-3 alone, the self-launch rehearsals.
 R=${1:-r05}
 PART=${2:-AB}
 mkdir -p gpurun_out
@@ -29,6 +30,8 @@ CG_PROFILE=1 timeout -k 10 300 python tools/cg_bench.py 30 > gpurun_out/${R}_cg.
 tail -2 gpurun_out/${R}_cg.log
 for t in o3 recipe; do timeout -k 10 300 python bench.py --tree $t --steps 5 --no-extras --no-cpu-baseline > gpurun_out/${R}_bench_tree_$t.json 2> gpurun_out/${R}_bench_tree_$t.log || exit 1; python -c "import json;print('tree $t', json.load(open('gpurun_out/${R}_bench_tree_$t.json'))['ms_per_step'])"; done
 for t in zpadfft o3 recipe; do timeout -k 10 300 python bench.py --osf 1.25 --tree $t --steps 10 --no-extras --no-cpu-baseline > gpurun_out/${R}_bench_osf125_$t.json 2> gpurun_out/${R}_bench_osf125_$t.log || exit 1; python -c "import json;print('osf 1.25 tree $t', json.load(open('gpurun_out/${R}_bench_osf125_$t.json'))['ms_per_step'])"; done
+fi
+if [[ $PART == *C* ]]; then
 for c in 12 6 3 7; do timeout -k 10 300 python bench.py --coils $c --steps 10 --no-extras --no-cpu-baseline > gpurun_out/${R}_bench_coils$c.json 2> gpurun_out/${R}_bench_coils$c.log || exit 1; python -c "import json;d=json.load(open('gpurun_out/${R}_bench_coils$c.json'));print('coils $c', d['ms_per_step'], d['config']['coil_chunk_widths'])"; done
 timeout -k 10 400 python bench.py --image 480,208,308 --osf 640/480 --steps 10 --no-extras > gpurun_out/${R}_bench_default_grid_640x277x410.json 2> gpurun_out/${R}_bench_default_grid_640x277x410.log || exit 1
 python -c "import json;d=json.load(open('gpurun_out/${R}_bench_default_grid_640x277x410.json'));print('640x277x410', d['ms_per_step'], d['parity_rel_err'])"
