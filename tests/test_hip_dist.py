@@ -148,6 +148,24 @@ B._scratch = None
 normal_operator(A, lamda=0.1).eval(y2, xs)
 a, b = y1.to_host(), y2.to_host()
 assert np.linalg.norm(a - b) <= 1e-6 * np.linalg.norm(b), np.linalg.norm(a - b) / np.linalg.norm(b)
+# a rank whose coil count is no power of two (8 coils on 3 ranks: 3 + 3 + 2): ONE 4-wide interleaved chunk whose fourth coil has zero
+# weights, cut to its three real coils by operators.HeadRows -- alpha and beta pass through to the leaf underneath, which reduces slab
+# by slab like any other
+del A, op
+B._scratch = None
+A = p.build_zpadfft(B, coils=[0, 1, 2])
+assert isinstance(A, ops.HeadRows) and A.child.right._C == 4
+comm.world = 2
+op = ShardedNormalOperator(A, comm, lamda=0.1, nslabs=3)
+assert op._leaf is A.child.right
+op.eval(y1, xs)
+assert op._route == 'slab'
+op.eval(y1, xs)
+comm.world = 1
+B._scratch = None
+normal_operator(A, lamda=0.1).eval(y2, xs)
+a, b = y1.to_host(), y2.to_host()
+assert np.linalg.norm(a - b) <= 1e-6 * np.linalg.norm(b), np.linalg.norm(a - b) / np.linalg.norm(b)
 del A, op
 B._scratch = None
 A = p.build_zpadfft(B, chunk=2)
