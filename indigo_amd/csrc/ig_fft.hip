@@ -382,7 +382,15 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
     const int tid = threadIdx.x;
     // inter-stage twiddles in the order the threads read them: entry t * R1 + k = w_n^(t k) (the second half of the plan's table),
     // so a thread's R1 - 1 reads are one base address plus compile-time offsets, two values per LDS instruction
-    for (int k = tid; k < n; k += NT) tws[k] = tw[n + k];
+    // (NT == n: one value per thread, requested here and written to LDS only after the stage-1 loads have been issued -- written
+    // straight away, the copy is a round trip of its own at the head of every workgroup: the compiler waits for it before anything else)
+    constexpr int TWN = n / NT;                      // 1 (32-column tiles) or 2
+    constexpr bool TW_LATE = (n % NT == 0) && TWN <= 2;
+    float2 tw_mine[TW_LATE ? TWN : 1];
+    if (TW_LATE) {
+#pragma unroll
+        for (int i = 0; i < TWN; ++i) tw_mine[i] = tw[n + tid + i * NT];
+    } else for (int k = tid; k < n; k += NT) tws[k] = tw[n + k];
 
     const int t = AXIS0 ? (tid % T) : (tid / W);
     const int w = AXIS0 ? (tid / T) : (tid % W);
@@ -390,37 +398,16 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
     // (Workgroups are dealt round-robin to the 8 XCDs.  Giving each XCD a contiguous range of tiles instead was measured
     // 10 % SLOWER on the z passes: with the default dealing all XCDs stream through the same DRAM pages together, and no
     // tile shares a cache line with another anyway.)
-    const unsigned tile = blockIdx.x;
-    const unsigned tr = tile % d.tpr, rest = tile / d.tpr;
-    const unsigned k1 = rest % d.ext1, k2 = rest / d.ext1;
-    const int64_t k0u = (int64_t)tr * ((!AXIS0 && d.cw) ? W / d.cw : W);
+    // (tile of the row, k1, k2): pass_tile, ig_fft_ab.h
+    unsigned tr, k1, k2;
+    pass_tile(d, tr, k1, k2);
+    const int64_t k0u = (int64_t)tr * ((!AXIS0 && d.cw) ? (d.cw_log2 >= 0 ? W >> d.cw_log2 : W / d.cw) : W);
     int in_lo = d.in_lo, in_hi = d.in_hi, out_lo = d.out_lo, out_hi = d.out_hi;
-    // The tile's support records -- ky hull of its kx tile, z range, segment bitmap word of this thread -- are three
-    // INDEPENDENT loads (all addressed by the tile index alone): request them together, test afterwards.  Tested one after
-    // the other (load, early return, next load ...) they were three dependent round trips at the head of every workgroup,
-    // before the first grid row could be asked for.
+    // the tile's support records, requested here and tested behind the descriptor set-up (pass_records, ig_fft_ab.h)
     short2 k1r = make_short2(0, 0x7fff), trg = make_short2(0, 0x7fff);
-    uint32_t zb = 0xffffffffu;
-    if (BOXED && !AXIS0) {
-        const int64_t tidx = (int64_t)k1 * d.tile_range_k1 + (tr >> d.tile_shift);
-        if (d.k1_range) k1r = d.k1_range[tr >> d.tile_shift];
-        if (d.tile_range) trg = d.tile_range[tidx];
-        if (d.tile_bits) zb = d.tile_bits[tidx * 16 + t];
-    }
-    if (BOXED && !AXIS0 && d.k1_range) {
-        if ((int)k1 < k1r.x || (int)k1 >= k1r.y) return;
-    }
-    if (BOXED && !AXIS0 && d.tile_range) {
-        const short2 r = trg;
-        if (d.tile_range_mode == 1) {
-            out_lo = out_lo > r.x ? out_lo : r.x;
-            out_hi = out_hi < r.y ? out_hi : r.y;
-            if (out_hi <= out_lo) return;                             // nothing of this tile is ever read
-        } else {
-            in_lo = in_lo > r.x ? in_lo : r.x;
-            in_hi = in_hi < r.y ? in_hi : r.y;
-        }
-    }
+    PassRecords rcd{0u, 0u, 0x7fff0000u, 0xffffffffu, false, false, false, true, false};
+    if (BOXED && !AXIS0) rcd = pass_records(d, tw, tr, k1, 16, t, true);
+    const bool has_k1r = rcd.has_k1r, has_trg = rcd.has_trg, has_zb = rcd.has_zb;
     // Buffer descriptors based at the tile's first column: every access is descriptor + a wave-uniform byte
     // offset (SGPR, or an immediate on axis 0) + ONE per-lane 32-bit offset.  A lane offset of IG_OOB fails the
     // hardware range check -- the load returns zero, the store is dropped -- which is how boxes and the ragged
@@ -436,7 +423,7 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
     bool valid;
     unsigned l_in, l_out, l_w;
     if (!AXIS0 && d.cw) {
-        const unsigned a = (unsigned)w % (unsigned)d.cw, yl = (unsigned)w / (unsigned)d.cw;
+        const unsigned yl = d.cw_log2 >= 0 ? (unsigned)w >> d.cw_log2 : (unsigned)w / (unsigned)d.cw, a = (unsigned)w - yl * (unsigned)d.cw;
         valid = k0u + yl < d.ext0;
         l_in = (a * (unsigned)d.in_sa + yl * (unsigned)d.in_s[0] + (unsigned)t * isj) * 8u;
         l_out = (a * (unsigned)d.out_sa + yl * (unsigned)d.out_s[0] + (unsigned)t * osj) * 8u;
@@ -450,19 +437,36 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
     if (!valid) l_in = l_out = l_w = IG_OOB;
     if (!WMODE) l_w = IG_OOB;
     if (SUMW && (w % SUMW) != 0) l_out = IG_OOB;            // only a column's first sub-column stores the coil sum
+    // ---- the records are needed from here on (everything above overlapped their round trip)
+    if (has_k1r) k1r = rcd.k1_hull();
+    if (has_k1r) {
+        if ((int)k1 < k1r.x || (int)k1 >= k1r.y) return;
+    }
+    // (A half-input pass does not wait for its range here where it need not: its loads need nothing of it -- the output side is
+    // narrowed behind the loads.  The y pass, whose hulls do not depend on k1 and are never empty inside a support; and a z pass
+    // that has the ky hulls for its early exit above: an empty range inside the hull only leaves no store flagged.)
+    const bool defer_out = HALF_IN && has_trg && d.tile_range_mode == 1 && (rcd.scalar || has_k1r);
+    if (has_trg && !defer_out) {
+        const short2 r = trg = rcd.range();
+        if (d.tile_range_mode == 1) {
+            out_lo = out_lo > r.x ? out_lo : r.x;
+            out_hi = out_hi < r.y ? out_hi : r.y;
+            if (out_hi <= out_lo) return;                             // nothing of this tile is ever read
+        } else {
+            in_lo = in_lo > r.x ? in_lo : r.x;
+            in_hi = in_hi < r.y ? in_hi : r.y;
+        }
+    }
 
     // Element j = t + 16*m of this thread's column <-> bit m of a 32-bit word: ibits flags the inputs to read
     // (stage 1 loads m = k), obits the outputs to keep (stage 2 stores m = q + r*R1/16).  Boxes [lo, hi) become
     // bit ranges; a per-tile bitmap (k-space support at 16-row granularity) is and-ed in.
+    auto ceil16 = [](int a) -> int { a += 15; return a <= 0 ? 0 : (a >= 512 ? 32 : a >> 4); };
+    auto below = [](int h) -> uint32_t { return h >= 32 ? 0xffffffffu : ((1u << h) - 1u); };
     uint32_t ibits = 0xffffffffu, obits = 0xffffffffu;
     if (BOXED) {
-        auto ceil16 = [](int a) -> int { a += 15; return a <= 0 ? 0 : (a >= 512 ? 32 : a >> 4); };
-        auto below = [](int h) -> uint32_t { return h >= 32 ? 0xffffffffu : ((1u << h) - 1u); };
         ibits = below(ceil16(in_hi - t)) & ~below(ceil16(in_lo - t));
-        obits = below(ceil16(out_hi - t)) & ~below(ceil16(out_lo - t));
-        if (!AXIS0 && d.tile_bits) {
-            if (d.tile_range_mode == 1) obits &= zb; else ibits &= zb;
-        }
+        if (has_zb && d.tile_range_mode != 1) ibits &= rcd.bits();
     }
     // Wave-uniform version of the input mask (the OR over the wave's 64 / W values of t): where a bit is clear NO lane of the
     // wave wants that element, and the load instruction itself is skipped by a scalar branch -- a k-space column is
@@ -480,15 +484,8 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
 #pragma unroll
         for (int l = 0; l < 64; l += W) gin |= (uint32_t)__builtin_amdgcn_readlane((int)ibits, l);
     }
-    // the same for the stores of unweighted passes with a run-time output box -- as ONE opaque block per store (buf_st_gated)
     constexpr bool GATE_ST = BOXED && !AXIS0 && WMODE == 0 && !HALF_OUT && HALF != 3;
     uint32_t gout = 0xffffffffu;
-    if (GATE_ST) {
-        gout = 0;
-#pragma unroll
-        for (int l = 0; l < 64; l += W) gout |= (uint32_t)__builtin_amdgcn_readlane((int)obits, l);
-    }
-
     // ---- stage 1: radix R1 on inputs j = t + k*R2, results (times w_n^{t k}) to the exchange
     // Strided passes re-base their descriptors once per GRP elements -- one 64-bit scalar add, hidden from the compiler, which
     // otherwise recomputes base + k * step with two 32-bit multiplies, a high multiply and their adds for every element -- and
@@ -530,6 +527,26 @@ k_fft_2stage(PassDesc d, const float2* __restrict__ tw) {
             if (WMODE == 1) v[k] = cxmul_r(v[k], wv[k]);
             if (inv) v[k] = cconj(v[k]);
         }
+    }
+    // ---- the output side of the boxes, behind the loads (the half-input y pass has not waited for its record until here)
+    if (defer_out) {
+        trg = rcd.range();
+        out_lo = out_lo > trg.x ? out_lo : trg.x;
+        out_hi = out_hi < trg.y ? out_hi : trg.y;
+    }
+    if (BOXED) {
+        obits = below(ceil16(out_hi - t)) & ~below(ceil16(out_lo - t));
+        if (has_zb && d.tile_range_mode == 1) obits &= rcd.bits();
+    }
+    // the wave-uniform mask for the stores of unweighted passes with a run-time output box -- as ONE opaque block per store (buf_st_gated)
+    if (GATE_ST) {
+        gout = 0;
+#pragma unroll
+        for (int l = 0; l < 64; l += W) gout |= (uint32_t)__builtin_amdgcn_readlane((int)obits, l);
+    }
+    if (TW_LATE) {
+#pragma unroll
+        for (int i = 0; i < TWN; ++i) tws[tid + i * NT] = tw_mine[i];
     }
     __syncthreads();            // twiddle table visible (the global loads above are already in flight)
     if (HALF_IN) PFFTHalfIn<R1>::run(v);
@@ -649,7 +666,7 @@ k_fft3d_a(const float2* __restrict__ in, float2* __restrict__ out, const float2*
     extern __shared__ float2 lds[];
     float2* __restrict__ tws = lds + F3_LDS_ELEMS;
     const int tid = threadIdx.x;
-    for (int k = tid; k < 256; k += 512) tws[k] = tw[k];
+    for (int k = tid; k < 256; k += 512) tws[k] = tw[k];       // (round 5: written behind the loads instead, as in k_fft_2stage, the transform took 1.73 against 1.69 ms)
     // each XCD walks a contiguous range of (n2, z, volume) triples: the four n2 workgroups of a plane -- interleaved 2 KB lines
     // of the same 512 KB -- run behind one L2 at about the same time
     const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), tot = gridDim.x * gridDim.y * gridDim.z;
@@ -784,7 +801,7 @@ k_fft3d_b(const float2* __restrict__ in, float2* __restrict__ out, const float2*
     extern __shared__ float2 lds[];
     float2* __restrict__ tws = lds + 2 * F3_LDS_ELEMS;
     const int tid = threadIdx.x;
-    for (int k = tid; k < 256; k += 512) tws[k] = tw[k];
+    for (int k = tid; k < 256; k += 512) tws[k] = tw[k];       // (round 5: written behind the loads instead, as in k_fft_2stage, the transform took 1.73 against 1.69 ms)
     // blocks are dealt round-robin to the 8 XCDs: give each XCD a contiguous range of (x tile, k1, volume) triples, so that the
     // sixteen x tiles of a row group -- adjacent 128-byte pieces of the same 2 KB rows -- run behind one L2 at about the same time
     const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), tot = gridDim.x * gridDim.y * gridDim.z;
@@ -1198,6 +1215,18 @@ int plan_axis(ig_ctx* ctx, ig_fft* p, int a) {
     return IG_OK;
 }
 
+// The launch grid of a pass kernel: (tiles of a row, k1, k2) in three dimensions where the extents allow (the dispatch order of the
+// linear numbering, without the divisions at the head of every workgroup -- pass_tile, ig_fft_ab.h), else linear.  Also notes log2 of
+// a power-of-two lane split.
+static dim3 pass_grid(PassDesc& d, int64_t tpr) {
+    d.tpr = (unsigned)tpr;
+    d.cw_log2 = -1;
+    if (d.cw > 0 && (d.cw & (d.cw - 1)) == 0) { d.cw_log2 = 0; while ((1 << d.cw_log2) < d.cw) ++d.cw_log2; }
+    const int64_t rows = d.ncols / d.ext0, ext2 = d.ext1 > 0 ? rows / d.ext1 : 0;
+    d.grid3 = (d.ext1 >= 1 && d.ext1 <= 65535 && ext2 >= 1 && ext2 <= 65535 && d.ext1 * ext2 == rows) ? 1 : 0;
+    return d.grid3 ? dim3((unsigned)tpr, (unsigned)d.ext1, (unsigned)ext2) : dim3((unsigned)(tpr * rows));
+}
+
 // launch one 2-stage axis pass (n in {256, 512}); axis0 selects the lane mapping for contiguous columns
 int launch_2stage(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d_in, bool axis0, int wmode) {
     PassDesc d = d_in;
@@ -1208,7 +1237,7 @@ int launch_2stage(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d_in, bool ax
     const int64_t tpr = (d.ext0 + cpt - 1) / cpt;
     const int64_t blocks = tpr * (d.ncols / d.ext0);           // ncols = ext0 * ext1 * ext2
     IG_REQUIRE(ctx, blocks <= 0x7fffffffLL && d.ext1 <= 0x7fffffffLL, "ig_fft: too many tiles");
-    d.tpr = (unsigned)tpr;
+    const dim3 grid = pass_grid(d, tpr);
     {   // every in-tile byte offset must stay inside the 2 GB descriptor window
         const int64_t lim = 0x7fffffffLL / 8;
         // (strided passes re-base once per 4 groups of 16 elements and reach the three groups in between through the scalar
@@ -1219,7 +1248,7 @@ int launch_2stage(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d_in, bool ax
         IG_REQUIRE(ctx, d.in_sj >= 0 && d.out_sj >= 0 && d.in_s[0] >= 0 && d.out_s[0] >= 0 && span_in < lim && span_out < lim && span_w < lim,
                    "ig_fft: axis stride too large for the two-stage kernel");
     }
-    const dim3 grid((unsigned)blocks), block((unsigned)(ax.W * ax.T));
+    const dim3 block((unsigned)(ax.W * ax.T));
 #define IG_2S(R1_, AX0_, WM_, BX_, HF_)                                                             \
     hipLaunchKernelGGL((k_fft_2stage<R1_, 16, 16, 16, AX0_, WM_, BX_, HF_>), grid, block, ax.lds_bytes, ctx->stream, d, ax.d_tw)
 #define IG_2S_W(R1_, AX0_)                                                                           \
@@ -1262,9 +1291,8 @@ int launch_2stage(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d_in, bool ax
         (!d.tile_range || d.tile_shift >= 1)) {
         // 32-column tiles: 256-byte segments per row, 512 threads, 69.6 KB of LDS (2 workgroups per CU)
         PassDesc d2 = d;
-        d2.tpr = (unsigned)(d.ext0 / 32);
         if (d2.tile_range) d2.tile_shift = d.tile_shift - 1;
-        const dim3 g2((unsigned)(d2.tpr * (d.ncols / d.ext0))), b2(512);
+        const dim3 g2 = pass_grid(d2, d.ext0 / 32), b2(512);
         const size_t lds2 = ((size_t)16 * 16 * 32 + 512) * 8;
         if (!ctx->fft_w32_attr) {          // per context (= per device): the attribute is a per-device property
             IG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fft_2stage<32, 16, 16, 32, false, 0, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
@@ -1314,7 +1342,7 @@ int launch_ab_desc(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d_in, int wm
     const int64_t tpr = (d.ext0 + cpt - 1) / cpt;
     const int64_t blocks = tpr * (d.ncols / d.ext0);
     IG_REQUIRE(ctx, blocks <= 0x7fffffffLL && d.ext1 <= 0x7fffffffLL, "ig_fft: too many tiles");
-    d.tpr = (unsigned)tpr;
+    const dim3 grid = pass_grid(d, tpr);
     {   // a thread's lane offset reaches (B - 1) element steps + the tile's lanes: inside the 2 GB descriptor window
         const int64_t lim = 0x7fffffffLL / 8, reach = ax.ab_B - 1;
         const int64_t span_in = reach * d.in_sj + 15 * d.in_s[0] + 15 * d.in_sa, span_out = reach * d.out_sj + 15 * d.out_s[0] + 15 * d.out_sa;
@@ -1331,7 +1359,7 @@ int launch_ab_desc(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d_in, int wm
     // 320^3 grid, same box, alternating runs: 4.03 / 4.08 ms per evaluation against 3.84 / 3.86 ms on 16-column tiles -- padded z
     // 0.56 against 0.47 ms, padded y 0.61-0.63 against 0.57: 20 threads per column make a 32-column workgroup 10 waves with an 80 KB
     // exchange image.  profiles/r05_lab_osf125_ab_w32_{1,0}.json)
-    const dim3 grid((unsigned)blocks), block((unsigned)(anyfft::AB_W * ax.ab_B));
+    const dim3 block((unsigned)(anyfft::AB_W * ax.ab_B));
     int r = ig_abd_launch_part0(ctx->stream, ax.n, wm, grid, block, d, ax.d_tw);
     if (!r) r = ig_abd_launch_part1(ctx->stream, ax.n, wm, grid, block, d, ax.d_tw);
     if (!r) r = ig_abd_launch_part2(ctx->stream, ax.n, wm, grid, block, d, ax.d_tw);
@@ -1432,13 +1460,13 @@ int launch_chirp_desc(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d_in) {
     const int64_t tpr = (d.ext0 + anyfft::AB_W - 1) / anyfft::AB_W;
     const int64_t blocks = tpr * (d.ncols / d.ext0);
     IG_REQUIRE(ctx, blocks <= 0x7fffffffLL && d.ext1 <= 0x7fffffffLL, "ig_fft: too many tiles");
-    d.tpr = (unsigned)tpr;
+    const dim3 grid = pass_grid(d, tpr);
     {
         const int64_t lim = 0x7fffffffLL / 8, reach = ch.sub.ab_B - 1;
         IG_REQUIRE(ctx, d.in_sj >= 0 && d.out_sj >= 0 && d.in_s[0] >= 0 && d.out_s[0] >= 0 && reach * d.in_sj + 15 * d.in_s[0] < lim && reach * d.out_sj + 15 * d.out_s[0] < lim,
                    "ig_fft: axis stride too large for the chirp-z kernel");
     }
-    const dim3 grid((unsigned)blocks), block((unsigned)(anyfft::AB_W * ch.sub.ab_B));
+    const dim3 block((unsigned)(anyfft::AB_W * ch.sub.ab_B));
     int r = ig_abz_launch_part0(ctx->stream, ch.m, grid, block, d, ch.sub.d_tw);
     if (!r) r = ig_abz_launch_part1(ctx->stream, ch.m, grid, block, d, ch.sub.d_tw);
     if (!r) r = ig_abz_launch_part2(ctx->stream, ch.m, grid, block, d, ch.sub.d_tw);
@@ -1886,6 +1914,7 @@ static int exec_padded_layout2(ig_fft* p, const float2* x, int64_t x_bstride, co
         d.ext0 = C * n0; d.ext1 = n1; d.ncols = C * n0 * n1;
         d.in_lo = (int)l2; d.in_hi = (int)(l2 + b2); d.out_lo = 0; d.out_hi = (int)n2; d.inverse = 0;
         d.tile_range = support; d.tile_range_mode = 1; d.tile_range_k1 = snt; d.tile_shift = sshift;
+        // (round 5, measured: with the ky hulls for the early exit and range and bitmap read behind the loads, this pass took 1.029 ms against 1.010)
         if (support) {      // the output-side form of the bitmaps (it follows the input-side form where the two differ)
             d.tile_bits = reinterpret_cast<const uint32_t*>(support + n1 * snt + snt) + (p->zw_out != p->zw_in ? n1 * snt * p->zw_in : 0);
             d.tile_words = p->zw_out;

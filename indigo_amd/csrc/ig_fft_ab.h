@@ -33,6 +33,8 @@ struct PassDesc {
     int64_t in_s[3], out_s[3], w_s[3];
     int64_t ext0, ext1, ncols;
     unsigned tpr;               // tiles per (k1, k2) row = ceil(ext0 / W); filled in by the launcher
+    int grid3;                  // k_fft_2stage: the launch grid is (tpr, ext1, ext2) -- no divisions at the head of a workgroup; filled in by the launcher
+    int cw_log2;                // log2(cw) where cw is a power of two, else -1; filled in by the launcher
     // Optional split of a tile's W lanes (strided passes): cw > 0 makes lane w address sub-column a = w % cw (element
     // strides in_sa / out_sa / w_sa) of column k0 = tile*(W/cw) + w/cw, i.e. a tile is W/cw columns of cw contiguous
     // sub-columns.  The coil-interleaved grid layout uses it for its x passes (cw = coils, columns = lines).
@@ -60,6 +62,52 @@ struct PassDesc {
 
 
 #include "ig_packed.h"
+
+// ---- the head of a pass workgroup (k_fft_2stage, k_fft_ab_desc, k_fft_chirp) -----------------------------------------------
+// Round 5: everything between the start of a workgroup and its first grid row in flight is time in which the workgroup keeps
+// nothing of HBM busy, and only two of these workgroups fit a CU.  Measured on the headline (same box, alternating runs): the
+// twiddle copy written to LDS on the spot (a round trip the compiler waits for before anything else), the two integer divisions
+// of the linear tile number and the support records fetched one after the other cost 2 ... 6 % of every y / z pass.
+// (1) The launcher passes (tile of the row, k1, k2) as a three-dimensional grid where the extents allow: the same dispatch order
+//     as the linear numbering, no divisions.
+__device__ __forceinline__ void pass_tile(const PassDesc& d, unsigned& tr, unsigned& k1, unsigned& k2) {
+    if (d.grid3) { tr = blockIdx.x; k1 = blockIdx.y; k2 = blockIdx.z; }
+    else { const unsigned tile = blockIdx.x, rest = tile / d.tpr; tr = tile % d.tpr; k1 = rest % (unsigned)d.ext1; k2 = rest / (unsigned)d.ext1; }
+}
+// (2) The tile's support records -- ky hull of its kx tile, z range, bitmap word of this thread -- are INDEPENDENT loads, all
+//     addressed by the tile index alone: requested together at the top of the kernel, used as late as possible.  The ky hull does
+//     not depend on k1 (one word per kx tile: the same for a whole column of workgroups): a scalar load, served by the scalar
+//     cache; so is a range that does not depend on k1 (the y passes).  A range per (k1, tile) and the bitmap word are vector
+//     loads, the range read back with v_readlane where it is needed -- as a scalar load the compiler sank it into the block of
+//     its first use, a dependent trip of its own behind the hull's.
+struct PassRecords {
+    uint32_t rec_v, rec_s, hull_s, zb_raw;
+    bool has_k1r, has_trg, has_zb, word_ok, scalar;
+    __device__ __forceinline__ short2 k1_hull() const { return make_short2((short)(hull_s & 0xffffu), (short)(hull_s >> 16)); }
+    __device__ __forceinline__ short2 range() const {
+        const uint32_t a = scalar ? rec_s : (uint32_t)__builtin_amdgcn_readfirstlane((int)rec_v);
+        return make_short2((short)(a & 0xffffu), (short)(a >> 16));
+    }
+    // this thread's bitmap word (all ones without a bitmap); called where the word is USED: a select on the loaded value right
+    // behind the load makes the compiler wait for it there
+    __device__ __forceinline__ uint32_t bits() const { return has_zb ? (word_ok ? zb_raw : 0u) : 0xffffffffu; }
+};
+__device__ __forceinline__ PassRecords pass_records(const PassDesc& d, const void* safe, unsigned tr, unsigned k1, int words, int word, bool word_ok) {
+    PassRecords r;
+    r.rec_v = 0; r.rec_s = 0; r.hull_s = 0x7fff0000u; r.zb_raw = 0xffffffffu; r.word_ok = word_ok;
+    r.has_k1r = d.k1_range != nullptr; r.has_trg = d.tile_range != nullptr; r.has_zb = d.tile_bits != nullptr;
+    r.scalar = r.has_trg && d.tile_range_k1 == 0;
+    if (r.has_k1r) r.hull_s = *reinterpret_cast<const uint32_t*>(d.k1_range + (tr >> d.tile_shift));
+    if (r.scalar) r.rec_s = *reinterpret_cast<const uint32_t*>(d.tile_range + (tr >> d.tile_shift));
+    if ((r.has_trg && !r.scalar) || r.has_zb) {
+        const int64_t tidx = (int64_t)k1 * d.tile_range_k1 + (tr >> d.tile_shift);
+        const uint32_t* pt = (r.has_trg && !r.scalar) ? reinterpret_cast<const uint32_t*>(d.tile_range + tidx) : reinterpret_cast<const uint32_t*>(safe);
+        const uint32_t* pb = (r.has_zb && word_ok) ? d.tile_bits + (tidx * words + word) : reinterpret_cast<const uint32_t*>(safe);
+        r.zb_raw = *pb;
+        r.rec_v = *pt;
+    }
+    return r;
+}
 
 namespace anyfft {
 
@@ -334,14 +382,19 @@ k_fft_ab_desc(PassDesc d, const float2* __restrict__ tw) {
     extern __shared__ float2 lds[];
     float2* __restrict__ tws = lds + AR * B * W;
     const int tid = threadIdx.x;
-    for (int k = tid; k < N; k += W * B) tws[k] = tw[k];
+    // the twiddles: requested here, written to LDS behind the stage-1 loads (written on the spot they are a round trip of their own)
+    constexpr int TWN = (N + W * B - 1) / (W * B);
+    float2 tw_mine[TWN];
+#pragma unroll
+    for (int i = 0; i < TWN; ++i) { const int k = tid + i * W * B; tw_mine[i] = tw[k < N ? k : N - 1]; }       // (no branch: the load must not be waited for here)
     const int b = tid / W, w = tid % W;
     const bool inv = d.inverse != 0;
     // the workgroup's tile: 16 consecutive k0 (or 16 / cw columns x cw sub-columns) of one (k1, k2) row
-    const unsigned tile = blockIdx.x;
-    const unsigned tr = tile % d.tpr, rest = tile / d.tpr;
-    const unsigned k1i = rest % d.ext1, k2i = rest / d.ext1;
-    const int64_t k0u = (int64_t)tr * (d.cw ? W / d.cw : W);
+    unsigned tr, k1i, k2i;
+    pass_tile(d, tr, k1i, k2i);
+    const int tw_ = d.tile_words ? d.tile_words : 16;
+    const PassRecords rcd = pass_records(d, tw, tr, k1i, tw_, b, b < tw_);
+    const int64_t k0u = (int64_t)tr * (d.cw ? (d.cw_log2 >= 0 ? W >> d.cw_log2 : W / d.cw) : W);
     const float2* const b_in = d.in + (k0u * d.in_s[0] + (int64_t)k1i * d.in_s[1] + (int64_t)k2i * d.in_s[2]);
     float2* const b_out = d.out + (k0u * d.out_s[0] + (int64_t)k1i * d.out_s[1] + (int64_t)k2i * d.out_s[2]);
     const float2* const b_w = WMODE ? d.w + (k0u * d.w_s[0] + (int64_t)k1i * d.w_s[1] + (int64_t)k2i * d.w_s[2]) : nullptr;
@@ -349,7 +402,7 @@ k_fft_ab_desc(PassDesc d, const float2* __restrict__ tw) {
     bool valid;
     unsigned l_in, l_out, l_w;
     if (d.cw) {
-        const unsigned a = (unsigned)w % (unsigned)d.cw, yl = (unsigned)w / (unsigned)d.cw;
+        const unsigned yl = d.cw_log2 >= 0 ? (unsigned)w >> d.cw_log2 : (unsigned)w / (unsigned)d.cw, a = (unsigned)w - yl * (unsigned)d.cw;
         valid = k0u + yl < d.ext0;
         l_in = (a * (unsigned)d.in_sa + yl * (unsigned)d.in_s[0] + (unsigned)b * isj) * 8u;
         l_out = (a * (unsigned)d.out_sa + yl * (unsigned)d.out_s[0] + (unsigned)b * osj) * 8u;
@@ -363,17 +416,16 @@ k_fft_ab_desc(PassDesc d, const float2* __restrict__ tw) {
     if (!valid) l_in = l_out = l_w = IG_OOB;
     if (!WMODE) l_w = IG_OOB;
     if (SUMW && (w % SUMW) != 0) l_out = IG_OOB;            // only a column's first sub-column stores the coil sum
-    // the tile's support records (three independent loads, all addressed by the tile index: requested together, tested afterwards)
+    // the tile's support records (requested at the top: pass_records), tested here
     int in_lo = d.in_lo, in_hi = d.in_hi, out_lo = d.out_lo, out_hi = d.out_hi;
-    uint32_t zb = 0xffffffffu;
+    const bool defer_out = rcd.has_trg && d.tile_range_mode == 1 && (rcd.scalar || rcd.has_k1r);
     {
-        short2 k1r = make_short2(0, 0x7fff), trg = make_short2(0, 0x7fff);
-        const int64_t tidx = (int64_t)k1i * d.tile_range_k1 + (tr >> d.tile_shift);
-        if (d.k1_range) k1r = d.k1_range[tr >> d.tile_shift];
-        if (d.tile_range) trg = d.tile_range[tidx];
-        if (d.tile_bits) { const int tw_ = d.tile_words ? d.tile_words : 16; zb = b < tw_ ? d.tile_bits[tidx * tw_ + b] : 0u; }
-        if (d.k1_range && ((int)k1i < k1r.x || (int)k1i >= k1r.y)) return;          // (wave- and workgroup-uniform: before any barrier)
-        if (d.tile_range) {
+        if (rcd.has_k1r) { const short2 k1r = rcd.k1_hull(); if ((int)k1i < k1r.x || (int)k1i >= k1r.y) return; }          // (wave- and workgroup-uniform: before any barrier)
+        // (a zero-padded pass does not wait for its range here where it need not: its loads need nothing of it, the output side is
+        // narrowed behind them.  The y pass -- output hull of the kx tile, never empty inside a support -- and a z pass whose tiles
+        // outside the ky hull of their kx tile have left above: an empty range inside the hull only leaves no store flagged.)
+        if (rcd.has_trg && !defer_out) {
+            const short2 trg = rcd.range();
             if (d.tile_range_mode == 1) {
                 out_lo = out_lo > trg.x ? out_lo : trg.x;
                 out_hi = out_hi < trg.y ? out_hi : trg.y;
@@ -387,17 +439,10 @@ k_fft_ab_desc(PassDesc d, const float2* __restrict__ tw) {
     // element j = b + B a <-> bit a of ibits (stage 1 loads); output k = b + A k2 <-> bit k2 of obits (stage 2 stores, b < A)
     auto below = [](int h) -> uint32_t { return h >= 32 ? 0xffffffffu : ((1u << h) - 1u); };
     uint32_t ibits = below(ab_ceil_div_clamp(in_hi - b, B, A)) & ~below(ab_ceil_div_clamp(in_lo - b, B, A));
-    uint32_t obits = below(ab_ceil_div_clamp(out_hi - b, A, B)) & ~below(ab_ceil_div_clamp(out_lo - b, A, B));
-    if (d.tile_bits) { if (d.tile_range_mode == 1) obits &= zb; else ibits &= zb; }
+    if (d.tile_range_mode != 1) ibits &= rcd.bits();
     uint32_t gin = 0;                                          // wave-uniform: elements SOME lane of this wave wants
 #pragma unroll
     for (int l = 0; l < 64; l += W) gin |= (uint32_t)__builtin_amdgcn_readlane((int)ibits, l);
-    uint32_t gout = 0xffffffffu;                               // the same for the outputs (unweighted passes gate their stores with it)
-    if (WMODE == 0) {
-        gout = 0;
-#pragma unroll
-        for (int l = 0; l < 64; l += W) gout |= (uint32_t)__builtin_amdgcn_readlane((int)obits, l);
-    }
 
     float2 v[A];
     {
@@ -415,6 +460,22 @@ k_fft_ab_desc(PassDesc d, const float2* __restrict__ tw) {
             if (inv) v[a].y = -v[a].y;
         }
     }
+    // ---- the output side of the boxes, behind the loads
+    if (defer_out) {
+        const short2 trg = rcd.range();
+        out_lo = out_lo > trg.x ? out_lo : trg.x;
+        out_hi = out_hi < trg.y ? out_hi : trg.y;
+    }
+    uint32_t obits = below(ab_ceil_div_clamp(out_hi - b, A, B)) & ~below(ab_ceil_div_clamp(out_lo - b, A, B));
+    if (d.tile_range_mode == 1) obits &= rcd.bits();
+    uint32_t gout = 0xffffffffu;                               // wave-uniform: outputs SOME lane of this wave keeps (unweighted passes gate their stores with it)
+    if (WMODE == 0) {
+        gout = 0;
+#pragma unroll
+        for (int l = 0; l < 64; l += W) gout |= (uint32_t)__builtin_amdgcn_readlane((int)obits, l);
+    }
+#pragma unroll
+    for (int i = 0; i < TWN; ++i) if (tid + i * W * B < N) tws[tid + i * W * B] = tw_mine[i];
     RegDFT<A>::run(v);
     __syncthreads();                                   // the twiddle table is in place
 #pragma unroll
@@ -490,9 +551,9 @@ k_fft_chirp(PassDesc d, const float2* __restrict__ tw) {
     const int tid = threadIdx.x;
     for (int k = tid; k < N; k += AB_W * B) { tws[k] = tw[k]; t_b[k] = d.w[k]; t_hat[k] = d.w2[k]; t_out[k] = d.w2[N + k]; }
     const int b = tid / AB_W, w = tid % AB_W;
-    const unsigned tile = blockIdx.x;
-    const unsigned tr = tile % d.tpr, rest = tile / d.tpr;
-    const unsigned k1i = rest % d.ext1, k2i = rest / d.ext1;
+    unsigned tr, k1i, k2i;
+    pass_tile(d, tr, k1i, k2i);
+    const PassRecords rcd = pass_records(d, tw, tr, k1i, B, b, true);
     const int64_t k0u = (int64_t)tr * AB_W;
     const float2* const b_in = d.in + (k0u * d.in_s[0] + (int64_t)k1i * d.in_s[1] + (int64_t)k2i * d.in_s[2]);
     float2* const b_out = d.out + (k0u * d.out_s[0] + (int64_t)k1i * d.out_s[1] + (int64_t)k2i * d.out_s[2]);
@@ -506,15 +567,10 @@ k_fft_chirp(PassDesc d, const float2* __restrict__ tw) {
     // transform of m = A B >= 2 n - 1 points, of which only rows below n exist --, so the bitmaps of a chirp-z axis are B words per
     // entry on both sides: bit kz / B of word kz % B (ig_fft_support_words).  All of it wave- and workgroup-uniform, before any barrier.
     int in_lo = d.in_lo, in_hi = d.in_hi, out_lo = d.out_lo, out_hi = d.out_hi;
-    uint32_t zb = 0xffffffffu;
     {
-        short2 k1r = make_short2(0, 0x7fff), trg = make_short2(0, 0x7fff);
-        const int64_t tidx = (int64_t)k1i * d.tile_range_k1 + (tr >> d.tile_shift);
-        if (d.k1_range) k1r = d.k1_range[tr >> d.tile_shift];
-        if (d.tile_range) trg = d.tile_range[tidx];
-        if (d.tile_bits) zb = d.tile_bits[tidx * B + b];
-        if (d.k1_range && ((int)k1i < k1r.x || (int)k1i >= k1r.y)) return;
-        if (d.tile_range) {
+        if (rcd.has_k1r) { const short2 k1r = rcd.k1_hull(); if ((int)k1i < k1r.x || (int)k1i >= k1r.y) return; }
+        if (rcd.has_trg) {
+            const short2 trg = rcd.range();
             if (d.tile_range_mode == 1) {
                 out_lo = out_lo > trg.x ? out_lo : trg.x;
                 out_hi = out_hi < trg.y ? out_hi : trg.y;
@@ -529,7 +585,7 @@ k_fft_chirp(PassDesc d, const float2* __restrict__ tw) {
     // input j = b + B a <-> bit a; output k = b + B k2 (k2 < A) <-> bit k2
     uint32_t ibits = below(ab_ceil_div_clamp(in_hi - b, B, A)) & ~below(ab_ceil_div_clamp(in_lo - b, B, A));
     uint32_t obits = below(ab_ceil_div_clamp(out_hi - b, B, A)) & ~below(ab_ceil_div_clamp(out_lo - b, B, A));
-    if (d.tile_bits) { if (d.tile_range_mode == 1) obits &= zb; else ibits &= zb; }
+    if (d.tile_range_mode == 1) obits &= rcd.bits(); else ibits &= rcd.bits();
     uint32_t gin = 0, gout = 0;
 #pragma unroll
     for (int l = 0; l < 64; l += AB_W) { gin |= (uint32_t)__builtin_amdgcn_readlane((int)ibits, l); gout |= (uint32_t)__builtin_amdgcn_readlane((int)obits, l); }
