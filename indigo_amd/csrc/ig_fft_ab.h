@@ -295,7 +295,12 @@ k_fft_ab(const float2* __restrict__ x, float2* __restrict__ y, const float2* __r
     extern __shared__ float2 lds[];
     float2* __restrict__ tws = lds + (AXIS0 ? AB_W * AR * (B | 1) : AR * B * AB_W);
     const int tid = threadIdx.x;
-    for (int k = tid; k < N; k += AB_W * B) tws[k] = tw[k];
+    // the twiddles: requested here, written to LDS behind the stage-1 loads (see pass_tile above: written on the spot, the copy is a
+    // round trip of its own at the head of every workgroup)
+    constexpr int TWN = (N + AB_W * B - 1) / (AB_W * B);
+    float2 tw_mine[TWN];
+#pragma unroll
+    for (int i = 0; i < TWN; ++i) { const int k = tid + i * AB_W * B; tw_mine[i] = tw[k < N ? k : N - 1]; }
     const int b = AXIS0 ? tid % B : tid / AB_W, w = AXIS0 ? tid / B : tid % AB_W;
     const int64_t col = (int64_t)blockIdx.x * AB_W + w;
     const bool valid = col < ncols;
@@ -317,6 +322,8 @@ k_fft_ab(const float2* __restrict__ x, float2* __restrict__ y, const float2* __r
 #pragma unroll
         for (int a = 0; a < A; ++a) v[a] = make_float2(0.f, 0.f);
     }
+#pragma unroll
+    for (int i = 0; i < TWN; ++i) if (tid + i * AB_W * B < N) tws[tid + i * AB_W * B] = tw_mine[i];
     RegDFT<A>::run(v);
     __syncthreads();                                   // the twiddle table is in place
 #pragma unroll
