@@ -556,7 +556,15 @@ k_fft_chirp(PassDesc d, const float2* __restrict__ tw) {
     float2* __restrict__ t_hat = t_b + N;
     float2* __restrict__ t_out = t_hat + N;
     const int tid = threadIdx.x;
-    for (int k = tid; k < N; k += AB_W * B) { tws[k] = tw[k]; t_b[k] = d.w[k]; t_hat[k] = d.w2[k]; t_out[k] = d.w2[N + k]; }
+    // (requested here, written to LDS behind the first transform's loads: written on the spot the copies are a round trip of their own
+    // at the head of a workgroup of which one or two fit a CU)
+    constexpr int TWN = (N + AB_W * B - 1) / (AB_W * B);
+    float2 tab_mine[TWN][4];
+#pragma unroll
+    for (int i = 0; i < TWN; ++i) {
+        const int k = tid + i * AB_W * B, kk = k < N ? k : N - 1;
+        tab_mine[i][0] = tw[kk]; tab_mine[i][1] = d.w[kk]; tab_mine[i][2] = d.w2[kk]; tab_mine[i][3] = d.w2[N + kk];
+    }
     const int b = tid / AB_W, w = tid % AB_W;
     unsigned tr, k1i, k2i;
     pass_tile(d, tr, k1i, k2i);
@@ -606,6 +614,11 @@ k_fft_chirp(PassDesc d, const float2* __restrict__ tw) {
         if (!((gin >> a) & 1u)) { v[a] = mk(0.f, 0.f); continue; }
         const unsigned off = (unsigned)__builtin_amdgcn_sbfe((int)~ibits, a, 1);
         v[a] = from2(buf_ld<true>(make_rsrc(b_in + (int64_t)(B * a) * d.in_sj), l_in | off, 0));
+    }
+#pragma unroll
+    for (int i = 0; i < TWN; ++i) {
+        const int k = tid + i * AB_W * B;
+        if (k < N) { tws[k] = tab_mine[i][0]; t_b[k] = tab_mine[i][1]; t_hat[k] = tab_mine[i][2]; t_out[k] = tab_mine[i][3]; }
     }
     __syncthreads();                                   // the tables are in place (the loads above are in flight)
 #pragma unroll
