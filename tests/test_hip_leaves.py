@@ -553,6 +553,14 @@ def test_fft_shapes(hip, shape):
     _check_fft(hip, tuple(shape), 3, seed=sum(shape))
 
 
+def test_fft_more_rows_than_a_launch_grid_dimension_holds(hip):
+    """the pass kernels take (tile, k1, k2) as a three-dimensional launch grid where the extents allow (pass_grid, ig_fft.hip); with
+    more than 65535 rows of columns -- here a batch of 66000 transforms of 4 x 256 points: the 256-point axis steps 4 elements, its
+    rows are the batch members -- the launcher falls back to the linear grid and the kernel to its divisions.  Both routes vs numpy."""
+    _check_fft(hip, (4, 256), 66000, seed=11)
+    _check_fft(hip, (4, 256), 300, seed=12)
+
+
 AB_LENGTHS = [160, 192, 224, 240, 270, 288, 320, 360, 384, 392, 400, 432, 480, 576, 600, 640,
               # further lengths of the generated list (tools/gen_ab_list.py): odd ones, 5 x 25, the longest splits (four exchange rounds)
               96, 105, 125, 147, 243, 375, 441, 567, 625, 675, 729, 840, 1000 - 40, 1024]
