@@ -532,7 +532,10 @@ def run_sense(args, cfg, B, comm, world, rank, steps, warmup, want_cpu, quiet=Fa
                                    if world > 1 else ("rank %d of %d alone (no communication)" % shard if shard else "single GPU")),
                    "grid_layout": layout, "tree": tree, "coil_chunks_per_rank": nchunks,
                    "coil_chunk_widths": [lf['width'] for lf in leaves_z] or None, "spokes_scale": scale,
-                   "support_table_kx_points_per_entry": (sup_tile if sup_tab is not None else None)},
+                   "support_table_kx_points_per_entry": (sup_tile if sup_tab is not None else None),
+                   # large arrays are allocated a few times and the best-placed candidate kept (HipBackend.tuning['placement_candidates'],
+                   # DESIGN.md 3.1): bytes, the candidates' probe times in ms, the one kept -- part of set-up, outside the timed region
+                   "placement": [list(e) for e in getattr(B, "_placement_log", [])][-4:] or None},
         "roofline": roofline,
         "eval_traffic_GB": traffic_bytes / 1e9,
         "eval_traffic_frac": traffic_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,

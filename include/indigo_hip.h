@@ -77,6 +77,10 @@ int  ig_library_bytes(ig_ctx* ctx, size_t* bytes);
  * ---------------------------------------------------------------------- */
 int  ig_malloc(ig_ctx* ctx, size_t nbytes, void** dptr);      /* >=256-B aligned; nbytes==0 gives a valid unique pointer */
 int  ig_free(ig_ctx* ctx, void* dptr);                         /* synchronous w.r.t. the stream */
+/* Writes zeros over the buffer as 512 rows of 256-byte segments nbytes / 512 apart and reports the fastest of three passes in ms:
+ * how well THIS allocation serves passes that step megabytes per element (no reference counterpart; the backend keeps the best of a
+ * few candidates for its large arrays).  Destroys the contents.  *ms = 0 for buffers too small to have such a pattern. */
+int  ig_probe_placement(ig_ctx* ctx, void* dptr, size_t nbytes, double* ms);
 int  ig_memset0(ig_ctx* ctx, void* dptr, size_t nbytes);
 /* 2-D strided copy of `height` rows of `width_bytes` bytes.  H2D and D2H are
  * synchronous (host buffer is pageable numpy memory); D2D is asynchronous.  */

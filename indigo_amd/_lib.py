@@ -32,6 +32,7 @@ PROTOTYPES = {
     "ig_library_bytes":   (c_int, [c_void_p, POINTER(c_size_t)]),
     "ig_malloc":          (c_int, [c_void_p, c_size_t, POINTER(c_void_p)]),
     "ig_free":            (c_int, [c_void_p, c_void_p]),
+    "ig_probe_placement": (c_int, [c_void_p, c_void_p, c_size_t, POINTER(c_double)]),
     "ig_memset0":         (c_int, [c_void_p, c_void_p, c_size_t]),
     "ig_copy2d":          (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_size_t, c_size_t, c_int]),
     "ig_event_create":    (c_int, [c_void_p, POINTER(c_void_p)]),

@@ -108,9 +108,12 @@ class HipBackend(Backend):
         #   wide_bricks   64-column column-major panels: brick scatter through LDS (adjoint)
         #   slots         coil counts whose adjoint gridding is the slot-format scatter (ig_ccsrmm_t_slots): the ranks of a coil-sharded
         #                 run with one or two coils
+        #   placement_candidates / placement_min_bytes   arrays of at least that many bytes (scratch arenas, grids) are allocated that many
+        #                 times, probed (ig_probe_placement) and the best-placed candidate kept; 1 = plain allocation
         #   cg_graph      HipBackend.cg replays a block of iterations as one HIP graph launch (ig_graph_*).  Off: measured on the headline
         #                 problem the replay saves 0.03 ms of a 6.89 ms iteration and recording costs 5 ms per solve (profiles/r05_cg_graph_ab.log)
-        self.tuning = dict(cg_graph=False, bricks=(4, 8), slots=(1, 2), slot_shape=(4, 4, 256, 64), support_tile={8: 4, 4: 8}, brick_shape={8: (2, 2, 4096, 4096), 4: (2, 4, 4096, 4096)}, xrows=True, runs=True, wide_bricks=True,
+        self._placement_log = []          # (bytes, candidate probe times in ms, chosen) of every array placed by probing
+        self.tuning = dict(placement_candidates=3, placement_min_bytes=1 << 31, cg_graph=False, bricks=(4, 8), slots=(1, 2), slot_shape=(4, 4, 256, 64), support_tile={8: 4, 4: 8}, brick_shape={8: (2, 2, 4096, 4096), 4: (2, 4, 4096, 4096)}, xrows=True, runs=True, wide_bricks=True,
                            wide_brick_shape=(2, 2), wide_task_shape=(8192, 2048))
 
     def __del__(self):
@@ -199,9 +202,37 @@ class HipBackend(Backend):
 
         def _malloc(self, shape, dtype):
             b = self._backend
+            ncand = int(b.tuning.get('placement_candidates', 1))
+            if ncand > 1 and self.nbytes >= int(b.tuning.get('placement_min_bytes', 1 << 31)):
+                return self._malloc_best_placed(ncand)
             ptr = ctypes.c_void_p()
             b._check(b._L.ig_malloc(b._ctx, self.nbytes, ctypes.byref(ptr)), "ig_malloc(%d bytes)" % self.nbytes)
             return ptr.value
+
+        def _malloc_best_placed(self, ncand):
+            """A large array (a scratch arena, a grid): allocate up to `ncand` candidates, time the library's placement probe on each
+            (ig_probe_placement: the write pattern of a pass that steps megabytes per element) and keep the fastest -- allocations of
+            one size made by one process differ by 3 ... 6 % in such passes, repeatably.  Candidates that no longer
+            fit are simply not tried; the losers are freed before this returns."""
+            b = self._backend
+            cands = []
+            for _ in range(ncand):
+                ptr = ctypes.c_void_p()
+                rc = b._L.ig_malloc(b._ctx, self.nbytes, ctypes.byref(ptr))
+                if rc != 0:
+                    if not cands:
+                        b._check(rc, "ig_malloc(%d bytes)" % self.nbytes)
+                    break
+                ms = ctypes.c_double(0.0)
+                b._check(b._L.ig_probe_placement(b._ctx, ptr, self.nbytes, ctypes.byref(ms)), "ig_probe_placement")
+                cands.append((ms.value, ptr.value))
+            best = max(cands) if b.tuning.get('placement_pick') == 'worst' else min(cands)       # ('worst': lab, to see what the probe's spread is worth)
+            for ms, ptr in cands:
+                if ptr != best[1]:
+                    b._L.ig_free(b._ctx, ctypes.c_void_p(ptr))
+            b._placement_log.append((self.nbytes, [round(ms, 4) for ms, _ in cands], round(best[0], 4)))
+            log.debug("placement: %d bytes, candidates %s ms -> %.4f", self.nbytes, [round(ms, 4) for ms, _ in cands], best[0])
+            return best[1]
 
         def _free(self):
             b = self._backend

@@ -232,6 +232,49 @@ int ig_malloc(ig_ctx* ctx, size_t nbytes, void** dptr) {
     return IG_OK;
 }
 
+// Placement probe (round 5): the passes that step megabytes per element (the y passes of the coil-interleaved grid:
+// 512 rows of 256-byte segments 16 MB apart) run 3 ... 6 % slower on some allocations than on others of the same size made by the
+// same process -- the same kernel on six hipMalloc'ed buffers: 1.61 ms on three, 1.66 ... 1.70 on the others, repeatably; two runs of
+// the benchmark on one box differed by exactly that.  This writes zeros over the buffer in that pattern (512 rows of nbytes / 512,
+// in tiles of 256-byte segments) and reports the time of the fastest of three passes; the backend allocates a few candidates for its
+// large arrays and keeps the best (HipBackend.tuning['placement_candidates']).  The buffer's contents are destroyed.
+namespace {
+__global__ void __launch_bounds__(512)
+k_probe_placement(float4* __restrict__ p, size_t pitch16 /* row pitch in float4 */) {
+    const size_t tile = blockIdx.x;
+    const int lane = threadIdx.x & 15, row0 = threadIdx.x >> 4;
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+        p[(size_t)(row0 + 32 * s) * pitch16 + tile * 16 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+}   // namespace
+
+int ig_probe_placement(ig_ctx* ctx, void* dptr, size_t nbytes, double* ms) {
+    IG_REQUIRE(ctx, ctx && ms, "ig_probe_placement: bad arguments");
+    *ms = 0.0;
+    const size_t pitch = (nbytes / 512) & ~(size_t)4095;
+    if (!dptr || pitch == 0) return IG_OK;                     // too small to have such a pattern
+    if (int rc = ig_set_device(ctx)) return rc;
+    hipEvent_t e0, e1;
+    IG_HIP(ctx, hipEventCreate(&e0));
+    IG_HIP(ctx, hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int rep = 0; rep < 4; ++rep) {
+        IG_HIP(ctx, hipEventRecord(e0, ctx->stream));
+        hipLaunchKernelGGL(k_probe_placement, dim3((unsigned)(pitch / 256)), dim3(512), 0, ctx->stream, (float4*)dptr, pitch / 16);
+        IG_HIP(ctx, hipEventRecord(e1, ctx->stream));
+        IG_HIP(ctx, hipEventSynchronize(e1));
+        float t = 0.f;
+        IG_HIP(ctx, hipEventElapsedTime(&t, e0, e1));
+        if (rep && t < best) best = t;
+    }
+    IG_HIP(ctx, hipEventDestroy(e0));
+    IG_HIP(ctx, hipEventDestroy(e1));
+    IG_LAUNCH_CHECK(ctx, "k_probe_placement");
+    *ms = best;
+    return IG_OK;
+}
+
 int ig_free(ig_ctx* ctx, void* dptr) {
     IG_REQUIRE(ctx, ctx != nullptr, "ig_free: ctx is NULL");
     if (!dptr) return IG_OK;

@@ -49,6 +49,34 @@ def test_array_roundtrips(hip, n):
         hip.zero_array(arr.shape, np.complex128).copy_from(arr)
 
 
+
+def test_large_arrays_are_placed_by_probing(hip):
+    """arrays of at least tuning['placement_min_bytes'] are allocated tuning['placement_candidates'] times, each candidate timed by
+    ig_probe_placement (the write pattern of a pass that steps megabytes per element) and the fastest kept; the probe destroys the
+    contents, so it must run before anything is written: zero_array still returns zeros, copy_array the host's values, and the
+    losers are freed (mem_usage does not grow by more than the array)."""
+    old = dict(hip.tuning)
+    try:
+        hip.tuning['placement_min_bytes'] = 32 << 20
+        hip.tuning['placement_candidates'] = 3
+        n = (48 << 20) // 8
+        before = len(hip._placement_log)
+        z = hip.zero_array((n,), C64)
+        assert len(hip._placement_log) == before + 1
+        nbytes, cands, chosen = hip._placement_log[-1]
+        assert nbytes == n * 8 and len(cands) == 3 and chosen == min(cands) and chosen > 0
+        assert not z.to_host().any()
+        x = rand64c(n, seed=3)
+        x_d = hip.copy_array(x)
+        assert len(hip._placement_log) == before + 2
+        np.testing.assert_equal(x_d.to_host(), x)
+        hip.tuning['placement_candidates'] = 1
+        hip.zero_array((n,), C64)
+        assert len(hip._placement_log) == before + 2           # plain allocation
+    finally:
+        hip.tuning.clear()
+        hip.tuning.update(old)
+
 @pytest.mark.parametrize("s", [-2, -1, 1, 2])
 def test_array_slice_1d(hip, s):
     arr = np.arange(10)
