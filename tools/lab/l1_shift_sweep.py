@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """LAB (round 5): the compact intermediate of the zero-padded / cropped transforms (L1, behind the full-size part of the workspace)
-shifted by IG_LAB_L1_SHIFT elements, all in ONE process (same physical placement of every buffer): per-pass times of the headline."""
+shifted by IG_LAB_L1_SHIFT elements, all in ONE process (same physical placement of every buffer): per-pass times of the headline.
+The switch (a getenv in exec_padded_layout2 / exec_cropped_layout2 plus 32 MB more workspace) existed for that run only:
+profiles/r05_l1_shift_sweep.txt -- the shift moves the y passes by less than 2.5 %; what matters is the allocation."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
