@@ -226,6 +226,12 @@ class HipBackend(Backend):
                 ms = ctypes.c_double(0.0)
                 b._check(b._L.ig_probe_placement(b._ctx, ptr, self.nbytes, ctypes.byref(ms)), "ig_probe_placement")
                 cands.append((ms.value, ptr.value))
+            if len(cands) > 1:
+                # the first candidate may have been timed while the clocks were still coming up (the probe is often the first work of a
+                # process): time it once more, now behind the others, and keep its better figure
+                ms = ctypes.c_double(0.0)
+                b._check(b._L.ig_probe_placement(b._ctx, ctypes.c_void_p(cands[0][1]), self.nbytes, ctypes.byref(ms)), "ig_probe_placement")
+                cands[0] = (min(cands[0][0], ms.value), cands[0][1])
             best = max(cands) if b.tuning.get('placement_pick') == 'worst' else min(cands)       # ('worst': lab, to see what the probe's spread is worth)
             for ms, ptr in cands:
                 if ptr != best[1]:
