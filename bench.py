@@ -158,6 +158,9 @@ def parse():
                     "scan -- the k-space support table then flags most of the ball)")
     ap.add_argument("--no-dense", action="store_true", help="default run at N = 1: skip the extra dense-trajectory measurement")
     ap.add_argument("--coils", type=int, default=0, help="coils (default 8 / 32 for config 4 / 5)")
+    ap.add_argument("--width", type=float, default=2.0, help="configs 4 / 5: half-width of the Kaiser-Bessel gridding kernel in grid cells (indigo's "
+                    "`width`): 2 = BASELINE's 'width-4' kernel, 27 taps per sample; 3 = the default of the reference's Backend.NUFFT "
+                    "(indigo/backends/backend.py:403; examples/pics.py:92 passes none): 125 taps per sample")
     ap.add_argument("--osf", type=lambda v: (float(v.split("/")[0]) / float(v.split("/")[1])) if "/" in v else float(v), default=0.0, help="config 4: oversampling factor of the gridding (default 2.0; 1.25 puts the 256^3 "
                     "image on the 320^3 grid the reference's own driver would pick, examples/pics.py:87-90)")
     ap.add_argument("--tree", choices=["zpadfft", "o3", "recipe"], default="zpadfft",
@@ -169,6 +172,8 @@ def parse():
     ap.add_argument("--comm", choices=["auto", "rccl", "torch"], default="auto",
                     help="all-reduce provider for N > 1: the library's own RCCL binding (ig_comm_*), or torch.distributed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--parity", action="store_true", help="configs 4 / 5 with --no-cpu-baseline: still check the benchmarked operator against the "
+                    "float64 evaluation of a one-coil operator (oracle/precise.py)")
     ap.add_argument("--no-config5", action="store_true", help="default run: skip the extra config-5 measurement")
     ap.add_argument("--no-leaf-configs", action="store_true", help="default run at N = 1: skip the extra config-2 / config-3 measurements")
     ap.add_argument("--batch", type=int, default=16, help="config 2: number of volumes")
@@ -182,7 +187,7 @@ def parse():
     args.image_dims = tuple(dims) if len(dims) == 3 else None          # non-cubic image (config 4 only)
     args.image = dims[0] if len(dims) == 1 else 0
     # the standard problem of the selected config: what the committed PMC summaries and the headline's name describe
-    args.standard = not (args.image or args.image_dims or args.coils or args.osf or args.spokes_scale != 1.0) and args.tree == "zpadfft"
+    args.standard = not (args.image or args.image_dims or args.coils or args.osf or args.spokes_scale != 1.0 or args.width != 2.0) and args.tree == "zpadfft"
     return args
 
 
@@ -368,7 +373,7 @@ def make_comm(args, B, world, rank, local_rank):
 # ---------------------------------------------------------------------------------------------------------
 # configs 4 and 5: SENSE A^H A
 # ---------------------------------------------------------------------------------------------------------
-def sense_problem(cfg, img, C, osf=0.0, dims=None, spokes_scale=1.0):
+def sense_problem(cfg, img, C, osf=0.0, dims=None, spokes_scale=1.0, width=2.0):
     from indigo_amd.sense import SenseProblem
     if cfg == 4:
         osf = osf or 2.0
@@ -376,12 +381,12 @@ def sense_problem(cfg, img, C, osf=0.0, dims=None, spokes_scale=1.0):
         nreadout = int(N[0] * osf)                           # samples per spoke = oversampled grid edge along the readout
         # 3617 spokes at 256^3 -> T = 1,851,904 at oversampling 2; scaled with the area of the (y, z) face for other images
         nspokes = int(round(3617 * (N[1] * N[2]) / 256.0 ** 2 * spokes_scale))
-        return SenseProblem.synthetic(N, C, nspokes=nspokes, nreadout=nreadout, width=2, ntable=128,
+        return SenseProblem.synthetic(N, C, nspokes=nspokes, nreadout=nreadout, width=width, ntable=128,
                                       oversamp=osf, seed=4)
     # config 5: 320^3 in 512^3 (oversampling 1.6), maps generated per coil so that a rank only materialises its own
     grid = int(img * 1.6)
     nspokes = int(round(3617 * (img / 256.0) ** 2))          # 5652 spokes at 320^3 -> T = 2,893,824
-    return SenseProblem.synthetic((img,) * 3, C, nspokes=nspokes, nreadout=grid, width=2, ntable=128,
+    return SenseProblem.synthetic((img,) * 3, C, nspokes=nspokes, nreadout=grid, width=width, ntable=128,
                                   oversamp=1.6, seed=5, lazy_maps=True)
 
 
@@ -397,7 +402,9 @@ def run_sense(args, cfg, B, comm, world, rank, steps, warmup, want_cpu, quiet=Fa
     C = args.coils or (8 if cfg == 4 else 32)
     dims = getattr(args, 'image_dims', None) if cfg == 4 else None
     scale = float(getattr(args, 'spokes_scale', 1.0)) if cfg == 4 else 1.0
-    p = sense_problem(cfg, img, C, args.osf if cfg == 4 else 0.0, dims, scale)
+    width = float(getattr(args, 'width', 2.0))
+    width = int(width) if width == int(width) else width
+    p = sense_problem(cfg, img, C, args.osf if cfg == 4 else 0.0, dims, scale, width)
     shard = None
     if args.shard:
         r, w = (int(v) for v in args.shard.split("/"))
@@ -523,10 +530,10 @@ def run_sense(args, cfg, B, comm, world, rank, steps, warmup, want_cpu, quiet=Fa
 
     out = {
         "ms_per_step": ms_per_step, "value": value, "setup_s": round(setup_s, 2),
-        "config": {"workload": "non-Cartesian SENSE A^H A, image %s, %d coils, grid %s (osf %.4g), radial T=%d, KB width 4; "
+        "config": {"workload": "non-Cartesian SENSE A^H A, image %s, %d coils, grid %s (osf %.4g), radial T=%d, KB width %g; "
                                "-O3 tree S'->FFT->G'->G'^H->IFFT->S'^H%s" % (
                                    ("%d^3" % p.N[0]) if len(set(p.N)) == 1 else "x".join(str(n) for n in p.N), C,
-                                   ("%d^3" % p.oN[0]) if len(set(p.oN)) == 1 else "x".join(str(n) for n in p.oN), p.oversamp, p.T,
+                                   ("%d^3" % p.oN[0]) if len(set(p.oN)) == 1 else "x".join(str(n) for n in p.oN), p.oversamp, p.T, 2 * p.width,
                                    " (BASELINE config %d)" % cfg),
                    "parallelism": ("coil-sharded x%d (%d coils per rank), one all-reduce of the image per eval" % (world, len(coils))
                                    if world > 1 else ("rank %d of %d alone (no communication)" % shard if shard else "single GPU")),
@@ -634,7 +641,7 @@ def bench_sense(args, world, rank, local_rank):
     log("device:", B.device_name(), "world", world)
     cfg = args.config
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and not args.shard and cfg == 4
-    res = run_sense(args, cfg, B, comm, world, rank, args.steps, args.warmup, want_cpu)
+    res = run_sense(args, cfg, B, comm, world, rank, args.steps, args.warmup, want_cpu, want_parity=(args.parity and world == 1 and not args.shard))
 
     import threading
     emit_lock = threading.Lock()

@@ -307,6 +307,34 @@ int  ig_ccsrmm_t_slots(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, float alpha
                        const int32_t* brick_table, const int32_t* shared_bricks, int64_t nshared, int support_tile, int support_zwords,
                        int entry_words /* 4 = the 16-byte entries; 3 = {cell, re, row}, 12 bytes: a matrix whose weights are all real */);
 
+/* Gridding from the SEPARABLE form of the matrix (records of ig_interp3_sep, on the device): the taps are computed, not
+ * streamed -- 64 bytes per sample instead of 27 stored taps (216 .. 324 bytes), 128 instead of 125 taps at the reference's
+ * default kernel width 3 (Backend.NUFFT, indigo/backends/backend.py:403).  Replaces, for the coil-interleaved grid panel of the
+ * fused SENSE leaf, the products Backend.csr_matrix.forward / .adjoint (indigo/backends/backend.py:569-585) run through ccsrmm.
+ *   ig_grid_gather_sep   Y (M x NC, column-major, ldy) = alpha * G * X_il + beta * Y;  X_il: n0 * nm * ns grid points x NC
+ *                        interleaved coils (axes in memory order, as the records').  NC in {2, 4, 8}.                       */
+int  ig_grid_gather_sep(ig_ctx* ctx, int64_t M, int64_t NC, int tw, const void* records, const void* X_il,
+                        int64_t n0, int64_t nm, int64_t ns, float alpha_re, float alpha_im, float beta_re, float beta_im,
+                        void* Y, int64_t ldy);
+
+/*   ig_grid_scatter_sep  Y_il = alpha * G^H * X  (X: M x NC column-major, ldx) as a race-free scatter of SHARES: a share = (sample,
+ *                        brick of 16 x bm x bs grid cells its footprint meets), 8 bytes {sample, ox + 8 | (om + 8) << 5 | (os + 8) << 10 |
+ *                        blo << 15 | bhi << 18 | clo << 22 | chi << 25}: tap (a, b, c) sits at brick cell (ox + a, om + b, os + c), taps
+ *                        b in [blo, bhi), c in [clo, chi) are inside the brick.  ig_grid_shares_count / _fill (host) bin them by brick
+ *                        (sample order inside a brick).  tasks as for ig_ccsrmm_t_bricks with shares in place of entries; brick_table:
+ *                        16 bytes per non-empty brick {brick, end of its shares, uint64 flagged segments: bit xs + (16 / support_tile) *
+ *                        (im + bm * is)} -- only flagged segments are written; shared_table: the table rows of the bricks several tasks
+ *                        add into (float atomics; zeroed first).  A wave keeps one brick image in LDS (16 * bm * bs * NC * 8 bytes) and
+ *                        computes every tap from the sample's record; what the cu_exw_csrmm_H scatter of the reference
+ *                        (indigo/backends/_customgpu.cu:49-81) does under its exwrite promise, made safe by binning.                 */
+int  ig_grid_shares_count(int64_t M, const uint32_t* records, int tw, int64_t n0, int64_t nm, int64_t ns, int bm, int bs, int32_t* brick_shares);
+int  ig_grid_shares_fill(int64_t M, const uint32_t* records, int tw, int64_t n0, int64_t nm, int64_t ns, int bm, int bs,
+                         const int64_t* brick_ptr, uint32_t* shares);
+int  ig_grid_scatter_sep(ig_ctx* ctx, int64_t M, int64_t NC, int tw, const void* records, const void* shares, const void* X, int64_t ldx,
+                         void* Y_il, int64_t n0, int64_t nm, int64_t ns, int bm, int bs, const int32_t* tasks, int64_t ntasks,
+                         const int32_t* brick_table, const int32_t* shared_table, int64_t nshared, int support_tile,
+                         float alpha_re, float alpha_im);
+
 /* The same scatter for the reference's own panel layout, 64 columns: Y(K x 64, column-major, ldy) = alpha * A^H * X(M x 64,
  * column-major, ldx) for ANY CSR matrix with K a multiple of 16 (beta == 0: Y is zeroed first).  Bricks are 16 consecutive
  * rows of Y: ig_grid_bricks_count / _fill with (n0, nm, ns) = (K, 1, 1), bm = bs = 1, unit = 1 give `entries` (12 bytes:
@@ -425,6 +453,22 @@ int  ig_interp3_fill(int64_t m, const int64_t* N, double width, const double* ta
 int  ig_interp3_fill_modulated(int64_t m, const int64_t* N, double width, const double* table, int64_t ntable,
                                const double* coord, const int32_t* rowptr, int32_t* colind, void* values, int grid_order,
                                const double* phase_x, const double* phase_y, const double* phase_z, double scale);
+/* The SEPARABLE form of the same matrix (round 6): the reference's weights are products of per-axis factors by construction
+ * (w = wz * wy * wx, indigo/interp.py:42-52) and what `pics.py -O3` folds into the stored values on an even grid -- the centred
+ * transform's modulation exp(i pi k) and 1 / sqrt(P), examples/pics.py:104-177 -- is a sign per axis and cell and a constant.  One
+ * record of ig_interp3_sep_words(tw) 32-bit words per sample, axes in MEMORY order of the grid (0 = x, 1 = middle, 2 = slow:
+ * (x, y, z) for grid_order 0, (x, z, y) for grid_order 1):
+ *   words [0, tw) / [tw, 2 tw) / [2 tw, 3 tw)   float32 weights of the taps on axis 0 / 1 / 2 (times sign_*[cell]; axis 2 also
+ *                                               times `scale`); unused weights are 0
+ *   word 3 tw       first tap (wrapped) on axis 0 | first tap on axis 1 << 16
+ *   word 3 tw + 1   first tap on axis 2 | taps on axis 0 << 16 | taps on axis 1 << 20 | taps on axis 2 << 24
+ * tw = 4 (kernel half-width <= 2), 6 (<= 3) or 8 (<= 4): 16 / 32 / 32 words.  sign_x / _y / _z: +-1 per grid cell of the
+ * REFERENCE axes x, y, z (N[0] / N[1] / N[2] doubles) or NULL.  IG_ERR_UNSUPPORTED when a sample has more than tw taps on an axis.
+ * Host memory.  The gridding kernels that compute their taps from these records: ig_grid_gather_sep, ig_grid_scatter_sep.   */
+int  ig_interp3_sep_words(int tw);
+int  ig_interp3_sep(int64_t m, const int64_t* N, double width, const double* table, int64_t ntable, const double* coord,
+                    int grid_order, const double* sign_x, const double* sign_y, const double* sign_z, double scale,
+                    int tw, uint32_t* records);
 /* k-space support table (host) of a gridding matrix whose columns number the grid as kx + n0*(kz + n2*ky): for every
  * (ky, kx tile of `tile` points) the kz hull and one bit per kz that holds a nonzero, and the ky hull of every kx tile --
  * the table ig_fft_exec_padded / _cropped and the gridding kernels take.  The bitmaps come with zw_in words per (ky, kx tile)

@@ -114,7 +114,9 @@ class HipBackend(Backend):
         #                 problem the replay saves 0.03 ms of a 6.89 ms iteration and recording costs 5 ms per solve (profiles/r05_cg_graph_ab.log)
         self._placement_log = []          # (bytes, candidate probe times in ms, chosen) of every array placed by probing
         self.tuning = dict(placement_candidates=3, placement_min_bytes=1 << 31, cg_graph=False, bricks=(4, 8), slots=(1, 2), slot_shape=(4, 4, 256, 64), support_tile={8: 4, 4: 8}, brick_shape={8: (2, 2, 4096, 4096), 4: (2, 4, 4096, 4096)}, xrows=True, runs=True, wide_bricks=True,
-                           wide_brick_shape=(2, 2), wide_task_shape=(8192, 2048))
+                           wide_brick_shape=(2, 2), wide_task_shape=(8192, 2048),
+                           # round 6: gridding from the separable form of the matrix (one record per sample, taps computed)
+                           separable=True, sep_gather=True, sep_scatter=True, shares=(4, 8), share_shape={8: (8, 2, 1024, 1024), 4: (8, 4, 1024, 1024)})
 
     def __del__(self):
         try:
@@ -853,6 +855,7 @@ class HipBackend(Backend):
             self._support = (self._backend.copy_array(np.ascontiguousarray(table, dtype=np.int16).reshape(-1),
                                                       name=self._name + ".support"), int(n0), int(nm))
             self._support_zw = int(zw)
+            self._support_host = table
 
         def set_grid_support_fine(self, table, tile, ncols=None):
             """a support table with `tile` (8 or 4) kx points per entry: what the brick scatter writes by (the gather routes keep
@@ -866,6 +869,7 @@ class HipBackend(Backend):
             self._support_fine = (self._backend.copy_array(np.ascontiguousarray(table, dtype=np.int16).reshape(-1),
                                                            name=self._name + ".supportFine"), int(tile))
             self.__dict__.setdefault('_support_fine_by', {})[None if ncols is None else int(ncols)] = self._support_fine
+            self.__dict__.setdefault('_support_fine_host_by', {})[None if ncols is None else int(ncols)] = (table, int(tile))
 
         def _format(self, which, ncols, exact=False):
             """the binned format ('_bricks' / '_slots') or fine table ('_support_fine') registered for panels of `ncols` columns"""
@@ -978,6 +982,80 @@ class HipBackend(Backend):
                                slot_ptr=b.copy_array(slot_ptr[:int(nslots.value) + 1].copy(), name=self._name + ".slotPtr"),
                                shared=b.copy_array(shared if shared.size else np.zeros(1, np.int32), name=self._name + ".slotSharedBricks"))
             self.__dict__.setdefault('_slots_by', {})[int(ncols)] = self._slots
+
+        def set_grid_separable(self, sep):
+            """The matrix in SEPARABLE form (indigo_amd.interp.interp_sep_records: one record per sample, columns numbered in the
+            memory order of the coil-interleaved grid panel): the products with interleaved panels of 2, 4 or 8 columns compute their
+            taps from the records (ig_grid_gather_sep / ig_grid_scatter_sep) instead of streaming the stored ones."""
+            b = self._backend
+            n0, nm, ns = (int(v) for v in sep['dims'])
+            assert sep['records'].shape[0] == self.shape[0] and n0 * nm * ns == self.shape[1]
+            self._sep = dict(tw=int(sep['tw']), dims=(n0, nm, ns), gconst=complex(sep['gconst']), host=np.ascontiguousarray(sep['records']),
+                             records=b.copy_array(np.ascontiguousarray(sep['records']).reshape(-1), name=self._name + ".sepRecords"))
+
+        def set_grid_shares(self, ncols=8, bm=8, bs=2, chunk=1024, run=1024):
+            """The adjoint of an `ncols`-column interleaved panel as a scatter of SHARES (ig_grid_scatter_sep): every (sample, brick of
+            16 x bm x bs cells) pair the sample's footprint meets is one 8-byte share, binned by brick on the host (ig_grid_shares_count /
+            _fill: brick order, sample order inside a brick); the taps come from the separable records (set_grid_separable, which must
+            come first, as must set_grid_support_fine: a brick's flagged segments are looked up here, once).  A task (one wave) is a run
+            of consecutive non-empty bricks of about `run` shares, or a piece of at most `chunk` shares of a heavy brick (shared)."""
+            b = self._backend
+            sep = getattr(self, '_sep', None)
+            assert sep is not None and ncols in (2, 4, 8)
+            n0, nm, ns = sep['dims']
+            rec, tw = sep['host'], sep['tw']
+            fine = self._format('_support_fine_host', ncols)
+            sup = getattr(self, '_support_host', None)
+            tab, tile, zw = (fine[0], fine[1], getattr(self, '_support_zw', 16)) if fine is not None else \
+                            (sup, 16, getattr(self, '_support_zw', 16)) if sup is not None else (None, 16, 16)
+            by = self.__dict__.setdefault('_shares_by', {})
+            xs = 16 // tile
+            while xs * bm * bs > 64 and bs > 1:
+                bs //= 2
+            while xs * bm * bs > 64 and bm > 1:
+                bm //= 2
+            nb = (n0 // 16) * (nm // bm) * (ns // bs)
+            counts = np.zeros(nb, dtype=np.int32)
+            if n0 % 16 or nm % bm or ns % bs or b._L.ig_grid_shares_count(rec.shape[0], rec.ctypes.data, tw, n0, nm, ns, bm, bs, counts.ctypes.data) != 0:
+                log.info("%s: no share format; the adjoint keeps the stored-tap routes", self._name)
+                by[int(ncols)] = None
+                return
+            ptr = np.zeros(nb + 1, dtype=np.int64)
+            np.cumsum(counts, out=ptr[1:])
+            assert ptr[-1] < 2**31, "shares are addressed with 32 bits"
+            shares = np.empty((max(int(ptr[-1]), 1), 2), dtype=np.uint32)
+            _lib.check(b._L.ig_grid_shares_fill(rec.shape[0], rec.ctypes.data, tw, n0, nm, ns, bm, bs, ptr.ctypes.data, shares.ctypes.data),
+                       None, "ig_grid_shares_fill")
+            tasks, table, shared = brick_tasks(counts, ptr, int(chunk), int(run), max_bricks=64)
+            # the flagged segments of every non-empty brick: bit xs + XS * (im + bm * is), from the support table's input-side bitmaps
+            bricks = table[:, 0].astype(np.int64) if table.size else np.zeros(0, np.int64)
+            mask = np.full(bricks.size, np.uint64(0xffffffffffffffff) if xs * bm * bs == 64 else np.uint64((1 << (xs * bm * bs)) - 1), dtype=np.uint64)
+            if tab is not None and bricks.size:
+                nt = n0 // tile
+                tabh = np.ascontiguousarray(tab, dtype=np.int16).reshape(-1)
+                off = 2 * (ns * nt + nt)
+                bits = tabh[off:off + 2 * ns * nt * zw].view(np.uint32).reshape(ns * nt, zw)
+                nbx, nbm = n0 // 16, nm // bm
+                bx, bmi, bsi = bricks % nbx, (bricks // nbx) % nbm, bricks // (nbx * nbm)
+                mask[:] = 0
+                for is_ in range(bs):
+                    for im in range(bm):
+                        km = bmi * bm + im
+                        for x in range(xs):
+                            bit = (bits[(bsi * bs + is_) * nt + bx * xs + x, km % zw] >> (km // zw).astype(np.uint32)) & np.uint32(1)
+                            mask |= bit.astype(np.uint64) << np.uint64(x + xs * (im + bm * is_))
+            tab16 = np.empty((max(bricks.size, 1), 4), dtype=np.uint32)
+            if bricks.size:
+                tab16[:, 0:2] = table.astype(np.uint32)
+                tab16[:, 2] = (mask & np.uint64(0xffffffff)).astype(np.uint32)
+                tab16[:, 3] = (mask >> np.uint64(32)).astype(np.uint32)
+            sh_rows = tab16[np.searchsorted(bricks, shared.astype(np.int64))] if shared.size else np.zeros((1, 4), np.uint32)
+            by[int(ncols)] = dict(bm=int(bm), bs=int(bs), tile=int(tile), ncols=int(ncols), ntasks=int(tasks.shape[0]), nshared=int(shared.size),
+                                  nshares=int(ptr[-1]), nbricks=int(bricks.size),
+                                  tasks=b.copy_array(tasks.reshape(-1) if tasks.size else np.zeros(4, np.int32), name=self._name + ".shareTasks"),
+                                  table=b.copy_array(tab16.reshape(-1), name=self._name + ".shareTable"),
+                                  shares=b.copy_array(shares.reshape(-1), name=self._name + ".shares"),
+                                  shared=b.copy_array(np.ascontiguousarray(sh_rows).reshape(-1), name=self._name + ".shareSharedBricks"))
 
         def set_grid_dims(self, n0, nm, ns):
             """Hint: the columns of the matrix are the points of an n0 x nm x ns grid, n0 running fastest (a gridding matrix).
@@ -1162,6 +1240,14 @@ class HipBackend(Backend):
                 ar, ai = _cplx(alpha)
                 br, bi = _cplx(beta)
                 m, k = self.shape
+                sep = getattr(self, '_sep', None)
+                if sep is not None and x.shape[1] in (2, 4, 8) and b.tuning.get('sep_gather', True):
+                    # the taps computed from one 64-byte record per sample (ig_grid_gather_sep): no index or value stream
+                    gr, gi = _cplx(complex(alpha) * sep['gconst'])
+                    n0, nm, ns = sep['dims']
+                    b._check(b._L.ig_grid_gather_sep(b._ctx, m, x.shape[1], sep['tw'], ctypes.c_void_p(sep['records']._arr), ctypes.c_void_p(x._arr),
+                                                     n0, nm, ns, gr, gi, br, bi, ctypes.c_void_p(y._arr), y._leading_dim), "ig_grid_gather_sep")
+                    return
                 vre = self._real_values() if x.shape[1] in (2, 4, 8) else None
                 if vre is not None:
                     # every weight real (see weights_are_real): the gather reads 4-byte values
@@ -1228,6 +1314,20 @@ class HipBackend(Backend):
             b = self._backend
             sup = getattr(self, '_support', None)
             perm = getattr(self, '_perm', None)
+            shf = self._format('_shares', x.shape[1], exact=True)
+            if (shf is not None and perm is None and beta == 0 and y.contiguous and getattr(self, '_grid_il', False) and shf['ntasks'] > 0
+                    and b.tuning.get('sep_scatter', True)):
+                sep = self._sep
+                if not (self._format('_support_fine', x.shape[1]) is not None or sup is not None):
+                    y._zero()           # without a support table every row is defined: bricks no sample touches stay zero
+                ar, ai = _cplx(complex(alpha) * np.conj(sep['gconst']))
+                n0, nm, ns = sep['dims']
+                b._check(b._L.ig_grid_scatter_sep(b._ctx, self.shape[0], x.shape[1], sep['tw'], ctypes.c_void_p(sep['records']._arr),
+                                                  ctypes.c_void_p(shf['shares']._arr), ctypes.c_void_p(x._arr), x._leading_dim, ctypes.c_void_p(y._arr),
+                                                  n0, nm, ns, shf['bm'], shf['bs'], ctypes.c_void_p(shf['tasks']._arr), shf['ntasks'],
+                                                  ctypes.c_void_p(shf['table']._arr), ctypes.c_void_p(shf['shared']._arr), shf['nshared'], shf['tile'], ar, ai),
+                         "ig_grid_scatter_sep")
+                return
             br = self._format('_bricks', x.shape[1], exact=True)
             # (the gather routes over the transposed matrix read 16-word bitmaps only: with another table they compute every
             # row -- a superset of what any reader of the grid looks at)

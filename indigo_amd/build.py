@@ -18,7 +18,7 @@ LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "lib", "obj")
 LIBNAME = "libindigo_hip.so"
 
-SOURCES = ["ig_fft_abd0.hip", "ig_fft_abd1.hip", "ig_fft_abd2.hip", "ig_fft_abd3.hip", "ig_fft.hip", "ig_spmm.hip", "ig_context.hip", "ig_blas.hip",
+SOURCES = ["ig_fft_abd0.hip", "ig_fft_abd1.hip", "ig_fft_abd2.hip", "ig_fft_abd3.hip", "ig_fft.hip", "ig_spmm.hip", "ig_gridsep.hip", "ig_context.hip", "ig_blas.hip",
            "ig_comm.hip", "ig_interp.hip", "ig_dense.hip"]       # (the slow ones first: four compile side by side)
 ARCH = "gfx950"
 CXXFLAGS = [

@@ -175,6 +175,67 @@ static int interp3_fill(int64_t m, const int64_t* N, double width, const double*
     return IG_OK;
 }
 
+// ---- the separable form of a gridding matrix (round 6) --------------------------------------------------------------------
+// The reference's weights are products of three per-axis factors by construction (w = wz * wy * wx, indigo/interp.py:42-52), and
+// what `pics.py -O3` folds into the gridding matrix on an even grid -- the centred transform's modulation exp(i pi k) and its
+// 1 / sqrt(P) (examples/pics.py:104-177) -- is a sign per axis and cell and a constant.  So a sample is fully described by its first
+// tap and tap count per axis and 3 x tw per-axis weights: ONE record of 64 bytes (tw = 4) instead of 27 stored taps of 8 .. 12
+// bytes each (216 .. 324 bytes; at the reference's default width 3: 125 taps, 1000 .. 1500 bytes against 128).  The gridding kernels
+// of ig_gridsep.hip compute the taps from the records.
+//   record (ig_interp3_sep_words(tw) 32-bit words; axes in MEMORY order of the grid: 0 = x, 1 = middle, 2 = slow -- (x, y, z) for
+//   grid_order 0, (x, z, y) for grid_order 1):
+//     words [0, tw)       float weights of the x taps       (w * sign_x[cell])
+//     words [tw, 2 tw)    float weights of the middle axis  (w * sign[cell])
+//     words [2 tw, 3 tw)  float weights of the slow axis    (w * sign[cell] * scale)       unused weights are 0
+//     word 3 tw           first tap (wrapped into the grid) on axis 0 | on axis 1 << 16
+//     word 3 tw + 1       first tap on axis 2 | taps on axis 0 << 16 | on axis 1 << 20 | on axis 2 << 24
+// Each factor is rounded to float32 once; a tap's weight is the float32 product (w1 * w2) * w0: at most five roundings where the
+// stored matrix has two -- 3e-7 relative in the worst case, against the 1e-5 the parity tests allow.
+extern "C" int ig_interp3_sep_words(int tw) { return tw == 4 ? 16 : (tw == 6 || tw == 8) ? 32 : -1; }
+
+extern "C" int ig_interp3_sep(int64_t m, const int64_t* N, double width, const double* table, int64_t ntable, const double* coord,
+                              int grid_order, const double* sign_x, const double* sign_y, const double* sign_z, double scale,
+                              int tw, uint32_t* records) {
+    const int rw = ig_interp3_sep_words(tw);
+    if (m < 0 || !N || !coord || !table || ntable < 2 || !(width > 0) || rw < 0 || (m > 0 && !records) || (grid_order != 0 && grid_order != 1))
+        return ig_fail(nullptr, IG_ERR_ARG, "ig_interp3_sep: bad arguments (tw is 4, 6 or 8; grid_order 0 or 1)");
+    for (int d = 0; d < 3; ++d)
+        if (N[d] < tw || N[d] > 65535) return ig_fail(nullptr, IG_ERR_UNSUPPORTED, "ig_interp3_sep: grid axis of %lld points (tw .. 65535)", (long long)N[d]);
+    const double* c[3] = {coord, coord + m, coord + 2 * m};
+    const double* sg[3] = {sign_x, sign_y, sign_z};
+    const int axis_of[3] = {0, grid_order == 0 ? 1 : 2, grid_order == 0 ? 2 : 1};       // memory axis -> reference axis
+    std::atomic<int> bad{0};
+    parallel_rows(m, [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; ++i) {
+            uint32_t* r = records + (size_t)i * rw;
+            for (int q = 0; q < rw; ++q) r[q] = 0u;
+            uint32_t first[3], count[3];
+            for (int a = 0; a < 3; ++a) {
+                const int d = axis_of[a];
+                const int64_t n = N[d];
+                const double pos = (double)n * c[d][i] + (double)(n / 2);
+                const Taps t = taps_of(pos, width);
+                if (t.count > tw) bad = 1;
+                const int64_t cnt = t.count > tw ? tw : t.count;
+                first[a] = (uint32_t)wrap(t.start, n);
+                count[a] = (uint32_t)cnt;
+                for (int64_t q = 0; q < cnt; ++q) {
+                    const int64_t x = t.start + q;
+                    double w = lin_interp(table, ntable, std::fabs((double)x - pos) / width);
+                    if (sg[d]) w *= sg[d][wrap(x, n)];
+                    if (a == 2) w *= scale;
+                    const float wf = (float)w;
+                    __builtin_memcpy(r + a * tw + q, &wf, 4);
+                }
+            }
+            r[3 * tw] = first[0] | (first[1] << 16);
+            r[3 * tw + 1] = first[2] | (count[0] << 16) | (count[1] << 20) | (count[2] << 24);
+        }
+    });
+    if (bad) return ig_fail(nullptr, IG_ERR_UNSUPPORTED, "ig_interp3_sep: a sample has more than tw = %d taps on an axis (kernel half-width %g)", tw, width);
+    return IG_OK;
+}
+
 extern "C" {
 
 int ig_interp3_fill(int64_t m, const int64_t* N, double width, const double* table, int64_t ntable,

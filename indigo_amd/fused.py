@@ -183,11 +183,12 @@ def pad_coils(w, width, interleaved=True):
 
 
 def assemble(backend, Gm, oN, N, weights_of, Cn, layout, chunks, table=None, box_lo=None, row_order=None,
-             name='SENSE-fusedFFT', zw=(16, 16)):
+             name='SENSE-fusedFFT', zw=(16, 16), sep=None):
     """A = KronI(C, G') * ZpadFFT, or a VStack of such trees over coil chunks sharing ONE device copy of G'.
 
     Gm          gridding matrix (T x P, complex64 CSR) with its columns in the order of `layout` (see
                 permute_grid_columns; layout 2 uses layout 1's numbering)
+    sep         the same matrix in separable form (interp_sep_records, grid_order 1) or None
     weights_of  (lo, hi) -> weights array box + (hi - lo,) for that run of coils (maps * roll-off * modulation)
     chunks      [(lo, hi, width)] from choose_layout: width coils interleaved, hi - lo of them real
     More coils than a chunk holds (the reference's `batch` hint, indigo/operators.py:15-17,341: evaluate a wide
@@ -214,7 +215,7 @@ def assemble(backend, Gm, oN, N, weights_of, Cn, layout, chunks, table=None, box
     for w in il_widths:
         tile = int(tile_of.get(w, 8) if isinstance(tile_of, dict) else tile_of)
         if (table is not None and tile in (4, 8) and w * tile >= 32 and getattr(backend, 'supports_support_tile', False)
-                and w in tuning.get('bricks', ())):
+                and (w in tuning.get('bricks', ()) or (sep is not None and w in tuning.get('shares', ())))):
             if tile not in by_tile:
                 by_tile[tile] = grid_support(Gm, oN, tile, zw)
             fine[w] = (by_tile[tile], tile)
@@ -224,14 +225,26 @@ def assemble(backend, Gm, oN, N, weights_of, Cn, layout, chunks, table=None, box
         G = backend.SpMatrix(Gm, name='interp*mod*scale')
         if interleaved:
             G._grid_interleaved = True
+            if sep is not None and tuning.get('separable', True):
+                # the same matrix as one record per sample (indigo_amd.interp.interp_sep_records): the interleaved products compute
+                # their taps instead of streaming the stored ones
+                G._grid_separable = sep
         if table is not None:
             G._grid_support = (table, int(oN[0]), int(oN[2]), int(zw[0]))
         if row_order is not None:
             G._row_order = row_order
             return G
-        bricks, slots, fines = {}, {}, {}
+        bricks, slots, fines, shares = {}, {}, {}, {}
         for w in (il_widths if interleaved else [ncols]):
-            if interleaved and w in tuning.get('bricks', ()) and x16:
+            if interleaved and sep is not None and tuning.get('separable', True) and w in tuning.get('shares', ()) and x16:
+                # adjoint gridding as a scatter of (sample, brick) SHARES with the taps computed from the separable records
+                # (ig_grid_scatter_sep): no stored taps at all
+                sshape = tuning.get('share_shape', {})
+                sshape = tuple(sshape.get(w, (8, 2, 1024, 1024)) if isinstance(sshape, dict) else sshape)
+                shares[w] = (pow2_divisor(oN[2], sshape[0]), pow2_divisor(oN[1], sshape[1])) + sshape[2:]
+                if w in fine:
+                    fines[w] = fine[w]
+            elif interleaved and w in tuning.get('bricks', ()) and x16:
                 # adjoint gridding by grid bricks (a scatter binned on the host) instead of a gather over the transposed matrix.
                 # Measured (config 4): 8 coils 0.91 ms against 1.82 ms (gather + its deferred long rows); 4 coils 0.68 against
                 # 1.05 ms.  Two coils or one would pad every sample's share of a brick to 32 / 64 entries: they take the slots.
@@ -248,6 +261,8 @@ def assemble(backend, Gm, oN, N, weights_of, Cn, layout, chunks, table=None, box
                 slots[w] = (int(oN[0]), int(oN[2]), int(oN[1]), w, pow2_divisor(oN[2], sshape[0]), pow2_divisor(oN[1], sshape[1])) + sshape[2:]
         if fines:
             G._grid_support_fine = fines
+        if shares:
+            G._grid_shares = shares
         if bricks:
             G._grid_bricks = bricks
         if slots:

@@ -15,7 +15,7 @@ the caller casts it (the NUFFT factory stores float32 weights as complex64).
 import numpy as np
 import scipy.sparse as spp
 
-__all__ = ['lin_interp', 'interp_mat', 'interp_csr_arrays', 'interp_csr_arrays_numpy']
+__all__ = ['lin_interp', 'interp_mat', 'interp_csr_arrays', 'interp_csr_arrays_numpy', 'interp_sep_records', 'sep_expand']
 
 
 def lin_interp(table, x):
@@ -127,6 +127,78 @@ def interp_csr_modulated(m, N, width, table, coord, phases, scale, grid_order=0)
                                            indices.ctypes.data, data.ctypes.data, int(grid_order), px.ctypes.data, py.ctypes.data,
                                            pz.ctypes.data, float(scale)), None, "ig_interp3_fill_modulated")
     return indptr, indices, data
+
+
+def _axis_signs(ph):
+    """exp(2 pi i ph[k]) = g * s[k] with s[k] = +-1 and |g| = 1 -- the modulation of a centred transform on an even axis -- or None"""
+    m = np.exp(2j * np.pi * np.asarray(ph, dtype=np.float64))
+    g = m[0]
+    r = m / g
+    s = np.round(r.real)
+    if np.abs(r.imag).max() > 1e-9 or np.abs(np.abs(s) - 1.0).max() > 0 or np.abs(r.real - s).max() > 1e-9:
+        return None
+    return complex(g), s
+
+
+def interp_sep_records(m, N, width, table, coord, phases=None, scale=1.0, grid_order=0):
+    """The SEPARABLE form of  interp * diag(exp(2 pi i (px[kx] + py[ky] + pz[kz]))) * scale  (indigo/interp.py:18-60 builds every
+    tap as w = wz * wy * wx; examples/pics.py:104-177 folds the centred transform's modulation and normalisation in): one
+    record per sample -- first tap and tap count per axis, per-axis float32 weights with the modulation's SIGN folded in
+    (ig_interp3_sep, include/indigo_hip.h).  Returns dict(records (m, words) uint32, tw, gconst, dims = grid axes in memory order)
+    with  G' = gconst * (the matrix the records describe), or None when the modulation is no sign per axis (an odd axis: its
+    phases are genuinely complex) or the kernel is wider than 8 taps per axis."""
+    import ctypes
+    from indigo_amd import _lib
+    L = _lib.lib()
+    N = tuple(int(n) for n in N)
+    coord = np.ascontiguousarray(np.asarray(coord, dtype=np.float64).reshape(3, -1))
+    assert coord.shape[1] == m
+    table = np.ascontiguousarray(table, dtype=np.float64)
+    gconst, signs = 1.0 + 0.0j, [None, None, None]
+    if phases is not None:
+        for d in range(3):
+            gs = _axis_signs(phases[d])
+            if gs is None:
+                return None
+            gconst *= gs[0]
+            signs[d] = np.ascontiguousarray(gs[1], dtype=np.float64)
+            assert signs[d].size == N[d]
+    tw = 4 if 2 * width <= 4 else 6 if 2 * width <= 6 else 8 if 2 * width <= 8 else None
+    if tw is None or min(N) < tw or max(N) > 65535:
+        return None
+    words = L.ig_interp3_sep_words(tw)
+    rec = np.empty((m, words), dtype=np.uint32)
+    dims = (ctypes.c_int64 * 3)(*N)
+    rc = L.ig_interp3_sep(m, dims, float(width), table.ctypes.data, table.size, coord.ctypes.data, int(grid_order),
+                          *[sg.ctypes.data if sg is not None else None for sg in signs], float(scale), tw, rec.ctypes.data)
+    if rc != 0:
+        return None
+    mem = (N[0], N[1], N[2]) if grid_order == 0 else (N[0], N[2], N[1])
+    if abs(gconst.imag) < 1e-12:
+        gconst = complex(round(gconst.real), 0.0) if abs(abs(gconst.real) - 1.0) < 1e-12 else complex(gconst.real, 0.0)
+    return dict(records=rec, tw=tw, gconst=gconst, dims=mem, grid_order=int(grid_order))
+
+
+def sep_expand(sep, lo=0, hi=None):
+    """(rows, cols, vals) of the taps the records [lo, hi) describe -- columns numbered in the records' memory order, values in the
+    float32 arithmetic of the kernels ((w1 * w2) * w0, then times gconst): the dense form of the separable matrix, for tests"""
+    rec, tw = sep['records'], sep['tw']
+    hi = rec.shape[0] if hi is None else hi
+    r = rec[lo:hi]
+    n0, nm, ns = sep['dims']
+    w = r[:, :3 * tw].view(np.float32).reshape(-1, 3, tw)
+    h0, h1 = r[:, 3 * tw], r[:, 3 * tw + 1]
+    j = np.stack([h0 & 0xffff, h0 >> 16, h1 & 0xffff], axis=1).astype(np.int64)
+    cnt = np.stack([(h1 >> 16) & 15, (h1 >> 20) & 15, (h1 >> 24) & 15], axis=1).astype(np.int64)
+    a = np.arange(tw)
+    k0 = (j[:, 0, None] + a) % n0
+    k1 = (j[:, 1, None] + a) % nm
+    k2 = (j[:, 2, None] + a) % ns
+    col = k0[:, None, None, :] + n0 * (k1[:, None, :, None] + nm * k2[:, :, None, None])
+    val = ((w[:, 1][:, None, :, None] * w[:, 2][:, :, None, None]).astype(np.float32) * w[:, 0][:, None, None, :]).astype(np.float32)
+    ok = (a < cnt[:, 0, None])[:, None, None, :] & (a < cnt[:, 1, None])[:, None, :, None] & (a < cnt[:, 2, None])[:, :, None, None]
+    row = np.broadcast_to(np.arange(lo, hi)[:, None, None, None], col.shape)
+    return row[ok], col[ok], (val[ok].astype(np.complex64) * np.complex64(sep['gconst']))
 
 
 def interp_csr_arrays_numpy(m, N, width, table, coord, dtype=np.float32, chunk=65536):

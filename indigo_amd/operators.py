@@ -259,6 +259,13 @@ class SpMatrix(Operator):
                 if args is not None and hasattr(self._matrix_d, setter):
                     for a in ([args[w] for w in sorted(args)] if isinstance(args, dict) else [args]):
                         getattr(self._matrix_d, setter)(*a)
+            sep = getattr(self, '_grid_separable', None)
+            if sep is not None and hasattr(self._matrix_d, 'set_grid_separable'):
+                self._matrix_d.set_grid_separable(sep)
+            shares = getattr(self, '_grid_shares', None)
+            if shares is not None and hasattr(self._matrix_d, 'set_grid_shares'):
+                for w in sorted(shares):
+                    self._matrix_d.set_grid_shares(w, *shares[w])
             dims = getattr(self, '_grid_dims', None) or getattr(self._matrix, '_grid_dims', None)
             if dims is not None and hasattr(self._matrix_d, 'set_grid_dims'):
                 self._matrix_d.set_grid_dims(*dims)          # (n0, nm, ns), n0 fastest: the grid the columns form

@@ -21,7 +21,7 @@ from scipy.signal.windows import kaiser
 
 from indigo_amd import fused
 from indigo_amd import operators as op
-from indigo_amd.interp import interp_csr_arrays, interp_csr_modulated
+from indigo_amd.interp import interp_csr_arrays, interp_csr_modulated, interp_sep_records
 from indigo_amd.noncart import rolloff3
 from indigo_amd.transforms import sense_recipe, reserve_for
 
@@ -123,6 +123,18 @@ class SenseProblem(object):
         G = spp.csr_matrix((data, indices, indptr), shape=(self.T, P))
         self._interp_cache[layout] = G            # 0.6 GB per layout at 5e7 nonzeros; drop_cache() releases them
         return G
+
+    def fused_interp_sep(self, layout=1):
+        """G' in separable form (indigo_amd.interp.interp_sep_records: one record per sample -- first tap, tap counts and per-axis
+        weights with the modulation's sign folded in) for the grid order of `layout`, or None when the grid's modulation is no sign
+        per axis (odd axes)"""
+        key = ('sep', layout)
+        if key not in self._interp_cache:
+            P = int(np.prod(self.oN))
+            scale = np.float32(1.0) / np.sqrt(np.float32(P))
+            self._interp_cache[key] = interp_sep_records(self.T, self.oN, self.width, self.table, self.coord.reshape(3, -1, order='F'),
+                                                         _mod_axis_phases(self.oN), scale, grid_order=1 if layout >= 1 else 0)
+        return self._interp_cache[key]
 
     def fused_maps_T(self, coils=None):
         """S'^H stored form: CSR of shape (N, C*P) whose adjoint is S' = (I_C (x) mod*zpad*apod) * maps."""
@@ -285,7 +297,8 @@ class SenseProblem(object):
         order = self.locality_order(Gm) if reorder and Cn <= 8 else None
         widths = {lo: w for lo, _, w in chunks}
         A = fused.assemble(backend, Gm, self.oN, self.N, lambda lo, hi: self.fused_weights(coils[lo:hi], interleaved=(widths.get(lo, 0) > 1)), Cn,
-                           layout, chunks, table=table, row_order=order, zw=zw)
+                           layout, chunks, table=table, row_order=order, zw=zw,
+                           sep=self.fused_interp_sep(1) if (layout == 2 and order is None) else None)
         self.last_support_fine = getattr(A, '_support_fine', None)       # (table, tile) when the tree took a finer table
         return A
 
