@@ -313,9 +313,10 @@ int  ig_ccsrmm_t_slots(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, float alpha
  * fused SENSE leaf, the products Backend.csr_matrix.forward / .adjoint (indigo/backends/backend.py:569-585) run through ccsrmm.
  *   ig_grid_gather_sep   Y (M x NC, column-major, ldy) = alpha * G * X_il + beta * Y;  X_il: n0 * nm * ns grid points x NC
  *                        interleaved coils (axes in memory order, as the records').  NC in {2, 4, 8}.                       */
-int  ig_grid_gather_sep(ig_ctx* ctx, int64_t M, int64_t NC, int tw, const void* records, const void* X_il,
+int  ig_grid_gather_sep(ig_ctx* ctx, int64_t M, int64_t NC, int tw, const void* records, int64_t rec_stride, const void* X_il,
                         int64_t n0, int64_t nm, int64_t ns, float alpha_re, float alpha_im, float beta_re, float beta_im,
                         void* Y, int64_t ldy);
+/* (rec_stride: 32-bit words from one sample's record to the next, >= ig_interp3_sep_words(tw), a multiple of 4.) */
 
 /*   ig_grid_scatter_sep  Y_il = alpha * G^H * X  (X: M x NC column-major, ldx) as a race-free scatter of SHARES: a share = (sample,
  *                        brick of 16 x bm x bs grid cells its footprint meets), 8 bytes {sample, ox + 8 | (om + 8) << 5 | (os + 8) << 10 |
@@ -330,10 +331,17 @@ int  ig_grid_gather_sep(ig_ctx* ctx, int64_t M, int64_t NC, int tw, const void* 
 int  ig_grid_shares_count(int64_t M, const uint32_t* records, int tw, int64_t n0, int64_t nm, int64_t ns, int bm, int bs, int32_t* brick_shares);
 int  ig_grid_shares_fill(int64_t M, const uint32_t* records, int tw, int64_t n0, int64_t nm, int64_t ns, int bm, int bs,
                          const int64_t* brick_ptr, uint32_t* shares);
-int  ig_grid_scatter_sep(ig_ctx* ctx, int64_t M, int64_t NC, int tw, const void* records, const void* shares, const void* X, int64_t ldx,
+int  ig_grid_scatter_sep(ig_ctx* ctx, int64_t M, int64_t NC, int tw, void* records, int64_t rec_stride, const void* shares, const void* X, int64_t ldx,
                          void* Y_il, int64_t n0, int64_t nm, int64_t ns, int bm, int bs, const int32_t* tasks, int64_t ntasks,
                          const int32_t* brick_table, const int32_t* shared_table, int64_t nshared, int support_tile,
-                         float alpha_re, float alpha_im);
+                         float alpha_re, float alpha_im, int form);
+/* form 0: the brick image in LDS, vector multiply-adds (rec_stride = ig_interp3_sep_words(tw); 2, 4 or 8 coils; 16 * bm * bs * NC * 8 bytes
+ *         of LDS per wave).
+ * form 1: the brick image in registers, the accumulation as outer products on the matrix cores (v_mfma_f32_16x16x1_4b_f32: fp32 in,
+ *         fp32 accumulate; one instruction adds a share's taps on all 16 x 4 cells of one slow-axis plane of the brick for all coils):
+ *         bricks of 16 x (bm <= 4) x (bs <= 4) cells, 4 or 8 coils; `records` must leave room behind every record for the sample's
+ *         panel row (rec_stride >= words + 2 NC) -- the call writes X[t, :] there, so that a share's record and panel row are ONE
+ *         line.  The scatter is bound by instruction issue, not by HBM: hence the matrix pipe.                    */
 
 /* The same scatter for the reference's own panel layout, 64 columns: Y(K x 64, column-major, ldy) = alpha * A^H * X(M x 64,
  * column-major, ldx) for ANY CSR matrix with K a multiple of 16 (beta == 0: Y is zeroed first).  Bricks are 16 consecutive

@@ -116,7 +116,7 @@ class HipBackend(Backend):
         self.tuning = dict(placement_candidates=3, placement_min_bytes=1 << 31, cg_graph=False, bricks=(4, 8), slots=(1, 2), slot_shape=(4, 4, 256, 64), support_tile={8: 4, 4: 8}, brick_shape={8: (2, 2, 4096, 4096), 4: (2, 4, 4096, 4096)}, xrows=True, runs=True, wide_bricks=True,
                            wide_brick_shape=(2, 2), wide_task_shape=(8192, 2048),
                            # round 6: gridding from the separable form of the matrix (one record per sample, taps computed)
-                           separable=True, sep_gather=True, sep_scatter=True, shares=(4, 8), share_shape={8: (8, 2, 1024, 1024), 4: (8, 4, 1024, 1024)})
+                           separable=True, sep_gather=True, sep_scatter=True, sep_mfma=True, shares=(4, 8), shares_min_tw=6, share_shape={8: (4, 4, 1024, 1024), 4: (4, 4, 1024, 1024)})
 
     def __del__(self):
         try:
@@ -990,8 +990,14 @@ class HipBackend(Backend):
             b = self._backend
             n0, nm, ns = (int(v) for v in sep['dims'])
             assert sep['records'].shape[0] == self.shape[0] and n0 * nm * ns == self.shape[1]
-            self._sep = dict(tw=int(sep['tw']), dims=(n0, nm, ns), gconst=complex(sep['gconst']), host=np.ascontiguousarray(sep['records']),
-                             records=b.copy_array(np.ascontiguousarray(sep['records']).reshape(-1), name=self._name + ".sepRecords"))
+            rec = np.ascontiguousarray(sep['records'])
+            # on the device every record leaves room for the sample's panel row behind it (the MFMA scatter reads both as one line)
+            rw = rec.shape[1]
+            rs = 32 if rw == 16 else 64
+            recx = np.zeros((rec.shape[0], rs), dtype=np.uint32)
+            recx[:, :rw] = rec
+            self._sep = dict(tw=int(sep['tw']), dims=(n0, nm, ns), gconst=complex(sep['gconst']), host=rec, stride=rs,
+                             records=b.copy_array(recx.reshape(-1), name=self._name + ".sepRecords"))
 
         def set_grid_shares(self, ncols=8, bm=8, bs=2, chunk=1024, run=1024):
             """The adjoint of an `ncols`-column interleaved panel as a scatter of SHARES (ig_grid_scatter_sep): every (sample, brick of
@@ -1245,7 +1251,7 @@ class HipBackend(Backend):
                     # the taps computed from one 64-byte record per sample (ig_grid_gather_sep): no index or value stream
                     gr, gi = _cplx(complex(alpha) * sep['gconst'])
                     n0, nm, ns = sep['dims']
-                    b._check(b._L.ig_grid_gather_sep(b._ctx, m, x.shape[1], sep['tw'], ctypes.c_void_p(sep['records']._arr), ctypes.c_void_p(x._arr),
+                    b._check(b._L.ig_grid_gather_sep(b._ctx, m, x.shape[1], sep['tw'], ctypes.c_void_p(sep['records']._arr), sep['stride'], ctypes.c_void_p(x._arr),
                                                      n0, nm, ns, gr, gi, br, bi, ctypes.c_void_p(y._arr), y._leading_dim), "ig_grid_gather_sep")
                     return
                 vre = self._real_values() if x.shape[1] in (2, 4, 8) else None
@@ -1322,10 +1328,15 @@ class HipBackend(Backend):
                     y._zero()           # without a support table every row is defined: bricks no sample touches stay zero
                 ar, ai = _cplx(complex(alpha) * np.conj(sep['gconst']))
                 n0, nm, ns = sep['dims']
-                b._check(b._L.ig_grid_scatter_sep(b._ctx, self.shape[0], x.shape[1], sep['tw'], ctypes.c_void_p(sep['records']._arr),
+                form = 1 if (b.tuning.get('sep_mfma', True) and x.shape[1] in (4, 8) and shf['bm'] <= 4 and shf['bs'] <= 4) else 0
+                form |= int(b.tuning.get('sep_dbg', 0)) << 4
+                if (form & 15) == 0 and '_records_plain' not in sep:        # (the LDS form reads records without the panel-row gap)
+                    sep['_records_plain'] = b.copy_array(sep['host'].reshape(-1), name=self._name + ".sepRecordsPlain")
+                recs, stride = (sep['records'], sep['stride']) if (form & 15) == 1 else (sep['_records_plain'], sep['host'].shape[1])
+                b._check(b._L.ig_grid_scatter_sep(b._ctx, self.shape[0], x.shape[1], sep['tw'], ctypes.c_void_p(recs._arr), stride,
                                                   ctypes.c_void_p(shf['shares']._arr), ctypes.c_void_p(x._arr), x._leading_dim, ctypes.c_void_p(y._arr),
                                                   n0, nm, ns, shf['bm'], shf['bs'], ctypes.c_void_p(shf['tasks']._arr), shf['ntasks'],
-                                                  ctypes.c_void_p(shf['table']._arr), ctypes.c_void_p(shf['shared']._arr), shf['nshared'], shf['tile'], ar, ai),
+                                                  ctypes.c_void_p(shf['table']._arr), ctypes.c_void_p(shf['shared']._arr), shf['nshared'], shf['tile'], ar, ai, form),
                          "ig_grid_scatter_sep")
                 return
             br = self._format('_bricks', x.shape[1], exact=True)

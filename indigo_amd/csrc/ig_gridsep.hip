@@ -73,9 +73,9 @@ __device__ __forceinline__ void gather_rows(float4& acc, const float4* __restric
 
 template <int NC, int TW, int BMODE>
 __global__ void __launch_bounds__(BLK)
-k_grid_gather_sep(int64_t M, const uint32_t* __restrict__ rec, const float4* __restrict__ X4, int n0, int nm, int ns,
+k_grid_gather_sep(int64_t M, const uint32_t* __restrict__ rec, int rs /* words per record (>= sep_words) */, const float4* __restrict__ X4, int n0, int nm, int ns,
                   float2* __restrict__ Y, int64_t ldy, float2 alpha, float2 beta) {
-    constexpr int QL = NC / 2, XL = TW <= 4 ? 4 : 8, LPS = QL * XL, SPW = 64 / LPS, RW = sep_words(TW);
+    constexpr int QL = NC / 2, XL = TW <= 4 ? 4 : 8, LPS = QL * XL, SPW = 64 / LPS;
     constexpr int CG = TW <= 4 ? 4 : 2;                                   // slow-axis rows whose loads are in flight together
     static_assert(LPS <= 64 && NC >= 2, "a sample's lanes fit a wave");
     const int lane = threadIdx.x & 63;
@@ -84,7 +84,7 @@ k_grid_gather_sep(int64_t M, const uint32_t* __restrict__ rec, const float4* __r
     const int64_t wave = blk * WPB + (threadIdx.x >> 6);
     const int64_t t = wave * SPW + g;
     const bool ok = t < M;
-    const uint32_t* __restrict__ r = rec + (size_t)(ok ? t : M - 1) * RW;
+    const uint32_t* __restrict__ r = rec + (size_t)(ok ? t : M - 1) * (uint32_t)rs;
     const uint32_t h0 = r[3 * TW], h1 = r[3 * TW + 1];
     const int j0 = (int)(h0 & 0xffffu), j1 = (int)(h0 >> 16), j2 = (int)(h1 & 0xffffu);
     const int c0 = (int)((h1 >> 16) & 15u), c1 = (int)((h1 >> 20) & 15u), c2 = (int)((h1 >> 24) & 15u);
@@ -132,7 +132,7 @@ k_grid_gather_sep(int64_t M, const uint32_t* __restrict__ rec, const float4* __r
 // The SCATTER, race-free by binning as in k_grid_bricks (ig_spmm.hip) -- a wave owns a run of grid bricks of 16 x BM x BS cells, keeps
 // ONE brick image in LDS, accumulates with plain read-add-write and stores the image's flagged segments at each brick boundary --
 // but what is binned are SHARES, not taps: a share = (sample, brick) for every brick the sample's footprint meets, 8 bytes:
-//   word 0   sample
+//   word 0   sample | the brick's slow-axis cells that hold a tap of the share << 28 (bricks of <= 4 slow cells; else 15)
 //   word 1   ox + 8 | (om + 8) << 5 | (os + 8) << 10 | blo << 15 | bhi << 18 | clo << 22 | chi << 25
 //            tap (a, b, c) of the sample sits at brick cell (ox + a, om + b, os + c); the taps b in [blo, bhi), c in [clo, chi) and
 //            those a with 0 <= ox + a < 16 are the ones inside this brick
@@ -198,6 +198,7 @@ k_grid_scatter_sep(const ShareTask* __restrict__ tasks, int ntasks, const ShareB
         const int64_t pt = ((int64_t)__builtin_amdgcn_readlane((int)(my_pt >> 32), cur) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_pt, cur);
         for (int row0 = 0; row0 < nrows; row0 += RP) {
             const int row = row0 + f_row;
+            if (row >= nrows) continue;                    // (bricks of fewer rows than a pass covers: narrow panels)
             const int seg = (f_x >> st_log2) + (row << xs_log2);
             const bool mine = (mask >> seg) & 1ull;
             float4* src = img + row * LR + f_xq;
@@ -232,11 +233,28 @@ k_grid_scatter_sep(const ShareTask* __restrict__ tasks, int ntasks, const ShareB
 #pragma unroll
             for (int k = 0; k < G; ++k) {
                 const int s = s0 + k < nbatch ? s0 + k : nbatch - 1;
-                const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)sh.x, s);
+                const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)sh.x, s) & 0x0fffffffu;
                 w[k] = lane_base[(size_t)t * lane_stride];
             }
         };
         auto process = [&](const uint32_t (&w)[G], int s0) __attribute__((always_inline)) {
+            // hand-offs of the whole group first (independent of the image: all G x 6 ds_bpermute are in flight together) ...
+            float w0[G], w1[G];
+            float4 xv[G];
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+                const int sk = s0 + k < nbatch ? s0 + k : nbatch - 1;
+                const uint32_t geo = (uint32_t)__builtin_amdgcn_readlane((int)sh.y, sk);
+                const int b = (int)((geo >> 15) & 7u) + bl;
+                const int wi = (int)w[k];
+                w0[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(i * 4, wi));
+                xv[k].x = __int_as_float(__builtin_amdgcn_ds_bpermute((RW + 4 * q) * 4, wi));
+                xv[k].y = __int_as_float(__builtin_amdgcn_ds_bpermute((RW + 4 * q + 1) * 4, wi));
+                xv[k].z = __int_as_float(__builtin_amdgcn_ds_bpermute((RW + 4 * q + 2) * 4, wi));
+                xv[k].w = __int_as_float(__builtin_amdgcn_ds_bpermute((RW + 4 * q + 3) * 4, wi));
+                w1[k] = __int_as_float(__builtin_amdgcn_ds_bpermute((TW + (b < TW ? b : 0)) * 4, wi));
+            }
+            // ... then share by share: the image cells of all slow-axis taps are read before the first multiply-add
 #pragma unroll
             for (int k = 0; k < G; ++k) {
                 const int s = s0 + k;
@@ -246,26 +264,31 @@ k_grid_scatter_sep(const ShareTask* __restrict__ tasks, int ntasks, const ShareB
                 const int ox = (int)(geo & 31u) - 8, om = (int)((geo >> 5) & 31u) - 8, os = (int)((geo >> 10) & 31u) - 8;
                 const int blo = (int)((geo >> 15) & 7u), bhi = (int)((geo >> 18) & 15u), clo = (int)((geo >> 22) & 7u), chi = (int)((geo >> 25) & 15u);
                 const int wi = (int)w[k];
-                const float w0 = __int_as_float(__builtin_amdgcn_ds_bpermute(i * 4, wi));
-                float4 xv;
-                xv.x = __int_as_float(__builtin_amdgcn_ds_bpermute((RW + 4 * q) * 4, wi));
-                xv.y = __int_as_float(__builtin_amdgcn_ds_bpermute((RW + 4 * q + 1) * 4, wi));
-                xv.z = __int_as_float(__builtin_amdgcn_ds_bpermute((RW + 4 * q + 2) * 4, wi));
-                xv.w = __int_as_float(__builtin_amdgcn_ds_bpermute((RW + 4 * q + 3) * 4, wi));
                 const int cx = ox + i;
                 const bool vx = (unsigned)cx < 16u && i < TW;
                 for (int b0 = blo; b0 < bhi; b0 += BL) {
                     const int b = b0 + bl;
-                    const float w01 = w0 * __int_as_float(__builtin_amdgcn_ds_bpermute((TW + (b < TW ? b : 0)) * 4, wi));
+                    float w01 = w0[k] * w1[k];
+                    if (b0 != blo) w01 = w0[k] * __int_as_float(__builtin_amdgcn_ds_bpermute((TW + (b < TW ? b : 0)) * 4, wi));
                     if (vx && b < bhi) {
-                        const int cell0 = cx + 16 * (om + b);
-                        for (int c = clo; c < chi; ++c) {
-                            const float w = w01 * __int_as_float(__builtin_amdgcn_readlane(wi, 2 * TW + c));
-                            float4* a = img + (cell0 + (16 << bm_log2) * (os + c)) * QL + q;
-                            float4 v = *a;                 // plain read-add-write: the lanes of a round hold distinct cells of ONE sample,
-                            v.x = fmaf(w, xv.x, v.x); v.y = fmaf(w, xv.y, v.y);       // the image is this wave's, and a wave's LDS
-                            v.z = fmaf(w, xv.z, v.z); v.w = fmaf(w, xv.w, v.w);       // operations execute in order
-                            *a = v;
+                        constexpr int CT = TW < 4 ? TW : 4;
+                        float4* a0 = img + (cx + 16 * (om + b) + (16 << bm_log2) * (os + clo)) * QL + q;
+                        const int cstep = (16 << bm_log2) * QL;
+                        for (int c0 = clo; c0 < chi; c0 += CT, a0 += CT * cstep) {
+                            float4 v[CT];
+#pragma unroll
+                            for (int u = 0; u < CT; ++u)
+                                if (c0 + u < chi) v[u] = a0[u * cstep];          // plain read-add-write: the lanes of a round hold distinct
+#pragma unroll
+                            for (int u = 0; u < CT; ++u)                         // cells of ONE sample, the image is this wave's, and a
+                                if (c0 + u < chi) {                              // wave's LDS operations execute in order
+                                    const float wt = w01 * __int_as_float(__builtin_amdgcn_readlane(wi, 2 * TW + c0 + u));
+                                    v[u].x = fmaf(wt, xv[k].x, v[u].x); v[u].y = fmaf(wt, xv[k].y, v[u].y);
+                                    v[u].z = fmaf(wt, xv[k].z, v[u].z); v[u].w = fmaf(wt, xv[k].w, v[u].w);
+                                }
+#pragma unroll
+                            for (int u = 0; u < CT; ++u)
+                                if (c0 + u < chi) a0[u * cstep] = v[u];
                         }
                     }
                 }
@@ -281,6 +304,213 @@ k_grid_scatter_sep(const ShareTask* __restrict__ tasks, int ntasks, const ShareB
         }
     }
     flush();
+}
+
+// ---- adjoint on the matrix cores ---------------------------------------------------------------------------------------------------
+// The same scatter of shares with the brick image in REGISTERS and the accumulation as outer products on the MFMA pipe.  The
+// stored-tap scatter (k_grid_bricks, ig_spmm.hip) and the LDS form above spend ~130 vector instructions per sample to issue the
+// 27 x 16 multiply-adds a sample is (7 wave instructions' worth): they are bound by instruction issue, not by HBM (1.8 TB/s on a
+// densely sampled trajectory, profiles/r06_*).  A share's contribution to a brick of 16 (x) x 4 (middle) x NG (slow) cells IS a sum of
+// outer products: for slow-axis cell g and middle-axis cell beta
+//       image[x, beta, g][f] += wx[x - ox] * (wm[beta - om] * ws[g - os] * X[t, f]),        f = 0 .. 2 NC - 1 floats of the NC coils
+// which v_mfma_f32_16x16x1_4b_f32 computes for all 16 x, all 4 beta (its four blocks) and all 16 f in ONE instruction of 32 clocks:
+// A = wx[x - ox] (lane = x + 16 beta), B = wm[beta - om] ws[g - os] X[t, f] (lane = f + 16 beta), D = the 16 registers of group g.
+// A share costs NG MFMAs whatever the number of taps inside it -- 27 (kernel width 2) or 125 (the reference's default width 3) --
+// plus three ds_bpermute hand-offs (x weight, middle weight, panel value) and one v_readlane + multiply per group.  fp32 in, fp32
+// accumulate: the same arithmetic as the vector form.  Record and panel row of a sample are ONE 128-byte line (`recx`: the pack
+// kernel writes the panel row behind the record), fetched by one lane-word load per share.
+typedef float v16f_t __attribute__((ext_vector_type(16)));
+
+template <bool SHARED, int NG, int XW>
+__device__ __forceinline__ void mfma_flush(v16f_t (&acc)[NG], float* __restrict__ Yf, int64_t pt, uint64_t mask, float2 alpha, float sgn_ai, bool f_ok,
+                                           int beta, int mn, int n0, int nm, int bm, int bs, int st_log2) {
+    const int xs_log2 = 4 - st_log2;
+    const int xseg = (4 * beta) >> st_log2;                // (a lane's four cells 4 beta .. 4 beta + 3 lie in one segment: segments are >= 4 cells)
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (g < bs) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (b < bm) {
+                    // D of block b: register 4 b + r of lane (f, xq) holds cell x = 4 xq + r, float f
+                    float* dst = Yf + (pt + 4 * beta + (int64_t)n0 * (b + (int64_t)nm * g)) * XW + mn;
+                    const bool mine = f_ok && ((mask >> (xseg + ((b + bm * g) << xs_log2))) & 1ull);
+                    float o[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = acc[g][4 * b + r];
+                        const float pv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+                        o[r] = fmaf(alpha.x, v, sgn_ai * pv);
+                    }
+                    if (mine) {
+                        // (asm: the compiler's wait-count bookkeeping does not see these and so leaves the prefetched records alone; the
+                        // cell's offset rides as the instruction's immediate: one address per brick row)
+                        if (SHARED)
+                            asm volatile("global_atomic_add_f32 %0, %1, off\n\tglobal_atomic_add_f32 %0, %2, off offset:%5\n\t"
+                                         "global_atomic_add_f32 %0, %3, off offset:%6\n\tglobal_atomic_add_f32 %0, %4, off offset:%7"
+                                         :: "v"(dst), "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "i"(XW * 4), "i"(2 * XW * 4), "i"(3 * XW * 4) : "memory");
+                        else
+                            asm volatile("global_store_dword %0, %1, off\n\tglobal_store_dword %0, %2, off offset:%5\n\t"
+                                         "global_store_dword %0, %3, off offset:%6\n\tglobal_store_dword %0, %4, off offset:%7"
+                                         :: "v"(dst), "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "i"(XW * 4), "i"(2 * XW * 4), "i"(3 * XW * 4) : "memory");
+                    }
+                    __builtin_amdgcn_sched_barrier(0);     // (keep the 16 rows' addresses from all being formed up front)
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
+    }
+}
+
+template <int NC, int TW, int NG>
+__global__ void __launch_bounds__(BLK, 3)                  // (three waves per SIMD: 168 registers, 64 of them the brick image)
+k_grid_scatter_mfma(const ShareTask* __restrict__ tasks, int ntasks, const ShareBrick* __restrict__ btab, const uint2* __restrict__ shares,
+                    const uint32_t* __restrict__ recx, int rs /* words per sample: record, then the packed panel row */,
+                    float* __restrict__ Yf, float2 alpha, int n0, int nm, int bm_log2, int bs_log2, int nbx, int nbm, int st_log2) {
+    constexpr int RW = sep_words(TW), XW = 2 * NC, ZL = 3 * TW + 2;          // ZL: a record word that is always zero
+    constexpr int PW = RW + 16;                            // ring slot words [PW, PW + TW + 6): 0 0 0, the slow-axis weights, 0 0 0
+    constexpr int G = 4, R = 16;                           // shares per group (their loads are in flight together); ring slots
+    static_assert(PW + TW + 6 <= 64 && XW <= 16 && NG == 4, "a ring slot holds record, panel row and the padded slow-axis weights");
+    __shared__ uint32_t ring_all[WPB][R][64];              // lane-word images of the next shares' record + panel row
+    __shared__ uint2 hdr_all[WPB][128];                    // two batches of share headers
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int task = blockIdx.x * WPB + wv;
+    if (task >= ntasks) return;                            // (no workgroup barrier below: waves are independent)
+    const ShareTask tk = tasks[task];
+    const int nb = tk.nb_flags & 0xffff;
+    const bool shared = (tk.nb_flags >> 16) & 1;
+    const int nsh = tk.hi - tk.lo;
+    const int bm = 1 << bm_log2, bs = 1 << bs_log2;
+    const int beta = lane >> 4, mn = lane & 15;            // block (middle-axis cell of the brick); x cell (A, D rows) / float (B, D columns)
+    uint32_t* __restrict__ ring = &ring_all[wv][0][0];
+
+    int my_end = 0x7fffffff;
+    uint32_t my_mlo = 0xffffffffu, my_mhi = 0xffffffffu;
+    int64_t my_pt = 0;
+    if (lane < nb) {
+        const ShareBrick br = btab[tk.bt + lane];
+        if (!shared) my_end = br.end - tk.lo;
+        my_mlo = br.mask_lo; my_mhi = br.mask_hi;
+        const int bx = br.brick % nbx, bmi = (br.brick / nbx) % nbm, bsi = br.brick / (nbx * nbm);
+        my_pt = (int64_t)bx * 16 + (int64_t)n0 * (((int64_t)bmi << bm_log2) + (int64_t)nm * ((int64_t)bsi << bs_log2));
+    }
+    v16f_t acc[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
+
+    // what lane L fetches of a sample: L < RW the record, RW <= L < RW + XW the panel row, PW + 3 <= L < PW + 3 + TW the slow-axis
+    // weights once more (between zeros: a share reads four of these words starting at PW + 3 - os, whatever os is), else a zero word
+    const int lw = lane < RW + XW ? lane : (lane >= PW + 3 && lane < PW + 3 + TW) ? 2 * TW + (lane - PW - 3) : ZL;
+    const uint32_t* lane_base = recx + lw;
+    const float sgn_ai = (mn & 1) ? alpha.y : -alpha.y;    // out = ar * v + sgn_ai * (the other part of the complex value: the neighbouring lane's)
+    const bool f_ok = mn < XW;
+    const int xv_off = (f_ok ? RW + mn : ZL) * 4, mn4 = mn * 4, beta4 = (TW + beta) * 4;
+
+    int cur = 0;
+    int cur_end = __builtin_amdgcn_readlane(my_end, 0);
+    auto brick_of = [&](int& pt_hi, int& pt_lo, uint32_t& mlo, uint32_t& mhi) __attribute__((always_inline)) {
+        mlo = (uint32_t)__builtin_amdgcn_readlane((int)my_mlo, cur); mhi = (uint32_t)__builtin_amdgcn_readlane((int)my_mhi, cur);
+        pt_hi = __builtin_amdgcn_readlane((int)(my_pt >> 32), cur); pt_lo = __builtin_amdgcn_readlane((int)(uint32_t)my_pt, cur);
+    };
+
+    // Share headers: 64 per batch, lane-parallel (one coalesced 512-byte load), kept in LDS two batches deep with a third in
+    // flight -- every later access is an LDS read, so nothing in the loop waits for a scalar or vector load it has just issued.
+    const uint2* __restrict__ shp = shares + tk.lo;
+    uint2* __restrict__ hdrs = &hdr_all[wv][0];
+    auto load_batch = [&](int b) __attribute__((always_inline)) {
+        const int idx = b * 64 + lane;
+        return idx < nsh ? shp[idx] : make_uint2(0u, 0u);
+    };
+    {
+        const uint2 b0 = load_batch(0), b1 = load_batch(1);
+        hdrs[lane] = b0;
+        hdrs[64 + lane] = b1;
+    }
+    uint2 sh_next = load_batch(2);
+    int cb = 0;                                            // LDS holds batches cb and cb + 1; sh_next holds batch cb + 2
+
+    // The pipeline of a group of G shares:  Q  the lane-word loads of record + panel row  ->  S  the loaded words into the ring  ->
+    // P  the outer products.  Step i runs Q(i + 2), P(i), S(i + 1): a load has two groups' worth of work to arrive in.
+    auto request = [&](uint32_t (&w)[G], int gi) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            const int sraw = G * gi + k;
+            const int sc = sraw < nsh ? sraw : nsh - 1;
+            const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdrs[sc & 127].x) & 0x0fffffffu;          // (wave-uniform address)
+            w[k] = lane_base[(size_t)t * (uint32_t)rs];
+        }
+    };
+    auto stage = [&](const uint32_t (&w)[G], int gi) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < G; ++k) ring[((G * gi + k) & (R - 1)) * 64 + lane] = w[k];
+    };
+    auto process = [&](int gi) __attribute__((always_inline)) {
+        for (int k = 0; k < G; ++k) {                      // (a run-time loop: ONE share site, one flush site)
+            const int s = G * gi + k;
+            if (s >= nsh) break;                           // (wave-uniform)
+            if (s >= cur_end) {                            // (every brick of the table holds at least one share; shared tasks never get here)
+                int ph, pl; uint32_t mlo, mhi;
+                brick_of(ph, pl, mlo, mhi);
+                mfma_flush<false, NG, XW>(acc, Yf, ((int64_t)ph << 32) | (uint32_t)pl, ((uint64_t)mhi << 32) | mlo, alpha, sgn_ai, f_ok, beta, mn, n0, nm, bm, bs, st_log2);
+                ++cur;
+                cur_end = __builtin_amdgcn_readlane(my_end, cur & 63);
+            }
+            const uint2 hd = hdrs[s & 127];
+            const uint32_t geo = (uint32_t)__builtin_amdgcn_readfirstlane((int)hd.y), gmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)hd.x) >> 28;
+            const char* slot = reinterpret_cast<const char*>(ring) + (s & (R - 1)) * 256;
+            // byte offsets into the slot: x weight of cell mn, middle weight of block beta (a zero word outside the taps), panel value
+            const int ox4 = (int)(geo & 31u) * 4 - 32, om4 = (int)((geo >> 5) & 31u) * 4 - 32, os4 = (int)((geo >> 10) & 31u) * 4 - 32;
+            const unsigned dx = (unsigned)(mn4 - ox4), db = (unsigned)(beta4 - om4);
+            const float ax = __uint_as_float(*reinterpret_cast<const uint32_t*>(slot + (dx < (unsigned)(4 * TW) ? dx : (unsigned)(4 * ZL))));
+            const float wm = __uint_as_float(*reinterpret_cast<const uint32_t*>(slot + (db - 4u * TW < (unsigned)(4 * TW) ? db : (unsigned)(4 * ZL))));
+            const float xv = __uint_as_float(*reinterpret_cast<const uint32_t*>(slot + xv_off));
+            const uint32_t* wsp = reinterpret_cast<const uint32_t*>(slot + (PW + 3) * 4 - os4);             // (wave-uniform: broadcast reads)
+            const float bmx = wm * xv;
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+                if ((gmask >> g) & 1u)                     // (wave-uniform: slow-axis cells without a tap of this share cost nothing)
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x1f32(ax, bmx * __uint_as_float(wsp[g]), acc[g], 0, 0, 0);
+        }
+    };
+
+    const int ngroups = (nsh + G - 1) / G;
+    uint32_t wa[G], wb[G];
+    request(wa, 0);
+    request(wb, 1);
+    stage(wa, 0);
+    for (int gi = 0; gi < ngroups; gi += 2) {
+        if (((G * gi) >> 6) != cb) {                       // processing enters batch cb + 1: batch cb + 2 takes the place of batch cb
+            ++cb;
+            hdrs[((cb + 1) & 1) * 64 + lane] = sh_next;
+            sh_next = load_batch(cb + 2);
+        }
+        request(wa, gi + 2);
+        process(gi);
+        stage(wb, gi + 1);
+        request(wb, gi + 3);
+        process(gi + 1);
+        stage(wa, gi + 2);
+    }
+    {
+        int ph, pl; uint32_t mlo, mhi;
+        brick_of(ph, pl, mlo, mhi);
+        const int64_t pt = ((int64_t)ph << 32) | (uint32_t)pl;
+        const uint64_t mask = ((uint64_t)mhi << 32) | mlo;
+        if (shared) mfma_flush<true, NG, XW>(acc, Yf, pt, mask, alpha, sgn_ai, f_ok, beta, mn, n0, nm, bm, bs, st_log2);
+        else        mfma_flush<false, NG, XW>(acc, Yf, pt, mask, alpha, sgn_ai, f_ok, beta, mn, n0, nm, bm, bs, st_log2);
+    }
+}
+
+// the record of every sample with room for its panel row behind it: recx[t * rs + 0 .. RW) = record, [RW, RW + 2 NC) = X[t, :]
+template <int NC>
+__global__ void __launch_bounds__(BLK)
+k_sep_pack_recx(int64_t rows, const float2* __restrict__ X, int64_t ld, float2* __restrict__ recx2 /* recx as float2 */, int rs2 /* rs / 2 */, int rw2 /* RW / 2 */) {
+    for (int64_t e = (int64_t)blockIdx.x * BLK + threadIdx.x; e < rows * NC; e += (int64_t)gridDim.x * BLK)
+        recx2[(e / NC) * rs2 + rw2 + e % NC] = X[(e % NC) * ld + e / NC];
 }
 
 // zero the flagged segments of the bricks that several tasks add into
@@ -345,7 +575,9 @@ inline void for_shares(const ShareGeom& g, const uint32_t* r, F&& f) {
                 const int64_t brick = px[a].brick + g.nbr[0] * (pm[b].brick + g.nbr[1] * (int64_t)ps[c].brick);
                 const uint32_t geo = (uint32_t)(px[a].o + 8) | ((uint32_t)(pm[b].o + 8) << 5) | ((uint32_t)(ps[c].o + 8) << 10) |
                                      ((uint32_t)pm[b].lo << 15) | ((uint32_t)pm[b].hi << 18) | ((uint32_t)ps[c].lo << 22) | ((uint32_t)ps[c].hi << 25);
-                f(brick, geo);
+                // the slow-axis cells of the brick that hold a tap of this share (bricks of at most 4 slow cells: the MFMA form)
+                const uint32_t gmask = g.bdim[2] <= 4 ? ((((1u << (ps[c].hi - ps[c].lo)) - 1u) << (ps[c].o + ps[c].lo)) & 15u) : 15u;
+                f(brick, geo, gmask);
             }
 }
 
@@ -383,13 +615,14 @@ extern "C" {
 
 // Y (M x NC, column-major, ldy) = alpha * G X + beta * Y for the gridding matrix given by `records` (ig_interp3_sep with grid_order
 // matching the panel: axes (n0, nm, ns) in memory order) and the coil-interleaved grid panel X (n0 * nm * ns rows of NC values).
-int ig_grid_gather_sep(ig_ctx* ctx, int64_t M, int64_t NC, int tw, const void* records, const void* X_il, int64_t n0, int64_t nm, int64_t ns,
+int ig_grid_gather_sep(ig_ctx* ctx, int64_t M, int64_t NC, int tw, const void* records, int64_t rec_stride, const void* X_il, int64_t n0, int64_t nm, int64_t ns,
                        float ar, float ai, float br, float bi, void* Y, int64_t ldy) {
     IG_REQUIRE(ctx, ctx != nullptr, "ig_grid_gather_sep: ctx is NULL");
     IG_REQUIRE(ctx, M >= 0 && (NC == 2 || NC == 4 || NC == 8) && (tw == 4 || tw == 6 || tw == 8), "ig_grid_gather_sep: 2, 4 or 8 interleaved coils; tw 4, 6 or 8");
     IG_REQUIRE(ctx, n0 >= tw && nm >= tw && ns >= tw && n0 <= 65535 && nm <= 65535 && ns <= 65535 && n0 * nm * ns * (NC / 2) < (1LL << 32),
                "ig_grid_gather_sep: grid %lld x %lld x %lld x %lld coils out of range", (long long)n0, (long long)nm, (long long)ns, (long long)NC);
     IG_REQUIRE(ctx, M == 0 || (records && X_il && Y && ldy >= M), "ig_grid_gather_sep: NULL pointer or ldy < M");
+    IG_REQUIRE(ctx, rec_stride >= sep_words(tw) && rec_stride % 4 == 0 && rec_stride <= 1024, "ig_grid_gather_sep: record stride %lld words", (long long)rec_stride);
     IG_REQUIRE(ctx, (reinterpret_cast<uintptr_t>(X_il) & 15u) == 0 && (reinterpret_cast<uintptr_t>(records) & 15u) == 0, "ig_grid_gather_sep: 16-byte aligned panel and records");
     if (M == 0) return IG_OK;
     if (int rc = ig_set_device(ctx)) return rc;
@@ -401,9 +634,9 @@ int ig_grid_gather_sep(ig_ctx* ctx, int64_t M, int64_t NC, int tw, const void* r
         const int64_t blocks = ((M + spw - 1) / spw + WPB - 1) / WPB;                                                            \
         IG_REQUIRE(ctx, blocks <= 0x7fffffffLL, "ig_grid_gather_sep: too many samples for one launch");                          \
         if (b0) hipLaunchKernelGGL((k_grid_gather_sep<NC_, TW_, 0>), dim3((unsigned)blocks), dim3(BLK), 0, ctx->stream, M,       \
-                                   (const uint32_t*)records, (const float4*)X_il, (int)n0, (int)nm, (int)ns, (float2*)Y, ldy, alpha, beta); \
+                                   (const uint32_t*)records, (int)rec_stride, (const float4*)X_il, (int)n0, (int)nm, (int)ns, (float2*)Y, ldy, alpha, beta); \
         else    hipLaunchKernelGGL((k_grid_gather_sep<NC_, TW_, 1>), dim3((unsigned)blocks), dim3(BLK), 0, ctx->stream, M,       \
-                                   (const uint32_t*)records, (const float4*)X_il, (int)n0, (int)nm, (int)ns, (float2*)Y, ldy, alpha, beta); \
+                                   (const uint32_t*)records, (int)rec_stride, (const float4*)X_il, (int)n0, (int)nm, (int)ns, (float2*)Y, ldy, alpha, beta); \
     } while (0)
 #define IG_GS_TW(NC_) do { if (tw == 4) IG_GS(NC_, 4); else if (tw == 6) IG_GS(NC_, 6); else IG_GS(NC_, 8); } while (0)
     if (NC == 8) IG_GS_TW(8);
@@ -432,7 +665,7 @@ int ig_grid_shares_count(int64_t M, const uint32_t* records, int tw, int64_t n0,
         cnt[t].assign((size_t)nb, 0);
         const int64_t lo = std::min<int64_t>(M, t * per), hi = std::min<int64_t>(M, lo + per);
         for (int64_t s = lo; s < hi; ++s)
-            for_shares(g, records + (size_t)s * g.rw, [&](int64_t brick, uint32_t) { if (++cnt[t][brick] < 0) bad = 1; });
+            for_shares(g, records + (size_t)s * g.rw, [&](int64_t brick, uint32_t, uint32_t) { if (++cnt[t][brick] < 0) bad = 1; });
     });
     run_threads(nt, [&](int t) {
         const int64_t pb = (nb + nt - 1) / nt, lo = std::min<int64_t>(nb, t * pb), hi = std::min<int64_t>(nb, lo + pb);
@@ -450,8 +683,8 @@ int ig_grid_shares_count(int64_t M, const uint32_t* records, int tw, int64_t n0,
 int ig_grid_shares_fill(int64_t M, const uint32_t* records, int tw, int64_t n0, int64_t nm, int64_t ns, int bm, int bs,
                         const int64_t* brick_ptr /* exclusive prefix sums of the counts, nbricks + 1 */, uint32_t* shares /* 2 words each */) {
     ShareGeom g;
-    if (M < 0 || (M > 0 && (!records || !shares)) || !brick_ptr || !share_geom(g, tw, n0, nm, ns, bm, bs))
-        return ig_fail(nullptr, IG_ERR_ARG, "ig_grid_shares_fill: bad arguments");
+    if (M < 0 || M >= (1LL << 28) || (M > 0 && (!records || !shares)) || !brick_ptr || !share_geom(g, tw, n0, nm, ns, bm, bs))
+        return ig_fail(nullptr, IG_ERR_ARG, "ig_grid_shares_fill: bad arguments (fewer than 2^28 samples)");
     const int64_t nb = g.nbr[0] * g.nbr[1] * g.nbr[2];
     const int nt = share_threads(M);
     const int64_t per = (M + nt - 1) / nt;
@@ -460,7 +693,7 @@ int ig_grid_shares_fill(int64_t M, const uint32_t* records, int tw, int64_t n0, 
         cur[t].assign((size_t)nb, 0);
         const int64_t lo = std::min<int64_t>(M, t * per), hi = std::min<int64_t>(M, lo + per);
         for (int64_t s = lo; s < hi; ++s)
-            for_shares(g, records + (size_t)s * g.rw, [&](int64_t brick, uint32_t) { ++cur[t][brick]; });
+            for_shares(g, records + (size_t)s * g.rw, [&](int64_t brick, uint32_t, uint32_t) { ++cur[t][brick]; });
     });
     std::atomic<int> mismatch{0};
     run_threads(nt, [&](int t) {                   // per-thread counts -> per-thread cursors
@@ -476,9 +709,9 @@ int ig_grid_shares_fill(int64_t M, const uint32_t* records, int tw, int64_t n0, 
         int32_t* cursor = cur[t].data();
         const int64_t lo = std::min<int64_t>(M, t * per), hi = std::min<int64_t>(M, lo + per);
         for (int64_t s = lo; s < hi; ++s)
-            for_shares(g, records + (size_t)s * g.rw, [&](int64_t brick, uint32_t geo) {
+            for_shares(g, records + (size_t)s * g.rw, [&](int64_t brick, uint32_t geo, uint32_t gmask) {
                 uint32_t* o = shares + 2 * (size_t)(brick_ptr[brick] + cursor[brick]++);
-                o[0] = (uint32_t)s; o[1] = geo;
+                o[0] = (uint32_t)s | (gmask << 28); o[1] = geo;
             });
     });
     return IG_OK;
@@ -488,9 +721,9 @@ int ig_grid_shares_fill(int64_t M, const uint32_t* records, int tw, int64_t n0, 
 // X (M x NC, column-major, ldx).  tasks / brick_table as for ig_ccsrmm_t_bricks with shares in place of entries and 16-byte table rows
 // {brick, end of its shares, flagged segments: 64 bits, bit xs + (16 / support_tile) * (im + bm * is)}; shared_table: the rows of the
 // bricks several tasks add into (zeroed first; those tasks add with float atomics).
-int ig_grid_scatter_sep(ig_ctx* ctx, int64_t M, int64_t NC, int tw, const void* records, const void* shares, const void* X, int64_t ldx,
+int ig_grid_scatter_sep(ig_ctx* ctx, int64_t M, int64_t NC, int tw, void* records, int64_t rec_stride, const void* shares, const void* X, int64_t ldx,
                         void* Y_il, int64_t n0, int64_t nm, int64_t ns, int bm, int bs, const int32_t* tasks, int64_t ntasks,
-                        const int32_t* brick_table, const int32_t* shared_table, int64_t nshared, int support_tile, float ar, float ai) {
+                        const int32_t* brick_table, const int32_t* shared_table, int64_t nshared, int support_tile, float ar, float ai, int form) {
     IG_REQUIRE(ctx, ctx != nullptr, "ig_grid_scatter_sep: ctx is NULL");
     ShareGeom g;
     IG_REQUIRE(ctx, M >= 0 && M <= 0x7fffffffLL && (NC == 2 || NC == 4 || NC == 8) && share_geom(g, tw, n0, nm, ns, bm, bs),
@@ -503,31 +736,57 @@ int ig_grid_scatter_sep(ig_ctx* ctx, int64_t M, int64_t NC, int tw, const void* 
     if (ntasks == 0 || M == 0) return IG_OK;
     if (int rc = ig_set_device(ctx)) return rc;
     const float2 alpha = make_float2(ar, ai);
+    const int rw = sep_words(tw);
+    IG_REQUIRE(ctx, rec_stride >= rw && rec_stride % 4 == 0 && ((form & 15) == 0 || rec_stride >= rw + 2 * NC), "ig_grid_scatter_sep: record stride %lld (words): the record, and for the MFMA form the panel row behind it", (long long)rec_stride);
+    int bm_log2 = 0, bs_log2 = 0;
+    while ((1 << bm_log2) < bm) ++bm_log2;
+    while ((1 << bs_log2) < bs) ++bs_log2;
+    const int st_log2 = support_tile == 16 ? 4 : support_tile == 8 ? 3 : 2;
+    const int nbx = (int)(n0 / 16), nbm = (int)(nm / bm);
+    const unsigned blocks = (unsigned)((ntasks + WPB - 1) / WPB);
     const size_t need = (size_t)M * NC * 8;
+#define IG_ZERO(NC_) do { if (nshared) {                                                                                                 \
+            ig_prof_scope prof(ctx, "grid_sep_zero");                                                                                    \
+            hipLaunchKernelGGL((k_grid_sep_zero<NC_>), dim3((unsigned)nshared), dim3(BLK), 0, ctx->stream, (const ShareBrick*)shared_table, \
+                               (float4*)Y_il, (int)n0, (int)nm, bm_log2, bs_log2, nbx, nbm, st_log2); } } while (0)
+    if ((form & 15) == 1) {
+        // outer products on the MFMA pipe, brick image in registers: bricks of 16 x (<= 4) x (<= 4) cells, 4 or 8 coils
+        IG_REQUIRE(ctx, (NC == 8 || NC == 4) && bm <= 4 && bs <= 4, "ig_grid_scatter_sep: the MFMA form takes 4 or 8 coils and bricks of 16 x (<= 4) x (<= 4) cells");
+        int64_t gp = (M * NC + BLK - 1) / BLK;
+        const int64_t cap = (int64_t)ctx->num_cu * 16;
+        if (gp > cap) gp = cap;
+#define IG_SM(NC_, TW_) do {                                                                                                             \
+        {   ig_prof_scope prof(ctx, "pack_panel", 2.0 * (double)need);                                                                   \
+            hipLaunchKernelGGL((k_sep_pack_recx<NC_>), dim3((unsigned)gp), dim3(BLK), 0, ctx->stream, M, (const float2*)X, ldx, (float2*)records, (int)(rec_stride / 2), rw / 2); } \
+        IG_ZERO(NC_);                                                                                                                    \
+        ig_prof_scope prof(ctx, "grid_scatter_sep");                                                                                     \
+        hipLaunchKernelGGL((k_grid_scatter_mfma<NC_, TW_, 4>), dim3(blocks), dim3(BLK), 0, ctx->stream, (const ShareTask*)tasks, (int)ntasks, \
+                           (const ShareBrick*)brick_table, (const uint2*)shares, (const uint32_t*)records, (int)rec_stride, (float*)Y_il, \
+                           alpha, (int)n0, (int)nm, bm_log2, bs_log2, nbx, nbm, st_log2);                                                \
+    } while (0)
+#define IG_SM_TW(NC_) do { if (tw == 4) IG_SM(NC_, 4); else if (tw == 6) IG_SM(NC_, 6); else IG_SM(NC_, 8); } while (0)
+        if (NC == 8) IG_SM_TW(8); else IG_SM_TW(4);
+#undef IG_SM_TW
+#undef IG_SM
+        IG_LAUNCH_CHECK(ctx, "k_grid_scatter_mfma");
+        return IG_OK;
+    }
+    IG_REQUIRE(ctx, rec_stride == rw, "ig_grid_scatter_sep: the LDS form reads records of %d words", rw);
     if (ctx->xpack_bytes < need) {
         if (ctx->d_xpack) { IG_HIP(ctx, hipStreamSynchronize(ctx->stream)); IG_HIP(ctx, hipFree(ctx->d_xpack)); ctx->d_xpack = nullptr; ctx->xpack_bytes = 0; }
         IG_HIP(ctx, hipMalloc((void**)&ctx->d_xpack, need));
         ctx->xpack_bytes = need;
     }
     float2* xpk = (float2*)ctx->d_xpack;
-    int bm_log2 = 0, bs_log2 = 0;
-    while ((1 << bm_log2) < bm) ++bm_log2;
-    while ((1 << bs_log2) < bs) ++bs_log2;
-    const int st_log2 = support_tile == 16 ? 4 : support_tile == 8 ? 3 : 2;
-    const int nbx = (int)(n0 / 16), nbm = (int)(nm / bm);
     const size_t lds = (size_t)WPB * 16 * bm * bs * NC * 8;                // one brick image per wave
     IG_REQUIRE(ctx, lds <= 160 * 1024, "ig_grid_scatter_sep: bricks of 16 x %d x %d cells x %lld coils need %zu bytes of LDS per workgroup", bm, bs, (long long)NC, lds);
-    const unsigned blocks = (unsigned)((ntasks + WPB - 1) / WPB);
 #define IG_SS(NC_, TW_) do {                                                                                                             \
         {   ig_prof_scope prof(ctx, "pack_panel", 2.0 * (double)need);                                                                   \
             int64_t gp = (M * NC_ + BLK - 1) / BLK;                                                                                      \
             const int64_t cap = (int64_t)ctx->num_cu * 16;                                                                               \
             if (gp > cap) gp = cap;                                                                                                      \
             hipLaunchKernelGGL((k_sep_pack_panel<NC_>), dim3((unsigned)gp), dim3(BLK), 0, ctx->stream, M, (const float2*)X, ldx, xpk); } \
-        if (nshared) {                                                                                                                   \
-            ig_prof_scope prof(ctx, "grid_sep_zero");                                                                                    \
-            hipLaunchKernelGGL((k_grid_sep_zero<NC_>), dim3((unsigned)nshared), dim3(BLK), 0, ctx->stream, (const ShareBrick*)shared_table, \
-                               (float4*)Y_il, (int)n0, (int)nm, bm_log2, bs_log2, nbx, nbm, st_log2); }                                  \
+        IG_ZERO(NC_);                                                                                                                    \
         if (lds > 64 * 1024)                                                                                                             \
             IG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grid_scatter_sep<NC_, TW_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         ig_prof_scope prof(ctx, "grid_scatter_sep");                                                                                     \
@@ -541,6 +800,7 @@ int ig_grid_scatter_sep(ig_ctx* ctx, int64_t M, int64_t NC, int tw, const void* 
     else IG_SS_TW(2);
 #undef IG_SS_TW
 #undef IG_SS
+#undef IG_ZERO
     IG_LAUNCH_CHECK(ctx, "k_grid_scatter_sep");
     return IG_OK;
 }

@@ -236,9 +236,13 @@ def assemble(backend, Gm, oN, N, weights_of, Cn, layout, chunks, table=None, box
             return G
         bricks, slots, fines, shares = {}, {}, {}, {}
         for w in (il_widths if interleaved else [ncols]):
-            if interleaved and sep is not None and tuning.get('separable', True) and w in tuning.get('shares', ()) and x16:
+            if (interleaved and sep is not None and tuning.get('separable', True) and w in tuning.get('shares', ()) and x16
+                    and sep['tw'] >= tuning.get('shares_min_tw', 6)):
                 # adjoint gridding as a scatter of (sample, brick) SHARES with the taps computed from the separable records
-                # (ig_grid_scatter_sep): no stored taps at all
+                # (ig_grid_scatter_sep): no stored taps at all.  A share costs the same whatever the number of taps inside it, so
+                # this is the route of wide kernels -- the reference's default half-width 3 (125 taps per sample: 1.6 ms against
+                # 2.2 ms for the stored-tap bricks on the headline trajectory); at half-width 2 (27 taps) the stored taps win
+                # (0.62 against 0.88 ms), measured in profiles/r06_scatter_forms.txt
                 sshape = tuning.get('share_shape', {})
                 sshape = tuple(sshape.get(w, (8, 2, 1024, 1024)) if isinstance(sshape, dict) else sshape)
                 shares[w] = (pow2_divisor(oN[2], sshape[0]), pow2_divisor(oN[1], sshape[1])) + sshape[2:]
