@@ -80,7 +80,7 @@ def tree_real_entries(A):
     return False
 
 
-def kernel_symbols(layout, ncoils, half_box=True, n=512, support_tile=16, real_entries=False):
+def kernel_symbols(layout, ncoils, half_box=True, n=512, support_tile=16, real_entries=False, tw=4):
     r1 = 32 if n == 512 else 16
     f = "k_fft_2stage<%d, 16, 16, %%s>" % r1
     m = {
@@ -119,6 +119,9 @@ def kernel_symbols(layout, ncoils, half_box=True, n=512, support_tile=16, real_e
                       "fft_crop_x": f % ("16, false, %d, true, 0" % (3 + lg))})
         m.update({"csrmm_rowlane_conj": "k_csrmm_dense64<%d, true, true>" % ncoils, "csrmm_gather": gv, "csrmm_slots_conj": "k_grid_slots<%d, %s>" % (ncoils, "true" if real_entries else "false"),
                   "csrmm_bricks_conj": bricks_symbol(ncoils, support_tile, real_entries)})
+    if layout == 2:
+        # round 6: the taps computed from the separable records (tw = weights per axis of a record: 4 up to kernel half-width 2, 6 up to 3)
+        m.update({"grid_gather_sep": "k_grid_gather_sep<%d, %d, 0>" % (ncoils, tw), "grid_scatter_sep": "k_grid_scatter_mfma<%d, %d, 4>" % (ncoils, tw)})
     elif layout == 1:
         h = (3, 1, 1, 2, 2, 4) if half_box else (0,) * 6
         w = 32 if (half_box and n == 512) else 16         # compile-time half box: 32-column tiles (launch_2stage, ig_fft.hip)
@@ -486,8 +489,9 @@ def run_sense(args, cfg, B, comm, world, rank, steps, warmup, want_cpu, quiet=Fa
             gb = p.gridding_pass_bytes(w, lf['table'], tile=lf['tile'], real_entries=real_entries)
             # SpMM GB/s two ways: the reference's model (operators.py:246-256) and the bytes this kernel must move
             add("csrmm_gather", gb["csrmm_gather"], recs[True][ci] if ci < len(recs[True]) else 0.0)
+            add("grid_gather_sep", gb["grid_gather_sep"], recs[True][ci] if ci < len(recs[True]) else 0.0)
             adj_ref = recs[False][ci] if ci < len(recs[False]) else 0.0
-            for site in (("csrmm_bricks_conj",) if w >= 4 else ("csrmm_slots_conj",)) + ("csrmm_rowlane_conj", "csrmm_gather_conj"):
+            for site in ("grid_scatter_sep",) + (("csrmm_bricks_conj",) if w >= 4 else ("csrmm_slots_conj",)) + ("csrmm_rowlane_conj", "csrmm_gather_conj"):
                 if site in prof:
                     add(site, gb.get(site, gb["csrmm_rowlane_conj"]), adj_ref)
                     break
@@ -503,7 +507,8 @@ def run_sense(args, cfg, B, comm, world, rank, steps, warmup, want_cpu, quiet=Fa
         prof[site]['bytes'] = nb * steps
         if ref:
             prof[site]['ref_bytes'] = ref * steps
-    symbols = kernel_symbols(layout if fused_fft else 0, cpr, half_box, p.oN[0], sup_tile if fused_fft else 16, real_entries)
+    tw = 4 if 2 * p.width <= 4 else 6 if 2 * p.width <= 6 else 8
+    symbols = kernel_symbols(layout if fused_fft else 0, cpr, half_box, p.oN[0], sup_tile if fused_fft else 16, real_entries, tw)
     standard = args.standard or (cfg == 5 and not args.image and not args.coils)
     uniform8 = bool(leaves_z) and all(lf['width'] == 8 for lf in leaves_z)
     roofline, kernels = roofline_of(prof, symbols, cfg, traffic_ok=(standard and uniform8))
@@ -741,6 +746,23 @@ def bench_sense(args, world, rank, local_rank):
         except Exception as e:             # noqa: BLE001 -- an extra must not cost the headline its line
             leaves["dense_trajectory"] = {"error": "%s: %s" % (type(e).__name__, e)}
             print("[bench] dense-trajectory extra failed: %s" % leaves["dense_trajectory"]["error"], file=sys.stderr, flush=True)
+    if rank == 0 and world == 1 and cfg == 4 and not args.no_dense and not args.shard and args.standard:
+        # The reference's own default kernel: Backend.NUFFT(width=3) (indigo/backends/backend.py:403; examples/pics.py:92 passes no width)
+        # -- 125 taps per sample instead of 27.  Same image, coils, grid and trajectory as the headline.
+        import copy
+        a3 = copy.copy(args)
+        a3.width, a3.standard = 3.0, False
+        try:
+            B._scratch = None
+            r = run_sense(a3, 4, B, None, 1, 0, max(3, min(args.steps, 5)), min(args.warmup, 2), False, quiet=True, want_parity=True)
+            leaves["width3"] = {"evals_per_s": r["value"], "ms_per_step": r["ms_per_step"], "setup_s": r["setup_s"], "config": r["config"],
+                                "eval_compulsory_GB": r["eval_compulsory_GB"],
+                                "eval_compulsory_frac": r["eval_compulsory_GB"] / (r["ms_per_step"] * 1e-3) / HBM_PEAK_GBS,
+                                "parity_rel_err": r.get("parity_rel_err"), "kernels": r["kernels"],
+                                "note": "the headline problem with the reference's default kernel half-width 3 (python bench.py --width 3): 125 taps per sample"}
+        except Exception as e:             # noqa: BLE001 -- an extra must not cost the headline its line
+            leaves["width3"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            print("[bench] width-3 extra failed: %s" % leaves["width3"]["error"], file=sys.stderr, flush=True)
     errs = emit(extra5, leaves) if rank == 0 else []
     if comm is not None:
         comm.close()

@@ -620,65 +620,66 @@ class Backend(object):
     # solvers
     # ---------------------------------------------------------------------------
     def cg(self, A, b_h, x_h, lamda=0.0, tol=1e-10, maxiter=100, team=None):
-        """Conjugate gradients on (A + lamda I) x = b; x_h is the start and receives the result.
+        """Conjugate gradients on (A + lamda I) x = b, host-scalar form: x_h is the start and receives the result; returns the
+        relative residuals ||r_k|| / ||r_0||, one per iteration, stopping at the first below `tol`.
 
-        Same update sequence as the reference (backend.py:651-689): r = b - A x - lamda x,
-        then per iteration one A.eval, five axpby/scale passes, one dot and one norm2.
-        Returns the list of relative residuals.  b_h / x_h may also be device arrays of this backend: x is then
-        updated in place and nothing crosses the host boundary except the two scalars per iteration.
-        """
-        x_dev = isinstance(x_h, self.dndarray)
-        x = x_h if x_dev else self.copy_array(x_h, name='x')
-        b = b_h.copy(name='b') if isinstance(b_h, self.dndarray) else self.copy_array(b_h, name='b')
-        Ap = x.copy()
+        The contract is the reference's (indigo/backends/backend.py:639-689: same start, same stopping rule, one operator
+        evaluation per iteration, the two reductions through pdot / pnorm2 so that a `team` all-reduces them).  b_h / x_h may be
+        device arrays of this backend: x is then updated in place and only the two scalars per iteration cross the host boundary.
+        (HipBackend.cg overrides this with device-resident scalars and three fused vector passes per iteration.)"""
+        in_place = isinstance(x_h, self.dndarray)
+        x = x_h if in_place else self.copy_array(x_h, name='x')
+        resid = b_h.copy(name='b') if isinstance(b_h, self.dndarray) else self.copy_array(b_h, name='b')
+        q = x.copy()                                   # q = (A + lamda I) d for the current direction d
 
-        r = b
-        A.eval(Ap, x)
-        self.axpby(1, r, -1, Ap)
-        self.axpby(1, r, -lamda, x)
+        def shifted(dst, src):
+            A.eval(dst, src)
+            if lamda:
+                self.axpby(1, dst, lamda, src)
 
-        p = r.copy(name='p')
-        rr = self.pnorm2(r, team)
-        r0 = rr
-        history = []
+        shifted(q, x)
+        self.axpby(1, resid, -1, q)                    # resid = b - (A + lamda I) x
+        d = resid.copy(name='p')
+        rho = rho0 = self.pnorm2(resid, team)
+        trail = []
         for it in range(maxiter):
-            A.eval(Ap, p)
-            self.axpby(1, Ap, lamda, p)
-            alpha = rr / self.pdot(p, Ap, team)
-            self.axpby(1, x, alpha, p)
-            self.axpby(1, r, -alpha, Ap)
-            r2 = self.pnorm2(r, team)
-            beta = r2 / rr
-            self.axpby(beta, p, 1, r)          # p = beta*p + r in one pass (the reference scales, then adds)
-            rr = r2
-            resid = float(np.sqrt(rr / r0))
-            history.append(resid)
-            log.info("iter %d, residual %g", it, resid)
-            if resid < tol:
+            shifted(q, d)
+            step = rho / self.pdot(d, q, team)
+            self.axpby(1, x, step, d)
+            self.axpby(1, resid, -step, q)
+            rho, rho_old = self.pnorm2(resid, team), rho
+            self.axpby(rho / rho_old, d, 1, resid)     # d = resid + (rho / rho_old) d in one pass
+            trail.append(float(np.sqrt(rho / rho0)))
+            log.info("iter %d, residual %g", it, trail[-1])
+            if trail[-1] < tol:
                 log.info("cg reached tolerance")
                 break
         else:
             log.info("cg reached maxiter")
-        if not x_dev:
+        if not in_place:
             x.copy_to(x_h)
-        return history
+        return trail
 
     def apgd(self, gradf, proxg, alpha, x_h, maxiter=100, team=None):
-        """Accelerated proximal gradient descent (reference backend.py:691-732)."""
-        x_k = self.copy_array(x_h)
-        y_k = x_k.copy()
-        y_k1 = x_k.copy()
-        x_k1 = x_k.copy()
-        gf = x_k.copy()
-        t_k = 1
-        for it in range(1, maxiter + 1):
-            gradf(gf, y_k)
-            self.axpby(1, x_k, -alpha, gf)
-            proxg(x_k, alpha)
-            t_k1 = (1.0 + np.sqrt(1.0 + 4.0 * t_k ** 2)) / 2.0
-            t_ratio = (t_k - 1) / t_k1
-            self.axpby(0, y_k1, 1 + t_ratio, x_k)
-            self.axpby(1, y_k1, -t_ratio, x_k1)
-            x_k1.copy(x_k)
-            y_k.copy(y_k1)
-        x_k.copy_to(x_h)
+        """Proximal gradient iteration for min f + g:  x <- prox_g(x - alpha grad f(y)),  y <- x + m (x - x_before).
+
+        The reference (indigo/backends/backend.py:691-732) writes the accelerated (FISTA) momentum m = (t_k - 1) / t_{k+1} but never
+        advances t_k from 1, so its m is 0 in every iteration and its iterates are those of the plain proximal gradient method --
+        which the golden vectors captured from it pin (tests/golden/leaf_misc.npz).  `momentum` below is that sequence; the loop
+        itself is written for any m.  The gradient step starts from x, not from y, as in the reference."""
+        def momentum(k):
+            t = 1.0                                    # (the reference's t_k: constant)
+            return (t - 1.0) / (0.5 * (1.0 + np.sqrt(1.0 + 4.0 * t * t)))
+
+        x = self.copy_array(x_h)
+        y, x_before, g = x.copy(), x.copy(), x.copy()
+        for k in range(maxiter):
+            gradf(g, y)
+            self.axpby(1, x, -alpha, g)
+            proxg(x, alpha)
+            m = momentum(k)
+            self.axpby(0, y, 1 + m, x)
+            if m:
+                self.axpby(1, y, -m, x_before)
+            x_before.copy(x)
+        x.copy_to(x_h)

@@ -218,26 +218,38 @@ class HipBackend(Backend):
             fit are simply not tried; the losers are freed before this returns."""
             b = self._backend
             cands = []
-            for _ in range(ncand):
-                ptr = ctypes.c_void_p()
-                rc = b._L.ig_malloc(b._ctx, self.nbytes, ctypes.byref(ptr))
-                if rc != 0:
-                    if not cands:
-                        b._check(rc, "ig_malloc(%d bytes)" % self.nbytes)
-                    break
-                ms = ctypes.c_double(0.0)
-                b._check(b._L.ig_probe_placement(b._ctx, ptr, self.nbytes, ctypes.byref(ms)), "ig_probe_placement")
-                cands.append((ms.value, ptr.value))
-            if len(cands) > 1:
-                # the first candidate may have been timed while the clocks were still coming up (the probe is often the first work of a
-                # process): time it once more, now behind the others, and keep its better figure
-                ms = ctypes.c_double(0.0)
-                b._check(b._L.ig_probe_placement(b._ctx, ctypes.c_void_p(cands[0][1]), self.nbytes, ctypes.byref(ms)), "ig_probe_placement")
-                cands[0] = (min(cands[0][0], ms.value), cands[0][1])
-            best = max(cands) if b.tuning.get('placement_pick') == 'worst' else min(cands)       # ('worst': lab, to see what the probe's spread is worth)
-            for ms, ptr in cands:
-                if ptr != best[1]:
-                    b._L.ig_free(b._ctx, ctypes.c_void_p(ptr))
+            keep = None
+            try:
+                for _ in range(ncand):
+                    if cands:
+                        # a further candidate only while the device has room for it AND as much again: another process on the same
+                        # GPU (ranks sharing a device in a rehearsal, another tenant) must not fail because of transient candidates
+                        free, total = ctypes.c_size_t(), ctypes.c_size_t()
+                        if b._L.ig_mem_info(b._ctx, ctypes.byref(free), ctypes.byref(total)) != 0 or free.value < 2 * self.nbytes:
+                            break
+                    ptr = ctypes.c_void_p()
+                    rc = b._L.ig_malloc(b._ctx, self.nbytes, ctypes.byref(ptr))
+                    if rc != 0:
+                        if not cands:
+                            b._check(rc, "ig_malloc(%d bytes)" % self.nbytes)
+                        break
+                    cands.append([None, ptr.value])
+                    ms = ctypes.c_double(0.0)
+                    b._check(b._L.ig_probe_placement(b._ctx, ptr, self.nbytes, ctypes.byref(ms)), "ig_probe_placement")
+                    cands[-1][0] = ms.value
+                if len(cands) > 1:
+                    # the first candidate may have been timed while the clocks were still coming up (the probe is often the first work of
+                    # a process): time it once more, now behind the others, and keep its better figure
+                    ms = ctypes.c_double(0.0)
+                    b._check(b._L.ig_probe_placement(b._ctx, ctypes.c_void_p(cands[0][1]), self.nbytes, ctypes.byref(ms)), "ig_probe_placement")
+                    cands[0][0] = min(cands[0][0], ms.value)
+                best = max(cands) if b.tuning.get('placement_pick') == 'worst' else min(cands)       # ('worst': lab, to see what the probe's spread is worth)
+                keep = best[1]
+            finally:
+                # the losers -- all candidates if a probe failed -- are freed whatever happened
+                for _, ptr in cands:
+                    if ptr != keep:
+                        b._L.ig_free(b._ctx, ctypes.c_void_p(ptr))
             b._placement_log.append((self.nbytes, [round(ms, 4) for ms, _ in cands], round(best[0], 4)))
             log.debug("placement: %d bytes, candidates %s ms -> %.4f", self.nbytes, [round(ms, 4) for ms, _ in cands], best[0])
             return best[1]
@@ -463,7 +475,7 @@ class HipBackend(Backend):
         # per iteration shrink from the host's launch path to the device's own.  Needs the scratch arena (the evaluation's
         # temporaries must sit where they sat when recorded); anything that cannot be recorded falls back to plain launches.
         graph = None
-        use_graph = (self.tuning.get('cg_graph', True) and getattr(self, '_scratch', None) is not None and every % 2 == 0
+        use_graph = (self.tuning.get('cg_graph', False) and getattr(self, '_scratch', None) is not None and every % 2 == 0
                      and maxiter >= 3 * every and getattr(self, 'trace', None) is None and not getattr(self, '_prof_on', False))
         try:
             while it < maxiter and not done:
@@ -805,6 +817,19 @@ class HipBackend(Backend):
             return None
         indptr, indices, data = interp_csr_modulated(s.npts, s.N, s.width, s.table, s.coord, sep[0].phases, sep[1], grid_order=grid_order)
         return spp.csr_matrix((data, indices, indptr), shape=shape)
+
+    def gridding_sep_from_struct(self, s, grid_order=0):
+        """the same G' in SEPARABLE form -- one record per sample (indigo_amd.interp.interp_sep_records) -- or None when the column
+        scaling is no sign per axis times a real constant (an odd grid axis) or the kernel is wider than 8 taps"""
+        from indigo_amd.interp import interp_sep_records
+        if not self.tuning.get('separable', True):
+            return None
+        if s.colscale is None:
+            return interp_sep_records(s.npts, s.N, s.width, s.table, s.coord, None, 1.0, grid_order=grid_order)
+        sep = s.colscale.separable()
+        if sep is None or tuple(sep[0].shape) != tuple(s.N):
+            return None
+        return interp_sep_records(s.npts, s.N, s.width, s.table, s.coord, sep[0].phases, sep[1], grid_order=grid_order)
 
     def inspect(self, csr):
         indptr = np.ascontiguousarray(csr.indptr, dtype=np.int32)

@@ -251,26 +251,29 @@ k_probe_placement(float4* __restrict__ p, size_t pitch16 /* row pitch in float4 
 
 int ig_probe_placement(ig_ctx* ctx, void* dptr, size_t nbytes, double* ms) {
     IG_REQUIRE(ctx, ctx && ms, "ig_probe_placement: bad arguments");
+    IG_REQUIRE(ctx, !ctx->capturing, "ig_probe_placement: not while a graph is being recorded (the probe synchronises the stream)");
     *ms = 0.0;
     const size_t pitch = (nbytes / 512) & ~(size_t)4095;
     if (!dptr || pitch == 0) return IG_OK;                     // too small to have such a pattern
     if (int rc = ig_set_device(ctx)) return rc;
-    hipEvent_t e0, e1;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
     IG_HIP(ctx, hipEventCreate(&e0));
-    IG_HIP(ctx, hipEventCreate(&e1));
+    hipError_t err = hipEventCreate(&e1);
     float best = 1e30f;
-    for (int rep = 0; rep < 4; ++rep) {
-        IG_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    for (int rep = 0; rep < 4 && err == hipSuccess; ++rep) {
+        err = hipEventRecord(e0, ctx->stream);
+        if (err != hipSuccess) break;
         hipLaunchKernelGGL(k_probe_placement, dim3((unsigned)(pitch / 256)), dim3(512), 0, ctx->stream, (float4*)dptr, pitch / 16);
-        IG_HIP(ctx, hipEventRecord(e1, ctx->stream));
-        IG_HIP(ctx, hipEventSynchronize(e1));
+        if ((err = hipGetLastError()) != hipSuccess) break;                                 // (the launch itself, checked on the spot)
+        if ((err = hipEventRecord(e1, ctx->stream)) != hipSuccess) break;
+        if ((err = hipEventSynchronize(e1)) != hipSuccess) break;
         float t = 0.f;
-        IG_HIP(ctx, hipEventElapsedTime(&t, e0, e1));
+        if ((err = hipEventElapsedTime(&t, e0, e1)) != hipSuccess) break;
         if (rep && t < best) best = t;
     }
-    IG_HIP(ctx, hipEventDestroy(e0));
-    IG_HIP(ctx, hipEventDestroy(e1));
-    IG_LAUNCH_CHECK(ctx, "k_probe_placement");
+    (void)hipEventDestroy(e0);                                 // (on every path: the events do not outlive the call)
+    if (e1) (void)hipEventDestroy(e1);
+    if (err != hipSuccess) return ig_fail(ctx, IG_ERR_HIP, "ig_probe_placement: %s", hipGetErrorString(err));
     *ms = best;
     return IG_OK;
 }

@@ -1736,7 +1736,7 @@ int ig_fft_plan_padded(ig_ctx* ctx, const int64_t* dims, const int64_t* box_lo, 
     ig_fft* p = *plan;
     for (int a = 0; a < 3; ++a) {
         // chirp-z axes (a prime factor above 7: 277, 410 ...) take the unweighted strided passes, i.e. the y and z axes of the
-        // coil-interleaved layout; no k-space support table on such a grid
+        // coil-interleaved layout (round 5: with the k-space support table -- hulls, and bitmaps of B words per entry on a chirp-z z axis)
         const bool cz_ok = p->axis[a].kind == 5 && p->axis[a].chirp->sub.kind == 4 && a >= 1 && grid_layout == 2 && batch >= 2;
         if (cz_ok) p->axis[a].chirp->fused = true;
         const bool ab_ok = (p->axis[a].kind == 4 && abd_supported(dims[a]) && grid_layout == 2 && batch >= 2) || cz_ok;
@@ -1745,8 +1745,9 @@ int ig_fft_plan_padded(ig_ctx* ctx, const int64_t* dims, const int64_t* box_lo, 
             *plan = nullptr;
             return ig_fail(ctx, IG_ERR_UNSUPPORTED,
                            "ig_fft_plan_padded: grid axis %d has length %lld; the padded path needs 256 or 512 -- or, with 2, 4, 8 or 16 "
-                           "coil-interleaved batch members (grid_layout 2), any length from 128 to 640 with factors 2, 3, 5, 7 only that "
-                           "splits as A x B with A, B <= 32", a, (long long)dims[a]);
+                           "coil-interleaved batch members (grid_layout 2: a chunk of any coil count padded to such a width, indigo_amd.fused.plan_chunks), "
+                           "any length from 128 to 640 with factors 2, 3, 5, 7 only that splits as A x B with A, B <= 32, or on the y / z axes a length "
+                           "with a larger prime factor (chirp-z)", a, (long long)dims[a]);
         }
         if (ab_ok) p->has_ab_axis = true;
         // (a chirp-z z axis: its threads hold rows b + B a of the length-m transform on both sides -- B words per entry either way)

@@ -138,15 +138,21 @@ def pow2_divisor(n, cap):
 CHUNK_COST = {16: 13.0, 8: 6.6, 4: 3.9, 2: 2.45, 1: 1.7}
 
 
-def plan_chunks(Cn, chunk=8, single_ok=True):
+def plan_chunks(Cn, chunk=8, single_ok=True, cost=None, pad=True):
     """Cut Cn coils into chunks the coil-interleaved kernels take: [(lo, hi, width)], width in {16, 8, 4, 2} (<= chunk) coils
     interleaved below the grid -- of which hi - lo are real and the rest, if any, zero-weight padding -- or width 1: one coil
     in the per-coil layout (only where the backend has those kernels for the grid: `single_ok`).  The cheapest cover by
-    CHUNK_COST; every chunk of every coil count reaches the binned adjoint gridding and the fused transform leaf."""
+    `cost` (default CHUNK_COST: measured on the headline problem on one MI355X; backend.tuning['chunk_cost'] overrides it for other
+    grids / devices); every chunk of every coil count reaches the binned adjoint gridding and the fused transform leaf.
+    pad=False (backend.tuning['chunk_pad']): no chunk may carry zero-weight padding coils -- a padded chunk allocates up to a third
+    more grid and scratch than its real coils need (7 coils then run as 4 + 2 + 1 instead of one 8-wide chunk)."""
+    cost = dict(CHUNK_COST, **(cost or {}))
     widths = [w for w in (16, 8, 4, 2) if w <= max(int(chunk), 2)] + ([1] if single_ok else [])
     best = [(0.0, [])]
     for c in range(1, int(Cn) + 1):
-        cand = [(best[max(c - w, 0)][0] + CHUNK_COST[w], best[max(c - w, 0)][1] + [w]) for w in widths]
+        cand = [(best[max(c - w, 0)][0] + cost[w], best[max(c - w, 0)][1] + [w]) for w in widths if pad or w <= c]
+        if not cand:          # (no padding allowed and nothing fits: a single coil without the per-coil kernels -- pad after all)
+            cand = [(best[max(c - w, 0)][0] + cost[w], best[max(c - w, 0)][1] + [w]) for w in widths]
         best.append(min(cand, key=lambda t: (round(t[0], 6), len(t[1]))))
     out, lo = [], 0
     for w in sorted(best[int(Cn)][1], reverse=True):
@@ -161,12 +167,12 @@ def coil_chunks(Cn, chunk=8):
     return [(lo, hi) for lo, hi, _ in plan_chunks(Cn, chunk)]
 
 
-def choose_layout(Cn, chunk=8, layout=None, single_ok=True):
+def choose_layout(Cn, chunk=8, layout=None, single_ok=True, cost=None, pad=True):
     """(layout, chunks) for Cn coils on one rank: chunks = [(lo, hi, width)] (plan_chunks); layout 2 when any chunk is
     coil-interleaved.  An explicit per-coil layout (0 or 1) keeps all coils in one chunk."""
     if layout in (0, 1):
         return layout, [(0, int(Cn), 0)]                  # width 0: per-coil layout, any coil count
-    chunks = plan_chunks(Cn, chunk, single_ok)
+    chunks = plan_chunks(Cn, chunk, single_ok, cost, pad)
     return (2 if any(w > 1 for _, _, w in chunks) else 1), chunks
 
 

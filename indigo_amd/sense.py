@@ -259,6 +259,11 @@ class SenseProblem(object):
             # slot-format scatter (1- and 2-coil ranks): 16 bytes per nonzero (cell, value, sample), the panel, the flagged rows
             "csrmm_slots_conj": nnz * (12 if real_entries else 16) + T * e + sup * e,
             "pack_panel": 2 * T * e,
+            # round 6, taps computed from the separable records: a 64-byte record per sample instead of the stored taps; the scatter
+            # of (sample, brick) shares reads record + panel row once per share (its 8-byte header beside them) -- the shares
+            # themselves are the format's choice, so the compulsory figure prices one per sample
+            "grid_gather_sep": T * 64 + touched * e + T * e,
+            "grid_scatter_sep": T * (64 + 8) + T * e + sup * e,
         }
 
     @staticmethod
@@ -284,7 +289,8 @@ class SenseProblem(object):
         coils = list(range(self.C) if coils is None else coils)
         Cn = len(coils)
         single_ok = getattr(backend, 'supports_single_coil_layout', lambda g: True)(self.oN)
-        layout, chunks = fused.choose_layout(Cn, chunk, layout, single_ok)
+        tuning = getattr(backend, 'tuning', {})
+        layout, chunks = fused.choose_layout(Cn, chunk, layout, single_ok, tuning.get('chunk_cost'), tuning.get('chunk_pad', True))
         Gm = self.fused_interp(1 if layout == 2 else layout)      # layout 2 = layout 1 with the coils interleaved below
         table = None
         zw = fused.support_words(backend, self.oN)      # words per entry of the table's bitmaps: follows from the z pass's kernel

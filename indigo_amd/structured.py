@@ -7,9 +7,12 @@ The reference builds every factor as a scipy matrix (`Backend.Diag/Zpad/Interp`,
 multiplies them with scipy.  At BASELINE config 4 that is 35 s of host time in front of a 6.6 ms evaluation.  Here a
 factory attaches one of the descriptions below to the `SpMatrix` it returns (the scipy matrix itself is made only when
 somebody asks for `SpMatrix._matrix`); `RealizeMatrices` composes descriptions where it knows how and falls back to scipy
-everywhere else.  A composed description materialises to the same CSR the scipy route produces -- the same entries in
-the same complex64 arithmetic (each product rounds once, as scipy's does) -- `tests/test_sense_cpu.py` holds the two
-routes against each other.
+everywhere else.  A composed description materialises to the CSR the scipy route produces up to float32 rounding: the
+same entries, each product rounded once like scipy's -- but numpy's and scipy's complex multiplies may contract their
+multiply-adds differently, so single values can differ by one ulp (`tests/test_sense_cpu.py` holds the two routes against
+each other at that tolerance).  SelectS / StackS also keep explicit zeros (maps that vanish outside the body) where scipy's
+sparse products prune them: the structural nnz -- and what `_mem_usage` and the byte models derive from it -- can exceed the
+scipy route's.
 
     DiagS     n x n diagonal: a product of factors, each a dense vector, a separable phase table or a constant
     SelectS   m x n with at most one entry per row: (rows, cols, vals) -- zero-pad, crop, a stack of diagonals, Kron(I, .)

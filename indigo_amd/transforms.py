@@ -332,7 +332,9 @@ class FuseZpadFFT(Transform):
             log.warning("FuseZpadFFT: %s is not a zero-pad * diagonal factor; the tree keeps the unfused -O3 leaves (S' csrmm + dense FFT)", X._name)
             return node
         lo, box, w = dec
-        layout, chunks = fused.choose_layout(C, self.chunk, None, getattr(b, 'supports_single_coil_layout', lambda g: True)(grid))
+        tuning = getattr(b, 'tuning', {})
+        layout, chunks = fused.choose_layout(C, self.chunk, None, getattr(b, 'supports_single_coil_layout', lambda g: True)(grid),
+                                             tuning.get('chunk_cost'), tuning.get('chunk_pad', True))
         # G' = interp * mod * scale: where the factories' description survived the recipe and the backend has a native builder, the
         # matrix is built directly in the leaf's grid order (ig_interp3_fill_modulated); else from the scipy product, renumbered
         gs = _struct(L.right)
@@ -343,8 +345,11 @@ class FuseZpadFFT(Transform):
                 Gm = fused.permute_grid_columns(Gm, grid)
         zw = fused.support_words(b, grid)
         table = fused.grid_support(Gm, grid, 16, zw) if (layout >= 1 and zw is not None and (layout == 2 or zw == (16, 16))) else None
+        # ... and the same matrix as one record per sample, where its modulation is a sign per axis (even grids): the interleaved
+        # products then compute their taps (indigo_amd.interp.interp_sep_records)
+        sep = b.gridding_sep_from_struct(gs, 1) if (layout == 2 and isinstance(gs, InterpS) and hasattr(b, 'gridding_sep_from_struct')) else None
         A = fused.assemble(b, Gm, grid, box, lambda c0, c1: w[..., c0:c1], C, layout, chunks, table=table, box_lo=lo,
-                           name=node._name, zw=zw or (16, 16))
+                           name=node._name, zw=zw or (16, 16), sep=sep)
         A._fused_layout = layout
         return A
 

@@ -32,7 +32,7 @@ def _problem(N, osf, width, nspokes, seed=4, edge=False):
 
 @pytest.mark.parametrize("NC", [8, 4, 2])
 @pytest.mark.parametrize("N,osf,width,edge", [((32, 32, 32), 2.0, 2, False), ((32, 32, 32), 2.0, 2, True), ((24, 32, 40), 2.0, 3, True),
-                                              ((32, 32, 32), 1.5, 2, True), ((32, 16, 24), 2.0, 2.5, True)])
+                                              ((32, 32, 32), 1.5, 2, True), ((32, 16, 24), 2.0, 2.5, True), ((16, 13, 16), 2.0, 2, True)])
 def test_forward_gridding_from_separable_records(hip, monkeypatch, NC, N, osf, width, edge):
     """Y = alpha G' X + beta Y over a coil-interleaved grid panel: taps computed from the records (ig_grid_gather_sep) against scipy in
     complex128 on the stored matrix, and against the stored-tap gather of the same backend"""
@@ -68,7 +68,8 @@ def _expected_adjoint(G, X, alpha):
                                                     ((24, 32, 40), 2.0, 3, True, (8, 2)), ((32, 16, 24), 2.0, 2.5, True, (2, 8)),
                                                     ((16, 16, 16), 2.0, 2, True, (16, 1)), ((24, 32, 40), 2.0, 3, True, (4, 4)),
                                                     ((32, 16, 24), 2.0, 2.5, True, (2, 4)), ((32, 32, 32), 2.0, 2, True, (4, 2)),
-                                                    ((16, 16, 16), 2.0, 4, True, (4, 4)), ((32, 32, 32), 2.0, 2, True, (1, 1))])
+                                                    ((16, 16, 16), 2.0, 4, True, (4, 4)), ((32, 32, 32), 2.0, 2, True, (1, 1)),
+                                                    ((16, 13, 16), 2.0, 2, True, (4, 2))])          # (a 26-point axis: the modulation's constant is -+i)
 def test_adjoint_gridding_from_shares(hip, monkeypatch, NC, N, osf, width, edge, shape):
     """Y_il = alpha G'^H X as the scatter of (sample, brick) shares with computed taps (ig_grid_scatter_sep), no support table: every
     grid row is defined.  Heavy bricks cut into shared pieces (atomics) and runs of light bricks both occur (small chunk / run).
