@@ -172,8 +172,9 @@ def parse():
     ap.add_argument("--layout", type=int, default=-1, help="grid layout of the fused tree: 1 = (x,z,y) per coil, 2 = coils interleaved "
                     "(default: 2 when this rank holds 2, 4, 8 or more coils, else 1)")
     ap.add_argument("--shard", default="", help="R/W: time rank R's coils of a W-rank run on this one GPU, no communication")
-    ap.add_argument("--comm", choices=["auto", "rccl", "torch"], default="auto",
-                    help="all-reduce provider for N > 1: the library's own RCCL binding (ig_comm_*), or torch.distributed")
+    ap.add_argument("--comm", choices=["auto", "rccl", "torch", "direct"], default="auto",
+                    help="all-reduce provider for N > 1: the library's own RCCL binding (ig_comm_*), torch.distributed, or direct: the "
+                         "library's own reduce-scatter + all-gather over HIP IPC windows (no RCCL; every rank talks to all peers at once)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--parity", action="store_true", help="configs 4 / 5 with --no-cpu-baseline: still check the benchmarked operator against the "
                     "float64 evaluation of a one-coil operator (oracle/precise.py)")
@@ -347,6 +348,10 @@ def make_comm(args, B, world, rank, local_rank):
     if world == 1:
         return None
     from indigo_amd import dist as igdist
+    if args.comm == "direct":
+        c = igdist.DirectComm(B, rank, world)
+        log("communicator: %s" % c.describe())
+        return c
     if args.comm in ("auto", "rccl") and os.environ.get("INDIGO_BENCH_DIST_BACKEND", "nccl") == "nccl":
         # (RcclComm raises on ALL ranks together or on none: what can fail on one rank alone -- loading RCCL -- is voted on in
         # the id handshake before anyone enters ncclCommInitRank, and the handshake itself times out everywhere at once; so
@@ -1092,7 +1097,7 @@ def main():
         faulthandler.dump_traceback_later(wd, exit=True, file=sys.stderr)
     # (--shard R/W times one rank's share in this ONE process, whatever --gpus says the full run would use)
     assert world == args.gpus or (args.shard and world == 1), "--gpus %d but WORLD_SIZE is %d" % (args.gpus, world)
-    if world > 1 and args.comm != "rccl":
+    if world > 1 and args.comm in ("auto", "torch"):
         # The collective is the library's own RCCL binding (ig_comm_*).  Under `--comm auto` torch is imported FIRST --
         # before libindigo_hip.so loads -- only so that the fallback to torch.distributed stays possible: torch ships its own
         # HIP runtime and RCCL, and whichever copy is loaded first must serve both (the library then reuses torch's copies).

@@ -591,6 +591,16 @@ int  ig_fft_destroy(ig_fft* plan);
 int  ig_comm_preflight(void);
 int  ig_comm_unique_id(void* id_out /* IG_COMM_ID_BYTES, host */);
 int  ig_comm_init_rank(ig_ctx* ctx, int nranks, int rank, const void* id, ig_comm** out);   /* collective */
+/* The DIRECT communicator (round 6; no RCCL): the ranks of ONE node (one process per GPU) each expose a window of device memory to
+ * the others through hipIpcGetMemHandle / hipIpcOpenMemHandle, and ig_allreduce_sum_f32 becomes a reduce-scatter + all-gather over
+ * peer-mapped memory: every rank sums ITS 1 / nranks slab of all windows (rank order: the same bits everywhere) and writes it back
+ * into all of them -- its traffic runs over all of the GPU's xGMI links at once, where a ring all-reduce is bound by one.
+ * `name`: a POSIX shared-memory name ("/...") the ranks agree on, unique to the communicator -- it carries the IPC handles, a barrier
+ * and the host scalars (ig_allreduce_max_f64_host / _sum_ / ig_comm_barrier work on it); window_bytes: a multiple of 4096, messages
+ * larger than the window go in pieces.  Collective; every rank fails within timeout_s if one never arrives.  The all-reduce of such
+ * a communicator is HOST-synchronous (stream sync + shared-memory barrier between its phases: no kernel ever spins on a flag another
+ * process must set); ig_allreduce_sum_f32_side equals ig_allreduce_sum_f32.  At most 16 ranks.                                   */
+int  ig_comm_init_direct(ig_ctx* ctx, int nranks, int rank, const char* name, size_t window_bytes, double timeout_s, ig_comm** out);
 int  ig_comm_info(ig_comm* comm, int* rank, int* nranks, char* rccl_lib, size_t len);
 /* in-place sum over the ranks of nfloats float32 (an image of N complex64 is 2N floats), in order with the context's
  * stream like every other call -- no host synchronisation.  (All collectives of a communicator run on the communicator's

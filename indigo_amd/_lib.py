@@ -146,6 +146,7 @@ PROTOTYPES = {
     "ig_comm_preflight":  (c_int, []),
     "ig_comm_unique_id":  (c_int, [c_void_p]),
     "ig_comm_init_rank":  (c_int, [c_void_p, c_int, c_int, c_void_p, POINTER(c_void_p)]),
+    "ig_comm_init_direct": (c_int, [c_void_p, c_int, c_int, c_char_p, c_size_t, c_double, POINTER(c_void_p)]),
     "ig_comm_info":       (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), c_char_p, c_size_t]),
     "ig_allreduce_sum_f32": (c_int, [c_void_p, c_void_p, c_int64]),
     "ig_allreduce_sum_f32_side": (c_int, [c_void_p, c_void_p, c_int64]),

@@ -272,6 +272,37 @@ class RcclComm(object):
             pass
 
 
+class DirectComm(RcclComm):
+    """The library's own all-reduce route, no RCCL (ig_comm_init_direct): every rank exposes a window of device memory to the other
+    ranks of the node through HIP IPC and reduces its 1 / world slab of all windows -- a direct reduce-scatter + all-gather over all
+    xGMI links where RCCL may pick a ring.  Same interface as RcclComm (the C ABI routes ig_allreduce_* by the communicator's kind);
+    host-synchronous, so the slab overlap is off.  The ranks agree on the shared-memory name through the same file rendezvous as
+    the RCCL id (a random 16-byte token of rank 0)."""
+
+    def __init__(self, backend, rank, world, timeout=60.0, window_bytes=256 << 20, name=None):
+        self._backend, self.rank, self.world = backend, int(rank), int(world)
+        self._L = backend._L
+        self.overlap = False
+        self._pending = False
+        path = (_rendezvous_path() + ".direct") if (world > 1 and name is None) else None
+        if name is None:
+            raw, _ = exchange_id(self.rank, self.world, lambda: os.urandom(16), path, 16, timeout, ready=True) if world > 1 else (os.urandom(16), True)
+            name = "/indigo_direct_" + raw.hex()
+        comm = ctypes.c_void_p()
+        try:
+            backend._check(self._L.ig_comm_init_direct(backend._ctx, self.world, self.rank, name.encode(), int(window_bytes) // 4096 * 4096,
+                                                       float(timeout), ctypes.byref(comm)), "ig_comm_init_direct")
+            self._comm = comm
+        finally:
+            if path:
+                cleanup_rendezvous(self.rank, self.world, path, timeout=10.0 if getattr(self, '_comm', None) else 0.0)
+
+    def describe(self):
+        buf = ctypes.create_string_buffer(256)
+        self._L.ig_comm_info(self._comm, None, None, buf, 256)
+        return "ig_comm (C ABI), %s, %d ranks, host-synchronous" % (buf.value.decode(), self.world)
+
+
 class TorchComm(object):
     """Sum all-reduce of a backend array across the default torch.distributed process group."""
     overlap = False

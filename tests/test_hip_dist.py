@@ -267,3 +267,85 @@ def test_two_rccl_ranks_against_the_unsharded_operator(tmp_path):
             pytest.fail("two-rank RCCL workers timed out")
         outs.append(o)
     assert all(p.returncode == 0 and "OK rank" in o for p, o in zip(procs, outs)), "\n".join(o[-3000:] for o in outs)
+
+
+DIRECT_WORKER = r"""
+import os, sys, hashlib
+sys.path.insert(0, os.environ["REPO_ROOT"])
+import numpy as np
+from indigo_amd.backends import get_backend
+from indigo_amd.dist import DirectComm, ShardedNormalOperator, coil_range
+from indigo_amd.sense import SenseProblem, normal_operator
+from indigo_amd.util import rand64c
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+B = get_backend("hip", device_id=0)                  # every rank on the ONE GPU of the box: IPC works across processes on a shared device
+comm = DirectComm(B, rank, world, name=os.environ["DIRECT_NAME"], window_bytes=int(os.environ["DIRECT_WINDOW"]), timeout=120.0)
+assert "direct" in comm.describe()
+digests = []
+for n in (100003, 1 << 20, 5):                       # a ragged length, one larger than the window (pieces), one shorter than the rank count's slabs
+    xs = [rand64c(n, seed=10 * n % 9973 + r) for r in range(world)]
+    d = B.copy_array(xs[rank])
+    B.scale(d, 2.0)                                  # queued on the backend's stream: the collective must see it ...
+    comm.allreduce_(d)
+    got = d.to_host()
+    digests.append(hashlib.sha256(got.tobytes()).hexdigest()[:16])
+    B.axpby(1, d, 1, B.copy_array(xs[rank]))         # ... and later work its result
+    exp = 2.0 * np.sum(np.stack(xs).astype(np.complex128), axis=0)
+    assert np.linalg.norm(got - exp) <= 1e-6 * np.linalg.norm(exp), (n, np.linalg.norm(got - exp) / np.linalg.norm(exp))
+    # the sum in rank order, float32: bit for bit what numpy gives in that order
+    ref = np.zeros(n, np.complex64)
+    for x in xs:
+        ref = (ref + (2.0 * x).astype(np.complex64)).astype(np.complex64)
+    assert np.array_equal(got.view(np.float32), ref.view(np.float32)), n
+    assert np.linalg.norm(d.to_host() - (exp + xs[rank])) <= 1e-6 * np.linalg.norm(exp)
+assert comm.max(float(rank)) == world - 1 and comm.allreduce(float(rank + 1)) == world * (world + 1) / 2
+comm.barrier()
+# the coil-sharded normal operator against the unsharded one
+p = SenseProblem.synthetic((64, 64, 64), 4 * world, nspokes=100, nreadout=128, width=2, oversamp=2.0, seed=5)
+c64 = np.dtype("complex64")
+xs = B.copy_array(rand64c(int(np.prod(p.N)), 1, seed=2))
+A = p.build_zpadfft(B, coils=coil_range(4 * world, rank, world))
+y = B.zero_array((A.shape[1], 1), c64)
+op = ShardedNormalOperator(A, comm, lamda=0.1)
+op.eval(y, xs)
+op.eval(y, xs)
+got = y.to_host()
+B._scratch = None
+del A, op
+Afull = p.build_zpadfft(B)
+y2 = B.zero_array((Afull.shape[1], 1), c64)
+normal_operator(Afull, lamda=0.1).eval(y2, xs)
+ref = y2.to_host()
+err = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+assert err < 1e-5, err
+comm.barrier()
+comm.close()
+print("OK rank", rank, "digests", " ".join(digests), "err %.2e" % err)
+"""
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_direct_allreduce_over_ipc_windows_on_one_gpu(world):
+    """The library's own all-reduce route (ig_comm_init_direct: reduce-scatter + all-gather over peer-mapped IPC windows, no RCCL),
+    rehearsed with `world` processes on the ONE GPU of the box -- protocol, piece-wise messages, bit-exactness (every rank holds the
+    same bits: the float32 sum in rank order), stream ordering, host scalars, and the coil-sharded normal operator against the
+    unsharded one.  What this cannot show is bandwidth over xGMI: that needs the GPUs of a node."""
+    name = "/indigo_direct_test_%d_%d" % (os.getpid(), world)
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, REPO_ROOT=ROOT, RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0", DIRECT_NAME=name,
+                   DIRECT_WINDOW=str(4 << 20))
+        env.pop("INDIGO_HIP_WITH_TORCH", None)
+        procs.append(subprocess.Popen([sys.executable, "-c", DIRECT_WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("direct all-reduce workers timed out")
+        outs.append(o)
+    assert all(p.returncode == 0 and "OK rank" in o for p, o in zip(procs, outs)), "\n".join(o[-3000:] for o in outs)
+    digests = {o.split("digests", 1)[1].split("err")[0].strip() for o in outs}
+    assert len(digests) == 1, digests          # every rank holds the same bits
