@@ -921,6 +921,28 @@ def bench_spmm(args, local_rank, B=None):
             ts.append(time.perf_counter() - t1)
         cpu = dict(value=1.0 / (min(ts[1:]) * ncol / 8.0), unit="products/s", cores=1, kind="port", **host_info(),
                    sample="scipy csr @ dense (np.py:120-127) on 8 of the %d columns, warm-up + min of 5 (%.2f s), scaled" % (ncol, min(ts[1:])))
+    # What this product can reach THROUGH the reference's boundary (column-major panels): the model prices every touched panel row once,
+    # but a column-major panel is read in 128-byte lines of ONE column -- 16 rows -- and a gather of `ncol` columns a whole panel apart
+    # needs the transposition: read the lines that hold a touched row, write the touched rows packed, read them packed, the matrix,
+    # the result; all at the rate the memory system moves such a pattern without any arithmetic (tools/stride_probe.hip,
+    # profiles/r05_stride_probe.txt: 5.4 - 5.6 TB/s).  The adjoint: the k-space panel packed (read, write, read), every row of the
+    # result written once (beta = 0 defines it), the matrix with 8-byte entries.
+    PROBE_GBS = 5500.0
+    touched = np.zeros(P, dtype=bool)
+    touched[G.indices] = True
+    n_touched = int(touched.sum())
+    n_lines16 = int(np.count_nonzero(touched.reshape(-1, 16).any(axis=1))) * 16 if P % 16 == 0 else P
+    e = 8.0 * ncol
+    floor_fwd = n_lines16 * e + 2.0 * n_touched * e + (G.nnz * 12.0 + (T + 1) * 4.0) + T * e
+    floor_adj = 3.0 * T * e + P * e + G.nnz * 8.0
+    floor = dict(bytes=floor_fwd, ms=floor_fwd / PROBE_GBS / 1e6, frac_by_model=fb / (floor_fwd / PROBE_GBS / 1e6 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                 rate_GBps=PROBE_GBS,
+                 derivation="lines of 16 panel rows that hold a touched row x %d columns (%.2f GB) + the touched rows written and read packed "
+                            "(2 x %.2f GB) + matrix (%.2f GB) + result (%.2f GB), at the stride probe's %.1f TB/s" % (
+                                ncol, n_lines16 * e / 1e9, n_touched * e / 1e9, (G.nnz * 12.0 + (T + 1) * 4.0) / 1e9, T * e / 1e9, PROBE_GBS / 1e3),
+                 adjoint=dict(bytes=floor_adj, ms=floor_adj / PROBE_GBS / 1e6, frac_by_model=ab / (floor_adj / PROBE_GBS / 1e6 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              derivation="k-space panel read, written packed, read packed (3 x %.2f GB) + every row of the result written once "
+                                         "(%.2f GB) + 8-byte entries (%.2f GB)" % (T * e / 1e9, P * e / 1e9, G.nnz * 8.0 / 1e9)))
     out = {"metric": "gridding CSR (%d x %d^3, nnz %.2e) x %d-column SpMM products/sec" % (T, n, G.nnz, ncol), "value": args.steps / elapsed,
            "unit": "products/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "complex64 (f32)", "data": "synthetic",
@@ -937,7 +959,8 @@ def bench_spmm(args, local_rank, B=None):
                             bytes_model="SURVEY 8(d) / operators.py:246-256: nnz*12 + (M+1)*4 + K*n*8*col_frac + M*n*8",
                             traffic=traffic, traffic_source=src if traffic else None, traffic_note=traffic_note if traffic else None,
                             traffic_stale=pmc_stale(pmc),
-                            traffic_frac_of_peak=(traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None),
+                            traffic_frac_of_peak=(traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                            floor_ms=floor["ms"], floor=floor),
            "cpu_baseline": cpu, "parity_rel_err": perr,
            "kernels": {"forward": ktab_f, "adjoint": ktab_a}}
     del X, Y, Z, S

@@ -113,7 +113,7 @@ class HipBackend(Backend):
         #   cg_graph      HipBackend.cg replays a block of iterations as one HIP graph launch (ig_graph_*).  Off: measured on the headline
         #                 problem the replay saves 0.03 ms of a 6.89 ms iteration and recording costs 5 ms per solve (profiles/r05_cg_graph_ab.log)
         self._placement_log = []          # (bytes, candidate probe times in ms, chosen) of every array placed by probing
-        self.tuning = dict(placement_candidates=3, placement_min_bytes=1 << 31, cg_graph=False, bricks=(4, 8), slots=(1, 2), slot_shape=(4, 4, 256, 64), support_tile={8: 4, 4: 8}, brick_shape={8: (2, 2, 4096, 4096), 4: (2, 4, 4096, 4096)}, xrows=True, runs=True, wide_bricks=True,
+        self.tuning = dict(placement_candidates=3, placement_min_bytes=1 << 31, placement_window_gb=8, cg_graph=False, bricks=(4, 8), slots=(1, 2), slot_shape=(4, 4, 256, 64), support_tile={8: 4, 4: 8}, brick_shape={8: (2, 2, 4096, 4096), 4: (2, 4, 4096, 4096)}, xrows=True, runs=True, wide_bricks=True,
                            wide_brick_shape=(2, 2), wide_task_shape=(8192, 2048),
                            # round 6: gridding from the separable form of the matrix (one record per sample, taps computed)
                            separable=True, sep_gather=True, sep_scatter=True, sep_mfma=True, shares=(4, 8), shares_min_tw=6, share_shape={8: (4, 4, 1024, 1024), 4: (4, 4, 1024, 1024)})
@@ -204,12 +204,54 @@ class HipBackend(Backend):
 
         def _malloc(self, shape, dtype):
             b = self._backend
-            ncand = int(b.tuning.get('placement_candidates', 1))
-            if ncand > 1 and self.nbytes >= int(b.tuning.get('placement_min_bytes', 1 << 31)):
-                return self._malloc_best_placed(ncand)
+            if self.nbytes >= int(b.tuning.get('placement_min_bytes', 1 << 31)):
+                slack = int(b.tuning.get('placement_window_gb', 0))
+                if slack > 0:
+                    ptr = self._malloc_window(slack)
+                    if ptr is not None:
+                        return ptr
+                ncand = int(b.tuning.get('placement_candidates', 1))
+                if ncand > 1:
+                    return self._malloc_best_placed(ncand)
             ptr = ctypes.c_void_p()
             b._check(b._L.ig_malloc(b._ctx, self.nbytes, ctypes.byref(ptr)), "ig_malloc(%d bytes)" % self.nbytes)
             return ptr.value
+
+        def _malloc_window(self, slack_gb):
+            """A large array as the best-placed WINDOW of one allocation (round 6).  The passes that step megabytes per element run
+            3 ... 6 % faster or slower with where their array lies -- and that does not only differ from allocation to
+            allocation: inside ONE allocation the placement probe's time changes smoothly with the offset, by 10 % over 7 GB
+            (profiles/r06_placement_offsets.txt: 3.23 ms at the start of an allocation, 2.90 ms 6 - 7 GB in; a badly placed
+            allocation, 3.69 ms, recovers to 3.05 ms 10 GB in).  So: ONE allocation of nbytes + slack_gb GB, the probe
+            (ig_probe_placement) on the window at every GB step, the fastest window kept.  Against three candidate allocations: at
+            most slack_gb GB held beyond the array instead of three times its size for a moment, and a better placement than the best
+            whole allocation.  None (the caller falls back) when the device has no room for the slack."""
+            b = self._backend
+            GBs = 1 << 30
+            free, total = ctypes.c_size_t(), ctypes.c_size_t()
+            if b._L.ig_mem_info(b._ctx, ctypes.byref(free), ctypes.byref(total)) != 0 or free.value < self.nbytes + (slack_gb + 4) * GBs:
+                return None
+            base = ctypes.c_void_p()
+            if b._L.ig_malloc(b._ctx, self.nbytes + slack_gb * GBs, ctypes.byref(base)) != 0:
+                return None
+            times = []
+            try:
+                for off in range(slack_gb + 1):
+                    ms = ctypes.c_double(0.0)
+                    b._check(b._L.ig_probe_placement(b._ctx, ctypes.c_void_p(base.value + off * GBs), self.nbytes, ctypes.byref(ms)), "ig_probe_placement")
+                    times.append(ms.value)
+                # (the first window may have been timed while the clocks were still coming up: once more)
+                ms = ctypes.c_double(0.0)
+                b._check(b._L.ig_probe_placement(b._ctx, base, self.nbytes, ctypes.byref(ms)), "ig_probe_placement")
+                times[0] = min(times[0], ms.value)
+            except Exception:
+                b._L.ig_free(b._ctx, base)
+                raise
+            pick = int(np.argmax(times)) if b.tuning.get('placement_pick') == 'worst' else int(np.argmin(times))
+            self._alloc_base = base.value
+            b._placement_log.append((self.nbytes, [round(t, 4) for t in times], round(times[pick], 4)))
+            log.debug("placement: %d bytes, windows at +0 .. +%d GB %s ms -> +%d GB", self.nbytes, slack_gb, [round(t, 4) for t in times], pick)
+            return base.value + pick * GBs
 
         def _malloc_best_placed(self, ncand):
             """A large array (a scratch arena, a grid): allocate up to `ncand` candidates, time the library's placement probe on each
@@ -257,7 +299,7 @@ class HipBackend(Backend):
         def _free(self):
             b = self._backend
             if getattr(b, '_ctx', None):
-                b._L.ig_free(b._ctx, ctypes.c_void_p(self._arr))
+                b._L.ig_free(b._ctx, ctypes.c_void_p(getattr(self, '_alloc_base', None) or self._arr))
 
         def _zero(self):
             b = self._backend
