@@ -318,30 +318,27 @@ int  ig_grid_gather_sep(ig_ctx* ctx, int64_t M, int64_t NC, int tw, const void* 
                         void* Y, int64_t ldy);
 /* (rec_stride: 32-bit words from one sample's record to the next, >= ig_interp3_sep_words(tw), a multiple of 4.) */
 
-/*   ig_grid_scatter_sep  Y_il = alpha * G^H * X  (X: M x NC column-major, ldx) as a race-free scatter of SHARES: a share = (sample,
- *                        brick of 16 x bm x bs grid cells its footprint meets), 8 bytes {sample, ox + 8 | (om + 8) << 5 | (os + 8) << 10 |
- *                        blo << 15 | bhi << 18 | clo << 22 | chi << 25}: tap (a, b, c) sits at brick cell (ox + a, om + b, os + c), taps
- *                        b in [blo, bhi), c in [clo, chi) are inside the brick.  ig_grid_shares_count / _fill (host) bin them by brick
- *                        (sample order inside a brick).  tasks as for ig_ccsrmm_t_bricks with shares in place of entries; brick_table:
- *                        16 bytes per non-empty brick {brick, end of its shares, uint64 flagged segments: bit xs + (16 / support_tile) *
- *                        (im + bm * is)} -- only flagged segments are written; shared_table: the table rows of the bricks several tasks
- *                        add into (float atomics; zeroed first).  A wave keeps one brick image in LDS (16 * bm * bs * NC * 8 bytes) and
- *                        computes every tap from the sample's record; what the cu_exw_csrmm_H scatter of the reference
- *                        (indigo/backends/_customgpu.cu:49-81) does under its exwrite promise, made safe by binning.                 */
+/*   ig_grid_scatter_sep  Y_il = alpha * G^H * X  (X: M x NC column-major, ldx; NC = 4 or 8) as a race-free scatter of SHARES: a share =
+ *                        (sample, brick of 16 x bm x bs grid cells its footprint meets; bm, bs <= 4), 8 bytes {sample | slow-axis cells of
+ *                        the brick that hold a tap << 28, ox + 8 | (om + 8) << 5 | (os + 8) << 10 | blo << 15 | bhi << 18 | clo << 22 |
+ *                        chi << 25}: tap (a, b, c) sits at brick cell (ox + a, om + b, os + c), taps b in [blo, bhi), c in [clo, chi) are
+ *                        inside the brick.  ig_grid_shares_count / _fill (host) bin them by brick (sample order inside a brick).  tasks as
+ *                        for ig_ccsrmm_t_bricks with shares in place of entries; brick_table: 16 bytes per non-empty brick {brick, end of
+ *                        its shares, uint64 flagged segments: bit xs + (16 / support_tile) * (im + bm * is)} -- only flagged segments are
+ *                        written; shared_table: the table rows of the bricks several tasks add into (float atomics; zeroed first).
+ *                        A wave keeps the brick image in REGISTERS and accumulates on the matrix cores: one v_mfma_f32_16x16x1_4b_f32
+ *                        (fp32 in, fp32 accumulate) adds a share's taps on all 16 x 4 cells of one slow-axis plane of the brick for all
+ *                        coils, whatever the number of taps -- the scatter is bound by instruction issue, not by HBM.
+ *                        `records` must leave room behind every record for the sample's panel row (rec_stride >= words + 2 NC): the call
+ *                        writes X[t, :] there, so that a share's record and panel row are one line.  What the cu_exw_csrmm_H scatter of
+ *                        the reference (indigo/backends/_customgpu.cu:49-81) does under its exwrite promise, made safe by binning.     */
 int  ig_grid_shares_count(int64_t M, const uint32_t* records, int tw, int64_t n0, int64_t nm, int64_t ns, int bm, int bs, int32_t* brick_shares);
 int  ig_grid_shares_fill(int64_t M, const uint32_t* records, int tw, int64_t n0, int64_t nm, int64_t ns, int bm, int bs,
                          const int64_t* brick_ptr, uint32_t* shares);
 int  ig_grid_scatter_sep(ig_ctx* ctx, int64_t M, int64_t NC, int tw, void* records, int64_t rec_stride, const void* shares, const void* X, int64_t ldx,
                          void* Y_il, int64_t n0, int64_t nm, int64_t ns, int bm, int bs, const int32_t* tasks, int64_t ntasks,
                          const int32_t* brick_table, const int32_t* shared_table, int64_t nshared, int support_tile,
-                         float alpha_re, float alpha_im, int form);
-/* form 0: the brick image in LDS, vector multiply-adds (rec_stride = ig_interp3_sep_words(tw); 2, 4 or 8 coils; 16 * bm * bs * NC * 8 bytes
- *         of LDS per wave).
- * form 1: the brick image in registers, the accumulation as outer products on the matrix cores (v_mfma_f32_16x16x1_4b_f32: fp32 in,
- *         fp32 accumulate; one instruction adds a share's taps on all 16 x 4 cells of one slow-axis plane of the brick for all coils):
- *         bricks of 16 x (bm <= 4) x (bs <= 4) cells, 4 or 8 coils; `records` must leave room behind every record for the sample's
- *         panel row (rec_stride >= words + 2 NC) -- the call writes X[t, :] there, so that a share's record and panel row are ONE
- *         line.  The scatter is bound by instruction issue, not by HBM: hence the matrix pipe.                    */
+                         float alpha_re, float alpha_im);
 
 /* The same scatter for the reference's own panel layout, 64 columns: Y(K x 64, column-major, ldy) = alpha * A^H * X(M x 64,
  * column-major, ldx) for ANY CSR matrix with K a multiple of 16 (beta == 0: Y is zeroed first).  Bricks are 16 consecutive

@@ -128,7 +128,7 @@ PROTOTYPES = {
     "ig_grid_shares_count": (c_int, [c_int64, c_void_p, c_int, c_int64, c_int64, c_int64, c_int, c_int, c_void_p]),
     "ig_grid_shares_fill": (c_int, [c_int64, c_void_p, c_int, c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "ig_grid_scatter_sep": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64,
-                                    c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_float, c_float, c_int]),
+                                    c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_float, c_float]),
     "ig_interp3_fill_modulated": (c_int, [c_int64, POINTER(c_int64), c_double, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                           c_void_p, c_void_p, c_void_p, c_double]),
     "ig_fft_plan":        (c_int, [c_void_p, c_int, POINTER(c_int64), c_int64, POINTER(c_void_p), POINTER(c_size_t)]),

@@ -116,7 +116,7 @@ class HipBackend(Backend):
         self.tuning = dict(placement_candidates=3, placement_min_bytes=1 << 31, placement_window_gb=8, cg_graph=False, bricks=(4, 8), slots=(1, 2), slot_shape=(4, 4, 256, 64), support_tile={8: 4, 4: 8}, brick_shape={8: (2, 2, 4096, 4096), 4: (2, 4, 4096, 4096)}, xrows=True, runs=True, wide_bricks=True,
                            wide_brick_shape=(2, 2), wide_task_shape=(8192, 2048),
                            # round 6: gridding from the separable form of the matrix (one record per sample, taps computed)
-                           separable=True, sep_gather=True, sep_scatter=True, sep_mfma=True, shares=(4, 8), shares_min_tw=6, share_shape={8: (4, 4, 1024, 1024), 4: (4, 4, 1024, 1024)})
+                           separable=True, sep_gather=True, sep_scatter=True, shares=(4, 8), shares_min_tw=6, share_shape={8: (4, 4, 1024, 1024), 4: (4, 4, 1024, 1024)})
 
     def __del__(self):
         try:
@@ -1074,7 +1074,8 @@ class HipBackend(Backend):
             of consecutive non-empty bricks of about `run` shares, or a piece of at most `chunk` shares of a heavy brick (shared)."""
             b = self._backend
             sep = getattr(self, '_sep', None)
-            assert sep is not None and ncols in (2, 4, 8)
+            assert sep is not None and ncols in (4, 8)
+            bm, bs = min(int(bm), 4), min(int(bs), 4)          # (the brick image is four MFMA blocks x four accumulator groups)
             n0, nm, ns = sep['dims']
             rec, tw = sep['host'], sep['tw']
             fine = self._format('_support_fine_host', ncols)
@@ -1395,15 +1396,10 @@ class HipBackend(Backend):
                     y._zero()           # without a support table every row is defined: bricks no sample touches stay zero
                 ar, ai = _cplx(complex(alpha) * np.conj(sep['gconst']))
                 n0, nm, ns = sep['dims']
-                form = 1 if (b.tuning.get('sep_mfma', True) and x.shape[1] in (4, 8) and shf['bm'] <= 4 and shf['bs'] <= 4) else 0
-                form |= int(b.tuning.get('sep_dbg', 0)) << 4
-                if (form & 15) == 0 and '_records_plain' not in sep:        # (the LDS form reads records without the panel-row gap)
-                    sep['_records_plain'] = b.copy_array(sep['host'].reshape(-1), name=self._name + ".sepRecordsPlain")
-                recs, stride = (sep['records'], sep['stride']) if (form & 15) == 1 else (sep['_records_plain'], sep['host'].shape[1])
-                b._check(b._L.ig_grid_scatter_sep(b._ctx, self.shape[0], x.shape[1], sep['tw'], ctypes.c_void_p(recs._arr), stride,
+                b._check(b._L.ig_grid_scatter_sep(b._ctx, self.shape[0], x.shape[1], sep['tw'], ctypes.c_void_p(sep['records']._arr), sep['stride'],
                                                   ctypes.c_void_p(shf['shares']._arr), ctypes.c_void_p(x._arr), x._leading_dim, ctypes.c_void_p(y._arr),
                                                   n0, nm, ns, shf['bm'], shf['bs'], ctypes.c_void_p(shf['tasks']._arr), shf['ntasks'],
-                                                  ctypes.c_void_p(shf['table']._arr), ctypes.c_void_p(shf['shared']._arr), shf['nshared'], shf['tile'], ar, ai, form),
+                                                  ctypes.c_void_p(shf['table']._arr), ctypes.c_void_p(shf['shared']._arr), shf['nshared'], shf['tile'], ar, ai),
                          "ig_grid_scatter_sep")
                 return
             br = self._format('_bricks', x.shape[1], exact=True)

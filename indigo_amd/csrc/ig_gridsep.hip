@@ -8,9 +8,10 @@
 // (coil, kx, km, ks) at coil + NC * (kx + n0 * (km + nm * ks))):
 //
 //   forward   Y[t, :]  = alpha * sum_taps w(t, tap) * X[cell(t, tap), :] + beta * Y[t, :]          k_grid_gather_sep
-//   adjoint   Yg[cell, :] = alpha * sum_{t, tap -> cell} w(t, tap) * X[t, :]   (flagged segments)  k_grid_scatter_sep
+//   adjoint   Yg[cell, :] = alpha * sum_{t, tap -> cell} w(t, tap) * X[t, :]   (flagged segments)  k_grid_scatter_mfma
 //
-// Both are HBM- and issue-bound gather / scatter work on 64-byte grid rows: no MFMA.
+// The forward is bound by the vector-memory return path and HBM; the adjoint by instruction issue -- which is why its accumulation runs
+// as outer products on the matrix cores (fp32 in, fp32 accumulate).
 #include "ig_common.h"
 #include <vector>
 #include <thread>
@@ -129,196 +130,33 @@ k_grid_gather_sep(int64_t M, const uint32_t* __restrict__ rec, int rs /* words p
 }
 
 // ---- adjoint -------------------------------------------------------------------------------------------------------------------
-// The SCATTER, race-free by binning as in k_grid_bricks (ig_spmm.hip) -- a wave owns a run of grid bricks of 16 x BM x BS cells, keeps
-// ONE brick image in LDS, accumulates with plain read-add-write and stores the image's flagged segments at each brick boundary --
-// but what is binned are SHARES, not taps: a share = (sample, brick) for every brick the sample's footprint meets, 8 bytes:
+// The SCATTER, race-free by binning as in k_grid_bricks (ig_spmm.hip) -- a wave owns a run of grid bricks of 16 x 4 x 4 cells, keeps
+// ONE brick image, accumulates into it and stores the image's flagged segments at each brick boundary; bricks of the k-space centre
+// are cut into pieces whose waves add with float atomics -- but what is binned are SHARES, not taps: a share = (sample, brick) for
+// every brick the sample's footprint meets, 8 bytes:
 //   word 0   sample | the brick's slow-axis cells that hold a tap of the share << 28 (bricks of <= 4 slow cells; else 15)
 //   word 1   ox + 8 | (om + 8) << 5 | (os + 8) << 10 | blo << 15 | bhi << 18 | clo << 22 | chi << 25
 //            tap (a, b, c) of the sample sits at brick cell (ox + a, om + b, os + c); the taps b in [blo, bhi), c in [clo, chi) and
 //            those a with 0 <= ox + a < 16 are the ones inside this brick
-// and the taps are computed from the sample's record.  A lane of the accumulation is (q, i, bl): 16-byte piece q of the NC coils,
-// x tap i, middle-axis tap blo + bl (+ BL per sub-round); a round handles one slow-axis tap c: LDS read of 16 bytes, four
-// multiply-adds, LDS write.  Record and k-space panel row of a share arrive as ONE load -- lane L < RW: record word L, lanes RW ..
-// RW + 2 NC: the panel row's words -- issued a group of four shares ahead, and are handed to the lanes that need them by ds_bpermute
-// (x tap weight, middle-axis weight, the four floats of the lane's coil pair) and v_readlane (slow-axis weight: wave-uniform).
-// Against the stored-tap format: 8 bytes per share + 64 per record instead of 8 .. 12 bytes per tap padded to rounds (1.6 x);
-// bricks of 256 cells instead of 64 (2.5 shares per sample instead of 4.5 panel-row fetches).
-struct ShareTask { int32_t lo, hi, bt, nb_flags; };            // shares [lo, hi) = bricks table[bt .. bt + (nb_flags & 0xffff)); bit 16: shared
-struct ShareBrick { int32_t brick, end; uint32_t mask_lo, mask_hi; };   // a non-empty brick, where its shares end, its flagged segments
-
-typedef float v4f_t __attribute__((ext_vector_type(4)));
-
-template <int NC, int TW>
-__global__ void __launch_bounds__(BLK)
-k_grid_scatter_sep(const ShareTask* __restrict__ tasks, int ntasks, const ShareBrick* __restrict__ btab, const uint2* __restrict__ shares,
-                   const uint32_t* __restrict__ rec, const uint32_t* __restrict__ xp /* packed panel rows [t][NC] as words */,
-                   float4* __restrict__ Y4, float2 alpha, int n0, int nm, int bm_log2, int bs_log2, int nbx, int nbm, int st_log2) {
-    extern __shared__ float4 img_all[];                    // per wave: [cell][QL]
-    constexpr int QL = NC / 2, XL = TW <= 4 ? 4 : 8, BL = 64 / (QL * XL), RW = sep_words(TW), XW = 2 * NC;
-    static_assert(RW + XW <= 64, "record and panel row fit one lane-word load");
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int task = blockIdx.x * WPB + wv;
-    if (task >= ntasks) return;                            // (no workgroup barrier below: waves are independent)
-    const ShareTask tk = tasks[task];
-    const int nb = tk.nb_flags & 0xffff;
-    const bool shared = (tk.nb_flags >> 16) & 1;
-    const int nsh = tk.hi - tk.lo;
-    const int BM = 1 << bm_log2, nrows = 1 << (bm_log2 + bs_log2), ncell = 16 * nrows;
-    float4* __restrict__ img = img_all + (size_t)wv * ncell * QL;
-    const int q = lane % QL, i = (lane / QL) % XL, bl = lane / (QL * XL);
-
-    // the run's bricks, one per lane
-    int my_end = 0x7fffffff;
-    uint32_t my_mlo = 0xffffffffu, my_mhi = 0xffffffffu;
-    int64_t my_pt = 0;
-    if (lane < nb) {
-        const ShareBrick br = btab[tk.bt + lane];
-        if (!shared) my_end = br.end - tk.lo;
-        my_mlo = br.mask_lo; my_mhi = br.mask_hi;
-        const int bx = br.brick % nbx, bmi = (br.brick / nbx) % nbm, bsi = br.brick / (nbx * nbm);
-        my_pt = (int64_t)bx * 16 + (int64_t)n0 * (((int64_t)bmi << bm_log2) + (int64_t)nm * ((int64_t)bsi << bs_log2));
-    }
-    for (int e = lane; e < ncell * QL; e += 64) img[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-
-    // lane-word source of a share's record + panel row: lane L < RW: record word L; RW <= L < RW + XW: panel word L - RW
-    const bool is_rec = lane < RW;
-    const uint32_t* lane_base = is_rec ? rec + lane : xp + (lane < RW + XW ? lane - RW : XW - 1);
-    const uint32_t lane_stride = is_rec ? (uint32_t)RW : (uint32_t)XW;
-    const int xs_log2 = 4 - st_log2;
-    // flush roles: lane -> (row of the pass, x cell, coil piece)
-    constexpr int LR = 16 * QL, RP = 64 / LR;              // lanes per brick row, brick rows per pass
-    const int f_row = lane / LR, f_xq = lane % LR, f_x = f_xq / QL;
-
-    int cur = 0;
-    int cur_end = __builtin_amdgcn_readlane(my_end, 0);
-    auto flush = [&]() __attribute__((always_inline)) {
-        const uint32_t mlo = (uint32_t)__builtin_amdgcn_readlane((int)my_mlo, cur), mhi = (uint32_t)__builtin_amdgcn_readlane((int)my_mhi, cur);
-        const uint64_t mask = ((uint64_t)mhi << 32) | mlo;
-        const int64_t pt = ((int64_t)__builtin_amdgcn_readlane((int)(my_pt >> 32), cur) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)my_pt, cur);
-        for (int row0 = 0; row0 < nrows; row0 += RP) {
-            const int row = row0 + f_row;
-            if (row >= nrows) continue;                    // (bricks of fewer rows than a pass covers: narrow panels)
-            const int seg = (f_x >> st_log2) + (row << xs_log2);
-            const bool mine = (mask >> seg) & 1ull;
-            float4* src = img + row * LR + f_xq;
-            const float4 v = *src;
-            *src = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (mine) {
-                const float2 o0 = cmul(alpha, make_float2(v.x, v.y)), o1 = cmul(alpha, make_float2(v.z, v.w));
-                const int im = row & (BM - 1), is = row >> bm_log2;
-                float4* dst = Y4 + (pt + (int64_t)n0 * (im + (int64_t)nm * is)) * QL + f_xq;
-                // (stores and atomics as asm statements: the compiler's wait-count bookkeeping does not see them and so does not
-                // drain the prefetched records in front of every share group; nothing here reads Y back)
-                if (shared) {
-                    asm volatile("global_atomic_add_f32 %0, %1, off\n\tglobal_atomic_add_f32 %0, %2, off offset:4\n\t"
-                                 "global_atomic_add_f32 %0, %3, off offset:8\n\tglobal_atomic_add_f32 %0, %4, off offset:12"
-                                 :: "v"(dst), "v"(o0.x), "v"(o0.y), "v"(o1.x), "v"(o1.y) : "memory");
-                } else {
-                    const v4f_t o = {o0.x, o0.y, o1.x, o1.y};
-                    asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(dst), "v"(o) : "memory");
-                }
-            }
-        }
-        ++cur;
-        cur_end = __builtin_amdgcn_readlane(my_end, cur & 63);
-    };
-
-    constexpr int G = 4;                                   // shares whose record + panel loads are in flight together
-    for (int base = 0; base < nsh; base += 64) {
-        const int nbatch = nsh - base < 64 ? nsh - base : 64;
-        uint2 sh = make_uint2(0u, 0u);
-        if (lane < nbatch) sh = shares[(size_t)tk.lo + base + lane];
-        auto request = [&](uint32_t (&w)[G], int s0) __attribute__((always_inline)) {
-#pragma unroll
-            for (int k = 0; k < G; ++k) {
-                const int s = s0 + k < nbatch ? s0 + k : nbatch - 1;
-                const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)sh.x, s) & 0x0fffffffu;
-                w[k] = lane_base[(size_t)t * lane_stride];
-            }
-        };
-        auto process = [&](const uint32_t (&w)[G], int s0) __attribute__((always_inline)) {
-            // hand-offs of the whole group first (independent of the image: all G x 6 ds_bpermute are in flight together) ...
-            float w0[G], w1[G];
-            float4 xv[G];
-#pragma unroll
-            for (int k = 0; k < G; ++k) {
-                const int sk = s0 + k < nbatch ? s0 + k : nbatch - 1;
-                const uint32_t geo = (uint32_t)__builtin_amdgcn_readlane((int)sh.y, sk);
-                const int b = (int)((geo >> 15) & 7u) + bl;
-                const int wi = (int)w[k];
-                w0[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(i * 4, wi));
-                xv[k].x = __int_as_float(__builtin_amdgcn_ds_bpermute((RW + 4 * q) * 4, wi));
-                xv[k].y = __int_as_float(__builtin_amdgcn_ds_bpermute((RW + 4 * q + 1) * 4, wi));
-                xv[k].z = __int_as_float(__builtin_amdgcn_ds_bpermute((RW + 4 * q + 2) * 4, wi));
-                xv[k].w = __int_as_float(__builtin_amdgcn_ds_bpermute((RW + 4 * q + 3) * 4, wi));
-                w1[k] = __int_as_float(__builtin_amdgcn_ds_bpermute((TW + (b < TW ? b : 0)) * 4, wi));
-            }
-            // ... then share by share: the image cells of all slow-axis taps are read before the first multiply-add
-#pragma unroll
-            for (int k = 0; k < G; ++k) {
-                const int s = s0 + k;
-                if (s >= nbatch) break;                    // (wave-uniform)
-                if (base + s >= cur_end) flush();          // (every brick of the table holds at least one share)
-                const uint32_t geo = (uint32_t)__builtin_amdgcn_readlane((int)sh.y, s);
-                const int ox = (int)(geo & 31u) - 8, om = (int)((geo >> 5) & 31u) - 8, os = (int)((geo >> 10) & 31u) - 8;
-                const int blo = (int)((geo >> 15) & 7u), bhi = (int)((geo >> 18) & 15u), clo = (int)((geo >> 22) & 7u), chi = (int)((geo >> 25) & 15u);
-                const int wi = (int)w[k];
-                const int cx = ox + i;
-                const bool vx = (unsigned)cx < 16u && i < TW;
-                for (int b0 = blo; b0 < bhi; b0 += BL) {
-                    const int b = b0 + bl;
-                    float w01 = w0[k] * w1[k];
-                    if (b0 != blo) w01 = w0[k] * __int_as_float(__builtin_amdgcn_ds_bpermute((TW + (b < TW ? b : 0)) * 4, wi));
-                    if (vx && b < bhi) {
-                        constexpr int CT = TW < 4 ? TW : 4;
-                        float4* a0 = img + (cx + 16 * (om + b) + (16 << bm_log2) * (os + clo)) * QL + q;
-                        const int cstep = (16 << bm_log2) * QL;
-                        for (int c0 = clo; c0 < chi; c0 += CT, a0 += CT * cstep) {
-                            float4 v[CT];
-#pragma unroll
-                            for (int u = 0; u < CT; ++u)
-                                if (c0 + u < chi) v[u] = a0[u * cstep];          // plain read-add-write: the lanes of a round hold distinct
-#pragma unroll
-                            for (int u = 0; u < CT; ++u)                         // cells of ONE sample, the image is this wave's, and a
-                                if (c0 + u < chi) {                              // wave's LDS operations execute in order
-                                    const float wt = w01 * __int_as_float(__builtin_amdgcn_readlane(wi, 2 * TW + c0 + u));
-                                    v[u].x = fmaf(wt, xv[k].x, v[u].x); v[u].y = fmaf(wt, xv[k].y, v[u].y);
-                                    v[u].z = fmaf(wt, xv[k].z, v[u].z); v[u].w = fmaf(wt, xv[k].w, v[u].w);
-                                }
-#pragma unroll
-                            for (int u = 0; u < CT; ++u)
-                                if (c0 + u < chi) a0[u * cstep] = v[u];
-                        }
-                    }
-                }
-            }
-        };
-        uint32_t wa[G], wb[G];
-        request(wa, 0);
-        for (int s0 = 0; s0 < nbatch; s0 += 2 * G) {
-            request(wb, s0 + G);
-            process(wa, s0);
-            request(wa, s0 + 2 * G);
-            process(wb, s0 + G);
-        }
-    }
-    flush();
-}
-
-// ---- adjoint on the matrix cores ---------------------------------------------------------------------------------------------------
-// The same scatter of shares with the brick image in REGISTERS and the accumulation as outer products on the MFMA pipe.  The
-// stored-tap scatter (k_grid_bricks, ig_spmm.hip) and the LDS form above spend ~130 vector instructions per sample to issue the
-// 27 x 16 multiply-adds a sample is (7 wave instructions' worth): they are bound by instruction issue, not by HBM (1.8 TB/s on a
-// densely sampled trajectory, profiles/r06_*).  A share's contribution to a brick of 16 (x) x 4 (middle) x NG (slow) cells IS a sum of
+// and the taps are computed from the sample's record: 8 bytes per share + 64 per record instead of 8 .. 12 bytes per tap padded to
+// rounds (1.6 x); bricks of 256 cells instead of 64 (2.5 shares per sample instead of 4.5 panel-row fetches at kernel half-width 2).
+//
+// The brick image lives in REGISTERS and the accumulation runs as outer products on the MFMA pipe.  The stored-tap scatter spends
+// ~130 vector instructions per sample to issue the 27 x 16 multiply-adds a sample is (7 wave instructions' worth): it is bound by
+// instruction issue, not by HBM (1.8 TB/s on a densely sampled trajectory, profiles/r06_scatter_forms.txt; a first form of this
+// kernel with the image in LDS and vector multiply-adds was slower still and is gone).  A share's contribution to a brick IS a sum of
 // outer products: for slow-axis cell g and middle-axis cell beta
 //       image[x, beta, g][f] += wx[x - ox] * (wm[beta - om] * ws[g - os] * X[t, f]),        f = 0 .. 2 NC - 1 floats of the NC coils
 // which v_mfma_f32_16x16x1_4b_f32 computes for all 16 x, all 4 beta (its four blocks) and all 16 f in ONE instruction of 32 clocks:
 // A = wx[x - ox] (lane = x + 16 beta), B = wm[beta - om] ws[g - os] X[t, f] (lane = f + 16 beta), D = the 16 registers of group g.
-// A share costs NG MFMAs whatever the number of taps inside it -- 27 (kernel width 2) or 125 (the reference's default width 3) --
-// plus three ds_bpermute hand-offs (x weight, middle weight, panel value) and one v_readlane + multiply per group.  fp32 in, fp32
-// accumulate: the same arithmetic as the vector form.  Record and panel row of a sample are ONE 128-byte line (`recx`: the pack
-// kernel writes the panel row behind the record), fetched by one lane-word load per share.
+// A share costs one MFMA per slow-axis cell it touches whatever the number of taps inside it -- 27 (kernel half-width 2) or 125 (the
+// reference's default 3) -- plus a handful of LDS reads (x weight, middle weight, panel value, slow weights).  fp32 in, fp32
+// accumulate: the arithmetic of the vector kernels.  Record and panel row of a sample are ONE 128-byte line (`recx`: the pack kernel
+// writes the panel row behind the record), fetched by one lane-word load per share, two groups of four shares ahead, through a ring
+// in LDS; share headers come 64 at a time, two batches deep in LDS.
+struct ShareTask { int32_t lo, hi, bt, nb_flags; };            // shares [lo, hi) = bricks table[bt .. bt + (nb_flags & 0xffff)); bit 16: shared
+struct ShareBrick { int32_t brick, end; uint32_t mask_lo, mask_hi; };   // a non-empty brick, where its shares end, its flagged segments
+
 typedef float v16f_t __attribute__((ext_vector_type(16)));
 
 template <bool SHARED, int NG, int XW>
@@ -532,14 +370,6 @@ k_grid_sep_zero(const ShareBrick* __restrict__ bricks, float4* __restrict__ Y4, 
     }
 }
 
-// X (rows x NC, column-major, ld) -> packed rows [t][NC]
-template <int NC>
-__global__ void __launch_bounds__(BLK)
-k_sep_pack_panel(int64_t rows, const float2* __restrict__ X, int64_t ld, float2* __restrict__ Xp) {
-    for (int64_t e = (int64_t)blockIdx.x * BLK + threadIdx.x; e < rows * NC; e += (int64_t)gridDim.x * BLK)
-        Xp[e] = X[(e % NC) * ld + e / NC];
-}
-
 // ---- host: shares of the samples by grid brick -----------------------------------------------------------------------------------
 struct ShareGeom { int64_t n[3]; int bdim[3]; int64_t nbr[3]; int tw, rw; };
 
@@ -723,21 +553,20 @@ int ig_grid_shares_fill(int64_t M, const uint32_t* records, int tw, int64_t n0, 
 // bricks several tasks add into (zeroed first; those tasks add with float atomics).
 int ig_grid_scatter_sep(ig_ctx* ctx, int64_t M, int64_t NC, int tw, void* records, int64_t rec_stride, const void* shares, const void* X, int64_t ldx,
                         void* Y_il, int64_t n0, int64_t nm, int64_t ns, int bm, int bs, const int32_t* tasks, int64_t ntasks,
-                        const int32_t* brick_table, const int32_t* shared_table, int64_t nshared, int support_tile, float ar, float ai, int form) {
+                        const int32_t* brick_table, const int32_t* shared_table, int64_t nshared, int support_tile, float ar, float ai) {
     IG_REQUIRE(ctx, ctx != nullptr, "ig_grid_scatter_sep: ctx is NULL");
     ShareGeom g;
-    IG_REQUIRE(ctx, M >= 0 && M <= 0x7fffffffLL && (NC == 2 || NC == 4 || NC == 8) && share_geom(g, tw, n0, nm, ns, bm, bs),
-               "ig_grid_scatter_sep: 2, 4 or 8 interleaved coils; a grid that divides into 16 x bm x bs bricks; tw 4, 6 or 8");
+    IG_REQUIRE(ctx, M >= 0 && M < (1LL << 28) && (NC == 4 || NC == 8) && share_geom(g, tw, n0, nm, ns, bm, bs) && bm <= 4 && bs <= 4,
+               "ig_grid_scatter_sep: 4 or 8 interleaved coils; a grid that divides into bricks of 16 x (bm <= 4) x (bs <= 4) cells; tw 4, 6 or 8");
     IG_REQUIRE(ctx, support_tile == 16 || support_tile == 8 || support_tile == 4, "ig_grid_scatter_sep: support_tile 16, 8 or 4");
-    IG_REQUIRE(ctx, (16 / support_tile) * bm * bs <= 64, "ig_grid_scatter_sep: at most 64 segments per brick");
     IG_REQUIRE(ctx, ntasks >= 0 && ntasks <= 0x7fffffffLL && (ntasks == 0 || (tasks && brick_table && records && shares && X && Y_il)) && ldx >= M &&
                nshared >= 0 && (nshared == 0 || shared_table), "ig_grid_scatter_sep: bad task list or NULL array");
     IG_REQUIRE(ctx, n0 * nm * ns * (NC / 2) < (1LL << 32), "ig_grid_scatter_sep: grid panel too large");
+    const int rw = sep_words(tw);
+    IG_REQUIRE(ctx, rec_stride >= rw + 2 * NC && rec_stride % 4 == 0, "ig_grid_scatter_sep: record stride %lld words: the record (%d) and the panel row behind it", (long long)rec_stride, rw);
     if (ntasks == 0 || M == 0) return IG_OK;
     if (int rc = ig_set_device(ctx)) return rc;
     const float2 alpha = make_float2(ar, ai);
-    const int rw = sep_words(tw);
-    IG_REQUIRE(ctx, rec_stride >= rw && rec_stride % 4 == 0 && ((form & 15) == 0 || rec_stride >= rw + 2 * NC), "ig_grid_scatter_sep: record stride %lld (words): the record, and for the MFMA form the panel row behind it", (long long)rec_stride);
     int bm_log2 = 0, bs_log2 = 0;
     while ((1 << bm_log2) < bm) ++bm_log2;
     while ((1 << bs_log2) < bs) ++bs_log2;
@@ -745,63 +574,26 @@ int ig_grid_scatter_sep(ig_ctx* ctx, int64_t M, int64_t NC, int tw, void* record
     const int nbx = (int)(n0 / 16), nbm = (int)(nm / bm);
     const unsigned blocks = (unsigned)((ntasks + WPB - 1) / WPB);
     const size_t need = (size_t)M * NC * 8;
-#define IG_ZERO(NC_) do { if (nshared) {                                                                                                 \
-            ig_prof_scope prof(ctx, "grid_sep_zero");                                                                                    \
-            hipLaunchKernelGGL((k_grid_sep_zero<NC_>), dim3((unsigned)nshared), dim3(BLK), 0, ctx->stream, (const ShareBrick*)shared_table, \
-                               (float4*)Y_il, (int)n0, (int)nm, bm_log2, bs_log2, nbx, nbm, st_log2); } } while (0)
-    if ((form & 15) == 1) {
-        // outer products on the MFMA pipe, brick image in registers: bricks of 16 x (<= 4) x (<= 4) cells, 4 or 8 coils
-        IG_REQUIRE(ctx, (NC == 8 || NC == 4) && bm <= 4 && bs <= 4, "ig_grid_scatter_sep: the MFMA form takes 4 or 8 coils and bricks of 16 x (<= 4) x (<= 4) cells");
-        int64_t gp = (M * NC + BLK - 1) / BLK;
-        const int64_t cap = (int64_t)ctx->num_cu * 16;
-        if (gp > cap) gp = cap;
+    int64_t gp = (M * NC + BLK - 1) / BLK;
+    const int64_t cap = (int64_t)ctx->num_cu * 16;
+    if (gp > cap) gp = cap;
 #define IG_SM(NC_, TW_) do {                                                                                                             \
         {   ig_prof_scope prof(ctx, "pack_panel", 2.0 * (double)need);                                                                   \
             hipLaunchKernelGGL((k_sep_pack_recx<NC_>), dim3((unsigned)gp), dim3(BLK), 0, ctx->stream, M, (const float2*)X, ldx, (float2*)records, (int)(rec_stride / 2), rw / 2); } \
-        IG_ZERO(NC_);                                                                                                                    \
+        if (nshared) {                                                                                                                   \
+            ig_prof_scope prof(ctx, "grid_sep_zero");                                                                                    \
+            hipLaunchKernelGGL((k_grid_sep_zero<NC_>), dim3((unsigned)nshared), dim3(BLK), 0, ctx->stream, (const ShareBrick*)shared_table, \
+                               (float4*)Y_il, (int)n0, (int)nm, bm_log2, bs_log2, nbx, nbm, st_log2); }                                  \
         ig_prof_scope prof(ctx, "grid_scatter_sep");                                                                                     \
         hipLaunchKernelGGL((k_grid_scatter_mfma<NC_, TW_, 4>), dim3(blocks), dim3(BLK), 0, ctx->stream, (const ShareTask*)tasks, (int)ntasks, \
                            (const ShareBrick*)brick_table, (const uint2*)shares, (const uint32_t*)records, (int)rec_stride, (float*)Y_il, \
                            alpha, (int)n0, (int)nm, bm_log2, bs_log2, nbx, nbm, st_log2);                                                \
     } while (0)
 #define IG_SM_TW(NC_) do { if (tw == 4) IG_SM(NC_, 4); else if (tw == 6) IG_SM(NC_, 6); else IG_SM(NC_, 8); } while (0)
-        if (NC == 8) IG_SM_TW(8); else IG_SM_TW(4);
+    if (NC == 8) IG_SM_TW(8); else IG_SM_TW(4);
 #undef IG_SM_TW
 #undef IG_SM
-        IG_LAUNCH_CHECK(ctx, "k_grid_scatter_mfma");
-        return IG_OK;
-    }
-    IG_REQUIRE(ctx, rec_stride == rw, "ig_grid_scatter_sep: the LDS form reads records of %d words", rw);
-    if (ctx->xpack_bytes < need) {
-        if (ctx->d_xpack) { IG_HIP(ctx, hipStreamSynchronize(ctx->stream)); IG_HIP(ctx, hipFree(ctx->d_xpack)); ctx->d_xpack = nullptr; ctx->xpack_bytes = 0; }
-        IG_HIP(ctx, hipMalloc((void**)&ctx->d_xpack, need));
-        ctx->xpack_bytes = need;
-    }
-    float2* xpk = (float2*)ctx->d_xpack;
-    const size_t lds = (size_t)WPB * 16 * bm * bs * NC * 8;                // one brick image per wave
-    IG_REQUIRE(ctx, lds <= 160 * 1024, "ig_grid_scatter_sep: bricks of 16 x %d x %d cells x %lld coils need %zu bytes of LDS per workgroup", bm, bs, (long long)NC, lds);
-#define IG_SS(NC_, TW_) do {                                                                                                             \
-        {   ig_prof_scope prof(ctx, "pack_panel", 2.0 * (double)need);                                                                   \
-            int64_t gp = (M * NC_ + BLK - 1) / BLK;                                                                                      \
-            const int64_t cap = (int64_t)ctx->num_cu * 16;                                                                               \
-            if (gp > cap) gp = cap;                                                                                                      \
-            hipLaunchKernelGGL((k_sep_pack_panel<NC_>), dim3((unsigned)gp), dim3(BLK), 0, ctx->stream, M, (const float2*)X, ldx, xpk); } \
-        IG_ZERO(NC_);                                                                                                                    \
-        if (lds > 64 * 1024)                                                                                                             \
-            IG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grid_scatter_sep<NC_, TW_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        ig_prof_scope prof(ctx, "grid_scatter_sep");                                                                                     \
-        hipLaunchKernelGGL((k_grid_scatter_sep<NC_, TW_>), dim3(blocks), dim3(BLK), lds, ctx->stream, (const ShareTask*)tasks, (int)ntasks, \
-                           (const ShareBrick*)brick_table, (const uint2*)shares, (const uint32_t*)records, (const uint32_t*)xpk, (float4*)Y_il, \
-                           alpha, (int)n0, (int)nm, bm_log2, bs_log2, nbx, nbm, st_log2);                                                \
-    } while (0)
-#define IG_SS_TW(NC_) do { if (tw == 4) IG_SS(NC_, 4); else if (tw == 6) IG_SS(NC_, 6); else IG_SS(NC_, 8); } while (0)
-    if (NC == 8) IG_SS_TW(8);
-    else if (NC == 4) IG_SS_TW(4);
-    else IG_SS_TW(2);
-#undef IG_SS_TW
-#undef IG_SS
-#undef IG_ZERO
-    IG_LAUNCH_CHECK(ctx, "k_grid_scatter_sep");
+    IG_LAUNCH_CHECK(ctx, "k_grid_scatter_mfma");
     return IG_OK;
 }
 

@@ -15,7 +15,7 @@ f = glob.glob("$OUT/g$i/**/c_counter_collection.csv", recursive=True)[0]
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
 for r in csv.DictReader(open(f)):
     k = r["Kernel_Name"]
-    for tag in ("k_grid_bricks<", "k_grid_scatter_mfma<", "k_grid_scatter_sep<", "k_grid_gather_sep<", "k_csrmm_gather_v<"):
+    for tag in ("k_grid_bricks<", "k_grid_scatter_mfma<", "k_grid_scatter_sep<", "k_grid_gather_sep<", "k_grid_gather_mfma<", "k_csrmm_gather_v<"):
         if tag in k:
             acc[tag][r["Counter_Name"]] += float(r["Counter_Value"]); n[(tag, r["Counter_Name"])] += 1
 for k in acc:
