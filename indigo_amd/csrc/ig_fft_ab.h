@@ -554,16 +554,18 @@ k_fft_chirp(PassDesc d, const float2* __restrict__ tw) {
     // instructions, every one a 16-lane broadcast through the address unit.
     float2* __restrict__ t_b = tws + N;
     float2* __restrict__ t_hat = t_b + N;
-    float2* __restrict__ t_out = t_hat + N;
+    // (round 6: the output weights b_k / m are the chirp itself times 1 / m -- no table of their own: the 6.9 KB it took at m = 864 were
+    // what kept a second workgroup off the CU there, and a third at m = 560)
+    constexpr float INV_M = 1.0f / (float)N;
     const int tid = threadIdx.x;
     // (requested here, written to LDS behind the first transform's loads: written on the spot the copies are a round trip of their own
     // at the head of a workgroup of which one or two fit a CU)
     constexpr int TWN = (N + AB_W * B - 1) / (AB_W * B);
-    float2 tab_mine[TWN][4];
+    float2 tab_mine[TWN][3];
 #pragma unroll
     for (int i = 0; i < TWN; ++i) {
         const int k = tid + i * AB_W * B, kk = k < N ? k : N - 1;
-        tab_mine[i][0] = tw[kk]; tab_mine[i][1] = d.w[kk]; tab_mine[i][2] = d.w2[kk]; tab_mine[i][3] = d.w2[N + kk];
+        tab_mine[i][0] = tw[kk]; tab_mine[i][1] = d.w[kk]; tab_mine[i][2] = d.w2[kk];
     }
     const int b = tid / AB_W, w = tid % AB_W;
     unsigned tr, k1i, k2i;
@@ -618,7 +620,7 @@ k_fft_chirp(PassDesc d, const float2* __restrict__ tw) {
 #pragma unroll
     for (int i = 0; i < TWN; ++i) {
         const int k = tid + i * AB_W * B;
-        if (k < N) { tws[k] = tab_mine[i][0]; t_b[k] = tab_mine[i][1]; t_hat[k] = tab_mine[i][2]; t_out[k] = tab_mine[i][3]; }
+        if (k < N) { tws[k] = tab_mine[i][0]; t_b[k] = tab_mine[i][1]; t_hat[k] = tab_mine[i][2]; }
     }
     __syncthreads();                                   // the tables are in place (the loads above are in flight)
 #pragma unroll
@@ -666,7 +668,8 @@ k_fft_chirp(PassDesc d, const float2* __restrict__ tw) {
 #pragma unroll
             for (int k2 = 0; k2 < A; ++k2) {           // X[b + B k2], k2 < A: only k < n is ever kept
                 if (!((gout >> k2) & 1u)) continue;
-                const cx e = cxmulc(y[k2], from2(t_out[b + B * k2]));            // conj(y) . out
+                const float2 ob = t_b[b + B * k2];
+                const cx e = cxmulc(y[k2], from2(make_float2(ob.x * INV_M, ob.y * INV_M)));            // conj(y) . b_k / m
                 const unsigned off = (unsigned)__builtin_amdgcn_sbfe((int)~obits, k2, 1);
                 buf_st<true>(make_rsrc(b_out + (int64_t)(B * k2) * d.out_sj), l_out | off, 0, to2(e));
             }
@@ -677,10 +680,14 @@ template <int A, int B, int ROUNDS>
 constexpr size_t chirp_lds_bytes() {
     constexpr int AR = (A + ROUNDS - 1) / ROUNDS, BR = (B + ROUNDS - 1) / ROUNDS;
     constexpr int EX1 = AR * B * AB_W, EX2 = BR * A * AB_W;
-    return ((size_t)(EX1 > EX2 ? EX1 : EX2) + (size_t)4 * A * B) * 8;          // exchange image + twiddles + the three chirp tables
+    return ((size_t)(EX1 > EX2 ? EX1 : EX2) + (size_t)3 * A * B) * 8;          // exchange image + twiddles + the chirp and its transform
 }
-// exchange rounds of the chirp-z kernel: two where that lets a second workgroup onto the CU (80 KB each), else one
+// exchange rounds of the chirp-z kernel: as many (up to three) as let one more workgroup onto the CU's 160 KB, else one
 template <int A, int B>
-constexpr int chirp_rounds() { return (chirp_lds_bytes<A, B, 1>() > 80 * 1024 && chirp_lds_bytes<A, B, 2>() <= 80 * 1024) ? 2 : 1; }
+constexpr int chirp_rounds() {
+    constexpr size_t L1 = chirp_lds_bytes<A, B, 1>(), L2 = chirp_lds_bytes<A, B, 2>(), L3 = chirp_lds_bytes<A, B, 3>(), CU = 160 * 1024;
+    constexpr int w1 = (int)(CU / L1), w2 = (int)(CU / L2), w3 = (int)(CU / L3);
+    return (w2 > w1 && w2 <= 3) ? ((w3 > w2 && w3 <= 3) ? 3 : 2) : 1;
+}
 
 }  // namespace anyfft
