@@ -46,10 +46,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
-PMC_SUMMARIES = {4: os.path.join("profiles", "r05_cfg4_pmc_traffic.json"),
-                 2: os.path.join("profiles", "r05_cfg2_pmc_traffic.json"),
-                 3: os.path.join("profiles", "r05_cfg3_pmc_traffic.json"),
-                 5: os.path.join("profiles", "r05_cfg5_pmc_traffic.json")}
+PMC_SUMMARIES = {4: os.path.join("profiles", "r06_cfg4_pmc_traffic.json"),
+                 2: os.path.join("profiles", "r06_cfg2_pmc_traffic.json"),
+                 3: os.path.join("profiles", "r06_cfg3_pmc_traffic.json"),
+                 5: os.path.join("profiles", "r06_cfg5_pmc_traffic.json")}
 PMC_NOTE = " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE x2 per the gfx950 note)"
 
 

@@ -51,28 +51,43 @@ def test_array_roundtrips(hip, n):
 
 
 def test_large_arrays_are_placed_by_probing(hip):
-    """arrays of at least tuning['placement_min_bytes'] are allocated tuning['placement_candidates'] times, each candidate timed by
-    ig_probe_placement (the write pattern of a pass that steps megabytes per element) and the fastest kept; the probe destroys the
-    contents, so it must run before anything is written: zero_array still returns zeros, copy_array the host's values, and the
-    losers are freed (mem_usage does not grow by more than the array)."""
+    """arrays of at least tuning['placement_min_bytes'] are placed by probing (ig_probe_placement: the write pattern of a pass that steps
+    megabytes per element): as the best-placed window, at 1 GB steps, of ONE allocation of the array + tuning['placement_window_gb'] GB
+    (round 6) -- or, without a window, as the best of tuning['placement_candidates'] allocations (round 5).  The probe destroys the
+    contents, so it runs before anything is written: zero_array still returns zeros, copy_array the host's values; freeing a windowed
+    array frees its whole allocation."""
     old = dict(hip.tuning)
     try:
         hip.tuning['placement_min_bytes'] = 32 << 20
-        hip.tuning['placement_candidates'] = 3
         n = (48 << 20) // 8
+        # the window of one allocation
+        hip.tuning['placement_window_gb'] = 2
+        free0 = hip.mem_info()[0]
+        before = len(hip._placement_log)
+        z = hip.zero_array((n,), C64)
+        assert len(hip._placement_log) == before + 1
+        nbytes, times, chosen = hip._placement_log[-1]
+        assert nbytes == n * 8 and len(times) == 3 and chosen == min(times) and chosen > 0
+        assert (z._arr - z._alloc_base) % (1 << 30) == 0 and 0 <= z._arr - z._alloc_base <= 2 << 30
+        assert not z.to_host().any()
+        x = rand64c(n, seed=3)
+        x_d = hip.copy_array(x)
+        np.testing.assert_equal(x_d.to_host(), x)
+        del z, x_d
+        hip.barrier()
+        assert hip.mem_info()[0] >= free0 - (64 << 20)          # both allocations (2 GB + 48 MB each) are gone
+        # the best of three allocations
+        hip.tuning['placement_window_gb'] = 0
+        hip.tuning['placement_candidates'] = 3
         before = len(hip._placement_log)
         z = hip.zero_array((n,), C64)
         assert len(hip._placement_log) == before + 1
         nbytes, cands, chosen = hip._placement_log[-1]
         assert nbytes == n * 8 and len(cands) == 3 and chosen == min(cands) and chosen > 0
         assert not z.to_host().any()
-        x = rand64c(n, seed=3)
-        x_d = hip.copy_array(x)
-        assert len(hip._placement_log) == before + 2
-        np.testing.assert_equal(x_d.to_host(), x)
         hip.tuning['placement_candidates'] = 1
         hip.zero_array((n,), C64)
-        assert len(hip._placement_log) == before + 2           # plain allocation
+        assert len(hip._placement_log) == before + 1           # plain allocation
     finally:
         hip.tuning.clear()
         hip.tuning.update(old)
