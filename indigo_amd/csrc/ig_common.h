@@ -34,7 +34,6 @@ struct ig_ctx {
     // plan options (ig_set_option): which transform kernels a NEW plan may use.  0 = all; 1 = no register-resident A x B passes
     // (their lengths fall back to the multi-stage LDS kernel); 2 = only the one-stage-per-launch generic kernel
     int          opt_fft_kernels = 0;
-    int          opt_fft_touch_table = 0;   // lab (round 6): the cropped z pass is preceded by a kernel that reads the support table (memory-side cache warm)
     bool         bricks_attr = false;     // the brick-binned gridding kernel's dynamic-LDS opt-in was applied on this device
     bool         fft3d_attr = false;      // the two-launch 256^3 transform's dynamic-LDS opt-in was applied on this device
     bool         fft_w32_attr = false;    // the 32-column FFT kernels' dynamic-LDS opt-in was applied on this device

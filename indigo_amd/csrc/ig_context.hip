@@ -195,7 +195,6 @@ int ig_set_option(ig_ctx* ctx, const char* name, int64_t value) {
         ctx->opt_fft_kernels = (int)value;
         return IG_OK;
     }
-    if (std::string(name) == "fft.touch_table") { ctx->opt_fft_touch_table = value != 0; return IG_OK; }
     return ig_fail(ctx, IG_ERR_ARG, "ig_set_option: unknown option '%s'", name);
 }
 

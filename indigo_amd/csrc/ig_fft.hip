@@ -1925,12 +1925,6 @@ static int exec_padded_layout2(ig_fft* p, const float2* x, int64_t x_bstride, co
     return IG_OK;
 }
 
-// lab (round 6, fft.touch_table): read a support table once so that the pass behind finds it in the memory-side cache
-__global__ void k_touch_table(const uint4* __restrict__ p, size_t n) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { const uint4 v = p[i]; asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); }
-}
-
 // phases: bit 0 = the z pass (whole grid), bit 1 = the y and x passes, restricted to the image planes z0 <= z' < z1
 static int exec_cropped_layout2(ig_fft* p, const float2* y, const float2* w, float2* x, float2* work, const short2* support,
                                 bool sum_coils = false, int phases = 3, int64_t z0 = 0, int64_t z1 = -1) {
@@ -1955,10 +1949,6 @@ static int exec_cropped_layout2(ig_fft* p, const float2* y, const float2* w, flo
         d.tile_range = support; d.tile_range_mode = 2; d.tile_range_k1 = snt; d.tile_shift = sshift;
         if (support) { d.tile_bits = reinterpret_cast<const uint32_t*>(support + n1 * snt + snt); d.tile_words = p->zw_in; }
         if (support) d.k1_range = support + n1 * snt;                         // ky the y pass will never read
-        if (support && ctx->opt_fft_touch_table) {       // lab: ranges, ky hulls and the input-side bitmaps read once just before the pass
-            const size_t bytes = (size_t)(n1 * snt + snt) * 4 + (size_t)(n1 * snt) * p->zw_in * 4;
-            hipLaunchKernelGGL(k_touch_table, dim3((unsigned)((bytes / 16 + 255) / 256)), dim3(256), 0, ctx->stream, reinterpret_cast<const uint4*>(support), bytes / 16);
-        }
         if (int rc = launch_pass(ctx, p->axis[2], d, false, 0)) return rc;
     }
     if (!(phases & 2) || nz <= 0) return IG_OK;
