@@ -112,11 +112,20 @@ class HipBackend(Backend):
         #                 times, probed (ig_probe_placement) and the best-placed candidate kept; 1 = plain allocation
         #   cg_graph      HipBackend.cg replays a block of iterations as one HIP graph launch (ig_graph_*).  Off: measured on the headline
         #                 problem the replay saves 0.03 ms of a 6.89 ms iteration and recording costs 5 ms per solve (profiles/r05_cg_graph_ab.log)
+        #   placement_window_gb   (round 6) a large array is a window of ONE allocation that many GB larger, placed at the best-probing 1 GB step
+        #   separable / sep_gather / sep_scatter   the gridding matrix in separable form (one record per sample) and the kernels that compute
+        #                 their taps from it: forward on every even grid; adjoint (shares) for `shares` coil counts from `shares_min_tw` taps
+        #                 per axis on (kernel half-width > 2: below that the stored-tap bricks are faster)
+        #   share_shape   per coil count: (grid lines, slabs, heavy-brick piece, shares per run).  The PIECE bounds how many samples a wave sums
+        #                 into one float32 image before it adds it to the grid: pieces of 1024 shares put the evaluation 2.1e-5 from the float64
+        #                 one on an ill-conditioned problem (oversampling 1.25, half-width 3: the k-space centre's sum leaks to the image's edge,
+        #                 where the roll-off correction is large); 128: 4.7 ... 6.1e-6 over four runs, the stored-tap scatter 4.8 ... 7.6e-6 (the
+        #                 order of the float atomics differs from run to run), 0.95 against 0.98 ms (profiles/r06_share_pieces.txt)
         self._placement_log = []          # (bytes, candidate probe times in ms, chosen) of every array placed by probing
         self.tuning = dict(placement_candidates=3, placement_min_bytes=1 << 31, placement_window_gb=8, cg_graph=False, bricks=(4, 8), slots=(1, 2), slot_shape=(4, 4, 256, 64), support_tile={8: 4, 4: 8}, brick_shape={8: (2, 2, 4096, 4096), 4: (2, 4, 4096, 4096)}, xrows=True, runs=True, wide_bricks=True,
                            wide_brick_shape=(2, 2), wide_task_shape=(8192, 2048),
                            # round 6: gridding from the separable form of the matrix (one record per sample, taps computed)
-                           separable=True, sep_gather=True, sep_scatter=True, shares=(4, 8), shares_min_tw=6, share_shape={8: (4, 4, 1024, 1024), 4: (4, 4, 1024, 1024)})
+                           separable=True, sep_gather=True, sep_scatter=True, shares=(4, 8), shares_min_tw=6, share_shape={8: (4, 4, 128, 1024), 4: (4, 4, 128, 1024)})
 
     def __del__(self):
         try:

@@ -158,3 +158,22 @@ def test_adjoint_shares_write_only_flagged_segments(hip, NC, tile):
     own = cell_flag & ~np.isin(brick_of, np.fromiter(shb, dtype=np.int64, count=len(shb)))
     assert np.array_equal(outs[0][own], outs[1][own])
     assert rel_err(outs[1][cell_flag], outs[0][cell_flag]) < 2e-6
+
+
+def test_default_share_pieces_are_short(hip):
+    """a heavy brick of the k-space centre is cut into pieces of at most 128 shares by default: a wave sums a piece into ONE float32 brick
+    image before it adds it to the grid, and pieces of 1024 shares put an ill-conditioned evaluation (oversampling 1.25, half-width 3) 2.1e-5
+    from the float64 one where 128 give 5e-6 (profiles/r06_share_pieces.txt); the task list of a problem with a hot centre obeys it"""
+    assert all(v[2] <= 128 for v in hip.tuning['share_shape'].values())
+    p = _problem((32, 32, 32), 2.0, 3, nspokes=601, edge=False)
+    sep = p.fused_interp_sep(1)
+    A_d = hip.csr_matrix(hip, p.fused_interp(1))
+    A_d.set_grid_interleaved(True)
+    A_d.set_grid_separable(sep)
+    bm, bs, chunk, run = hip.tuning['share_shape'][8]
+    A_d.set_grid_shares(8, bm, bs, chunk, run)
+    sh = A_d._shares_by[8]
+    tasks = sh['tasks'].to_host().reshape(-1, 4)[:sh['ntasks']]
+    shared = (tasks[:, 3] >> 16) & 1
+    assert sh['nshared'] > 0 and shared.any()
+    assert (tasks[shared == 1, 1] - tasks[shared == 1, 0]).max() <= chunk

@@ -5,7 +5,7 @@
 # summaries are in profiles/); B = per-rank shares, CG, the recipe's trees, osf 1.25; C = coil counts, the reference driver's default grid,
 # plain transforms, configs 1-3 alone, the self-launch rehearsals.
 R=${1:-r06}
-PART=${2:-AB}
+PART=${2:-AB}          # A, D, B, C as below; W = the width-3 subset of A and C
 mkdir -p gpurun_out
 if [[ $PART == *A* ]]; then
 timeout -k 10 300 tools/profile_config.sh ${R}_cfg4 || exit 1
@@ -16,6 +16,16 @@ timeout -k 10 300 tools/profile_config.sh ${R}_cfg2 --config 2 || exit 1
 timeout -k 10 300 tools/profile_config.sh ${R}_cfg4_w3 --width 3 --steps 5 || exit 1
 timeout -k 10 400 tools/profile_config.sh ${R}_cfg4_dense --spokes-scale 8 --steps 5 || exit 1
 cp gpurun_out/${R}_cfg4_pmc_traffic.json gpurun_out/${R}_cfg5_pmc_traffic.json gpurun_out/${R}_cfg3_pmc_traffic.json gpurun_out/${R}_cfg2_pmc_traffic.json profiles/      # bench.py reads the PMC traffic from profiles/
+fi
+if [[ $PART == *W* ]]; then
+# (round 6) only what depends on the share format: the width-3 profile and bench lines
+timeout -k 10 300 tools/profile_config.sh ${R}_cfg4_w3 --width 3 --steps 5 || exit 1
+timeout -k 10 400 python bench.py --image 480,208,308 --osf 640/480 --width 3 --steps 10 --no-extras --no-cpu-baseline --parity > gpurun_out/${R}_bench_width3_default_grid.json 2> gpurun_out/${R}_bench_width3_default_grid.log || exit 1
+python -c "import json;d=json.load(open('gpurun_out/${R}_bench_width3_default_grid.json'));print('640x277x410 width 3', d['ms_per_step'], d['parity_rel_err'])"
+timeout -k 10 300 python bench.py --width 3 --steps 10 --no-extras --no-cpu-baseline --parity > gpurun_out/${R}_bench_width3.json 2> gpurun_out/${R}_bench_width3.log || exit 1
+python -c "import json;d=json.load(open('gpurun_out/${R}_bench_width3.json'));print('headline width 3', d['ms_per_step'], d['parity_rel_err'])"
+timeout -k 10 300 python bench.py --width 3 --osf 1.25 --steps 10 --no-extras --no-cpu-baseline --parity > gpurun_out/${R}_bench_width3_osf125.json 2> gpurun_out/${R}_bench_width3_osf125.log || exit 1
+python -c "import json;d=json.load(open('gpurun_out/${R}_bench_width3_osf125.json'));print('osf 1.25 width 3', d['ms_per_step'], d['parity_rel_err'])"
 fi
 if [[ $PART == *D* ]]; then
 # the default line as the driver runs it (headline + config 5 + configs 2 and 3 + the dense-trajectory extra), after part A's PMC
