@@ -122,7 +122,7 @@ class HipBackend(Backend):
         #                 where the roll-off correction is large); 128: 4.7 ... 6.1e-6 over four runs, the stored-tap scatter 4.8 ... 7.6e-6 (the
         #                 order of the float atomics differs from run to run), 0.95 against 0.98 ms (profiles/r06_share_pieces.txt)
         self._placement_log = []          # (bytes, candidate probe times in ms, chosen) of every array placed by probing
-        self.tuning = dict(placement_candidates=3, placement_min_bytes=1 << 31, placement_window_gb=8, cg_graph=False, bricks=(4, 8), slots=(1, 2), slot_shape=(4, 4, 256, 64), support_tile={8: 4, 4: 8}, brick_shape={8: (2, 2, 4096, 4096), 4: (2, 4, 4096, 4096)}, xrows=True, runs=True, wide_bricks=True,
+        self.tuning = dict(placement_candidates=3, placement_min_bytes=1 << 31, placement_window_gb=8, placement_window_allocs=2, cg_graph=False, bricks=(4, 8), slots=(1, 2), slot_shape=(4, 4, 256, 64), support_tile={8: 4, 4: 8}, brick_shape={8: (2, 2, 4096, 4096), 4: (2, 4, 4096, 4096)}, xrows=True, runs=True, wide_bricks=True,
                            wide_brick_shape=(2, 2), wide_task_shape=(8192, 2048),
                            # round 6: gridding from the separable form of the matrix (one record per sample, taps computed)
                            separable=True, sep_gather=True, sep_scatter=True, shares=(4, 8), shares_min_tw=6, share_shape={8: (4, 4, 128, 1024), 4: (4, 4, 128, 1024)})
@@ -227,40 +227,61 @@ class HipBackend(Backend):
             return ptr.value
 
         def _malloc_window(self, slack_gb):
-            """A large array as the best-placed WINDOW of one allocation (round 6).  The passes that step megabytes per element run
-            3 ... 6 % faster or slower with where their array lies -- and that does not only differ from allocation to
-            allocation: inside ONE allocation the placement probe's time changes smoothly with the offset, by 10 % over 7 GB
-            (profiles/r06_placement_offsets.txt: 3.23 ms at the start of an allocation, 2.90 ms 6 - 7 GB in; a badly placed
-            allocation, 3.69 ms, recovers to 3.05 ms 10 GB in).  So: ONE allocation of nbytes + slack_gb GB, the probe
-            (ig_probe_placement) on the window at every GB step, the fastest window kept.  Against three candidate allocations: at
-            most slack_gb GB held beyond the array instead of three times its size for a moment, and a better placement than the best
-            whole allocation.  None (the caller falls back) when the device has no room for the slack."""
+            """A large array as the best-placed WINDOW of an allocation (round 6).  The passes that step megabytes per element run
+            3 ... 6 % faster or slower with where their array lies -- from allocation to allocation (every other
+            process or so gets a slow first one: 3.6 - 3.7 ms in the placement probe against 3.2), and inside ONE allocation the
+            probe's time changes smoothly with the offset, by 10 % over 7 GB (profiles/r06_placement_offsets.txt: 3.23 ms at the
+            start of an allocation, 2.90 ms 6 - 7 GB in; a slow allocation stays at 3.69 ms for 5 GB and recovers to 3.05 ms 10 GB
+            in).  So: an allocation of nbytes + slack_gb GB, the probe (ig_probe_placement) on the window at every GB step; then --
+            while the device has room -- a SECOND such allocation (`placement_window_allocs`), because no window of a slow allocation
+            is as good as a fast one's; the fastest window of either is kept and the other allocation freed.  At most one extra
+            allocation for a moment (three whole candidates in round 5) and slack_gb GB held beyond the array.  None (the caller
+            falls back) when the device has no room for the slack."""
             b = self._backend
             GBs = 1 << 30
-            free, total = ctypes.c_size_t(), ctypes.c_size_t()
-            if b._L.ig_mem_info(b._ctx, ctypes.byref(free), ctypes.byref(total)) != 0 or free.value < self.nbytes + (slack_gb + 4) * GBs:
-                return None
-            base = ctypes.c_void_p()
-            if b._L.ig_malloc(b._ctx, self.nbytes + slack_gb * GBs, ctypes.byref(base)) != 0:
-                return None
-            times = []
+            nalloc = max(1, int(b.tuning.get('placement_window_allocs', 2)))
+            worst = b.tuning.get('placement_pick') == 'worst'
+            cands = []          # (best time, base, pick, times)
             try:
-                for off in range(slack_gb + 1):
-                    ms = ctypes.c_double(0.0)
-                    b._check(b._L.ig_probe_placement(b._ctx, ctypes.c_void_p(base.value + off * GBs), self.nbytes, ctypes.byref(ms)), "ig_probe_placement")
-                    times.append(ms.value)
-                # (the first window may have been timed while the clocks were still coming up: once more)
-                ms = ctypes.c_double(0.0)
-                b._check(b._L.ig_probe_placement(b._ctx, base, self.nbytes, ctypes.byref(ms)), "ig_probe_placement")
-                times[0] = min(times[0], ms.value)
+                for _ in range(nalloc):
+                    free, total = ctypes.c_size_t(), ctypes.c_size_t()
+                    # (a further allocation only while the device has room for it and as much again: another process on the same GPU
+                    # must not fail because of a transient candidate)
+                    need = (self.nbytes + (slack_gb + 4) * GBs) if not cands else 2 * (self.nbytes + slack_gb * GBs)
+                    if b._L.ig_mem_info(b._ctx, ctypes.byref(free), ctypes.byref(total)) != 0 or free.value < need:
+                        break
+                    base = ctypes.c_void_p()
+                    if b._L.ig_malloc(b._ctx, self.nbytes + slack_gb * GBs, ctypes.byref(base)) != 0:
+                        break
+                    cands.append([None, base.value, 0, []])
+                    times = []
+                    for off in range(slack_gb + 1):
+                        ms = ctypes.c_double(0.0)
+                        b._check(b._L.ig_probe_placement(b._ctx, ctypes.c_void_p(base.value + off * GBs), self.nbytes, ctypes.byref(ms)), "ig_probe_placement")
+                        times.append(ms.value)
+                    if len(cands) == 1:
+                        # (the first window may have been timed while the clocks were still coming up: once more)
+                        ms = ctypes.c_double(0.0)
+                        b._check(b._L.ig_probe_placement(b._ctx, base, self.nbytes, ctypes.byref(ms)), "ig_probe_placement")
+                        times[0] = min(times[0], ms.value)
+                    pick = int(np.argmax(times)) if worst else int(np.argmin(times))
+                    cands[-1] = [times[pick], base.value, pick, times]
             except Exception:
-                b._L.ig_free(b._ctx, base)
+                for c in cands:
+                    b._L.ig_free(b._ctx, ctypes.c_void_p(c[1]))
                 raise
-            pick = int(np.argmax(times)) if b.tuning.get('placement_pick') == 'worst' else int(np.argmin(times))
-            self._alloc_base = base.value
-            b._placement_log.append((self.nbytes, [round(t, 4) for t in times], round(times[pick], 4)))
-            log.debug("placement: %d bytes, windows at +0 .. +%d GB %s ms -> +%d GB", self.nbytes, slack_gb, [round(t, 4) for t in times], pick)
-            return base.value + pick * GBs
+            if not cands:
+                return None
+            keep = (max if worst else min)(range(len(cands)), key=lambda i: cands[i][0])
+            for i, c in enumerate(cands):
+                if i != keep:
+                    b._L.ig_free(b._ctx, ctypes.c_void_p(c[1]))
+            t, base, pick, times = cands[keep]
+            self._alloc_base = base
+            b._placement_log.append((self.nbytes, [[round(v, 4) for v in c[3]] for c in cands], round(t, 4)))
+            log.debug("placement: %d bytes, windows at +0 .. +%d GB of %d allocation(s) %s ms -> allocation %d, +%d GB", self.nbytes, slack_gb, len(cands),
+                      [[round(v, 4) for v in c[3]] for c in cands], keep, pick)
+            return base + pick * GBs
 
         def _malloc_best_placed(self, ncand):
             """A large array (a scratch arena, a grid): allocate up to `ncand` candidates, time the library's placement probe on each
