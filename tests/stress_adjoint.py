@@ -43,11 +43,11 @@ def rel(a, b):
 
 
 class Harness(object):
-    def __init__(self, hip, image=160, coils=7, chunk=2, nspokes=300, nreadout=256, oversamp=1.6, seed=5, log=print):
+    def __init__(self, hip, image=160, coils=7, chunk=2, nspokes=300, nreadout=256, oversamp=1.6, seed=5, log=print, width=2):
         from indigo_amd.sense import SenseProblem
         from indigo_amd.util import rand64c
         self.hip, self.log = hip, log
-        self.p = SenseProblem.synthetic((image,) * 3, coils, nspokes=nspokes, nreadout=nreadout, width=2, ntable=128,
+        self.p = SenseProblem.synthetic((image,) * 3, coils, nspokes=nspokes, nreadout=nreadout, width=width, ntable=128,
                                         oversamp=oversamp, seed=seed, lazy_maps=True)
         self.chunk = chunk
         self.k = rand64c(self.p.T * coils, 1, seed=2)
@@ -86,6 +86,12 @@ class Harness(object):
             sl = M._format('_slots', nc, exact=True)
             br = M._format('_bricks', nc, exact=True)
             fmt = sl if sl is not None else br
+            # (round 6) wide gridding kernels take the share scatter on the matrix cores (ig_grid_scatter_sep): its own bricks (16 x 4 x 4),
+            # its own shared pieces; the rows of its shared table start with the brick id
+            shr = getattr(M, '_shares_by', {}).get(nc) if (getattr(M, '_sep', None) is not None and hip.tuning.get('sep_scatter', True)) else None
+            if shr is not None:
+                fmt = dict(nshared=shr['nshared'], bm=shr['bm'], bs=shr['bs'],
+                           shared=hip.copy_array(np.ascontiguousarray(shr['shared'].to_host().reshape(-1, 4)[:max(shr['nshared'], 1), 0].astype(np.int32))))
             shared = np.zeros((n1, n2, nt), dtype=bool)                  # segments of bricks whose pieces add with atomics
             if fmt is not None and fmt['nshared']:
                 sb = fmt['shared'].to_host()[:fmt['nshared']].astype(np.int64)
@@ -97,7 +103,7 @@ class Harness(object):
                         for xs in range(16 // tile):
                             shared[bsi * bs + is_, bmi * bm + im, bx * (16 // tile) + xs] = True
             self.info.append(dict(nc=nc, real=ch.shape[0] // p.T, tree=tree, tile=tile, flag=flag,
-                                  fmt='slots' if (fmt is sl and sl is not None) else 'bricks' if fmt is not None else 'gather',
+                                  fmt='shares' if shr is not None else 'slots' if (fmt is sl and sl is not None) else 'bricks' if fmt is not None else 'gather',
                                   shared=shared, layout=Z._layout))
 
     def chunk_rows(self, i):
@@ -268,17 +274,18 @@ def main():
     ap.add_argument("--image", type=int, default=160)
     ap.add_argument("--coils", type=int, default=7)
     ap.add_argument("--chunk", type=int, default=2)
+    ap.add_argument("--width", type=float, default=2, help="half-width of the gridding kernel (3: the share scatter on the matrix cores)")
     ap.add_argument("--no-oracle", action="store_true")
     a = ap.parse_args()
     if a.procs > 1:                         # fresh processes, one after the other; this parent never touches the GPU
         rc = 0
         for pi in range(a.procs):
             cmd = [sys.executable, os.path.abspath(__file__), "--reps", str(a.reps), "--idle", str(a.idle), "--rebuild", str(a.rebuild),
-                   "--image", str(a.image), "--coils", str(a.coils), "--chunk", str(a.chunk)] + (["--no-oracle"] if a.no_oracle or pi else [])
+                   "--image", str(a.image), "--coils", str(a.coils), "--chunk", str(a.chunk), "--width", str(a.width)] + (["--no-oracle"] if a.no_oracle or pi else [])
             print("== process %d of %d" % (pi + 1, a.procs), flush=True)
             rc |= subprocess.call(cmd)
         sys.exit(rc)
-    f = run(a.reps, idle=a.idle, rebuild=a.rebuild, oracle=not a.no_oracle, image=a.image, coils=a.coils, chunk=a.chunk,
+    f = run(a.reps, idle=a.idle, rebuild=a.rebuild, oracle=not a.no_oracle, image=a.image, coils=a.coils, chunk=a.chunk, width=(int(a.width) if a.width == int(a.width) else a.width),
             log=lambda s: print(s, flush=True))
     print("stress_adjoint: %d deviations in %d evaluations" % (len(f), a.reps), flush=True)
     sys.exit(1 if f else 0)

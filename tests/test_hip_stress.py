@@ -37,6 +37,23 @@ def test_adjoint_of_eight_coil_bricks_is_bitwise_repeatable(hip):
     assert not findings, "\n".join(findings)
 
 
+def test_adjoint_of_shares_on_the_matrix_cores_is_bitwise_repeatable(hip):
+    """round 6: the same at kernel half-width 3 (the reference's default), where the 8-coil tree scatters (sample, brick) shares with computed
+    taps on the MFMA pipe (k_grid_scatter_mfma, bricks of 16 x 4 x 4 cells in registers): bit for bit on every brick no shared piece touches,
+    unflagged segments still NaN, the cropped transform of the poisoned grid bit for bit"""
+    import stress_adjoint
+    h = stress_adjoint.Harness(hip, coils=8, chunk=8, width=3, log=lambda s: None)
+    assert [inf['fmt'] for inf in h.info] == ['shares']
+    h.make_references(None)
+    findings = []
+    for it in range(10):
+        if it == 5:
+            h.build()
+        findings += h.check(it)
+    hip._scratch = None
+    assert not findings, "\n".join(findings)
+
+
 @pytest.mark.parametrize("coils,chunk,widths", [(6, 4, [4, 2]), (7, 4, [4, 4])])
 def test_adjoint_of_chunks_of_different_widths_is_bitwise_repeatable(hip, oracle_backend, coils, chunk, widths):
     """Chunks of DIFFERENT widths under one VStack -- 6 coils as 4 + 2: the brick rounds of the 4-wide chunk write by the 8-point
