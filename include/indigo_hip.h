@@ -542,6 +542,17 @@ int  ig_fft_plan_padded(ig_ctx* ctx, const int64_t* dims, const int64_t* box_lo,
  * (16 by default; 8, 4 or 2 as long as coils * tile >= 16).  The table then has n0/tile entries per (ky) row in each of its
  * three parts; a finer table flags fewer grid bytes (BASELINE config 4: 30.5 % of the grid at 16, 22.2 % at 8, 16.4 % at 4).   */
 int  ig_fft_set_support_tile(ig_fft* plan, int tile);
+/* (round 6) A circular shift by `shift` points on the IMAGE side of a y or z axis of a coil-interleaved (layout 2) padded plan --
+ * equivalently the modulation exp(2 pi i k shift / n) on its k-space side:
+ *     ig_fft_exec_padded            Y[k] = exp(+2 pi i k shift / n) * FFT(zeropad(...))[k]        along that axis
+ *     ig_fft_exec_cropped[_sum...]  x    = crop(IFFT(exp(-2 pi i k shift / n) * Y))               (its adjoint)
+ * This is what the reference's centred transform (Backend.fftc_mod, indigo/backends/backend.py:352-366: exp(2 pi i (k - c/2) c / n),
+ * c = n // 2) puts on an ODD axis; on an even axis it is the sign (-1)^k, which a gridding matrix absorbs in its weights.  Folded
+ * into the transform pass, the gridding matrix of a grid with odd axes keeps real weights (8-byte entries, separable records).
+ * Only chirp-z axes (ig_fft_padded_axis_kind == 5: the odd lengths int(N * osf) produces have a large prime factor more often than
+ * not -- 277) take it: the shift moves the origin of their input (forward) or output (inverse) weights and of the convolution kernel,
+ * at no cost per pass.  IG_ERR_UNSUPPORTED on any other axis (shift 0 is always accepted).                                          */
+int  ig_fft_set_axis_shift(ig_fft* plan, int axis, int64_t shift);
 int  ig_fft_support_words(int64_t n2, int* zw_in, int* zw_out);        /* host; IG_ERR_UNSUPPORTED: no zero-pad-aware z pass */
 /* what ig_fft_plan_padded would run an axis of n points with: 3 = the power-of-two kernel (256, 512; any layout), 4 = the A x B
  * kernel (smooth lengths 128 ... 640; coil-interleaved layout), 5 = chirp-z (Bluestein) over an A x B length m >= 2 n - 1 for

@@ -97,6 +97,7 @@ PROTOTYPES = {
     "ig_ccsrmm_t_bricks_wide_grid": (c_int, [c_void_p, c_int64, c_int64, c_float, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                              c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int]),
     "ig_fft_set_support_tile": (c_int, [c_void_p, c_int]),
+    "ig_fft_set_axis_shift": (c_int, [c_void_p, c_int, c_int64]),
     "ig_csr_runs_build":  (c_int, [c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_int)]),
     "ig_ccsrmm_xrows_runs": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                      c_void_p, c_int64, c_float, c_float, c_void_p, c_int64, c_void_p, c_int64]),

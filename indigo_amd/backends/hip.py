@@ -122,7 +122,7 @@ class HipBackend(Backend):
         #                 where the roll-off correction is large); 128: 4.7 ... 6.1e-6 over four runs, the stored-tap scatter 4.8 ... 7.6e-6 (the
         #                 order of the float atomics differs from run to run), 0.95 against 0.98 ms (profiles/r06_share_pieces.txt)
         self._placement_log = []          # (bytes, candidate probe times in ms, chosen) of every array placed by probing
-        self.tuning = dict(placement_candidates=3, placement_min_bytes=1 << 31, placement_window_gb=8, placement_window_allocs=2, cg_graph=False, bricks=(4, 8), slots=(1, 2), slot_shape=(4, 4, 256, 64), support_tile={8: 4, 4: 8}, brick_shape={8: (2, 2, 4096, 4096), 4: (2, 4, 4096, 4096)}, xrows=True, runs=True, wide_bricks=True,
+        self.tuning = dict(placement_candidates=3, placement_min_bytes=1 << 31, placement_window_gb=8, placement_window_allocs=2, fold_odd_axes=True, real_gridding=True, cg_graph=False, bricks=(4, 8), slots=(1, 2), slot_shape=(4, 4, 256, 64), support_tile={8: 4, 4: 8}, brick_shape={8: (2, 2, 4096, 4096), 4: (2, 4, 4096, 4096)}, xrows=True, runs=True, wide_bricks=True,
                            wide_brick_shape=(2, 2), wide_task_shape=(8192, 2048),
                            # round 6: gridding from the separable form of the matrix (one record per sample, taps computed)
                            separable=True, sep_gather=True, sep_scatter=True, shares=(4, 8), shares_min_tw=6, share_shape={8: (4, 4, 128, 1024), 4: (4, 4, 128, 1024)})
@@ -690,6 +690,53 @@ class HipBackend(Backend):
         # (5 = chirp-z: lengths with a prime factor above 7 -- 277, 410: int(N * osf) of the reference's driver -- on the y and z axes)
         return kinds[0] in (3, 4) and all(k in (3, 4, 5) for k in kinds[1:])
 
+    def fold_axis_shifts(self, grid, phases):
+        """Which axes' modulation the zero-padded / cropped transform of `grid` can carry itself (round 6).  `phases`: per-axis arrays
+        ph with the k-space modulation exp(2 pi i (ph_x[kx] + ph_y[ky] + ph_z[kz])) that the gridding matrix would otherwise hold
+        (Backend.fftc_mod, indigo/backends/backend.py:352-366).  On an ODD y or z axis that is linear in k with slope c / n, c = n // 2:
+        a circular shift by c on the image side, which a chirp-z axis takes into its tables for nothing (ig_fft_set_axis_shift).
+        Returns (shifts, phases') -- the shift per axis and the phases with those axes' terms replaced by their constant, so that
+        the matrix built from phases' has real weights times one complex constant -- or (None, None) when no axis qualifies."""
+        if not self.tuning.get('fold_odd_axes', True) or phases is None or len(grid) != 3:
+            return None, None
+        shifts, out = [0, 0, 0], [np.asarray(ph, dtype=np.float64) for ph in phases]
+        for a in (1, 2):
+            n = int(grid[a])
+            ph = out[a]
+            kind = ctypes.c_int(0)
+            if n % 2 == 0 or ph.size != n or self._L.ig_fft_padded_axis_kind(n, ctypes.byref(kind)) != 0 or kind.value != 5:
+                continue
+            slope = (ph[1:] - ph[:-1]) * n                    # c for a linear phase (any constant offset)
+            c = int(round(float(slope[0]))) % n
+            lin = ph[0] + np.arange(n) * (c / n)
+            d = (ph - lin)
+            if c == 0 or np.abs(d - np.round(d)).max() > 1e-9:          # (whole turns do not matter)
+                continue
+            shifts[a] = c
+            out[a] = np.full(n, ph[0])
+        return (tuple(shifts), out) if any(shifts) else (None, None)
+
+    def split_gridding_constant(self, phases):
+        """(g, phases') with exp(2 pi i sum phases) = g * exp(2 pi i sum phases'), |g| = 1, and exp(2 pi i phases'_d[k]) = +-1 on every
+        axis -- when the modulation is a sign per axis times a constant (every even axis of a centred transform: the constant is 1 for
+        lengths divisible by four, -+i otherwise; a folded odd axis: its constant phase), and the constant is not 1.  The fused leaf then
+        builds its gridding matrix from phases' -- REAL weights: 8-byte entries, 4-byte gather values, records with gconst = 1 -- and
+        multiplies g into the per-voxel weights of the transform to its right, which are complex anyway.  (1, None) otherwise."""
+        from indigo_amd.interp import _axis_signs
+        if not self.tuning.get('real_gridding', True) or phases is None:
+            return 1.0, None
+        g, out = 1.0 + 0.0j, []
+        for ph in phases:
+            gs = _axis_signs(ph)
+            if gs is None:
+                return 1.0, None
+            g *= gs[0]
+            ph = np.asarray(ph, dtype=np.float64)
+            out.append(ph - ph[0])
+        if abs(g - 1.0) < 1e-12:
+            return 1.0, None
+        return complex(g), out
+
     def supports_single_coil_layout(self, grid):
         """the per-coil grid layouts (one coil per panel column: a left-over single coil runs without a padding coil) exist for
         power-of-two grids only"""
@@ -697,8 +744,9 @@ class HipBackend(Backend):
 
     supports_support_tile = True          # ZpadFFT / the brick scatter take support tables of 8 or 4 kx points per entry
 
-    def _padded_plan(self, grid, box_lo, box_dims, batch, layout=0, support_tile=16):
-        key = ('padded', tuple(grid), tuple(box_lo), tuple(box_dims), int(batch), int(layout), int(support_tile))
+    def _padded_plan(self, grid, box_lo, box_dims, batch, layout=0, support_tile=16, kshift=None):
+        kshift = tuple(int(v) for v in kshift) if kshift is not None else (0, 0, 0)
+        key = ('padded', tuple(grid), tuple(box_lo), tuple(box_dims), int(batch), int(layout), int(support_tile), kshift)
         if key not in self._plans:
             a3 = ctypes.c_int64 * 3
             plan, ws = ctypes.c_void_p(), ctypes.c_size_t()
@@ -707,18 +755,21 @@ class HipBackend(Backend):
                         "ig_fft_plan_padded%s" % (key,))
             if int(support_tile) != 16:
                 self._check(self._L.ig_fft_set_support_tile(plan, int(support_tile)), "ig_fft_set_support_tile")
+            for axis, c in enumerate(kshift):          # (round 6) the centred transform's modulation of an odd chirp-z axis, carried by its passes
+                if c:
+                    self._check(self._L.ig_fft_set_axis_shift(plan, axis, int(c)), "ig_fft_set_axis_shift(axis %d, %d)" % (axis, c))
             self._plans[key] = (plan, ws.value)
         return self._plans[key]
 
     def _fft_padded_workspace(self, grid, box_lo, box_dims, batch, layout=0):
         return self._padded_plan(grid, box_lo, box_dims, batch, layout)[1]
 
-    def fft_padded(self, y, x, w, grid, box_lo, box_dims, workspace=None, layout=0, support=None, support_tile=16):
+    def fft_padded(self, y, x, w, grid, box_lo, box_dims, workspace=None, layout=0, support=None, support_tile=16, kshift=None):
         C = y.shape[1]
         assert y.dtype == _C64 and x.dtype == _C64 and y.contiguous and x.contiguous
         assert y.shape[0] == int(np.prod(grid)) and x.size == int(np.prod(box_dims))
         assert w is None or (w.contiguous and w.size == x.size * C)
-        plan, ws = self._padded_plan(grid, box_lo, box_dims, C, layout, support_tile)
+        plan, ws = self._padded_plan(grid, box_lo, box_dims, C, layout, support_tile, kshift)
         assert layout == 0 or (workspace is not None and workspace.nbytes >= ws)
         self._check(self._L.ig_fft_exec_padded(plan, ctypes.c_void_p(x._arr), 0,
                                                ctypes.c_void_p(w._arr) if w is not None else None,
@@ -727,14 +778,14 @@ class HipBackend(Backend):
                                                ctypes.c_void_p(support._arr) if support is not None else None),
                     "ig_fft_exec_padded")
 
-    def ifft_cropped(self, xc, y, w, grid, box_lo, box_dims, workspace, layout=0, support=None, support_tile=16, slab=None):
+    def ifft_cropped(self, xc, y, w, grid, box_lo, box_dims, workspace, layout=0, support=None, support_tile=16, slab=None, kshift=None):
         """xc[:, c] = conj(w[:, c]) * crop(IFFT(y[:, c])).  slab (grid layout 1 only): 'z' = only the z pass; (z0, z1) = the y and x
         passes of the image planes z0..z1-1 (after one 'z' call) -- the one-coil ranks of a coil-sharded run all-reduce finished
         slabs while later ones are transformed"""
         C = y.shape[1]
         assert y.dtype == _C64 and xc.dtype == _C64 and y.contiguous and xc.contiguous
         assert xc.shape == (int(np.prod(box_dims)), C) and (layout != 2 or xc.contiguous)
-        plan, ws = self._padded_plan(grid, box_lo, box_dims, C, layout, support_tile)
+        plan, ws = self._padded_plan(grid, box_lo, box_dims, C, layout, support_tile, kshift)
         assert workspace.nbytes >= ws
         if slab is not None:
             assert layout == 1
@@ -751,7 +802,7 @@ class HipBackend(Backend):
                                                 ctypes.c_void_p(support._arr) if support is not None else None),
                     "ig_fft_exec_cropped")
 
-    def ifft_cropped_sum(self, x, y, w, grid, box_lo, box_dims, workspace, support=None, slab=None, support_tile=16):
+    def ifft_cropped_sum(self, x, y, w, grid, box_lo, box_dims, workspace, support=None, slab=None, support_tile=16, kshift=None):
         """x = sum_c conj(w[:, c]) * crop(IFFT(y[:, c])) for a coil-interleaved grid panel y (layout 2): the cropped
         transform with the coil combination folded into its last pass.
         slab: None = everything; 'z' = only the z pass; (z0, z1) = the y and x passes of the image planes z0..z1-1
@@ -759,7 +810,7 @@ class HipBackend(Backend):
         C = y.shape[1]
         assert y.dtype == _C64 and x.dtype == _C64 and y.contiguous and x.contiguous and w is not None
         assert x.size == int(np.prod(box_dims))
-        plan, ws = self._padded_plan(grid, box_lo, box_dims, C, 2, support_tile)
+        plan, ws = self._padded_plan(grid, box_lo, box_dims, C, 2, support_tile, kshift)
         assert workspace.nbytes >= ws
         sup = ctypes.c_void_p(support._arr) if support is not None else None
         if slab is None:
@@ -873,11 +924,12 @@ class HipBackend(Backend):
         indptr, indices, data = interp_csr_arrays(npts, N, width, table, coord, dtype=np.float32)
         return spp.csr_matrix((data.astype(dtype), indices, indptr), shape=(npts, int(np.prod(N, dtype=np.int64))))
 
-    def gridding_from_struct(self, s, grid_order=0):
+    def gridding_from_struct(self, s, grid_order=0, phases=None):
         """G' = interp * diag(exp(2 pi i separable phase)) * real constant (what `pics.py -O3` folds into the gridding matrix,
         examples/pics.py:104-177) in ONE native pass over the trajectory, columns numbered for the fused leaf's grid order
         (ig_interp3_fill_modulated) -- instead of a scipy product of a 5e7-nonzero matrix with two 1.3e8-entry diagonals and a
-        renumbering sort.  None for any other column scaling: the caller takes the scipy route."""
+        renumbering sort.  None for any other column scaling: the caller takes the scipy route.  `phases`: per-axis phases to use instead of
+        the description's (fold_axis_shifts: the leaf's transform carries the rest)."""
         import scipy.sparse as spp
         from indigo_amd.interp import interp_csr_arrays, interp_csr_modulated
         shape = (s.npts, int(np.prod(s.N, dtype=np.int64)))
@@ -887,10 +939,10 @@ class HipBackend(Backend):
         sep = s.colscale.separable()
         if sep is None or tuple(sep[0].shape) != tuple(s.N):
             return None
-        indptr, indices, data = interp_csr_modulated(s.npts, s.N, s.width, s.table, s.coord, sep[0].phases, sep[1], grid_order=grid_order)
+        indptr, indices, data = interp_csr_modulated(s.npts, s.N, s.width, s.table, s.coord, sep[0].phases if phases is None else phases, sep[1], grid_order=grid_order)
         return spp.csr_matrix((data, indices, indptr), shape=shape)
 
-    def gridding_sep_from_struct(self, s, grid_order=0):
+    def gridding_sep_from_struct(self, s, grid_order=0, phases=None):
         """the same G' in SEPARABLE form -- one record per sample (indigo_amd.interp.interp_sep_records) -- or None when the column
         scaling is no sign per axis times a real constant (an odd grid axis) or the kernel is wider than 8 taps"""
         from indigo_amd.interp import interp_sep_records
@@ -901,7 +953,7 @@ class HipBackend(Backend):
         sep = s.colscale.separable()
         if sep is None or tuple(sep[0].shape) != tuple(s.N):
             return None
-        return interp_sep_records(s.npts, s.N, s.width, s.table, s.coord, sep[0].phases, sep[1], grid_order=grid_order)
+        return interp_sep_records(s.npts, s.N, s.width, s.table, s.coord, sep[0].phases if phases is None else phases, sep[1], grid_order=grid_order)
 
     def inspect(self, csr):
         indptr = np.ascontiguousarray(csr.indptr, dtype=np.int32)
@@ -1118,9 +1170,11 @@ class HipBackend(Backend):
                 bs //= 2
             while xs * bm * bs > 64 and bm > 1:
                 bm //= 2
-            nb = (n0 // 16) * (nm // bm) * (ns // bs)
+            # (bricks need not divide the middle and slow axes: the part of a last brick outside the grid is never flagged below)
+            nbx, nbm, nbs = n0 // 16, -(-nm // bm), -(-ns // bs)
+            nb = nbx * nbm * nbs
             counts = np.zeros(nb, dtype=np.int32)
-            if n0 % 16 or nm % bm or ns % bs or b._L.ig_grid_shares_count(rec.shape[0], rec.ctypes.data, tw, n0, nm, ns, bm, bs, counts.ctypes.data) != 0:
+            if n0 % 16 or b._L.ig_grid_shares_count(rec.shape[0], rec.ctypes.data, tw, n0, nm, ns, bm, bs, counts.ctypes.data) != 0:
                 log.info("%s: no share format; the adjoint keeps the stored-tap routes", self._name)
                 by[int(ncols)] = None
                 return
@@ -1133,21 +1187,24 @@ class HipBackend(Backend):
             tasks, table, shared = brick_tasks(counts, ptr, int(chunk), int(run), max_bricks=64)
             # the flagged segments of every non-empty brick: bit xs + XS * (im + bm * is), from the support table's input-side bitmaps
             bricks = table[:, 0].astype(np.int64) if table.size else np.zeros(0, np.int64)
-            mask = np.full(bricks.size, np.uint64(0xffffffffffffffff) if xs * bm * bs == 64 else np.uint64((1 << (xs * bm * bs)) - 1), dtype=np.uint64)
-            if tab is not None and bricks.size:
-                nt = n0 // tile
-                tabh = np.ascontiguousarray(tab, dtype=np.int16).reshape(-1)
-                off = 2 * (ns * nt + nt)
-                bits = tabh[off:off + 2 * ns * nt * zw].view(np.uint32).reshape(ns * nt, zw)
-                nbx, nbm = n0 // 16, nm // bm
+            mask = np.zeros(bricks.size, dtype=np.uint64)
+            if bricks.size:
+                bits = None
+                if tab is not None:
+                    nt = n0 // tile
+                    tabh = np.ascontiguousarray(tab, dtype=np.int16).reshape(-1)
+                    off = 2 * (ns * nt + nt)
+                    bits = tabh[off:off + 2 * ns * nt * zw].view(np.uint32).reshape(ns * nt, zw)
                 bx, bmi, bsi = bricks % nbx, (bricks // nbx) % nbm, bricks // (nbx * nbm)
-                mask[:] = 0
                 for is_ in range(bs):
                     for im in range(bm):
-                        km = bmi * bm + im
+                        km, ks = bmi * bm + im, bsi * bs + is_
+                        inside = (km < nm) & (ks < ns)                 # (a last brick may reach beyond the grid)
+                        kmc, ksc = np.minimum(km, nm - 1), np.minimum(ks, ns - 1)
                         for x in range(xs):
-                            bit = (bits[(bsi * bs + is_) * nt + bx * xs + x, km % zw] >> (km // zw).astype(np.uint32)) & np.uint32(1)
-                            mask |= bit.astype(np.uint64) << np.uint64(x + xs * (im + bm * is_))
+                            bit = inside.astype(np.uint64) if bits is None else \
+                                (((bits[ksc * nt + bx * xs + x, kmc % zw] >> (kmc // zw).astype(np.uint32)) & np.uint32(1)).astype(np.uint64) * inside)
+                            mask |= bit << np.uint64(x + xs * (im + bm * is_))
             tab16 = np.empty((max(bricks.size, 1), 4), dtype=np.uint32)
             if bricks.size:
                 tab16[:, 0:2] = table.astype(np.uint32)

@@ -1005,11 +1005,17 @@ struct Chirp {
     float2* d_bhat[2] = {nullptr, nullptr};
     float2* d_bout[2] = {nullptr, nullptr};
     float2* d_hat_out[2] = {nullptr, nullptr};     // bhat then bout in one array (the one-launch kernel's second table)
+    // (round 6) the tables of the one-launch kernel for a transform that carries a circular shift by `shift` points on its image side
+    // (ig_fft_set_axis_shift): input weights, then [transformed kernel, output weights / m]
+    int64_t shift = 0;
+    float2* d_in_s[2] = {nullptr, nullptr};
+    float2* d_hat_out_s[2] = {nullptr, nullptr};
     AxisPlan sub;                      // the length-m axis with this axis's inner / outer extents
     bool fused = false;                // ONE launch per pass (k_fft_chirp: both length-m transforms in registers / LDS; strided axes, m = A x B)
     ~Chirp() {
         for (int d = 0; d < 2; ++d) { if (d_b[d]) (void)hipFree(d_b[d]); if (d_bhat[d]) (void)hipFree(d_bhat[d]); if (d_bout[d]) (void)hipFree(d_bout[d]);
-                                      if (d_hat_out[d]) (void)hipFree(d_hat_out[d]); }
+                                      if (d_hat_out[d]) (void)hipFree(d_hat_out[d]);
+                                      if (d_in_s[d]) (void)hipFree(d_in_s[d]); if (d_hat_out_s[d]) (void)hipFree(d_hat_out_s[d]); }
         if (sub.d_tw) (void)hipFree(sub.d_tw);
     }
 };
@@ -1424,6 +1430,58 @@ int plan_chirp(ig_ctx* ctx, AxisPlan& ax, int64_t m) {
     return IG_OK;
 }
 
+// The tables of a chirp-z axis whose zero-padded / cropped passes carry a circular shift by c points on the image side -- equivalently
+// the modulation exp(2 pi i k c / n) on the k-space side: what a centred transform puts on an ODD axis (c = n / 2 rounded down; on an even
+// axis it is a sign, which the gridding matrix absorbs).  With j' = j - c:
+//    forward   Y_k = sum_j x_j exp(-2 pi i j' k / n) = b_k sum_j (x_j b_j') conj(b)_(k - j'),      b_t = exp(-i pi t^2 / n), any integer t
+//    inverse   x_j = sum_k Y_k exp(+2 pi i j' k / n) = conj(b)_j' sum_k (Y_k conj(b)_k) b_(j' - k)     (its adjoint)
+// i.e. the same convolution with the input (forward) or output (inverse) weights and the kernel's origin moved by c.
+int plan_chirp_shift(ig_ctx* ctx, Chirp& ch, int64_t n, int64_t c) {
+    typedef std::complex<double> cd;
+    const int64_t m = ch.m;
+    for (int d = 0; d < 2; ++d) {
+        if (ch.d_in_s[d]) { (void)hipFree(ch.d_in_s[d]); ch.d_in_s[d] = nullptr; }
+        if (ch.d_hat_out_s[d]) { (void)hipFree(ch.d_hat_out_s[d]); ch.d_hat_out_s[d] = nullptr; }
+    }
+    ch.shift = c;
+    if (c == 0) return IG_OK;
+    auto bt = [n](int64_t t) { const double ang = -M_PI * (double)((t * t) % (2 * n)) / (double)n; return cd(cos(ang), sin(ang)); };
+    std::vector<double> cs((size_t)m), sn((size_t)m);
+    for (int64_t k = 0; k < m; ++k) { cs[k] = cos(2.0 * M_PI * (double)k / (double)m); sn[k] = sin(2.0 * M_PI * (double)k / (double)m); }
+    std::vector<float2> t((size_t)(2 * m));
+    for (int dir = 0; dir < 2; ++dir) {
+        // the convolution kernel h[u mod m], u = (output index) - (input index) in (-n, n)
+        std::vector<cd> h((size_t)m, cd(0, 0)), H((size_t)m);
+        for (int64_t u = -(n - 1); u <= n - 1; ++u)
+            h[(size_t)((u % m + m) % m)] = dir == 0 ? std::conj(bt(u + c)) : bt(u - c);
+        for (int64_t k = 0; k < m; ++k) {
+            cd acc(0, 0);
+            for (int64_t u = 0; u < m; ++u) {
+                if (h[u] == cd(0, 0)) continue;
+                const int64_t q = (u * k) % m;
+                acc += h[u] * cd(cs[q], -sn[q]);
+            }
+            H[k] = acc;
+        }
+        // input weights (m entries; those at and beyond n are never used: inputs there are zeros that are never loaded)
+        for (int64_t j = 0; j < m; ++j) {
+            const cd v = j < n ? (dir == 0 ? bt(j - c) : std::conj(bt(j))) : cd(0, 0);
+            t[j] = make_float2((float)v.real(), (float)v.imag());
+        }
+        IG_HIP(ctx, hipMalloc((void**)&ch.d_in_s[dir], sizeof(float2) * (size_t)m));
+        IG_HIP(ctx, hipMemcpy(ch.d_in_s[dir], t.data(), sizeof(float2) * (size_t)m, hipMemcpyHostToDevice));
+        // [transformed kernel, output weights / m]
+        for (int64_t k = 0; k < m; ++k) {
+            t[k] = make_float2((float)H[k].real(), (float)H[k].imag());
+            const cd v = k < n ? (dir == 0 ? bt(k) : std::conj(bt(k - c))) / (double)m : cd(0, 0);
+            t[m + k] = make_float2((float)v.real(), (float)v.imag());
+        }
+        IG_HIP(ctx, hipMalloc((void**)&ch.d_hat_out_s[dir], sizeof(float2) * 2 * (size_t)m));
+        IG_HIP(ctx, hipMemcpy(ch.d_hat_out_s[dir], t.data(), sizeof(float2) * 2 * (size_t)m, hipMemcpyHostToDevice));
+    }
+    return IG_OK;
+}
+
 // elementwise steps of the unfused chirp-z route (contiguous axes, lengths beyond the A x B kernel)
 __global__ void __launch_bounds__(256)
 k_chirp_pre(const float2* __restrict__ x, float2* __restrict__ W, const float2* __restrict__ b, int64_t n, int64_t m, int64_t inner, int64_t total_m) {
@@ -1456,7 +1514,8 @@ int launch_chirp_desc(ig_ctx* ctx, const AxisPlan& ax, const PassDesc& d_in) {
     PassDesc d = d_in;
     if (d.ncols == 0) return IG_OK;
     const int dir = d.inverse ? 1 : 0;
-    d.w = ch.d_b[dir]; d.w2 = ch.d_hat_out[dir];
+    d.w = ch.d_b[dir]; d.w2 = ch.d_hat_out[dir]; d.chirp_out = 0;
+    if (ch.shift) { d.w = ch.d_in_s[dir]; d.w2 = ch.d_hat_out_s[dir]; d.chirp_out = 1; }
     const int64_t tpr = (d.ext0 + anyfft::AB_W - 1) / anyfft::AB_W;
     const int64_t blocks = tpr * (d.ncols / d.ext0);
     IG_REQUIRE(ctx, blocks <= 0x7fffffffLL && d.ext1 <= 0x7fffffffLL, "ig_fft: too many tiles");
@@ -2016,6 +2075,20 @@ int ig_fft_padded_axis_kind(int64_t n, int* kind) {
     if (big > 7 && n >= 32)
         for (int64_t c = 2 * n - 1; c <= 1024; ++c) if (ab_split(c, A, B)) { *kind = 5; break; }
     return IG_OK;
+}
+
+int ig_fft_set_axis_shift(ig_fft* p, int axis, int64_t shift) {
+    if (!p) return ig_fail(nullptr, IG_ERR_ARG, "ig_fft_set_axis_shift: plan is NULL");
+    ig_ctx* ctx = p->ctx;
+    IG_REQUIRE(ctx, p->padded && p->layout == 2 && axis >= 1 && axis < p->rank, "ig_fft_set_axis_shift: the y or z axis of a zero-padded plan of the coil-interleaved layout");
+    AxisPlan& ax = p->axis[axis];
+    IG_REQUIRE(ctx, shift >= 0 && shift < ax.n, "ig_fft_set_axis_shift: shift %lld outside [0, %lld)", (long long)shift, (long long)ax.n);
+    if (shift == 0 && !(ax.kind == 5 && ax.chirp && ax.chirp->shift)) return IG_OK;
+    if (!(ax.kind == 5 && ax.chirp && ax.chirp->fused))
+        return ig_fail(ctx, IG_ERR_UNSUPPORTED, "ig_fft_set_axis_shift: axis %d (%lld points) is no one-launch chirp-z axis", axis, (long long)ax.n);
+    if (int rc = ig_set_device(ctx)) return rc;
+    IG_HIP(ctx, hipStreamSynchronize(ctx->stream));          // (tables of a pass still in flight are about to be freed)
+    return plan_chirp_shift(ctx, *ax.chirp, ax.n, shift);
 }
 
 int ig_fft_set_support_tile(ig_fft* p, int tile) {

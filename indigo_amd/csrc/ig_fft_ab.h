@@ -29,6 +29,8 @@ struct PassDesc {
     const float2* in; float2* out; const float2* w;
     // chirp-z passes (k_fft_chirp): w and w2 are ONE-dimensional tables along the transform axis (no column dependence)
     const float2* w2;
+    int chirp_out;              // k_fft_chirp: 1 = the output weights are a table of their own, w2[m ..] (an axis whose transform carries a
+                                // circular shift, ig_fft_set_axis_shift); 0 = they are the input chirp w times 1 / m
     int64_t in_sj, out_sj, w_sj;
     int64_t in_s[3], out_s[3], w_s[3];
     int64_t ext0, ext1, ncols;
@@ -556,16 +558,21 @@ k_fft_chirp(PassDesc d, const float2* __restrict__ tw) {
     float2* __restrict__ t_hat = t_b + N;
     // (round 6: the output weights b_k / m are the chirp itself times 1 / m -- no table of their own: the 6.9 KB it took at m = 864 were
     // what kept a second workgroup off the CU there, and a third at m = 560)
+    // (an axis with a circular shift folded in, ig_fft_set_axis_shift, has input weights b_(j - c) and output weights b_k: a fourth table
+    // behind the others, which the launcher adds to the dynamic LDS only then)
     constexpr float INV_M = 1.0f / (float)N;
+    const bool outtab = d.chirp_out != 0;
+    float2* __restrict__ t_o = t_hat + N;
     const int tid = threadIdx.x;
     // (requested here, written to LDS behind the first transform's loads: written on the spot the copies are a round trip of their own
     // at the head of a workgroup of which one or two fit a CU)
     constexpr int TWN = (N + AB_W * B - 1) / (AB_W * B);
-    float2 tab_mine[TWN][3];
+    float2 tab_mine[TWN][4];
 #pragma unroll
     for (int i = 0; i < TWN; ++i) {
         const int k = tid + i * AB_W * B, kk = k < N ? k : N - 1;
         tab_mine[i][0] = tw[kk]; tab_mine[i][1] = d.w[kk]; tab_mine[i][2] = d.w2[kk];
+        tab_mine[i][3] = d.w2[outtab ? N + kk : kk];          // (no branch: the load must not be waited for here)
     }
     const int b = tid / AB_W, w = tid % AB_W;
     unsigned tr, k1i, k2i;
@@ -620,7 +627,7 @@ k_fft_chirp(PassDesc d, const float2* __restrict__ tw) {
 #pragma unroll
     for (int i = 0; i < TWN; ++i) {
         const int k = tid + i * AB_W * B;
-        if (k < N) { tws[k] = tab_mine[i][0]; t_b[k] = tab_mine[i][1]; t_hat[k] = tab_mine[i][2]; }
+        if (k < N) { tws[k] = tab_mine[i][0]; t_b[k] = tab_mine[i][1]; t_hat[k] = tab_mine[i][2]; if (outtab) t_o[k] = tab_mine[i][3]; }
     }
     __syncthreads();                                   // the tables are in place (the loads above are in flight)
 #pragma unroll
@@ -642,6 +649,8 @@ k_fft_chirp(PassDesc d, const float2* __restrict__ tw) {
             for (int bb = 0; bb < B; ++bb) u[bb] = from2(lds[ab_slot<AR, B, false>(b - r * AR, bb, w)]);
         }
     }
+    const float2* __restrict__ t_ow = outtab ? t_o : t_b;          // output weights: their own table (already / m) or the chirp times 1 / m
+    const float om = outtab ? 1.0f : INV_M;
     // ---- the convolution in the frequency domain, and the second (inverse) transform, (B, A): conj, forward, conj
     if (b < A) {
         RegDFT<B, cx>::run(u);
@@ -668,8 +677,8 @@ k_fft_chirp(PassDesc d, const float2* __restrict__ tw) {
 #pragma unroll
             for (int k2 = 0; k2 < A; ++k2) {           // X[b + B k2], k2 < A: only k < n is ever kept
                 if (!((gout >> k2) & 1u)) continue;
-                const float2 ob = t_b[b + B * k2];
-                const cx e = cxmulc(y[k2], from2(make_float2(ob.x * INV_M, ob.y * INV_M)));            // conj(y) . b_k / m
+                const float2 ob = t_ow[b + B * k2];
+                const cx e = cxmulc(y[k2], from2(make_float2(ob.x * om, ob.y * om)));            // conj(y) . b_k / m
                 const unsigned off = (unsigned)__builtin_amdgcn_sbfe((int)~obits, k2, 1);
                 buf_st<true>(make_rsrc(b_out + (int64_t)(B * k2) * d.out_sj), l_out | off, 0, to2(e));
             }

@@ -429,12 +429,14 @@ inline void run_threads(int nt, F&& body) {
 
 inline bool share_geom(ShareGeom& g, int tw, int64_t n0, int64_t nm, int64_t ns, int bm, int bs) {
     auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
-    if (!(tw == 4 || tw == 6 || tw == 8) || n0 < 16 || n0 % 16 || nm < tw || ns < tw || !pow2(bm) || !pow2(bs) || bm > 16 || bs > 16 || nm % bm || ns % bs ||
+    // (bricks need not divide the middle and slow axes: the last brick of an axis is then partly outside the grid -- no share ever holds a
+    // tap there, and the caller's segment masks never flag it.  277 = 69 * 4 + 1: the reference driver's default grid)
+    if (!(tw == 4 || tw == 6 || tw == 8) || n0 < 16 || n0 % 16 || nm < tw || ns < tw || !pow2(bm) || !pow2(bs) || bm > 16 || bs > 16 ||
         n0 > 65535 || nm > 65535 || ns > 65535)
         return false;
     g.n[0] = n0; g.n[1] = nm; g.n[2] = ns;
     g.bdim[0] = 16; g.bdim[1] = bm; g.bdim[2] = bs;
-    g.nbr[0] = n0 / 16; g.nbr[1] = nm / bm; g.nbr[2] = ns / bs;
+    g.nbr[0] = n0 / 16; g.nbr[1] = (nm + bm - 1) / bm; g.nbr[2] = (ns + bs - 1) / bs;
     g.tw = tw; g.rw = sep_words(tw);
     return g.nbr[0] * g.nbr[1] * g.nbr[2] < 0x7fffffffLL;
 }
@@ -485,7 +487,7 @@ int ig_grid_gather_sep(ig_ctx* ctx, int64_t M, int64_t NC, int tw, const void* r
 int ig_grid_shares_count(int64_t M, const uint32_t* records, int tw, int64_t n0, int64_t nm, int64_t ns, int bm, int bs, int32_t* brick_shares) {
     ShareGeom g;
     if (M < 0 || (M > 0 && !records) || !brick_shares || !share_geom(g, tw, n0, nm, ns, bm, bs))
-        return ig_fail(nullptr, IG_ERR_ARG, "ig_grid_shares_count: the grid must divide into 16 x bm x bs bricks (powers of two <= 16); tw 4, 6 or 8");
+        return ig_fail(nullptr, IG_ERR_ARG, "ig_grid_shares_count: a grid of a multiple of 16 points along x, bricks of 16 x bm x bs cells (powers of two <= 16); tw 4, 6 or 8");
     const int64_t nb = g.nbr[0] * g.nbr[1] * g.nbr[2];
     const int nt = share_threads(M);
     const int64_t per = (M + nt - 1) / nt;
@@ -557,7 +559,7 @@ int ig_grid_scatter_sep(ig_ctx* ctx, int64_t M, int64_t NC, int tw, void* record
     IG_REQUIRE(ctx, ctx != nullptr, "ig_grid_scatter_sep: ctx is NULL");
     ShareGeom g;
     IG_REQUIRE(ctx, M >= 0 && M < (1LL << 28) && (NC == 4 || NC == 8) && share_geom(g, tw, n0, nm, ns, bm, bs) && bm <= 4 && bs <= 4,
-               "ig_grid_scatter_sep: 4 or 8 interleaved coils; a grid that divides into bricks of 16 x (bm <= 4) x (bs <= 4) cells; tw 4, 6 or 8");
+               "ig_grid_scatter_sep: 4 or 8 interleaved coils; a multiple of 16 points along x; bricks of 16 x (bm <= 4) x (bs <= 4) cells; tw 4, 6 or 8");
     IG_REQUIRE(ctx, support_tile == 16 || support_tile == 8 || support_tile == 4, "ig_grid_scatter_sep: support_tile 16, 8 or 4");
     IG_REQUIRE(ctx, ntasks >= 0 && ntasks <= 0x7fffffffLL && (ntasks == 0 || (tasks && brick_table && records && shares && X && Y_il)) && ldx >= M &&
                nshared >= 0 && (nshared == 0 || shared_table), "ig_grid_scatter_sep: bad task list or NULL array");
@@ -571,7 +573,7 @@ int ig_grid_scatter_sep(ig_ctx* ctx, int64_t M, int64_t NC, int tw, void* record
     while ((1 << bm_log2) < bm) ++bm_log2;
     while ((1 << bs_log2) < bs) ++bs_log2;
     const int st_log2 = support_tile == 16 ? 4 : support_tile == 8 ? 3 : 2;
-    const int nbx = (int)(n0 / 16), nbm = (int)(nm / bm);
+    const int nbx = (int)(n0 / 16), nbm = (int)((nm + bm - 1) / bm);
     const unsigned blocks = (unsigned)((ntasks + WPB - 1) / WPB);
     const size_t need = (size_t)M * NC * 8;
     int64_t gp = (M * NC + BLK - 1) / BLK;

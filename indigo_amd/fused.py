@@ -189,12 +189,14 @@ def pad_coils(w, width, interleaved=True):
 
 
 def assemble(backend, Gm, oN, N, weights_of, Cn, layout, chunks, table=None, box_lo=None, row_order=None,
-             name='SENSE-fusedFFT', zw=(16, 16), sep=None):
+             name='SENSE-fusedFFT', zw=(16, 16), sep=None, kshift=None):
     """A = KronI(C, G') * ZpadFFT, or a VStack of such trees over coil chunks sharing ONE device copy of G'.
 
     Gm          gridding matrix (T x P, complex64 CSR) with its columns in the order of `layout` (see
                 permute_grid_columns; layout 2 uses layout 1's numbering)
     sep         the same matrix in separable form (interp_sep_records, grid_order 1) or None
+    kshift      per-axis circular shifts the leaf's transform carries (HipBackend.fold_axis_shifts: Gm and sep were then built without the
+                modulation of those axes) or None
     weights_of  (lo, hi) -> weights array box + (hi - lo,) for that run of coils (maps * roll-off * modulation)
     chunks      [(lo, hi, width)] from choose_layout: width coils interleaved, hi - lo of them real
     More coils than a chunk holds (the reference's `batch` hint, indigo/operators.py:15-17,341: evaluate a wide
@@ -251,7 +253,8 @@ def assemble(backend, Gm, oN, N, weights_of, Cn, layout, chunks, table=None, box
                 # (0.62 against 0.88 ms), measured in profiles/r06_scatter_forms.txt
                 sshape = tuning.get('share_shape', {})
                 sshape = tuple(sshape.get(w, (8, 2, 1024, 1024)) if isinstance(sshape, dict) else sshape)
-                shares[w] = (pow2_divisor(oN[2], sshape[0]), pow2_divisor(oN[1], sshape[1])) + sshape[2:]
+                # (share bricks need not divide the grid: 16 x 4 x 4 also on 640 x 277 x 410)
+                shares[w] = (int(sshape[0]), int(sshape[1])) + sshape[2:]
                 if w in fine:
                     fines[w] = fine[w]
             elif interleaved and w in tuning.get('bricks', ()) and x16:
@@ -280,6 +283,8 @@ def assemble(backend, Gm, oN, N, weights_of, Cn, layout, chunks, table=None, box
         return G
 
     G_il = gridding(True) if il_widths else None
+    kskw = {'kshift': tuple(int(v) for v in kshift)} if (kshift is not None and any(kshift)) else {}
+    assert not kskw or all(w > 1 for _, _, w in chunks), "a transform that carries an axis shift exists for the coil-interleaved layout only"
     G_pc = None
     trees = []
     for lo, hi, w in chunks:
@@ -287,9 +292,9 @@ def assemble(backend, Gm, oN, N, weights_of, Cn, layout, chunks, table=None, box
         if w > 1:
             wts = pad_coils(weights_of(lo, hi), w)
             if w in fine:
-                Z = backend.ZpadFFT(oN, N, wts, box_lo=box_lo, layout=2, support=fine[w][0], support_tile=fine[w][1], name='fft*zpad*apod*maps')
+                Z = backend.ZpadFFT(oN, N, wts, box_lo=box_lo, layout=2, support=fine[w][0], support_tile=fine[w][1], name='fft*zpad*apod*maps', **kskw)
             else:
-                Z = backend.ZpadFFT(oN, N, wts, box_lo=box_lo, layout=2, support=table, name='fft*zpad*apod*maps')
+                Z = backend.ZpadFFT(oN, N, wts, box_lo=box_lo, layout=2, support=table, name='fft*zpad*apod*maps', **kskw)
             tree = backend.KronI(w, G_il) * Z
             if real < w:
                 # zero-weight padding coils: their k-space rows come last, are exact zeros on the way out and read as zeros on the way in

@@ -339,7 +339,7 @@ class ZpadFFT(MatrixFreeOperator):
     with dense arrays, and tests pin both to the reference's S' + FFT composition.
     """
 
-    def __init__(self, backend, grid_shape, box_shape, weights, box_lo=None, layout=0, support=None, support_tile=16, **kwargs):
+    def __init__(self, backend, grid_shape, box_shape, weights, box_lo=None, layout=0, support=None, support_tile=16, kshift=None, **kwargs):
         # memory order of the output grids: 0 = (x, y, z) per coil, 1 = (x, z, y) per coil, 2 = (c, x, z, y) coils interleaved
         self._layout = int(layout)
         # optional k-space support table (layout 1): int16 [z_lo, z_hi) per (kx tile of 16, ky); outside it the
@@ -348,6 +348,11 @@ class ZpadFFT(MatrixFreeOperator):
         self._support_d = None
         # kx points per entry of the support table (layout 2 on backends that take a finer table: ig_fft_set_support_tile)
         self._tile_kw = {} if int(support_tile) == 16 else {'support_tile': int(support_tile)}
+        # circular shifts on the image side of the y / z axes that the transform itself carries (layout 2, chirp-z axes: ig_fft_set_axis_shift)
+        # = the centred transform's modulation on an odd axis, which the gridding matrix to the left then does not hold
+        if kshift is not None and any(int(v) for v in kshift):
+            assert int(layout) == 2 and int(kshift[0]) == 0
+            self._tile_kw['kshift'] = tuple(int(v) for v in kshift)
         self._grid = tuple(int(s) for s in grid_shape)
         self._box = tuple(int(s) for s in box_shape)
         assert len(self._grid) == 3 and len(self._box) == 3

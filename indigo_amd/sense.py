@@ -108,9 +108,20 @@ class SenseProblem(object):
         return A
 
     # -- direct construction of the -O3 factors ------------------------------------------------
-    def fused_interp(self, layout=0):
+    def fused_interp(self, layout=0, phases=None):
         """G' = interp * mod * (1/sqrt(P)) as a complex64 CSR (T x P).
-        layout=1 indexes the grid columns in (x, z, y) memory order (see operators.ZpadFFT)."""
+        layout=1 indexes the grid columns in (x, z, y) memory order (see operators.ZpadFFT).
+        phases: per-axis phase arrays to use INSTEAD of the centred transform's modulation -- a leaf whose transform carries the
+        modulation of an odd axis itself (HipBackend.fold_axis_shifts) asks for the matrix without it; not cached under `layout`"""
+        if phases is not None:
+            key = ('folded', layout)
+            if key not in self._interp_cache:
+                P = int(np.prod(self.oN))
+                scale = np.float32(1.0) / np.sqrt(np.float32(P))
+                indptr, indices, data = interp_csr_modulated(self.T, self.oN, self.width, self.table, self.coord.reshape(3, -1, order='F'),
+                                                             phases, scale, grid_order=1 if layout == 1 else 0)
+                self._interp_cache[key] = spp.csr_matrix((data, indices, indptr), shape=(self.T, P))
+            return self._interp_cache[key]
         if layout in self._interp_cache:
             return self._interp_cache[layout]
         P = int(np.prod(self.oN))
@@ -124,16 +135,16 @@ class SenseProblem(object):
         self._interp_cache[layout] = G            # 0.6 GB per layout at 5e7 nonzeros; drop_cache() releases them
         return G
 
-    def fused_interp_sep(self, layout=1):
+    def fused_interp_sep(self, layout=1, phases=None):
         """G' in separable form (indigo_amd.interp.interp_sep_records: one record per sample -- first tap, tap counts and per-axis
         weights with the modulation's sign folded in) for the grid order of `layout`, or None when the grid's modulation is no sign
-        per axis (odd axes)"""
-        key = ('sep', layout)
+        per axis (odd axes -- unless the leaf's transform carries their modulation: `phases`, as for fused_interp)"""
+        key = ('sep', layout) if phases is None else ('sep-folded', layout)
         if key not in self._interp_cache:
             P = int(np.prod(self.oN))
             scale = np.float32(1.0) / np.sqrt(np.float32(P))
             self._interp_cache[key] = interp_sep_records(self.T, self.oN, self.width, self.table, self.coord.reshape(3, -1, order='F'),
-                                                         _mod_axis_phases(self.oN), scale, grid_order=1 if layout >= 1 else 0)
+                                                         _mod_axis_phases(self.oN) if phases is None else phases, scale, grid_order=1 if layout >= 1 else 0)
         return self._interp_cache[key]
 
     def fused_maps_T(self, coils=None):
@@ -156,17 +167,21 @@ class SenseProblem(object):
             data[:, j] = np.conj(base * self.coil_map(c).reshape(Nn, order='F'))
         return spp.csr_matrix((data.reshape(-1), indices.reshape(-1), indptr), shape=(Nn, Cn * P))
 
-    def fused_weights(self, coils=None, interleaved=False):
+    def fused_weights(self, coils=None, interleaved=False, scale=1.0):
         """w[..., c] = mod(box) * apod * maps[..., c]: the per-voxel, per-coil factor of S' (F-ordered, box + (C,)).
         interleaved: the same values and shape with a voxel's coils side by side in memory (what the coil-interleaved grid
-        layout uploads: no transposition of a 2 GB array on the way)."""
+        layout uploads: no transposition of a 2 GB array on the way).
+        scale: a complex constant multiplied in (the constant of the k-space modulation that a leaf with a real gridding matrix moves
+        over here, HipBackend.split_gridding_constant)"""
         coils = list(range(self.C) if coils is None else coils)
         from indigo_amd.backends.backend import Backend
-        base = self._interp_cache.get('weights_base')       # the same for every coil chunk of a tree (config 5: four of them)
+        bkey = 'weights_base' if complex(scale) == 1.0 else ('weights_base', complex(scale))
+        base = self._interp_cache.get(bkey)       # the same for every coil chunk of a tree (config 5: four of them)
         if base is None:
             mod = fftc_mod_box(self.oN, self.N)
             apod = rolloff3(self.oversamp, self.width, self.beta, self.N).astype(_C64)
-            base = self._interp_cache['weights_base'] = (mod * apod).astype(_C64)
+            base = (mod * apod).astype(_C64) if complex(scale) == 1.0 else (mod * (apod * complex(scale))).astype(_C64)
+            self._interp_cache[bkey] = base
         if interleaved and len(coils) > 1:
             w = np.empty(self.N[::-1] + (len(coils),), dtype=_C64).transpose(2, 1, 0, 3)
             nz, nth = self.N[2], (8 if base.size >= 1 << 20 else 1)
@@ -291,7 +306,15 @@ class SenseProblem(object):
         single_ok = getattr(backend, 'supports_single_coil_layout', lambda g: True)(self.oN)
         tuning = getattr(backend, 'tuning', {})
         layout, chunks = fused.choose_layout(Cn, chunk, layout, single_ok, tuning.get('chunk_cost'), tuning.get('chunk_pad', True))
-        Gm = self.fused_interp(1 if layout == 2 else layout)      # layout 2 = layout 1 with the coils interleaved below
+        # odd axes whose transform pass can carry the centred transform's modulation itself (chirp-z axes: a circular shift folded into
+        # the pass's tables): the gridding matrix is then built without it and keeps real weights (HipBackend.fold_axis_shifts)
+        kshift, folded, gconst = None, None, 1.0
+        if layout == 2 and hasattr(backend, 'fold_axis_shifts'):
+            kshift, folded = backend.fold_axis_shifts(self.oN, _mod_axis_phases(self.oN))
+            # ... and what is left of the modulation as (a constant) x (a sign per axis): the constant goes to the transform's weights
+            gconst, split = backend.split_gridding_constant(folded if folded is not None else _mod_axis_phases(self.oN))
+            folded = split if split is not None else folded
+        Gm = self.fused_interp(1 if layout == 2 else layout, phases=folded)      # layout 2 = layout 1 with the coils interleaved below
         table = None
         zw = fused.support_words(backend, self.oN)      # words per entry of the table's bitmaps: follows from the z pass's kernel
         if (support is None or support) and layout >= 1 and zw is not None and (layout == 2 or zw == (16, 16)):
@@ -302,9 +325,9 @@ class SenseProblem(object):
         self.last_support_zw = zw
         order = self.locality_order(Gm) if reorder and Cn <= 8 else None
         widths = {lo: w for lo, _, w in chunks}
-        A = fused.assemble(backend, Gm, self.oN, self.N, lambda lo, hi: self.fused_weights(coils[lo:hi], interleaved=(widths.get(lo, 0) > 1)), Cn,
+        A = fused.assemble(backend, Gm, self.oN, self.N, lambda lo, hi: self.fused_weights(coils[lo:hi], interleaved=(widths.get(lo, 0) > 1), scale=gconst), Cn,
                            layout, chunks, table=table, row_order=order, zw=zw,
-                           sep=self.fused_interp_sep(1) if (layout == 2 and order is None) else None)
+                           sep=self.fused_interp_sep(1, phases=folded) if (layout == 2 and order is None) else None, kshift=kshift)
         self.last_support_fine = getattr(A, '_support_fine', None)       # (table, tile) when the tree took a finer table
         return A
 

@@ -338,7 +338,18 @@ class FuseZpadFFT(Transform):
         # G' = interp * mod * scale: where the factories' description survived the recipe and the backend has a native builder, the
         # matrix is built directly in the leaf's grid order (ig_interp3_fill_modulated); else from the scipy product, renumbered
         gs = _struct(L.right)
-        Gm = b.gridding_from_struct(gs, 1 if layout >= 1 else 0) if (isinstance(gs, InterpS) and hasattr(b, 'gridding_from_struct')) else None
+        # (round 6) the modulation of an odd chirp-z axis moves from G' into the transform that the leaf to its right runs: G' keeps real weights
+        kshift, folded, gconst = None, None, 1.0
+        if layout == 2 and isinstance(gs, InterpS) and gs.colscale is not None and hasattr(b, 'fold_axis_shifts'):
+            sp = gs.colscale.separable()
+            if sp is not None and tuple(sp[0].shape) == tuple(gs.N) == tuple(grid):
+                kshift, folded = b.fold_axis_shifts(grid, sp[0].phases)
+                # ... and what is left as (a constant) x (a sign per axis): the constant goes to the transform's weights, G' is real
+                gconst, split = b.split_gridding_constant(folded if folded is not None else sp[0].phases)
+                folded = split if split is not None else folded
+        Gm = b.gridding_from_struct(gs, 1 if layout >= 1 else 0, **({'phases': folded} if folded is not None else {})) if (isinstance(gs, InterpS) and hasattr(b, 'gridding_from_struct')) else None
+        if Gm is None:
+            kshift, folded, gconst = None, None, 1.0
         if Gm is None:
             Gm = L.right._matrix.astype(np.complex64).tocsr()
             if layout >= 1:
@@ -347,9 +358,10 @@ class FuseZpadFFT(Transform):
         table = fused.grid_support(Gm, grid, 16, zw) if (layout >= 1 and zw is not None and (layout == 2 or zw == (16, 16))) else None
         # ... and the same matrix as one record per sample, where its modulation is a sign per axis (even grids): the interleaved
         # products then compute their taps (indigo_amd.interp.interp_sep_records)
-        sep = b.gridding_sep_from_struct(gs, 1) if (layout == 2 and isinstance(gs, InterpS) and hasattr(b, 'gridding_sep_from_struct')) else None
-        A = fused.assemble(b, Gm, grid, box, lambda c0, c1: w[..., c0:c1], C, layout, chunks, table=table, box_lo=lo,
-                           name=node._name, zw=zw or (16, 16), sep=sep)
+        sep = b.gridding_sep_from_struct(gs, 1, **({'phases': folded} if folded is not None else {})) if (layout == 2 and isinstance(gs, InterpS) and hasattr(b, 'gridding_sep_from_struct')) else None
+        wsel = (lambda c0, c1: w[..., c0:c1]) if complex(gconst) == 1.0 else (lambda c0, c1: (w[..., c0:c1] * np.complex64(gconst)).astype(np.complex64))
+        A = fused.assemble(b, Gm, grid, box, wsel, C, layout, chunks, table=table, box_lo=lo,
+                           name=node._name, zw=zw or (16, 16), sep=sep, kshift=kshift)
         A._fused_layout = layout
         return A
 

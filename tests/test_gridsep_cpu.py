@@ -51,7 +51,7 @@ def _shares(sep, bm, bs):
     L = _lib.lib()
     rec, tw = sep['records'], sep['tw']
     n0, nm, ns = sep['dims']
-    nb = (n0 // 16) * (nm // bm) * (ns // bs)
+    nb = (n0 // 16) * (-(-nm // bm)) * (-(-ns // bs))
     counts = np.zeros(nb, np.int32)
     assert L.ig_grid_shares_count(rec.shape[0], rec.ctypes.data, tw, n0, nm, ns, bm, bs, counts.ctypes.data) == 0
     ptr = np.zeros(nb + 1, np.int64)
@@ -62,7 +62,8 @@ def _shares(sep, bm, bs):
 
 
 @pytest.mark.parametrize("N,osf,width,bm,bs", [((16, 16, 16), 2.0, 2, 8, 2), ((16, 16, 16), 2.0, 2, 4, 4), ((8, 16, 20), 2.0, 3, 4, 4),
-                                               ((8, 8, 8), 2.0, 2, 16, 1), ((8, 8, 8), 2.0, 2.5, 2, 8), ((8, 8, 8), 2.0, 4, 4, 4), ((8, 8, 8), 2.0, 2, 1, 1)])
+                                               ((8, 8, 8), 2.0, 2, 16, 1), ((8, 8, 8), 2.0, 2.5, 2, 8), ((8, 8, 8), 2.0, 4, 4, 4), ((8, 8, 8), 2.0, 2, 1, 1),
+                                               ((8, 13, 9), 2.0, 2, 4, 4), ((8, 9, 15), 2.0, 3, 4, 8)])          # bricks that do not divide the middle / slow axis
 def test_shares_hold_every_tap_exactly_once(N, osf, width, bm, bs):
     p = _problem(N, osf, width)
     sep = p.fused_interp_sep(1)
@@ -70,7 +71,7 @@ def test_shares_hold_every_tap_exactly_once(N, osf, width, bm, bs):
     n0, nm, ns = sep['dims']
     counts, sh = _shares(sep, bm, bs)
     brick = np.repeat(np.arange(counts.size), counts)
-    nbx, nbm = n0 // 16, nm // bm
+    nbx, nbm = n0 // 16, -(-nm // bm)
     bx, bmi, bsi = brick % nbx, (brick // nbx) % nbm, brick // (nbx * nbm)
     t, gmask, geo = (sh[:, 0] & 0x0fffffff).astype(np.int64), sh[:, 0] >> 28, sh[:, 1]
     assert (np.diff(t)[np.diff(brick) == 0] >= 0).all()                       # sample order inside a brick

@@ -475,6 +475,89 @@ def test_padded_transforms_with_chirp_z_axes_vs_numpy(hip):
     hip._scratch = None
 
 
+def test_padded_transforms_carry_the_modulation_of_odd_axes(hip):
+    """round 6 (ig_fft_set_axis_shift): a circular shift by c on the image side of a chirp-z axis = the modulation exp(2 pi i k c / n) on its
+    k-space side -- what the reference's centred transform (Backend.fftc_mod, indigo/backends/backend.py:352-366) puts on an ODD axis -- folded
+    into the pass's tables.  Grid 160 x 69 x 205 (both odd axes chirp-z), shifts n // 2 and an arbitrary one: fft_padded against numpy times the
+    modulation, the cropped transforms against numpy of the conjugate-modulated grid; an axis that is no chirp-z axis refuses"""
+    grid, box, C = (160, 69, 205), (120, 52, 154), 4
+    assert hip.supports_padded_fft(grid, C) and hip.padded_axis_kind(69) == 5 and hip.padded_axis_kind(205) == 5
+    lo = tuple(m // 2 + int(np.ceil(-n / 2)) for m, n in zip(grid, box))
+    P, N = int(np.prod(grid)), int(np.prod(box))
+    hip._scratch = None
+    x = rand64c(N, 1, seed=1)
+    w = rand64c(N, C, seed=2)
+    w_d = hip.copy_array(np.ascontiguousarray(w).reshape(-1))
+    sl = tuple(slice(l, l + b) for l, b in zip(lo, box))
+    ws = hip.zero_array((hip._fft_padded_workspace(grid, lo, box, C, 2) // 8,), C64)
+    g = rand64c(P, C, seed=3)
+    g_d = hip.copy_array(np.ascontiguousarray(g).reshape(-1)).reshape((P, C))
+    for ks in ((0, 34, 102), (0, 0, 7), (0, 68, 0)):
+        mod = np.ones(grid, dtype=np.complex128)
+        for a in (1, 2):
+            ph = np.exp(2j * np.pi * np.arange(grid[a]) * ks[a] / grid[a])
+            mod = mod * ph.reshape([-1 if d == a else 1 for d in range(3)])
+        y_d = hip.copy_array(np.full((P, C), np.nan, dtype=C64, order='F'))
+        hip.fft_padded(y_d, hip.copy_array(x), w_d, grid, lo, box, ws, 2, kshift=ks)
+        y = y_d.to_host().reshape(-1, order='F').reshape((C, grid[0], grid[2], grid[1]), order='F')        # (c, x, z, y)
+        for c in (0, C - 1):
+            full = np.zeros(grid, dtype=np.complex128, order='F')
+            full[sl] = (w[:, c] * x[:, 0]).reshape(box, order='F')
+            assert rel_err(y[c].transpose(0, 2, 1), mod * np.fft.fftn(full)) < RTOL, (ks, c)
+        xc_d = hip.copy_array(np.full((N, C), np.nan, dtype=C64, order='F'))
+        hip.ifft_cropped(xc_d, g_d, w_d, grid, lo, box, ws, 2, kshift=ks)
+        vol = g[:, 1].reshape((grid[0], grid[2], grid[1]), order='F').transpose(0, 2, 1)
+        ref = (np.fft.ifftn(np.conj(mod) * vol) * P)[sl].reshape(-1, order='F') * np.conj(w[:, 1])
+        assert rel_err(xc_d.to_host().reshape(-1, order='F').reshape(N, C)[:, 1], ref) < RTOL, ks
+        xs_d = hip.copy_array(np.full((N, 1), np.nan, dtype=C64, order='F'))
+        hip.ifft_cropped_sum(xs_d, y_d, w_d, grid, lo, box, ws, kshift=ks)          # the adjoint undoes the forward's modulation
+        assert rel_err(xs_d.to_host(), P * (np.abs(w) ** 2).sum(axis=1, keepdims=True) * x) < RTOL, ks
+    with pytest.raises(RuntimeError):
+        hip._padded_plan((160, 160, 205), (20, 20, 25), (120, 120, 154), C, 2, 16, (0, 80, 0))          # 160 points: an A x B axis
+    hip._scratch = None
+
+
+def test_sense_on_a_grid_with_odd_axes_keeps_a_real_gridding_matrix(hip, oracle_backend):
+    """round 6: image 120 x 52 x 77 on the grid the reference driver's default oversampling gives, 160 x 69 x 102 -- 69 is odd (the centred
+    transform's modulation there is a genuine phase ramp), 102 = 2 mod 4 (its constant is -+i).  The fused leaf moves the ramp into the chirp-z
+    pass of that axis and the constant into the transform's weights: the gridding matrix keeps REAL weights -- 8-byte brick entries, separable
+    records with gconst = 1 -- and the operator still equals the oracle's, which knows none of this"""
+    from indigo_amd import operators as op
+    p = SenseProblem.synthetic((120, 52, 77), 8, nspokes=300, nreadout=160, width=2, ntable=128, oversamp=640 / 480, seed=6)
+    assert p.oN == (160, 69, 102)
+    hip._scratch = None
+    oracle_backend._scratch = None
+    ks, folded = hip.fold_axis_shifts(p.oN, __import__('indigo_amd.sense', fromlist=['x'])._mod_axis_phases(p.oN))
+    assert ks == (0, 34, 0) and np.ptp(folded[1]) == 0
+    g, split = hip.split_gridding_constant(folded)
+    assert abs(abs(g) - 1) < 1e-12 and abs(g - 1) > 0.5 and all(np.allclose(np.exp(2j * np.pi * ph).imag, 0, atol=1e-12) for ph in split)
+    A = p.build_zpadfft(hip)
+    Z = A.right
+    assert isinstance(Z, op.ZpadFFT) and Z._tile_kw.get('kshift') == (0, 34, 0)
+    x = rand64c(A.shape[1], 1, seed=1)
+    k = rand64c(A.shape[0], 1, seed=2)
+    A_o = p.build_zpadfft(oracle_backend, layout=0, support=False)
+    assert rel_err(A * x, A_o * x) < RTOL
+    assert rel_err(A.H * k, A_o.H * k) < RTOL
+    M = A.left.right._matrix_d
+    assert M._sep is not None and M._sep['gconst'] == 1 and M._bricks_by[8]['words'] == 2
+    y_d = hip.zero_array((A.shape[1], 1), C64)
+    normal_operator(A, lamda=0.2).eval(y_d, hip.copy_array(x))
+    exp = A_o.H * (A_o * x) + np.float32(0.2) * x
+    assert rel_err(y_d.to_host(), exp) < RTOL
+    # the same at the reference's default half-width 3: record gather + share scatter on bricks that do not divide 69
+    p3 = SenseProblem.synthetic((120, 52, 77), 8, nspokes=300, nreadout=160, width=3, ntable=128, oversamp=640 / 480, seed=6)
+    A3 = p3.build_zpadfft(hip)
+    A3_o = p3.build_zpadfft(oracle_backend, layout=0, support=False)
+    assert rel_err(A3 * x, A3_o * x) < RTOL
+    k3 = rand64c(A3.shape[0], 1, seed=2)
+    assert rel_err(A3.H * k3, A3_o.H * k3) < RTOL
+    M3 = A3.left.right._matrix_d
+    assert M3._shares_by[8] is not None and (M3._shares_by[8]['bm'], M3._shares_by[8]['bs']) == (4, 4)
+    hip._scratch = None
+    oracle_backend._scratch = None
+
+
 @pytest.mark.parametrize("C", [4, 8])
 def test_sense_on_the_reference_drivers_grid_vs_oracle(hip, oracle_backend, C):
     """image 256^3 on a 320^3 grid (oversampling 1.25, the reference driver's choice of grid, examples/pics.py:87-90): the fused

@@ -68,7 +68,9 @@ def _expected_adjoint(G, X, alpha):
                                                     ((24, 32, 40), 2.0, 3, True, (4, 4)), ((32, 16, 24), 2.0, 2.5, True, (2, 4)),
                                                     ((32, 32, 32), 2.0, 2, True, (4, 2)), ((16, 16, 16), 2.0, 4, True, (4, 4)),
                                                     ((32, 32, 32), 2.0, 2, True, (1, 1)), ((24, 32, 40), 2.0, 3, False, (2, 2)),
-                                                    ((16, 13, 16), 2.0, 2, True, (4, 2))])          # (a 26-point axis: the modulation's constant is -+i)
+                                                    ((16, 13, 16), 2.0, 2, True, (4, 2)),           # (a 26-point axis: the modulation's constant is -+i)
+                                                    ((16, 13, 17), 2.0, 3, True, (4, 4)),           # bricks that do not divide the grid: 26 = 6 * 4 + 2 slabs,
+                                                    ((16, 15, 13), 2.0, 2, True, (4, 4))])          # 34 = 8 * 4 + 2 lines; 26 lines x 30 slabs
 def test_adjoint_gridding_from_shares(hip, monkeypatch, NC, N, osf, width, edge, shape):
     """Y_il = alpha G'^H X as the scatter of (sample, brick) shares with computed taps (ig_grid_scatter_sep: brick image in registers,
     outer products on the matrix cores), no support table: every grid row is defined.  Heavy bricks cut into shared pieces (atomics)
