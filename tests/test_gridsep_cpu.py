@@ -97,3 +97,38 @@ def test_shares_hold_every_tap_exactly_once(N, osf, width, bm, bs):
     assert rows.size == A.nnz and np.unique(rows * A.shape[1] + cols).size == rows.size          # every tap once
     B = spp.csr_matrix((vals if sep['gconst'].imag == 0 else np.abs(vals), (rows, cols)), shape=A.shape)
     assert abs(A - B).max() == 0
+
+
+def test_odd_axis_ramp_and_constant_leave_a_real_matrix():
+    """round 6: what the fused leaf does on a grid with an odd chirp-z axis (HipBackend.fold_axis_shifts / split_gridding_constant, called here
+    without a device: both are host logic over the library's host entry points).  G' of the reference's construction (interp * centred-transform
+    modulation * scale: pinned to the goldens in test_sense_cpu.py) must equal  g * (real matrix) * diag(ramp on the folded axis)  with the ramp
+    exp(2 pi i k c / n), c = n // 2 -- the circular shift the transform pass takes over (ig_fft_set_axis_shift)"""
+    import types
+    from indigo_amd.backends.hip import HipBackend
+    from indigo_amd.interp import interp_csr_modulated
+    fake = types.SimpleNamespace(_L=_lib.lib(), tuning={})
+    N = (64, 35, 51)            # image; grid 128 x 69 (odd, 3 * 23: chirp-z) x 102 (= 2 mod 4: constant -+i)
+    p = SenseProblem.synthetic(N, 2, nspokes=41, nreadout=128, width=2, oversamp=2.0, seed=3)
+    p.oN = (128, 69, 102)
+    p.drop_cache()
+    ph = _mod_axis_phases(p.oN)
+    ks, folded = HipBackend.fold_axis_shifts(fake, p.oN, ph)
+    assert ks == (0, 34, 0) and np.ptp(folded[1]) == 0 and folded[1][0] == ph[1][0] and folded[0] is not None
+    assert HipBackend.fold_axis_shifts(fake, (128, 64, 102), _mod_axis_phases((128, 64, 102))) == (None, None)           # nothing odd
+    assert HipBackend.fold_axis_shifts(fake, (128, 75, 102), _mod_axis_phases((128, 75, 102))) == (None, None)           # 75 = 3 * 5 * 5: an A x B axis
+    g, split = HipBackend.split_gridding_constant(fake, folded)
+    assert abs(abs(g) - 1.0) < 1e-12 and split is not None
+    coord = p.coord.reshape(3, -1, order='F')
+    scale = np.float32(1.0) / np.sqrt(np.float32(np.prod(p.oN)))
+    P = int(np.prod(p.oN))
+    full = spp.csr_matrix(interp_csr_modulated(p.T, p.oN, p.width, p.table, coord, ph, scale, grid_order=1)[::-1], shape=(p.T, P))
+    real = spp.csr_matrix(interp_csr_modulated(p.T, p.oN, p.width, p.table, coord, split, scale, grid_order=1)[::-1], shape=(p.T, P))
+    assert np.abs(real.data.imag).max() <= 2.0 ** -34 * np.abs(real.data.real).max()          # real up to the residue weights_are_real allows
+    # columns in (x, z, y) order: column = kx + n0 * (kz + n2 * ky)
+    ky = np.arange(P) // (p.oN[0] * p.oN[2])
+    ramp = np.exp(2j * np.pi * ky * 34 / 69)
+    rebuilt = (real.astype(np.complex128) @ spp.diags(ramp)) * g
+    assert abs(rebuilt - full.astype(np.complex128)).max() <= 3e-7 * np.abs(full.data).max()
+    sep = interp_sep_records(p.T, p.oN, p.width, p.table, coord, split, scale, 1)
+    assert sep is not None and sep['gconst'] == 1
