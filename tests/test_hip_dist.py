@@ -349,3 +349,50 @@ def test_direct_allreduce_over_ipc_windows_on_one_gpu(world):
     assert all(p.returncode == 0 and "OK rank" in o for p, o in zip(procs, outs)), "\n".join(o[-3000:] for o in outs)
     digests = {o.split("digests", 1)[1].split("err")[0].strip() for o in outs}
     assert len(digests) == 1, digests          # every rank holds the same bits
+
+
+DIRECT_DEAD_WORKER = r"""
+import os, sys, time
+sys.path.insert(0, os.environ["REPO_ROOT"])
+import numpy as np
+from indigo_amd.backends import get_backend
+from indigo_amd.dist import DirectComm
+from indigo_amd.util import rand64c
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+B = get_backend("hip", device_id=0)
+comm = DirectComm(B, rank, world, timeout=float(os.environ["DIRECT_TIMEOUT"]), window_bytes=4 << 20, name=os.environ["DIRECT_NAME"])
+d = B.copy_array(rand64c(100000, seed=rank))
+comm.allreduce_(d)                       # one good collective first
+if rank == 1:
+    os._exit(7)                          # dies without a word: no barrier, no clean-up
+t0 = time.time()
+try:
+    comm.allreduce_(d)
+except RuntimeError as e:
+    print("FAILED AS IT SHOULD after %.1f s: %s" % (time.time() - t0, e))
+    sys.exit(0)
+print("the collective returned although a rank was dead")
+sys.exit(3)
+"""
+
+
+def test_direct_allreduce_fails_instead_of_hanging_when_a_rank_dies():
+    """a rank that dies between two collectives: the survivor's next all-reduce gives up at its barrier after the communicator's timeout
+    (3 s here) with an error that says so -- it does not hang (round 3 saw a multi-rank rehearsal sit silent for seven minutes)"""
+    name = "/indigo_direct_dead_%d" % os.getpid()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, REPO_ROOT=ROOT, RANK=str(rank), WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0", DIRECT_NAME=name, DIRECT_TIMEOUT="3")
+        env.pop("INDIGO_HIP_WITH_TORCH", None)
+        procs.append(subprocess.Popen([sys.executable, "-c", DIRECT_DEAD_WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=120)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("the surviving rank hung")
+        outs.append(o)
+    assert procs[1].returncode == 7, outs[1][-2000:]
+    assert procs[0].returncode == 0 and "FAILED AS IT SHOULD" in outs[0] and "waited" in outs[0], outs[0][-3000:]
