@@ -322,7 +322,9 @@ int  ig_grid_gather_sep(ig_ctx* ctx, int64_t M, int64_t NC, int tw, const void* 
  *                        (sample, brick of 16 x bm x bs grid cells its footprint meets; bm, bs <= 4), 8 bytes {sample | slow-axis cells of
  *                        the brick that hold a tap << 28, ox + 8 | (om + 8) << 5 | (os + 8) << 10 | blo << 15 | bhi << 18 | clo << 22 |
  *                        chi << 25}: tap (a, b, c) sits at brick cell (ox + a, om + b, os + c), taps b in [blo, bhi), c in [clo, chi) are
- *                        inside the brick.  ig_grid_shares_count / _fill (host) bin them by brick (sample order inside a brick).  tasks as
+ *                        inside the brick.  n0 is a multiple of 16; bm and bs need NOT divide nm and ns: the bricks of an axis number
+ *                        ceil(n / b), the part of a last brick outside the grid holds no tap and must not be flagged (277 = 69 * 4 + 1).
+ *                        ig_grid_shares_count / _fill (host) bin the shares by brick (sample order inside a brick).  tasks as
  *                        for ig_ccsrmm_t_bricks with shares in place of entries; brick_table: 16 bytes per non-empty brick {brick, end of
  *                        its shares, uint64 flagged segments: bit xs + (16 / support_tile) * (im + bm * is)} -- only flagged segments are
  *                        written; shared_table: the table rows of the bricks several tasks add into (float atomics; zeroed first).

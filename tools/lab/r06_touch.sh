@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the option fft.touch_table existed for that one run only -- profiles/r06_touch_table_ab.txt keeps the result; this script is its record)
 # round 6, VERDICT r5 item 6: the cropped z pass waits for its support records (an HBM trip) before it can issue its loads.  A/B on one
 # box: the support table read once by a 5-microsecond kernel just before the pass (memory-side cache warm) against the plain pass.
 mkdir -p gpurun_out
