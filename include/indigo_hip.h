@@ -315,8 +315,13 @@ int  ig_ccsrmm_t_slots(ig_ctx* ctx, int64_t M, int64_t K, int64_t N, float alpha
  *                        interleaved coils (axes in memory order, as the records').  NC in {2, 4, 8}.                       */
 int  ig_grid_gather_sep(ig_ctx* ctx, int64_t M, int64_t NC, int tw, const void* records, int64_t rec_stride, const void* X_il,
                         int64_t n0, int64_t nm, int64_t ns, float alpha_re, float alpha_im, float beta_re, float beta_im,
-                        void* Y, int64_t ldy);
-/* (rec_stride: 32-bit words from one sample's record to the next, >= ig_interp3_sep_words(tw), a multiple of 4.) */
+                        void* Y, int64_t ldy, const uint32_t* group_order);
+/* (rec_stride: 32-bit words from one sample's record to the next, >= ig_interp3_sep_words(tw), a multiple of 4.
+ *  group_order, optional (NULL: trajectory order), device memory: a workgroup works on a group of ig_grid_gather_sep_group(NC, tw)
+ *  consecutive samples; group_order is a permutation of the ceil(M / group) groups that says which workgroup takes which -- sorted by
+ *  where the groups' samples lie on the grid, neighbouring workgroups read neighbouring grid rows, and a densely sampled trajectory stops
+ *  re-fetching them from HBM.  Results do not depend on it, bit for bit.) */
+int  ig_grid_gather_sep_group(int64_t NC, int tw);                     /* host; 0: no such kernel */
 
 /*   ig_grid_scatter_sep  Y_il = alpha * G^H * X  (X: M x NC column-major, ldx; NC = 4 or 8) as a race-free scatter of SHARES: a share =
  *                        (sample, brick of 16 x bm x bs grid cells its footprint meets; bm, bs <= 4), 8 bytes {sample | slow-axis cells of

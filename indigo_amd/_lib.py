@@ -125,7 +125,8 @@ PROTOTYPES = {
     "ig_interp3_sep":     (c_int, [c_int64, POINTER(c_int64), c_double, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_double,
                                    c_int, c_void_p]),
     "ig_grid_gather_sep": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_float, c_float, c_float, c_float,
-                                   c_void_p, c_int64]),
+                                   c_void_p, c_int64, c_void_p]),
+    "ig_grid_gather_sep_group": (c_int, [c_int64, c_int]),
     "ig_grid_shares_count": (c_int, [c_int64, c_void_p, c_int, c_int64, c_int64, c_int64, c_int, c_int, c_void_p]),
     "ig_grid_shares_fill": (c_int, [c_int64, c_void_p, c_int, c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "ig_grid_scatter_sep": (c_int, [c_void_p, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64,

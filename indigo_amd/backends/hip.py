@@ -122,7 +122,7 @@ class HipBackend(Backend):
         #                 where the roll-off correction is large); 128: 4.7 ... 6.1e-6 over four runs, the stored-tap scatter 4.8 ... 7.6e-6 (the
         #                 order of the float atomics differs from run to run), 0.95 against 0.98 ms (profiles/r06_share_pieces.txt)
         self._placement_log = []          # (bytes, candidate probe times in ms, chosen) of every array placed by probing
-        self.tuning = dict(placement_candidates=3, placement_min_bytes=1 << 31, placement_window_gb=8, placement_window_allocs=2, fold_odd_axes=True, real_gridding=True, cg_graph=False, bricks=(4, 8), slots=(1, 2), slot_shape=(4, 4, 256, 64), support_tile={8: 4, 4: 8}, brick_shape={8: (2, 2, 4096, 4096), 4: (2, 4, 4096, 4096)}, xrows=True, runs=True, wide_bricks=True,
+        self.tuning = dict(placement_candidates=3, placement_min_bytes=1 << 31, placement_window_gb=8, placement_window_allocs=2, fold_odd_axes=True, real_gridding=True, gather_order=True, cg_graph=False, bricks=(4, 8), slots=(1, 2), slot_shape=(4, 4, 256, 64), support_tile={8: 4, 4: 8}, brick_shape={8: (2, 2, 4096, 4096), 4: (2, 4, 4096, 4096)}, xrows=True, runs=True, wide_bricks=True,
                            wide_brick_shape=(2, 2), wide_task_shape=(8192, 2048),
                            # round 6: gridding from the separable form of the matrix (one record per sample, taps computed)
                            separable=True, sep_gather=True, sep_scatter=True, shares=(4, 8), shares_min_tw=6, share_shape={8: (4, 4, 128, 1024), 4: (4, 4, 128, 1024)})
@@ -1148,6 +1148,27 @@ class HipBackend(Backend):
             self._sep = dict(tw=int(sep['tw']), dims=(n0, nm, ns), gconst=complex(sep['gconst']), host=rec, stride=rs,
                              records=b.copy_array(recx.reshape(-1), name=self._name + ".sepRecords"))
 
+        def _gather_order(self, ncols):
+            """The order in which the workgroups of the record gather take their groups of consecutive samples (ig_grid_gather_sep's
+            group_order) for an `ncols`-column panel: the groups sorted by the 32^3-cell block of the grid their first sample's first tap
+            lies in, blocks in Morton order -- built once per panel width from the host copy of the records.  Measured
+            (profiles/r06_gather_order.txt): 8 x the spokes 3.28 -> 2.79 ms, half-width 3 1.46 -> 1.36 ms, the headline 0.430 -> 0.416 ms."""
+            sep = self._sep
+            by = sep.setdefault('order', {})
+            if ncols not in by:
+                rec, tw = sep['host'], sep['tw']
+                group = int(self._backend._L.ig_grid_gather_sep_group(int(ncols), int(tw)))
+                by[ncols] = None
+                if group > 0 and rec.shape[0] > 4 * group:
+                    h0, h1 = rec[::group, 3 * tw], rec[::group, 3 * tw + 1]
+                    j = [(h0 & 0xffff).astype(np.int64) >> 5, (h0 >> 16).astype(np.int64) >> 5, (h1 & 0xffff).astype(np.int64) >> 5]
+                    key = np.zeros_like(j[0])
+                    for bit in range(11):                       # axes of up to 65535 points: 11 bits of 32-cell blocks each
+                        for a in range(3):
+                            key |= ((j[a] >> bit) & 1) << (3 * bit + a)
+                    by[ncols] = self._backend.copy_array(np.argsort(key, kind='stable').astype(np.uint32), name=self._name + ".gatherOrder%d" % ncols)
+            return by[ncols]
+
         def set_grid_shares(self, ncols=8, bm=8, bs=2, chunk=1024, run=1024):
             """The adjoint of an `ncols`-column interleaved panel as a scatter of SHARES (ig_grid_scatter_sep): every (sample, brick of
             16 x bm x bs cells) pair the sample's footprint meets is one 8-byte share, binned by brick on the host (ig_grid_shares_count /
@@ -1406,8 +1427,10 @@ class HipBackend(Backend):
                     # the taps computed from one 64-byte record per sample (ig_grid_gather_sep): no index or value stream
                     gr, gi = _cplx(complex(alpha) * sep['gconst'])
                     n0, nm, ns = sep['dims']
+                    order = self._gather_order(x.shape[1]) if b.tuning.get('gather_order', True) else None
                     b._check(b._L.ig_grid_gather_sep(b._ctx, m, x.shape[1], sep['tw'], ctypes.c_void_p(sep['records']._arr), sep['stride'], ctypes.c_void_p(x._arr),
-                                                     n0, nm, ns, gr, gi, br, bi, ctypes.c_void_p(y._arr), y._leading_dim), "ig_grid_gather_sep")
+                                                     n0, nm, ns, gr, gi, br, bi, ctypes.c_void_p(y._arr), y._leading_dim,
+                                                     ctypes.c_void_p(order._arr) if order is not None else None), "ig_grid_gather_sep")
                     return
                 vre = self._real_values() if x.shape[1] in (2, 4, 8) else None
                 if vre is not None:

@@ -75,13 +75,18 @@ __device__ __forceinline__ void gather_rows(float4& acc, const float4* __restric
 template <int NC, int TW, int BMODE>
 __global__ void __launch_bounds__(BLK)
 k_grid_gather_sep(int64_t M, const uint32_t* __restrict__ rec, int rs /* words per record (>= sep_words) */, const float4* __restrict__ X4, int n0, int nm, int ns,
-                  float2* __restrict__ Y, int64_t ldy, float2 alpha, float2 beta) {
+                  float2* __restrict__ Y, int64_t ldy, float2 alpha, float2 beta, const uint32_t* __restrict__ order) {
     constexpr int QL = NC / 2, XL = TW <= 4 ? 4 : 8, LPS = QL * XL, SPW = 64 / LPS;
     constexpr int CG = TW <= 4 ? 4 : 2;                                   // slow-axis rows whose loads are in flight together
     static_assert(LPS <= 64 && NC >= 2, "a sample's lanes fit a wave");
     const int lane = threadIdx.x & 63;
     const int q = lane % QL, i = (lane / QL) % XL, g = lane / LPS;
-    const int64_t blk = xcd_block(blockIdx.x, gridDim.x);
+    // Which group of WPB * SPW consecutive samples this workgroup takes: by default in trajectory order; with `order` (a permutation of the
+    // groups, sorted by where their samples lie on the grid) neighbouring workgroups -- every XCD a contiguous range of them -- read
+    // neighbouring grid rows: a densely sampled trajectory, whose spokes cross the same cells far apart in trajectory order, re-fetches its
+    // grid rows 3.3 x from HBM otherwise (profiles/r06_gather_order.txt).  Same samples, same arithmetic, same bits.
+    int64_t blk = xcd_block(blockIdx.x, gridDim.x);
+    if (order) { const uint32_t o = order[blk]; blk = o < gridDim.x ? (int64_t)o : blk; }
     const int64_t wave = blk * WPB + (threadIdx.x >> 6);
     const int64_t t = wave * SPW + g;
     const bool ok = t < M;
@@ -447,8 +452,13 @@ extern "C" {
 
 // Y (M x NC, column-major, ldy) = alpha * G X + beta * Y for the gridding matrix given by `records` (ig_interp3_sep with grid_order
 // matching the panel: axes (n0, nm, ns) in memory order) and the coil-interleaved grid panel X (n0 * nm * ns rows of NC values).
+int ig_grid_gather_sep_group(int64_t NC, int tw) {
+    if (!(NC == 2 || NC == 4 || NC == 8) || !(tw == 4 || tw == 6 || tw == 8)) return 0;
+    return WPB * (64 / ((int)(NC / 2) * (tw <= 4 ? 4 : 8)));
+}
+
 int ig_grid_gather_sep(ig_ctx* ctx, int64_t M, int64_t NC, int tw, const void* records, int64_t rec_stride, const void* X_il, int64_t n0, int64_t nm, int64_t ns,
-                       float ar, float ai, float br, float bi, void* Y, int64_t ldy) {
+                       float ar, float ai, float br, float bi, void* Y, int64_t ldy, const uint32_t* group_order) {
     IG_REQUIRE(ctx, ctx != nullptr, "ig_grid_gather_sep: ctx is NULL");
     IG_REQUIRE(ctx, M >= 0 && (NC == 2 || NC == 4 || NC == 8) && (tw == 4 || tw == 6 || tw == 8), "ig_grid_gather_sep: 2, 4 or 8 interleaved coils; tw 4, 6 or 8");
     IG_REQUIRE(ctx, n0 >= tw && nm >= tw && ns >= tw && n0 <= 65535 && nm <= 65535 && ns <= 65535 && n0 * nm * ns * (NC / 2) < (1LL << 32),
@@ -466,9 +476,9 @@ int ig_grid_gather_sep(ig_ctx* ctx, int64_t M, int64_t NC, int tw, const void* r
         const int64_t blocks = ((M + spw - 1) / spw + WPB - 1) / WPB;                                                            \
         IG_REQUIRE(ctx, blocks <= 0x7fffffffLL, "ig_grid_gather_sep: too many samples for one launch");                          \
         if (b0) hipLaunchKernelGGL((k_grid_gather_sep<NC_, TW_, 0>), dim3((unsigned)blocks), dim3(BLK), 0, ctx->stream, M,       \
-                                   (const uint32_t*)records, (int)rec_stride, (const float4*)X_il, (int)n0, (int)nm, (int)ns, (float2*)Y, ldy, alpha, beta); \
+                                   (const uint32_t*)records, (int)rec_stride, (const float4*)X_il, (int)n0, (int)nm, (int)ns, (float2*)Y, ldy, alpha, beta, group_order); \
         else    hipLaunchKernelGGL((k_grid_gather_sep<NC_, TW_, 1>), dim3((unsigned)blocks), dim3(BLK), 0, ctx->stream, M,       \
-                                   (const uint32_t*)records, (int)rec_stride, (const float4*)X_il, (int)n0, (int)nm, (int)ns, (float2*)Y, ldy, alpha, beta); \
+                                   (const uint32_t*)records, (int)rec_stride, (const float4*)X_il, (int)n0, (int)nm, (int)ns, (float2*)Y, ldy, alpha, beta, group_order); \
     } while (0)
 #define IG_GS_TW(NC_) do { if (tw == 4) IG_GS(NC_, 4); else if (tw == 6) IG_GS(NC_, 6); else IG_GS(NC_, 8); } while (0)
     if (NC == 8) IG_GS_TW(8);

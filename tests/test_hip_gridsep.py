@@ -57,6 +57,16 @@ def test_forward_gridding_from_separable_records(hip, monkeypatch, NC, N, osf, w
             got[use] = y_d.to_host()
         assert rel_err(got[True], exp) < RTOL, (alpha, beta)
         assert rel_err(got[True], got[False]) < 2e-6
+        # the order in which the workgroups take their groups of samples (sorted by grid block by default) changes nothing, bit for bit
+        monkeypatch.setitem(hip.tuning, "sep_gather", True)
+        monkeypatch.setitem(hip.tuning, "gather_order", False)
+        y_d = hip.copy_array(Y0)
+        A_d = hip.csr_matrix(hip, G)
+        A_d.set_grid_interleaved(True)
+        A_d.set_grid_separable(sep)
+        A_d.forward(y_d, x_d, alpha=alpha, beta=beta)
+        monkeypatch.setitem(hip.tuning, "gather_order", True)
+        assert np.array_equal(y_d.to_host(), got[True])
 
 
 def _expected_adjoint(G, X, alpha):
