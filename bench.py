@@ -550,7 +550,7 @@ def run_sense(args, cfg, B, comm, world, rank, steps, warmup, want_cpu, quiet=Fa
                    "grid_layout": layout, "tree": tree, "coil_chunks_per_rank": nchunks,
                    "coil_chunk_widths": [lf['width'] for lf in leaves_z] or None, "spokes_scale": scale,
                    "support_table_kx_points_per_entry": (sup_tile if sup_tab is not None else None),
-                   # large arrays are placed by probing: the best 1 GB window of the better of two allocations (HipBackend.tuning[placement_window_gb / _allocs],
+                   # large arrays are placed by probing: the best 1 GB window of an allocation 24 GB longer than the array (HipBackend.tuning[placement_window_gb / _allocs],
                    # DESIGN.md 3.1): bytes, the candidates' probe times in ms, the one kept -- part of set-up, outside the timed region
                    "placement": [list(e) for e in getattr(B, "_placement_log", [])][-4:] or None},
         "roofline": roofline,

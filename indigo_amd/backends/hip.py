@@ -122,7 +122,7 @@ class HipBackend(Backend):
         #                 where the roll-off correction is large); 128: 4.7 ... 6.1e-6 over four runs, the stored-tap scatter 4.8 ... 7.6e-6 (the
         #                 order of the float atomics differs from run to run), 0.95 against 0.98 ms (profiles/r06_share_pieces.txt)
         self._placement_log = []          # (bytes, candidate probe times in ms, chosen) of every array placed by probing
-        self.tuning = dict(placement_candidates=3, placement_min_bytes=1 << 31, placement_window_gb=8, placement_window_allocs=2, fold_odd_axes=True, real_gridding=True, gather_order=True, cg_graph=False, bricks=(4, 8), slots=(1, 2), slot_shape=(4, 4, 256, 64), support_tile={8: 4, 4: 8}, brick_shape={8: (2, 2, 4096, 4096), 4: (2, 4, 4096, 4096)}, xrows=True, runs=True, wide_bricks=True,
+        self.tuning = dict(placement_candidates=3, placement_min_bytes=1 << 31, placement_window_gb=24, placement_window_allocs=3, fold_odd_axes=True, real_gridding=True, gather_order=True, cg_graph=False, bricks=(4, 8), slots=(1, 2), slot_shape=(4, 4, 256, 64), support_tile={8: 4, 4: 8}, brick_shape={8: (2, 2, 4096, 4096), 4: (2, 4, 4096, 4096)}, xrows=True, runs=True, wide_bricks=True,
                            wide_brick_shape=(2, 2), wide_task_shape=(8192, 2048),
                            # round 6: gridding from the separable form of the matrix (one record per sample, taps computed)
                            separable=True, sep_gather=True, sep_scatter=True, shares=(4, 8), shares_min_tw=6, share_shape={8: (4, 4, 128, 1024), 4: (4, 4, 128, 1024)})
@@ -230,16 +230,16 @@ class HipBackend(Backend):
             """A large array as the best-placed WINDOW of an allocation (round 6).  The passes that step megabytes per element run
             3 ... 6 % faster or slower with where their array lies -- from allocation to allocation (every other
             process or so gets a slow first one: 3.6 - 3.7 ms in the placement probe against 3.2), and inside ONE allocation the
-            probe's time changes smoothly with the offset, by 10 % over 7 GB (profiles/r06_placement_offsets.txt: 3.23 ms at the
-            start of an allocation, 2.90 ms 6 - 7 GB in; a slow allocation stays at 3.69 ms for 5 GB and recovers to 3.05 ms 10 GB
-            in).  So: an allocation of nbytes + slack_gb GB, the probe (ig_probe_placement) on the window at every GB step; then --
-            while the device has room -- a SECOND such allocation (`placement_window_allocs`), because no window of a slow allocation
-            is as good as a fast one's; the fastest window of either is kept and the other allocation freed.  At most one extra
-            allocation for a moment (three whole candidates in round 5) and slack_gb GB held beyond the array.  None (the caller
-            falls back) when the device has no room for the slack."""
+            probe's time changes smoothly with the offset (profiles/r06_placement_offsets.txt, r06_placement_slack.txt): a slow level
+            (3.7 ms for the headline's arena) over the first 0 ... 13 GB of an allocation, a ramp down over the next 7 - 8 GB, a fast
+            plateau (2.9 ms) behind; what looked like two kinds of allocation in round 5 is where an allocation starts relative to that
+            ramp.  So: an allocation of nbytes + slack_gb GB (24: the plateau has been inside it on every box so far), the probe
+            (ig_probe_placement) on the window at every GB step, the fastest window kept.  An allocation without a ramp (all windows
+            alike: all slow) is followed by another, up to `placement_window_allocs`; the losers are freed at the end.  slack_gb GB stay
+            held beyond the array.  None (the caller falls back) when the device has no room for the slack."""
             b = self._backend
             GBs = 1 << 30
-            nalloc = max(1, int(b.tuning.get('placement_window_allocs', 2)))
+            nalloc = max(1, int(b.tuning.get('placement_window_allocs', 3)))
             worst = b.tuning.get('placement_pick') == 'worst'
             cands = []          # (best time, base, pick, times)
             try:
@@ -266,10 +266,23 @@ class HipBackend(Backend):
                         times[0] = min(times[0], ms.value)
                     pick = int(np.argmax(times)) if worst else int(np.argmin(times))
                     cands[-1] = [times[pick], base.value, pick, times]
+                    # enough once a RAMP has been seen -- probes 8 % apart: the slow level (~3.7 ms on the headline's arena) and the fast one
+                    # (2.9) or the way down between them -- the best window is then on the fast side.  An allocation whose windows all
+                    # probe alike is all slow (a fast one always starts with a ramp): another one is tried, up to `placement_window_allocs`
+                    # (the losers are held until the choice is made: freed at once, the next allocation of the same size would get their
+                    # pages back)
+                    allt = [v for c in cands for v in c[3]]
+                    if min(allt) <= 0.92 * max(allt):
+                        break
             except Exception:
                 for c in cands:
-                    b._L.ig_free(b._ctx, ctypes.c_void_p(c[1]))
+                    if c[1] is not None:
+                        b._L.ig_free(b._ctx, ctypes.c_void_p(c[1]))
                 raise
+            for c in cands:
+                if c[0] is None:
+                    b._L.ig_free(b._ctx, ctypes.c_void_p(c[1]))
+            cands = [c for c in cands if c[0] is not None]
             if not cands:
                 return None
             keep = (max if worst else min)(range(len(cands)), key=lambda i: cands[i][0])

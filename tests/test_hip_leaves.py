@@ -67,8 +67,8 @@ def test_large_arrays_are_placed_by_probing(hip):
         z = hip.zero_array((n,), C64)
         assert len(hip._placement_log) == before + 1
         nbytes, allocs, chosen = hip._placement_log[-1]
-        # (two allocations of array + 2 GB, three windows each; the loser is freed at once)
-        assert nbytes == n * 8 and len(allocs) == 2 and all(len(t) == 3 for t in allocs) and chosen == min(min(t) for t in allocs) and chosen > 0
+        # (one to three allocations of array + 2 GB -- until a ramp has been seen --, three windows each; the losers are freed)
+        assert nbytes == n * 8 and 1 <= len(allocs) <= 3 and all(len(t) == 3 for t in allocs) and chosen == min(min(t) for t in allocs) and chosen > 0
         assert (z._arr - z._alloc_base) % (1 << 30) == 0 and 0 <= z._arr - z._alloc_base <= 2 << 30
         assert not z.to_host().any()
         x = rand64c(n, seed=3)
