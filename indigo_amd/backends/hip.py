@@ -1153,13 +1153,11 @@ class HipBackend(Backend):
             n0, nm, ns = (int(v) for v in sep['dims'])
             assert sep['records'].shape[0] == self.shape[0] and n0 * nm * ns == self.shape[1]
             rec = np.ascontiguousarray(sep['records'])
-            # on the device every record leaves room for the sample's panel row behind it (the MFMA scatter reads both as one line)
+            # the forward reads the records as they are (16 or 32 words apart: one 64- or 128-byte line each); the share scatter wants every
+            # record followed by room for the sample's panel row -- a second, wider copy that set_grid_shares uploads when it is needed
             rw = rec.shape[1]
-            rs = 32 if rw == 16 else 64
-            recx = np.zeros((rec.shape[0], rs), dtype=np.uint32)
-            recx[:, :rw] = rec
-            self._sep = dict(tw=int(sep['tw']), dims=(n0, nm, ns), gconst=complex(sep['gconst']), host=rec, stride=rs,
-                             records=b.copy_array(recx.reshape(-1), name=self._name + ".sepRecords"))
+            self._sep = dict(tw=int(sep['tw']), dims=(n0, nm, ns), gconst=complex(sep['gconst']), host=rec, stride=rw,
+                             records=b.copy_array(rec.reshape(-1), name=self._name + ".sepRecords"))
 
         def _gather_order(self, ncols):
             """The order in which the workgroups of the record gather take their groups of consecutive samples (ig_grid_gather_sep's
@@ -1245,6 +1243,14 @@ class HipBackend(Backend):
                 tab16[:, 2] = (mask & np.uint64(0xffffffff)).astype(np.uint32)
                 tab16[:, 3] = (mask >> np.uint64(32)).astype(np.uint32)
             sh_rows = tab16[np.searchsorted(bricks, shared.astype(np.int64))] if shared.size else np.zeros((1, 4), np.uint32)
+            if 'recx' not in sep:
+                # (the MFMA scatter reads a share's record and panel row as ONE line: record, then the row k_sep_pack_recx writes there)
+                rw = rec.shape[1]
+                rs = 32 if rw == 16 else 64
+                recx = np.zeros((rec.shape[0], rs), dtype=np.uint32)
+                recx[:, :rw] = rec
+                sep['recx'] = b.copy_array(recx.reshape(-1), name=self._name + ".sepRecordsWithRows")
+                sep['stride_x'] = rs
             by[int(ncols)] = dict(bm=int(bm), bs=int(bs), tile=int(tile), ncols=int(ncols), ntasks=int(tasks.shape[0]), nshared=int(shared.size),
                                   nshares=int(ptr[-1]), nbricks=int(bricks.size),
                                   tasks=b.copy_array(tasks.reshape(-1) if tasks.size else np.zeros(4, np.int32), name=self._name + ".shareTasks"),
@@ -1519,7 +1525,7 @@ class HipBackend(Backend):
                     y._zero()           # without a support table every row is defined: bricks no sample touches stay zero
                 ar, ai = _cplx(complex(alpha) * np.conj(sep['gconst']))
                 n0, nm, ns = sep['dims']
-                b._check(b._L.ig_grid_scatter_sep(b._ctx, self.shape[0], x.shape[1], sep['tw'], ctypes.c_void_p(sep['records']._arr), sep['stride'],
+                b._check(b._L.ig_grid_scatter_sep(b._ctx, self.shape[0], x.shape[1], sep['tw'], ctypes.c_void_p(sep['recx']._arr), sep['stride_x'],
                                                   ctypes.c_void_p(shf['shares']._arr), ctypes.c_void_p(x._arr), x._leading_dim, ctypes.c_void_p(y._arr),
                                                   n0, nm, ns, shf['bm'], shf['bs'], ctypes.c_void_p(shf['tasks']._arr), shf['ntasks'],
                                                   ctypes.c_void_p(shf['table']._arr), ctypes.c_void_p(shf['shared']._arr), shf['nshared'], shf['tile'], ar, ai),
